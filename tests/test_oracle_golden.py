@@ -1,0 +1,88 @@
+"""The CPU oracle (oracle/) against the committed golden vectors, which were produced by running the
+genuine reference in the build container (tests/golden/gen_golden.py).  Bit-exact on every stage."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+MAN = json.load(open(os.path.join(HERE, "golden", "manifest.json")))
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module", params=sorted(MAN["cases"]))
+def case(request):
+    c = MAN["cases"][request.param]
+    z = np.load(os.path.join(HERE, "golden", request.param + ".npz"))
+    g = orc.LidarGeom(**orc.GEOMS[c["geom"]])
+    tm = orc.transform_map(g)
+    return c, z, g, tm
+
+
+def test_uniform_path_matches_reference(case):
+    c, z, g, tm = case
+    o = orc.compress_frame(z["xyz"], g, tm, z["ground_model"])
+    s = c["sha"]
+    assert sha(tm) == s["tm"]
+    assert sha(o["range_image"]) == s["ri"]
+    assert sha(o["pc"]) == s["pc"]
+    assert sha(o["mask"]) == s["mask"]
+    assert int(o["mask"].sum()) == c["n_left"]
+    assert int((o["range_image"] != 0).sum()) == c["nnz"]
+    assert np.array_equal(o["seg_idx"].astype(np.uint8), z["seg_idx"])
+    assert sha(o["seg_idx"].astype(np.int32)) == s["seg_idx"]
+    assert sha(o["model_param"]) == s["model_param"]
+    assert np.array_equal(o["model_param"].view(np.uint64), z["model_param"].view(np.uint64))
+    assert sha(o["pred"]) == s["pred"]
+    assert sha(o["residual"]) == s["residual"]
+    assert np.array_equal(o["q"].astype(np.int16), z["q_uniform"])
+    assert [int(o["q"].min()), int(o["q"].max())] == c["q_range"]
+    od = orc.pack_payload(o["model_param"], o["seg_idx"], None, o["q"])
+    assert sha(od["contour_map"]) == s["contour_map"]
+    assert sha(od["idx_sequence"]) == s["idx_sequence"]
+    bs = orc.bitstream_bytes(od)
+    assert len(bs) == c["rpcc_bytes"]
+    assert bs == z["rpcc"].tobytes()
+
+
+def test_nonuniform_path_matches_reference(case):
+    c, z, g, tm = case
+    o = orc.compress_frame(z["xyz"], g, tm, z["ground_model"], uniform=False)
+    assert np.array_equal(o["key_point_map"].astype(np.uint8), z["key_point_map"])
+    assert np.array_equal(o["salience"].astype(np.uint8), z["salience"])
+    assert np.array_equal(o["q"].astype(np.int16), z["q_nonuniform"])
+
+
+def test_reconstruction_bound(case):
+    """README.md:101-106: max |range_rec - range| <= accuracy (uniform)."""
+    c, z, g, tm = case
+    o = orc.compress_frame(z["xyz"], g, tm, z["ground_model"])
+    seg = o["seg_idx"]
+    res = np.zeros(seg.shape, np.float32)
+    start = 0
+    for m in range(int(seg.max()) + 1):          # dequantize_residual, compress_utils.py:114-132
+        idx = np.where(seg == m)
+        if m == 1:
+            continue
+        res[idx] = o["q"][start:start + idx[0].shape[0]].astype(np.int16) * 0.04
+        start += idx[0].shape[0]
+    assert start == o["q"].shape[0]
+    rec = o["pred"][..., 0] + res
+    err = np.abs(rec - o["range_image"])[o["range_image"] != 0]
+    assert err.max() <= 0.02 + 1e-5
+
+
+def test_contour_known_answer():
+    """The reference's only known-answer vector: utils/contour_utils.py:181-195."""
+    k = MAN["contour_kat"]
+    cm, seq = orc.extract_contour(np.array(k["idx_map"]))
+    assert cm.tolist() == k["contour"]
+    assert seq.tolist() == k["idx_sequence"]
+    assert orc.recover_map(cm, seq).tolist() == k["idx_map"]
