@@ -1,0 +1,144 @@
+/*
+ * rpcc_hip.h -- C ABI of librpcc_hip.so: the MI355X (gfx950) implementation of the R-PCC per-frame
+ * compression hot path.  Plain pointers and sizes only; every pointer marked "dev" is a device
+ * (HBM) pointer, every kernel is enqueued on the caller's hipStream_t (passed as void*) and the call
+ * returns without synchronising unless stated.  The library allocates nothing: work buffers come
+ * from the caller (rpcc_workspace_bytes).  Return value: 0 = OK, negative = error
+ * (rpcc_last_error() gives the text); nothing throws or exits across this boundary.
+ *
+ * Each entry point names the reference interface it replaces (paths relative to the reference
+ * repository).  A "frame" is one LiDAR sweep; a batch holds B frames of one lidar geometry (H x W
+ * range image, P = H*W pixels); M = cluster_num (cfgs/compressor.yaml:22); labels are
+ * 0 = ground, 1 = empty pixel, 2..M+1 = FPS cluster k-2 (utils/segment_utils.py:168-169), K = M+2.
+ */
+#ifndef RPCC_HIP_H
+#define RPCC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RPCC_OK 0
+#define RPCC_ERR_ARG (-1)
+#define RPCC_ERR_HIP (-2)
+#define RPCC_MAX_CLUSTERS 254 /* labels are stored as uint8 */
+
+int rpcc_version(void);
+const char *rpcc_last_error(void);
+
+/* Lidar geometry: the scalars PCTransformer.__init__ derives from a lidar YAML
+ * (dataset/transformer.py:26-37); the three angles are the python doubles narrowed to C float
+ * exactly as pybind11 does at cpp_modules.cpp:427-428. */
+typedef struct rpcc_geom {
+    int32_t H, W;
+    float horizontal_fov, vertical_max, vertical_min; /* radians */
+} rpcc_geom;
+
+/* ---- a2: spherical projection ------------------------------------------------------------- *
+ * replaces dataset_utils_cpp.point_cloud_to_range_image_even (cpp_modules.cpp:427-467), batched.
+ *   xyz      dev f32 [total,3]   points of all frames back to back (AoS, as np.fromfile gives)
+ *   offsets  dev i64 [B+1]       frame b owns points offsets[b]..offsets[b+1]
+ *   total    host                offsets[B]
+ *   ri       dev f32 [B,P]  out  min positive depth per pixel, 0 where empty
+ *   scratch  dev i32 [B,P+8]     work buffer (contents undefined on return)
+ * Exact reference semantics incl. a depth-0 point resetting its pixel in input order.  Points
+ * whose depth is not finite are skipped (reference: undefined behaviour). */
+int rpcc_project(const float *xyz, const int64_t *offsets, int64_t total, int B, rpcc_geom g, float *ri,
+                 int32_t *scratch, void *stream);
+
+/* ---- a3+a5: back-projection + vertical ground residual + FPS state init -------------------- *
+ * replaces PCTransformer.range_image_to_point_cloud (dataset/transformer.py:94-101) and
+ * PointCloudSegment.calc_plane_residual_vertical cpu branch + mask (utils/segment_utils.py:44-47,
+ * 119-120).  Candidates (depth_dif > threshold) get temp = 1e10 (ops/fps/fps_utils.py:26), all other
+ * pixels temp = -1 (never selectable).
+ *   ri       dev f32 [B,P]
+ *   tm       dev f32 [P,3]       transform_map (dataset/transformer.py:41-54)
+ *   ground   dev f64 [B,4]       plane a,b,c,d per frame
+ *   temp     dev f32 [B,P]  out
+ *   info     dev i32 [B,4]  out  {n_left, first candidate pixel (P if none), nnz, 0}              */
+int rpcc_ground_mask(const float *ri, const float *tm, const double *ground, double threshold, int B, int P,
+                     float *temp, int32_t *info, void *stream);
+
+/* ---- a6: farthest point sampling ----------------------------------------------------------- *
+ * rpcc_fps_xyz replaces furthest_point_sampling_wrapper(b,n,m,points,temp,idx)
+ * (ops/fps/src/sampling.cpp:24-37, kernel ops/fps/src/sampling_gpu.cu:24-140): same arguments, same
+ * caller-initialised temp (1e10), idx[b][0] = 0, strict '>' arg-max, ties -> lowest index.
+ *   points dev f32 [B,N,3], temp dev f32 [B,N] in/out, idx dev i32 [B,M] out                      */
+int rpcc_fps_xyz(int B, int N, int M, const float *points, float *temp, int32_t *idx, void *stream);
+
+/* rpcc_fps_range is the same sampling run directly on the range image (xyz = ri * tm recomputed in
+ * registers; pixels with temp < 0 are not candidates).  It selects the pixels the reference selects
+ * on the compacted candidate list (utils/segment_utils.py:120-124).
+ *   info     dev i32 [B,4]       from rpcc_ground_mask (first candidate = start point)
+ *   cen_pix  dev i32 [B,M]  out  pixel index of each centre
+ *   centers  dev f32 [B,M,3] out cluster_centers                                                  */
+int rpcc_fps_range(const float *ri, const float *tm, float *temp, const int32_t *info, int B, int P, int M,
+                   int32_t *cen_pix, float *centers, void *stream);
+
+/* ---- a7: ground / cluster assignment + relabel ---------------------------------------------- *
+ * replaces calc_plane_residual_depth, calc_cluster_residual_radius, concatenate + argmax and the
+ * relabel (utils/segment_utils.py:21-23,64-67,127-131,168-169).
+ *   seg      dev u8 [B,P] out labels                                                              */
+int rpcc_assign(const float *ri, const float *tm, const double *ground, const float *centers, int B, int P, int M,
+                uint8_t *seg, void *stream);
+
+/* ---- a8: point model ------------------------------------------------------------------------- *
+ * replaces segment_utils_cpp.point_modeling (cpp_modules.cpp:471-518) + the model_param assembly
+ * (utils/segment_utils.py:183-185, tools/compress.py:102), then the pybind11 fp64->fp32 cast.
+ *   model    dev f32 [B,K,4] out row 0 = (float)ground, row 1 = 0, row k = [0,0,0,mean_k]
+ *                                (NaN 0xFFC00000 for a label without pixels)
+ *   counts   dev i32 [B,K]   out pixels per label
+ *   ws       dev, rpcc_workspace_bytes                                                            */
+int rpcc_point_model(const float *ri, const uint8_t *seg, const double *ground, int B, int P, int M, float *model,
+                     int32_t *counts, void *ws, void *stream);
+
+/* ---- a10+a11: intra-prediction + residual + uniform quantisation + ordered scatter ----------- *
+ * replaces segment_utils_cpp.intra_predict (cpp_modules.cpp:248-285), residual = ri - pred
+ * (tools/compress.py:106) and quantization_utils_cpp.uniform_quantize (cpp_modules.cpp:288-334).
+ *   acc      quantisation step (= 2*accuracy, tools/compress.py:46) as C float
+ *   q16      dev i16 [B,P] out   per frame: nnz values grouped by label ascending, row-major inside
+ *                                a label, already cast to int16 (utils/compress_utils.py:142)
+ *   q32      dev i32 [B,P] out   same as int32 (what uniform_quantize returns); either may be NULL
+ *   nnz      dev i32 [B]   out
+ *   pred     dev f32 [B,P] out   optional (NULL to skip)                                           */
+int rpcc_predict_quantize(const float *ri, const float *tm, const uint8_t *seg, const float *model,
+                          const int32_t *counts, float acc, int B, int P, int M, int16_t *q16, int32_t *q32,
+                          int32_t *nnz, float *pred, void *ws, void *stream);
+
+/* ---- fused batch entry: a2..a11 for B frames (uniform framework, FPS, point model) ----------- *
+ * The batched counterpart of the body of tools/compress.py:93-125 /
+ * tools/compress_datalist.py:91-125 with the ground model supplied by the caller. */
+typedef struct rpcc_batch_io {
+    const float *xyz;        /* dev f32 [total,3] */
+    const int64_t *offsets;  /* dev i64 [B+1] */
+    int64_t total;
+    const float *tm;         /* dev f32 [P,3] */
+    const double *ground;    /* dev f64 [B,4] */
+    float *ri;               /* dev f32 [B,P] out */
+    uint8_t *seg;            /* dev u8  [B,P] out */
+    int32_t *cen_pix;        /* dev i32 [B,M] out */
+    float *centers;          /* dev f32 [B,M,3] out */
+    float *model;            /* dev f32 [B,K,4] out */
+    int32_t *counts;         /* dev i32 [B,K] out */
+    int16_t *q16;            /* dev i16 [B,P] out */
+    int32_t *nnz;            /* dev i32 [B] out */
+    int32_t *info;           /* dev i32 [B,4] out */
+} rpcc_batch_io;
+
+size_t rpcc_workspace_bytes(int B, int P, int M);
+int rpcc_compress_batch(const rpcc_batch_io *io, int B, rpcc_geom g, int M, double ground_threshold, float acc,
+                        void *ws, void *stream);
+
+/* Timing hook for bench.py: records hipEvents around the FPS launch of the next
+ * rpcc_compress_batch / rpcc_fps_* calls on that stream; rpcc_fps_time_ms returns the accumulated
+ * milliseconds and launch count since the last reset (synchronises the events). */
+void rpcc_fps_timing(int enable);
+int rpcc_fps_time_ms(double *ms, int *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,83 @@
+"""ctypes binding of librpcc_hip.so (include/rpcc_hip.h).  There is no CPU fallback: if the HIP
+library is missing or a call fails, this raises."""
+import ctypes as C
+import os
+
+import torch  # imported first so the library binds to the HIP runtime torch already loaded
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "librpcc_hip.so")
+
+
+class Geom(C.Structure):
+    _fields_ = [("H", C.c_int32), ("W", C.c_int32), ("horizontal_fov", C.c_float), ("vertical_max", C.c_float),
+                ("vertical_min", C.c_float)]
+
+
+class BatchIO(C.Structure):
+    _fields_ = [("xyz", C.c_void_p), ("offsets", C.c_void_p), ("total", C.c_int64), ("tm", C.c_void_p),
+                ("ground", C.c_void_p), ("ri", C.c_void_p), ("seg", C.c_void_p), ("cen_pix", C.c_void_p),
+                ("centers", C.c_void_p), ("model", C.c_void_p), ("counts", C.c_void_p), ("q16", C.c_void_p),
+                ("nnz", C.c_void_p), ("info", C.c_void_p)]
+
+
+class RpccError(RuntimeError):
+    pass
+
+
+_lib = None
+
+_VP, _I, _I64, _F, _D = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
+_SIGS = {
+    "rpcc_version": (C.c_int, []),
+    "rpcc_last_error": (C.c_char_p, []),
+    "rpcc_project": (C.c_int, [_VP, _VP, _I64, _I, Geom, _VP, _VP, _VP]),
+    "rpcc_ground_mask": (C.c_int, [_VP, _VP, _VP, _D, _I, _I, _VP, _VP, _VP]),
+    "rpcc_fps_xyz": (C.c_int, [_I, _I, _I, _VP, _VP, _VP, _VP]),
+    "rpcc_fps_range": (C.c_int, [_VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP]),
+    "rpcc_assign": (C.c_int, [_VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP]),
+    "rpcc_point_model": (C.c_int, [_VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP]),
+    "rpcc_predict_quantize": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _F, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "rpcc_workspace_bytes": (C.c_size_t, [_I, _I, _I]),
+    "rpcc_compress_batch": (C.c_int, [C.POINTER(BatchIO), _I, Geom, _I, _D, _F, _VP, _VP]),
+    "rpcc_fps_timing": (None, [_I]),
+    "rpcc_fps_time_ms": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+}
+
+
+def exported_symbols():
+    return sorted(_SIGS)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RpccError("librpcc_hip.so is not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'`"
+                            % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(_lib, name)
+            fn.restype = res
+            fn.argtypes = args
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RpccError("librpcc_hip: %s (code %d)" % (lib().rpcc_last_error().decode(), rc))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL); the tensor must be contiguous and on a GPU."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RpccError("expected a GPU tensor; the HIP path has no CPU fallback")
+    if not t.is_contiguous():
+        raise RpccError("expected a contiguous tensor")
+    return C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,29 @@
+"""Builds librpcc_hip.so (the C-ABI HIP library) in-tree with hipcc for gfx950."""
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(_HERE, "csrc", "rpcc_hip.hip")
+DEPS = [SRC, os.path.join(_HERE, "csrc", "rpcc_device.h"),
+        os.path.join(os.path.dirname(_HERE), "include", "rpcc_hip.h")]
+LIB = os.path.join(_HERE, "lib", "librpcc_hip.so")
+
+# -ffp-contract=off: the reference arithmetic is un-fused x86 SSE; a contracted FMA changes results.
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC",
+               "-shared", "-Wno-unused-value"]
+
+
+def build(force=False, verbose=False):
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in DEPS):
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + HIPCC_FLAGS + [SRC, "-o", LIB]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

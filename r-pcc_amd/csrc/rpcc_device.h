@@ -1,0 +1,131 @@
+// rpcc_device.h -- device-side helpers shared by the gfx950 kernels of librpcc_hip.so.
+//
+// Numerics contract (DESIGN.md "Arithmetic"): every fp32/fp64 expression reproduces the reference's
+// un-fused x86 SSE arithmetic, so this translation unit is compiled with -ffp-contract=off, IEEE
+// divide/sqrt (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt) and denormals preserved.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define RPCC_WAVE 64
+
+namespace rpcc {
+
+__device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }
+__device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
+
+// ---------------------------------------------------------------------------------------------
+// glibc 2.35 atanf / atan2f (Sun fdlibm float algorithm) operation sequence.  The reference
+// projection calls libm atan2f (cpp_modules.cpp:447,450) whose result is not correctly rounded, so
+// the sequence itself is reproduced: plain fp32 + - * /, fabsf and integer tests only.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float atanf_fdlibm(float x) {
+    const float hi0 = 4.6364760399e-01f, hi1 = 7.8539812565e-01f, hi2 = 9.8279368877e-01f, hi3 = 1.5707962513e+00f;
+    const float lo0 = 5.0121582440e-09f, lo1 = 3.7748947079e-08f, lo2 = 3.4473217170e-08f, lo3 = 7.5497894159e-08f;
+    const float a0 = 3.3333334327e-01f, a1 = -2.0000000298e-01f, a2 = 1.4285714924e-01f, a3 = -1.1111110449e-01f,
+                a4 = 9.0908870101e-02f, a5 = -7.6918758452e-02f, a6 = 6.6610731184e-02f, a7 = -5.8335702866e-02f,
+                a8 = 4.9768779427e-02f, a9 = -3.6531571299e-02f, a10 = 1.6285819933e-02f;
+    const int32_t hx = (int32_t)f2u(x);
+    const int32_t ix = hx & 0x7fffffff;
+    if (ix >= 0x4c000000) {
+        if (ix > 0x7f800000) return x + x;
+        return (hx > 0) ? hi3 + lo3 : -hi3 - lo3;
+    }
+    float hi = 0.f, lo = 0.f;
+    bool reduced = true;
+    if (ix < 0x3ee00000) {
+        if (ix < 0x31000000) return x;
+        reduced = false;
+    } else {
+        x = fabsf(x);
+        if (ix < 0x3f980000) {
+            if (ix < 0x3f300000) { hi = hi0; lo = lo0; x = (2.0f * x - 1.0f) / (2.0f + x); }
+            else                 { hi = hi1; lo = lo1; x = (x - 1.0f) / (x + 1.0f); }
+        } else {
+            if (ix < 0x401c0000) { hi = hi2; lo = lo2; x = (x - 1.5f) / (1.0f + 1.5f * x); }
+            else                 { hi = hi3; lo = lo3; x = -1.0f / x; }
+        }
+    }
+    const float z = x * x;
+    const float w = z * z;
+    const float s1 = z * (a0 + w * (a2 + w * (a4 + w * (a6 + w * (a8 + w * a10)))));
+    const float s2 = w * (a1 + w * (a3 + w * (a5 + w * (a7 + w * a9))));
+    if (!reduced) return x - x * (s1 + s2);
+    const float r = hi - ((x * (s1 + s2) - lo) - x);
+    return (hx < 0) ? -r : r;
+}
+
+__device__ __forceinline__ float atan2f_fdlibm(float y, float x) {
+    const float tiny = 1.0e-30f, pi_o_4 = 7.8539818525e-01f, pi_o_2 = 1.5707963705e+00f, pi = 3.1415927410e+00f,
+                pi_lo = -8.7422776573e-08f;
+    const int32_t hx = (int32_t)f2u(x), hy = (int32_t)f2u(y);
+    const int32_t ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
+    if (ix > 0x7f800000 || iy > 0x7f800000) return x + y;
+    if (hx == 0x3f800000) return atanf_fdlibm(y);
+    const int32_t m = ((hy >> 31) & 1) | ((hx >> 30) & 2);
+    if (iy == 0) {
+        if (m < 2) return y;
+        return (m == 2) ? pi + tiny : -pi - tiny;
+    }
+    if (ix == 0) return (hy < 0) ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    if (ix == 0x7f800000) {
+        if (iy == 0x7f800000) {
+            switch (m) {
+                case 0: return pi_o_4 + tiny;
+                case 1: return -pi_o_4 - tiny;
+                case 2: return 3.0f * pi_o_4 + tiny;
+                default: return -3.0f * pi_o_4 - tiny;
+            }
+        }
+        switch (m) {
+            case 0: return 0.0f;
+            case 1: return -0.0f;
+            case 2: return pi + tiny;
+            default: return -pi - tiny;
+        }
+    }
+    if (iy == 0x7f800000) return (hy < 0) ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    const int32_t k = (iy - ix) >> 23;
+    float z;
+    if (k > 60) z = pi_o_2 + 0.5f * pi_lo;
+    else if (hx < 0 && k < -60) z = 0.0f;
+    else z = atanf_fdlibm(fabsf(y / x));
+    switch (m) {
+        case 0: return z;
+        case 1: return u2f(f2u(z) ^ 0x80000000u);
+        case 2: return pi - (z - pi_lo);
+        default: return (z - pi_lo) - pi;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Wavefront (64 lanes) reductions.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long t = __shfl_xor(v, o, RPCC_WAVE);
+        v = t > v ? t : v;
+    }
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, RPCC_WAVE);
+    return v;
+}
+__device__ __forceinline__ int wave_min_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, RPCC_WAVE));
+    return v;
+}
+
+// FPS arg-max key: larger squared distance first, then LOWER index (the sequential strict-'>' scan of
+// ops/fps/src/sampling_gpu.cu:67-68 restated as a total order).  value < 0 means "not a candidate".
+__device__ __forceinline__ unsigned long long fps_key(float v, uint32_t idx) {
+    const uint32_t hi = (v < 0.0f) ? 0u : f2u(v) + 1u;
+    return ((unsigned long long)hi << 32) | (unsigned long long)(0xFFFFFFFFu - idx);
+}
+__device__ __forceinline__ uint32_t fps_key_index(unsigned long long k) { return 0xFFFFFFFFu - (uint32_t)k; }
+
+}  // namespace rpcc

@@ -1,0 +1,727 @@
+// rpcc_hip.hip -- gfx950 (MI355X / CDNA4) kernels + C ABI of librpcc_hip.so.
+//
+// One translation unit, built by `hipcc --offload-arch=gfx950 -O3 -ffp-contract=off` (see
+// __graft_entry__.build / r-pcc_amd/build.py).  Interface: include/rpcc_hip.h.  Design, data layout
+// and the roofline of every kernel: DESIGN.md.  Reference citations are relative to the reference
+// repository root.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/rpcc_hip.h"
+#include "rpcc_device.h"
+
+using namespace rpcc;
+
+// ------------------------------------------------------------------------------------------------
+// host-side error plumbing
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+static int set_err(int code, const char *fmt, const char *a = "", const char *b = "") {
+    snprintf(g_err, sizeof(g_err), fmt, a, b);
+    return code;
+}
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) return set_err(RPCC_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+#define ARG_TRY(cond)                                                         \
+    do {                                                                      \
+        if (!(cond)) return set_err(RPCC_ERR_ARG, "bad argument: %s%s", #cond); \
+    } while (0)
+#define LAUNCH_CHECK() HIP_TRY(hipGetLastError())
+
+extern "C" int rpcc_version(void) { return 100; }
+extern "C" const char *rpcc_last_error(void) { return g_err; }
+
+// FPS timing hook (bench.py): hipEvents on the stream the kernel is launched on.
+static bool g_fps_timing = false;
+static hipEvent_t g_ev0[64], g_ev1[64];
+static int g_ev_n = 0, g_ev_alloc = 0;
+extern "C" void rpcc_fps_timing(int enable) {
+    g_fps_timing = enable != 0;
+    g_ev_n = 0;
+}
+extern "C" int rpcc_fps_time_ms(double *ms, int *launches) {
+    double tot = 0;
+    for (int i = 0; i < g_ev_n; i++) {
+        float t = 0;
+        HIP_TRY(hipEventSynchronize(g_ev1[i]));
+        HIP_TRY(hipEventElapsedTime(&t, g_ev0[i], g_ev1[i]));
+        tot += t;
+    }
+    if (ms) *ms = tot;
+    if (launches) *launches = g_ev_n;
+    g_ev_n = 0;
+    return RPCC_OK;
+}
+struct FpsTimer {
+    hipStream_t s;
+    bool on;
+    explicit FpsTimer(hipStream_t st) : s(st), on(g_fps_timing && g_ev_n < 64) {
+        if (!on) return;
+        while (g_ev_alloc <= g_ev_n) {
+            hipEventCreate(&g_ev0[g_ev_alloc]);
+            hipEventCreate(&g_ev1[g_ev_alloc]);
+            g_ev_alloc++;
+        }
+        hipEventRecord(g_ev0[g_ev_n], s);
+    }
+    ~FpsTimer() {
+        if (!on) return;
+        hipEventRecord(g_ev1[g_ev_n], s);
+        g_ev_n++;
+    }
+};
+
+// ================================================================================================
+// a2  spherical projection  (cpp_modules.cpp:427-467)
+// ================================================================================================
+#define RI_EMPTY 0xFFFFFFFFu
+
+struct RowCol {
+    float depth;
+    int pix;
+};
+
+__device__ __forceinline__ RowCol project_point(float x, float y, float z, const rpcc_geom g) {
+    RowCol o;
+    o.depth = sqrtf(x * x + y * y + z * z);                       // :446
+    float az = atan2f_fdlibm(y, x);                               // :447
+    if (az < 0) az = (float)((double)az + 2 * 3.14159265);        // :448-449 (double literal)
+    const float el = atan2f_fdlibm(z, sqrtf(x * x + y * y));      // :450
+    int col = (int)roundf(az / g.horizontal_fov * (float)g.W);    // :451
+    col = col % g.W;                                              // :452
+    const float vres = (g.vertical_max - g.vertical_min) / (float)(g.H - 1);  // :453
+    int row = (int)roundf((el - g.vertical_min) / vres);          // :454
+    row = row >= g.H ? g.H - 1 : row;                             // :455-458
+    row = row < 0 ? 0 : row;
+    o.pix = row * g.W + col;
+    return o;
+}
+
+__device__ __forceinline__ int find_frame(const int64_t *__restrict__ offs, int B, int64_t i) {
+    int lo = 0, hi = B;  // offs[lo] <= i < offs[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (offs[mid] <= i) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// MODE 0: min-depth pass, records frames that hold a depth-0 point.
+// MODE 1: for flagged frames, last input position of a depth-0 point per pixel.
+// MODE 2: for flagged frames, min-depth pass restricted to points after that position.
+template <int MODE>
+__global__ __launch_bounds__(256) void project_kernel(const float *__restrict__ xyz, const int64_t *__restrict__ offs,
+                                                      int64_t total, int B, rpcc_geom g, uint32_t *__restrict__ ri,
+                                                      int32_t *__restrict__ lastz, int32_t *__restrict__ flags) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    if (MODE != 0 && flags[B] == 0) return;  // no frame of this batch holds a depth-0 point
+    const int b = find_frame(offs, B, i);
+    if (MODE != 0 && flags[b] == 0) return;
+    const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+    const RowCol rc = project_point(x, y, z, g);
+    if (!(fabsf(rc.depth) <= 3.402823466e+38f)) return;  // NaN / inf depth: skipped (reference: UB)
+    const int64_t P = (int64_t)g.H * g.W;
+    const int32_t pos = (int32_t)(i - offs[b]) + 1;
+    if (MODE == 0) {
+        if (rc.depth == 0.0f) { flags[b] = 1; flags[B] = 1; return; }
+        atomicMin(&ri[b * P + rc.pix], f2u(rc.depth));
+    } else if (MODE == 1) {
+        if (rc.depth == 0.0f) atomicMax(&lastz[b * P + rc.pix], pos);
+    } else {
+        if (rc.depth != 0.0f && pos > lastz[b * P + rc.pix]) atomicMin(&ri[b * P + rc.pix], f2u(rc.depth));
+    }
+}
+
+// fills ri with the "untouched" pattern; with FIXUP only for flagged frames (and zeroes lastz there)
+template <bool FIXUP>
+__global__ __launch_bounds__(256) void project_fill_kernel(uint32_t *__restrict__ ri, int32_t *__restrict__ lastz,
+                                                           int32_t *__restrict__ flags, int P) {
+    const int b = blockIdx.y;
+    const int B = gridDim.y;
+    if (FIXUP && flags[b] == 0) return;
+    const int64_t base = (int64_t)b * P;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+        ri[base + p] = RI_EMPTY;
+        if (FIXUP) lastz[base + p] = 0;
+    }
+    if (!FIXUP && blockIdx.x == 0 && threadIdx.x == 0) {
+        flags[b] = 0;
+        if (b == 0) flags[B] = 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void project_finalize_kernel(uint32_t *__restrict__ ri, int64_t n) {
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x)
+        if (ri[p] == RI_EMPTY) ri[p] = 0u;
+}
+
+static int launch_project(const float *xyz, const int64_t *offsets, int64_t total, int B, rpcc_geom g, float *ri,
+                          int32_t *scratch, hipStream_t st, bool finalize) {
+    const int P = g.H * g.W;
+    uint32_t *rb = reinterpret_cast<uint32_t *>(ri);
+    int32_t *lastz = scratch;
+    int32_t *flags = scratch + (int64_t)B * P;
+    const dim3 fg((P + 1023) / 1024 < 64 ? (P + 1023) / 1024 : 64, B);
+    project_fill_kernel<false><<<fg, 256, 0, st>>>(rb, lastz, flags, P);
+    LAUNCH_CHECK();
+    if (total > 0) {
+        const unsigned nb = (unsigned)((total + 255) / 256);
+        project_kernel<0><<<nb, 256, 0, st>>>(xyz, offsets, total, B, g, rb, lastz, flags);
+        LAUNCH_CHECK();
+        // exact input-order semantics for frames that contain depth-0 points (rare): three more
+        // passes that return immediately for every other frame
+        project_fill_kernel<true><<<fg, 256, 0, st>>>(rb, lastz, flags, P);
+        project_kernel<1><<<nb, 256, 0, st>>>(xyz, offsets, total, B, g, rb, lastz, flags);
+        project_kernel<2><<<nb, 256, 0, st>>>(xyz, offsets, total, B, g, rb, lastz, flags);
+        LAUNCH_CHECK();
+    }
+    if (finalize) {
+        const int64_t n = (int64_t)B * P;
+        project_finalize_kernel<<<(unsigned)((n + 1023) / 1024 < 2048 ? (n + 1023) / 1024 : 2048), 256, 0, st>>>(rb, n);
+        LAUNCH_CHECK();
+    }
+    return RPCC_OK;
+}
+
+extern "C" int rpcc_project(const float *xyz, const int64_t *offsets, int64_t total, int B, rpcc_geom g, float *ri,
+                            int32_t *scratch, void *stream) {
+    ARG_TRY(B > 0 && g.H > 1 && g.W > 0 && total >= 0);
+    ARG_TRY(ri != nullptr && scratch != nullptr && offsets != nullptr);
+    ARG_TRY(total == 0 || xyz != nullptr);
+    return launch_project(xyz, offsets, total, B, g, ri, scratch, (hipStream_t)stream, true);
+}
+
+// ================================================================================================
+// a3 + a5  back-projection, vertical ground residual, candidate mask, FPS state init
+//          (dataset/transformer.py:94-101, utils/segment_utils.py:44-47,119-120)
+// ================================================================================================
+__global__ void info_init_kernel(int32_t *__restrict__ info, int B, int P) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) {
+        info[4 * b + 0] = 0;
+        info[4 * b + 1] = P;
+        info[4 * b + 2] = 0;
+        info[4 * b + 3] = 0;
+    }
+}
+
+// RAW: ri still holds the projection's bit patterns (RI_EMPTY = untouched) and is finalised here.
+template <bool RAW>
+__global__ __launch_bounds__(256) void ground_mask_kernel(float *__restrict__ ri, const float *__restrict__ tm,
+                                                          const double *__restrict__ ground, double thr, int P,
+                                                          float *__restrict__ temp, int32_t *__restrict__ info) {
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const double a = ground[4 * b], bb = ground[4 * b + 1], c = ground[4 * b + 2], d = ground[4 * b + 3];
+    // np.linalg.norm(plane_param[:, :3]) on a (1,1,4) array: all four components (segment_utils.py:47)
+    const double div = sqrt(((a * a + bb * bb) + c * c) + d * d);
+    bool cand = false, nz = false;
+    if (p < P) {
+        const int64_t gp = (int64_t)b * P + p;
+        float r = ri[gp];
+        if (RAW) {
+            if (f2u(r) == RI_EMPTY) r = 0.0f;
+            ri[gp] = r;
+        }
+        const float x = r * tm[3 * p], y = r * tm[3 * p + 1], z = r * tm[3 * p + 2];
+        const double s = ((double)x * a + (double)y * bb) + (double)z * c;
+        const double dd = fabs(s + d) / div;
+        cand = dd > thr;
+        nz = r != 0.0f;
+        temp[gp] = cand ? 1e10f : -1.0f;
+    }
+    const unsigned long long mc = __ballot(cand), mz = __ballot(nz);
+    if ((threadIdx.x & 63) == 0) {
+        if (mc) {
+            atomicAdd(&info[4 * b + 0], __popcll(mc));
+            atomicMin(&info[4 * b + 1], p + (int)__ffsll((long long)mc) - 1);
+        }
+        if (mz) atomicAdd(&info[4 * b + 2], __popcll(mz));
+    }
+}
+
+static int launch_ground_mask(float *ri, const float *tm, const double *ground, double thr, int B, int P, float *temp,
+                              int32_t *info, hipStream_t st, bool raw) {
+    info_init_kernel<<<(B + 255) / 256, 256, 0, st>>>(info, B, P);
+    const dim3 grid((P + 255) / 256, B);
+    if (raw) ground_mask_kernel<true><<<grid, 256, 0, st>>>(ri, tm, ground, thr, P, temp, info);
+    else     ground_mask_kernel<false><<<grid, 256, 0, st>>>(ri, tm, ground, thr, P, temp, info);
+    LAUNCH_CHECK();
+    return RPCC_OK;
+}
+
+extern "C" int rpcc_ground_mask(const float *ri, const float *tm, const double *ground, double threshold, int B, int P,
+                                float *temp, int32_t *info, void *stream) {
+    ARG_TRY(B > 0 && P > 0 && ri && tm && ground && temp && info);
+    return launch_ground_mask(const_cast<float *>(ri), tm, ground, threshold, B, P, temp, info, (hipStream_t)stream,
+                              false);
+}
+
+// ================================================================================================
+// a6  farthest point sampling  (ops/fps/src/sampling_gpu.cu:24-140, ops/fps/fps_utils.py:10-36)
+//     v1: one 1024-thread workgroup per frame, brute-force pass per centre.
+// ================================================================================================
+#define FPS_THREADS 1024
+
+__device__ __forceinline__ uint32_t block_argmax(unsigned long long key, unsigned long long *sm) {
+    key = wave_max_u64(key);
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();  // previous readers of sm are done
+    if ((threadIdx.x & 63) == 0) sm[wave] = key;
+    __syncthreads();
+    unsigned long long k = sm[threadIdx.x & 15];  // FPS_THREADS / 64 = 16 partials
+    k = wave_max_u64(k);
+    return fps_key_index(k);
+}
+
+__global__ __launch_bounds__(FPS_THREADS) void fps_xyz_kernel(int n, int m, const float *__restrict__ dataset,
+                                                              float *__restrict__ temp, int32_t *__restrict__ idxs) {
+    __shared__ unsigned long long sm[16];
+    if (m <= 0) return;
+    const int b = blockIdx.x;
+    dataset += (int64_t)b * n * 3;
+    temp += (int64_t)b * n;
+    idxs += (int64_t)b * m;
+    const int tid = threadIdx.x;
+    int old = 0;
+    if (tid == 0) idxs[0] = 0;
+    for (int j = 1; j < m; j++) {
+        const float x1 = dataset[old * 3 + 0], y1 = dataset[old * 3 + 1], z1 = dataset[old * 3 + 2];
+        float best = -1.0f;
+        int besti = 0;
+        for (int k = tid; k < n; k += FPS_THREADS) {
+            const float dx = dataset[k * 3 + 0] - x1, dy = dataset[k * 3 + 1] - y1, dz = dataset[k * 3 + 2] - z1;
+            const float d = (dx * dx + dy * dy) + dz * dz;  // sampling_gpu.cu:64, un-fused
+            const float t = temp[k];
+            const float d2 = fminf(d, t);
+            if (d2 != t) temp[k] = d2;
+            if (d2 > best) { best = d2; besti = k; }
+        }
+        old = (int)block_argmax(fps_key(best, (uint32_t)besti), sm);
+        if (tid == 0) idxs[j] = old;
+    }
+}
+
+// Range-image form: point k is pixel k, xyz = ri*tm in registers, temp < 0 = not a candidate.
+// Each thread owns 4 consecutive pixels per 4096-pixel stride (16-byte loads of ri/temp, 48 of tm).
+__global__ __launch_bounds__(FPS_THREADS) void fps_range_kernel(const float *__restrict__ ri, const float *__restrict__ tm,
+                                                                float *__restrict__ temp, const int32_t *__restrict__ info,
+                                                                int P, int M, int32_t *__restrict__ cen_pix,
+                                                                float *__restrict__ centers) {
+    __shared__ unsigned long long sm[16];
+    const int b = blockIdx.x;
+    ri += (int64_t)b * P;
+    temp += (int64_t)b * P;
+    cen_pix += (int64_t)b * M;
+    centers += (int64_t)b * M * 3;
+    const int tid = threadIdx.x;
+    int old = info[4 * b + 1];
+    if (old >= P) old = 0;  // no candidate at all: the reference would fail; keep indices defined
+    const int P4 = P & ~3;
+    for (int j = 0; j < M; j++) {
+        const float r0 = ri[old];
+        const float x1 = r0 * tm[3 * old], y1 = r0 * tm[3 * old + 1], z1 = r0 * tm[3 * old + 2];
+        if (tid == 0) {
+            cen_pix[j] = old;
+            centers[3 * j] = x1; centers[3 * j + 1] = y1; centers[3 * j + 2] = z1;
+        }
+        if (j == M - 1) break;
+        float best = -1.0f;
+        int besti = 0;
+        for (int k = tid * 4; k < P4; k += FPS_THREADS * 4) {
+            const float4 r = *reinterpret_cast<const float4 *>(ri + k);
+            const float4 t = *reinterpret_cast<const float4 *>(temp + k);
+            const float4 ta = *reinterpret_cast<const float4 *>(tm + 3 * k);
+            const float4 tb = *reinterpret_cast<const float4 *>(tm + 3 * k + 4);
+            const float4 tc = *reinterpret_cast<const float4 *>(tm + 3 * k + 8);
+            const float rr[4] = {r.x, r.y, r.z, r.w};
+            const float tt[4] = {t.x, t.y, t.z, t.w};
+            const float ray[12] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w, tc.x, tc.y, tc.z, tc.w};
+            float o[4];
+            bool changed = false;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float dx = rr[q] * ray[3 * q] - x1, dy = rr[q] * ray[3 * q + 1] - y1, dz = rr[q] * ray[3 * q + 2] - z1;
+                const float d = (dx * dx + dy * dy) + dz * dz;
+                const float d2 = fminf(d, tt[q]);
+                o[q] = d2;
+                changed |= d2 != tt[q];
+                if (d2 > best) { best = d2; besti = k + q; }
+            }
+            if (changed) *reinterpret_cast<float4 *>(temp + k) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+        for (int k = P4 + tid; k < P; k += FPS_THREADS) {  // tail when P is not a multiple of 4
+            const float rr = ri[k];
+            const float dx = rr * tm[3 * k] - x1, dy = rr * tm[3 * k + 1] - y1, dz = rr * tm[3 * k + 2] - z1;
+            const float d = (dx * dx + dy * dy) + dz * dz;
+            const float t = temp[k];
+            const float d2 = fminf(d, t);
+            if (d2 != t) temp[k] = d2;
+            if (d2 > best) { best = d2; besti = k; }
+        }
+        old = (int)block_argmax(fps_key(best, (uint32_t)besti), sm);
+    }
+}
+
+extern "C" int rpcc_fps_xyz(int B, int N, int M, const float *points, float *temp, int32_t *idx, void *stream) {
+    ARG_TRY(B > 0 && N > 0 && M >= 0 && points && temp && idx);
+    if (M == 0) return RPCC_OK;
+    hipStream_t st = (hipStream_t)stream;
+    FpsTimer tmr(st);
+    fps_xyz_kernel<<<B, FPS_THREADS, 0, st>>>(N, M, points, temp, idx);
+    LAUNCH_CHECK();
+    return RPCC_OK;
+}
+
+static int launch_fps_range(const float *ri, const float *tm, float *temp, const int32_t *info, int B, int P, int M,
+                            int32_t *cen_pix, float *centers, hipStream_t st) {
+    FpsTimer tmr(st);
+    fps_range_kernel<<<B, FPS_THREADS, 0, st>>>(ri, tm, temp, info, P, M, cen_pix, centers);
+    LAUNCH_CHECK();
+    return RPCC_OK;
+}
+
+extern "C" int rpcc_fps_range(const float *ri, const float *tm, float *temp, const int32_t *info, int B, int P, int M,
+                              int32_t *cen_pix, float *centers, void *stream) {
+    ARG_TRY(B > 0 && P > 0 && M > 0 && ri && tm && temp && info && cen_pix && centers);
+    ARG_TRY(((uintptr_t)ri % 16 == 0) && ((uintptr_t)temp % 16 == 0) && ((uintptr_t)tm % 16 == 0) && (P % 4 == 0));
+    return launch_fps_range(ri, tm, temp, info, B, P, M, cen_pix, centers, (hipStream_t)stream);
+}
+
+// ================================================================================================
+// a7  assignment + relabel  (utils/segment_utils.py:21-23,64-67,127-131,168-169)
+// ================================================================================================
+// distance = concat(ground fp64, radius fp32->fp64); seg = argmax(-abs(distance)) = first minimum of
+// |distance|.  The fp32 radius is sqrtf((dx*dx+dy*dy)+dz*dz); sqrtf is monotone, so the running minimum
+// is tracked on the squared distance and sqrtf is evaluated only when the squared distance strictly
+// improves -- the selected index is identical to evaluating all M square roots (DESIGN.md "assign").
+__global__ __launch_bounds__(256) void assign_kernel(const float *__restrict__ ri, const float *__restrict__ tm,
+                                                     const double *__restrict__ ground,
+                                                     const float *__restrict__ centers, int P, int M,
+                                                     uint8_t *__restrict__ seg) {
+    extern __shared__ float cen[];  // [M*3]
+    const int b = blockIdx.y;
+    for (int i = threadIdx.x; i < 3 * M; i += blockDim.x) cen[i] = centers[(int64_t)b * M * 3 + i];
+    __syncthreads();
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const double a = ground[4 * b], bb = ground[4 * b + 1], c = ground[4 * b + 2], d = ground[4 * b + 3];
+    const float r = ri[(int64_t)b * P + p];
+    const float tx = tm[3 * p], ty = tm[3 * p + 1], tz = tm[3 * p + 2];
+    const double den = ((double)tx * a + (double)ty * bb) + (double)tz * c;
+    const double g = (double)r - (-d / den);
+    const float x = r * tx, y = r * ty, z = r * tz;
+    float best_d2 = __builtin_inff(), best_s = __builtin_inff();
+    int best_k = -1;
+    for (int k = 0; k < M; k++) {
+        const float dx = x - cen[3 * k], dy = y - cen[3 * k + 1], dz = z - cen[3 * k + 2];
+        const float d2 = (dx * dx + dy * dy) + dz * dz;
+        if (d2 < best_d2) {
+            const float s = sqrtf(d2);
+            best_d2 = d2;
+            if (s < best_s) { best_s = s; best_k = k; }
+        }
+    }
+    int label = 0;
+    const double ag = fabs(g);
+    if (!(ag != ag) && best_k >= 0 && (double)best_s < ag) label = best_k + 2;  // ground first on ties / NaN
+    if (r == 0.0f) label = 1;
+    seg[(int64_t)b * P + p] = (uint8_t)label;
+}
+
+static int launch_assign(const float *ri, const float *tm, const double *ground, const float *centers, int B, int P,
+                         int M, uint8_t *seg, hipStream_t st) {
+    const dim3 grid((P + 255) / 256, B);
+    assign_kernel<<<grid, 256, (size_t)M * 3 * sizeof(float), st>>>(ri, tm, ground, centers, P, M, seg);
+    LAUNCH_CHECK();
+    return RPCC_OK;
+}
+
+extern "C" int rpcc_assign(const float *ri, const float *tm, const double *ground, const float *centers, int B, int P,
+                           int M, uint8_t *seg, void *stream) {
+    ARG_TRY(B > 0 && P > 0 && M > 0 && M <= RPCC_MAX_CLUSTERS && ri && tm && ground && centers && seg);
+    return launch_assign(ri, tm, ground, centers, B, P, M, seg, (hipStream_t)stream);
+}
+
+// ================================================================================================
+// a8  point model  (cpp_modules.cpp:471-518)  +  per-tile label histograms for the ordered scatter
+// ================================================================================================
+// Workspace layout (rpcc_workspace_bytes):  [ sums i64 B*KP | flags i32 B*4 (pad to 16 B) | hist u32 B*T*KP ]
+// KP = K rounded up to 64, T = ceil(P / TILE).  hist[b][t][k] is first the pixel count of label k in
+// tile t, then (after model_scan_kernel) the output offset of that tile's first label-k pixel.
+#define TILE 1024
+#define FX_UNIT_LOG2 28  // fixed-point unit 2^-28 m: exact for 2^-5 <= r < 2^8 (DESIGN.md "point model")
+
+static inline int kpad(int M) { return ((M + 2) + 63) & ~63; }
+static inline int ntiles(int P) { return (P + TILE - 1) / TILE; }
+struct WsLayout {
+    int64_t *sums;
+    int32_t *flags;
+    uint32_t *hist;
+    size_t bytes;
+};
+static WsLayout ws_layout(void *ws, int B, int P, int M) {
+    WsLayout L;
+    const size_t KP = (size_t)kpad(M), T = (size_t)ntiles(P);
+    char *p = reinterpret_cast<char *>(ws);
+    L.sums = reinterpret_cast<int64_t *>(p);
+    size_t off = (size_t)B * KP * 8;
+    L.flags = reinterpret_cast<int32_t *>(p + off);
+    off += (((size_t)B * 4 * 4) + 255) & ~(size_t)255;
+    L.hist = reinterpret_cast<uint32_t *>(p + off);
+    off += (size_t)B * T * KP * 4;
+    L.bytes = off;
+    return L;
+}
+extern "C" size_t rpcc_workspace_bytes(int B, int P, int M) {
+    if (B <= 0 || P <= 0 || M <= 0) return 0;
+    const size_t model_ws = ws_layout(nullptr, B, P, M).bytes;
+    const size_t proj_ws = ((size_t)B * ((size_t)P + 8)) * 4;  // projection scratch, carved after the model part
+    return model_ws + 256 + proj_ws + (size_t)B * P * 4;       // + FPS temp [B,P] f32
+}
+
+__global__ __launch_bounds__(256) void model_hist_kernel(const float *__restrict__ ri, const uint8_t *__restrict__ seg,
+                                                         int P, int KP, int T, int64_t *__restrict__ sums,
+                                                         int32_t *__restrict__ flags, uint32_t *__restrict__ hist) {
+    extern __shared__ unsigned char smem_raw[];
+    unsigned long long *ssum = reinterpret_cast<unsigned long long *>(smem_raw);  // [KP]
+    uint32_t *scnt = reinterpret_cast<uint32_t *>(ssum + KP);                      // [KP]
+    const int b = blockIdx.y, t = blockIdx.x;
+    for (int k = threadIdx.x; k < KP; k += blockDim.x) { ssum[k] = 0ull; scnt[k] = 0u; }
+    __syncthreads();
+    bool inexact = false;
+#pragma unroll
+    for (int j = 0; j < TILE / 256; j++) {
+        const int p = t * TILE + j * 256 + threadIdx.x;
+        if (p < P) {
+            const int64_t gp = (int64_t)b * P + p;
+            const int lab = seg[gp];
+            atomicAdd(&scnt[lab], 1u);
+            if (lab >= 2) {
+                const float r = ri[gp];
+                if (!(r >= 0.03125f && r < 256.0f)) inexact = true;
+                else atomicAdd(&ssum[lab], (unsigned long long)(long long)(r * 268435456.0f));  // exact: r * 2^28
+            }
+        }
+    }
+    if (__any(inexact) && (threadIdx.x & 63) == 0) flags[4 * b] = 1;
+    __syncthreads();
+    for (int k = threadIdx.x; k < KP; k += blockDim.x) {
+        hist[((int64_t)b * T + t) * KP + k] = scnt[k];
+        if (ssum[k]) atomicAdd(reinterpret_cast<unsigned long long *>(&sums[(int64_t)b * KP + k]), ssum[k]);
+    }
+}
+
+// One workgroup per frame: label totals, tile offsets, label bases, means, model rows.
+__global__ __launch_bounds__(256) void model_scan_kernel(const float *__restrict__ ri, const uint8_t *__restrict__ seg,
+                                                         const double *__restrict__ ground, int P, int M, int KP, int T,
+                                                         const int64_t *__restrict__ sums,
+                                                         const int32_t *__restrict__ flags, uint32_t *__restrict__ hist,
+                                                         float *__restrict__ model, int32_t *__restrict__ counts,
+                                                         int32_t *__restrict__ nnz) {
+    __shared__ uint32_t tot[256];
+    __shared__ uint32_t base[256];
+    const int b = blockIdx.x, k = threadIdx.x, K = M + 2;
+    uint32_t total = 0;
+    if (k < K) {
+        uint32_t *h = hist + (int64_t)b * T * KP + k;
+        for (int t = 0; t < T; t++) {
+            const uint32_t c = h[(int64_t)t * KP];
+            h[(int64_t)t * KP] = total;  // exclusive prefix over tiles (label base added below)
+            total += c;
+        }
+    }
+    tot[k] = (k < K && k != 1) ? total : 0u;
+    __syncthreads();
+    if (k == 0) {
+        uint32_t run = 0;
+        for (int i = 0; i < K; i++) { base[i] = run; run += tot[i]; }
+        if (nnz) nnz[b] = (int32_t)run;
+    }
+    __syncthreads();
+    if (k < K) {
+        uint32_t *h = hist + (int64_t)b * T * KP + k;
+        const uint32_t bs = base[k];
+        for (int t = 0; t < T; t++) h[(int64_t)t * KP] += bs;
+        if (counts) counts[(int64_t)b * K + k] = (int32_t)total;
+    }
+    if (k < K && model != nullptr) {
+        float *row = model + ((int64_t)b * K + k) * 4;
+        if (k == 0) {
+            row[0] = (float)ground[4 * b]; row[1] = (float)ground[4 * b + 1];
+            row[2] = (float)ground[4 * b + 2]; row[3] = (float)ground[4 * b + 3];
+        } else if (k == 1) {
+            row[0] = row[1] = row[2] = row[3] = 0.0f;
+        } else {
+            double s;
+            if (flags[4 * b]) {
+                // exact sequential double accumulation in row-major order (cpp_modules.cpp:514) for frames
+                // whose ranges fall outside the fixed-point window; one thread per label, rare.
+                s = 0.0;
+                const uint8_t *sg = seg + (int64_t)b * P;
+                const float *rr = ri + (int64_t)b * P;
+                for (int p = 0; p < P; p++)
+                    if (sg[p] == k) s += (double)rr[p];
+            } else {
+                s = (double)sums[(int64_t)b * KP + k] * (1.0 / 268435456.0);  // exact: sum < 2^53 units
+            }
+            const double n = (double)total;
+            row[0] = row[1] = row[2] = 0.0f;
+            row[3] = (total == 0) ? u2f(0xFFC00000u) : (float)(s / n);  // 0.0/0 on x86 = default NaN
+        }
+    }
+}
+
+static int launch_point_model(const float *ri, const uint8_t *seg, const double *ground, int B, int P, int M,
+                              float *model, int32_t *counts, int32_t *nnz, void *ws, hipStream_t st) {
+    const int KP = kpad(M), T = ntiles(P);
+    WsLayout L = ws_layout(ws, B, P, M);
+    HIP_TRY(hipMemsetAsync(L.sums, 0, (size_t)((char *)L.hist - (char *)L.sums), st));
+    model_hist_kernel<<<dim3(T, B), 256, (size_t)KP * 12, st>>>(ri, seg, P, KP, T, L.sums, L.flags, L.hist);
+    LAUNCH_CHECK();
+    model_scan_kernel<<<B, 256, 0, st>>>(ri, seg, ground, P, M, KP, T, L.sums, L.flags, L.hist, model, counts, nnz);
+    LAUNCH_CHECK();
+    return RPCC_OK;
+}
+
+extern "C" int rpcc_point_model(const float *ri, const uint8_t *seg, const double *ground, int B, int P, int M,
+                                float *model, int32_t *counts, void *ws, void *stream) {
+    ARG_TRY(B > 0 && P > 0 && M > 0 && M <= RPCC_MAX_CLUSTERS && ri && seg && ground && model && ws);
+    return launch_point_model(ri, seg, ground, B, P, M, model, counts, nullptr, ws, (hipStream_t)stream);
+}
+
+// ================================================================================================
+// a10 + a11  intra-prediction, residual, uniform quantisation, ordered scatter
+//            (cpp_modules.cpp:248-285, tools/compress.py:106, cpp_modules.cpp:288-334)
+// ================================================================================================
+// A 256-thread workgroup owns one 1024-pixel tile as 16 segments (4 passes x 4 waves) of 64
+// consecutive pixels.  Rank of a pixel inside its label = tile offset (model_scan_kernel) + pixels of
+// that label in earlier segments + earlier lanes of its own segment (ballot + popcount).
+__global__ __launch_bounds__(256) void predict_quantize_kernel(const float *__restrict__ ri, const float *__restrict__ tm,
+                                                               const uint8_t *__restrict__ seg,
+                                                               const float *__restrict__ model,
+                                                               const uint32_t *__restrict__ hist, float acc, int P, int M,
+                                                               int KP, int T, int16_t *__restrict__ q16,
+                                                               int32_t *__restrict__ q32, float *__restrict__ pred_out) {
+    extern __shared__ unsigned char smem_raw[];
+    float *smodel = reinterpret_cast<float *>(smem_raw);                 // [K*4]
+    uint32_t *segcnt = reinterpret_cast<uint32_t *>(smodel + 4 * KP);    // [16][KP]
+    const int b = blockIdx.y, t = blockIdx.x, K = M + 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 4 * K; i += 256) smodel[i] = model[(int64_t)b * K * 4 + i];
+    for (int i = threadIdx.x; i < 16 * KP; i += 256) segcnt[i] = 0u;
+    __syncthreads();
+    int qv[4], lab[4], rank[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int p = t * TILE + j * 256 + threadIdx.x;
+        lab[j] = -1;
+        qv[j] = 0;
+        rank[j] = 0;
+        if (p < P) {
+            const int64_t gp = (int64_t)b * P + p;
+            const int l = seg[gp];
+            const float r = ri[gp];
+            const float p0 = smodel[4 * l], p1 = smodel[4 * l + 1], p2 = smodel[4 * l + 2], p3 = smodel[4 * l + 3];
+            float pr;
+            if (p0 + p1 + p2 == 0.0f) pr = p3;                                        // cpp_modules.cpp:271-272
+            else pr = -p3 / (p0 * tm[3 * p] + p1 * tm[3 * p + 1] + p2 * tm[3 * p + 2]);  // :275-277
+            if (pred_out) pred_out[gp] = pr;
+            const float res = r - pr;                                                 // compress.py:106
+            qv[j] = (int)roundf(res / acc);                                           // cpp_modules.cpp:315
+            lab[j] = (l == 1) ? -1 : l;                                               // label 1 is skipped (:314)
+        }
+        // rank among equal labels inside this 64-pixel segment
+        int todo = lab[j];
+        while (true) {
+            const unsigned long long pending = __ballot(todo >= 0);
+            if (!pending) break;
+            const int leader = (int)__ffsll((long long)pending) - 1;
+            const int cur = __shfl(todo, leader, 64);
+            const unsigned long long same = __ballot(todo == cur);
+            if (todo == cur) {
+                rank[j] = __popcll(same & ((1ull << lane) - 1ull));
+                if (lane == leader) segcnt[(j * 4 + wave) * KP + cur] = (uint32_t)__popcll(same);
+                todo = -1;
+            }
+        }
+    }
+    __syncthreads();
+    // exclusive prefix over the 16 segments per label, seeded with the tile's offset
+    for (int k = threadIdx.x; k < K; k += 256) {
+        uint32_t run = hist[((int64_t)b * T + t) * KP + k];
+        for (int s = 0; s < 16; s++) {
+            const uint32_t c = segcnt[s * KP + k];
+            segcnt[s * KP + k] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (lab[j] >= 0) {
+            const int64_t o = (int64_t)b * P + segcnt[(j * 4 + wave) * KP + lab[j]] + rank[j];
+            if (q16) q16[o] = (int16_t)qv[j];  // astype(np.int16): two's-complement truncation
+            if (q32) q32[o] = qv[j];
+        }
+    }
+}
+
+static int launch_predict_quantize(const float *ri, const float *tm, const uint8_t *seg, const float *model, float acc,
+                                   int B, int P, int M, int16_t *q16, int32_t *q32, float *pred, void *ws,
+                                   hipStream_t st) {
+    const int KP = kpad(M), T = ntiles(P);
+    WsLayout L = ws_layout(ws, B, P, M);
+    const size_t sh = (size_t)KP * 4 * 4 + (size_t)16 * KP * 4;
+    predict_quantize_kernel<<<dim3(T, B), 256, sh, st>>>(ri, tm, seg, model, L.hist, acc, P, M, KP, T, q16, q32, pred);
+    LAUNCH_CHECK();
+    return RPCC_OK;
+}
+
+extern "C" int rpcc_predict_quantize(const float *ri, const float *tm, const uint8_t *seg, const float *model,
+                                     const int32_t *counts, float acc, int B, int P, int M, int16_t *q16, int32_t *q32,
+                                     int32_t *nnz, float *pred, void *ws, void *stream) {
+    ARG_TRY(B > 0 && P > 0 && M > 0 && M <= RPCC_MAX_CLUSTERS && ri && tm && seg && model && ws);
+    ARG_TRY(q16 || q32);
+    (void)counts;
+    hipStream_t st = (hipStream_t)stream;
+    // Self-contained entry: the tile offsets are rebuilt from this segmentation (histogram + scan with
+    // no model output); the model rows are the caller's (point or plane models).
+    const int KP = kpad(M), T = ntiles(P);
+    WsLayout L = ws_layout(ws, B, P, M);
+    HIP_TRY(hipMemsetAsync(L.sums, 0, (size_t)((char *)L.hist - (char *)L.sums), st));
+    model_hist_kernel<<<dim3(T, B), 256, (size_t)KP * 12, st>>>(ri, seg, P, KP, T, L.sums, L.flags, L.hist);
+    LAUNCH_CHECK();
+    model_scan_kernel<<<B, 256, 0, st>>>(ri, seg, nullptr, P, M, KP, T, L.sums, L.flags, L.hist, nullptr, nullptr, nnz);
+    LAUNCH_CHECK();
+    return launch_predict_quantize(ri, tm, seg, model, acc, B, P, M, q16, q32, pred, ws, st);
+}
+
+// ================================================================================================
+// fused batch entry (uniform framework, FPS segmentation, point model): a2 .. a11
+// ================================================================================================
+extern "C" int rpcc_compress_batch(const rpcc_batch_io *io, int B, rpcc_geom g, int M, double ground_threshold,
+                                   float acc, void *ws, void *stream) {
+    ARG_TRY(io != nullptr && ws != nullptr && B > 0 && M > 0 && M <= RPCC_MAX_CLUSTERS && g.H > 1 && g.W > 0);
+    ARG_TRY(io->offsets && io->tm && io->ground && io->ri && io->seg && io->cen_pix && io->centers && io->model &&
+            io->counts && io->q16 && io->nnz && io->info);
+    const int P = g.H * g.W;
+    ARG_TRY(P % 4 == 0);
+    hipStream_t st = (hipStream_t)stream;
+    WsLayout L = ws_layout(ws, B, P, M);
+    int32_t *proj_scratch = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(ws) + L.bytes + 256);
+    float *temp = reinterpret_cast<float *>(reinterpret_cast<char *>(proj_scratch) + ((size_t)B * ((size_t)P + 8)) * 4);
+    int rc;
+    if ((rc = launch_project(io->xyz, io->offsets, io->total, B, g, io->ri, proj_scratch, st, false))) return rc;
+    if ((rc = launch_ground_mask(io->ri, io->tm, io->ground, ground_threshold, B, P, temp, io->info, st, true))) return rc;
+    if ((rc = launch_fps_range(io->ri, io->tm, temp, io->info, B, P, M, io->cen_pix, io->centers, st))) return rc;
+    if ((rc = launch_assign(io->ri, io->tm, io->ground, io->centers, B, P, M, io->seg, st))) return rc;
+    if ((rc = launch_point_model(io->ri, io->seg, io->ground, B, P, M, io->model, io->counts, io->nnz, ws, st))) return rc;
+    return launch_predict_quantize(io->ri, io->tm, io->seg, io->model, acc, B, P, M, io->q16, nullptr, nullptr, ws, st);
+}

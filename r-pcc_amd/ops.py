@@ -1,0 +1,157 @@
+"""Stage-level Python wrappers of the C ABI (include/rpcc_hip.h): torch tensors in, torch tensors out.
+
+PyTorch is only the device-memory container and the stream provider here; all compute is in
+librpcc_hip.so.  Every function enqueues on torch's current HIP stream and does not synchronise.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import Geom, BatchIO, check, ptr, stream
+
+DEFAULT_CLUSTERS = 100
+
+
+def make_geom(H, W, horizontal_FOV, vertical_max, vertical_min):
+    """Geometry scalars as pybind11 hands them to the reference C++ (python doubles narrowed to float,
+    cpp_modules.cpp:427-428)."""
+    return Geom(int(H), int(W), float(horizontal_FOV), float(vertical_max), float(vertical_min))
+
+
+def transform_map(H, W, horizontal_FOV, vertical_max, vertical_min):
+    """a1: PCTransformer.create_transform_map (dataset/transformer.py:41-54).  Frame-invariant host
+    work (once per process): python-float cos/sin products rounded to fp32; the reference's H*W Python
+    loop is evaluated as an outer product of the same fp64 factors."""
+    vfov = vertical_max - vertical_min
+    alt = [vfov * (h / (H - 1)) + vertical_min for h in range(H)]
+    azi = [horizontal_FOV * (w / W) for w in range(W)]
+    ca = np.array([math.cos(a) for a in alt]); sa = np.array([math.sin(a) for a in alt])
+    cz = np.array([math.cos(a) for a in azi]); sz = np.array([math.sin(a) for a in azi])
+    tm = np.zeros((H, W, 3))
+    tm[..., 0] = ca[:, None] * cz[None, :]
+    tm[..., 1] = ca[:, None] * sz[None, :]
+    tm[..., 2] = sa[:, None]
+    return tm.astype(np.float32)
+
+
+def _dev(t):
+    return t.device
+
+
+def project(xyz, offsets, geom, ri=None, scratch=None):
+    """a2 batched.  xyz f32 [total,3], offsets i64 [B+1] (device) -> ri f32 [B,H,W]."""
+    B = offsets.numel() - 1
+    P = geom.H * geom.W
+    xyz = xyz.contiguous()
+    if ri is None:
+        ri = torch.empty((B, geom.H, geom.W), dtype=torch.float32, device=_dev(offsets))
+    if scratch is None:
+        scratch = torch.empty((B, P + 8), dtype=torch.int32, device=_dev(offsets))
+    check(_lib.lib().rpcc_project(ptr(xyz) if xyz.numel() else None, ptr(offsets), xyz.shape[0], B, geom, ptr(ri),
+                                  ptr(scratch), stream()))
+    return ri
+
+
+def ground_mask(ri, tm, ground, threshold):
+    """a3+a5.  -> (temp f32 [B,P], info i32 [B,4] = n_left, first candidate pixel, nnz, 0)."""
+    B = ri.shape[0]
+    P = ri[0].numel()
+    temp = torch.empty((B, P), dtype=torch.float32, device=_dev(ri))
+    info = torch.empty((B, 4), dtype=torch.int32, device=_dev(ri))
+    check(_lib.lib().rpcc_ground_mask(ptr(ri), ptr(tm), ptr(ground), float(threshold), B, P, ptr(temp), ptr(info),
+                                      stream()))
+    return temp, info
+
+
+def fps_xyz(points, npoint, temp=None):
+    """a6 on an explicit point list: furthest_point_sampling_wrapper(b,n,m,points,temp,idx)
+    (ops/fps/src/sampling.cpp:24-37).  points f32 [B,N,3] -> idx i32 [B,npoint]."""
+    B, N, _ = points.shape
+    if temp is None:
+        temp = torch.full((B, N), 1e10, dtype=torch.float32, device=_dev(points))
+    idx = torch.empty((B, npoint), dtype=torch.int32, device=_dev(points))
+    check(_lib.lib().rpcc_fps_xyz(B, N, npoint, ptr(points), ptr(temp), ptr(idx), stream()))
+    return idx
+
+
+def fps_range(ri, tm, temp, info, M):
+    B = ri.shape[0]
+    P = ri[0].numel()
+    cen_pix = torch.empty((B, M), dtype=torch.int32, device=_dev(ri))
+    centers = torch.empty((B, M, 3), dtype=torch.float32, device=_dev(ri))
+    check(_lib.lib().rpcc_fps_range(ptr(ri), ptr(tm), ptr(temp), ptr(info), B, P, M, ptr(cen_pix), ptr(centers),
+                                    stream()))
+    return cen_pix, centers
+
+
+def assign(ri, tm, ground, centers):
+    B = ri.shape[0]
+    P = ri[0].numel()
+    M = centers.shape[1]
+    seg = torch.empty((B,) + tuple(ri.shape[1:]), dtype=torch.uint8, device=_dev(ri))
+    check(_lib.lib().rpcc_assign(ptr(ri), ptr(tm), ptr(ground), ptr(centers), B, P, M, ptr(seg), stream()))
+    return seg
+
+
+def workspace(B, P, M, device):
+    n = _lib.lib().rpcc_workspace_bytes(B, P, M)
+    return torch.empty((n + 255) // 256 * 256, dtype=torch.uint8, device=device)
+
+
+def point_model(ri, seg, ground, M, ws=None):
+    B = ri.shape[0]
+    P = ri[0].numel()
+    K = M + 2
+    ws = workspace(B, P, M, _dev(ri)) if ws is None else ws
+    model = torch.empty((B, K, 4), dtype=torch.float32, device=_dev(ri))
+    counts = torch.empty((B, K), dtype=torch.int32, device=_dev(ri))
+    check(_lib.lib().rpcc_point_model(ptr(ri), ptr(seg), ptr(ground), B, P, M, ptr(model), ptr(counts), ptr(ws),
+                                      stream()))
+    return model, counts
+
+
+def predict_quantize(ri, tm, seg, model, acc, M, want_pred=False, int16=False, ws=None):
+    B = ri.shape[0]
+    P = ri[0].numel()
+    ws = workspace(B, P, M, _dev(ri)) if ws is None else ws
+    q = torch.zeros((B, P), dtype=torch.int16 if int16 else torch.int32, device=_dev(ri))
+    nnz = torch.empty((B,), dtype=torch.int32, device=_dev(ri))
+    pred = torch.empty((B, P), dtype=torch.float32, device=_dev(ri)) if want_pred else None
+    check(_lib.lib().rpcc_predict_quantize(ptr(ri), ptr(tm), ptr(seg), ptr(model), None, float(acc), B, P, M,
+                                           ptr(q) if int16 else None, None if int16 else ptr(q), ptr(nnz), ptr(pred),
+                                           ptr(ws), stream()))
+    return q, nnz, pred
+
+
+class BatchBuffers:
+    """Device buffers of one batch (B frames, one geometry), allocated once and reused."""
+
+    def __init__(self, B, geom, M, device):
+        P = geom.H * geom.W
+        K = M + 2
+        self.B, self.P, self.M, self.K, self.geom = B, P, M, K, geom
+        f32, i32 = torch.float32, torch.int32
+        self.ri = torch.empty((B, geom.H, geom.W), dtype=f32, device=device)
+        self.seg = torch.empty((B, geom.H, geom.W), dtype=torch.uint8, device=device)
+        self.cen_pix = torch.empty((B, M), dtype=i32, device=device)
+        self.centers = torch.empty((B, M, 3), dtype=f32, device=device)
+        self.model = torch.empty((B, K, 4), dtype=f32, device=device)
+        self.counts = torch.empty((B, K), dtype=i32, device=device)
+        self.q16 = torch.empty((B, P), dtype=torch.int16, device=device)
+        self.nnz = torch.empty((B,), dtype=i32, device=device)
+        self.info = torch.empty((B, 4), dtype=i32, device=device)
+        self.ws = workspace(B, P, M, device)
+
+
+def compress_batch(xyz, offsets, tm, ground, buf, ground_threshold=0.1, acc=0.04):
+    """Fused a2..a11 for a batch (uniform + FPS + point model), ground models supplied [B,4] f64."""
+    io = BatchIO(ptr(xyz).value, ptr(offsets).value, int(xyz.shape[0]), ptr(tm).value, ptr(ground).value,
+                 ptr(buf.ri).value, ptr(buf.seg).value, ptr(buf.cen_pix).value, ptr(buf.centers).value,
+                 ptr(buf.model).value, ptr(buf.counts).value, ptr(buf.q16).value, ptr(buf.nnz).value,
+                 ptr(buf.info).value)
+    check(_lib.lib().rpcc_compress_batch(C.byref(io), buf.B, buf.geom, buf.M, float(ground_threshold), float(acc),
+                                         ptr(buf.ws), stream()))
+    return buf

@@ -1,0 +1,49 @@
+"""The C-ABI library loads and exports every symbol include/rpcc_hip.h declares (no GPU needed)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as ge
+    ge.build()
+    import rpcc_amd  # noqa: F401
+    from rpcc_amd import _lib
+    return _lib
+
+
+def test_header_symbols_exported(built):
+    hdr = open(os.path.join(ROOT, "include", "rpcc_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(rpcc_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 12
+    lib = ctypes.CDLL(built.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert sorted(built.exported_symbols()) == declared
+
+
+def test_version_and_workspace(built):
+    lib = built.lib()
+    assert lib.rpcc_version() >= 100
+    assert lib.rpcc_workspace_bytes(256, 64 * 2048, 100) > 0
+    assert lib.rpcc_workspace_bytes(0, 64 * 2048, 100) == 0
+
+
+def test_argument_errors_do_not_crash(built):
+    lib = built.lib()
+    rc = lib.rpcc_fps_xyz(0, 10, 5, None, None, None, None)
+    assert rc == -1 and b"bad argument" in lib.rpcc_last_error()
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under r-pcc_amd/ may import, link or load it."""
+    bad = re.compile(r"(^|\n)\s*(from|import)\s+oracle\b|liborpcc|oracle/_ref|oracle\.oracle")
+    for dp, _, fs in os.walk(os.path.join(ROOT, "r-pcc_amd")):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                assert not bad.search(open(os.path.join(dp, f)).read()), (dp, f)
