@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/s of the R-PCC per-frame compression hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path (projection -> ground mask -> FPS segmentation -> point model ->
+intra-prediction -> quantisation + ordered scatter; entropy coder and file I/O excluded) over one
+batch of synthetic 64x2048 sweeps (BASELINE.json configs[1]: batch = 256 frames per GPU, uniform + FPS +
+point model, accuracy 0.02).  Inputs are resident in HBM before the timed region.  N > 1: one process
+per GPU (torch.distributed / RCCL), frames sharded across ranks (weak scaling, no data-path
+collective); the compressed payloads are gathered to rank 0 over RCCL after the timed hot path of
+each step (configs[3]).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
+    ap.add_argument("--geom", default="64x2048")
+    ap.add_argument("--clusters", type=int, default=100)
+    ap.add_argument("--accuracy", type=float, default=0.02)
+    ap.add_argument("--cpu-sample", type=int, default=24, help="frames timed on the host for cpu_baseline (0 = skip)")
+    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL payload gather")
+    return ap.parse_args()
+
+
+def cpu_baseline(frames, gms, g, tm, cfg, threads):
+    """The CPU oracle (plain-C port of the reference's cpu=True path, validated bit-exact against the
+    reference) on a bounded sample, frame-parallel like the reference's --workers ThreadPool
+    (tools/compress_datalist.py:202-206).  ctypes releases the GIL inside the C calls."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as orc
+    orc.lib()
+    run = lambda i: orc.compress_frame(frames[i], g, tm, gms[i], cfg)["q"].shape[0]
+    run(0)
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(threads) as ex:
+        list(ex.map(run, range(len(frames))))
+    dt = time.perf_counter() - t0
+    return len(frames) / dt
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    import rpcc_amd  # noqa: F401
+    from rpcc_amd import ops, synth, _lib
+
+    H, W = (int(v) for v in a.geom.split("x"))
+    hfov, vmax, vmin = 360 * (np.pi / 180), 2.0 * (np.pi / 180), -24.9 * (np.pi / 180)
+    geom = ops.make_geom(H, W, hfov, vmax, vmin)
+    tm_np = ops.transform_map(H, W, hfov, vmax, vmin)
+    P, M, B = H * W, a.clusters, a.batch
+    acc = a.accuracy * 2
+
+    # synthetic batch for this rank: frame ids are disjoint across ranks (frame-sharded datalist)
+    ids = range(rank * B, rank * B + B)
+    xyz, offs = synth.make_batch(ids, H, W, device=dev)
+    rng = np.random.default_rng(1234 + rank)
+    gms_np = np.tile(np.array([0.0, 0.0, -1.0, -1.73]), (B, 1)) + rng.normal(0, 0.004, (B, 4))
+    tm = torch.from_numpy(tm_np).to(dev)
+    gms = torch.from_numpy(gms_np).to(dev)
+    buf = ops.BatchBuffers(B, geom, M, dev)
+
+    gather = world > 1 and not a.no_gather
+    if gather:
+        import torch.distributed as dist
+        nnz_all = [torch.empty_like(buf.nnz) for _ in range(world)]
+        pay_all = [torch.empty_like(buf.q16) for _ in range(world)] if rank == 0 else None
+
+    def step():
+        ops.compress_batch(xyz, offs, tm, gms, buf, ground_threshold=0.1, acc=acc)
+        if gather:
+            dist.all_gather(nnz_all, buf.nnz)
+            dist.gather(buf.q16, pay_all, dst=0)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    lib = _lib.lib()
+    lib.rpcc_fps_timing(1)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    fps_ms, fps_n = C.c_double(0), C.c_int(0)
+    lib.rpcc_fps_time_ms(C.byref(fps_ms), C.byref(fps_n))
+    lib.rpcc_fps_timing(0)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    info = buf.info.cpu().numpy()
+    n_left, nnz = info[:, 0].astype(np.int64), info[:, 2].astype(np.int64)
+    n_in = np.diff(offs.cpu().numpy())
+    # algorithmic bytes (stream-once model per stage)
+    fps_bytes = 20.0 * (M - 1) * n_left.sum()
+    b_alg = 12.0 * n_in.sum() + 92.0 * P * B + 2.0 * nnz.sum() + fps_bytes
+
+    out = None
+    if rank == 0:
+        frames_per_s = world * B * a.steps / dt
+        fps_launch_ms = fps_ms.value / max(fps_n.value, 1)
+        achieved = fps_bytes / (fps_launch_ms * 1e-3) / 1e9 if fps_n.value else 0.0
+        out = {
+            "metric": "frames/s (64E, 64x2048 range img), projection->segmentation->model->quantise",
+            "value": round(frames_per_s, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: batch=%d synthetic Velodyne-64E frames (%dx%d) per GPU, uniform + FPS + "
+                                   "point-model, accuracy=%g, cluster_num=%d, ground model injected" % (B, H, W, a.accuracy, M),
+                       "frames_per_gpu_per_step": B, "sharding": "frames over ranks, no data-path collective"
+                       + (", RCCL gather of payloads to rank 0 per step" if gather else "")},
+            "roofline": {"bound": "hbm", "kernel": "fps_range_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "launch_ms": round(fps_launch_ms, 4), "alg_bytes_per_launch": fps_bytes,
+                         "whole_path_alg_GBs": round(b_alg * a.steps / dt / 1e9, 2)},
+        }
+        if a.cpu_sample > 0 and world == 1:
+            S = min(a.cpu_sample, B)
+            o = offs.cpu().numpy()
+            frames = [xyz[o[i]:o[i + 1]].cpu().numpy() for i in range(S)]
+            from oracle import oracle as orc
+            g = orc.LidarGeom(H=H, W=W, hfov_deg=360, vmax_deg=2.0, vmin_deg=-24.9)
+            cfg = dict(orc.DEFAULT_CFG, accuracy=a.accuracy, cluster_num=M)
+            threads = os.cpu_count() or 1
+            v = cpu_baseline(frames, gms_np, g, tm_np, cfg, threads)
+            out["cpu_baseline"] = {"value": round(v, 3), "unit": "frames/s", "cores": threads, "kind": "port",
+                                   "sample": "%d of the same synthetic frames, C port of the reference cpu=True path "
+                                             "(oracle/), frame-parallel over %d threads" % (S, threads)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -121,7 +121,9 @@ __global__ __launch_bounds__(256) void project_kernel(const float *__restrict__ 
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     if (MODE != 0 && flags[B] == 0) return;  // no frame of this batch holds a depth-0 point
-    const int b = find_frame(offs, B, i);
+    // one binary search per wavefront (first active lane); lanes beyond that frame's end search again
+    int b = __builtin_amdgcn_readfirstlane(find_frame(offs, B, __shfl(i, __ffsll((long long)__ballot(1)) - 1, 64)));
+    if (i >= offs[b + 1]) b = find_frame(offs, B, i);
     if (MODE != 0 && flags[b] == 0) return;
     const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
     const RowCol rc = project_point(x, y, z, g);
@@ -212,44 +214,58 @@ __global__ void info_init_kernel(int32_t *__restrict__ info, int B, int P) {
 }
 
 // RAW: ri still holds the projection's bit patterns (RI_EMPTY = untouched) and is finalised here.
+// A 256-thread workgroup owns GM_PIX consecutive pixels of one frame; counts are reduced per wave
+// (ballot), then per workgroup (LDS), then one atomic per counter per workgroup.
+#define GM_PIX 4096
 template <bool RAW>
 __global__ __launch_bounds__(256) void ground_mask_kernel(float *__restrict__ ri, const float *__restrict__ tm,
                                                           const double *__restrict__ ground, double thr, int P,
                                                           float *__restrict__ temp, int32_t *__restrict__ info) {
+    __shared__ int s_cnt[4], s_nz[4], s_first[4];
     const int b = blockIdx.y;
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
     const double a = ground[4 * b], bb = ground[4 * b + 1], c = ground[4 * b + 2], d = ground[4 * b + 3];
     // np.linalg.norm(plane_param[:, :3]) on a (1,1,4) array: all four components (segment_utils.py:47)
     const double div = sqrt(((a * a + bb * bb) + c * c) + d * d);
-    bool cand = false, nz = false;
-    if (p < P) {
-        const int64_t gp = (int64_t)b * P + p;
-        float r = ri[gp];
-        if (RAW) {
-            if (f2u(r) == RI_EMPTY) r = 0.0f;
-            ri[gp] = r;
+    int cnt = 0, nzc = 0, first = P;
+#pragma unroll 4
+    for (int it = 0; it < GM_PIX / 256; it++) {
+        const int p = blockIdx.x * GM_PIX + it * 256 + threadIdx.x;
+        bool cand = false, nz = false;
+        if (p < P) {
+            const int64_t gp = (int64_t)b * P + p;
+            float r = ri[gp];
+            if (RAW) {
+                if (f2u(r) == RI_EMPTY) r = 0.0f;
+                ri[gp] = r;
+            }
+            const float x = r * tm[3 * p], y = r * tm[3 * p + 1], z = r * tm[3 * p + 2];
+            const double s = ((double)x * a + (double)y * bb) + (double)z * c;
+            const double dd = fabs(s + d) / div;
+            cand = dd > thr;
+            nz = r != 0.0f;
+            temp[gp] = cand ? 1e10f : -1.0f;
         }
-        const float x = r * tm[3 * p], y = r * tm[3 * p + 1], z = r * tm[3 * p + 2];
-        const double s = ((double)x * a + (double)y * bb) + (double)z * c;
-        const double dd = fabs(s + d) / div;
-        cand = dd > thr;
-        nz = r != 0.0f;
-        temp[gp] = cand ? 1e10f : -1.0f;
+        const unsigned long long mc = __ballot(cand), mz = __ballot(nz);
+        cnt += __popcll(mc);
+        nzc += __popcll(mz);
+        if (mc && first == P) first = (p - (int)(threadIdx.x & 63)) + (int)__ffsll((long long)mc) - 1;
     }
-    const unsigned long long mc = __ballot(cand), mz = __ballot(nz);
-    if ((threadIdx.x & 63) == 0) {
-        if (mc) {
-            atomicAdd(&info[4 * b + 0], __popcll(mc));
-            atomicMin(&info[4 * b + 1], p + (int)__ffsll((long long)mc) - 1);
-        }
-        if (mz) atomicAdd(&info[4 * b + 2], __popcll(mz));
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_cnt[wave] = cnt; s_nz[wave] = nzc; s_first[wave] = first; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int tc = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        const int tz = s_nz[0] + s_nz[1] + s_nz[2] + s_nz[3];
+        const int tf = min(min(s_first[0], s_first[1]), min(s_first[2], s_first[3]));
+        if (tc) { atomicAdd(&info[4 * b + 0], tc); atomicMin(&info[4 * b + 1], tf); }
+        if (tz) atomicAdd(&info[4 * b + 2], tz);
     }
 }
 
 static int launch_ground_mask(float *ri, const float *tm, const double *ground, double thr, int B, int P, float *temp,
                               int32_t *info, hipStream_t st, bool raw) {
     info_init_kernel<<<(B + 255) / 256, 256, 0, st>>>(info, B, P);
-    const dim3 grid((P + 255) / 256, B);
+    const dim3 grid((P + GM_PIX - 1) / GM_PIX, B);
     if (raw) ground_mask_kernel<true><<<grid, 256, 0, st>>>(ri, tm, ground, thr, P, temp, info);
     else     ground_mask_kernel<false><<<grid, 256, 0, st>>>(ri, tm, ground, thr, P, temp, info);
     LAUNCH_CHECK();
@@ -401,44 +417,81 @@ extern "C" int rpcc_fps_range(const float *ri, const float *tm, float *temp, con
 // |distance|.  The fp32 radius is sqrtf((dx*dx+dy*dy)+dz*dz); sqrtf is monotone, so the running minimum
 // is tracked on the squared distance and sqrtf is evaluated only when the squared distance strictly
 // improves -- the selected index is identical to evaluating all M square roots (DESIGN.md "assign").
+#define ASSIGN_Q 4  // pixels per thread: one ds_read_b128 of a centre feeds 4 distance evaluations
+__device__ __forceinline__ float next_up_pos(float v) { return u2f(f2u(v) + 1u); }  // v >= 0, finite
+
 __global__ __launch_bounds__(256) void assign_kernel(const float *__restrict__ ri, const float *__restrict__ tm,
                                                      const double *__restrict__ ground,
                                                      const float *__restrict__ centers, int P, int M,
                                                      uint8_t *__restrict__ seg) {
-    extern __shared__ float cen[];  // [M*3]
+    extern __shared__ __attribute__((aligned(16))) float4 cen4[];  // [M] (x,y,z,0)
     const int b = blockIdx.y;
-    for (int i = threadIdx.x; i < 3 * M; i += blockDim.x) cen[i] = centers[(int64_t)b * M * 3 + i];
+    for (int i = threadIdx.x; i < M; i += blockDim.x) {
+        const float *c = centers + ((int64_t)b * M + i) * 3;
+        cen4[i] = make_float4(c[0], c[1], c[2], 0.0f);
+    }
     __syncthreads();
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= P) return;
     const double a = ground[4 * b], bb = ground[4 * b + 1], c = ground[4 * b + 2], d = ground[4 * b + 3];
-    const float r = ri[(int64_t)b * P + p];
-    const float tx = tm[3 * p], ty = tm[3 * p + 1], tz = tm[3 * p + 2];
-    const double den = ((double)tx * a + (double)ty * bb) + (double)tz * c;
-    const double g = (double)r - (-d / den);
-    const float x = r * tx, y = r * ty, z = r * tz;
-    float best_d2 = __builtin_inff(), best_s = __builtin_inff();
-    int best_k = -1;
+    float r[ASSIGN_Q], x[ASSIGN_Q], y[ASSIGN_Q], z[ASSIGN_Q], m1[ASSIGN_Q], m2[ASSIGN_Q];
+    int k1[ASSIGN_Q];
+    double ag[ASSIGN_Q];
+    const int p0 = blockIdx.x * (256 * ASSIGN_Q) + threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < ASSIGN_Q; q++) {
+        const int p = min(p0 + q * 256, P - 1);
+        r[q] = ri[(int64_t)b * P + p];
+        const float tx = tm[3 * p], ty = tm[3 * p + 1], tz = tm[3 * p + 2];
+        const double den = ((double)tx * a + (double)ty * bb) + (double)tz * c;
+        ag[q] = fabs((double)r[q] - (-d / den));
+        x[q] = r[q] * tx; y[q] = r[q] * ty; z[q] = r[q] * tz;
+        m1[q] = __builtin_inff(); m2[q] = __builtin_inff(); k1[q] = -1;
+    }
+    // smallest and second-smallest squared distance (strict '<': first occurrence keeps the index)
     for (int k = 0; k < M; k++) {
-        const float dx = x - cen[3 * k], dy = y - cen[3 * k + 1], dz = z - cen[3 * k + 2];
-        const float d2 = (dx * dx + dy * dy) + dz * dz;
-        if (d2 < best_d2) {
-            const float s = sqrtf(d2);
-            best_d2 = d2;
-            if (s < best_s) { best_s = s; best_k = k; }
+        const float4 cc = cen4[k];
+#pragma unroll
+        for (int q = 0; q < ASSIGN_Q; q++) {
+            const float dx = x[q] - cc.x, dy = y[q] - cc.y, dz = z[q] - cc.z;
+            const float d2 = (dx * dx + dy * dy) + dz * dz;
+            const bool lt = d2 < m1[q];
+            m2[q] = lt ? m1[q] : fminf(m2[q], d2);
+            k1[q] = lt ? k : k1[q];
+            m1[q] = lt ? d2 : m1[q];
         }
     }
-    int label = 0;
-    const double ag = fabs(g);
-    if (!(ag != ag) && best_k >= 0 && (double)best_s < ag) label = best_k + 2;  // ground first on ties / NaN
-    if (r == 0.0f) label = 1;
-    seg[(int64_t)b * P + p] = (uint8_t)label;
+#pragma unroll
+    for (int q = 0; q < ASSIGN_Q; q++) {
+        const int p = p0 + q * 256;
+        int label = 0;
+        if (k1[q] >= 0) {
+            // radius = sqrtf(min d2).  Every squared distance that rounds to the same radius ties with it,
+            // and numpy's argmax keeps the lowest index: U = largest float whose sqrtf equals the radius.
+            const float s = sqrtf(m1[q]);
+            float U = m1[q];
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const float n = next_up_pos(U);
+                if (U < 3.0e38f && sqrtf(n) == s) U = n;
+            }
+            int kk = k1[q];
+            if (m2[q] <= U) {  // another centre may tie after the square root (rare): first index with d2 <= U
+                for (int k = 0; k < kk; k++) {
+                    const float4 cc = cen4[k];
+                    const float dx = x[q] - cc.x, dy = y[q] - cc.y, dz = z[q] - cc.z;
+                    if ((dx * dx + dy * dy) + dz * dz <= U) { kk = k; break; }
+                }
+            }
+            if (!(ag[q] != ag[q]) && (double)s < ag[q]) label = kk + 2;  // ground (index 0) wins ties and NaN
+        }
+        if (r[q] == 0.0f) label = 1;
+        if (p < P) seg[(int64_t)b * P + p] = (uint8_t)label;
+    }
 }
 
 static int launch_assign(const float *ri, const float *tm, const double *ground, const float *centers, int B, int P,
                          int M, uint8_t *seg, hipStream_t st) {
-    const dim3 grid((P + 255) / 256, B);
-    assign_kernel<<<grid, 256, (size_t)M * 3 * sizeof(float), st>>>(ri, tm, ground, centers, P, M, seg);
+    const dim3 grid((P + 256 * ASSIGN_Q - 1) / (256 * ASSIGN_Q), B);
+    assign_kernel<<<grid, 256, (size_t)M * sizeof(float4), st>>>(ri, tm, ground, centers, P, M, seg);
     LAUNCH_CHECK();
     return RPCC_OK;
 }

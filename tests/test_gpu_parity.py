@@ -248,3 +248,41 @@ def test_full_size_batch_properties(env):
     ops.compress_batch(xyz, offs, d_tm, _to(env, gms), buf)
     torch.cuda.synchronize()
     assert np.array_equal(buf.q16.cpu().numpy()[:, :nnz.min()], q_first[:, :nnz.min()])
+
+
+def test_assign_sqrt_ties_and_duplicates(env):
+    """argmax(-abs(distance)) keeps the LOWEST index among clusters whose fp32 radius is equal: that
+    includes squared distances that differ by an ulp but round to the same sqrtf, exact duplicates of a
+    centre, and ties between the ground term and a cluster (ground wins)."""
+    torch, ops, orc = env["torch"], env["ops"], env["orc"]
+    g, geom, tm = _geom(env, "VelodyneVLP16")
+    rng = np.random.default_rng(31)
+    ri = rng.uniform(2, 60, (g.H, g.W)).astype(np.float32)
+    ri[rng.random(ri.shape) < 0.1] = 0
+    pc = orc.backproject(ri, tm).reshape(-1, 3)
+    M = 100
+    cen = pc[rng.choice(pc.shape[0], M, replace=False)].copy()
+    # centres mirrored about chosen pixels, the LOWER index nudged by a few ulps: near-ties under sqrtf
+    n_sqrt_ties = 0
+    pix = rng.choice(pc.shape[0], 40, replace=False)
+    for j, p in enumerate(pix):
+        if j >= 40:
+            break
+        v = rng.normal(0, 0.4, 3).astype(np.float32)
+        hi, lo = 99 - j, 2 * j if 2 * j < 50 else j
+        cen[hi] = pc[p] + v
+        cb = pc[p] - v
+        cb[rng.integers(0, 3)] *= np.float32(1 + rng.integers(-3, 4) * 2.0 ** -23)
+        cen[lo] = cb
+    cen[60] = cen[10]                                              # exact duplicate centre
+    plane = np.array([0.01, -0.02, -0.9997, -1.72])
+    exp = orc.assign(ri, pc.reshape(g.H, g.W, 3), tm, plane, cen)
+    d = pc[:, None, :] - cen[None, :, :]
+    d2 = (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
+    rad = np.sqrt(d2)
+    kmin = d2.argmin(1)
+    n_sqrt_ties = int(((rad == rad[np.arange(len(kmin)), kmin][:, None]) & (d2 != d2[np.arange(len(kmin)), kmin][:, None])).any(1).sum())
+    assert n_sqrt_ties > 0, "test inputs must contain sqrt-level ties"
+    got = ops.assign(_to(env, ri[None]), _to(env, tm), _to(env, plane[None]), _to(env, cen[None]))[0].cpu().numpy()
+    assert np.array_equal(got, exp.astype(np.uint8))
+    assert np.array_equal(exp, orc.np_assign(ri.reshape(g.H, g.W, 1), pc.reshape(g.H, g.W, 3), tm, plane, cen))
