@@ -74,9 +74,14 @@ int rpcc_fps_xyz(int B, int N, int M, const float *points, float *temp, int32_t 
  * on the compacted candidate list (utils/segment_utils.py:120-124).
  *   info     dev i32 [B,4]       from rpcc_ground_mask (first candidate = start point)
  *   cen_pix  dev i32 [B,M]  out  pixel index of each centre
- *   centers  dev f32 [B,M,3] out cluster_centers                                                  */
+ *   centers  dev f32 [B,M,3] out cluster_centers
+ *   ws       dev scratch for a planar copy of tm (12*P bytes); NULL selects the brute-force kernel */
 int rpcc_fps_range(const float *ri, const float *tm, float *temp, const int32_t *info, int B, int P, int M,
-                   int32_t *cen_pix, float *centers, void *stream);
+                   int32_t *cen_pix, float *centers, void *ws /* dev, >= 12*P bytes, or NULL */, void *stream);
+
+/* Test hook: force the brute-force FPS kernels (one full pass per centre) instead of the exact
+ * tile-pruned ones; both give identical results. */
+void rpcc_fps_force_bruteforce(int on);
 
 /* ---- a7: ground / cluster assignment + relabel ---------------------------------------------- *
  * replaces calc_plane_residual_depth, calc_cluster_residual_radius, concatenate + argmax and the

@@ -34,7 +34,8 @@ _SIGS = {
     "rpcc_project": (C.c_int, [_VP, _VP, _I64, _I, Geom, _VP, _VP, _VP]),
     "rpcc_ground_mask": (C.c_int, [_VP, _VP, _VP, _D, _I, _I, _VP, _VP, _VP]),
     "rpcc_fps_xyz": (C.c_int, [_I, _I, _I, _VP, _VP, _VP, _VP]),
-    "rpcc_fps_range": (C.c_int, [_VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP]),
+    "rpcc_fps_range": (C.c_int, [_VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP]),
+    "rpcc_fps_force_bruteforce": (None, [_I]),
     "rpcc_assign": (C.c_int, [_VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP]),
     "rpcc_point_model": (C.c_int, [_VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP]),
     "rpcc_predict_quantize": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _F, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP]),

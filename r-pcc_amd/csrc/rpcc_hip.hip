@@ -385,18 +385,201 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_range_kernel(const float *__r
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// v2: exact tile-pruned FPS.  Points are grouped in tiles of 64 consecutive indices (one wavefront).
+// Per tile the workgroup keeps in LDS: the bounding box of the tile's candidates, the tile's current
+// maximum of temp with its (lowest) index, and that point's coordinates.  For a new centre c a tile
+// can only change if some point is closer to c than its temp, i.e. only if
+//     bound(c, box) < tile_max,   bound = ((bx*bx)+(by*by))+(bz*bz),  b* = per-axis gap to the box.
+// bound is evaluated with the SAME fp32 operation sequence as the point distance on per-axis gaps that
+// are <= every candidate's |d*| (rounding is monotone), so bound <= computed distance of every
+// candidate and skipping is bit-exact, not approximate (DESIGN.md "FPS").  Everything else -- min with
+// temp, strict '>' arg-max with lowest-index ties -- is the brute-force definition.
+// ------------------------------------------------------------------------------------------------
+struct FpsLds {
+    float *lo[3], *hi[3], *tmax, *cx[3];
+    uint32_t *targ;
+    uint16_t *work;
+    __device__ FpsLds(unsigned char *base, int T) {
+        float *f = reinterpret_cast<float *>(base);
+        for (int a = 0; a < 3; a++) { lo[a] = f + (size_t)a * T; hi[a] = f + (size_t)(3 + a) * T; cx[a] = f + (size_t)(7 + a) * T; }
+        tmax = f + (size_t)6 * T;
+        targ = reinterpret_cast<uint32_t *>(f + (size_t)10 * T);
+        work = reinterpret_cast<uint16_t *>(f + (size_t)11 * T);
+    }
+};
+static inline size_t fps_tiled_lds_bytes(int T) { return (size_t)T * 46 + 64; }
+#define FPS_TILED_MAX_TILES 3400  // 46 B/tile must fit the 160 KiB LDS of one CU
+
+__device__ __forceinline__ float wave_min_f32(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, RPCC_WAVE));
+    return v;
+}
+__device__ __forceinline__ float wave_max_f32(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, RPCC_WAVE));
+    return v;
+}
+
+// RANGE: point k = (ri[k]*tx[k], ri[k]*ty[k], ri[k]*tz[k]) with SoA rays; else AoS xyz[k*3..].
+template <bool RANGE>
+__device__ __forceinline__ void fps_load_point(const float *__restrict__ src, const float *__restrict__ tx,
+                                               const float *__restrict__ ty, const float *__restrict__ tz, int k,
+                                               float &x, float &y, float &z) {
+    if (RANGE) {
+        const float r = src[k];
+        x = r * tx[k]; y = r * ty[k]; z = r * tz[k];
+    } else {
+        x = src[3 * (int64_t)k]; y = src[3 * (int64_t)k + 1]; z = src[3 * (int64_t)k + 2];
+    }
+}
+
+template <bool RANGE>
+__global__ __launch_bounds__(FPS_THREADS) void fps_tiled_kernel(const float *__restrict__ src,
+                                                                const float *__restrict__ tx,
+                                                                const float *__restrict__ ty,
+                                                                const float *__restrict__ tz, float *__restrict__ temp,
+                                                                const int32_t *__restrict__ info, int N, int M, int T,
+                                                                int32_t *__restrict__ out_idx,
+                                                                float *__restrict__ out_cen) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char fps_smem[];
+    __shared__ unsigned long long red[16];
+    __shared__ int wcount;
+    FpsLds L(fps_smem, T);
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    src += (int64_t)b * N * (RANGE ? 1 : 3);
+    temp += (int64_t)b * N;
+    out_idx += (int64_t)b * M;
+    if (out_cen) out_cen += (int64_t)b * M * 3;
+    if (M <= 0) return;
+
+    int old = 0;
+    if (RANGE) { old = info[4 * b + 1]; if (old >= N) old = 0; }
+    float c0, c1, c2;
+    fps_load_point<RANGE>(src, tx, ty, tz, old, c0, c1, c2);
+    if (tid == 0) {
+        out_idx[0] = old;
+        if (out_cen) { out_cen[0] = c0; out_cen[1] = c1; out_cen[2] = c2; }
+        wcount = 0;
+    }
+
+    // one tile: distance update against the current centre, tile maximum, (optionally) bounding box
+    auto process_tile = [&](int t, bool with_box) {
+        const int p = t * 64 + lane;
+        const bool valid = p < N;
+        float x = 0.f, y = 0.f, z = 0.f, tp = -1.0f;
+        if (valid) { fps_load_point<RANGE>(src, tx, ty, tz, p, x, y, z); tp = temp[p]; }
+        if (with_box) {
+            const bool cand = tp >= 0.0f;
+            const float big = 3.0e38f;
+            const float l0 = wave_min_f32(cand ? x : big), l1 = wave_min_f32(cand ? y : big), l2 = wave_min_f32(cand ? z : big);
+            const float h0 = wave_max_f32(cand ? x : -big), h1 = wave_max_f32(cand ? y : -big), h2 = wave_max_f32(cand ? z : -big);
+            if (lane == 0) { L.lo[0][t] = l0; L.lo[1][t] = l1; L.lo[2][t] = l2; L.hi[0][t] = h0; L.hi[1][t] = h1; L.hi[2][t] = h2; }
+        }
+        const float dx = x - c0, dy = y - c1, dz = z - c2;
+        const float d = (dx * dx + dy * dy) + dz * dz;  // sampling_gpu.cu:64, un-fused
+        const float nt = fminf(d, tp);
+        if (valid && nt != tp) temp[p] = nt;
+        const unsigned long long k = wave_max_u64(fps_key(valid ? nt : -1.0f, (uint32_t)p));
+        const int wl = (int)fps_key_index(k) - t * 64;
+        const float wx = __shfl(x, wl, 64), wy = __shfl(y, wl, 64), wz = __shfl(z, wl, 64), wt = __shfl(nt, wl, 64);
+        if (lane == 0) { L.tmax[t] = wt; L.targ[t] = fps_key_index(k); L.cx[0][t] = wx; L.cx[1][t] = wy; L.cx[2][t] = wz; }
+    };
+
+    // arg-max over the tile table -> next centre (index and coordinates)
+    auto select_next = [&]() {
+        unsigned long long k = 0ull;
+        for (int t = tid; t < T; t += FPS_THREADS) {
+            const unsigned long long kk = fps_key(L.tmax[t], L.targ[t]);
+            k = kk > k ? kk : k;
+        }
+        k = wave_max_u64(k);
+        if (lane == 0) red[wave] = k;
+        __syncthreads();
+        k = wave_max_u64(red[lane & 15]);
+        old = (int)fps_key_index(k);
+        const int t = old >> 6;
+        c0 = L.cx[0][t]; c1 = L.cx[1][t]; c2 = L.cx[2][t];
+    };
+
+    // first centre: every tile is visited once (also builds the boxes)
+    if (M > 1) {
+        for (int t = wave; t < T; t += FPS_THREADS / 64) process_tile(t, true);
+        __syncthreads();
+        select_next();
+        if (tid == 0) { out_idx[1] = old; if (out_cen) { out_cen[3] = c0; out_cen[4] = c1; out_cen[5] = c2; } }
+    }
+    for (int j = 2; j < M; j++) {
+        // tile test against the new centre; active tiles go to the work list
+        for (int t = tid; t < T; t += FPS_THREADS) {
+            const float g0 = fmaxf(fmaxf(L.lo[0][t] - c0, c0 - L.hi[0][t]), 0.0f);
+            const float g1 = fmaxf(fmaxf(L.lo[1][t] - c1, c1 - L.hi[1][t]), 0.0f);
+            const float g2 = fmaxf(fmaxf(L.lo[2][t] - c2, c2 - L.hi[2][t]), 0.0f);
+            const float bound = (g0 * g0 + g1 * g1) + g2 * g2;
+            const bool act = bound < L.tmax[t];
+            const unsigned long long m = __ballot(act);
+            if (m) {
+                int base = 0;
+                if (lane == (int)__ffsll((long long)m) - 1) base = atomicAdd(&wcount, __popcll(m));
+                base = __shfl(base, (int)__ffsll((long long)m) - 1, 64);
+                if (act) L.work[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)t;
+            }
+        }
+        __syncthreads();
+        const int n = wcount;
+        for (int e = wave; e < n; e += FPS_THREADS / 64) process_tile((int)L.work[e], false);
+        __syncthreads();
+        if (tid == 0) wcount = 0;
+        select_next();
+        if (tid == 0) { out_idx[j] = old; if (out_cen) { out_cen[3 * j] = c0; out_cen[3 * j + 1] = c1; out_cen[3 * j + 2] = c2; } }
+    }
+}
+
+// AoS transform_map [P,3] -> three planes (frame-invariant; 12 B/pixel once per call)
+__global__ __launch_bounds__(256) void rays_soa_kernel(const float *__restrict__ tm, int P, float *__restrict__ soa) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < P) { soa[p] = tm[3 * p]; soa[P + p] = tm[3 * p + 1]; soa[2 * (int64_t)P + p] = tm[3 * p + 2]; }
+}
+
+static bool g_fps_force_v1 = false;
+extern "C" void rpcc_fps_force_bruteforce(int on) { g_fps_force_v1 = on != 0; }
+
 extern "C" int rpcc_fps_xyz(int B, int N, int M, const float *points, float *temp, int32_t *idx, void *stream) {
     ARG_TRY(B > 0 && N > 0 && M >= 0 && points && temp && idx);
     if (M == 0) return RPCC_OK;
     hipStream_t st = (hipStream_t)stream;
     FpsTimer tmr(st);
-    fps_xyz_kernel<<<B, FPS_THREADS, 0, st>>>(N, M, points, temp, idx);
+    const int T = (N + 63) / 64;
+    if (!g_fps_force_v1 && T <= FPS_TILED_MAX_TILES && N < (1 << 30) / 3) {
+        const size_t sh = fps_tiled_lds_bytes(T);
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_tiled_kernel<false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+        fps_tiled_kernel<false><<<B, FPS_THREADS, sh, st>>>(points, nullptr, nullptr, nullptr, temp, nullptr, N, M, T, idx, nullptr);
+    } else {
+        fps_xyz_kernel<<<B, FPS_THREADS, 0, st>>>(N, M, points, temp, idx);
+    }
     LAUNCH_CHECK();
     return RPCC_OK;
 }
 
+// rays_soa: dev f32 [3,P] scratch (may be NULL -> brute-force kernel on the AoS table)
 static int launch_fps_range(const float *ri, const float *tm, float *temp, const int32_t *info, int B, int P, int M,
-                            int32_t *cen_pix, float *centers, hipStream_t st) {
+                            int32_t *cen_pix, float *centers, float *rays_soa, hipStream_t st) {
+    const int T = (P + 63) / 64;
+    if (!g_fps_force_v1 && rays_soa != nullptr && T <= FPS_TILED_MAX_TILES) {
+        rays_soa_kernel<<<(P + 255) / 256, 256, 0, st>>>(tm, P, rays_soa);
+        const size_t sh = fps_tiled_lds_bytes(T);
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_tiled_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+        FpsTimer tmr(st);
+        fps_tiled_kernel<true><<<B, FPS_THREADS, sh, st>>>(ri, rays_soa, rays_soa + P, rays_soa + 2 * (int64_t)P, temp, info,
+                                                        P, M, T, cen_pix, centers);
+        LAUNCH_CHECK();
+        return RPCC_OK;
+    }
+    if (P % 4 != 0 || ((uintptr_t)ri % 16) || ((uintptr_t)temp % 16) || ((uintptr_t)tm % 16))
+        return set_err(RPCC_ERR_ARG, "fps_range brute-force path needs 16-byte aligned buffers and P %% 4 == 0%s%s");
     FpsTimer tmr(st);
     fps_range_kernel<<<B, FPS_THREADS, 0, st>>>(ri, tm, temp, info, P, M, cen_pix, centers);
     LAUNCH_CHECK();
@@ -404,10 +587,10 @@ static int launch_fps_range(const float *ri, const float *tm, float *temp, const
 }
 
 extern "C" int rpcc_fps_range(const float *ri, const float *tm, float *temp, const int32_t *info, int B, int P, int M,
-                              int32_t *cen_pix, float *centers, void *stream) {
+                              int32_t *cen_pix, float *centers, void *ws, void *stream) {
     ARG_TRY(B > 0 && P > 0 && M > 0 && ri && tm && temp && info && cen_pix && centers);
-    ARG_TRY(((uintptr_t)ri % 16 == 0) && ((uintptr_t)temp % 16 == 0) && ((uintptr_t)tm % 16 == 0) && (P % 4 == 0));
-    return launch_fps_range(ri, tm, temp, info, B, P, M, cen_pix, centers, (hipStream_t)stream);
+    return launch_fps_range(ri, tm, temp, info, B, P, M, cen_pix, centers, reinterpret_cast<float *>(ws),
+                            (hipStream_t)stream);
 }
 
 // ================================================================================================
@@ -536,7 +719,8 @@ extern "C" size_t rpcc_workspace_bytes(int B, int P, int M) {
     if (B <= 0 || P <= 0 || M <= 0) return 0;
     const size_t model_ws = ws_layout(nullptr, B, P, M).bytes;
     const size_t proj_ws = ((size_t)B * ((size_t)P + 8)) * 4;  // projection scratch, carved after the model part
-    return model_ws + 256 + proj_ws + (size_t)B * P * 4;       // + FPS temp [B,P] f32
+    return model_ws + 256 + proj_ws + (size_t)B * P * 4        // + FPS temp [B,P] f32
+           + (size_t)3 * P * 4 + 256;                           // + SoA copy of the ray table
 }
 
 __global__ __launch_bounds__(256) void model_hist_kernel(const float *__restrict__ ri, const uint8_t *__restrict__ seg,
@@ -773,7 +957,8 @@ extern "C" int rpcc_compress_batch(const rpcc_batch_io *io, int B, rpcc_geom g, 
     int rc;
     if ((rc = launch_project(io->xyz, io->offsets, io->total, B, g, io->ri, proj_scratch, st, false))) return rc;
     if ((rc = launch_ground_mask(io->ri, io->tm, io->ground, ground_threshold, B, P, temp, io->info, st, true))) return rc;
-    if ((rc = launch_fps_range(io->ri, io->tm, temp, io->info, B, P, M, io->cen_pix, io->centers, st))) return rc;
+    float *rays_soa = temp + (size_t)B * P;
+    if ((rc = launch_fps_range(io->ri, io->tm, temp, io->info, B, P, M, io->cen_pix, io->centers, rays_soa, st))) return rc;
     if ((rc = launch_assign(io->ri, io->tm, io->ground, io->centers, B, P, M, io->seg, st))) return rc;
     if ((rc = launch_point_model(io->ri, io->seg, io->ground, B, P, M, io->model, io->counts, io->nnz, ws, st))) return rc;
     return launch_predict_quantize(io->ri, io->tm, io->seg, io->model, acc, B, P, M, io->q16, nullptr, nullptr, ws, st);

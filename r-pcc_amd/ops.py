@@ -82,9 +82,15 @@ def fps_range(ri, tm, temp, info, M):
     P = ri[0].numel()
     cen_pix = torch.empty((B, M), dtype=torch.int32, device=_dev(ri))
     centers = torch.empty((B, M, 3), dtype=torch.float32, device=_dev(ri))
+    rays = torch.empty((3, P), dtype=torch.float32, device=_dev(ri))
     check(_lib.lib().rpcc_fps_range(ptr(ri), ptr(tm), ptr(temp), ptr(info), B, P, M, ptr(cen_pix), ptr(centers),
-                                    stream()))
+                                    ptr(rays), stream()))
     return cen_pix, centers
+
+
+def fps_force_bruteforce(on):
+    """Test hook: route FPS calls to the brute-force kernels (identical results, one pass per centre)."""
+    _lib.lib().rpcc_fps_force_bruteforce(1 if on else 0)
 
 
 def assign(ri, tm, ground, centers):

@@ -286,3 +286,47 @@ def test_assign_sqrt_ties_and_duplicates(env):
     got = ops.assign(_to(env, ri[None]), _to(env, tm), _to(env, plane[None]), _to(env, cen[None]))[0].cpu().numpy()
     assert np.array_equal(got, exp.astype(np.uint8))
     assert np.array_equal(exp, orc.np_assign(ri.reshape(g.H, g.W, 1), pc.reshape(g.H, g.W, 3), tm, plane, cen))
+
+
+def test_fps_tiled_equals_bruteforce(env):
+    """The tile-pruned FPS kernels are exact: same indices, same centres AND the same final temp array
+    (bit for bit) as the brute-force kernels, on range images and on explicit point lists."""
+    torch, ops, orc, synth = env["torch"], env["ops"], env["orc"], env["synth"]
+    for name, ids in (("Velodyne64E_2048", (5, 6)), ("Velodyne64E", (7,)), ("Velodyne32E", (8,)), ("VelodyneVLP16", (9,))):
+        g, geom, tm = _geom(env, name)
+        gd = orc.GEOMS[name]
+        frames = [synth.make_frame(i, g.H, g.W, vmax_deg=gd["vmax_deg"], vmin_deg=gd["vmin_deg"]).numpy() for i in ids]
+        offs = np.zeros(len(frames) + 1, np.int64)
+        offs[1:] = np.cumsum([f.shape[0] for f in frames])
+        ri = ops.project(_to(env, np.concatenate(frames)), _to(env, offs), geom)
+        gms = _to(env, np.tile(np.array([0.002, -0.004, -0.99999, -1.73]), (len(frames), 1)))
+        res = {}
+        for mode in (True, False):
+            ops.fps_force_bruteforce(mode)
+            try:
+                temp, info = ops.ground_mask(ri, _to(env, tm), gms, 0.1)
+                cen_pix, centers = ops.fps_range(ri, _to(env, tm), temp, info, 100)
+                res[mode] = (cen_pix.cpu().numpy(), centers.cpu().numpy(), temp.cpu().numpy())
+            finally:
+                ops.fps_force_bruteforce(False)
+        for a, b in zip(res[True], res[False]):
+            assert _beq(a, b), name
+        for i, f in enumerate(frames):
+            o = orc.compress_frame(f, g, tm, gms[i].cpu().numpy())
+            assert np.array_equal(res[False][0][i], o["fps_pix"])
+    rng = np.random.default_rng(77)
+    for (B, N, M) in [(2, 30000, 100), (1, 777, 50), (1, 64, 10), (1, 200000, 100), (1, 300000, 20)]:
+        pts = rng.normal(0, 10, (B, N, 3)).astype(np.float32)
+        pts[:, N // 3: 2 * (N // 3)] = pts[:, : N // 3]
+        out = {}
+        for mode in (True, False):
+            ops.fps_force_bruteforce(mode)
+            try:
+                temp = torch.full((B, N), 1e10, dtype=torch.float32, device=env["dev"])
+                idx = ops.fps_xyz(_to(env, pts), M, temp=temp)
+                out[mode] = (idx.cpu().numpy(), temp.cpu().numpy())
+            finally:
+                ops.fps_force_bruteforce(False)
+        assert _beq(out[True][0], out[False][0]) and _beq(out[True][1], out[False][1]), (B, N, M)
+        if N <= 30000:
+            assert np.array_equal(out[False][0][0], orc.fps(pts[0], M))
