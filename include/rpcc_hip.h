@@ -49,6 +49,17 @@ typedef struct rpcc_geom {
 int rpcc_project(const float *xyz, const int64_t *offsets, int64_t total, int B, rpcc_geom g, float *ri,
                  int32_t *scratch, void *stream);
 
+/* ---- a4: ground plane ----------------------------------------------------------------------- *
+ * replaces the ground branch of PointCloudSegment.segment: candidate selection + RANSAC
+ * (utils/segment_utils.py:74-82,101-108).  The reference uses Open3D segment_plane on an unseeded
+ * np.random.choice subsample (third-party, random); this is the build's deterministic seeded
+ * definition (DESIGN.md "RANSAC"): z < -1.5 candidates, systematic subsample to 5000, all pixels if
+ * fewer than 800, 100 hypotheses of 10 points, 0.1 m inlier distance, refit on the inliers.
+ *   ground   dev f64 [B,4] out   plane a,b,c,d (unit normal) per frame; frame b uses seed + b
+ *   inliers  dev i32 [B]   out   inlier count of the winning hypothesis (may be NULL)            */
+int rpcc_ground_ransac(const float *ri, const float *tm, int B, int P, uint32_t seed, double *ground,
+                       int32_t *inliers, void *stream);
+
 /* ---- a3+a5: back-projection + vertical ground residual + FPS state init -------------------- *
  * replaces PCTransformer.range_image_to_point_cloud (dataset/transformer.py:94-101) and
  * PointCloudSegment.calc_plane_residual_vertical cpu branch + mask (utils/segment_utils.py:44-47,
@@ -121,7 +132,8 @@ typedef struct rpcc_batch_io {
     const int64_t *offsets;  /* dev i64 [B+1] */
     int64_t total;
     const float *tm;         /* dev f32 [P,3] */
-    const double *ground;    /* dev f64 [B,4] */
+    double *ground;          /* dev f64 [B,4]  in (ground_seed < 0: injected models) / out (fitted here) */
+    int64_t ground_seed;     /* >= 0: fit the ground plane with rpcc_ground_ransac(seed = ground_seed) */
     float *ri;               /* dev f32 [B,P] out */
     uint8_t *seg;            /* dev u8  [B,P] out */
     int32_t *cen_pix;        /* dev i32 [B,M] out */

@@ -41,7 +41,8 @@ def lib():
         _LIB.orc_plane_divisor4.restype = C.c_double
         _LIB.orc_np_mean_f32.restype = C.c_float
         _LIB.orc_np_mean_f32.argtypes = [C.c_void_p, C.c_long]
-        for n in ("orc_uniform_quantize", "orc_nonuniform_quantize", "orc_extract_contour"):
+        for n in ("orc_uniform_quantize", "orc_nonuniform_quantize", "orc_extract_contour", "orc_ransac_plane",
+                  "orc_ground_candidates"):
             getattr(_LIB, n).restype = C.c_long
     return _LIB
 
@@ -230,6 +231,30 @@ def recover_map(contour_map, idx_sequence):
 def np_mean_f32(a):
     a = _f32(a).reshape(-1)
     return np.float32(lib().orc_np_mean_f32(_p(a), C.c_long(a.size)))
+
+
+def ransac_plane(pts, ransac_n, iters, thr=0.1, seed=0):
+    """Build-defined seeded RANSAC (NOT Open3D): sequential form of the specification the HIP kernel
+    implements (DESIGN.md "RANSAC").  -> (plane fp64[4], inlier count of the winning hypothesis)."""
+    pts = _f32(pts)
+    plane = np.zeros(4, np.float64)
+    n = lib().orc_ransac_plane(_p(pts), C.c_long(pts.shape[0]), int(ransac_n), int(iters), C.c_double(thr),
+                               C.c_uint32(seed), _p(plane))
+    return plane, int(n)
+
+
+def ground_candidates(ri, tm, zthr=-1.5, max_pts=5000, min_pts=800):
+    """Ground RANSAC input (utils/segment_utils.py:101-106) with the deterministic subsample."""
+    ri, tm = _f32(ri).reshape(-1), _f32(tm)
+    out = np.empty((ri.size, 3), np.float32)
+    m = lib().orc_ground_candidates(_p(ri), _p(tm), C.c_long(ri.size), C.c_float(zthr), C.c_long(max_pts),
+                                    C.c_long(min_pts), _p(out))
+    return out[:m].copy()
+
+
+def ground_model(ri, tm, seed=0):
+    """a4 with the build's seeded RANSAC: candidates -> plane (ransac_n=10, 100 iterations, 0.1 m)."""
+    return ransac_plane(ground_candidates(ri, tm), 10, 100, 0.1, seed)[0]
 
 
 # ------------------------------------------------------------------------------------------------

@@ -487,3 +487,128 @@ uint32_t orc_mix32(uint32_t a, uint32_t b, uint32_t c) {
     h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
     return h;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* RANSAC plane specification (sequential form).  Points are fp32 xyz promoted to fp64.          */
+/* ------------------------------------------------------------------------------------------ */
+#define RS_NT 256 /* number of strided partial sums of the ordered fp64 reduction */
+
+/* ordered fp64 sum of v[0..n): partial[t] = sum_{i = t (mod 256), ascending} v[i]; then a fixed binary
+ * tree partial[t] += partial[t+stride], stride = 128..1.  The HIP kernel uses the same order. */
+static double rs_treesum(const double *v, long n) {
+    double part[RS_NT];
+    for (int t = 0; t < RS_NT; t++) {
+        double s = 0.0;
+        for (long i = t; i < n; i += RS_NT) s += v[i];
+        part[t] = s;
+    }
+    for (int stride = RS_NT / 2; stride >= 1; stride >>= 1)
+        for (int t = 0; t < stride; t++) part[t] += part[t + stride];
+    return part[0];
+}
+
+/* plane through a point set given its centroid and centred second moments: the closed form that
+ * solves for the axis with the largest 2x2 determinant.  Returns 0 when degenerate. */
+static int rs_plane_from_moments(const double c[3], double xx, double xy, double xz, double yy, double yz, double zz,
+                                 double out[4]) {
+    const double det_x = yy * zz - yz * yz, det_y = xx * zz - xz * xz, det_z = xx * yy - xy * xy;
+    double a, b, cc;
+    if (det_x >= det_y && det_x >= det_z) { a = det_x; b = xz * yz - xy * zz; cc = xy * yz - xz * yy; }
+    else if (det_y >= det_z) { a = xz * yz - xy * zz; b = det_y; cc = xy * xz - yz * xx; }
+    else { a = xy * yz - xz * yy; b = xy * xz - yz * xx; cc = det_z; }
+    const double nrm = sqrt((a * a + b * b) + cc * cc);
+    if (!(nrm > 0.0)) return 0;
+    a /= nrm; b /= nrm; cc /= nrm;
+    out[0] = a; out[1] = b; out[2] = cc;
+    out[3] = -((a * c[0] + b * c[1]) + cc * c[2]);
+    return 1;
+}
+
+/* pts: fp32 [n,3].  ransac_n sample size, iters hypotheses, thr inlier distance, seed.
+ * Returns the inlier count of the winning hypothesis; plane[4] fp64 out. */
+long orc_ransac_plane(const float *pts, long n, int ransac_n, int iters, double thr, uint32_t seed, double *plane) {
+    plane[0] = 0; plane[1] = 0; plane[2] = 1; plane[3] = 0;
+    if (n < ransac_n || ransac_n < 3 || ransac_n > 16) return 0;
+    long best_cnt = -1;
+    double best[4] = {0, 0, 1, 0};
+    for (int h = 0; h < iters; h++) {
+        long idx[16];
+        for (int k = 0; k < ransac_n; k++) {
+            uint32_t a = 0;
+            long cand;
+            int dup;
+            do {
+                cand = (long)(orc_mix32(seed, (uint32_t)(h * 16 + k), a++) % (uint32_t)n);
+                dup = 0;
+                for (int j = 0; j < k; j++) dup |= (idx[j] == cand);
+            } while (dup);
+            idx[k] = cand;
+        }
+        double c[3] = {0, 0, 0};
+        for (int k = 0; k < ransac_n; k++) for (int a = 0; a < 3; a++) c[a] += (double)pts[3 * idx[k] + a];
+        for (int a = 0; a < 3; a++) c[a] /= (double)ransac_n;
+        double xx = 0, xy = 0, xz = 0, yy = 0, yz = 0, zz = 0;
+        for (int k = 0; k < ransac_n; k++) {
+            const double rx = (double)pts[3 * idx[k]] - c[0], ry = (double)pts[3 * idx[k] + 1] - c[1],
+                         rz = (double)pts[3 * idx[k] + 2] - c[2];
+            xx += rx * rx; xy += rx * ry; xz += rx * rz; yy += ry * ry; yz += ry * rz; zz += rz * rz;
+        }
+        double pl[4];
+        if (!rs_plane_from_moments(c, xx, xy, xz, yy, yz, zz, pl)) continue;
+        long cnt = 0;
+        for (long i = 0; i < n; i++) {
+            const double dist = fabs(((pl[0] * (double)pts[3 * i] + pl[1] * (double)pts[3 * i + 1]) + pl[2] * (double)pts[3 * i + 2]) + pl[3]);
+            cnt += dist < thr;
+        }
+        if (cnt > best_cnt) { best_cnt = cnt; memcpy(best, pl, sizeof(best)); }
+    }
+    if (best_cnt < 0) return 0;
+    memcpy(plane, best, sizeof(best));
+    if (best_cnt < 3) return best_cnt;
+    /* refit on the inliers of the winner, ordered reductions */
+    double *v = (double *)malloc(sizeof(double) * (size_t)n);
+    unsigned char *in = (unsigned char *)malloc((size_t)n);
+    for (long i = 0; i < n; i++) {
+        const double dist = fabs(((best[0] * (double)pts[3 * i] + best[1] * (double)pts[3 * i + 1]) + best[2] * (double)pts[3 * i + 2]) + best[3]);
+        in[i] = dist < thr;
+    }
+    double c[3];
+    for (int a = 0; a < 3; a++) {
+        for (long i = 0; i < n; i++) v[i] = in[i] ? (double)pts[3 * i + a] : 0.0;
+        c[a] = rs_treesum(v, n) / (double)best_cnt;
+    }
+    double m[6];
+    static const int A[6] = {0, 0, 0, 1, 1, 2}, Bx[6] = {0, 1, 2, 1, 2, 2};
+    for (int q = 0; q < 6; q++) {
+        for (long i = 0; i < n; i++)
+            v[i] = in[i] ? ((double)pts[3 * i + A[q]] - c[A[q]]) * ((double)pts[3 * i + Bx[q]] - c[Bx[q]]) : 0.0;
+        m[q] = rs_treesum(v, n);
+    }
+    double pl[4];
+    if (rs_plane_from_moments(c, m[0], m[1], m[2], m[3], m[4], m[5], pl)) memcpy(plane, pl, sizeof(pl));
+    free(v); free(in);
+    return best_cnt;
+}
+
+/* Ground candidate selection (utils/segment_utils.py:101-106) with the build's deterministic
+ * stand-in for np.random.choice: pixels with z < -1.5 in row-major order; more than max_pts ->
+ * systematic subsample of exactly max_pts (candidate i kept iff floor((i+1)*max/n) > floor(i*max/n));
+ * fewer than min_pts -> every pixel (zeros included).  Writes fp32 xyz, returns the count. */
+long orc_ground_candidates(const float *ri, const float *tm, long P, float zthr, long max_pts, long min_pts, float *out) {
+    long nc = 0;
+    for (long p = 0; p < P; p++) nc += (ri[p] * tm[3 * p + 2] < zthr);
+    long m = 0;
+    if (nc < min_pts) {
+        for (long p = 0; p < P; p++) { out[3 * m] = ri[p] * tm[3 * p]; out[3 * m + 1] = ri[p] * tm[3 * p + 1]; out[3 * m + 2] = ri[p] * tm[3 * p + 2]; m++; }
+        return m;
+    }
+    long i = 0;
+    for (long p = 0; p < P; p++) {
+        if (!(ri[p] * tm[3 * p + 2] < zthr)) continue;
+        int keep = 1;
+        if (nc > max_pts) keep = ((i + 1) * max_pts) / nc > (i * max_pts) / nc;
+        if (keep) { out[3 * m] = ri[p] * tm[3 * p]; out[3 * m + 1] = ri[p] * tm[3 * p + 1]; out[3 * m + 2] = ri[p] * tm[3 * p + 2]; m++; }
+        i++;
+    }
+    return m;
+}

@@ -16,7 +16,7 @@ class Geom(C.Structure):
 
 class BatchIO(C.Structure):
     _fields_ = [("xyz", C.c_void_p), ("offsets", C.c_void_p), ("total", C.c_int64), ("tm", C.c_void_p),
-                ("ground", C.c_void_p), ("ri", C.c_void_p), ("seg", C.c_void_p), ("cen_pix", C.c_void_p),
+                ("ground", C.c_void_p), ("ground_seed", C.c_int64), ("ri", C.c_void_p), ("seg", C.c_void_p), ("cen_pix", C.c_void_p),
                 ("centers", C.c_void_p), ("model", C.c_void_p), ("counts", C.c_void_p), ("q16", C.c_void_p),
                 ("nnz", C.c_void_p), ("info", C.c_void_p)]
 
@@ -32,6 +32,7 @@ _SIGS = {
     "rpcc_version": (C.c_int, []),
     "rpcc_last_error": (C.c_char_p, []),
     "rpcc_project": (C.c_int, [_VP, _VP, _I64, _I, Geom, _VP, _VP, _VP]),
+    "rpcc_ground_ransac": (C.c_int, [_VP, _VP, _I, _I, C.c_uint32, _VP, _VP, _VP]),
     "rpcc_ground_mask": (C.c_int, [_VP, _VP, _VP, _D, _I, _I, _VP, _VP, _VP]),
     "rpcc_fps_xyz": (C.c_int, [_I, _I, _I, _VP, _VP, _VP, _VP]),
     "rpcc_fps_range": (C.c_int, [_VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP]),

@@ -200,6 +200,245 @@ extern "C" int rpcc_project(const float *xyz, const int64_t *offsets, int64_t to
 }
 
 // ================================================================================================
+// a4  ground plane: candidate selection + seeded RANSAC  (utils/segment_utils.py:74-82,101-108)
+// ================================================================================================
+// The reference calls Open3D's segment_plane (random, not vendored, unpinned) on a random subsample.
+// This is the build's own deterministic definition (DESIGN.md "RANSAC"); its sequential form lives in
+// the oracle (orc_ransac_plane / orc_ground_candidates) and the two agree bit for bit:
+//   candidates  pixels with z = ri*tz < zthr in row-major order; more than max_pts -> systematic
+//               subsample of exactly max_pts (candidate i kept iff floor((i+1)*max/n) > floor(i*max/n),
+//               its slot is floor(i*max/n)); fewer than min_pts -> every pixel, zeros included
+//   hypotheses  `iters` samples of `ransac_n` distinct points drawn with a counter-based hash
+//   fit         centroid + centred second moments, largest-determinant closed form, fp64
+//   score       inlier count (|n.p+d| < thr), ties -> lower hypothesis id
+//   refit       the same closed form on the winner's inliers; fp64 sums in a fixed order (256 strided
+//               partials, then a binary tree)
+#define RS_THREADS 1024
+#define RS_NT 256
+#define RS_MAX_LIST 5120
+
+__device__ __forceinline__ uint32_t mix32(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t h = a * 0x9E3779B1u + 0x7F4A7C15u;
+    h ^= b + 0x85EBCA6Bu + (h << 6) + (h >> 2);
+    h *= 0xC2B2AE35u;
+    h ^= c + 0x27D4EB2Fu + (h << 6) + (h >> 2);
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+
+__device__ __forceinline__ bool plane_from_moments(const double c[3], double xx, double xy, double xz, double yy,
+                                                   double yz, double zz, double out[4]) {
+    const double det_x = yy * zz - yz * yz, det_y = xx * zz - xz * xz, det_z = xx * yy - xy * xy;
+    double a, b, cc;
+    if (det_x >= det_y && det_x >= det_z) { a = det_x; b = xz * yz - xy * zz; cc = xy * yz - xz * yy; }
+    else if (det_y >= det_z) { a = xz * yz - xy * zz; b = det_y; cc = xy * xz - yz * xx; }
+    else { a = xy * yz - xz * yy; b = xy * xz - yz * xx; cc = det_z; }
+    const double nrm = sqrt((a * a + b * b) + cc * cc);
+    if (!(nrm > 0.0)) return false;
+    a /= nrm; b /= nrm; cc /= nrm;
+    out[0] = a; out[1] = b; out[2] = cc;
+    out[3] = -((a * c[0] + b * c[1]) + cc * c[2]);
+    return true;
+}
+
+// Point source of one RANSAC problem: a compacted fp32 list in LDS, or every pixel of a range image.
+struct RsPoints {
+    const float *lds;   // [n,3] or nullptr
+    const float *ri;    // frame's range image
+    const float *tm;    // [P,3]
+    int n;
+    int raw;            // ri still holds projection bit patterns (RI_EMPTY = empty pixel)
+    __device__ __forceinline__ void get(int i, double &x, double &y, double &z) const {
+        if (lds) { x = (double)lds[3 * i]; y = (double)lds[3 * i + 1]; z = (double)lds[3 * i + 2]; }
+        else { float r = ri[i]; if (raw && f2u(r) == RI_EMPTY) r = 0.0f; x = (double)(r * tm[3 * i]); y = (double)(r * tm[3 * i + 1]); z = (double)(r * tm[3 * i + 2]); }
+    }
+};
+
+__device__ __forceinline__ double plane_dist(const double pl[4], double x, double y, double z) {
+    return fabs(((pl[0] * x + pl[1] * y) + pl[2] * z) + pl[3]);
+}
+
+// ordered fp64 reduction: thread t < 256 owns partial t; result valid in every thread after return
+__device__ __forceinline__ double rs_treesum(double partial, double *sred) {
+    const int t = threadIdx.x;
+    __syncthreads();
+    if (t < RS_NT) sred[t] = partial;
+    __syncthreads();
+    for (int stride = RS_NT / 2; stride >= 1; stride >>= 1) {
+        if (t < stride) sred[t] += sred[t + stride];
+        __syncthreads();
+    }
+    return sred[0];
+}
+
+// Workgroup-wide RANSAC on `pts`; all RS_THREADS threads call it.  Returns the winner's inlier count.
+__device__ int ransac_plane_wg(const RsPoints &pts, int ransac_n, int iters, double thr, uint32_t seed, double plane[4],
+                               double *sred /* [RS_NT] */, double *swin /* [16*4] */, int *sbest /* [16*2] */) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = pts.n;
+    plane[0] = 0; plane[1] = 0; plane[2] = 1; plane[3] = 0;
+    if (n < ransac_n || ransac_n < 3 || ransac_n > 16) return 0;
+    int best_cnt = -1, best_h = 0x7fffffff;
+    double best[4] = {0, 0, 1, 0};
+    for (int h = wave; h < iters; h += RS_THREADS / 64) {
+        int idx[16];
+        for (int k = 0; k < ransac_n; k++) {
+            uint32_t a = 0;
+            int cand;
+            bool dup;
+            do {
+                cand = (int)(mix32(seed, (uint32_t)(h * 16 + k), a++) % (uint32_t)n);
+                dup = false;
+                for (int j = 0; j < k; j++) dup |= (idx[j] == cand);
+            } while (dup);
+            idx[k] = cand;
+        }
+        double c[3] = {0, 0, 0};
+        for (int k = 0; k < ransac_n; k++) { double x, y, z; pts.get(idx[k], x, y, z); c[0] += x; c[1] += y; c[2] += z; }
+        c[0] /= (double)ransac_n; c[1] /= (double)ransac_n; c[2] /= (double)ransac_n;
+        double xx = 0, xy = 0, xz = 0, yy = 0, yz = 0, zz = 0;
+        for (int k = 0; k < ransac_n; k++) {
+            double x, y, z; pts.get(idx[k], x, y, z);
+            const double rx = x - c[0], ry = y - c[1], rz = z - c[2];
+            xx += rx * rx; xy += rx * ry; xz += rx * rz; yy += ry * ry; yz += ry * rz; zz += rz * rz;
+        }
+        double pl[4];
+        if (!plane_from_moments(c, xx, xy, xz, yy, yz, zz, pl)) continue;  // wave-uniform
+        int cnt = 0;
+        for (int i = lane; i < n; i += 64) { double x, y, z; pts.get(i, x, y, z); cnt += plane_dist(pl, x, y, z) < thr; }
+        cnt = wave_sum_i32(cnt);
+        if (cnt > best_cnt) { best_cnt = cnt; best_h = h; best[0] = pl[0]; best[1] = pl[1]; best[2] = pl[2]; best[3] = pl[3]; }
+    }
+    __syncthreads();
+    if (lane == 0) {
+        sbest[2 * wave] = best_cnt; sbest[2 * wave + 1] = best_h;
+        swin[4 * wave] = best[0]; swin[4 * wave + 1] = best[1]; swin[4 * wave + 2] = best[2]; swin[4 * wave + 3] = best[3];
+    }
+    __syncthreads();
+    int wbest = -1, wcnt = -1, wh = 0x7fffffff;
+    for (int w = 0; w < RS_THREADS / 64; w++) {
+        const int c = sbest[2 * w], hh = sbest[2 * w + 1];
+        if (c > wcnt || (c == wcnt && c >= 0 && hh < wh)) { wcnt = c; wh = hh; wbest = w; }
+    }
+    if (wcnt < 0) return 0;
+    plane[0] = swin[4 * wbest]; plane[1] = swin[4 * wbest + 1]; plane[2] = swin[4 * wbest + 2]; plane[3] = swin[4 * wbest + 3];
+    if (wcnt < 3) return wcnt;
+    const double w0 = plane[0], w1 = plane[1], w2 = plane[2], w3 = plane[3];
+    const double win[4] = {w0, w1, w2, w3};
+    // refit on the winner's inliers
+    double c[3];
+    {
+        double sx = 0, sy = 0, sz = 0;
+        if (tid < RS_NT)
+            for (int i = tid; i < n; i += RS_NT) {
+                double x, y, z; pts.get(i, x, y, z);
+                if (plane_dist(win, x, y, z) < thr) { sx += x; sy += y; sz += z; }
+            }
+        c[0] = rs_treesum(sx, sred) / (double)wcnt;
+        c[1] = rs_treesum(sy, sred) / (double)wcnt;
+        c[2] = rs_treesum(sz, sred) / (double)wcnt;
+    }
+    double m[6] = {0, 0, 0, 0, 0, 0};
+    if (tid < RS_NT)
+        for (int i = tid; i < n; i += RS_NT) {
+            double x, y, z; pts.get(i, x, y, z);
+            if (plane_dist(win, x, y, z) < thr) {
+                const double rx = x - c[0], ry = y - c[1], rz = z - c[2];
+                m[0] += rx * rx; m[1] += rx * ry; m[2] += rx * rz; m[3] += ry * ry; m[4] += ry * rz; m[5] += rz * rz;
+            }
+        }
+    for (int q = 0; q < 6; q++) m[q] = rs_treesum(m[q], sred);
+    double pl[4];
+    if (plane_from_moments(c, m[0], m[1], m[2], m[3], m[4], m[5], pl)) { plane[0] = pl[0]; plane[1] = pl[1]; plane[2] = pl[2]; plane[3] = pl[3]; }
+    return wcnt;
+}
+
+__global__ __launch_bounds__(RS_THREADS) void ground_ransac_kernel(const float *__restrict__ ri_all,
+                                                                   const float *__restrict__ tm, int P, float zthr,
+                                                                   int max_pts, int min_pts, int ransac_n, int iters,
+                                                                   double thr, uint32_t seed0, int raw,
+                                                                   double *__restrict__ ground,
+                                                                   int32_t *__restrict__ ninl) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char rs_smem[];
+    double *sred = reinterpret_cast<double *>(rs_smem);          // [256]
+    double *swin = sred + RS_NT;                                 // [64]
+    int *sbest = reinterpret_cast<int *>(swin + 64);             // [32]
+    int *swave = sbest + 32;                                     // [16]
+    float *list = reinterpret_cast<float *>(swave + 16);         // [max_pts*3]
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *ri = ri_all + (int64_t)b * P;
+    // each wave owns a contiguous run of pixels (rounded up to whole 64-pixel steps)
+    const int per_wave = (((P + 15) / 16) + 63) & ~63;
+    const int w0 = wave * per_wave, w1 = min(P, w0 + per_wave);
+    auto zval = [&](int p) -> float {
+        float r = ri[p];
+        if (raw && f2u(r) == RI_EMPTY) r = 0.0f;  // projection bits not finalised yet
+        return r * tm[3 * p + 2];
+    };
+    int cnt = 0;
+    for (int p0 = w0; p0 < w1; p0 += 64) {
+        const int p = p0 + lane;
+        cnt += __popcll(__ballot(p < w1 && zval(p) < zthr));
+    }
+    if (lane == 0) swave[wave] = cnt;
+    __syncthreads();
+    int nc = 0, base = 0;
+    for (int w = 0; w < 16; w++) { if (w < wave) base += swave[w]; nc += swave[w]; }
+    RsPoints pts;
+    pts.ri = ri; pts.tm = tm; pts.lds = nullptr; pts.n = P; pts.raw = raw;
+    if (nc >= min_pts) {
+        int run = base;
+        for (int p0 = w0; p0 < w1; p0 += 64) {
+            const int p = p0 + lane;
+            const bool c = p < w1 && zval(p) < zthr;
+            const unsigned long long m = __ballot(c);
+            if (c) {
+                const long long i = run + __popcll(m & ((1ull << lane) - 1ull));
+                bool keep = true;
+                long long slot = i;
+                if (nc > max_pts) {
+                    slot = (i * max_pts) / nc;
+                    keep = ((i + 1) * max_pts) / nc > slot;
+                }
+                if (keep) {
+                    float r = ri[p];
+                    if (raw && f2u(r) == RI_EMPTY) r = 0.0f;
+                    list[3 * slot] = r * tm[3 * p]; list[3 * slot + 1] = r * tm[3 * p + 1]; list[3 * slot + 2] = r * tm[3 * p + 2];
+                }
+            }
+            run += __popcll(m);
+        }
+        pts.lds = list;
+        pts.n = nc > max_pts ? max_pts : nc;
+    }
+    __syncthreads();
+    double plane[4];
+    const int inl = ransac_plane_wg(pts, ransac_n, iters, thr, seed0 + (uint32_t)b, plane, sred, swin, sbest);
+    if (tid == 0) {
+        ground[4 * b] = plane[0]; ground[4 * b + 1] = plane[1]; ground[4 * b + 2] = plane[2]; ground[4 * b + 3] = plane[3];
+        if (ninl) ninl[b] = inl;
+    }
+}
+
+static int launch_ground_ransac(const float *ri, const float *tm, int B, int P, uint32_t seed0, bool raw, double *ground,
+                                int32_t *ninl, hipStream_t st) {
+    const int max_pts = 5000, min_pts = 800;
+    const size_t sh = (size_t)RS_NT * 8 + 64 * 8 + 32 * 4 + 16 * 4 + (size_t)max_pts * 3 * 4;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&ground_ransac_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+    ground_ransac_kernel<<<B, RS_THREADS, sh, st>>>(ri, tm, P, -1.5f, max_pts, min_pts, 10, 100, 0.1, seed0, raw ? 1 : 0,
+                                                    ground, ninl);
+    LAUNCH_CHECK();
+    return RPCC_OK;
+}
+
+extern "C" int rpcc_ground_ransac(const float *ri, const float *tm, int B, int P, uint32_t seed, double *ground,
+                                  int32_t *inliers, void *stream) {
+    ARG_TRY(B > 0 && P > 0 && ri && tm && ground);
+    return launch_ground_ransac(ri, tm, B, P, seed, false, ground, inliers, (hipStream_t)stream);
+}
+
+// ================================================================================================
 // a3 + a5  back-projection, vertical ground residual, candidate mask, FPS state init
 //          (dataset/transformer.py:94-101, utils/segment_utils.py:44-47,119-120)
 // ================================================================================================
@@ -948,6 +1187,7 @@ extern "C" int rpcc_compress_batch(const rpcc_batch_io *io, int B, rpcc_geom g, 
     ARG_TRY(io != nullptr && ws != nullptr && B > 0 && M > 0 && M <= RPCC_MAX_CLUSTERS && g.H > 1 && g.W > 0);
     ARG_TRY(io->offsets && io->tm && io->ground && io->ri && io->seg && io->cen_pix && io->centers && io->model &&
             io->counts && io->q16 && io->nnz && io->info);
+    const bool fit_ground = io->ground_seed >= 0;  // >= 0: fit the ground plane here (seed + frame index)
     const int P = g.H * g.W;
     ARG_TRY(P % 4 == 0);
     hipStream_t st = (hipStream_t)stream;
@@ -956,6 +1196,9 @@ extern "C" int rpcc_compress_batch(const rpcc_batch_io *io, int B, rpcc_geom g, 
     float *temp = reinterpret_cast<float *>(reinterpret_cast<char *>(proj_scratch) + ((size_t)B * ((size_t)P + 8)) * 4);
     int rc;
     if ((rc = launch_project(io->xyz, io->offsets, io->total, B, g, io->ri, proj_scratch, st, false))) return rc;
+    if (fit_ground &&
+        (rc = launch_ground_ransac(io->ri, io->tm, B, P, (uint32_t)io->ground_seed, true, io->ground, nullptr, st)))
+        return rc;
     if ((rc = launch_ground_mask(io->ri, io->tm, io->ground, ground_threshold, B, P, temp, io->info, st, true))) return rc;
     float *rays_soa = temp + (size_t)B * P;
     if ((rc = launch_fps_range(io->ri, io->tm, temp, io->info, B, P, M, io->cen_pix, io->centers, rays_soa, st))) return rc;

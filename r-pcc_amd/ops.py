@@ -55,6 +55,16 @@ def project(xyz, offsets, geom, ri=None, scratch=None):
     return ri
 
 
+def ground_ransac(ri, tm, seed=0):
+    """a4: seeded ground-plane RANSAC -> (ground f64 [B,4], inlier counts i32 [B])."""
+    B = ri.shape[0]
+    P = ri[0].numel()
+    ground = torch.empty((B, 4), dtype=torch.float64, device=_dev(ri))
+    inl = torch.empty((B,), dtype=torch.int32, device=_dev(ri))
+    check(_lib.lib().rpcc_ground_ransac(ptr(ri), ptr(tm), B, P, int(seed), ptr(ground), ptr(inl), stream()))
+    return ground, inl
+
+
 def ground_mask(ri, tm, ground, threshold):
     """a3+a5.  -> (temp f32 [B,P], info i32 [B,4] = n_left, first candidate pixel, nnz, 0)."""
     B = ri.shape[0]
@@ -152,10 +162,11 @@ class BatchBuffers:
         self.ws = workspace(B, P, M, device)
 
 
-def compress_batch(xyz, offsets, tm, ground, buf, ground_threshold=0.1, acc=0.04):
-    """Fused a2..a11 for a batch (uniform + FPS + point model), ground models supplied [B,4] f64."""
+def compress_batch(xyz, offsets, tm, ground, buf, ground_threshold=0.1, acc=0.04, ground_seed=-1):
+    """Fused a2..a11 for a batch (uniform + FPS + point model).  ground f64 [B,4]: injected models when
+    ground_seed < 0, otherwise output of the seeded ground RANSAC run inside the call."""
     io = BatchIO(ptr(xyz).value, ptr(offsets).value, int(xyz.shape[0]), ptr(tm).value, ptr(ground).value,
-                 ptr(buf.ri).value, ptr(buf.seg).value, ptr(buf.cen_pix).value, ptr(buf.centers).value,
+                 int(ground_seed), ptr(buf.ri).value, ptr(buf.seg).value, ptr(buf.cen_pix).value, ptr(buf.centers).value,
                  ptr(buf.model).value, ptr(buf.counts).value, ptr(buf.q16).value, ptr(buf.nnz).value,
                  ptr(buf.info).value)
     check(_lib.lib().rpcc_compress_batch(C.byref(io), buf.B, buf.geom, buf.M, float(ground_threshold), float(acc),

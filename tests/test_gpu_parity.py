@@ -330,3 +330,46 @@ def test_fps_tiled_equals_bruteforce(env):
         assert _beq(out[True][0], out[False][0]) and _beq(out[True][1], out[False][1]), (B, N, M)
         if N <= 30000:
             assert np.array_equal(out[False][0][0], orc.fps(pts[0], M))
+
+
+def test_ground_ransac_matches_specification(env):
+    """a4: the seeded ground RANSAC kernel equals the sequential form of its specification (oracle)
+    bit for bit -- >5000 candidates (systematic subsample), 800..5000 (all candidates) and <800
+    (every pixel) -- and the plane is a sensible ground plane."""
+    torch, ops, orc, synth = env["torch"], env["ops"], env["orc"], env["synth"]
+    g, geom, tm = _geom(env, "Velodyne64E_2048")
+    f0 = synth.make_frame(11, g.H, g.W).numpy()
+    f1 = f0[f0[:, 2] > -1.45]                                                    # no ground at all
+    low = np.flatnonzero(f0[:, 2] < -1.5)
+    f2 = np.concatenate([f0[f0[:, 2] >= -1.5], f0[low[:3000]]])                  # ~3000 candidates
+    z = np.load(os.path.join(HERE, "golden", "example_64E.npz"))
+    for frames, name in (([f0, f1, f2], "Velodyne64E_2048"), ([z["xyz"]], "Velodyne64E")):
+        g, geom, tm = _geom(env, name)
+        offs = np.zeros(len(frames) + 1, np.int64)
+        offs[1:] = np.cumsum([f.shape[0] for f in frames])
+        ri = ops.project(_to(env, np.concatenate(frames)), _to(env, offs), geom)
+        ground, inl = ops.ground_ransac(ri, _to(env, tm), seed=40)
+        ground, inl = ground.cpu().numpy(), inl.cpu().numpy()
+        for i, f in enumerate(frames):
+            rio = orc.project(f, g)
+            cand = orc.ground_candidates(rio, tm)
+            pl, n = orc.ransac_plane(cand, 10, 100, 0.1, 40 + i)
+            assert _beq(ground[i], pl), (name, i, ground[i], pl)
+            assert inl[i] == n
+        assert abs(abs(ground[0][2]) - 1) < 0.01 and abs(abs(ground[0][3]) - 1.73) < 0.1
+    # fused entry with the ground fit inside == stage-by-stage with that model injected
+    g, geom, tm = _geom(env, "Velodyne64E_2048")
+    frames = [f0, f2]
+    offs = np.zeros(3, np.int64)
+    offs[1:] = np.cumsum([f.shape[0] for f in frames])
+    buf = ops.BatchBuffers(2, geom, 100, env["dev"])
+    gfit = torch.zeros((2, 4), dtype=torch.float64, device=env["dev"])
+    ops.compress_batch(_to(env, np.concatenate(frames)), _to(env, offs), _to(env, tm), gfit, buf, ground_seed=7)
+    torch.cuda.synchronize()
+    for i, f in enumerate(frames):
+        gm = orc.ground_model(orc.project(f, g), tm, seed=7 + i)
+        assert _beq(gfit[i].cpu().numpy(), gm)
+        o = orc.compress_frame(f, g, tm, gm)
+        n = int(buf.nnz[i])
+        assert np.array_equal(buf.seg[i].cpu().numpy(), o["seg_idx"].astype(np.uint8))
+        assert np.array_equal(buf.q16[i, :n].cpu().numpy(), o["q"].astype(np.int16))
