@@ -98,8 +98,8 @@ void rpcc_fps_force_bruteforce(int on);
  * replaces calc_plane_residual_depth, calc_cluster_residual_radius, concatenate + argmax and the
  * relabel (utils/segment_utils.py:21-23,64-67,127-131,168-169).
  *   seg      dev u8 [B,P] out labels                                                              */
-int rpcc_assign(const float *ri, const float *tm, const double *ground, const float *centers, int B, int P, int M,
-                uint8_t *seg, void *stream);
+int rpcc_assign(const float *ri, const float *tm, const double *ground, const float *centers, int B, int H, int W,
+                int M, uint8_t *seg, void *stream);
 
 /* ---- a8: point model ------------------------------------------------------------------------- *
  * replaces segment_utils_cpp.point_modeling (cpp_modules.cpp:471-518) + the model_param assembly

@@ -37,7 +37,7 @@ _SIGS = {
     "rpcc_fps_xyz": (C.c_int, [_I, _I, _I, _VP, _VP, _VP, _VP]),
     "rpcc_fps_range": (C.c_int, [_VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP]),
     "rpcc_fps_force_bruteforce": (None, [_I]),
-    "rpcc_assign": (C.c_int, [_VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP]),
+    "rpcc_assign": (C.c_int, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP]),
     "rpcc_point_model": (C.c_int, [_VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP]),
     "rpcc_predict_quantize": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _F, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
     "rpcc_workspace_bytes": (C.c_size_t, [_I, _I, _I]),

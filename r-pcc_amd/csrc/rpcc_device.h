@@ -120,6 +120,40 @@ __device__ __forceinline__ int wave_min_i32(int v) {
     return v;
 }
 
+// ---------------------------------------------------------------------------------------------
+// DPP reductions (no LDS crossbar): inclusive scan inside each 16-lane row with row_shr 1/2/4/8, then
+// row_bcast:15 (rows 1,3) and row_bcast:31 (rows 2,3); lane 63 holds the total, read with readlane.
+// `id` is the identity of the operation (lanes without a source keep it).
+// ---------------------------------------------------------------------------------------------
+#define RPCC_DPP(old_, src_, ctrl_, rmask_) __builtin_amdgcn_update_dpp((int)(old_), (int)(src_), ctrl_, rmask_, 0xf, false)
+
+__device__ __forceinline__ float dpp_min_f32(float v) {
+    const int id = 0x7f800000;  // +inf
+#define STEP_(ctrl_, rm_) v = fminf(v, u2f((uint32_t)RPCC_DPP(id, f2u(v), ctrl_, rm_)))
+    STEP_(0x111, 0xf); STEP_(0x112, 0xf); STEP_(0x114, 0xf); STEP_(0x118, 0xf); STEP_(0x142, 0xa); STEP_(0x143, 0xc);
+#undef STEP_
+    return u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(v), 63));
+}
+__device__ __forceinline__ float dpp_max_f32(float v) {
+    const int id = (int)0xff800000;  // -inf
+#define STEP_(ctrl_, rm_) v = fmaxf(v, u2f((uint32_t)RPCC_DPP(id, f2u(v), ctrl_, rm_)))
+    STEP_(0x111, 0xf); STEP_(0x112, 0xf); STEP_(0x114, 0xf); STEP_(0x118, 0xf); STEP_(0x142, 0xa); STEP_(0x143, 0xc);
+#undef STEP_
+    return u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(v), 63));
+}
+__device__ __forceinline__ uint32_t dpp_max_u32(uint32_t v) {
+#define STEP_(ctrl_, rm_) v = max(v, (uint32_t)RPCC_DPP(0, v, ctrl_, rm_))
+    STEP_(0x111, 0xf); STEP_(0x112, 0xf); STEP_(0x114, 0xf); STEP_(0x118, 0xf); STEP_(0x142, 0xa); STEP_(0x143, 0xc);
+#undef STEP_
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ uint32_t dpp_min_u32(uint32_t v) {
+#define STEP_(ctrl_, rm_) v = min(v, (uint32_t)RPCC_DPP(-1, v, ctrl_, rm_))
+    STEP_(0x111, 0xf); STEP_(0x112, 0xf); STEP_(0x114, 0xf); STEP_(0x118, 0xf); STEP_(0x142, 0xa); STEP_(0x143, 0xc);
+#undef STEP_
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // FPS arg-max key: larger squared distance first, then LOWER index (the sequential strict-'>' scan of
 // ops/fps/src/sampling_gpu.cu:67-68 restated as a total order).  value < 0 means "not a candidate".
 __device__ __forceinline__ unsigned long long fps_key(float v, uint32_t idx) {

@@ -839,89 +839,123 @@ extern "C" int rpcc_fps_range(const float *ri, const float *tm, float *temp, con
 // |distance|.  The fp32 radius is sqrtf((dx*dx+dy*dy)+dz*dz); sqrtf is monotone, so the running minimum
 // is tracked on the squared distance and sqrtf is evaluated only when the squared distance strictly
 // improves -- the selected index is identical to evaluating all M square roots (DESIGN.md "assign").
-#define ASSIGN_Q 4  // pixels per thread: one ds_read_b128 of a centre feeds 4 distance evaluations
+// v3: per-tile centre pruning.  A wavefront owns a 4-row x 16-column tile of the range image (compact in
+// 3-D).  With [lo,hi] the bounding box of the tile's non-empty pixels, for every centre k
+//     dmin_k = ((gx*gx)+(gy*gy))+(gz*gz)   g* = per-axis gap to the box      <= computed d2_k(p)
+//     dmax_k = ((fx*fx)+(fy*fy))+(fz*fz)   f* = per-axis farthest distance   >= computed d2_k(p)
+// for every pixel p of the tile (same fp32 operation order as the distance; rounding is monotone).
+// A centre with dmin_k > 1.000002 * min_j dmax_j is farther than the best centre by more than the
+// sqrtf tie window for every pixel, so it can neither win nor tie and is skipped.  The survivors are
+// visited in ascending index order with the two-smallest tracking below -- identical labels.
 __device__ __forceinline__ float next_up_pos(float v) { return u2f(f2u(v) + 1u); }  // v >= 0, finite
 
+#define ASSIGN_TILES_PER_WAVE 4
 __global__ __launch_bounds__(256) void assign_kernel(const float *__restrict__ ri, const float *__restrict__ tm,
                                                      const double *__restrict__ ground,
-                                                     const float *__restrict__ centers, int P, int M,
+                                                     const float *__restrict__ centers, int H, int W, int M,
                                                      uint8_t *__restrict__ seg) {
     extern __shared__ __attribute__((aligned(16))) float4 cen4[];  // [M] (x,y,z,0)
-    const int b = blockIdx.y;
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int P = H * W;
     for (int i = threadIdx.x; i < M; i += blockDim.x) {
         const float *c = centers + ((int64_t)b * M + i) * 3;
         cen4[i] = make_float4(c[0], c[1], c[2], 0.0f);
     }
     __syncthreads();
     const double a = ground[4 * b], bb = ground[4 * b + 1], c = ground[4 * b + 2], d = ground[4 * b + 3];
-    float r[ASSIGN_Q], x[ASSIGN_Q], y[ASSIGN_Q], z[ASSIGN_Q], m1[ASSIGN_Q], m2[ASSIGN_Q];
-    int k1[ASSIGN_Q];
-    double ag[ASSIGN_Q];
-    const int p0 = blockIdx.x * (256 * ASSIGN_Q) + threadIdx.x;
-#pragma unroll
-    for (int q = 0; q < ASSIGN_Q; q++) {
-        const int p = min(p0 + q * 256, P - 1);
-        r[q] = ri[(int64_t)b * P + p];
+    const int tcols = (W + 15) >> 4, ntile = ((H + 3) >> 2) * tcols;
+    const int t0 = (blockIdx.x * 4 + wave) * ASSIGN_TILES_PER_WAVE;
+    for (int t = t0; t < min(t0 + ASSIGN_TILES_PER_WAVE, ntile); t++) {
+        const int row = (t / tcols) * 4 + (lane >> 4), col = (t % tcols) * 16 + (lane & 15);
+        const bool valid = row < H && col < W;
+        const int p = valid ? row * W + col : 0;
+        const float r = valid ? ri[(int64_t)b * P + p] : 0.0f;
         const float tx = tm[3 * p], ty = tm[3 * p + 1], tz = tm[3 * p + 2];
-        const double den = ((double)tx * a + (double)ty * bb) + (double)tz * c;
-        ag[q] = fabs((double)r[q] - (-d / den));
-        x[q] = r[q] * tx; y[q] = r[q] * ty; z[q] = r[q] * tz;
-        m1[q] = __builtin_inff(); m2[q] = __builtin_inff(); k1[q] = -1;
-    }
-    // smallest and second-smallest squared distance (strict '<': first occurrence keeps the index)
-    for (int k = 0; k < M; k++) {
-        const float4 cc = cen4[k];
-#pragma unroll
-        for (int q = 0; q < ASSIGN_Q; q++) {
-            const float dx = x[q] - cc.x, dy = y[q] - cc.y, dz = z[q] - cc.z;
-            const float d2 = (dx * dx + dy * dy) + dz * dz;
-            const bool lt = d2 < m1[q];
-            m2[q] = lt ? m1[q] : fminf(m2[q], d2);
-            k1[q] = lt ? k : k1[q];
-            m1[q] = lt ? d2 : m1[q];
+        const float x = r * tx, y = r * ty, z = r * tz;
+        const bool live = valid && r != 0.0f;
+        if (__ballot(live) == 0ull) {  // nothing but empty pixels
+            if (valid) seg[(int64_t)b * P + p] = 1;
+            continue;
         }
-    }
+        const float inf = __builtin_inff();
+        const float lo0 = dpp_min_f32(live ? x : inf), lo1 = dpp_min_f32(live ? y : inf), lo2 = dpp_min_f32(live ? z : inf);
+        const float hi0 = dpp_max_f32(live ? x : -inf), hi1 = dpp_max_f32(live ? y : -inf), hi2 = dpp_max_f32(live ? z : -inf);
+        // screen the centres: lane handles centres lane, lane+64, ...
+        float my_dmin[4], upper = inf;
 #pragma unroll
-    for (int q = 0; q < ASSIGN_Q; q++) {
-        const int p = p0 + q * 256;
+        for (int rd = 0; rd < 4; rd++) {
+            const int k = rd * 64 + lane;
+            my_dmin[rd] = inf;
+            if (rd * 64 < M && k < M) {
+                const float4 cc = cen4[k];
+                const float g0 = fmaxf(fmaxf(lo0 - cc.x, cc.x - hi0), 0.0f), f0 = fmaxf(fabsf(lo0 - cc.x), fabsf(hi0 - cc.x));
+                const float g1 = fmaxf(fmaxf(lo1 - cc.y, cc.y - hi1), 0.0f), f1 = fmaxf(fabsf(lo1 - cc.y), fabsf(hi1 - cc.y));
+                const float g2 = fmaxf(fmaxf(lo2 - cc.z, cc.z - hi2), 0.0f), f2 = fmaxf(fabsf(lo2 - cc.z), fabsf(hi2 - cc.z));
+                my_dmin[rd] = (g0 * g0 + g1 * g1) + g2 * g2;
+                upper = fminf(upper, (f0 * f0 + f1 * f1) + f2 * f2);
+            }
+        }
+        upper = dpp_min_f32(upper);
+        const float cut = upper * 1.000002f;
+        float m1 = inf, m2 = inf;
+        int k1 = -1;
+#pragma unroll
+        for (int rd = 0; rd < 4; rd++) {
+            if (rd * 64 >= M) break;
+            unsigned long long surv = __ballot(my_dmin[rd] <= cut);
+            while (surv) {
+                const int k = rd * 64 + (int)__ffsll((long long)surv) - 1;
+                surv &= surv - 1ull;
+                const float4 cc = cen4[k];
+                const float dx = x - cc.x, dy = y - cc.y, dz = z - cc.z;
+                const float d2 = (dx * dx + dy * dy) + dz * dz;
+                const bool lt = d2 < m1;
+                m2 = lt ? m1 : fminf(m2, d2);
+                k1 = lt ? k : k1;
+                m1 = lt ? d2 : m1;
+            }
+        }
         int label = 0;
-        if (k1[q] >= 0) {
+        if (k1 >= 0) {
             // radius = sqrtf(min d2).  Every squared distance that rounds to the same radius ties with it,
             // and numpy's argmax keeps the lowest index: U = largest float whose sqrtf equals the radius.
-            const float s = sqrtf(m1[q]);
-            float U = m1[q];
+            const float s = sqrtf(m1);
+            float U = m1;
 #pragma unroll
             for (int j = 0; j < 3; j++) {
                 const float n = next_up_pos(U);
                 if (U < 3.0e38f && sqrtf(n) == s) U = n;
             }
-            int kk = k1[q];
-            if (m2[q] <= U) {  // another centre may tie after the square root (rare): first index with d2 <= U
+            int kk = k1;
+            if (m2 <= U) {  // another centre may tie after the square root (rare): first index with d2 <= U
                 for (int k = 0; k < kk; k++) {
                     const float4 cc = cen4[k];
-                    const float dx = x[q] - cc.x, dy = y[q] - cc.y, dz = z[q] - cc.z;
+                    const float dx = x - cc.x, dy = y - cc.y, dz = z - cc.z;
                     if ((dx * dx + dy * dy) + dz * dz <= U) { kk = k; break; }
                 }
             }
-            if (!(ag[q] != ag[q]) && (double)s < ag[q]) label = kk + 2;  // ground (index 0) wins ties and NaN
+            const double den = ((double)tx * a + (double)ty * bb) + (double)tz * c;
+            const double ag = fabs((double)r - (-d / den));
+            if (!(ag != ag) && (double)s < ag) label = kk + 2;  // ground (index 0) wins ties and NaN
         }
-        if (r[q] == 0.0f) label = 1;
-        if (p < P) seg[(int64_t)b * P + p] = (uint8_t)label;
+        if (r == 0.0f) label = 1;
+        if (valid) seg[(int64_t)b * P + p] = (uint8_t)label;
     }
 }
 
-static int launch_assign(const float *ri, const float *tm, const double *ground, const float *centers, int B, int P,
-                         int M, uint8_t *seg, hipStream_t st) {
-    const dim3 grid((P + 256 * ASSIGN_Q - 1) / (256 * ASSIGN_Q), B);
-    assign_kernel<<<grid, 256, (size_t)M * sizeof(float4), st>>>(ri, tm, ground, centers, P, M, seg);
+static int launch_assign(const float *ri, const float *tm, const double *ground, const float *centers, int B, int H,
+                         int W, int M, uint8_t *seg, hipStream_t st) {
+    const int ntile = ((H + 3) / 4) * ((W + 15) / 16);
+    const dim3 grid((ntile + 4 * ASSIGN_TILES_PER_WAVE - 1) / (4 * ASSIGN_TILES_PER_WAVE), B);
+    assign_kernel<<<grid, 256, (size_t)M * sizeof(float4), st>>>(ri, tm, ground, centers, H, W, M, seg);
     LAUNCH_CHECK();
     return RPCC_OK;
 }
 
-extern "C" int rpcc_assign(const float *ri, const float *tm, const double *ground, const float *centers, int B, int P,
-                           int M, uint8_t *seg, void *stream) {
-    ARG_TRY(B > 0 && P > 0 && M > 0 && M <= RPCC_MAX_CLUSTERS && ri && tm && ground && centers && seg);
-    return launch_assign(ri, tm, ground, centers, B, P, M, seg, (hipStream_t)stream);
+extern "C" int rpcc_assign(const float *ri, const float *tm, const double *ground, const float *centers, int B, int H,
+                           int W, int M, uint8_t *seg, void *stream) {
+    ARG_TRY(B > 0 && H > 0 && W > 0 && M > 0 && M <= RPCC_MAX_CLUSTERS && ri && tm && ground && centers && seg);
+    return launch_assign(ri, tm, ground, centers, B, H, W, M, seg, (hipStream_t)stream);
 }
 
 // ================================================================================================
@@ -1202,7 +1236,7 @@ extern "C" int rpcc_compress_batch(const rpcc_batch_io *io, int B, rpcc_geom g, 
     if ((rc = launch_ground_mask(io->ri, io->tm, io->ground, ground_threshold, B, P, temp, io->info, st, true))) return rc;
     float *rays_soa = temp + (size_t)B * P;
     if ((rc = launch_fps_range(io->ri, io->tm, temp, io->info, B, P, M, io->cen_pix, io->centers, rays_soa, st))) return rc;
-    if ((rc = launch_assign(io->ri, io->tm, io->ground, io->centers, B, P, M, io->seg, st))) return rc;
+    if ((rc = launch_assign(io->ri, io->tm, io->ground, io->centers, B, g.H, g.W, M, io->seg, st))) return rc;
     if ((rc = launch_point_model(io->ri, io->seg, io->ground, B, P, M, io->model, io->counts, io->nnz, ws, st))) return rc;
     return launch_predict_quantize(io->ri, io->tm, io->seg, io->model, acc, B, P, M, io->q16, nullptr, nullptr, ws, st);
 }

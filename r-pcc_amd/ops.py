@@ -104,11 +104,10 @@ def fps_force_bruteforce(on):
 
 
 def assign(ri, tm, ground, centers):
-    B = ri.shape[0]
-    P = ri[0].numel()
+    B, H, W = ri.shape
     M = centers.shape[1]
-    seg = torch.empty((B,) + tuple(ri.shape[1:]), dtype=torch.uint8, device=_dev(ri))
-    check(_lib.lib().rpcc_assign(ptr(ri), ptr(tm), ptr(ground), ptr(centers), B, P, M, ptr(seg), stream()))
+    seg = torch.empty((B, H, W), dtype=torch.uint8, device=_dev(ri))
+    check(_lib.lib().rpcc_assign(ptr(ri), ptr(tm), ptr(ground), ptr(centers), B, H, W, M, ptr(seg), stream()))
     return seg
 
 
