@@ -703,48 +703,75 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_tiled_kernel(const float *__r
         wcount = 0;
     }
 
-    // one tile: distance update against the current centre, tile maximum, (optionally) bounding box
-    auto process_tile = [&](int t, bool with_box) {
+    // A tile's data in registers (loads are issued for a group of tiles before any is consumed, so the
+    // HBM/L2 latency of a round is paid once per group, not once per tile).
+    struct TileRegs { float x, y, z, tp; };
+    auto load_tile = [&](int t, TileRegs &q) {
+        const int p = t * 64 + lane;
+        q.x = 0.f; q.y = 0.f; q.z = 0.f; q.tp = -1.0f;
+        if (p < N) { fps_load_point<RANGE>(src, tx, ty, tz, p, q.x, q.y, q.z); q.tp = temp[p]; }
+    };
+    // distance update against the current centre, tile maximum, (optionally) bounding box
+    auto compute_tile = [&](int t, const TileRegs &q, bool with_box) {
         const int p = t * 64 + lane;
         const bool valid = p < N;
-        float x = 0.f, y = 0.f, z = 0.f, tp = -1.0f;
-        if (valid) { fps_load_point<RANGE>(src, tx, ty, tz, p, x, y, z); tp = temp[p]; }
         if (with_box) {
-            const bool cand = tp >= 0.0f;
-            const float big = 3.0e38f;
-            const float l0 = wave_min_f32(cand ? x : big), l1 = wave_min_f32(cand ? y : big), l2 = wave_min_f32(cand ? z : big);
-            const float h0 = wave_max_f32(cand ? x : -big), h1 = wave_max_f32(cand ? y : -big), h2 = wave_max_f32(cand ? z : -big);
+            const bool cand = q.tp >= 0.0f;
+            const float inf = __builtin_inff();
+            const float l0 = dpp_min_f32(cand ? q.x : inf), l1 = dpp_min_f32(cand ? q.y : inf), l2 = dpp_min_f32(cand ? q.z : inf);
+            const float h0 = dpp_max_f32(cand ? q.x : -inf), h1 = dpp_max_f32(cand ? q.y : -inf), h2 = dpp_max_f32(cand ? q.z : -inf);
             if (lane == 0) { L.lo[0][t] = l0; L.lo[1][t] = l1; L.lo[2][t] = l2; L.hi[0][t] = h0; L.hi[1][t] = h1; L.hi[2][t] = h2; }
         }
-        const float dx = x - c0, dy = y - c1, dz = z - c2;
+        const float dx = q.x - c0, dy = q.y - c1, dz = q.z - c2;
         const float d = (dx * dx + dy * dy) + dz * dz;  // sampling_gpu.cu:64, un-fused
-        const float nt = fminf(d, tp);
-        if (valid && nt != tp) temp[p] = nt;
-        const unsigned long long k = wave_max_u64(fps_key(valid ? nt : -1.0f, (uint32_t)p));
-        const int wl = (int)fps_key_index(k) - t * 64;
-        const float wx = __shfl(x, wl, 64), wy = __shfl(y, wl, 64), wz = __shfl(z, wl, 64), wt = __shfl(nt, wl, 64);
-        if (lane == 0) { L.tmax[t] = wt; L.targ[t] = fps_key_index(k); L.cx[0][t] = wx; L.cx[1][t] = wy; L.cx[2][t] = wz; }
+        const float nt = fminf(d, q.tp);
+        if (valid && nt != q.tp) temp[p] = nt;
+        // tile arg-max: largest value, lowest lane (= lowest index) among equals
+        const uint32_t ord = (!valid || nt < 0.0f) ? 0u : f2u(nt) + 1u;
+        const uint32_t vmax = dpp_max_u32(ord);
+        const int wl = __builtin_amdgcn_readfirstlane((int)__ffsll((long long)__ballot(ord == vmax)) - 1);
+        const float wt = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(nt), wl));
+        const float wx = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(q.x), wl));
+        const float wy = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(q.y), wl));
+        const float wz = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(q.z), wl));
+        if (lane == 0) {
+            L.tmax[t] = (vmax == 0u) ? -1.0f : wt;
+            L.targ[t] = (uint32_t)(t * 64 + wl);
+            L.cx[0][t] = wx; L.cx[1][t] = wy; L.cx[2][t] = wz;
+        }
     };
 
     // arg-max over the tile table -> next centre (index and coordinates)
     auto select_next = [&]() {
-        unsigned long long k = 0ull;
+        uint32_t hi = 0u, ix = 0xFFFFFFFFu;  // orderable value, index
         for (int t = tid; t < T; t += FPS_THREADS) {
-            const unsigned long long kk = fps_key(L.tmax[t], L.targ[t]);
-            k = kk > k ? kk : k;
+            const float v = L.tmax[t];
+            const uint32_t h = (v < 0.0f) ? 0u : f2u(v) + 1u, i = L.targ[t];
+            if (h > hi || (h == hi && i < ix)) { hi = h; ix = i; }
         }
-        k = wave_max_u64(k);
-        if (lane == 0) red[wave] = k;
+        uint32_t vmax = dpp_max_u32(hi);
+        uint32_t imin = dpp_min_u32(hi == vmax ? ix : 0xFFFFFFFFu);
+        if (lane == 0) red[wave] = ((unsigned long long)vmax << 32) | imin;
         __syncthreads();
-        k = wave_max_u64(red[lane & 15]);
-        old = (int)fps_key_index(k);
+        const unsigned long long k = red[lane & 15];
+        hi = (uint32_t)(k >> 32); ix = (uint32_t)k;
+        vmax = dpp_max_u32(hi);
+        imin = dpp_min_u32(hi == vmax ? ix : 0xFFFFFFFFu);
+        old = (imin == 0xFFFFFFFFu) ? 0 : (int)imin;
         const int t = old >> 6;
         c0 = L.cx[0][t]; c1 = L.cx[1][t]; c2 = L.cx[2][t];
     };
 
+    constexpr int NW = FPS_THREADS / 64, GROUP = 4;
     // first centre: every tile is visited once (also builds the boxes)
     if (M > 1) {
-        for (int t = wave; t < T; t += FPS_THREADS / 64) process_tile(t, true);
+        for (int t = wave; t < T; t += NW * GROUP) {
+            TileRegs q[GROUP];
+#pragma unroll
+            for (int g = 0; g < GROUP; g++) if (t + g * NW < T) load_tile(t + g * NW, q[g]);
+#pragma unroll
+            for (int g = 0; g < GROUP; g++) if (t + g * NW < T) compute_tile(t + g * NW, q[g], true);
+        }
         __syncthreads();
         select_next();
         if (tid == 0) { out_idx[1] = old; if (out_cen) { out_cen[3] = c0; out_cen[4] = c1; out_cen[5] = c2; } }
@@ -767,7 +794,14 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_tiled_kernel(const float *__r
         }
         __syncthreads();
         const int n = wcount;
-        for (int e = wave; e < n; e += FPS_THREADS / 64) process_tile((int)L.work[e], false);
+        for (int e = wave; e < n; e += NW * GROUP) {
+            TileRegs q[GROUP];
+            int tt[GROUP];
+#pragma unroll
+            for (int g = 0; g < GROUP; g++) if (e + g * NW < n) { tt[g] = (int)L.work[e + g * NW]; load_tile(tt[g], q[g]); }
+#pragma unroll
+            for (int g = 0; g < GROUP; g++) if (e + g * NW < n) compute_tile(tt[g], q[g], false);
+        }
         __syncthreads();
         if (tid == 0) wcount = 0;
         select_next();
