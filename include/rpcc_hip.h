@@ -43,11 +43,14 @@ typedef struct rpcc_geom {
  *   offsets  dev i64 [B+1]       frame b owns points offsets[b]..offsets[b+1]
  *   total    host                offsets[B]
  *   ri       dev f32 [B,P]  out  min positive depth per pixel, 0 where empty
- *   scratch  dev i32 [B,P+8]     work buffer (contents undefined on return)
+ *   scratch  dev, scratch_bytes  work buffer (contents undefined on return).  With
+ *            rpcc_project_scratch_bytes(total,B,P) bytes the LDS-band path runs; with at least
+ *            B*(P+8)*4 bytes the device-atomic path runs (same result).
  * Exact reference semantics incl. a depth-0 point resetting its pixel in input order.  Points
  * whose depth is not finite are skipped (reference: undefined behaviour). */
+size_t rpcc_project_scratch_bytes(int64_t total, int B, int P);
 int rpcc_project(const float *xyz, const int64_t *offsets, int64_t total, int B, rpcc_geom g, float *ri,
-                 int32_t *scratch, void *stream);
+                 void *scratch, size_t scratch_bytes, void *stream);
 
 /* ---- a4: ground plane ----------------------------------------------------------------------- *
  * replaces the ground branch of PointCloudSegment.segment: candidate selection + RANSAC
@@ -145,7 +148,7 @@ typedef struct rpcc_batch_io {
     int32_t *info;           /* dev i32 [B,4] out */
 } rpcc_batch_io;
 
-size_t rpcc_workspace_bytes(int B, int P, int M);
+size_t rpcc_workspace_bytes(int B, int P, int M, int64_t total_points);
 int rpcc_compress_batch(const rpcc_batch_io *io, int B, rpcc_geom g, int M, double ground_threshold, float acc,
                         void *ws, void *stream);
 

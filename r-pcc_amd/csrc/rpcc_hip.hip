@@ -111,32 +111,36 @@ __device__ __forceinline__ int find_frame(const int64_t *__restrict__ offs, int 
     return lo;
 }
 
-// MODE 0: min-depth pass, records frames that hold a depth-0 point.
+// MODE 0: min-depth pass over every frame, records frames that hold a depth-0 point.
+// MODE 3: MODE 0 restricted to flagged frames.
 // MODE 1: for flagged frames, last input position of a depth-0 point per pixel.
 // MODE 2: for flagged frames, min-depth pass restricted to points after that position.
+// Grid-stride; the flagged-only modes leave at once when no frame of the batch is flagged (flags[B]).
 template <int MODE>
 __global__ __launch_bounds__(256) void project_kernel(const float *__restrict__ xyz, const int64_t *__restrict__ offs,
                                                       int64_t total, int B, rpcc_geom g, uint32_t *__restrict__ ri,
                                                       int32_t *__restrict__ lastz, int32_t *__restrict__ flags) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
     if (MODE != 0 && flags[B] == 0) return;  // no frame of this batch holds a depth-0 point
-    // one binary search per wavefront (first active lane); lanes beyond that frame's end search again
-    int b = __builtin_amdgcn_readfirstlane(find_frame(offs, B, __shfl(i, __ffsll((long long)__ballot(1)) - 1, 64)));
-    if (i >= offs[b + 1]) b = find_frame(offs, B, i);
-    if (MODE != 0 && flags[b] == 0) return;
-    const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
-    const RowCol rc = project_point(x, y, z, g);
-    if (!(fabsf(rc.depth) <= 3.402823466e+38f)) return;  // NaN / inf depth: skipped (reference: UB)
     const int64_t P = (int64_t)g.H * g.W;
-    const int32_t pos = (int32_t)(i - offs[b]) + 1;
-    if (MODE == 0) {
-        if (rc.depth == 0.0f) { flags[b] = 1; flags[B] = 1; return; }
-        atomicMin(&ri[b * P + rc.pix], f2u(rc.depth));
-    } else if (MODE == 1) {
-        if (rc.depth == 0.0f) atomicMax(&lastz[b * P + rc.pix], pos);
-    } else {
-        if (rc.depth != 0.0f && pos > lastz[b * P + rc.pix]) atomicMin(&ri[b * P + rc.pix], f2u(rc.depth));
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        // one binary search per wavefront (first active lane); lanes beyond that frame's end search again
+        int b = __builtin_amdgcn_readfirstlane(find_frame(offs, B, __shfl(i, __ffsll((long long)__ballot(1)) - 1, 64)));
+        if (i >= offs[b + 1]) b = find_frame(offs, B, i);
+        if (MODE != 0 && flags[b] == 0) continue;
+        const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+        const RowCol rc = project_point(x, y, z, g);
+        if (!(fabsf(rc.depth) <= 3.402823466e+38f)) continue;  // NaN / inf depth: skipped (reference: UB)
+        const int32_t pos = (int32_t)(i - offs[b]) + 1;
+        if (MODE == 0) {
+            if (rc.depth == 0.0f) { flags[b] = 1; flags[B] = 1; continue; }
+            atomicMin(&ri[b * P + rc.pix], f2u(rc.depth));
+        } else if (MODE == 3) {
+            if (rc.depth != 0.0f) atomicMin(&ri[b * P + rc.pix], f2u(rc.depth));
+        } else if (MODE == 1) {
+            if (rc.depth == 0.0f) atomicMax(&lastz[b * P + rc.pix], pos);
+        } else {
+            if (rc.depth != 0.0f && pos > lastz[b * P + rc.pix]) atomicMin(&ri[b * P + rc.pix], f2u(rc.depth));
+        }
     }
 }
 
@@ -158,45 +162,125 @@ __global__ __launch_bounds__(256) void project_fill_kernel(uint32_t *__restrict_
     }
 }
 
-__global__ __launch_bounds__(256) void project_finalize_kernel(uint32_t *__restrict__ ri, int64_t n) {
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x)
-        if (ri[p] == RI_EMPTY) ri[p] = 0u;
+// RI_EMPTY -> 0.  FLAGGED: only frames with flags[b] set (the others are already final).
+template <bool FLAGGED>
+__global__ __launch_bounds__(256) void project_finalize_kernel(uint32_t *__restrict__ ri, int P,
+                                                               const int32_t *__restrict__ flags) {
+    const int b = blockIdx.y;
+    if (FLAGGED && flags[b] == 0) return;
+    const int64_t base = (int64_t)b * P;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x)
+        if (ri[base + p] == RI_EMPTY) ri[base + p] = 0u;
 }
 
+// ---- fast path: (pixel, depth) list + per-band minimum in LDS ----------------------------------------
+// Device-scope atomics on a 134 MB image cost one fabric transaction per point.  Instead every point
+// is projected once into an 8-byte (pixel, depth bits) record, and one workgroup per (frame, band of
+// BAND_PX pixels) takes the minimum of its band in LDS (ds_min_u32) while streaming the frame's records
+// from L2 / Infinity Cache.  Frames that contain a depth-0 point are left to the exact input-order
+// passes above.
+#define BAND_PX 32768  // 128 KiB of LDS
+#define BAND_THREADS 1024
+
+__global__ __launch_bounds__(256) void project_pix_kernel(const float *__restrict__ xyz, const int64_t *__restrict__ offs,
+                                                          int64_t total, int B, rpcc_geom g, uint2 *__restrict__ pd,
+                                                          int32_t *__restrict__ flags) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+    const RowCol rc = project_point(x, y, z, g);
+    uint2 o = make_uint2(0xFFFFFFFFu, 0u);
+    if (fabsf(rc.depth) <= 3.402823466e+38f) {
+        if (rc.depth == 0.0f) {
+            int b = find_frame(offs, B, i);
+            flags[b] = 1; flags[B] = 1;
+        } else {
+            o = make_uint2((uint32_t)rc.pix, f2u(rc.depth));
+        }
+    }
+    pd[i] = o;
+}
+
+__global__ __launch_bounds__(BAND_THREADS) void project_band_kernel(const uint2 *__restrict__ pd,
+                                                                    const int64_t *__restrict__ offs, int P,
+                                                                    uint32_t *__restrict__ ri,
+                                                                    const int32_t *__restrict__ flags) {
+    extern __shared__ uint32_t band[];  // [BAND_PX]
+    const int b = blockIdx.y;
+    if (flags[b]) return;
+    const uint32_t band0 = blockIdx.x * BAND_PX;
+    const uint32_t npx = min((uint32_t)BAND_PX, (uint32_t)P - band0);
+    for (uint32_t p = threadIdx.x; p < npx; p += BAND_THREADS) band[p] = RI_EMPTY;
+    __syncthreads();
+    const int64_t n0 = offs[b], n1 = offs[b + 1];
+    for (int64_t i = n0 + threadIdx.x; i < n1; i += BAND_THREADS) {
+        const uint2 v = pd[i];
+        const uint32_t rel = v.x - band0;  // skipped records (0xFFFFFFFF) fall outside every band
+        if (rel < npx) atomicMin(&band[rel], v.y);
+    }
+    __syncthreads();
+    uint32_t *out = ri + (int64_t)b * P + band0;
+    for (uint32_t p = threadIdx.x; p < npx; p += BAND_THREADS) {
+        const uint32_t v = band[p];
+        out[p] = (v == RI_EMPTY) ? 0u : v;
+    }
+}
+
+static size_t project_scratch_bytes(int64_t total, int B, int P) {
+    return ((size_t)B * ((size_t)P + 8)) * 4 + 256 + (size_t)(total > 0 ? total : 0) * 8;
+}
+extern "C" size_t rpcc_project_scratch_bytes(int64_t total, int B, int P) { return project_scratch_bytes(total, B, P); }
+
+// On return ri is final (0 = empty pixel).  scratch_bytes < rpcc_project_scratch_bytes() selects the
+// atomic path, which only needs B*(P+8)*4 bytes.
 static int launch_project(const float *xyz, const int64_t *offsets, int64_t total, int B, rpcc_geom g, float *ri,
-                          int32_t *scratch, hipStream_t st, bool finalize) {
+                          void *scratch, size_t scratch_bytes, hipStream_t st) {
     const int P = g.H * g.W;
     uint32_t *rb = reinterpret_cast<uint32_t *>(ri);
-    int32_t *lastz = scratch;
-    int32_t *flags = scratch + (int64_t)B * P;
+    int32_t *lastz = reinterpret_cast<int32_t *>(scratch);
+    int32_t *flags = lastz + (int64_t)B * P;
     const dim3 fg((P + 1023) / 1024 < 64 ? (P + 1023) / 1024 : 64, B);
+    const unsigned nb = (unsigned)((total + 255) / 256);
+    const unsigned nb_small = nb < 2048 ? (nb ? nb : 1) : 2048;
+    const bool fast = scratch_bytes >= project_scratch_bytes(total, B, P);
+    if (fast) {
+        uint2 *pd = reinterpret_cast<uint2 *>(reinterpret_cast<char *>(scratch) + ((size_t)B * ((size_t)P + 8)) * 4 + 256);
+        HIP_TRY(hipMemsetAsync(flags, 0, (size_t)(B + 1) * 4, st));
+        if (total > 0) project_pix_kernel<<<nb, 256, 0, st>>>(xyz, offsets, total, B, g, pd, flags);
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&project_band_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, BAND_PX * 4));
+        project_band_kernel<<<dim3((P + BAND_PX - 1) / BAND_PX, B), BAND_THREADS, BAND_PX * 4, st>>>(pd, offsets, P, rb, flags);
+        LAUNCH_CHECK();
+        if (total > 0) {  // exact input-order semantics for frames with depth-0 points: no-ops otherwise
+            project_fill_kernel<true><<<fg, 256, 0, st>>>(rb, lastz, flags, P);
+            project_kernel<1><<<nb_small, 256, 0, st>>>(xyz, offsets, total, B, g, rb, lastz, flags);
+            project_kernel<2><<<nb_small, 256, 0, st>>>(xyz, offsets, total, B, g, rb, lastz, flags);
+            project_finalize_kernel<true><<<fg, 256, 0, st>>>(rb, P, flags);
+            LAUNCH_CHECK();
+        }
+        return RPCC_OK;
+    }
     project_fill_kernel<false><<<fg, 256, 0, st>>>(rb, lastz, flags, P);
     LAUNCH_CHECK();
     if (total > 0) {
-        const unsigned nb = (unsigned)((total + 255) / 256);
         project_kernel<0><<<nb, 256, 0, st>>>(xyz, offsets, total, B, g, rb, lastz, flags);
-        LAUNCH_CHECK();
-        // exact input-order semantics for frames that contain depth-0 points (rare): three more
-        // passes that return immediately for every other frame
         project_fill_kernel<true><<<fg, 256, 0, st>>>(rb, lastz, flags, P);
-        project_kernel<1><<<nb, 256, 0, st>>>(xyz, offsets, total, B, g, rb, lastz, flags);
-        project_kernel<2><<<nb, 256, 0, st>>>(xyz, offsets, total, B, g, rb, lastz, flags);
+        project_kernel<1><<<nb_small, 256, 0, st>>>(xyz, offsets, total, B, g, rb, lastz, flags);
+        project_kernel<2><<<nb_small, 256, 0, st>>>(xyz, offsets, total, B, g, rb, lastz, flags);
         LAUNCH_CHECK();
     }
-    if (finalize) {
-        const int64_t n = (int64_t)B * P;
-        project_finalize_kernel<<<(unsigned)((n + 1023) / 1024 < 2048 ? (n + 1023) / 1024 : 2048), 256, 0, st>>>(rb, n);
-        LAUNCH_CHECK();
-    }
+    project_finalize_kernel<false><<<fg, 256, 0, st>>>(rb, P, flags);
+    LAUNCH_CHECK();
     return RPCC_OK;
 }
 
 extern "C" int rpcc_project(const float *xyz, const int64_t *offsets, int64_t total, int B, rpcc_geom g, float *ri,
-                            int32_t *scratch, void *stream) {
+                            void *scratch, size_t scratch_bytes, void *stream) {
     ARG_TRY(B > 0 && g.H > 1 && g.W > 0 && total >= 0);
     ARG_TRY(ri != nullptr && scratch != nullptr && offsets != nullptr);
     ARG_TRY(total == 0 || xyz != nullptr);
-    return launch_project(xyz, offsets, total, B, g, ri, scratch, (hipStream_t)stream, true);
+    ARG_TRY(scratch_bytes >= ((size_t)B * ((size_t)g.H * g.W + 8)) * 4);
+    return launch_project(xyz, offsets, total, B, g, ri, scratch, scratch_bytes, (hipStream_t)stream);
 }
 
 // ================================================================================================
@@ -1022,10 +1106,10 @@ static WsLayout ws_layout(void *ws, int B, int P, int M) {
     L.bytes = off;
     return L;
 }
-extern "C" size_t rpcc_workspace_bytes(int B, int P, int M) {
+extern "C" size_t rpcc_workspace_bytes(int B, int P, int M, int64_t total_points) {
     if (B <= 0 || P <= 0 || M <= 0) return 0;
     const size_t model_ws = ws_layout(nullptr, B, P, M).bytes;
-    const size_t proj_ws = ((size_t)B * ((size_t)P + 8)) * 4;  // projection scratch, carved after the model part
+    const size_t proj_ws = (project_scratch_bytes(total_points, B, P) + 255) & ~(size_t)255;  // carved after the model part
     return model_ws + 256 + proj_ws + (size_t)B * P * 4        // + FPS temp [B,P] f32
            + (size_t)3 * P * 4 + 256;                           // + SoA copy of the ray table
 }
@@ -1260,14 +1344,15 @@ extern "C" int rpcc_compress_batch(const rpcc_batch_io *io, int B, rpcc_geom g, 
     ARG_TRY(P % 4 == 0);
     hipStream_t st = (hipStream_t)stream;
     WsLayout L = ws_layout(ws, B, P, M);
-    int32_t *proj_scratch = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(ws) + L.bytes + 256);
-    float *temp = reinterpret_cast<float *>(reinterpret_cast<char *>(proj_scratch) + ((size_t)B * ((size_t)P + 8)) * 4);
+    char *proj_scratch = reinterpret_cast<char *>(ws) + L.bytes + 256;
+    const size_t proj_bytes = (project_scratch_bytes(io->total, B, P) + 255) & ~(size_t)255;
+    float *temp = reinterpret_cast<float *>(proj_scratch + proj_bytes);
     int rc;
-    if ((rc = launch_project(io->xyz, io->offsets, io->total, B, g, io->ri, proj_scratch, st, false))) return rc;
+    if ((rc = launch_project(io->xyz, io->offsets, io->total, B, g, io->ri, proj_scratch, proj_bytes, st))) return rc;
     if (fit_ground &&
-        (rc = launch_ground_ransac(io->ri, io->tm, B, P, (uint32_t)io->ground_seed, true, io->ground, nullptr, st)))
+        (rc = launch_ground_ransac(io->ri, io->tm, B, P, (uint32_t)io->ground_seed, false, io->ground, nullptr, st)))
         return rc;
-    if ((rc = launch_ground_mask(io->ri, io->tm, io->ground, ground_threshold, B, P, temp, io->info, st, true))) return rc;
+    if ((rc = launch_ground_mask(io->ri, io->tm, io->ground, ground_threshold, B, P, temp, io->info, st, false))) return rc;
     float *rays_soa = temp + (size_t)B * P;
     if ((rc = launch_fps_range(io->ri, io->tm, temp, io->info, B, P, M, io->cen_pix, io->centers, rays_soa, st))) return rc;
     if ((rc = launch_assign(io->ri, io->tm, io->ground, io->centers, B, g.H, g.W, M, io->seg, st))) return rc;

@@ -41,17 +41,20 @@ def _dev(t):
     return t.device
 
 
-def project(xyz, offsets, geom, ri=None, scratch=None):
-    """a2 batched.  xyz f32 [total,3], offsets i64 [B+1] (device) -> ri f32 [B,H,W]."""
+def project(xyz, offsets, geom, ri=None, scratch=None, atomic_path=False):
+    """a2 batched.  xyz f32 [total,3], offsets i64 [B+1] (device) -> ri f32 [B,H,W].
+    atomic_path=True gives the library only the small scratch, which selects the device-atomic kernels
+    (same result as the default LDS-band kernels)."""
     B = offsets.numel() - 1
     P = geom.H * geom.W
     xyz = xyz.contiguous()
     if ri is None:
         ri = torch.empty((B, geom.H, geom.W), dtype=torch.float32, device=_dev(offsets))
     if scratch is None:
-        scratch = torch.empty((B, P + 8), dtype=torch.int32, device=_dev(offsets))
+        n = B * (P + 8) * 4 if atomic_path else _lib.lib().rpcc_project_scratch_bytes(xyz.shape[0], B, P)
+        scratch = torch.empty(n, dtype=torch.uint8, device=_dev(offsets))
     check(_lib.lib().rpcc_project(ptr(xyz) if xyz.numel() else None, ptr(offsets), xyz.shape[0], B, geom, ptr(ri),
-                                  ptr(scratch), stream()))
+                                  ptr(scratch), scratch.numel() * scratch.element_size(), stream()))
     return ri
 
 
@@ -111,8 +114,8 @@ def assign(ri, tm, ground, centers):
     return seg
 
 
-def workspace(B, P, M, device):
-    n = _lib.lib().rpcc_workspace_bytes(B, P, M)
+def workspace(B, P, M, device, total_points=0):
+    n = _lib.lib().rpcc_workspace_bytes(B, P, M, int(total_points))
     return torch.empty((n + 255) // 256 * 256, dtype=torch.uint8, device=device)
 
 
@@ -144,7 +147,7 @@ def predict_quantize(ri, tm, seg, model, acc, M, want_pred=False, int16=False, w
 class BatchBuffers:
     """Device buffers of one batch (B frames, one geometry), allocated once and reused."""
 
-    def __init__(self, B, geom, M, device):
+    def __init__(self, B, geom, M, device, max_points=None):
         P = geom.H * geom.W
         K = M + 2
         self.B, self.P, self.M, self.K, self.geom = B, P, M, K, geom
@@ -158,12 +161,17 @@ class BatchBuffers:
         self.q16 = torch.empty((B, P), dtype=torch.int16, device=device)
         self.nnz = torch.empty((B,), dtype=i32, device=device)
         self.info = torch.empty((B, 4), dtype=i32, device=device)
-        self.ws = workspace(B, P, M, device)
+        # max_points: capacity (sum of N over the batch) for the projection's record list; default 2 per pixel
+        self.max_points = int(max_points) if max_points is not None else 2 * B * P
+        self.ws = workspace(B, P, M, device, self.max_points)
 
 
 def compress_batch(xyz, offsets, tm, ground, buf, ground_threshold=0.1, acc=0.04, ground_seed=-1):
     """Fused a2..a11 for a batch (uniform + FPS + point model).  ground f64 [B,4]: injected models when
     ground_seed < 0, otherwise output of the seeded ground RANSAC run inside the call."""
+    if xyz.shape[0] > buf.max_points:
+        buf.max_points = int(xyz.shape[0])
+        buf.ws = workspace(buf.B, buf.P, buf.M, xyz.device, buf.max_points)
     io = BatchIO(ptr(xyz).value, ptr(offsets).value, int(xyz.shape[0]), ptr(tm).value, ptr(ground).value,
                  int(ground_seed), ptr(buf.ri).value, ptr(buf.seg).value, ptr(buf.cen_pix).value, ptr(buf.centers).value,
                  ptr(buf.model).value, ptr(buf.counts).value, ptr(buf.q16).value, ptr(buf.nnz).value,

@@ -30,8 +30,8 @@ def test_header_symbols_exported(built):
 def test_version_and_workspace(built):
     lib = built.lib()
     assert lib.rpcc_version() >= 100
-    assert lib.rpcc_workspace_bytes(256, 64 * 2048, 100) > 0
-    assert lib.rpcc_workspace_bytes(0, 64 * 2048, 100) == 0
+    assert lib.rpcc_workspace_bytes(256, 64 * 2048, 100, 0) > 0
+    assert lib.rpcc_workspace_bytes(0, 64 * 2048, 100, 0) == 0
 
 
 def test_argument_errors_do_not_crash(built):

@@ -131,16 +131,25 @@ def test_projection_edge_cases(env):
     frames = [a, b, c, d, b[::-1].copy()]
     offs = np.zeros(len(frames) + 1, np.int64)
     offs[1:] = np.cumsum([f.shape[0] for f in frames])
-    ri = ops.project(_to(env, np.concatenate(frames)), _to(env, offs), geom).cpu().numpy()
-    for i, f in enumerate(frames):
-        assert _beq(ri[i], orc.project(f, g)), i
-    assert not _beq(ri[1], ri[4])                                 # input order matters with depth-0 points
+    for atomic in (False, True):                                  # LDS-band path and device-atomic path
+        ri = ops.project(_to(env, np.concatenate(frames)), _to(env, offs), geom, atomic_path=atomic).cpu().numpy()
+        for i, f in enumerate(frames):
+            assert _beq(ri[i], orc.project(f, g)), (atomic, i)
+        assert not _beq(ri[1], ri[4])                             # input order matters with depth-0 points
     # non-finite points are skipped (documented deviation: the reference is undefined there)
     e = a[:1000].copy()
     e[5] = [np.nan, 1, 1]; e[6] = [np.inf, 1, 1]; e[7] = [1e30, 1e30, 0]
     keep = np.ones(1000, bool); keep[[5, 6, 7]] = False
-    ri_e = ops.project(_to(env, e), _to(env, np.array([0, 1000], np.int64)), geom).cpu().numpy()
-    assert _beq(ri_e[0], orc.project(e[keep], g))
+    for atomic in (False, True):
+        ri_e = ops.project(_to(env, e), _to(env, np.array([0, 1000], np.int64)), geom, atomic_path=atomic).cpu().numpy()
+        assert _beq(ri_e[0], orc.project(e[keep], g))
+    # a geometry whose image is not a whole number of LDS bands, real data with many pixel collisions
+    z = np.load(os.path.join(HERE, "golden", "example_64E.npz"))
+    g32, geom32, _ = _geom(env, "Velodyne32E")
+    for atomic in (False, True):
+        r = ops.project(_to(env, z["xyz"]), _to(env, np.array([0, z["xyz"].shape[0]], np.int64)), geom32,
+                        atomic_path=atomic).cpu().numpy()
+        assert _beq(r[0], orc.project(z["xyz"], g32))
 
 
 def test_fps_xyz_operator(env):
