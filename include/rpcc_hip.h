@@ -72,9 +72,14 @@ int rpcc_ground_ransac(const float *ri, const float *tm, int B, int P, uint32_t 
  *   tm       dev f32 [P,3]       transform_map (dataset/transformer.py:41-54)
  *   ground   dev f64 [B,4]       plane a,b,c,d per frame
  *   temp     dev f32 [B,P]  out
- *   info     dev i32 [B,4]  out  {n_left, first candidate pixel (P if none), nnz, 0}              */
+ *   info     dev i32 [B,4]  out  {n_left, first candidate pixel (P if none), nnz, fps_table valid}  */
 int rpcc_ground_mask(const float *ri, const float *tm, const double *ground, double threshold, int B, int P,
-                     float *temp, int32_t *info, void *stream);
+                     float *temp, int32_t *info, void *fps_table, void *stream);
+/* fps_table (optional, rpcc_fps_table_bytes(B,P) bytes, or NULL): when given, the kernel also runs the
+ * first pass of the farthest point sampling (distance of every candidate to the first centre, per-tile
+ * bounding boxes and maxima) and temp holds min(1e10, that distance) for frames with info[b][3] == 1;
+ * pass the same table to rpcc_fps_range.  Results are identical with and without it. */
+size_t rpcc_fps_table_bytes(int B, int P);
 
 /* ---- a6: farthest point sampling ----------------------------------------------------------- *
  * rpcc_fps_xyz replaces furthest_point_sampling_wrapper(b,n,m,points,temp,idx)
@@ -91,7 +96,8 @@ int rpcc_fps_xyz(int B, int N, int M, const float *points, float *temp, int32_t 
  *   centers  dev f32 [B,M,3] out cluster_centers
  *   ws       dev scratch for a planar copy of tm (12*P bytes); NULL selects the brute-force kernel */
 int rpcc_fps_range(const float *ri, const float *tm, float *temp, const int32_t *info, int B, int P, int M,
-                   int32_t *cen_pix, float *centers, void *ws /* dev, >= 12*P bytes, or NULL */, void *stream);
+                   int32_t *cen_pix, float *centers, void *ws /* dev, >= 12*P bytes, or NULL */,
+                   const void *fps_table /* from rpcc_ground_mask, or NULL */, void *stream);
 
 /* Test hook: force the brute-force FPS kernels (one full pass per centre) instead of the exact
  * tile-pruned ones; both give identical results. */
@@ -151,6 +157,10 @@ typedef struct rpcc_batch_io {
 size_t rpcc_workspace_bytes(int B, int P, int M, int64_t total_points);
 int rpcc_compress_batch(const rpcc_batch_io *io, int B, rpcc_geom g, int M, double ground_threshold, float acc,
                         void *ws, void *stream);
+
+/* Developer hook: register a device int64[64] buffer; instrumented kernels store the shader clock at
+ * phase boundaries (block 0 only).  NULL disables it (default). */
+int rpcc_debug_stamps(void *dev_i64_buffer);
 
 /* Timing hook for bench.py: records hipEvents around the FPS launch of the next
  * rpcc_compress_batch / rpcc_fps_* calls on that stream; rpcc_fps_time_ms returns the accumulated

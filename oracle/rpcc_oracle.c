@@ -524,6 +524,11 @@ static int rs_plane_from_moments(const double c[3], double xx, double xy, double
     return 1;
 }
 
+/* inlier test: fp32, un-fused, plane narrowed to fp32 */
+static int rs_inlier(const float pl[4], const float *q, float thr) {
+    return fabsf(((pl[0] * q[0] + pl[1] * q[1]) + pl[2] * q[2]) + pl[3]) < thr;
+}
+
 /* pts: fp32 [n,3].  ransac_n sample size, iters hypotheses, thr inlier distance, seed.
  * Returns the inlier count of the winning hypothesis; plane[4] fp64 out. */
 long orc_ransac_plane(const float *pts, long n, int ransac_n, int iters, double thr, uint32_t seed, double *plane) {
@@ -556,10 +561,8 @@ long orc_ransac_plane(const float *pts, long n, int ransac_n, int iters, double 
         double pl[4];
         if (!rs_plane_from_moments(c, xx, xy, xz, yy, yz, zz, pl)) continue;
         long cnt = 0;
-        for (long i = 0; i < n; i++) {
-            const double dist = fabs(((pl[0] * (double)pts[3 * i] + pl[1] * (double)pts[3 * i + 1]) + pl[2] * (double)pts[3 * i + 2]) + pl[3]);
-            cnt += dist < thr;
-        }
+        const float pf[4] = {(float)pl[0], (float)pl[1], (float)pl[2], (float)pl[3]};
+        for (long i = 0; i < n; i++) cnt += rs_inlier(pf, &pts[3 * i], (float)thr);
         if (cnt > best_cnt) { best_cnt = cnt; memcpy(best, pl, sizeof(best)); }
     }
     if (best_cnt < 0) return 0;
@@ -568,10 +571,8 @@ long orc_ransac_plane(const float *pts, long n, int ransac_n, int iters, double 
     /* refit on the inliers of the winner, ordered reductions */
     double *v = (double *)malloc(sizeof(double) * (size_t)n);
     unsigned char *in = (unsigned char *)malloc((size_t)n);
-    for (long i = 0; i < n; i++) {
-        const double dist = fabs(((best[0] * (double)pts[3 * i] + best[1] * (double)pts[3 * i + 1]) + best[2] * (double)pts[3 * i + 2]) + best[3]);
-        in[i] = dist < thr;
-    }
+    const float bf[4] = {(float)best[0], (float)best[1], (float)best[2], (float)best[3]};
+    for (long i = 0; i < n; i++) in[i] = (unsigned char)rs_inlier(bf, &pts[3 * i], (float)thr);
     double c[3];
     for (int a = 0; a < 3; a++) {
         for (long i = 0; i < n; i++) v[i] = in[i] ? (double)pts[3 * i + a] : 0.0;

@@ -154,6 +154,13 @@ __device__ __forceinline__ uint32_t dpp_min_u32(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+__device__ __forceinline__ uint32_t dpp_sum_u32(uint32_t v) {
+#define STEP_(ctrl_, rm_) v = v + (uint32_t)RPCC_DPP(0, v, ctrl_, rm_)
+    STEP_(0x111, 0xf); STEP_(0x112, 0xf); STEP_(0x114, 0xf); STEP_(0x118, 0xf); STEP_(0x142, 0xa); STEP_(0x143, 0xc);
+#undef STEP_
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // FPS arg-max key: larger squared distance first, then LOWER index (the sequential strict-'>' scan of
 // ops/fps/src/sampling_gpu.cu:67-68 restated as a total order).  value < 0 means "not a candidate".
 __device__ __forceinline__ unsigned long long fps_key(float v, uint32_t idx) {

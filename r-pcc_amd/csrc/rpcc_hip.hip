@@ -36,6 +36,20 @@ static int set_err(int code, const char *fmt, const char *a = "", const char *b 
 extern "C" int rpcc_version(void) { return 100; }
 extern "C" const char *rpcc_last_error(void) { return g_err; }
 
+// Developer phase timing: when a buffer is registered, block 0 / thread 0 of instrumented kernels stores
+// s_memtime at phase boundaries (tools_dev/phase_times.py).  NULL (default) = one scalar load per stamp.
+__device__ long long *g_dbg_stamps = nullptr;
+extern "C" int rpcc_debug_stamps(void *dev_i64_buffer) {
+    long long *p = reinterpret_cast<long long *>(dev_i64_buffer);
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_stamps), &p, sizeof(p)));
+    return RPCC_OK;
+}
+#define DBG_STAMP(slot_)                                                                     \
+    do {                                                                                     \
+        if (g_dbg_stamps != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) \
+            g_dbg_stamps[slot_] = (long long)__builtin_readcyclecounter();                   \
+    } while (0)
+
 // FPS timing hook (bench.py): hipEvents on the stream the kernel is launched on.
 static bool g_fps_timing = false;
 static hipEvent_t g_ev0[64], g_ev1[64];
@@ -213,10 +227,19 @@ __global__ __launch_bounds__(BAND_THREADS) void project_band_kernel(const uint2 
     for (uint32_t p = threadIdx.x; p < npx; p += BAND_THREADS) band[p] = RI_EMPTY;
     __syncthreads();
     const int64_t n0 = offs[b], n1 = offs[b + 1];
-    for (int64_t i = n0 + threadIdx.x; i < n1; i += BAND_THREADS) {
-        const uint2 v = pd[i];
-        const uint32_t rel = v.x - band0;  // skipped records (0xFFFFFFFF) fall outside every band
-        if (rel < npx) atomicMin(&band[rel], v.y);
+    for (int64_t i = n0 + threadIdx.x; i < n1; i += BAND_THREADS * 8) {  // 8 records in flight per thread
+        uint2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {  // unconditional (clamped) loads; out-of-range slots are masked below
+            const int64_t ii = i + (int64_t)u * BAND_THREADS;
+            v[u] = pd[ii < n1 ? ii : n1 - 1];
+            if (ii >= n1) v[u].x = 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t rel = v[u].x - band0;  // skipped records (0xFFFFFFFF) fall outside every band
+            if (rel < npx) atomicMin(&band[rel], v[u].y);
+        }
     }
     __syncthreads();
     uint32_t *out = ri + (int64_t)b * P + band0;
@@ -300,6 +323,7 @@ extern "C" int rpcc_project(const float *xyz, const int64_t *offsets, int64_t to
 #define RS_THREADS 1024
 #define RS_NT 256
 #define RS_MAX_LIST 5120
+#define RS_MAX_HYP 128
 
 __device__ __forceinline__ uint32_t mix32(uint32_t a, uint32_t b, uint32_t c) {
     uint32_t h = a * 0x9E3779B1u + 0x7F4A7C15u;
@@ -336,64 +360,116 @@ struct RsPoints {
         if (lds) { x = (double)lds[3 * i]; y = (double)lds[3 * i + 1]; z = (double)lds[3 * i + 2]; }
         else { float r = ri[i]; if (raw && f2u(r) == RI_EMPTY) r = 0.0f; x = (double)(r * tm[3 * i]); y = (double)(r * tm[3 * i + 1]); z = (double)(r * tm[3 * i + 2]); }
     }
+    __device__ __forceinline__ void getf(int i, float &x, float &y, float &z) const {
+        if (lds) { x = lds[3 * i]; y = lds[3 * i + 1]; z = lds[3 * i + 2]; }
+        else { float r = ri[i]; if (raw && f2u(r) == RI_EMPTY) r = 0.0f; x = r * tm[3 * i]; y = r * tm[3 * i + 1]; z = r * tm[3 * i + 2]; }
+    }
 };
 
-__device__ __forceinline__ double plane_dist(const double pl[4], double x, double y, double z) {
-    return fabs(((pl[0] * x + pl[1] * y) + pl[2] * z) + pl[3]);
+// inlier test of the specification: fp32, un-fused, plane narrowed to fp32
+__device__ __forceinline__ bool plane_inlier(const float pl[4], float x, float y, float z, float thr) {
+    return fabsf(((pl[0] * x + pl[1] * y) + pl[2] * z) + pl[3]) < thr;
 }
 
-// ordered fp64 reduction: thread t < 256 owns partial t; result valid in every thread after return
-__device__ __forceinline__ double rs_treesum(double partial, double *sred) {
+// ordered fp64 reduction of NV values at once: thread t < 256 owns partial t of each; the results are
+// valid in every thread after return.  sred: [NV][RS_NT].
+template <int NV>
+__device__ __forceinline__ void rs_treesum(double (&v)[NV], double *sred) {
     const int t = threadIdx.x;
     __syncthreads();
-    if (t < RS_NT) sred[t] = partial;
+    if (t < RS_NT) {
+#pragma unroll
+        for (int q = 0; q < NV; q++) sred[q * RS_NT + t] = v[q];
+    }
     __syncthreads();
     for (int stride = RS_NT / 2; stride >= 1; stride >>= 1) {
-        if (t < stride) sred[t] += sred[t + stride];
+        if (t < stride) {
+#pragma unroll
+            for (int q = 0; q < NV; q++) sred[q * RS_NT + t] += sred[q * RS_NT + t + stride];
+        }
         __syncthreads();
     }
-    return sred[0];
+#pragma unroll
+    for (int q = 0; q < NV; q++) v[q] = sred[q * RS_NT];
 }
 
-// Workgroup-wide RANSAC on `pts`; all RS_THREADS threads call it.  Returns the winner's inlier count.
-__device__ int ransac_plane_wg(const RsPoints &pts, int ransac_n, int iters, double thr, uint32_t seed, double plane[4],
-                               double *sred /* [RS_NT] */, double *swin /* [16*4] */, int *sbest /* [16*2] */) {
+// Workgroup-wide RANSAC on `pts` (RN = sample size); all RS_THREADS threads call it.  Returns the
+// winner's inlier count.  sred [6*RS_NT] doubles, swin [16*4] doubles, sbest [16*2] ints.
+template <int RN>
+__device__ int ransac_plane_wg(const RsPoints &pts, int iters, double thr, uint32_t seed, double plane[4], double *sred,
+                               double *swin, int *sbest) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = pts.n;
+    const float thr_f = (float)thr;
     plane[0] = 0; plane[1] = 0; plane[2] = 1; plane[3] = 0;
-    if (n < ransac_n || ransac_n < 3 || ransac_n > 16) return 0;
-    int best_cnt = -1, best_h = 0x7fffffff;
-    double best[4] = {0, 0, 1, 0};
-    for (int h = wave; h < iters; h += RS_THREADS / 64) {
-        int idx[16];
-        for (int k = 0; k < ransac_n; k++) {
+    if (n < RN || iters > RS_MAX_HYP) return 0;
+    // (1) fits: one hypothesis per lane (iters <= RS_MAX_HYP), results narrowed to fp32 in LDS
+    float *hyp = reinterpret_cast<float *>(sred);  // [iters][4] fp32 planes + validity, reused before the sums
+    double *hypd = swin + 64;                      // [iters][4] fp64 planes (winner is read back from here)
+    if (tid < iters) {
+        const int h = tid;
+        int idx[RN];
+#pragma unroll
+        for (int k = 0; k < RN; k++) {
             uint32_t a = 0;
             int cand;
             bool dup;
             do {
                 cand = (int)(mix32(seed, (uint32_t)(h * 16 + k), a++) % (uint32_t)n);
                 dup = false;
-                for (int j = 0; j < k; j++) dup |= (idx[j] == cand);
+#pragma unroll
+                for (int j = 0; j < RN; j++) dup |= (j < k) && (idx[j] == cand);
             } while (dup);
             idx[k] = cand;
         }
+        double px[RN], py[RN], pz[RN];
         double c[3] = {0, 0, 0};
-        for (int k = 0; k < ransac_n; k++) { double x, y, z; pts.get(idx[k], x, y, z); c[0] += x; c[1] += y; c[2] += z; }
-        c[0] /= (double)ransac_n; c[1] /= (double)ransac_n; c[2] /= (double)ransac_n;
+#pragma unroll
+        for (int k = 0; k < RN; k++) { pts.get(idx[k], px[k], py[k], pz[k]); c[0] += px[k]; c[1] += py[k]; c[2] += pz[k]; }
+        c[0] /= (double)RN; c[1] /= (double)RN; c[2] /= (double)RN;
         double xx = 0, xy = 0, xz = 0, yy = 0, yz = 0, zz = 0;
-        for (int k = 0; k < ransac_n; k++) {
-            double x, y, z; pts.get(idx[k], x, y, z);
-            const double rx = x - c[0], ry = y - c[1], rz = z - c[2];
+#pragma unroll
+        for (int k = 0; k < RN; k++) {
+            const double rx = px[k] - c[0], ry = py[k] - c[1], rz = pz[k] - c[2];
             xx += rx * rx; xy += rx * ry; xz += rx * rz; yy += ry * ry; yz += ry * rz; zz += rz * rz;
         }
-        double pl[4];
-        if (!plane_from_moments(c, xx, xy, xz, yy, yz, zz, pl)) continue;  // wave-uniform
-        int cnt = 0;
-        for (int i = lane; i < n; i += 64) { double x, y, z; pts.get(i, x, y, z); cnt += plane_dist(pl, x, y, z) < thr; }
-        cnt = wave_sum_i32(cnt);
-        if (cnt > best_cnt) { best_cnt = cnt; best_h = h; best[0] = pl[0]; best[1] = pl[1]; best[2] = pl[2]; best[3] = pl[3]; }
+        double pl[4] = {0, 0, 0, 0};
+        const bool ok = plane_from_moments(c, xx, xy, xz, yy, yz, zz, pl);
+        hyp[5 * h] = (float)pl[0]; hyp[5 * h + 1] = (float)pl[1]; hyp[5 * h + 2] = (float)pl[2]; hyp[5 * h + 3] = (float)pl[3];
+        hyp[5 * h + 4] = ok ? 1.0f : 0.0f;
+        hypd[4 * h] = pl[0]; hypd[4 * h + 1] = pl[1]; hypd[4 * h + 2] = pl[2]; hypd[4 * h + 3] = pl[3];
     }
     __syncthreads();
+    // (2) scoring: wavefront w counts the inliers of hypotheses w, w+16, ... -- all of them in one pass
+    // over the points (a point is read from LDS once and tested against up to RS_HPW planes)
+    constexpr int RS_HPW = RS_MAX_HYP / (RS_THREADS / 64);
+    float pf[RS_HPW][4];
+    int cnt[RS_HPW];
+#pragma unroll
+    for (int q = 0; q < RS_HPW; q++) {
+        const int h = wave + q * (RS_THREADS / 64);
+        const bool ok = h < iters && hyp[5 * (h < iters ? h : 0) + 4] != 0.0f;
+        const int hh = h < iters ? h : 0;
+        pf[q][0] = hyp[5 * hh]; pf[q][1] = hyp[5 * hh + 1]; pf[q][2] = hyp[5 * hh + 2];
+        pf[q][3] = ok ? hyp[5 * hh + 3] : __builtin_inff();  // invalid -> never an inlier
+        cnt[q] = 0;
+    }
+    for (int i = lane; i < n; i += 64) {
+        float x, y, z; pts.getf(i, x, y, z);
+#pragma unroll
+        for (int q = 0; q < RS_HPW; q++) cnt[q] += plane_inlier(pf[q], x, y, z, thr_f);
+    }
+    int best_cnt = -1, best_h = 0x7fffffff;
+#pragma unroll
+    for (int q = 0; q < RS_HPW; q++) {
+        const int h = wave + q * (RS_THREADS / 64);
+        const int c = (int)dpp_sum_u32((uint32_t)cnt[q]);
+        if (h < iters && hyp[5 * h + 4] != 0.0f && c > best_cnt) { best_cnt = c; best_h = h; }
+    }
+    double best[4] = {0, 0, 1, 0};
+    if (best_cnt >= 0) { best[0] = hypd[4 * best_h]; best[1] = hypd[4 * best_h + 1]; best[2] = hypd[4 * best_h + 2]; best[3] = hypd[4 * best_h + 3]; }
+    __syncthreads();
+    DBG_STAMP(3);
     if (lane == 0) {
         sbest[2 * wave] = best_cnt; sbest[2 * wave + 1] = best_h;
         swin[4 * wave] = best[0]; swin[4 * wave + 1] = best[1]; swin[4 * wave + 2] = best[2]; swin[4 * wave + 3] = best[3];
@@ -407,31 +483,28 @@ __device__ int ransac_plane_wg(const RsPoints &pts, int ransac_n, int iters, dou
     if (wcnt < 0) return 0;
     plane[0] = swin[4 * wbest]; plane[1] = swin[4 * wbest + 1]; plane[2] = swin[4 * wbest + 2]; plane[3] = swin[4 * wbest + 3];
     if (wcnt < 3) return wcnt;
-    const double w0 = plane[0], w1 = plane[1], w2 = plane[2], w3 = plane[3];
-    const double win[4] = {w0, w1, w2, w3};
-    // refit on the winner's inliers
-    double c[3];
-    {
-        double sx = 0, sy = 0, sz = 0;
-        if (tid < RS_NT)
-            for (int i = tid; i < n; i += RS_NT) {
-                double x, y, z; pts.get(i, x, y, z);
-                if (plane_dist(win, x, y, z) < thr) { sx += x; sy += y; sz += z; }
-            }
-        c[0] = rs_treesum(sx, sred) / (double)wcnt;
-        c[1] = rs_treesum(sy, sred) / (double)wcnt;
-        c[2] = rs_treesum(sz, sred) / (double)wcnt;
-    }
+    const float wf[4] = {(float)plane[0], (float)plane[1], (float)plane[2], (float)plane[3]};
+    // refit on the winner's inliers (fp64 moments, ordered sums)
+    double c[3] = {0, 0, 0};
+    if (tid < RS_NT)
+        for (int i = tid; i < n; i += RS_NT) {
+            float x, y, z; pts.getf(i, x, y, z);
+            if (plane_inlier(wf, x, y, z, thr_f)) { c[0] += (double)x; c[1] += (double)y; c[2] += (double)z; }
+        }
+    DBG_STAMP(4);
+    rs_treesum<3>(c, sred);
+    DBG_STAMP(5);
+    c[0] /= (double)wcnt; c[1] /= (double)wcnt; c[2] /= (double)wcnt;
     double m[6] = {0, 0, 0, 0, 0, 0};
     if (tid < RS_NT)
         for (int i = tid; i < n; i += RS_NT) {
-            double x, y, z; pts.get(i, x, y, z);
-            if (plane_dist(win, x, y, z) < thr) {
-                const double rx = x - c[0], ry = y - c[1], rz = z - c[2];
+            float x, y, z; pts.getf(i, x, y, z);
+            if (plane_inlier(wf, x, y, z, thr_f)) {
+                const double rx = (double)x - c[0], ry = (double)y - c[1], rz = (double)z - c[2];
                 m[0] += rx * rx; m[1] += rx * ry; m[2] += rx * rz; m[3] += ry * ry; m[4] += ry * rz; m[5] += rz * rz;
             }
         }
-    for (int q = 0; q < 6; q++) m[q] = rs_treesum(m[q], sred);
+    rs_treesum<6>(m, sred);
     double pl[4];
     if (plane_from_moments(c, m[0], m[1], m[2], m[3], m[4], m[5], pl)) { plane[0] = pl[0]; plane[1] = pl[1]; plane[2] = pl[2]; plane[3] = pl[3]; }
     return wcnt;
@@ -444,13 +517,14 @@ __global__ __launch_bounds__(RS_THREADS) void ground_ransac_kernel(const float *
                                                                    double *__restrict__ ground,
                                                                    int32_t *__restrict__ ninl) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rs_smem[];
-    double *sred = reinterpret_cast<double *>(rs_smem);          // [256]
-    double *swin = sred + RS_NT;                                 // [64]
-    int *sbest = reinterpret_cast<int *>(swin + 64);             // [32]
+    double *sred = reinterpret_cast<double *>(rs_smem);          // [6*256]
+    double *swin = sred + 6 * RS_NT;                             // [64] + [RS_MAX_HYP*4] fp64 hypotheses
+    int *sbest = reinterpret_cast<int *>(swin + 64 + RS_MAX_HYP * 4);  // [32]
     int *swave = sbest + 32;                                     // [16]
     float *list = reinterpret_cast<float *>(swave + 16);         // [max_pts*3]
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float *ri = ri_all + (int64_t)b * P;
+    DBG_STAMP(0);
     // each wave owns a contiguous run of pixels (rounded up to whole 64-pixel steps)
     const int per_wave = (((P + 15) / 16) + 63) & ~63;
     const int w0 = wave * per_wave, w1 = min(P, w0 + per_wave);
@@ -460,44 +534,58 @@ __global__ __launch_bounds__(RS_THREADS) void ground_ransac_kernel(const float *
         return r * tm[3 * p + 2];
     };
     int cnt = 0;
-    for (int p0 = w0; p0 < w1; p0 += 64) {
-        const int p = p0 + lane;
-        cnt += __popcll(__ballot(p < w1 && zval(p) < zthr));
+    for (int p0 = w0; p0 < w1; p0 += 64 * 8) {  // 8 independent loads in flight per lane
+        float zv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) zv[u] = zval(min(p0 + u * 64 + lane, P - 1));  // unconditional loads (clamped)
+#pragma unroll
+        for (int u = 0; u < 8; u++) cnt += __popcll(__ballot(p0 + u * 64 + lane < w1 && zv[u] < zthr));
     }
     if (lane == 0) swave[wave] = cnt;
     __syncthreads();
+    DBG_STAMP(1);
     int nc = 0, base = 0;
     for (int w = 0; w < 16; w++) { if (w < wave) base += swave[w]; nc += swave[w]; }
     RsPoints pts;
     pts.ri = ri; pts.tm = tm; pts.lds = nullptr; pts.n = P; pts.raw = raw;
     if (nc >= min_pts) {
         int run = base;
-        for (int p0 = w0; p0 < w1; p0 += 64) {
-            const int p = p0 + lane;
-            const bool c = p < w1 && zval(p) < zthr;
-            const unsigned long long m = __ballot(c);
-            if (c) {
-                const long long i = run + __popcll(m & ((1ull << lane) - 1ull));
-                bool keep = true;
-                long long slot = i;
-                if (nc > max_pts) {
-                    slot = (i * max_pts) / nc;
-                    keep = ((i + 1) * max_pts) / nc > slot;
-                }
-                if (keep) {
-                    float r = ri[p];
-                    if (raw && f2u(r) == RI_EMPTY) r = 0.0f;
-                    list[3 * slot] = r * tm[3 * p]; list[3 * slot + 1] = r * tm[3 * p + 1]; list[3 * slot + 2] = r * tm[3 * p + 2];
-                }
+        for (int p00 = w0; p00 < w1; p00 += 64 * 8) {  // all loads of 8 steps are issued before any is used
+            float xv[8], yv[8], zv[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {  // unconditional (clamped) loads: a guarded load would be waited for at once
+                const int p = min(p00 + u * 64 + lane, P - 1);
+                float r = ri[p];
+                if (raw && f2u(r) == RI_EMPTY) r = 0.0f;
+                xv[u] = r * tm[3 * p]; yv[u] = r * tm[3 * p + 1]; zv[u] = r * tm[3 * p + 2];
             }
-            run += __popcll(m);
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int p = p00 + u * 64 + lane;
+                const bool c = p < w1 && zv[u] < zthr;
+                const unsigned long long m = __ballot(c);
+                if (c) {
+                    const long long i = run + __popcll(m & ((1ull << lane) - 1ull));
+                    bool keep = true;
+                    long long slot = i;
+                    if (nc > max_pts) {
+                        slot = (i * max_pts) / nc;
+                        keep = ((i + 1) * max_pts) / nc > slot;
+                    }
+                    if (keep) { list[3 * slot] = xv[u]; list[3 * slot + 1] = yv[u]; list[3 * slot + 2] = zv[u]; }
+                }
+                run += __popcll(m);
+            }
         }
         pts.lds = list;
         pts.n = nc > max_pts ? max_pts : nc;
     }
     __syncthreads();
+    DBG_STAMP(2);
     double plane[4];
-    const int inl = ransac_plane_wg(pts, ransac_n, iters, thr, seed0 + (uint32_t)b, plane, sred, swin, sbest);
+    (void)ransac_n;  // the ground fit samples 10 points (utils/segment_utils.py:75)
+    const int inl = ransac_plane_wg<10>(pts, iters, thr, seed0 + (uint32_t)b, plane, sred, swin, sbest);
+    DBG_STAMP(6);
     if (tid == 0) {
         ground[4 * b] = plane[0]; ground[4 * b + 1] = plane[1]; ground[4 * b + 2] = plane[2]; ground[4 * b + 3] = plane[3];
         if (ninl) ninl[b] = inl;
@@ -507,7 +595,7 @@ __global__ __launch_bounds__(RS_THREADS) void ground_ransac_kernel(const float *
 static int launch_ground_ransac(const float *ri, const float *tm, int B, int P, uint32_t seed0, bool raw, double *ground,
                                 int32_t *ninl, hipStream_t st) {
     const int max_pts = 5000, min_pts = 800;
-    const size_t sh = (size_t)RS_NT * 8 + 64 * 8 + 32 * 4 + 16 * 4 + (size_t)max_pts * 3 * 4;
+    const size_t sh = (size_t)6 * RS_NT * 8 + (64 + RS_MAX_HYP * 4) * 8 + 32 * 4 + 16 * 4 + (size_t)max_pts * 3 * 4;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&ground_ransac_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
     ground_ransac_kernel<<<B, RS_THREADS, sh, st>>>(ri, tm, P, -1.5f, max_pts, min_pts, 10, 100, 0.1, seed0, raw ? 1 : 0,
@@ -539,42 +627,96 @@ __global__ void info_init_kernel(int32_t *__restrict__ info, int B, int P) {
 // RAW: ri still holds the projection's bit patterns (RI_EMPTY = untouched) and is finalised here.
 // A 256-thread workgroup owns GM_PIX consecutive pixels of one frame; counts are reduced per wave
 // (ballot), then per workgroup (LDS), then one atomic per counter per workgroup.
+//
+// TAB: the kernel also performs the FIRST pass of the farthest point sampling at full-chip parallelism.
+// FPS starts at the first candidate in row-major order.  Every wavefront re-derives it from the first
+// 64 pixels of the frame; if one of them is a candidate (the usual case: the first pixels are empty and
+// empty pixels are candidates) the kernel writes temp = min(1e10, d(pixel, first centre)) instead of
+// 1e10 and fills the FPS tile table (bounding box, tile maximum, its index and coordinates -- layout of
+// FpsLds) so the FPS kernel starts at the second centre.  Otherwise info[b][3] stays 0 and the classic
+// temp = 1e10 / -1 is written (the FPS kernel then does its own first pass).  Same arithmetic either way.
 #define GM_PIX 4096
-template <bool RAW>
+#define FPS_TAB_ROWS 11  // lo[3], hi[3], tmax, cx[3], targ
+template <bool RAW, bool TAB>
 __global__ __launch_bounds__(256) void ground_mask_kernel(float *__restrict__ ri, const float *__restrict__ tm,
                                                           const double *__restrict__ ground, double thr, int P,
-                                                          float *__restrict__ temp, int32_t *__restrict__ info) {
+                                                          float *__restrict__ temp, int32_t *__restrict__ info,
+                                                          float *__restrict__ tiletab) {
     __shared__ int s_cnt[4], s_nz[4], s_first[4];
-    const int b = blockIdx.y;
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const double a = ground[4 * b], bb = ground[4 * b + 1], c = ground[4 * b + 2], d = ground[4 * b + 3];
     // np.linalg.norm(plane_param[:, :3]) on a (1,1,4) array: all four components (segment_utils.py:47)
     const double div = sqrt(((a * a + bb * bb) + c * c) + d * d);
+    auto load_px = [&](int p, float &r, float &x, float &y, float &z) -> bool {  // returns "is a candidate"
+        r = ri[(int64_t)b * P + p];
+        if (RAW && f2u(r) == RI_EMPTY) r = 0.0f;
+        x = r * tm[3 * p]; y = r * tm[3 * p + 1]; z = r * tm[3 * p + 2];
+        const double s = ((double)x * a + (double)y * bb) + (double)z * c;
+        return fabs(s + d) / div > thr;
+    };
+    bool fast = false;
+    int f0 = 0;
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+    const int T = (P + 63) >> 6;
+    if (TAB) {
+        float r, x, y, z;
+        const bool cd = load_px(min(lane, P - 1), r, x, y, z) && lane < P;
+        const unsigned long long m = __ballot(cd);
+        fast = m != 0ull;
+        f0 = fast ? (int)__ffsll((long long)m) - 1 : 0;
+        c0 = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(x), f0));
+        c1 = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(y), f0));
+        c2 = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(z), f0));
+        if (blockIdx.x == 0 && threadIdx.x == 0) info[4 * b + 3] = fast ? 1 : 0;
+    }
+    float *tab = TAB ? tiletab + (int64_t)b * FPS_TAB_ROWS * T : nullptr;
     int cnt = 0, nzc = 0, first = P;
-#pragma unroll 4
+#pragma unroll 2
     for (int it = 0; it < GM_PIX / 256; it++) {
         const int p = blockIdx.x * GM_PIX + it * 256 + threadIdx.x;
-        bool cand = false, nz = false;
-        if (p < P) {
-            const int64_t gp = (int64_t)b * P + p;
-            float r = ri[gp];
-            if (RAW) {
-                if (f2u(r) == RI_EMPTY) r = 0.0f;
-                ri[gp] = r;
-            }
-            const float x = r * tm[3 * p], y = r * tm[3 * p + 1], z = r * tm[3 * p + 2];
-            const double s = ((double)x * a + (double)y * bb) + (double)z * c;
-            const double dd = fabs(s + d) / div;
-            cand = dd > thr;
-            nz = r != 0.0f;
-            temp[gp] = cand ? 1e10f : -1.0f;
+        if (blockIdx.x * GM_PIX + it * 256 >= P) break;  // whole workgroup past the image (uniform)
+        const bool valid = p < P;
+        const int pc = valid ? p : P - 1;
+        float r, x, y, z;
+        const bool cand = load_px(pc, r, x, y, z) && valid;
+        const bool nz = valid && r != 0.0f;
+        float nt = cand ? 1e10f : -1.0f;
+        if (TAB && fast) {
+            const float dx = x - c0, dy = y - c1, dz = z - c2;
+            const float dist = (dx * dx + dy * dy) + dz * dz;  // sampling_gpu.cu:64, un-fused
+            nt = cand ? fminf(dist, 1e10f) : -1.0f;
+        }
+        if (valid) {
+            if (RAW) ri[(int64_t)b * P + p] = r;
+            temp[(int64_t)b * P + p] = nt;
         }
         const unsigned long long mc = __ballot(cand), mz = __ballot(nz);
         cnt += __popcll(mc);
         nzc += __popcll(mz);
-        if (mc && first == P) first = (p - (int)(threadIdx.x & 63)) + (int)__ffsll((long long)mc) - 1;
+        if (mc && first == P) first = (p - lane) + (int)__ffsll((long long)mc) - 1;
+        if (TAB && fast) {  // this wavefront's 64 pixels are FPS tile (p - lane) / 64
+            const int t = (p - lane) >> 6;
+            const float inf = __builtin_inff();
+            const float l0 = dpp_min_f32(cand ? x : inf), l1 = dpp_min_f32(cand ? y : inf), l2 = dpp_min_f32(cand ? z : inf);
+            const float h0 = dpp_max_f32(cand ? x : -inf), h1 = dpp_max_f32(cand ? y : -inf), h2 = dpp_max_f32(cand ? z : -inf);
+            const uint32_t ord = (!valid || nt < 0.0f) ? 0u : f2u(nt) + 1u;
+            const uint32_t vmax = dpp_max_u32(ord);
+            const int wl = __builtin_amdgcn_readfirstlane((int)__ffsll((long long)__ballot(ord == vmax)) - 1);
+            const float wt = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(nt), wl));
+            const float wx = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(x), wl));
+            const float wy = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(y), wl));
+            const float wz = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(z), wl));
+            if (lane < FPS_TAB_ROWS) {
+                float v = l0;
+                v = lane == 1 ? l1 : v; v = lane == 2 ? l2 : v; v = lane == 3 ? h0 : v; v = lane == 4 ? h1 : v;
+                v = lane == 5 ? h2 : v; v = lane == 6 ? ((vmax == 0u) ? -1.0f : wt) : v;
+                v = lane == 7 ? wx : v; v = lane == 8 ? wy : v; v = lane == 9 ? wz : v;
+                v = lane == 10 ? u2f((uint32_t)(t * 64 + wl)) : v;
+                tab[(int64_t)lane * T + t] = v;
+            }
+        }
     }
-    const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { s_cnt[wave] = cnt; s_nz[wave] = nzc; s_first[wave] = first; }
+    if (lane == 0) { s_cnt[wave] = cnt; s_nz[wave] = nzc; s_first[wave] = first; }
     __syncthreads();
     if (threadIdx.x == 0) {
         const int tc = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
@@ -585,21 +727,29 @@ __global__ __launch_bounds__(256) void ground_mask_kernel(float *__restrict__ ri
     }
 }
 
+// tiletab: dev f32 [B][11][T] (T = ceil(P/64)) or NULL
 static int launch_ground_mask(float *ri, const float *tm, const double *ground, double thr, int B, int P, float *temp,
-                              int32_t *info, hipStream_t st, bool raw) {
+                              int32_t *info, float *tiletab, hipStream_t st, bool raw) {
     info_init_kernel<<<(B + 255) / 256, 256, 0, st>>>(info, B, P);
     const dim3 grid((P + GM_PIX - 1) / GM_PIX, B);
-    if (raw) ground_mask_kernel<true><<<grid, 256, 0, st>>>(ri, tm, ground, thr, P, temp, info);
-    else     ground_mask_kernel<false><<<grid, 256, 0, st>>>(ri, tm, ground, thr, P, temp, info);
+    if (tiletab) {
+        if (raw) ground_mask_kernel<true, true><<<grid, 256, 0, st>>>(ri, tm, ground, thr, P, temp, info, tiletab);
+        else     ground_mask_kernel<false, true><<<grid, 256, 0, st>>>(ri, tm, ground, thr, P, temp, info, tiletab);
+    } else {
+        if (raw) ground_mask_kernel<true, false><<<grid, 256, 0, st>>>(ri, tm, ground, thr, P, temp, info, nullptr);
+        else     ground_mask_kernel<false, false><<<grid, 256, 0, st>>>(ri, tm, ground, thr, P, temp, info, nullptr);
+    }
     LAUNCH_CHECK();
     return RPCC_OK;
 }
 
+extern "C" size_t rpcc_fps_table_bytes(int B, int P) { return (size_t)B * FPS_TAB_ROWS * ((P + 63) / 64) * 4; }
+
 extern "C" int rpcc_ground_mask(const float *ri, const float *tm, const double *ground, double threshold, int B, int P,
-                                float *temp, int32_t *info, void *stream) {
+                                float *temp, int32_t *info, void *fps_table, void *stream) {
     ARG_TRY(B > 0 && P > 0 && ri && tm && ground && temp && info);
-    return launch_ground_mask(const_cast<float *>(ri), tm, ground, threshold, B, P, temp, info, (hipStream_t)stream,
-                              false);
+    return launch_ground_mask(const_cast<float *>(ri), tm, ground, threshold, B, P, temp, info,
+                              reinterpret_cast<float *>(fps_table), (hipStream_t)stream, false);
 }
 
 // ================================================================================================
@@ -765,7 +915,8 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_tiled_kernel(const float *__r
                                                                 const float *__restrict__ tz, float *__restrict__ temp,
                                                                 const int32_t *__restrict__ info, int N, int M, int T,
                                                                 int32_t *__restrict__ out_idx,
-                                                                float *__restrict__ out_cen) {
+                                                                float *__restrict__ out_cen,
+                                                                const float *__restrict__ tiletab) {
     extern __shared__ __attribute__((aligned(16))) unsigned char fps_smem[];
     __shared__ unsigned long long red[16];
     __shared__ int wcount;
@@ -792,8 +943,10 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_tiled_kernel(const float *__r
     struct TileRegs { float x, y, z, tp; };
     auto load_tile = [&](int t, TileRegs &q) {
         const int p = t * 64 + lane;
-        q.x = 0.f; q.y = 0.f; q.z = 0.f; q.tp = -1.0f;
-        if (p < N) { fps_load_point<RANGE>(src, tx, ty, tz, p, q.x, q.y, q.z); q.tp = temp[p]; }
+        const int pc = min(p, N - 1);  // unconditional (clamped) loads keep the whole group in flight
+        fps_load_point<RANGE>(src, tx, ty, tz, pc, q.x, q.y, q.z);
+        q.tp = temp[pc];
+        if (p >= N) { q.x = 0.f; q.y = 0.f; q.z = 0.f; q.tp = -1.0f; }
     };
     // distance update against the current centre, tile maximum, (optionally) bounding box
     auto compute_tile = [&](int t, const TileRegs &q, bool with_box) {
@@ -847,8 +1000,20 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_tiled_kernel(const float *__r
     };
 
     constexpr int NW = FPS_THREADS / 64, GROUP = 4;
-    // first centre: every tile is visited once (also builds the boxes)
-    if (M > 1) {
+    DBG_STAMP(8);
+    // first centre: every tile is visited once (also builds the boxes) -- unless ground_mask already did
+    // that pass and left the tile table (info[b][3] == 1)
+    const bool have_tab = RANGE && tiletab != nullptr && info[4 * b + 3] == 1;
+    if (M > 1 && have_tab) {
+        const float *tab = tiletab + (int64_t)b * FPS_TAB_ROWS * T;
+        float *dst = reinterpret_cast<float *>(fps_smem);
+        for (int i = tid; i < FPS_TAB_ROWS * T; i += FPS_THREADS) dst[i] = tab[i];
+        __syncthreads();
+        DBG_STAMP(9);
+        select_next();
+        DBG_STAMP(10);
+        if (tid == 0) { out_idx[1] = old; if (out_cen) { out_cen[3] = c0; out_cen[4] = c1; out_cen[5] = c2; } }
+    } else if (M > 1) {
         for (int t = wave; t < T; t += NW * GROUP) {
             TileRegs q[GROUP];
 #pragma unroll
@@ -857,10 +1022,15 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_tiled_kernel(const float *__r
             for (int g = 0; g < GROUP; g++) if (t + g * NW < T) compute_tile(t + g * NW, q[g], true);
         }
         __syncthreads();
+        DBG_STAMP(9);
         select_next();
+        DBG_STAMP(10);
         if (tid == 0) { out_idx[1] = old; if (out_cen) { out_cen[3] = c0; out_cen[4] = c1; out_cen[5] = c2; } }
     }
     for (int j = 2; j < M; j++) {
+        if (j == 10) DBG_STAMP(11);
+        if (j == 50) DBG_STAMP(12);
+        if (j == 99) { DBG_STAMP(13); }
         // tile test against the new centre; active tiles go to the work list
         for (int t = tid; t < T; t += FPS_THREADS) {
             const float g0 = fmaxf(fmaxf(L.lo[0][t] - c0, c0 - L.hi[0][t]), 0.0f);
@@ -877,7 +1047,9 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_tiled_kernel(const float *__r
             }
         }
         __syncthreads();
+        if (j == 99) DBG_STAMP(14);
         const int n = wcount;
+        if (j == 99 && g_dbg_stamps != nullptr && blockIdx.x == 0 && tid == 0) g_dbg_stamps[20] = n;
         for (int e = wave; e < n; e += NW * GROUP) {
             TileRegs q[GROUP];
             int tt[GROUP];
@@ -887,8 +1059,10 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_tiled_kernel(const float *__r
             for (int g = 0; g < GROUP; g++) if (e + g * NW < n) compute_tile(tt[g], q[g], false);
         }
         __syncthreads();
+        if (j == 99) DBG_STAMP(15);
         if (tid == 0) wcount = 0;
         select_next();
+        if (j == 99) DBG_STAMP(16);
         if (tid == 0) { out_idx[j] = old; if (out_cen) { out_cen[3 * j] = c0; out_cen[3 * j + 1] = c1; out_cen[3 * j + 2] = c2; } }
     }
 }
@@ -912,7 +1086,7 @@ extern "C" int rpcc_fps_xyz(int B, int N, int M, const float *points, float *tem
         const size_t sh = fps_tiled_lds_bytes(T);
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_tiled_kernel<false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-        fps_tiled_kernel<false><<<B, FPS_THREADS, sh, st>>>(points, nullptr, nullptr, nullptr, temp, nullptr, N, M, T, idx, nullptr);
+        fps_tiled_kernel<false><<<B, FPS_THREADS, sh, st>>>(points, nullptr, nullptr, nullptr, temp, nullptr, N, M, T, idx, nullptr, nullptr);
     } else {
         fps_xyz_kernel<<<B, FPS_THREADS, 0, st>>>(N, M, points, temp, idx);
     }
@@ -922,7 +1096,7 @@ extern "C" int rpcc_fps_xyz(int B, int N, int M, const float *points, float *tem
 
 // rays_soa: dev f32 [3,P] scratch (may be NULL -> brute-force kernel on the AoS table)
 static int launch_fps_range(const float *ri, const float *tm, float *temp, const int32_t *info, int B, int P, int M,
-                            int32_t *cen_pix, float *centers, float *rays_soa, hipStream_t st) {
+                            int32_t *cen_pix, float *centers, float *rays_soa, const float *tiletab, hipStream_t st) {
     const int T = (P + 63) / 64;
     if (!g_fps_force_v1 && rays_soa != nullptr && T <= FPS_TILED_MAX_TILES) {
         rays_soa_kernel<<<(P + 255) / 256, 256, 0, st>>>(tm, P, rays_soa);
@@ -931,10 +1105,12 @@ static int launch_fps_range(const float *ri, const float *tm, float *temp, const
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
         FpsTimer tmr(st);
         fps_tiled_kernel<true><<<B, FPS_THREADS, sh, st>>>(ri, rays_soa, rays_soa + P, rays_soa + 2 * (int64_t)P, temp, info,
-                                                        P, M, T, cen_pix, centers);
+                                                        P, M, T, cen_pix, centers, tiletab);
         LAUNCH_CHECK();
         return RPCC_OK;
     }
+    if (tiletab != nullptr && !g_fps_force_v1)
+        return set_err(RPCC_ERR_ARG, "fps_range: an FPS table was produced but the tiled kernel cannot run (image too large)%s%s");
     if (P % 4 != 0 || ((uintptr_t)ri % 16) || ((uintptr_t)temp % 16) || ((uintptr_t)tm % 16))
         return set_err(RPCC_ERR_ARG, "fps_range brute-force path needs 16-byte aligned buffers and P %% 4 == 0%s%s");
     FpsTimer tmr(st);
@@ -944,10 +1120,11 @@ static int launch_fps_range(const float *ri, const float *tm, float *temp, const
 }
 
 extern "C" int rpcc_fps_range(const float *ri, const float *tm, float *temp, const int32_t *info, int B, int P, int M,
-                              int32_t *cen_pix, float *centers, void *ws, void *stream) {
+                              int32_t *cen_pix, float *centers, void *ws, const void *fps_table, void *stream) {
     ARG_TRY(B > 0 && P > 0 && M > 0 && ri && tm && temp && info && cen_pix && centers);
+    ARG_TRY(fps_table == nullptr || ws != nullptr);  // the table is only consumed by the tiled kernel
     return launch_fps_range(ri, tm, temp, info, B, P, M, cen_pix, centers, reinterpret_cast<float *>(ws),
-                            (hipStream_t)stream);
+                            reinterpret_cast<const float *>(fps_table), (hipStream_t)stream);
 }
 
 // ================================================================================================
@@ -987,7 +1164,8 @@ __global__ __launch_bounds__(256) void assign_kernel(const float *__restrict__ r
         const int row = (t / tcols) * 4 + (lane >> 4), col = (t % tcols) * 16 + (lane & 15);
         const bool valid = row < H && col < W;
         const int p = valid ? row * W + col : 0;
-        const float r = valid ? ri[(int64_t)b * P + p] : 0.0f;
+        float r = ri[(int64_t)b * P + p];
+        if (!valid) r = 0.0f;
         const float tx = tm[3 * p], ty = tm[3 * p + 1], tz = tm[3 * p + 2];
         const float x = r * tx, y = r * ty, z = r * tz;
         const bool live = valid && r != 0.0f;
@@ -1111,7 +1289,8 @@ extern "C" size_t rpcc_workspace_bytes(int B, int P, int M, int64_t total_points
     const size_t model_ws = ws_layout(nullptr, B, P, M).bytes;
     const size_t proj_ws = (project_scratch_bytes(total_points, B, P) + 255) & ~(size_t)255;  // carved after the model part
     return model_ws + 256 + proj_ws + (size_t)B * P * 4        // + FPS temp [B,P] f32
-           + (size_t)3 * P * 4 + 256;                           // + SoA copy of the ray table
+           + (size_t)3 * P * 4 + 256                            // + SoA copy of the ray table
+           + (size_t)B * FPS_TAB_ROWS * ((P + 63) / 64) * 4;    // + FPS tile table
 }
 
 __global__ __launch_bounds__(256) void model_hist_kernel(const float *__restrict__ ri, const uint8_t *__restrict__ seg,
@@ -1120,25 +1299,46 @@ __global__ __launch_bounds__(256) void model_hist_kernel(const float *__restrict
     extern __shared__ unsigned char smem_raw[];
     unsigned long long *ssum = reinterpret_cast<unsigned long long *>(smem_raw);  // [KP]
     uint32_t *scnt = reinterpret_cast<uint32_t *>(ssum + KP);                      // [KP]
-    const int b = blockIdx.y, t = blockIdx.x;
+    const int b = blockIdx.y, t = blockIdx.x, lane = threadIdx.x & 63;
     for (int k = threadIdx.x; k < KP; k += blockDim.x) { ssum[k] = 0ull; scnt[k] = 0u; }
     __syncthreads();
     bool inexact = false;
 #pragma unroll
     for (int j = 0; j < TILE / 256; j++) {
         const int p = t * TILE + j * 256 + threadIdx.x;
+        int todo = -1;
+        unsigned long long v = 0ull;
         if (p < P) {
             const int64_t gp = (int64_t)b * P + p;
-            const int lab = seg[gp];
-            atomicAdd(&scnt[lab], 1u);
-            if (lab >= 2) {
+            todo = seg[gp];
+            if (todo >= 2) {
                 const float r = ri[gp];
                 if (!(r >= 0.03125f && r < 256.0f)) inexact = true;
-                else atomicAdd(&ssum[lab], (unsigned long long)(long long)(r * 268435456.0f));  // exact: r * 2^28
+                else v = (unsigned long long)(long long)(r * 268435456.0f);  // exact: r * 2^28 < 2^36
             }
         }
+        // labels are spatially coherent: aggregate per distinct label of the wavefront (ballot + DPP sums),
+        // one LDS atomic pair per (wavefront, label) instead of one per pixel
+        while (true) {
+            const unsigned long long pending = __ballot(todo >= 0);
+            if (!pending) break;
+            const int leader = (int)__ffsll((long long)pending) - 1;
+            const int cur = __builtin_amdgcn_readlane(todo, leader);
+            const bool mine = todo == cur;
+            const unsigned long long same = __ballot(mine);
+            uint32_t lo = 0u, hi = 0u;
+            if (cur >= 2) {
+                lo = dpp_sum_u32(mine ? (uint32_t)(v & 0x3FFFFull) : 0u);
+                hi = dpp_sum_u32(mine ? (uint32_t)(v >> 18) : 0u);
+            }
+            if (lane == leader) {
+                atomicAdd(&scnt[cur], (uint32_t)__popcll(same));
+                if (cur >= 2) atomicAdd(&ssum[cur], (unsigned long long)lo + ((unsigned long long)hi << 18));
+            }
+            if (mine) todo = -1;
+        }
     }
-    if (__any(inexact) && (threadIdx.x & 63) == 0) flags[4 * b] = 1;
+    if (__any(inexact) && lane == 0) flags[4 * b] = 1;
     __syncthreads();
     for (int k = threadIdx.x; k < KP; k += blockDim.x) {
         hist[((int64_t)b * T + t) * KP + k] = scnt[k];
@@ -1153,15 +1353,22 @@ __global__ __launch_bounds__(256) void model_scan_kernel(const float *__restrict
                                                          const int32_t *__restrict__ flags, uint32_t *__restrict__ hist,
                                                          float *__restrict__ model, int32_t *__restrict__ counts,
                                                          int32_t *__restrict__ nnz) {
+    extern __shared__ uint32_t sh[];  // [T*KP] when it fits in LDS (use_lds), else unused
     __shared__ uint32_t tot[256];
     __shared__ uint32_t base[256];
     const int b = blockIdx.x, k = threadIdx.x, K = M + 2;
+    uint32_t *gh = hist + (int64_t)b * T * KP;
+    const bool use_lds = (size_t)T * KP * 4 <= 96 * 1024;
+    uint32_t *h = use_lds ? sh : gh;
+    if (use_lds) {  // coalesced copy in; the per-label walks below then run at LDS latency
+        for (int i = threadIdx.x; i < T * KP; i += blockDim.x) sh[i] = gh[i];
+        __syncthreads();
+    }
     uint32_t total = 0;
     if (k < K) {
-        uint32_t *h = hist + (int64_t)b * T * KP + k;
         for (int t = 0; t < T; t++) {
-            const uint32_t c = h[(int64_t)t * KP];
-            h[(int64_t)t * KP] = total;  // exclusive prefix over tiles (label base added below)
+            const uint32_t c = h[(int64_t)t * KP + k];
+            h[(int64_t)t * KP + k] = total;  // exclusive prefix over tiles (label base added below)
             total += c;
         }
     }
@@ -1174,10 +1381,13 @@ __global__ __launch_bounds__(256) void model_scan_kernel(const float *__restrict
     }
     __syncthreads();
     if (k < K) {
-        uint32_t *h = hist + (int64_t)b * T * KP + k;
         const uint32_t bs = base[k];
-        for (int t = 0; t < T; t++) h[(int64_t)t * KP] += bs;
+        for (int t = 0; t < T; t++) h[(int64_t)t * KP + k] += bs;
         if (counts) counts[(int64_t)b * K + k] = (int32_t)total;
+    }
+    if (use_lds) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < T * KP; i += blockDim.x) gh[i] = sh[i];
     }
     if (k < K && model != nullptr) {
         float *row = model + ((int64_t)b * K + k) * 4;
@@ -1206,6 +1416,11 @@ __global__ __launch_bounds__(256) void model_scan_kernel(const float *__restrict
     }
 }
 
+static size_t scan_lds_bytes(int P, int M) {
+    const size_t n = (size_t)ntiles(P) * kpad(M) * 4;
+    return n <= 96 * 1024 ? n : 0;
+}
+
 static int launch_point_model(const float *ri, const uint8_t *seg, const double *ground, int B, int P, int M,
                               float *model, int32_t *counts, int32_t *nnz, void *ws, hipStream_t st) {
     const int KP = kpad(M), T = ntiles(P);
@@ -1213,7 +1428,9 @@ static int launch_point_model(const float *ri, const uint8_t *seg, const double 
     HIP_TRY(hipMemsetAsync(L.sums, 0, (size_t)((char *)L.hist - (char *)L.sums), st));
     model_hist_kernel<<<dim3(T, B), 256, (size_t)KP * 12, st>>>(ri, seg, P, KP, T, L.sums, L.flags, L.hist);
     LAUNCH_CHECK();
-    model_scan_kernel<<<B, 256, 0, st>>>(ri, seg, ground, P, M, KP, T, L.sums, L.flags, L.hist, model, counts, nnz);
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&model_scan_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    model_scan_kernel<<<B, 256, scan_lds_bytes(P, M), st>>>(ri, seg, ground, P, M, KP, T, L.sums, L.flags, L.hist, model, counts, nnz);
     LAUNCH_CHECK();
     return RPCC_OK;
 }
@@ -1326,7 +1543,9 @@ extern "C" int rpcc_predict_quantize(const float *ri, const float *tm, const uin
     HIP_TRY(hipMemsetAsync(L.sums, 0, (size_t)((char *)L.hist - (char *)L.sums), st));
     model_hist_kernel<<<dim3(T, B), 256, (size_t)KP * 12, st>>>(ri, seg, P, KP, T, L.sums, L.flags, L.hist);
     LAUNCH_CHECK();
-    model_scan_kernel<<<B, 256, 0, st>>>(ri, seg, nullptr, P, M, KP, T, L.sums, L.flags, L.hist, nullptr, nullptr, nnz);
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&model_scan_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    model_scan_kernel<<<B, 256, scan_lds_bytes(P, M), st>>>(ri, seg, nullptr, P, M, KP, T, L.sums, L.flags, L.hist, nullptr, nullptr, nnz);
     LAUNCH_CHECK();
     return launch_predict_quantize(ri, tm, seg, model, acc, B, P, M, q16, q32, pred, ws, st);
 }
@@ -1352,9 +1571,15 @@ extern "C" int rpcc_compress_batch(const rpcc_batch_io *io, int B, rpcc_geom g, 
     if (fit_ground &&
         (rc = launch_ground_ransac(io->ri, io->tm, B, P, (uint32_t)io->ground_seed, false, io->ground, nullptr, st)))
         return rc;
-    if ((rc = launch_ground_mask(io->ri, io->tm, io->ground, ground_threshold, B, P, temp, io->info, st, false))) return rc;
     float *rays_soa = temp + (size_t)B * P;
-    if ((rc = launch_fps_range(io->ri, io->tm, temp, io->info, B, P, M, io->cen_pix, io->centers, rays_soa, st))) return rc;
+    float *tiletab = rays_soa + (size_t)3 * P + 64;
+    const bool tiled = !g_fps_force_v1 && (P + 63) / 64 <= FPS_TILED_MAX_TILES;
+    if ((rc = launch_ground_mask(io->ri, io->tm, io->ground, ground_threshold, B, P, temp, io->info,
+                                 tiled ? tiletab : nullptr, st, false)))
+        return rc;
+    if ((rc = launch_fps_range(io->ri, io->tm, temp, io->info, B, P, M, io->cen_pix, io->centers, rays_soa,
+                               tiled ? tiletab : nullptr, st)))
+        return rc;
     if ((rc = launch_assign(io->ri, io->tm, io->ground, io->centers, B, g.H, g.W, M, io->seg, st))) return rc;
     if ((rc = launch_point_model(io->ri, io->seg, io->ground, B, P, M, io->model, io->counts, io->nnz, ws, st))) return rc;
     return launch_predict_quantize(io->ri, io->tm, io->seg, io->model, acc, B, P, M, io->q16, nullptr, nullptr, ws, st);

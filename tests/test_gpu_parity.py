@@ -309,17 +309,36 @@ def test_fps_tiled_equals_bruteforce(env):
         offs[1:] = np.cumsum([f.shape[0] for f in frames])
         ri = ops.project(_to(env, np.concatenate(frames)), _to(env, offs), geom)
         gms = _to(env, np.tile(np.array([0.002, -0.004, -0.99999, -1.73]), (len(frames), 1)))
+        # one more frame whose first 64 pixels lie ON the ground plane: none of them is a candidate, so the
+        # "first FPS pass inside ground_mask" shortcut must decline (info[b][3] == 0) and fall back
+        if name == "Velodyne64E_2048":
+            pl = gms[0].cpu().numpy()
+            r_plane = (-pl[3] / (tm[0, :64].astype(np.float64) @ pl[:3])).astype(np.float32)
+            assert (r_plane > 0).all()
+            ri = torch.cat([ri, ri[:1].clone()], 0)
+            ri[-1, 0, :64] = _to(env, r_plane)
+            gms = torch.cat([gms, gms[:1]], 0)
         res = {}
-        for mode in (True, False):
-            ops.fps_force_bruteforce(mode)
+        for mode in ("brute", "tiled", "tiled+table"):
+            ops.fps_force_bruteforce(mode == "brute")
             try:
-                temp, info = ops.ground_mask(ri, _to(env, tm), gms, 0.1)
-                cen_pix, centers = ops.fps_range(ri, _to(env, tm), temp, info, 100)
+                if mode == "tiled+table":
+                    temp, info, tab = ops.ground_mask(ri, _to(env, tm), gms, 0.1, fps_table=True)
+                    flags = info[:, 3].cpu().numpy()
+                    assert flags[0] == 1
+                    if name == "Velodyne64E_2048":
+                        assert flags[-1] == 0
+                else:
+                    temp, info = ops.ground_mask(ri, _to(env, tm), gms, 0.1)
+                    tab = None
+                cen_pix, centers = ops.fps_range(ri, _to(env, tm), temp, info, 100, fps_table=tab)
                 res[mode] = (cen_pix.cpu().numpy(), centers.cpu().numpy(), temp.cpu().numpy())
             finally:
                 ops.fps_force_bruteforce(False)
-        for a, b in zip(res[True], res[False]):
-            assert _beq(a, b), name
+        for mode in ("tiled", "tiled+table"):
+            for a, b in zip(res["brute"], res[mode]):
+                assert _beq(a, b), (name, mode)
+        res[False] = res["tiled+table"]
         for i, f in enumerate(frames):
             o = orc.compress_frame(f, g, tm, gms[i].cpu().numpy())
             assert np.array_equal(res[False][0][i], o["fps_pix"])

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Developer tool: phase stamps (shader clock) of block 0 of the instrumented single-WG-per-frame kernels."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import rpcc_amd
+from rpcc_amd import ops, synth, _lib
+
+dev = torch.device("cuda:0")
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+H, W = 64, 2048
+hfov, vmax, vmin = 2*np.pi, 2.0*np.pi/180, -24.9*np.pi/180
+geom = ops.make_geom(H, W, hfov, vmax, vmin)
+tm = torch.from_numpy(ops.transform_map(H, W, hfov, vmax, vmin)).to(dev)
+xyz, offs = synth.make_batch(range(B), H, W, device=dev)
+ri = ops.project(xyz, offs, geom)
+stamps = torch.zeros(64, dtype=torch.int64, device=dev)
+for which in ("ransac", "fps"):
+    stamps.zero_()
+    _lib.check(_lib.lib().rpcc_debug_stamps(_lib.ptr(stamps)))
+    if which == "ransac":
+        g, inl = ops.ground_ransac(ri, tm, 0)
+    else:
+        temp, info = ops.ground_mask(ri, tm, g, 0.1)
+        ops.fps_range(ri, tm, temp, info, 100)
+    torch.cuda.synchronize()
+    _lib.lib().rpcc_debug_stamps(None)
+    s = stamps.cpu().numpy()
+    nz = np.flatnonzero(s)
+    print(which, "stamps (cycles since first, ~100MHz or shader clk):")
+    base = s[nz[0]] if len(nz) else 0
+    for i in nz:
+        print("   slot %2d: %10d" % (i, s[i] - base))
