@@ -133,6 +133,38 @@ int rpcc_predict_quantize(const float *ri, const float *tm, const uint8_t *seg, 
                           const int32_t *counts, float acc, int B, int P, int M, int16_t *q16, int32_t *q32,
                           int32_t *nnz, float *pred, void *ws, void *stream);
 
+/* ---- a3: back-projection as its own entry --------------------------------------------------- *
+ * replaces PCTransformer.range_image_to_point_cloud (dataset/transformer.py:94-101).
+ *   pc       dev f32 [B,P,3] out  ri[...,None] * transform_map                                     */
+int rpcc_backproject(const float *ri, const float *tm, int B, int P, float *pc, void *stream);
+
+/* ---- f1: contour map + index sequence --------------------------------------------------------- *
+ * replaces contour_utils_cpp.extract_contour (cpp_modules.cpp:521-558) and the casts/packing of
+ * compress_point_cloud (utils/compress_utils.py:156-160).
+ *   contour_bits dev u8  [B, ceil(P/8)] out  np.packbits(contour_map) (first pixel = MSB)
+ *   idx_sequence dev u16 [B,P]          out  labels at the contour positions, row-major; nseq[b] entries
+ *   ws           dev, rpcc_codec_workspace_bytes(B,P,M)                                            */
+size_t rpcc_codec_workspace_bytes(int B, int P, int M);
+int rpcc_contour_encode(const uint8_t *seg, int B, int H, int W, uint8_t *contour_bits, uint16_t *idx_sequence,
+                        int32_t *nseq, void *ws, void *stream);
+
+/* ---- f3: decoder ------------------------------------------------------------------------------- *
+ * rpcc_contour_decode replaces np.unpackbits + contour_utils_cpp.recover_map (cpp_modules.cpp:561-593,
+ * utils/compress_utils.py:202-206).
+ * rpcc_decode replaces QuantizationModule.dequantize_residual (utils/compress_utils.py:114-132),
+ * intra_predict, range_image_rec = pred + residual and range_image_to_point_cloud
+ * (tools/decompress.py:88-112).
+ *   q16        dev i16 [B,P]   label-ordered quantised residuals (as stored in the bitstream)
+ *   model      dev f32 [B,K,4] plane_param from the bitstream
+ *   level_acc  HOST f64 [max(levels,1)]  quantisation step(s): uniform -> levels = 0 and level_acc[0]
+ *   salience   dev u8 [B,K]    per-label level (non-uniform only)
+ *   ri_rec     dev f32 [B,P] out ;  pc_rec dev f32 [B,P,3] out (may be NULL)                        */
+int rpcc_contour_decode(const uint8_t *contour_bits, const uint16_t *idx_sequence, int B, int H, int W, uint8_t *seg,
+                        void *ws, void *stream);
+int rpcc_decode(const uint8_t *seg, const int16_t *q16, const float *model, const float *tm, const double *level_acc,
+                int levels, const uint8_t *salience, int B, int P, int M, float *ri_rec, float *pc_rec, void *ws,
+                void *stream);
+
 /* ---- fused batch entry: a2..a11 for B frames (uniform framework, FPS, point model) ----------- *
  * The batched counterpart of the body of tools/compress.py:93-125 /
  * tools/compress_datalist.py:91-125 with the ground model supplied by the caller. */

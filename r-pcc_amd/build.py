@@ -4,8 +4,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(_HERE, "csrc", "rpcc_hip.hip")
-DEPS = [SRC, os.path.join(_HERE, "csrc", "rpcc_device.h"),
-        os.path.join(os.path.dirname(_HERE), "include", "rpcc_hip.h")]
+DEPS = [os.path.join(_HERE, "csrc", f) for f in sorted(os.listdir(os.path.join(_HERE, "csrc")))] + \
+       [os.path.join(os.path.dirname(_HERE), "include", "rpcc_hip.h")]
 LIB = os.path.join(_HERE, "lib", "librpcc_hip.so")
 
 # -ffp-contract=off: the reference arithmetic is un-fused x86 SSE; a contracted FMA changes results.

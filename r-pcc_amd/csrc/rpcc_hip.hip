@@ -1311,7 +1311,7 @@ __global__ __launch_bounds__(256) void model_hist_kernel(const float *__restrict
         if (p < P) {
             const int64_t gp = (int64_t)b * P + p;
             todo = seg[gp];
-            if (todo >= 2) {
+            if (todo >= 2 && ri != nullptr) {
                 const float r = ri[gp];
                 if (!(r >= 0.03125f && r < 256.0f)) inexact = true;
                 else v = (unsigned long long)(long long)(r * 268435456.0f);  // exact: r * 2^28 < 2^36
@@ -1548,6 +1548,72 @@ extern "C" int rpcc_predict_quantize(const float *ri, const float *tm, const uin
     model_scan_kernel<<<B, 256, scan_lds_bytes(P, M), st>>>(ri, seg, nullptr, P, M, KP, T, L.sums, L.flags, L.hist, nullptr, nullptr, nnz);
     LAUNCH_CHECK();
     return launch_predict_quantize(ri, tm, seg, model, acc, B, P, M, q16, q32, pred, ws, st);
+}
+
+// ================================================================================================
+// f1 / f3  contour codec, decoder body, a3 as a stand-alone entry   (kernels: codec_kernels.h)
+// ================================================================================================
+#include "codec_kernels.h"
+
+extern "C" size_t rpcc_codec_workspace_bytes(int B, int P, int M) {
+    if (B <= 0 || P <= 0 || M <= 0) return 0;
+    return ws_layout(nullptr, B, P, M).bytes + 256 + (size_t)B * ntiles(P) * 4;
+}
+
+extern "C" int rpcc_contour_encode(const uint8_t *seg, int B, int H, int W, uint8_t *contour_bits, uint16_t *idx_sequence,
+                                   int32_t *nseq, void *ws, void *stream) {
+    ARG_TRY(B > 0 && H > 0 && W > 0 && seg && contour_bits && idx_sequence && nseq && ws);
+    hipStream_t st = (hipStream_t)stream;
+    const int P = H * W, T = ntiles(P);
+    uint32_t *tile_cnt = reinterpret_cast<uint32_t *>(ws);
+    contour_count_kernel<<<dim3(T, B), 256, 0, st>>>(seg, P, W, T, tile_cnt);
+    tile_scan_kernel<<<B, 256, 0, st>>>(tile_cnt, T, nseq);
+    contour_write_kernel<<<dim3(T, B), 256, 0, st>>>(seg, P, W, T, tile_cnt, contour_bits, idx_sequence);
+    LAUNCH_CHECK();
+    return RPCC_OK;
+}
+
+extern "C" int rpcc_contour_decode(const uint8_t *contour_bits, const uint16_t *idx_sequence, int B, int H, int W,
+                                   uint8_t *seg, void *ws, void *stream) {
+    ARG_TRY(B > 0 && H > 0 && W > 0 && seg && contour_bits && idx_sequence && ws);
+    hipStream_t st = (hipStream_t)stream;
+    const int P = H * W, T = ntiles(P);
+    uint32_t *tile_cnt = reinterpret_cast<uint32_t *>(ws);
+    contour_bits_count_kernel<<<dim3(T, B), 256, 0, st>>>(contour_bits, P, T, tile_cnt);
+    tile_scan_kernel<<<B, 256, 0, st>>>(tile_cnt, T, nullptr);
+    recover_map_kernel<<<dim3(T, B), 256, 0, st>>>(contour_bits, idx_sequence, P, T, tile_cnt, seg);
+    LAUNCH_CHECK();
+    return RPCC_OK;
+}
+
+extern "C" int rpcc_decode(const uint8_t *seg, const int16_t *q16, const float *model, const float *tm,
+                           const double *level_acc, int levels, const uint8_t *salience, int B, int P, int M,
+                           float *ri_rec, float *pc_rec, void *ws, void *stream) {
+    ARG_TRY(B > 0 && P > 0 && M > 0 && M <= RPCC_MAX_CLUSTERS && seg && q16 && model && tm && level_acc && ri_rec && ws);
+    ARG_TRY(levels >= 0 && levels <= 8 && (levels == 0 || salience != nullptr));
+    hipStream_t st = (hipStream_t)stream;
+    const int KP = kpad(M), T = ntiles(P);
+    WsLayout L = ws_layout(ws, B, P, M);
+    HIP_TRY(hipMemsetAsync(L.sums, 0, (size_t)((char *)L.hist - (char *)L.sums), st));
+    model_hist_kernel<<<dim3(T, B), 256, (size_t)KP * 12, st>>>(nullptr, seg, P, KP, T, L.sums, L.flags, L.hist);
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&model_scan_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    model_scan_kernel<<<B, 256, scan_lds_bytes(P, M), st>>>(nullptr, seg, nullptr, P, M, KP, T, L.sums, L.flags, L.hist,
+                                                            nullptr, nullptr, nullptr);
+    DecodeSteps steps;
+    steps.levels = levels;
+    for (int i = 0; i < 8; i++) steps.acc[i] = i < (levels ? levels : 1) ? level_acc[i] : 0.0;
+    const size_t sh = (size_t)KP * 4 * 4 + (size_t)16 * KP * 4;
+    decode_kernel<<<dim3(T, B), 256, sh, st>>>(seg, q16, model, tm, L.hist, salience, steps, P, M, KP, T, ri_rec, pc_rec);
+    LAUNCH_CHECK();
+    return RPCC_OK;
+}
+
+extern "C" int rpcc_backproject(const float *ri, const float *tm, int B, int P, float *pc, void *stream) {
+    ARG_TRY(B > 0 && P > 0 && ri && tm && pc);
+    backproject_kernel<<<dim3((P + 255) / 256, B), 256, 0, (hipStream_t)stream>>>(ri, tm, P, pc);
+    LAUNCH_CHECK();
+    return RPCC_OK;
 }
 
 // ================================================================================================

@@ -149,6 +149,58 @@ def predict_quantize(ri, tm, seg, model, acc, M, want_pred=False, int16=False, w
     return q, nnz, pred
 
 
+def backproject(ri, tm):
+    """a3: pc = ri[...,None] * transform_map -> f32 [B,H,W,3]."""
+    B = ri.shape[0]
+    P = ri[0].numel()
+    pc = torch.empty(tuple(ri.shape[:3]) + (3,), dtype=torch.float32, device=_dev(ri))
+    check(_lib.lib().rpcc_backproject(ptr(ri), ptr(tm), B, P, ptr(pc), stream()))
+    return pc
+
+
+def codec_workspace(B, P, M, device):
+    return torch.empty(_lib.lib().rpcc_codec_workspace_bytes(B, P, M), dtype=torch.uint8, device=device)
+
+
+def contour_encode(seg, M=DEFAULT_CLUSTERS, ws=None):
+    """f1: seg u8 [B,H,W] -> (contour_bits u8 [B,ceil(P/8)], idx_sequence u16 [B,P], nseq i32 [B])."""
+    B, H, W = seg.shape
+    P = H * W
+    ws = codec_workspace(B, P, M, _dev(seg)) if ws is None else ws
+    bits = torch.empty((B, (P + 7) // 8), dtype=torch.uint8, device=_dev(seg))
+    seq = torch.empty((B, P), dtype=torch.uint16, device=_dev(seg))
+    nseq = torch.empty((B,), dtype=torch.int32, device=_dev(seg))
+    check(_lib.lib().rpcc_contour_encode(ptr(seg), B, H, W, ptr(bits), ptr(seq), ptr(nseq), ptr(ws), stream()))
+    return bits, seq, nseq
+
+
+def contour_decode(bits, seq, H, W, M=DEFAULT_CLUSTERS, ws=None):
+    """f3: recover_map on the packed contour bits -> seg u8 [B,H,W]."""
+    B = bits.shape[0]
+    P = H * W
+    ws = codec_workspace(B, P, M, _dev(bits)) if ws is None else ws
+    seg = torch.empty((B, H, W), dtype=torch.uint8, device=_dev(bits))
+    check(_lib.lib().rpcc_contour_decode(ptr(bits), ptr(seq), B, H, W, ptr(seg), ptr(ws), stream()))
+    return seg
+
+
+def decode(seg, q16, model, tm, level_acc, salience=None, want_points=False, ws=None):
+    """f3: dequantise + predict + reconstruct.  level_acc: float (uniform) or sequence (non-uniform, with
+    salience u8 [B,K]).  -> (ri_rec f32 [B,H,W], pc_rec f32 [B,H,W,3] or None)."""
+    B, H, W = seg.shape
+    P = H * W
+    M = model.shape[1] - 2
+    ws = codec_workspace(B, P, M, _dev(seg)) if ws is None else ws
+    uniform = salience is None
+    acc = [float(level_acc)] if uniform else [float(a) for a in level_acc]
+    arr = (C.c_double * len(acc))(*acc)
+    rec = torch.empty((B, H, W), dtype=torch.float32, device=_dev(seg))
+    pc = torch.empty((B, H, W, 3), dtype=torch.float32, device=_dev(seg)) if want_points else None
+    check(_lib.lib().rpcc_decode(ptr(seg), ptr(q16), ptr(model), ptr(tm), arr, 0 if uniform else len(acc),
+                                 ptr(salience), B, P, M, ptr(rec), ptr(pc), ptr(ws), stream()))
+    return rec, pc
+
+
 class BatchBuffers:
     """Device buffers of one batch (B frames, one geometry), allocated once and reused."""
 

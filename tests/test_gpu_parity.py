@@ -401,3 +401,89 @@ def test_ground_ransac_matches_specification(env):
         n = int(buf.nnz[i])
         assert np.array_equal(buf.seg[i].cpu().numpy(), o["seg_idx"].astype(np.uint8))
         assert np.array_equal(buf.q16[i, :n].cpu().numpy(), o["q"].astype(np.int16))
+
+
+def _np_dequantize(q, seg, steps, salience=None):
+    """dequantize_residual, utils/compress_utils.py:114-132 (numpy, as the reference writes it)."""
+    residual = np.zeros_like(seg, dtype=np.float32)
+    start = 0
+    for m in range(int(seg.max()) + 1):
+        idx = np.where(seg == m)
+        if m == 1:
+            continue
+        cur = steps if salience is None else steps[salience[m]]
+        residual[idx] = q[start:start + idx[0].shape[0]] * cur
+        start += idx[0].shape[0]
+    assert start == q.shape[0]
+    return np.expand_dims(residual, -1)
+
+
+@pytest.mark.parametrize("case", sorted(MAN["cases"]))
+def test_contour_codec_and_decoder(env, case):
+    """f1: contour bits / index sequence == the reference payload; f3: recover_map, dequantise, predict,
+    reconstruct == the reference decoder arithmetic; reconstruction error <= accuracy."""
+    import hashlib
+    torch, ops, orc = env["torch"], env["ops"], env["orc"]
+    c = MAN["cases"][case]
+    z = np.load(os.path.join(HERE, "golden", case + ".npz"))
+    g, geom, tm = _geom(env, c["geom"])
+    seg_np = z["seg_idx"]
+    seg = _to(env, seg_np[None])
+    bits, seq, nseq = ops.contour_encode(seg)
+    n = int(nseq[0])
+    cm, sq = orc.extract_contour(seg_np.astype(np.int32))
+    assert n == sq.shape[0]
+    assert np.array_equal(bits[0].cpu().numpy(), np.packbits(cm.astype(bool), axis=None))
+    assert np.array_equal(seq[0, :n].cpu().numpy(), sq.astype(np.uint16))
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    assert sha(bits[0].cpu().numpy()) == c["sha"]["contour_map"]
+    assert sha(seq[0, :n].cpu().numpy()) == c["sha"]["idx_sequence"]
+    # decoder
+    seg_rec = ops.contour_decode(bits, seq, g.H, g.W)
+    assert np.array_equal(seg_rec[0].cpu().numpy(), seg_np)
+    mp32 = z["model_param"].astype(np.float32)
+    model = np.zeros((1, 102, 4), np.float32)
+    model[0, :mp32.shape[0]] = mp32
+    q = z["q_uniform"]
+    q_pad = np.zeros((1, g.H * g.W), np.int16)
+    q_pad[0, :q.shape[0]] = q
+    rec, pc = ops.decode(seg_rec, _to(env, q_pad), _to(env, model), _to(env, tm), 0.04, want_points=True)
+    pred = orc.intra_predict(seg_np.astype(np.int32), mp32, tm)
+    exp = pred + _np_dequantize(q, seg_np, 0.04)
+    assert _beq(rec[0].cpu().numpy().reshape(g.H, g.W, 1), exp)
+    assert _beq(pc[0].cpu().numpy(), exp * tm)
+    ri = orc.project(z["xyz"], g)
+    err = np.abs(rec[0].cpu().numpy() - ri)[ri != 0]
+    assert err.max() <= 0.02 + 1e-5
+    # non-uniform steps
+    sal = z["salience"]
+    salp = np.zeros((1, 102), np.uint8)
+    salp[0, :sal.shape[0]] = sal
+    steps = np.array([0.04] * 4) + np.array([0, 0.02, 0.04, 0.06])
+    qn = z["q_nonuniform"]
+    qn_pad = np.zeros((1, g.H * g.W), np.int16)
+    qn_pad[0, :qn.shape[0]] = qn
+    rec_n, _ = ops.decode(seg_rec, _to(env, qn_pad), _to(env, model), _to(env, tm), steps, salience=_to(env, salp))
+    exp_n = pred + _np_dequantize(qn, seg_np, steps, sal)
+    assert _beq(rec_n[0].cpu().numpy().reshape(g.H, g.W, 1), exp_n)
+    # a3 entry
+    assert _beq(ops.backproject(_to(env, ri[None]), _to(env, tm))[0].cpu().numpy(), orc.backproject(ri, tm))
+
+
+def test_contour_codec_ragged_rows(env):
+    """Widths that are not multiples of 8 / 64 / 1024 and the reference's own known-answer vector."""
+    torch, ops, orc = env["torch"], env["ops"], env["orc"]
+    k = MAN["contour_kat"]
+    rng = np.random.default_rng(12)
+    maps = [np.array(k["idx_map"], np.uint8)]
+    for (h, w) in [(3, 5), (7, 13), (16, 1800), (5, 1031), (64, 2000)]:
+        maps.append(np.repeat(rng.integers(0, 102, (h, (w + 6) // 7)), 7, axis=1)[:, :w].astype(np.uint8))
+    for mp in maps:
+        seg = _to(env, mp[None])
+        bits, seq, nseq = ops.contour_encode(seg)
+        cm, sq = orc.extract_contour(mp.astype(np.int32))
+        n = int(nseq[0])
+        assert n == sq.shape[0] and np.array_equal(seq[0, :n].cpu().numpy(), sq.astype(np.uint16)), mp.shape
+        assert np.array_equal(bits[0].cpu().numpy(), np.packbits(cm.astype(bool), axis=None)), mp.shape
+        assert np.array_equal(ops.contour_decode(bits, seq, mp.shape[0], mp.shape[1])[0].cpu().numpy(), mp), mp.shape
+    assert orc.extract_contour(np.array(k["idx_map"]))[1].tolist() == k["idx_sequence"]
