@@ -120,18 +120,42 @@ int rpcc_assign(const float *ri, const float *tm, const double *ground, const fl
 int rpcc_point_model(const float *ri, const uint8_t *seg, const double *ground, int B, int P, int M, float *model,
                      int32_t *counts, void *ws, void *stream);
 
-/* ---- a10+a11: intra-prediction + residual + uniform quantisation + ordered scatter ----------- *
+/* ---- a10+a11(+a13): intra-prediction + residual + quantisation + ordered scatter ------------- *
  * replaces segment_utils_cpp.intra_predict (cpp_modules.cpp:248-285), residual = ri - pred
- * (tools/compress.py:106) and quantization_utils_cpp.uniform_quantize (cpp_modules.cpp:288-334).
- *   acc      quantisation step (= 2*accuracy, tools/compress.py:46) as C float
- *   q16      dev i16 [B,P] out   per frame: nnz values grouped by label ascending, row-major inside
- *                                a label, already cast to int16 (utils/compress_utils.py:142)
- *   q32      dev i32 [B,P] out   same as int32 (what uniform_quantize returns); either may be NULL
- *   nnz      dev i32 [B]   out
- *   pred     dev f32 [B,P] out   optional (NULL to skip)                                           */
+ * (tools/compress.py:106), quantization_utils_cpp.uniform_quantize (cpp_modules.cpp:288-334) and the
+ * quantising half of nonuniform_quantize (cpp_modules.cpp:404-422).
+ *   acc         quantisation step (= 2*accuracy, tools/compress.py:46) as C float (uniform)
+ *   label_acc   dev f32 [B,K] per-label step from rpcc_salience (non-uniform), or NULL
+ *   residual_in dev f32 [B,P] residual supplied by the caller (QuantizationModule.quantize_residual's
+ *               own argument, utils/compress_utils.py:57), or NULL to compute ri - pred here
+ *   q16         dev i16 [B,P] out   per frame: nnz values grouped by label ascending, row-major inside
+ *                                   a label, already cast to int16 (utils/compress_utils.py:142)
+ *   q32         dev i32 [B,P] out   same as int32 (what the quantisers return); either may be NULL
+ *   nnz         dev i32 [B]   out
+ *   pred        dev f32 [B,P] out   optional (NULL to skip)                                          */
 int rpcc_predict_quantize(const float *ri, const float *tm, const uint8_t *seg, const float *model,
-                          const int32_t *counts, float acc, int B, int P, int M, int16_t *q16, int32_t *q32,
-                          int32_t *nnz, float *pred, void *ws, void *stream);
+                          const float *label_acc, const float *residual_in, float acc, int B, int P, int M,
+                          int16_t *q16, int32_t *q32, int32_t *nnz, float *pred, void *ws, void *stream);
+
+/* a10 alone: segment_utils_cpp.intra_predict (cpp_modules.cpp:248-285) -> pred dev f32 [B,P]. */
+int rpcc_intra_predict(const uint8_t *seg, const float *model, const float *tm, int B, int P, int M, float *pred,
+                       void *stream);
+
+/* ---- a12: key points ---------------------------------------------------------------------------- *
+ * replaces feature_extractor_cpp.extract_features_with_segment (cpp_modules.cpp:28-121, mark_as_picked
+ * :10-25) with zero-initialised outputs (the reference leaves unwritten cells uninitialised).
+ *   feat          dev f32 [B,H,W] out   curvature feature
+ *   key_point_map dev u8  [B,H,W] out   0 none, 1 flat, 2 less sharp, 3 sharp                         */
+int rpcc_extract_features(const float *ri, const uint8_t *seg, int B, int H, int W, int feature_region, int segments,
+                          int sharp_num, int less_sharp_num, int flat_num, float *feat, uint8_t *key_point_map,
+                          void *stream);
+
+/* ---- a13: salience levels ------------------------------------------------------------------------ *
+ * replaces the per-label level selection of nonuniform_quantize (cpp_modules.cpp:355-405).
+ *   level_kp_num HOST i32 [levels], level_acc HOST f32 [levels]  (base step + delta, compress_utils.py:48)
+ *   salience   dev u8  [B,K] out   level per label;  label_acc dev f32 [B,K] out  its step            */
+int rpcc_salience(const uint8_t *seg, const uint8_t *key_point_map, const int32_t *level_kp_num, const float *level_acc,
+                  int levels, int ground_level, int B, int P, int M, uint8_t *salience, float *label_acc, void *stream);
 
 /* ---- a3: back-projection as its own entry --------------------------------------------------- *
  * replaces PCTransformer.range_image_to_point_cloud (dataset/transformer.py:94-101).

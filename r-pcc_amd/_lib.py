@@ -41,7 +41,10 @@ _SIGS = {
     "rpcc_fps_force_bruteforce": (None, [_I]),
     "rpcc_assign": (C.c_int, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP]),
     "rpcc_point_model": (C.c_int, [_VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP]),
-    "rpcc_predict_quantize": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _F, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "rpcc_predict_quantize": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _F, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "rpcc_intra_predict": (C.c_int, [_VP, _VP, _VP, _I, _I, _I, _VP, _VP]),
+    "rpcc_extract_features": (C.c_int, [_VP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _VP, _VP, _VP]),
+    "rpcc_salience": (C.c_int, [_VP, _VP, C.POINTER(C.c_int32), C.POINTER(C.c_float), _I, _I, _I, _I, _I, _VP, _VP, _VP]),
     "rpcc_backproject": (C.c_int, [_VP, _VP, _I, _I, _VP, _VP]),
     "rpcc_codec_workspace_bytes": (C.c_size_t, [_I, _I, _I]),
     "rpcc_contour_encode": (C.c_int, [_VP, _I, _I, _I, _VP, _VP, _VP, _VP, _VP]),

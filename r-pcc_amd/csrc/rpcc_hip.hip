@@ -1451,7 +1451,9 @@ extern "C" int rpcc_point_model(const float *ri, const uint8_t *seg, const doubl
 __global__ __launch_bounds__(256) void predict_quantize_kernel(const float *__restrict__ ri, const float *__restrict__ tm,
                                                                const uint8_t *__restrict__ seg,
                                                                const float *__restrict__ model,
-                                                               const uint32_t *__restrict__ hist, float acc, int P, int M,
+                                                               const uint32_t *__restrict__ hist, float acc,
+                                                               const float *__restrict__ label_acc,
+                                                               const float *__restrict__ residual_in, int P, int M,
                                                                int KP, int T, int16_t *__restrict__ q16,
                                                                int32_t *__restrict__ q32, float *__restrict__ pred_out) {
     extern __shared__ unsigned char smem_raw[];
@@ -1478,8 +1480,9 @@ __global__ __launch_bounds__(256) void predict_quantize_kernel(const float *__re
             if (p0 + p1 + p2 == 0.0f) pr = p3;                                        // cpp_modules.cpp:271-272
             else pr = -p3 / (p0 * tm[3 * p] + p1 * tm[3 * p + 1] + p2 * tm[3 * p + 2]);  // :275-277
             if (pred_out) pred_out[gp] = pr;
-            const float res = r - pr;                                                 // compress.py:106
-            qv[j] = (int)roundf(res / acc);                                           // cpp_modules.cpp:315
+            const float res = residual_in ? residual_in[gp] : r - pr;                 // compress.py:106
+            const float step = label_acc ? label_acc[(int64_t)b * K + l] : acc;       // cpp_modules.cpp:404,419
+            qv[j] = (int)roundf(res / step);                                          // cpp_modules.cpp:315
             lab[j] = (l == 1) ? -1 : l;                                               // label 1 is skipped (:314)
         }
         // rank among equal labels inside this 64-pixel segment
@@ -1519,22 +1522,22 @@ __global__ __launch_bounds__(256) void predict_quantize_kernel(const float *__re
 }
 
 static int launch_predict_quantize(const float *ri, const float *tm, const uint8_t *seg, const float *model, float acc,
-                                   int B, int P, int M, int16_t *q16, int32_t *q32, float *pred, void *ws,
-                                   hipStream_t st) {
+                                   const float *label_acc, const float *residual_in, int B, int P, int M, int16_t *q16,
+                                   int32_t *q32, float *pred, void *ws, hipStream_t st) {
     const int KP = kpad(M), T = ntiles(P);
     WsLayout L = ws_layout(ws, B, P, M);
     const size_t sh = (size_t)KP * 4 * 4 + (size_t)16 * KP * 4;
-    predict_quantize_kernel<<<dim3(T, B), 256, sh, st>>>(ri, tm, seg, model, L.hist, acc, P, M, KP, T, q16, q32, pred);
+    predict_quantize_kernel<<<dim3(T, B), 256, sh, st>>>(ri, tm, seg, model, L.hist, acc, label_acc, residual_in, P, M, KP,
+                                                         T, q16, q32, pred);
     LAUNCH_CHECK();
     return RPCC_OK;
 }
 
 extern "C" int rpcc_predict_quantize(const float *ri, const float *tm, const uint8_t *seg, const float *model,
-                                     const int32_t *counts, float acc, int B, int P, int M, int16_t *q16, int32_t *q32,
-                                     int32_t *nnz, float *pred, void *ws, void *stream) {
+                                     const float *label_acc, const float *residual_in, float acc, int B, int P, int M,
+                                     int16_t *q16, int32_t *q32, int32_t *nnz, float *pred, void *ws, void *stream) {
     ARG_TRY(B > 0 && P > 0 && M > 0 && M <= RPCC_MAX_CLUSTERS && ri && tm && seg && model && ws);
     ARG_TRY(q16 || q32);
-    (void)counts;
     hipStream_t st = (hipStream_t)stream;
     // Self-contained entry: the tile offsets are rebuilt from this segmentation (histogram + scan with
     // no model output); the model rows are the caller's (point or plane models).
@@ -1547,7 +1550,7 @@ extern "C" int rpcc_predict_quantize(const float *ri, const float *tm, const uin
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     model_scan_kernel<<<B, 256, scan_lds_bytes(P, M), st>>>(ri, seg, nullptr, P, M, KP, T, L.sums, L.flags, L.hist, nullptr, nullptr, nnz);
     LAUNCH_CHECK();
-    return launch_predict_quantize(ri, tm, seg, model, acc, B, P, M, q16, q32, pred, ws, st);
+    return launch_predict_quantize(ri, tm, seg, model, acc, label_acc, residual_in, B, P, M, q16, q32, pred, ws, st);
 }
 
 // ================================================================================================
@@ -1617,6 +1620,54 @@ extern "C" int rpcc_backproject(const float *ri, const float *tm, int B, int P, 
 }
 
 // ================================================================================================
+// a12 / a13  non-uniform framework: key points and salience levels   (kernels: feature_kernels.h)
+// ================================================================================================
+#include "feature_kernels.h"
+
+extern "C" int rpcc_extract_features(const float *ri, const uint8_t *seg, int B, int H, int W, int feature_region,
+                                     int segments, int sharp_num, int less_sharp_num, int flat_num, float *feat,
+                                     uint8_t *key_point_map, void *stream) {
+    ARG_TRY(B > 0 && H > 0 && W > 0 && ri && seg && feat && key_point_map);
+    ARG_TRY(feature_region >= 1 && feature_region <= 16 && segments >= 1 && W < 65536);
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n = (int64_t)B * H * W;
+    HIP_TRY(hipMemsetAsync(feat, 0, (size_t)n * 4, st));
+    HIP_TRY(hipMemsetAsync(key_point_map, 0, (size_t)n, st));
+    int NS = 64;
+    while (NS < (W + segments - 1) / segments) NS <<= 1;
+    const size_t sh = (size_t)(3 * W + (W & 1)) * 4 + (size_t)NS * 8 + (size_t)W * 2 + (size_t)W + 16;
+    ARG_TRY(sh <= 160 * 1024);
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&features_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+    FeatParams fp = {feature_region, segments, sharp_num, less_sharp_num, flat_num};
+    features_kernel<<<dim3(H, B), 64, sh, st>>>(ri, seg, H, W, NS, fp, feat, key_point_map);
+    LAUNCH_CHECK();
+    return RPCC_OK;
+}
+
+extern "C" int rpcc_salience(const uint8_t *seg, const uint8_t *key_point_map, const int32_t *level_kp_num,
+                             const float *level_acc, int levels, int ground_level, int B, int P, int M,
+                             uint8_t *salience, float *label_acc, void *stream) {
+    ARG_TRY(B > 0 && P > 0 && M > 0 && M <= RPCC_MAX_CLUSTERS && seg && key_point_map && salience && label_acc);
+    ARG_TRY(level_kp_num && level_acc && levels >= 1 && levels <= 8 && ground_level >= 0 && ground_level < levels);
+    SalienceParams sp;
+    for (int i = 0; i < 8; i++) { sp.level_kp_num[i] = i < levels ? level_kp_num[i] : 0; sp.level_acc[i] = i < levels ? level_acc[i] : 0.f; }
+    sp.levels = levels;
+    sp.ground_level = ground_level;
+    salience_kernel<<<B, 256, 0, (hipStream_t)stream>>>(seg, key_point_map, P, M, sp, salience, label_acc);
+    LAUNCH_CHECK();
+    return RPCC_OK;
+}
+
+extern "C" int rpcc_intra_predict(const uint8_t *seg, const float *model, const float *tm, int B, int P, int M, float *pred,
+                                  void *stream) {
+    ARG_TRY(B > 0 && P > 0 && M > 0 && seg && model && tm && pred);
+    intra_predict_kernel<<<dim3((P + 255) / 256, B), 256, 0, (hipStream_t)stream>>>(seg, model, tm, P, M + 2, pred);
+    LAUNCH_CHECK();
+    return RPCC_OK;
+}
+
+// ================================================================================================
 // fused batch entry (uniform framework, FPS segmentation, point model): a2 .. a11
 // ================================================================================================
 extern "C" int rpcc_compress_batch(const rpcc_batch_io *io, int B, rpcc_geom g, int M, double ground_threshold,
@@ -1648,5 +1699,6 @@ extern "C" int rpcc_compress_batch(const rpcc_batch_io *io, int B, rpcc_geom g, 
         return rc;
     if ((rc = launch_assign(io->ri, io->tm, io->ground, io->centers, B, g.H, g.W, M, io->seg, st))) return rc;
     if ((rc = launch_point_model(io->ri, io->seg, io->ground, B, P, M, io->model, io->counts, io->nnz, ws, st))) return rc;
-    return launch_predict_quantize(io->ri, io->tm, io->seg, io->model, acc, B, P, M, io->q16, nullptr, nullptr, ws, st);
+    return launch_predict_quantize(io->ri, io->tm, io->seg, io->model, acc, nullptr, nullptr, B, P, M, io->q16, nullptr,
+                                   nullptr, ws, st);
 }

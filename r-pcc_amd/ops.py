@@ -136,17 +136,54 @@ def point_model(ri, seg, ground, M, ws=None):
     return model, counts
 
 
-def predict_quantize(ri, tm, seg, model, acc, M, want_pred=False, int16=False, ws=None):
+def predict_quantize(ri, tm, seg, model, acc, M, want_pred=False, int16=False, ws=None, label_acc=None,
+                     residual=None):
+    """a10+a11(+a13).  label_acc f32 [B,K]: per-label steps (non-uniform); residual f32 [B,P]: use this
+    residual instead of ri - pred.  -> (q [B,P] label-ordered, nnz [B], pred or None)."""
     B = ri.shape[0]
     P = ri[0].numel()
     ws = workspace(B, P, M, _dev(ri)) if ws is None else ws
     q = torch.zeros((B, P), dtype=torch.int16 if int16 else torch.int32, device=_dev(ri))
     nnz = torch.empty((B,), dtype=torch.int32, device=_dev(ri))
     pred = torch.empty((B, P), dtype=torch.float32, device=_dev(ri)) if want_pred else None
-    check(_lib.lib().rpcc_predict_quantize(ptr(ri), ptr(tm), ptr(seg), ptr(model), None, float(acc), B, P, M,
-                                           ptr(q) if int16 else None, None if int16 else ptr(q), ptr(nnz), ptr(pred),
-                                           ptr(ws), stream()))
+    check(_lib.lib().rpcc_predict_quantize(ptr(ri), ptr(tm), ptr(seg), ptr(model), ptr(label_acc), ptr(residual),
+                                           float(acc), B, P, M, ptr(q) if int16 else None,
+                                           None if int16 else ptr(q), ptr(nnz), ptr(pred), ptr(ws), stream()))
     return q, nnz, pred
+
+
+def intra_predict(seg, model, tm):
+    """a10 alone -> pred f32 [B,H,W]."""
+    B = seg.shape[0]
+    P = seg[0].numel()
+    pred = torch.empty(tuple(seg.shape), dtype=torch.float32, device=_dev(seg))
+    check(_lib.lib().rpcc_intra_predict(ptr(seg), ptr(model), ptr(tm), B, P, model.shape[1] - 2, ptr(pred), stream()))
+    return pred
+
+
+def extract_features(ri, seg, feature_region=3, segments=8, sharp_num=4, less_sharp_num=8, flat_num=6):
+    """a12 -> (feat f32 [B,H,W], key_point_map u8 [B,H,W])."""
+    B, H, W = seg.shape
+    feat = torch.empty((B, H, W), dtype=torch.float32, device=_dev(seg))
+    kp = torch.empty((B, H, W), dtype=torch.uint8, device=_dev(seg))
+    check(_lib.lib().rpcc_extract_features(ptr(ri), ptr(seg), B, H, W, feature_region, segments, sharp_num,
+                                           less_sharp_num, flat_num, ptr(feat), ptr(kp), stream()))
+    return feat, kp
+
+
+def salience(seg, kp, level_kp_num, level_acc, ground_level, M):
+    """a13 (levels) -> (salience u8 [B,K], label_acc f32 [B,K])."""
+    B = seg.shape[0]
+    P = seg[0].numel()
+    K = M + 2
+    L = len(level_kp_num)
+    lk = (C.c_int32 * L)(*[int(x) for x in level_kp_num])
+    la = (C.c_float * L)(*[float(x) for x in level_acc])
+    sal = torch.empty((B, K), dtype=torch.uint8, device=_dev(seg))
+    lacc = torch.empty((B, K), dtype=torch.float32, device=_dev(seg))
+    check(_lib.lib().rpcc_salience(ptr(seg), ptr(kp), lk, la, L, int(ground_level), B, P, M, ptr(sal), ptr(lacc),
+                                   stream()))
+    return sal, lacc
 
 
 def backproject(ri, tm):

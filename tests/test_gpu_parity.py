@@ -487,3 +487,57 @@ def test_contour_codec_ragged_rows(env):
         assert np.array_equal(bits[0].cpu().numpy(), np.packbits(cm.astype(bool), axis=None)), mp.shape
         assert np.array_equal(ops.contour_decode(bits, seq, mp.shape[0], mp.shape[1])[0].cpu().numpy(), mp), mp.shape
     assert orc.extract_contour(np.array(k["idx_map"]))[1].tolist() == k["idx_sequence"]
+
+
+@pytest.mark.parametrize("case", sorted(MAN["cases"]))
+def test_nonuniform_framework(env, case):
+    """a12 key points, a13 salience levels + per-label quantisation == the reference C++ run with a
+    zero-initialised key point map (golden q_nonuniform / salience / key_point_map)."""
+    torch, ops, orc = env["torch"], env["ops"], env["orc"]
+    c = MAN["cases"][case]
+    z = np.load(os.path.join(HERE, "golden", case + ".npz"))
+    g, geom, tm = _geom(env, c["geom"])
+    ri_np = orc.project(z["xyz"], g)
+    seg_np = z["seg_idx"]
+    ri, seg = _to(env, ri_np[None]), _to(env, seg_np[None])
+    feat, kp = ops.extract_features(ri, seg)
+    feat_o, kp_o = orc.extract_features_with_segment(ri_np, seg_np.astype(np.int32))
+    assert np.array_equal(kp[0].cpu().numpy(), z["key_point_map"])
+    assert np.array_equal(kp[0].cpu().numpy(), kp_o.astype(np.uint8))
+    assert _beq(feat[0].cpu().numpy(), feat_o)
+    lacc = (np.array([0.04] * 4) + np.array([0, 0.02, 0.04, 0.06])).astype(np.float32)
+    sal, label_acc = ops.salience(seg, kp, [30, 10, 3, 0], lacc, 2, 100)
+    nrow = z["salience"].shape[0]
+    assert np.array_equal(sal[0, :nrow].cpu().numpy(), z["salience"])
+    mp = np.zeros((1, 102, 4), np.float32)
+    mp[0, :nrow] = z["model_param"].astype(np.float32)
+    q, nnz, _ = ops.predict_quantize(ri, _to(env, tm), seg, _to(env, mp), 0.04, 100, int16=True, label_acc=label_acc)
+    n = int(nnz[0])
+    assert n == z["q_nonuniform"].shape[0]
+    assert np.array_equal(q[0, :n].cpu().numpy(), z["q_nonuniform"])
+    # the quantiser's own seam: residual handed in by the caller (utils/compress_utils.py:57)
+    pred = ops.intra_predict(seg, _to(env, mp), _to(env, tm))
+    assert _beq(pred[0].cpu().numpy().reshape(g.H, g.W, 1), orc.intra_predict(seg_np.astype(np.int32), mp[0], tm))
+    res = (ri - pred).reshape(1, -1).contiguous()
+    q2, _, _ = ops.predict_quantize(ri, _to(env, tm), seg, _to(env, mp), 0.04, 100, residual=res)
+    assert np.array_equal(q2[0, :n].cpu().numpy().astype(np.int16), z["q_uniform"])
+
+
+def test_features_edge_rows(env):
+    """Rows with too few valid pixels are skipped; ties in curvature; gaps trigger the occlusion gate;
+    odd widths."""
+    torch, ops, orc = env["torch"], env["ops"], env["orc"]
+    rng = np.random.default_rng(15)
+    for (H, W) in [(8, 301), (16, 1800), (4, 64), (3, 2250)]:
+        seg = np.repeat(rng.integers(0, 20, (H, (W + 4) // 5)), 5, axis=1)[:, :W].astype(np.uint8)
+        ri = (15 + 4 * np.sin(np.arange(W) / 9.0)[None, :] + rng.normal(0, 0.03, (H, W))).astype(np.float32)
+        ri[:, ::53] += 2.5
+        ri[0, :] = 20.0                       # constant row: every curvature is exactly 0
+        seg[1, :] = 0                         # no valid pixel at all
+        seg[2, 10:] = 1                       # fewer than segments + 2*fr + 1 valid pixels
+        ri[seg == 1] = 0
+        feat, kp = ops.extract_features(_to(env, ri[None]), _to(env, seg[None]))
+        f_o, k_o = orc.extract_features_with_segment(ri, seg.astype(np.int32))
+        assert np.array_equal(kp[0].cpu().numpy(), k_o.astype(np.uint8)), (H, W)
+        assert _beq(feat[0].cpu().numpy(), f_o), (H, W)
+        assert k_o.max() >= 1
