@@ -273,3 +273,40 @@ def compress_batch(xyz, offsets, tm, ground, buf, ground_threshold=0.1, acc=0.04
     check(_lib.lib().rpcc_compress_batch(C.byref(io), buf.B, buf.geom, buf.M, float(ground_threshold), float(acc),
                                          ptr(buf.ws), stream()))
     return buf
+
+
+def compress_batch_general(xyz, offsets, tm, ground, buf, cc, fit_ground):
+    """Stage-by-stage batch path for the configurations the fused entry does not cover (non-uniform
+    framework and / or plane model).  `cc` is a pipeline.BatchCompressor (settings holder).  Fills `buf`
+    like compress_batch and returns the salience levels u8 [B,K] (None for the uniform framework)."""
+    B, M, geom = buf.B, buf.M, buf.geom
+    project(xyz, offsets, geom, ri=buf.ri)
+    if fit_ground:
+        g, _ = ground_ransac(buf.ri, tm, seed=cc.seed)
+        ground.copy_(g)
+    temp, info, tab = ground_mask(buf.ri, tm, ground, cc.ground_threshold, fps_table=True)
+    buf.info.copy_(info)
+    cen_pix, centers = fps_range(buf.ri, tm, temp, info, M, fps_table=tab)
+    buf.cen_pix.copy_(cen_pix)
+    buf.centers.copy_(centers)
+    seg = assign(buf.ri, tm, ground, centers)
+    buf.seg.copy_(seg)
+    if cc.model_method == "point":
+        model, counts = point_model(buf.ri, buf.seg, ground, M, ws=buf.ws)
+    else:
+        model, counts = plane_model(buf.ri, tm, buf.seg, M, angle_threshold=cc.cfg.get("plane_angle_threshold", 75),
+                                    seed=cc.seed, ground=ground, want_counts=True)
+    buf.model.copy_(model)
+    buf.counts.copy_(counts)
+    sal = label_acc = None
+    if not cc.uniform:
+        c = cc.cfg
+        _, kp = extract_features(buf.ri, buf.seg, c.get("feature_region", 3), c.get("segments", 8), c.get("sharp_num", 4),
+                                 c.get("less_sharp_num", 8), c.get("flat_num", 6))
+        lk = c.get("level_key_point_num", (30, 10, 3, 0))
+        la = np.array([cc.acc] * len(lk)) + np.array(c.get("level_delta_acc", (0, 0.02, 0.04, 0.06)))
+        sal, label_acc = salience(buf.seg, kp, lk, la.astype(np.float32), c.get("ground_salience_level", 2), M)
+    q, nnz, _ = predict_quantize(buf.ri, tm, buf.seg, buf.model, cc.acc, M, int16=True, ws=buf.ws, label_acc=label_acc)
+    buf.q16.copy_(q)
+    buf.nnz.copy_(nnz)
+    return sal

@@ -1,0 +1,72 @@
+"""Batched front-end: B frames of one lidar geometry through the fused HIP entry, then the host-side
+payload assembly (casts, container, entropy coder) of the reference's compress_point_cloud /
+save_compressed_bitstream.  This is the counterpart of the closure body of
+tools/compress_datalist.py:91-142 for a whole batch at once."""
+import numpy as np
+import torch
+
+from . import ops
+from .compress_utils import BasicCompressor, pack_bitstream
+
+
+class BatchCompressor:
+    def __init__(self, transformer, cluster_num=100, accuracy=0.02, ground_threshold=0.1, uniform=True,
+                 model_method="point", compressor_cfg=None, basic_compressor="bzip2", device=None, seed=0):
+        self.T = transformer
+        self.device = torch.device(device) if device is not None else transformer.device
+        self.M = int(cluster_num)
+        self.acc = accuracy * 2                     # tools/compress.py:46
+        self.ground_threshold = ground_threshold
+        self.uniform = uniform
+        self.model_method = model_method
+        self.cfg = compressor_cfg or {}
+        self.bc = BasicCompressor(method_name=basic_compressor)
+        self.seed = int(seed)
+        self._buf = None
+        self._codec_ws = None
+
+    def _buffers(self, B):
+        if self._buf is None or self._buf.B != B:
+            self._buf = ops.BatchBuffers(B, self.T.geom, self.M, self.device)
+            self._codec_ws = ops.codec_workspace(B, self.T.H * self.T.W, self.M, self.device)
+        return self._buf
+
+    def compress_device(self, xyz, offsets, ground=None):
+        """Device part.  xyz f32 [sum N,3], offsets i64 [B+1] on the device.  Returns the BatchBuffers plus
+        contour bits / index sequences (and salience for the non-uniform framework), all still in HBM."""
+        B = offsets.numel() - 1
+        buf = self._buffers(B)
+        fit = ground is None
+        g = torch.zeros((B, 4), dtype=torch.float64, device=self.device) if fit else ground
+        if self.uniform and self.model_method == "point":
+            ops.compress_batch(xyz, offsets, self.T.tm_dev, g, buf, self.ground_threshold, self.acc,
+                               ground_seed=self.seed if fit else -1)
+            sal = None
+        else:
+            sal = ops.compress_batch_general(xyz, offsets, self.T.tm_dev, g, buf, self, fit)
+        bits, seq, nseq = ops.contour_encode(buf.seg, self.M, ws=self._codec_ws)
+        return buf, g, bits, seq, nseq, sal
+
+    def compress(self, frames, ground=None):
+        """frames: list of [N,3] arrays.  -> list of .rpcc byte strings (one per frame)."""
+        offs = np.zeros(len(frames) + 1, np.int64)
+        offs[1:] = np.cumsum([f.shape[0] for f in frames])
+        xyz = torch.from_numpy(np.ascontiguousarray(np.concatenate([f[:, :3] for f in frames]), dtype=np.float32)).to(self.device)
+        gnd = None if ground is None else torch.from_numpy(np.asarray(ground, np.float64).reshape(-1, 4)).to(self.device)
+        buf, g, bits, seq, nseq, sal = self.compress_device(xyz, torch.from_numpy(offs).to(self.device), gnd)
+        torch.cuda.synchronize()
+        nnz, nseq_h = buf.nnz.cpu().numpy(), nseq.cpu().numpy()
+        seg_max = buf.counts.cpu().numpy()
+        q16, bits_h, seq_h, model = buf.q16.cpu().numpy(), bits.cpu().numpy(), seq.cpu().numpy(), buf.model.cpu().numpy()
+        sal_h = None if sal is None else sal.cpu().numpy()
+        out = []
+        for b in range(len(frames)):
+            nrow = int(np.flatnonzero(seg_max[b])[-1]) + 1          # max(seg)+1 rows (tools/compress.py:102)
+            od = {"residual_quantized": q16[b, : nnz[b]]}
+            if sal_h is not None:
+                od["salience_level"] = sal_h[b, :nrow]
+            od["contour_map"] = bits_h[b]
+            od["idx_sequence"] = seq_h[b, : nseq_h[b]]
+            od["plane_param"] = model[b, :nrow]
+            out.append(pack_bitstream(self.bc.compress_dict(od), uniform=self.uniform))
+        return out

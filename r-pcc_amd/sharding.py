@@ -1,0 +1,61 @@
+"""Frame sharding and payload gathering for one-process-per-GPU runs.
+
+Frames are independent, so the data path has no collective: rank r of R compresses datalist entries
+r, r+R, r+2R, ...  The only exchange is the final gather of the variable-length payloads to rank 0:
+an all_gather of the byte counts, then a gather of the padded byte buffers (RCCL on GPUs, gloo in the
+CPU tests).  Both functions take the process group as an argument and work with any backend."""
+import torch
+import torch.distributed as dist
+
+
+def shard_indices(n_items, rank, world):
+    """Round-robin shard of range(n_items) for `rank` of `world`."""
+    return list(range(rank, n_items, world))
+
+
+def owner_of(index, world):
+    return index % world
+
+
+def gather_payloads(local_payloads, device, group=None, dst=0):
+    """local_payloads: list of `bytes`/uint8 tensors produced by this rank (its shard, in shard order).
+    Returns on `dst` the payloads of ALL ranks re-interleaved into datalist order, elsewhere None.
+    Two collectives: all_gather of the per-frame sizes, gather of the concatenated bytes (padded to the
+    largest rank total)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    tens = [p if torch.is_tensor(p) else torch.frombuffer(bytearray(p), dtype=torch.uint8) for p in local_payloads]
+    sizes = torch.tensor([t.numel() for t in tens], dtype=torch.int64, device=device)
+    n_local = torch.tensor([sizes.numel()], dtype=torch.int64, device=device)
+    counts = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(counts, n_local, group=group)
+    counts = [int(c.item()) for c in counts]
+    max_n = max(counts) if counts else 0
+    pad_sizes = torch.zeros(max_n, dtype=torch.int64, device=device)
+    pad_sizes[: sizes.numel()] = sizes
+    all_sizes = [torch.zeros(max_n, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(all_sizes, pad_sizes, group=group)
+    totals = [int(s[:c].sum().item()) for s, c in zip(all_sizes, counts)]
+    max_bytes = max(totals) if totals else 0
+    buf = torch.zeros(max(max_bytes, 1), dtype=torch.uint8, device=device)
+    if tens:
+        cat = torch.cat([t.to(device) for t in tens]) if len(tens) > 1 else tens[0].to(device)
+        buf[: cat.numel()] = cat
+    recv = [torch.zeros_like(buf) for _ in range(world)] if rank == dst else None
+    dist.gather(buf, recv, dst=dst, group=group)
+    if rank != dst:
+        return None
+    per_rank = []
+    for r in range(world):
+        off, items = 0, []
+        for k in range(counts[r]):
+            n = int(all_sizes[r][k].item())
+            items.append(bytes(recv[r][off:off + n].cpu().numpy().tobytes()))
+            off += n
+        per_rank.append(items)
+    total = sum(counts)
+    out = [None] * total
+    for r in range(world):
+        for k, item in enumerate(per_rank[r]):
+            out[r + k * world] = item
+    return out

@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Datalist compression -- counterpart of the reference's tools/compress_datalist.py.  Same flags
+(+ --batch); frames go through the device in batches (one fused call per batch), a thread pool does
+the host-side part (file reads, entropy coding, file writes) like the reference's ThreadPoolExecutor.
+Output path rule of the reference (tools/compress_datalist.py:136-142): output_dir + original path with
+the extension replaced by `rpcc`.
+
+Multi-GPU: launch one process per GPU (torchrun); rank r takes datalist entries r, r+R, ... (frames are
+independent; no collective on the data path)."""
+import os
+import sys
+import time
+from concurrent import futures
+
+BASE_DIR = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, BASE_DIR)
+
+import numpy as np  # noqa: E402
+
+import rpcc_amd  # noqa: E402,F401
+from rpcc_amd.dataset import build_dataset  # noqa: E402
+from rpcc_amd.pipeline import BatchCompressor  # noqa: E402
+from rpcc_amd.sharding import shard_indices  # noqa: E402
+from rpcc_amd.tools.compress import make_parser, resolve_cfg  # noqa: E402
+
+
+def output_path_for(output_dir, file_name):
+    """tools/compress_datalist.py:136-142."""
+    file_name = file_name.strip()
+    if file_name[0] == "/":
+        file_name = file_name[1:]
+    out = os.path.join(output_dir, file_name)
+    return out.replace(out.split(".")[-1], "rpcc")
+
+
+def compress(args):
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    device = "cuda:%d" % local
+    cfg, accuracy, segment_cfg, model_cfg, basic_compressor, uniform = resolve_cfg(args)
+    dataset = build_dataset(datalist=args.datalist, lidar_type=args.lidar, device=device)
+    bc = BatchCompressor(dataset.PCTransformer, cluster_num=segment_cfg["cluster_num"], accuracy=accuracy / 2,
+                         ground_threshold=segment_cfg["ground_vertical_threshold"], uniform=uniform,
+                         model_method=model_cfg["model_method"], compressor_cfg=dict(cfg),
+                         basic_compressor=basic_compressor.method_name, seed=args.seed)
+    mine = shard_indices(len(dataset), rank, world)
+    t0 = time.time()
+    total_bytes = 0
+    with futures.ThreadPoolExecutor(args.workers) as pool:
+        for s in range(0, len(mine), args.batch):
+            idx = mine[s:s + args.batch]
+            names = [dataset.data_list[i] for i in idx]
+            frames = list(pool.map(dataset.load_data, names))
+            blobs = bc.compress(frames)
+
+            def write(job):
+                name, blob = job
+                out = output_path_for(args.output_dir, name)
+                os.makedirs(os.path.dirname(out), exist_ok=True)
+                with open(out, "wb") as f:
+                    f.write(blob)
+                return len(blob)
+            total_bytes += sum(pool.map(write, zip(names, blobs)))
+            if args.output:
+                for name, blob, fr in zip(names, blobs, frames):
+                    print("%s: %d points -> %d bytes" % (name, fr.shape[0], len(blob)))
+    dt = time.time() - t0
+    print("rank %d/%d: %d frames in %.3f s (%.1f frames/s incl. file I/O and entropy coding), %d bytes"
+          % (rank, world, len(mine), dt, len(mine) / max(dt, 1e-9), total_bytes))
+
+
+if __name__ == "__main__":
+    a = make_parser(datalist=True).parse_args()
+    print("Input arguments:")
+    for key, val in vars(a).items():
+        print("{:16} {}".format(key, val))
+    compress(a)
