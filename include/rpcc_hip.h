@@ -120,6 +120,18 @@ int rpcc_assign(const float *ri, const float *tm, const double *ground, const fl
 int rpcc_point_model(const float *ri, const uint8_t *seg, const double *ground, int B, int P, int M, float *model,
                      int32_t *counts, void *ws, void *stream);
 
+/* ---- a9: plane model --------------------------------------------------------------------------- *
+ * replaces cluster_modeling('plane') (utils/segment_utils.py:188-216) incl. plane_angle_validation
+ * (:84-93) and the fp32 numpy-mean fallbacks.  RANSAC (ransac_n = 4, 10 iterations, 0.1 m) is the
+ * build's seeded specification (Open3D in the reference); label k of frame b uses hash(seed, b, k).
+ *   ground   dev f64 [B,4] or NULL   copied (as fp32) into row 0
+ *   cos_cut  HOST double: a plane is rejected when some pixel has |n.t|/|n|*|t| <= cos_cut, i.e.
+ *            arccos(.) > angle threshold; the caller derives it from its own arccos (ops.plane_model)
+ *   model    dev f32 [B,K,4] out;  counts dev i32 [B,K] out;  ws rpcc_plane_workspace_bytes(B,P,M)   */
+size_t rpcc_plane_workspace_bytes(int B, int P, int M);
+int rpcc_plane_model(const float *ri, const float *tm, const uint8_t *seg, const double *ground, int B, int P, int M,
+                     double cos_cut, uint32_t seed, float *model, int32_t *counts, void *ws, void *stream);
+
 /* ---- a10+a11(+a13): intra-prediction + residual + quantisation + ordered scatter ------------- *
  * replaces segment_utils_cpp.intra_predict (cpp_modules.cpp:248-285), residual = ri - pred
  * (tools/compress.py:106), quantization_utils_cpp.uniform_quantize (cpp_modules.cpp:288-334) and the

@@ -257,6 +257,43 @@ def ground_model(ri, tm, seed=0):
     return ransac_plane(ground_candidates(ri, tm), 10, 100, 0.1, seed)[0]
 
 
+def mix32(a, b, c):
+    lib().orc_mix32.restype = C.c_uint32
+    return int(lib().orc_mix32(C.c_uint32(a & 0xFFFFFFFF), C.c_uint32(b & 0xFFFFFFFF), C.c_uint32(c & 0xFFFFFFFF)))
+
+
+def plane_angle_ok(plane_model, scan_vector, angle_deg):
+    """plane_angle_validation (utils/segment_utils.py:84-93), the reference's own numpy expression."""
+    with np.errstate(invalid="ignore"):
+        alpha = np.arccos(np.abs(np.sum(np.expand_dims(plane_model[:3], 0) * scan_vector, -1)) /
+                          np.linalg.norm(plane_model[:3]) * np.linalg.norm(scan_vector, ord=2, axis=-1))
+    return not (alpha.max() > np.pi * (angle_deg / 180))
+
+
+def cluster_modeling_plane(pc, ri, seg, tm, angle_deg=75, seed=0, frame=0):
+    """a9: cluster_modeling('plane') (utils/segment_utils.py:188-216) with the build's seeded RANSAC in
+    place of Open3D: label k of frame b uses seed mix32(seed, b, k).  -> float64 [max, 4] (rows for labels 1..max)."""
+    rows = []
+    ri3 = ri.reshape(seg.shape[0], seg.shape[1], 1)
+    for i in range(int(seg.max()) + 1):
+        if i == 0:
+            continue
+        if i == 1:
+            rows.append([0, 0, 0, 0.0])
+            continue
+        idx = np.where(seg == i)
+        cur = ri3[idx]
+        if idx[0].shape[0] < 30:
+            rows.append([0, 0, 0, np_mean_f32(cur)])
+            continue
+        plane, _ = ransac_plane(pc[idx], 4, 10, 0.1, mix32(seed, frame, i))
+        if plane_angle_ok(plane, tm[idx], angle_deg):
+            rows.append(list(plane))
+        else:
+            rows.append([0, 0, 0, np_mean_f32(cur)])
+    return np.asarray(rows)
+
+
 # ------------------------------------------------------------------------------------------------
 # Per-frame pipeline glue (tools/compress.py:93-131) with injected ground / plane models
 # ------------------------------------------------------------------------------------------------

@@ -1668,6 +1668,38 @@ extern "C" int rpcc_intra_predict(const uint8_t *seg, const float *model, const 
 }
 
 // ================================================================================================
+// a9  plane model   (kernels: plane_kernels.h)
+// ================================================================================================
+#include "plane_kernels.h"
+
+extern "C" size_t rpcc_plane_workspace_bytes(int B, int P, int M) {
+    if (B <= 0 || P <= 0 || M <= 0) return 0;
+    return ws_layout(nullptr, B, P, M).bytes + 256 + (size_t)B * P * 4;
+}
+
+extern "C" int rpcc_plane_model(const float *ri, const float *tm, const uint8_t *seg, const double *ground, int B, int P,
+                                int M, double cos_cut, uint32_t seed, float *model, int32_t *counts, void *ws,
+                                void *stream) {
+    ARG_TRY(B > 0 && P > 0 && M > 0 && M <= RPCC_MAX_CLUSTERS && ri && tm && seg && model && counts && ws);
+    hipStream_t st = (hipStream_t)stream;
+    const int KP = kpad(M), T = ntiles(P), K = M + 2;
+    WsLayout L = ws_layout(ws, B, P, M);
+    uint32_t *order = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(ws) + L.bytes + 256);
+    HIP_TRY(hipMemsetAsync(L.sums, 0, (size_t)((char *)L.hist - (char *)L.sums), st));
+    model_hist_kernel<<<dim3(T, B), 256, (size_t)KP * 12, st>>>(nullptr, seg, P, KP, T, L.sums, L.flags, L.hist);
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&model_scan_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    model_scan_kernel<<<B, 256, scan_lds_bytes(P, M), st>>>(nullptr, seg, nullptr, P, M, KP, T, L.sums, L.flags, L.hist,
+                                                            nullptr, counts, nullptr);
+    label_order_kernel<<<dim3(T, B), 256, (size_t)16 * KP * 4, st>>>(seg, L.hist, P, M, KP, T, order);
+    PlaneParams pp;
+    pp.cos_cut = cos_cut; pp.thr = 0.1f; pp.min_points = 30; pp.iters = 10; pp.seed = seed;
+    plane_model_kernel<<<dim3(K, B), 64, 0, st>>>(ri, tm, order, L.hist, counts, ground, P, M, KP, T, pp, model);
+    LAUNCH_CHECK();
+    return RPCC_OK;
+}
+
+// ================================================================================================
 // fused batch entry (uniform framework, FPS segmentation, point model): a2 .. a11
 // ================================================================================================
 extern "C" int rpcc_compress_batch(const rpcc_batch_io *io, int B, rpcc_geom g, int M, double ground_threshold,

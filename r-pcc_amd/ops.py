@@ -275,6 +275,38 @@ def compress_batch(xyz, offsets, tm, ground, buf, ground_threshold=0.1, acc=0.04
     return buf
 
 
+def angle_cos_cut(angle_threshold_deg):
+    """Largest double v with arccos(v) > pi*(angle/180): the reference rejects a plane when
+    alpha.max() > threshold (utils/segment_utils.py:89); the kernel compares v <= cos_cut instead of
+    evaluating arccos per pixel.  Found by bisection on numpy's own arccos."""
+    thr = np.pi * (angle_threshold_deg / 180)
+    lo, hi = 0.0, 1.0          # arccos(lo) > thr >= arccos(hi)
+    if not np.arccos(lo) > thr:
+        return -1.0            # nothing in [0,1] is rejected
+    for _ in range(200):
+        mid = 0.5 * (lo + hi)
+        if mid == lo or mid == hi:
+            break
+        if np.arccos(mid) > thr:
+            lo = mid
+        else:
+            hi = mid
+    return float(lo)
+
+
+def plane_model(ri, tm, seg, M, angle_threshold=75, seed=0, ground=None, want_counts=False):
+    """a9 -> model f32 [B,K,4] (and counts i32 [B,K])."""
+    B = ri.shape[0]
+    P = ri[0].numel()
+    K = M + 2
+    ws = torch.empty(_lib.lib().rpcc_plane_workspace_bytes(B, P, M), dtype=torch.uint8, device=_dev(ri))
+    model = torch.empty((B, K, 4), dtype=torch.float32, device=_dev(ri))
+    counts = torch.empty((B, K), dtype=torch.int32, device=_dev(ri))
+    check(_lib.lib().rpcc_plane_model(ptr(ri), ptr(tm), ptr(seg), ptr(ground), B, P, M, angle_cos_cut(angle_threshold),
+                                      int(seed) & 0xFFFFFFFF, ptr(model), ptr(counts), ptr(ws), stream()))
+    return (model, counts) if want_counts else model
+
+
 def compress_batch_general(xyz, offsets, tm, ground, buf, cc, fit_ground):
     """Stage-by-stage batch path for the configurations the fused entry does not cover (non-uniform
     framework and / or plane model).  `cc` is a pipeline.BatchCompressor (settings holder).  Fills `buf`

@@ -541,3 +541,47 @@ def test_features_edge_rows(env):
         assert np.array_equal(kp[0].cpu().numpy(), k_o.astype(np.uint8)), (H, W)
         assert _beq(feat[0].cpu().numpy(), f_o), (H, W)
         assert k_o.max() >= 1
+
+
+@pytest.mark.parametrize("case,angle", [("example_64E", 75), ("synth_64x2048", 75), ("synth_vlp16", 75), ("synth_32E", 40),
+                                        ("example_64E", 20)])
+def test_plane_model(env, case, angle):
+    """a9: per-label plane model == cluster_modeling('plane') of the reference with the build's seeded
+    RANSAC in Open3D's place: plane rows, angle rejection -> numpy fp32 mean, < 30 pixel labels, empty
+    labels.  Then the planes are used for prediction + quantisation like tools/compress.py does."""
+    torch, ops, orc = env["torch"], env["ops"], env["orc"]
+    c = MAN["cases"][case]
+    z = np.load(os.path.join(HERE, "golden", case + ".npz"))
+    g, geom, tm = _geom(env, c["geom"])
+    ri_np = orc.project(z["xyz"], g)
+    seg_np = z["seg_idx"].copy()
+    seg_np[seg_np == 40] = 41                                    # an empty label
+    small = np.flatnonzero(seg_np.reshape(-1) == 50)
+    seg_np.reshape(-1)[small[12:]] = 51                          # a label with < 30 pixels
+    pc = orc.backproject(ri_np, tm)
+    ri2 = np.stack([ri_np, ri_np])
+    seg2 = np.stack([seg_np, seg_np])
+    gm = np.stack([z["ground_model"], z["ground_model"]])
+    model, counts = ops.plane_model(_to(env, ri2), _to(env, tm), _to(env, seg2), 100, angle_threshold=angle, seed=5,
+                                    ground=_to(env, gm), want_counts=True)
+    model = model.cpu().numpy()
+    nrow = int(seg_np.max()) + 1
+    n_plane = n_mean = 0
+    for b in range(2):                                           # frame index enters the per-label seed
+        exp = orc.cluster_modeling_plane(pc, ri_np, seg_np.astype(np.int64), tm, angle_deg=angle, seed=5, frame=b)
+        exp32 = exp.astype(np.float32)
+        assert _beq(model[b, 1:nrow], exp32), (case, b)
+        assert _beq(model[b, 0], gm[b].astype(np.float32))
+        n_plane += int((exp[:, :3] != 0).any(1).sum())
+        n_mean += int(((exp[:, :3] == 0).all(1) & (exp[:, 3] != 0)).sum())
+    assert model.view(np.uint32)[0, 40, 3] == 0xFFC00000
+    assert n_mean > 0 and (n_plane > 0 or angle < 30)
+    assert np.array_equal(counts[0].cpu().numpy()[:nrow], np.bincount(seg_np.reshape(-1), minlength=nrow))
+    # downstream: prediction with plane rows + quantisation == oracle with the same rows
+    mp = np.concatenate((gm[:1], orc.cluster_modeling_plane(pc, ri_np, seg_np.astype(np.int64), tm, angle, 5, 0)), 0)
+    q, nnz, pred = ops.predict_quantize(_to(env, ri_np[None]), _to(env, tm), _to(env, seg_np[None]), _to(env, model[:1]),
+                                        0.04, 100, want_pred=True)
+    pr = orc.intra_predict(seg_np.astype(np.int32), mp, tm)
+    assert _beq(pred[0].cpu().numpy().reshape(g.H, g.W, 1), pr)
+    qo = orc.uniform_quantize(seg_np.astype(np.int32), ri_np.reshape(g.H, g.W, 1) - pr, 0.04)
+    assert np.array_equal(q[0, : int(nnz[0])].cpu().numpy(), qo)
