@@ -137,6 +137,16 @@ def main():
         frames_per_s = world * B * a.steps / dt
         fps_launch_ms = fps_ms.value / max(fps_n.value, 1)
         achieved = fps_bytes / (fps_launch_ms * 1e-3) / 1e9 if fps_n.value else 0.0
+        # HBM-side bytes per FPS launch from the committed PMC pass (rocprofv3 cannot run inside this process);
+        # only reported when that pass was taken on this very configuration
+        traffic, traffic_src = None, None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))
+            if pm["config"] == {"batch": B, "geom": a.geom, "clusters": M}:
+                traffic = pm["kernels"]["fps_tiled_kernel<true>"]["traffic_bytes_per_launch"]
+                traffic_src = "profiles/r01_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, x2 read correction)"
+        except Exception:
+            pass
         out = {
             "metric": "frames/s (64E, 64x2048 range img), projection->segmentation->model->quantise",
             "value": round(frames_per_s, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -146,10 +156,14 @@ def main():
                                    "point-model, accuracy=%g, cluster_num=%d, ground plane by seeded RANSAC inside the step" % (B, H, W, a.accuracy, M),
                        "frames_per_gpu_per_step": B, "sharding": "frames over ranks, no data-path collective"
                        + (", RCCL gather of payloads to rank 0 per step" if gather else "")},
-            "roofline": {"bound": "hbm", "kernel": "fps_range_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": "fps_tiled_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "launch_ms": round(fps_launch_ms, 4), "alg_bytes_per_launch": fps_bytes,
-                         "whole_path_alg_GBs": round(b_alg * a.steps / dt / 1e9, 2)},
+                         "whole_path_alg_GBs": round(b_alg * a.steps / dt / 1e9, 2),
+                         "note": "achieved = algorithmic bytes of the brute-force stream model (20*(M-1)*n_left per frame, "
+                                 "SURVEY 8d) / measured launch time; the exact tile-pruned kernel skips most of those bytes, "
+                                 "so frac > 1 is expected; traffic = PMC-measured HBM-side bytes per launch"},
         }
         if a.cpu_sample > 0 and world == 1:
             S = min(B, max(a.cpu_sample, 2 * (os.cpu_count() or 1)))
