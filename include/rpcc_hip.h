@@ -73,13 +73,13 @@ int rpcc_ground_ransac(const float *ri, const float *tm, int B, int P, uint32_t 
  *   ground   dev f64 [B,4]       plane a,b,c,d per frame
  *   temp     dev f32 [B,P]  out
  *   info     dev i32 [B,4]  out  {n_left, first candidate pixel (P if none), nnz, fps_table valid}  */
-int rpcc_ground_mask(const float *ri, const float *tm, const double *ground, double threshold, int B, int P,
+int rpcc_ground_mask(const float *ri, const float *tm, const double *ground, double threshold, int B, int H, int W,
                      float *temp, int32_t *info, void *fps_table, void *stream);
-/* fps_table (optional, rpcc_fps_table_bytes(B,P) bytes, or NULL): when given, the kernel also runs the
+/* fps_table (optional, rpcc_fps_table_bytes(B,H,W) bytes, or NULL): when given, the kernel also runs the
  * first pass of the farthest point sampling (distance of every candidate to the first centre, per-tile
  * bounding boxes and maxima) and temp holds min(1e10, that distance) for frames with info[b][3] == 1;
  * pass the same table to rpcc_fps_range.  Results are identical with and without it. */
-size_t rpcc_fps_table_bytes(int B, int P);
+size_t rpcc_fps_table_bytes(int B, int H, int W);
 
 /* ---- a6: farthest point sampling ----------------------------------------------------------- *
  * rpcc_fps_xyz replaces furthest_point_sampling_wrapper(b,n,m,points,temp,idx)
@@ -95,7 +95,7 @@ int rpcc_fps_xyz(int B, int N, int M, const float *points, float *temp, int32_t 
  *   cen_pix  dev i32 [B,M]  out  pixel index of each centre
  *   centers  dev f32 [B,M,3] out cluster_centers
  *   ws       dev scratch for a planar copy of tm (12*P bytes); NULL selects the brute-force kernel */
-int rpcc_fps_range(const float *ri, const float *tm, float *temp, const int32_t *info, int B, int P, int M,
+int rpcc_fps_range(const float *ri, const float *tm, float *temp, const int32_t *info, int B, int H, int W, int M,
                    int32_t *cen_pix, float *centers, void *ws /* dev, >= 12*P bytes, or NULL */,
                    const void *fps_table /* from rpcc_ground_mask, or NULL */, void *stream);
 

@@ -34,10 +34,10 @@ _SIGS = {
     "rpcc_project_scratch_bytes": (C.c_size_t, [_I64, _I, _I]),
     "rpcc_project": (C.c_int, [_VP, _VP, _I64, _I, Geom, _VP, _VP, C.c_size_t, _VP]),
     "rpcc_ground_ransac": (C.c_int, [_VP, _VP, _I, _I, C.c_uint32, _VP, _VP, _VP]),
-    "rpcc_ground_mask": (C.c_int, [_VP, _VP, _VP, _D, _I, _I, _VP, _VP, _VP, _VP]),
-    "rpcc_fps_table_bytes": (C.c_size_t, [_I, _I]),
+    "rpcc_ground_mask": (C.c_int, [_VP, _VP, _VP, _D, _I, _I, _I, _VP, _VP, _VP, _VP]),
+    "rpcc_fps_table_bytes": (C.c_size_t, [_I, _I, _I]),
     "rpcc_fps_xyz": (C.c_int, [_I, _I, _I, _VP, _VP, _VP, _VP]),
-    "rpcc_fps_range": (C.c_int, [_VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP, _VP]),
+    "rpcc_fps_range": (C.c_int, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP, _VP, _VP, _VP]),
     "rpcc_fps_force_bruteforce": (None, [_I]),
     "rpcc_assign": (C.c_int, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP]),
     "rpcc_point_model": (C.c_int, [_VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP]),

@@ -1,0 +1,397 @@
+// fps_kernels.h -- exact tile-pruned farthest point sampling (a6) and the ground-mask kernel that performs
+// its first pass (a3+a5 + FPS pass 1); included by rpcc_hip.hip.
+//
+// Tiles hold 128 points = 2 per lane of one wavefront, "half" h in {0,1}:
+//   range image:  tile t = (tr, tc) covers rows 4*tr .. 4*tr+3, columns 32*tc .. 32*tc+31 (compact in 3-D);
+//                 lane l, half h  ->  row 4*tr + 2*h + (l >> 5), column 32*tc + (l & 31)
+//   point list:   tile t covers indices 128*t .. 128*t+127; lane l, half h -> 128*t + 64*h + l
+// In both layouts (half, lane) in lexicographic order is increasing point index, which is what the
+// lowest-index tie rule of the arg-max needs.
+//
+// Per tile the workgroup keeps in LDS (FpsLds, 11 dwords): the bounding box of the tile's candidates, the
+// tile's current maximum of temp with its (lowest) index, and that point's coordinates.  For a new centre
+// c a tile can only change if some point is closer to c than its temp, i.e. only if
+//     bound(c, box) < tile_max,   bound = ((bx*bx)+(by*by))+(bz*bz),  b* = per-axis gap to the box.
+// bound is evaluated with the SAME fp32 operation sequence as the point distance on per-axis gaps that
+// are <= every candidate's |d*| (rounding is monotone), so bound <= computed distance of every candidate
+// and skipping is bit-exact, not approximate (DESIGN.md "FPS").  Everything else -- min with temp, strict
+// '>' arg-max with lowest-index ties -- is the brute-force definition.
+#pragma once
+
+#define FPS_TAB_ROWS 11  // lo[3], hi[3], tmax, cx[3], targ
+#define FPS_TILE 128
+
+struct FpsTiling {
+    int N;      // points per frame (P for a range image)
+    int W, H;   // range image shape (RANGE only)
+    int tcols;  // tiles per tile-row (RANGE only)
+    int T;      // tiles per frame
+};
+static inline FpsTiling fps_tiling_range(int H, int W) {
+    FpsTiling g;
+    g.N = H * W; g.W = W; g.H = H; g.tcols = (W + 31) / 32; g.T = ((H + 3) / 4) * g.tcols;
+    return g;
+}
+static inline FpsTiling fps_tiling_list(int N) {
+    FpsTiling g;
+    g.N = N; g.W = 0; g.H = 0; g.tcols = 0; g.T = (N + FPS_TILE - 1) / FPS_TILE;
+    return g;
+}
+
+// index of (tile, half, lane); -1 when outside
+template <bool RANGE>
+__device__ __forceinline__ int fps_tile_point(const FpsTiling &g, int t, int half, int lane) {
+    if (RANGE) {
+        const int tr = t / g.tcols, tc = t - tr * g.tcols;
+        const int row = 4 * tr + 2 * half + (lane >> 5), col = 32 * tc + (lane & 31);
+        return (row < g.H && col < g.W) ? row * g.W + col : -1;
+    }
+    const int p = t * FPS_TILE + half * 64 + lane;
+    return p < g.N ? p : -1;
+}
+template <bool RANGE>
+__device__ __forceinline__ int fps_tile_of(const FpsTiling &g, int p) {
+    if (RANGE) {
+        const int row = p / g.W, col = p - row * g.W;
+        return (row >> 2) * g.tcols + (col >> 5);
+    }
+    return p / FPS_TILE;
+}
+
+struct FpsLds {
+    float *lo[3], *hi[3], *tmax, *cx[3];
+    uint32_t *targ;
+    uint16_t *work;
+    __device__ FpsLds(unsigned char *base, int T) {
+        float *f = reinterpret_cast<float *>(base);
+        for (int a = 0; a < 3; a++) { lo[a] = f + (size_t)a * T; hi[a] = f + (size_t)(3 + a) * T; cx[a] = f + (size_t)(7 + a) * T; }
+        tmax = f + (size_t)6 * T;
+        targ = reinterpret_cast<uint32_t *>(f + (size_t)10 * T);
+        work = reinterpret_cast<uint16_t *>(f + (size_t)11 * T);
+    }
+};
+static inline size_t fps_tiled_lds_bytes(int T) { return (size_t)T * 46 + 64; }
+#define FPS_TILED_MAX_TILES 3400  // 46 B/tile must fit the 160 KiB LDS of one CU
+
+// Per-tile reductions shared by the FPS kernel and the ground-mask kernel.  x/y/z/nt: the lane's two
+// points; cand: they take part in the bounding box; valid: they exist.  Writes the 11 table values of
+// tile t through `put(row, value)` from lanes 0..10 (one dword each).
+struct TileStats {
+    float v[FPS_TAB_ROWS];
+};
+__device__ __forceinline__ void fps_tile_argmax(const float (&x)[2], const float (&y)[2], const float (&z)[2],
+                                                const float (&nt)[2], const bool (&valid)[2], const int (&pidx)[2],
+                                                float &wt, float &wx, float &wy, float &wz, uint32_t &widx) {
+    // largest value, lowest (half, lane) among equals
+    const uint32_t o0 = (!valid[0] || nt[0] < 0.0f) ? 0u : f2u(nt[0]) + 1u;
+    const uint32_t o1 = (!valid[1] || nt[1] < 0.0f) ? 0u : f2u(nt[1]) + 1u;
+    const uint32_t vmax = dpp_max_u32(o0 > o1 ? o0 : o1);
+    const unsigned long long m0 = __ballot(o0 == vmax);
+    const unsigned long long m1 = __ballot(o1 == vmax);
+    const int half = m0 ? 0 : 1;
+    const int wl = __builtin_amdgcn_readfirstlane((int)__ffsll((long long)(m0 ? m0 : m1)) - 1);
+    const float st = half ? nt[1] : nt[0], sx = half ? x[1] : x[0], sy = half ? y[1] : y[0], sz = half ? z[1] : z[0];
+    const int sp = half ? pidx[1] : pidx[0];
+    wt = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(st), wl));
+    wx = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(sx), wl));
+    wy = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(sy), wl));
+    wz = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(sz), wl));
+    widx = (uint32_t)__builtin_amdgcn_readlane(sp, wl);
+    if (vmax == 0u) wt = -1.0f;
+}
+__device__ __forceinline__ void fps_tile_box(const float (&x)[2], const float (&y)[2], const float (&z)[2],
+                                             const bool (&cand)[2], float (&lo)[3], float (&hi)[3]) {
+    const float inf = __builtin_inff();
+    lo[0] = dpp_min_f32(fminf(cand[0] ? x[0] : inf, cand[1] ? x[1] : inf));
+    lo[1] = dpp_min_f32(fminf(cand[0] ? y[0] : inf, cand[1] ? y[1] : inf));
+    lo[2] = dpp_min_f32(fminf(cand[0] ? z[0] : inf, cand[1] ? z[1] : inf));
+    hi[0] = dpp_max_f32(fmaxf(cand[0] ? x[0] : -inf, cand[1] ? x[1] : -inf));
+    hi[1] = dpp_max_f32(fmaxf(cand[0] ? y[0] : -inf, cand[1] ? y[1] : -inf));
+    hi[2] = dpp_max_f32(fmaxf(cand[0] ? z[0] : -inf, cand[1] ? z[1] : -inf));
+}
+
+// RANGE: point k = (ri[k]*tx[k], ri[k]*ty[k], ri[k]*tz[k]) with SoA rays; else AoS xyz[k*3..].
+template <bool RANGE>
+__device__ __forceinline__ void fps_load_point(const float *__restrict__ src, const float *__restrict__ tx,
+                                               const float *__restrict__ ty, const float *__restrict__ tz, int k,
+                                               float &x, float &y, float &z) {
+    if (RANGE) {
+        const float r = src[k];
+        x = r * tx[k]; y = r * ty[k]; z = r * tz[k];
+    } else {
+        x = src[3 * (int64_t)k]; y = src[3 * (int64_t)k + 1]; z = src[3 * (int64_t)k + 2];
+    }
+}
+
+#define FPS_THREADS 1024
+
+template <bool RANGE>
+__global__ __launch_bounds__(FPS_THREADS) void fps_tiled_kernel(const float *__restrict__ src,
+                                                                const float *__restrict__ tx,
+                                                                const float *__restrict__ ty,
+                                                                const float *__restrict__ tz, float *__restrict__ temp,
+                                                                const int32_t *__restrict__ info, FpsTiling g, int M,
+                                                                int32_t *__restrict__ out_idx,
+                                                                float *__restrict__ out_cen,
+                                                                const float *__restrict__ tiletab) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char fps_smem[];
+    __shared__ unsigned long long red[16];
+    __shared__ int redt[16];
+    __shared__ int wcount;
+    const int T = g.T, N = g.N;
+    FpsLds L(fps_smem, T);
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    src += (int64_t)b * N * (RANGE ? 1 : 3);
+    temp += (int64_t)b * N;
+    out_idx += (int64_t)b * M;
+    if (out_cen) out_cen += (int64_t)b * M * 3;
+    if (M <= 0) return;
+
+    int old = 0;
+    if (RANGE) { old = info[4 * b + 1]; if (old >= N) old = 0; }
+    float c0, c1, c2;
+    fps_load_point<RANGE>(src, tx, ty, tz, old, c0, c1, c2);
+    if (tid == 0) {
+        out_idx[0] = old;
+        if (out_cen) { out_cen[0] = c0; out_cen[1] = c1; out_cen[2] = c2; }
+        wcount = 0;
+    }
+
+    // A tile's data in registers (loads are issued for a group of tiles before any is consumed, so the
+    // memory latency of a round is paid once per group; all loads are unconditional on clamped indices).
+    struct TileRegs { float x[2], y[2], z[2], tp[2]; int p[2]; };
+    auto load_tile = [&](int t, TileRegs &q) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            q.p[h] = fps_tile_point<RANGE>(g, t, h, lane);
+            const int pc = q.p[h] < 0 ? 0 : q.p[h];
+            fps_load_point<RANGE>(src, tx, ty, tz, pc, q.x[h], q.y[h], q.z[h]);
+            q.tp[h] = temp[pc];
+            if (q.p[h] < 0) { q.x[h] = 0.f; q.y[h] = 0.f; q.z[h] = 0.f; q.tp[h] = -1.0f; }
+        }
+    };
+    // distance update against the current centre, tile maximum, (optionally) bounding box
+    auto compute_tile = [&](int t, const TileRegs &q, bool with_box) {
+        bool valid[2], cand[2];
+        float nt[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            valid[h] = q.p[h] >= 0;
+            cand[h] = q.tp[h] >= 0.0f;
+            const float dx = q.x[h] - c0, dy = q.y[h] - c1, dz = q.z[h] - c2;
+            const float d = (dx * dx + dy * dy) + dz * dz;  // sampling_gpu.cu:64, un-fused
+            nt[h] = fminf(d, q.tp[h]);
+            if (valid[h] && nt[h] != q.tp[h]) temp[q.p[h]] = nt[h];
+        }
+        if (with_box) {
+            float lo[3], hi[3];
+            fps_tile_box(q.x, q.y, q.z, cand, lo, hi);
+            if (lane == 0) { L.lo[0][t] = lo[0]; L.lo[1][t] = lo[1]; L.lo[2][t] = lo[2]; L.hi[0][t] = hi[0]; L.hi[1][t] = hi[1]; L.hi[2][t] = hi[2]; }
+        }
+        float wt, wx, wy, wz;
+        uint32_t widx;
+        fps_tile_argmax(q.x, q.y, q.z, nt, valid, q.p, wt, wx, wy, wz, widx);
+        if (lane == 0) { L.tmax[t] = wt; L.targ[t] = widx; L.cx[0][t] = wx; L.cx[1][t] = wy; L.cx[2][t] = wz; }
+    };
+
+    // arg-max over the tile table -> next centre (index and coordinates)
+    auto select_next = [&]() {
+        uint32_t hi = 0u, ix = 0xFFFFFFFFu;  // orderable value, index
+        int bt = 0;
+        for (int t = tid; t < T; t += FPS_THREADS) {
+            const float v = L.tmax[t];
+            const uint32_t h = (v < 0.0f) ? 0u : f2u(v) + 1u, i = L.targ[t];
+            if (h > hi || (h == hi && i < ix)) { hi = h; ix = i; bt = t; }
+        }
+        uint32_t vmax = dpp_max_u32(hi);
+        uint32_t imin = dpp_min_u32(hi == vmax ? ix : 0xFFFFFFFFu);
+        {
+            const unsigned long long mm = __ballot(hi == vmax && ix == imin);
+            const int wl = __builtin_amdgcn_readfirstlane((int)__ffsll((long long)mm) - 1);
+            const int wt_ = __builtin_amdgcn_readlane(bt, wl < 0 ? 0 : wl);
+            if (lane == 0) { red[wave] = ((unsigned long long)vmax << 32) | imin; redt[wave] = wt_; }
+        }
+        __syncthreads();
+        const unsigned long long k = red[lane & 15];
+        const int kt = redt[lane & 15];
+        hi = (uint32_t)(k >> 32); ix = (uint32_t)k;
+        vmax = dpp_max_u32(hi);
+        imin = dpp_min_u32(hi == vmax ? ix : 0xFFFFFFFFu);
+        const unsigned long long mm = __ballot(hi == vmax && ix == imin);
+        const int wl = __builtin_amdgcn_readfirstlane((int)__ffsll((long long)mm) - 1);
+        const int t = __builtin_amdgcn_readlane(kt, wl < 0 ? 0 : wl);
+        if (imin == 0xFFFFFFFFu) {  // no candidate anywhere: keep indices defined (the reference would fail)
+            old = 0;
+            fps_load_point<RANGE>(src, tx, ty, tz, 0, c0, c1, c2);
+        } else {
+            old = (int)imin;
+            c0 = L.cx[0][t]; c1 = L.cx[1][t]; c2 = L.cx[2][t];
+        }
+    };
+
+    constexpr int NW = FPS_THREADS / 64, GROUP = 4;
+    DBG_STAMP(8);
+    // first centre: every tile is visited once (also builds the boxes) -- unless ground_mask already did
+    // that pass and left the tile table (info[b][3] == 1)
+    const bool have_tab = RANGE && tiletab != nullptr && info[4 * b + 3] == 1;
+    if (M > 1 && have_tab) {
+        const float *tab = tiletab + (int64_t)b * FPS_TAB_ROWS * T;
+        float *dst = reinterpret_cast<float *>(fps_smem);
+        for (int i = tid; i < FPS_TAB_ROWS * T; i += FPS_THREADS) dst[i] = tab[i];
+        __syncthreads();
+    } else if (M > 1) {
+        for (int t = wave; t < T; t += NW * GROUP) {
+            TileRegs q[GROUP];
+#pragma unroll
+            for (int gi = 0; gi < GROUP; gi++) if (t + gi * NW < T) load_tile(t + gi * NW, q[gi]);
+#pragma unroll
+            for (int gi = 0; gi < GROUP; gi++) if (t + gi * NW < T) compute_tile(t + gi * NW, q[gi], true);
+        }
+        __syncthreads();
+    }
+    if (M > 1) {
+        DBG_STAMP(9);
+        select_next();
+        DBG_STAMP(10);
+        if (tid == 0) { out_idx[1] = old; if (out_cen) { out_cen[3] = c0; out_cen[4] = c1; out_cen[5] = c2; } }
+    }
+    long long acc_a = 0, acc_b = 0, acc_c = 0, acc_n = 0, tq = 0;
+    const bool prof = g_dbg_stamps != nullptr && blockIdx.x == 0 && tid == 0;
+    for (int j = 2; j < M; j++) {
+        if (prof) tq = (long long)__builtin_readcyclecounter();
+        // tile test against the new centre; active tiles go to the work list
+        for (int t = tid; t < T; t += FPS_THREADS) {
+            const float g0 = fmaxf(fmaxf(L.lo[0][t] - c0, c0 - L.hi[0][t]), 0.0f);
+            const float g1 = fmaxf(fmaxf(L.lo[1][t] - c1, c1 - L.hi[1][t]), 0.0f);
+            const float g2 = fmaxf(fmaxf(L.lo[2][t] - c2, c2 - L.hi[2][t]), 0.0f);
+            const float bound = (g0 * g0 + g1 * g1) + g2 * g2;
+            const bool act = bound < L.tmax[t];
+            const unsigned long long m = __ballot(act);
+            if (m) {
+                int base = 0;
+                if (lane == (int)__ffsll((long long)m) - 1) base = atomicAdd(&wcount, __popcll(m));
+                base = __shfl(base, (int)__ffsll((long long)m) - 1, 64);
+                if (act) L.work[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)t;
+            }
+        }
+        __syncthreads();
+        const int n = wcount;
+        if (prof) { const long long t1 = (long long)__builtin_readcyclecounter(); acc_a += t1 - tq; tq = t1; acc_n += n; }
+        for (int e = wave; e < n; e += NW * GROUP) {
+            TileRegs q[GROUP];
+            int tt[GROUP];
+#pragma unroll
+            for (int gi = 0; gi < GROUP; gi++) {
+                const int ee = e + gi * NW;
+                tt[gi] = (int)L.work[ee < n ? ee : n - 1];
+                load_tile(tt[gi], q[gi]);   // unconditional (a repeated tile for the tail is harmless and unused)
+            }
+#pragma unroll
+            for (int gi = 0; gi < GROUP; gi++) if (e + gi * NW < n) compute_tile(tt[gi], q[gi], false);
+        }
+        __syncthreads();
+        if (prof) { const long long t1 = (long long)__builtin_readcyclecounter(); acc_b += t1 - tq; tq = t1; }
+        if (tid == 0) wcount = 0;
+        select_next();
+        if (prof) { const long long t1 = (long long)__builtin_readcyclecounter(); acc_c += t1 - tq; tq = t1; }
+        if (tid == 0) { out_idx[j] = old; if (out_cen) { out_cen[3 * j] = c0; out_cen[3 * j + 1] = c1; out_cen[3 * j + 2] = c2; } }
+    }
+    DBG_STAMP(16);
+    if (prof) { g_dbg_stamps[24] = acc_a; g_dbg_stamps[25] = acc_b; g_dbg_stamps[26] = acc_c; g_dbg_stamps[27] = acc_n; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// a3 + a5 with the FIRST pass of the farthest point sampling (at full-chip parallelism).
+// FPS starts at the first candidate in row-major order.  Every wavefront re-derives it from the first
+// 64 pixels of the frame; if one of them is a candidate (the usual case: the first pixels are empty and
+// empty pixels are candidates) the kernel writes temp = min(1e10, d(pixel, first centre)) instead of
+// 1e10 and fills the FPS tile table (FpsLds layout) so the FPS kernel starts at the second centre.
+// Otherwise info[b][3] stays 0, the classic temp = 1e10 / -1 is written and the FPS kernel does its own
+// first pass.  Same arithmetic either way.  One wavefront per 4x32 tile, TAB_TPW tiles per wavefront.
+// ------------------------------------------------------------------------------------------------
+#define TAB_TPW 4
+template <bool RAW>
+__global__ __launch_bounds__(256) void ground_mask_tab_kernel(float *__restrict__ ri, const float *__restrict__ tm,
+                                                              const double *__restrict__ ground, double thr, FpsTiling g,
+                                                              float *__restrict__ temp, int32_t *__restrict__ info,
+                                                              float *__restrict__ tiletab) {
+    __shared__ int s_cnt[4], s_nz[4], s_first[4];
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int P = g.N, T = g.T;
+    const double a = ground[4 * b], bb = ground[4 * b + 1], c = ground[4 * b + 2], d = ground[4 * b + 3];
+    // np.linalg.norm(plane_param[:, :3]) on a (1,1,4) array: all four components (segment_utils.py:47)
+    const double div = sqrt(((a * a + bb * bb) + c * c) + d * d);
+    auto load_px = [&](int p, float &r, float &x, float &y, float &z) -> bool {  // returns "is a candidate"
+        r = ri[(int64_t)b * P + p];
+        if (RAW && f2u(r) == RI_EMPTY) r = 0.0f;
+        x = r * tm[3 * p]; y = r * tm[3 * p + 1]; z = r * tm[3 * p + 2];
+        const double s = ((double)x * a + (double)y * bb) + (double)z * c;
+        return fabs(s + d) / div > thr;
+    };
+    bool fast;
+    float c0, c1, c2;
+    {
+        float r, x, y, z;
+        const bool cd = load_px(min(lane, P - 1), r, x, y, z) && lane < P;
+        const unsigned long long m = __ballot(cd);
+        fast = m != 0ull;
+        const int f0 = fast ? (int)__ffsll((long long)m) - 1 : 0;
+        c0 = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(x), f0));
+        c1 = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(y), f0));
+        c2 = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(z), f0));
+        if (blockIdx.x == 0 && threadIdx.x == 0) info[4 * b + 3] = fast ? 1 : 0;
+    }
+    float *tab = tiletab + (int64_t)b * FPS_TAB_ROWS * T;
+    int cnt = 0, nzc = 0, first = P;
+    const int t0 = (blockIdx.x * 4 + wave) * TAB_TPW;
+    for (int t = t0; t < min(t0 + TAB_TPW, T); t++) {
+        float x[2], y[2], z[2], nt[2];
+        bool valid[2], cand[2];
+        int pidx[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            pidx[h] = fps_tile_point<true>(g, t, h, lane);
+            valid[h] = pidx[h] >= 0;
+            const int pc = valid[h] ? pidx[h] : 0;
+            float r;
+            cand[h] = load_px(pc, r, x[h], y[h], z[h]) && valid[h];
+            const bool nz = valid[h] && r != 0.0f;
+            nt[h] = cand[h] ? 1e10f : -1.0f;
+            if (fast) {
+                const float dx = x[h] - c0, dy = y[h] - c1, dz = z[h] - c2;
+                const float dist = (dx * dx + dy * dy) + dz * dz;  // sampling_gpu.cu:64, un-fused
+                nt[h] = cand[h] ? fminf(dist, 1e10f) : -1.0f;
+            }
+            if (valid[h]) {
+                if (RAW) ri[(int64_t)b * P + pidx[h]] = r;
+                temp[(int64_t)b * P + pidx[h]] = nt[h];
+            }
+            const unsigned long long mc = __ballot(cand[h]), mz = __ballot(nz);
+            cnt += __popcll(mc);
+            nzc += __popcll(mz);
+            if (mc) first = min(first, (int)__builtin_amdgcn_readlane(pidx[h], (int)__ffsll((long long)mc) - 1));
+        }
+        if (fast) {
+            float lo[3], hi[3], wt, wx, wy, wz;
+            uint32_t widx;
+            fps_tile_box(x, y, z, cand, lo, hi);
+            fps_tile_argmax(x, y, z, nt, valid, pidx, wt, wx, wy, wz, widx);
+            if (lane < FPS_TAB_ROWS) {
+                float v = lo[0];
+                v = lane == 1 ? lo[1] : v; v = lane == 2 ? lo[2] : v; v = lane == 3 ? hi[0] : v; v = lane == 4 ? hi[1] : v;
+                v = lane == 5 ? hi[2] : v; v = lane == 6 ? wt : v; v = lane == 7 ? wx : v; v = lane == 8 ? wy : v;
+                v = lane == 9 ? wz : v; v = lane == 10 ? u2f(widx) : v;
+                tab[(int64_t)lane * T + t] = v;
+            }
+        }
+    }
+    if (lane == 0) { s_cnt[wave] = cnt; s_nz[wave] = nzc; s_first[wave] = first; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int tc = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        const int tz = s_nz[0] + s_nz[1] + s_nz[2] + s_nz[3];
+        const int tf = min(min(s_first[0], s_first[1]), min(s_first[2], s_first[3]));
+        if (tc) { atomicAdd(&info[4 * b + 0], tc); atomicMin(&info[4 * b + 1], tf); }
+        if (tz) atomicAdd(&info[4 * b + 2], tz);
+    }
+}

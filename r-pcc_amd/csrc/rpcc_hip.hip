@@ -627,49 +627,17 @@ __global__ void info_init_kernel(int32_t *__restrict__ info, int B, int P) {
 // RAW: ri still holds the projection's bit patterns (RI_EMPTY = untouched) and is finalised here.
 // A 256-thread workgroup owns GM_PIX consecutive pixels of one frame; counts are reduced per wave
 // (ballot), then per workgroup (LDS), then one atomic per counter per workgroup.
-//
-// TAB: the kernel also performs the FIRST pass of the farthest point sampling at full-chip parallelism.
-// FPS starts at the first candidate in row-major order.  Every wavefront re-derives it from the first
-// 64 pixels of the frame; if one of them is a candidate (the usual case: the first pixels are empty and
-// empty pixels are candidates) the kernel writes temp = min(1e10, d(pixel, first centre)) instead of
-// 1e10 and fills the FPS tile table (bounding box, tile maximum, its index and coordinates -- layout of
-// FpsLds) so the FPS kernel starts at the second centre.  Otherwise info[b][3] stays 0 and the classic
-// temp = 1e10 / -1 is written (the FPS kernel then does its own first pass).  Same arithmetic either way.
+// (The variant that also runs the first FPS pass is ground_mask_tab_kernel in fps_kernels.h.)
 #define GM_PIX 4096
-#define FPS_TAB_ROWS 11  // lo[3], hi[3], tmax, cx[3], targ
-template <bool RAW, bool TAB>
+template <bool RAW>
 __global__ __launch_bounds__(256) void ground_mask_kernel(float *__restrict__ ri, const float *__restrict__ tm,
                                                           const double *__restrict__ ground, double thr, int P,
-                                                          float *__restrict__ temp, int32_t *__restrict__ info,
-                                                          float *__restrict__ tiletab) {
+                                                          float *__restrict__ temp, int32_t *__restrict__ info) {
     __shared__ int s_cnt[4], s_nz[4], s_first[4];
     const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const double a = ground[4 * b], bb = ground[4 * b + 1], c = ground[4 * b + 2], d = ground[4 * b + 3];
     // np.linalg.norm(plane_param[:, :3]) on a (1,1,4) array: all four components (segment_utils.py:47)
     const double div = sqrt(((a * a + bb * bb) + c * c) + d * d);
-    auto load_px = [&](int p, float &r, float &x, float &y, float &z) -> bool {  // returns "is a candidate"
-        r = ri[(int64_t)b * P + p];
-        if (RAW && f2u(r) == RI_EMPTY) r = 0.0f;
-        x = r * tm[3 * p]; y = r * tm[3 * p + 1]; z = r * tm[3 * p + 2];
-        const double s = ((double)x * a + (double)y * bb) + (double)z * c;
-        return fabs(s + d) / div > thr;
-    };
-    bool fast = false;
-    int f0 = 0;
-    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
-    const int T = (P + 63) >> 6;
-    if (TAB) {
-        float r, x, y, z;
-        const bool cd = load_px(min(lane, P - 1), r, x, y, z) && lane < P;
-        const unsigned long long m = __ballot(cd);
-        fast = m != 0ull;
-        f0 = fast ? (int)__ffsll((long long)m) - 1 : 0;
-        c0 = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(x), f0));
-        c1 = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(y), f0));
-        c2 = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(z), f0));
-        if (blockIdx.x == 0 && threadIdx.x == 0) info[4 * b + 3] = fast ? 1 : 0;
-    }
-    float *tab = TAB ? tiletab + (int64_t)b * FPS_TAB_ROWS * T : nullptr;
     int cnt = 0, nzc = 0, first = P;
 #pragma unroll 2
     for (int it = 0; it < GM_PIX / 256; it++) {
@@ -677,44 +645,20 @@ __global__ __launch_bounds__(256) void ground_mask_kernel(float *__restrict__ ri
         if (blockIdx.x * GM_PIX + it * 256 >= P) break;  // whole workgroup past the image (uniform)
         const bool valid = p < P;
         const int pc = valid ? p : P - 1;
-        float r, x, y, z;
-        const bool cand = load_px(pc, r, x, y, z) && valid;
+        float r = ri[(int64_t)b * P + pc];
+        if (RAW && f2u(r) == RI_EMPTY) r = 0.0f;
+        const float x = r * tm[3 * pc], y = r * tm[3 * pc + 1], z = r * tm[3 * pc + 2];
+        const double s = ((double)x * a + (double)y * bb) + (double)z * c;
+        const bool cand = valid && fabs(s + d) / div > thr;
         const bool nz = valid && r != 0.0f;
-        float nt = cand ? 1e10f : -1.0f;
-        if (TAB && fast) {
-            const float dx = x - c0, dy = y - c1, dz = z - c2;
-            const float dist = (dx * dx + dy * dy) + dz * dz;  // sampling_gpu.cu:64, un-fused
-            nt = cand ? fminf(dist, 1e10f) : -1.0f;
-        }
         if (valid) {
             if (RAW) ri[(int64_t)b * P + p] = r;
-            temp[(int64_t)b * P + p] = nt;
+            temp[(int64_t)b * P + p] = cand ? 1e10f : -1.0f;
         }
         const unsigned long long mc = __ballot(cand), mz = __ballot(nz);
         cnt += __popcll(mc);
         nzc += __popcll(mz);
         if (mc && first == P) first = (p - lane) + (int)__ffsll((long long)mc) - 1;
-        if (TAB && fast) {  // this wavefront's 64 pixels are FPS tile (p - lane) / 64
-            const int t = (p - lane) >> 6;
-            const float inf = __builtin_inff();
-            const float l0 = dpp_min_f32(cand ? x : inf), l1 = dpp_min_f32(cand ? y : inf), l2 = dpp_min_f32(cand ? z : inf);
-            const float h0 = dpp_max_f32(cand ? x : -inf), h1 = dpp_max_f32(cand ? y : -inf), h2 = dpp_max_f32(cand ? z : -inf);
-            const uint32_t ord = (!valid || nt < 0.0f) ? 0u : f2u(nt) + 1u;
-            const uint32_t vmax = dpp_max_u32(ord);
-            const int wl = __builtin_amdgcn_readfirstlane((int)__ffsll((long long)__ballot(ord == vmax)) - 1);
-            const float wt = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(nt), wl));
-            const float wx = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(x), wl));
-            const float wy = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(y), wl));
-            const float wz = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(z), wl));
-            if (lane < FPS_TAB_ROWS) {
-                float v = l0;
-                v = lane == 1 ? l1 : v; v = lane == 2 ? l2 : v; v = lane == 3 ? h0 : v; v = lane == 4 ? h1 : v;
-                v = lane == 5 ? h2 : v; v = lane == 6 ? ((vmax == 0u) ? -1.0f : wt) : v;
-                v = lane == 7 ? wx : v; v = lane == 8 ? wy : v; v = lane == 9 ? wz : v;
-                v = lane == 10 ? u2f((uint32_t)(t * 64 + wl)) : v;
-                tab[(int64_t)lane * T + t] = v;
-            }
-        }
     }
     if (lane == 0) { s_cnt[wave] = cnt; s_nz[wave] = nzc; s_first[wave] = first; }
     __syncthreads();
@@ -727,28 +671,36 @@ __global__ __launch_bounds__(256) void ground_mask_kernel(float *__restrict__ ri
     }
 }
 
-// tiletab: dev f32 [B][11][T] (T = ceil(P/64)) or NULL
-static int launch_ground_mask(float *ri, const float *tm, const double *ground, double thr, int B, int P, float *temp,
-                              int32_t *info, float *tiletab, hipStream_t st, bool raw) {
+#include "fps_kernels.h"
+
+// tiletab: dev f32 [B][11][T] (T = tiles of fps_tiling_range(H,W)) or NULL
+static int launch_ground_mask(float *ri, const float *tm, const double *ground, double thr, int B, int H, int W,
+                              float *temp, int32_t *info, float *tiletab, hipStream_t st, bool raw) {
+    const int P = H * W;
     info_init_kernel<<<(B + 255) / 256, 256, 0, st>>>(info, B, P);
-    const dim3 grid((P + GM_PIX - 1) / GM_PIX, B);
     if (tiletab) {
-        if (raw) ground_mask_kernel<true, true><<<grid, 256, 0, st>>>(ri, tm, ground, thr, P, temp, info, tiletab);
-        else     ground_mask_kernel<false, true><<<grid, 256, 0, st>>>(ri, tm, ground, thr, P, temp, info, tiletab);
+        const FpsTiling g = fps_tiling_range(H, W);
+        const dim3 grid((g.T + 4 * TAB_TPW - 1) / (4 * TAB_TPW), B);
+        if (raw) ground_mask_tab_kernel<true><<<grid, 256, 0, st>>>(ri, tm, ground, thr, g, temp, info, tiletab);
+        else     ground_mask_tab_kernel<false><<<grid, 256, 0, st>>>(ri, tm, ground, thr, g, temp, info, tiletab);
     } else {
-        if (raw) ground_mask_kernel<true, false><<<grid, 256, 0, st>>>(ri, tm, ground, thr, P, temp, info, nullptr);
-        else     ground_mask_kernel<false, false><<<grid, 256, 0, st>>>(ri, tm, ground, thr, P, temp, info, nullptr);
+        const dim3 grid((P + GM_PIX - 1) / GM_PIX, B);
+        if (raw) ground_mask_kernel<true><<<grid, 256, 0, st>>>(ri, tm, ground, thr, P, temp, info);
+        else     ground_mask_kernel<false><<<grid, 256, 0, st>>>(ri, tm, ground, thr, P, temp, info);
     }
     LAUNCH_CHECK();
     return RPCC_OK;
 }
 
-extern "C" size_t rpcc_fps_table_bytes(int B, int P) { return (size_t)B * FPS_TAB_ROWS * ((P + 63) / 64) * 4; }
+extern "C" size_t rpcc_fps_table_bytes(int B, int H, int W) {
+    return (size_t)B * FPS_TAB_ROWS * fps_tiling_range(H, W).T * 4;
+}
 
-extern "C" int rpcc_ground_mask(const float *ri, const float *tm, const double *ground, double threshold, int B, int P,
-                                float *temp, int32_t *info, void *fps_table, void *stream) {
-    ARG_TRY(B > 0 && P > 0 && ri && tm && ground && temp && info);
-    return launch_ground_mask(const_cast<float *>(ri), tm, ground, threshold, B, P, temp, info,
+extern "C" int rpcc_ground_mask(const float *ri, const float *tm, const double *ground, double threshold, int B, int H,
+                                int W, float *temp, int32_t *info, void *fps_table, void *stream) {
+    ARG_TRY(B > 0 && H > 0 && W > 0 && ri && tm && ground && temp && info);
+    ARG_TRY(fps_table == nullptr || fps_tiling_range(H, W).T <= FPS_TILED_MAX_TILES);
+    return launch_ground_mask(const_cast<float *>(ri), tm, ground, threshold, B, H, W, temp, info,
                               reinterpret_cast<float *>(fps_table), (hipStream_t)stream, false);
 }
 
@@ -756,8 +708,6 @@ extern "C" int rpcc_ground_mask(const float *ri, const float *tm, const double *
 // a6  farthest point sampling  (ops/fps/src/sampling_gpu.cu:24-140, ops/fps/fps_utils.py:10-36)
 //     v1: one 1024-thread workgroup per frame, brute-force pass per centre.
 // ================================================================================================
-#define FPS_THREADS 1024
-
 __device__ __forceinline__ uint32_t block_argmax(unsigned long long key, unsigned long long *sm) {
     key = wave_max_u64(key);
     const int wave = threadIdx.x >> 6;
@@ -858,215 +808,6 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_range_kernel(const float *__r
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// v2: exact tile-pruned FPS.  Points are grouped in tiles of 64 consecutive indices (one wavefront).
-// Per tile the workgroup keeps in LDS: the bounding box of the tile's candidates, the tile's current
-// maximum of temp with its (lowest) index, and that point's coordinates.  For a new centre c a tile
-// can only change if some point is closer to c than its temp, i.e. only if
-//     bound(c, box) < tile_max,   bound = ((bx*bx)+(by*by))+(bz*bz),  b* = per-axis gap to the box.
-// bound is evaluated with the SAME fp32 operation sequence as the point distance on per-axis gaps that
-// are <= every candidate's |d*| (rounding is monotone), so bound <= computed distance of every
-// candidate and skipping is bit-exact, not approximate (DESIGN.md "FPS").  Everything else -- min with
-// temp, strict '>' arg-max with lowest-index ties -- is the brute-force definition.
-// ------------------------------------------------------------------------------------------------
-struct FpsLds {
-    float *lo[3], *hi[3], *tmax, *cx[3];
-    uint32_t *targ;
-    uint16_t *work;
-    __device__ FpsLds(unsigned char *base, int T) {
-        float *f = reinterpret_cast<float *>(base);
-        for (int a = 0; a < 3; a++) { lo[a] = f + (size_t)a * T; hi[a] = f + (size_t)(3 + a) * T; cx[a] = f + (size_t)(7 + a) * T; }
-        tmax = f + (size_t)6 * T;
-        targ = reinterpret_cast<uint32_t *>(f + (size_t)10 * T);
-        work = reinterpret_cast<uint16_t *>(f + (size_t)11 * T);
-    }
-};
-static inline size_t fps_tiled_lds_bytes(int T) { return (size_t)T * 46 + 64; }
-#define FPS_TILED_MAX_TILES 3400  // 46 B/tile must fit the 160 KiB LDS of one CU
-
-__device__ __forceinline__ float wave_min_f32(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, RPCC_WAVE));
-    return v;
-}
-__device__ __forceinline__ float wave_max_f32(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, RPCC_WAVE));
-    return v;
-}
-
-// RANGE: point k = (ri[k]*tx[k], ri[k]*ty[k], ri[k]*tz[k]) with SoA rays; else AoS xyz[k*3..].
-template <bool RANGE>
-__device__ __forceinline__ void fps_load_point(const float *__restrict__ src, const float *__restrict__ tx,
-                                               const float *__restrict__ ty, const float *__restrict__ tz, int k,
-                                               float &x, float &y, float &z) {
-    if (RANGE) {
-        const float r = src[k];
-        x = r * tx[k]; y = r * ty[k]; z = r * tz[k];
-    } else {
-        x = src[3 * (int64_t)k]; y = src[3 * (int64_t)k + 1]; z = src[3 * (int64_t)k + 2];
-    }
-}
-
-template <bool RANGE>
-__global__ __launch_bounds__(FPS_THREADS) void fps_tiled_kernel(const float *__restrict__ src,
-                                                                const float *__restrict__ tx,
-                                                                const float *__restrict__ ty,
-                                                                const float *__restrict__ tz, float *__restrict__ temp,
-                                                                const int32_t *__restrict__ info, int N, int M, int T,
-                                                                int32_t *__restrict__ out_idx,
-                                                                float *__restrict__ out_cen,
-                                                                const float *__restrict__ tiletab) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char fps_smem[];
-    __shared__ unsigned long long red[16];
-    __shared__ int wcount;
-    FpsLds L(fps_smem, T);
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    src += (int64_t)b * N * (RANGE ? 1 : 3);
-    temp += (int64_t)b * N;
-    out_idx += (int64_t)b * M;
-    if (out_cen) out_cen += (int64_t)b * M * 3;
-    if (M <= 0) return;
-
-    int old = 0;
-    if (RANGE) { old = info[4 * b + 1]; if (old >= N) old = 0; }
-    float c0, c1, c2;
-    fps_load_point<RANGE>(src, tx, ty, tz, old, c0, c1, c2);
-    if (tid == 0) {
-        out_idx[0] = old;
-        if (out_cen) { out_cen[0] = c0; out_cen[1] = c1; out_cen[2] = c2; }
-        wcount = 0;
-    }
-
-    // A tile's data in registers (loads are issued for a group of tiles before any is consumed, so the
-    // HBM/L2 latency of a round is paid once per group, not once per tile).
-    struct TileRegs { float x, y, z, tp; };
-    auto load_tile = [&](int t, TileRegs &q) {
-        const int p = t * 64 + lane;
-        const int pc = min(p, N - 1);  // unconditional (clamped) loads keep the whole group in flight
-        fps_load_point<RANGE>(src, tx, ty, tz, pc, q.x, q.y, q.z);
-        q.tp = temp[pc];
-        if (p >= N) { q.x = 0.f; q.y = 0.f; q.z = 0.f; q.tp = -1.0f; }
-    };
-    // distance update against the current centre, tile maximum, (optionally) bounding box
-    auto compute_tile = [&](int t, const TileRegs &q, bool with_box) {
-        const int p = t * 64 + lane;
-        const bool valid = p < N;
-        if (with_box) {
-            const bool cand = q.tp >= 0.0f;
-            const float inf = __builtin_inff();
-            const float l0 = dpp_min_f32(cand ? q.x : inf), l1 = dpp_min_f32(cand ? q.y : inf), l2 = dpp_min_f32(cand ? q.z : inf);
-            const float h0 = dpp_max_f32(cand ? q.x : -inf), h1 = dpp_max_f32(cand ? q.y : -inf), h2 = dpp_max_f32(cand ? q.z : -inf);
-            if (lane == 0) { L.lo[0][t] = l0; L.lo[1][t] = l1; L.lo[2][t] = l2; L.hi[0][t] = h0; L.hi[1][t] = h1; L.hi[2][t] = h2; }
-        }
-        const float dx = q.x - c0, dy = q.y - c1, dz = q.z - c2;
-        const float d = (dx * dx + dy * dy) + dz * dz;  // sampling_gpu.cu:64, un-fused
-        const float nt = fminf(d, q.tp);
-        if (valid && nt != q.tp) temp[p] = nt;
-        // tile arg-max: largest value, lowest lane (= lowest index) among equals
-        const uint32_t ord = (!valid || nt < 0.0f) ? 0u : f2u(nt) + 1u;
-        const uint32_t vmax = dpp_max_u32(ord);
-        const int wl = __builtin_amdgcn_readfirstlane((int)__ffsll((long long)__ballot(ord == vmax)) - 1);
-        const float wt = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(nt), wl));
-        const float wx = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(q.x), wl));
-        const float wy = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(q.y), wl));
-        const float wz = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(q.z), wl));
-        if (lane == 0) {
-            L.tmax[t] = (vmax == 0u) ? -1.0f : wt;
-            L.targ[t] = (uint32_t)(t * 64 + wl);
-            L.cx[0][t] = wx; L.cx[1][t] = wy; L.cx[2][t] = wz;
-        }
-    };
-
-    // arg-max over the tile table -> next centre (index and coordinates)
-    auto select_next = [&]() {
-        uint32_t hi = 0u, ix = 0xFFFFFFFFu;  // orderable value, index
-        for (int t = tid; t < T; t += FPS_THREADS) {
-            const float v = L.tmax[t];
-            const uint32_t h = (v < 0.0f) ? 0u : f2u(v) + 1u, i = L.targ[t];
-            if (h > hi || (h == hi && i < ix)) { hi = h; ix = i; }
-        }
-        uint32_t vmax = dpp_max_u32(hi);
-        uint32_t imin = dpp_min_u32(hi == vmax ? ix : 0xFFFFFFFFu);
-        if (lane == 0) red[wave] = ((unsigned long long)vmax << 32) | imin;
-        __syncthreads();
-        const unsigned long long k = red[lane & 15];
-        hi = (uint32_t)(k >> 32); ix = (uint32_t)k;
-        vmax = dpp_max_u32(hi);
-        imin = dpp_min_u32(hi == vmax ? ix : 0xFFFFFFFFu);
-        old = (imin == 0xFFFFFFFFu) ? 0 : (int)imin;
-        const int t = old >> 6;
-        c0 = L.cx[0][t]; c1 = L.cx[1][t]; c2 = L.cx[2][t];
-    };
-
-    constexpr int NW = FPS_THREADS / 64, GROUP = 4;
-    DBG_STAMP(8);
-    // first centre: every tile is visited once (also builds the boxes) -- unless ground_mask already did
-    // that pass and left the tile table (info[b][3] == 1)
-    const bool have_tab = RANGE && tiletab != nullptr && info[4 * b + 3] == 1;
-    if (M > 1 && have_tab) {
-        const float *tab = tiletab + (int64_t)b * FPS_TAB_ROWS * T;
-        float *dst = reinterpret_cast<float *>(fps_smem);
-        for (int i = tid; i < FPS_TAB_ROWS * T; i += FPS_THREADS) dst[i] = tab[i];
-        __syncthreads();
-        DBG_STAMP(9);
-        select_next();
-        DBG_STAMP(10);
-        if (tid == 0) { out_idx[1] = old; if (out_cen) { out_cen[3] = c0; out_cen[4] = c1; out_cen[5] = c2; } }
-    } else if (M > 1) {
-        for (int t = wave; t < T; t += NW * GROUP) {
-            TileRegs q[GROUP];
-#pragma unroll
-            for (int g = 0; g < GROUP; g++) if (t + g * NW < T) load_tile(t + g * NW, q[g]);
-#pragma unroll
-            for (int g = 0; g < GROUP; g++) if (t + g * NW < T) compute_tile(t + g * NW, q[g], true);
-        }
-        __syncthreads();
-        DBG_STAMP(9);
-        select_next();
-        DBG_STAMP(10);
-        if (tid == 0) { out_idx[1] = old; if (out_cen) { out_cen[3] = c0; out_cen[4] = c1; out_cen[5] = c2; } }
-    }
-    for (int j = 2; j < M; j++) {
-        if (j == 10) DBG_STAMP(11);
-        if (j == 50) DBG_STAMP(12);
-        if (j == 99) { DBG_STAMP(13); }
-        // tile test against the new centre; active tiles go to the work list
-        for (int t = tid; t < T; t += FPS_THREADS) {
-            const float g0 = fmaxf(fmaxf(L.lo[0][t] - c0, c0 - L.hi[0][t]), 0.0f);
-            const float g1 = fmaxf(fmaxf(L.lo[1][t] - c1, c1 - L.hi[1][t]), 0.0f);
-            const float g2 = fmaxf(fmaxf(L.lo[2][t] - c2, c2 - L.hi[2][t]), 0.0f);
-            const float bound = (g0 * g0 + g1 * g1) + g2 * g2;
-            const bool act = bound < L.tmax[t];
-            const unsigned long long m = __ballot(act);
-            if (m) {
-                int base = 0;
-                if (lane == (int)__ffsll((long long)m) - 1) base = atomicAdd(&wcount, __popcll(m));
-                base = __shfl(base, (int)__ffsll((long long)m) - 1, 64);
-                if (act) L.work[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)t;
-            }
-        }
-        __syncthreads();
-        if (j == 99) DBG_STAMP(14);
-        const int n = wcount;
-        if (j == 99 && g_dbg_stamps != nullptr && blockIdx.x == 0 && tid == 0) g_dbg_stamps[20] = n;
-        for (int e = wave; e < n; e += NW * GROUP) {
-            TileRegs q[GROUP];
-            int tt[GROUP];
-#pragma unroll
-            for (int g = 0; g < GROUP; g++) if (e + g * NW < n) { tt[g] = (int)L.work[e + g * NW]; load_tile(tt[g], q[g]); }
-#pragma unroll
-            for (int g = 0; g < GROUP; g++) if (e + g * NW < n) compute_tile(tt[g], q[g], false);
-        }
-        __syncthreads();
-        if (j == 99) DBG_STAMP(15);
-        if (tid == 0) wcount = 0;
-        select_next();
-        if (j == 99) DBG_STAMP(16);
-        if (tid == 0) { out_idx[j] = old; if (out_cen) { out_cen[3 * j] = c0; out_cen[3 * j + 1] = c1; out_cen[3 * j + 2] = c2; } }
-    }
-}
-
 // AoS transform_map [P,3] -> three planes (frame-invariant; 12 B/pixel once per call)
 __global__ __launch_bounds__(256) void rays_soa_kernel(const float *__restrict__ tm, int P, float *__restrict__ soa) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1081,12 +822,13 @@ extern "C" int rpcc_fps_xyz(int B, int N, int M, const float *points, float *tem
     if (M == 0) return RPCC_OK;
     hipStream_t st = (hipStream_t)stream;
     FpsTimer tmr(st);
-    const int T = (N + 63) / 64;
-    if (!g_fps_force_v1 && T <= FPS_TILED_MAX_TILES && N < (1 << 30) / 3) {
-        const size_t sh = fps_tiled_lds_bytes(T);
+    const FpsTiling g = fps_tiling_list(N);
+    if (!g_fps_force_v1 && g.T <= FPS_TILED_MAX_TILES && N < (1 << 30) / 3) {
+        const size_t sh = fps_tiled_lds_bytes(g.T);
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_tiled_kernel<false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-        fps_tiled_kernel<false><<<B, FPS_THREADS, sh, st>>>(points, nullptr, nullptr, nullptr, temp, nullptr, N, M, T, idx, nullptr, nullptr);
+        fps_tiled_kernel<false><<<B, FPS_THREADS, sh, st>>>(points, nullptr, nullptr, nullptr, temp, nullptr, g, M, idx,
+                                                         nullptr, nullptr);
     } else {
         fps_xyz_kernel<<<B, FPS_THREADS, 0, st>>>(N, M, points, temp, idx);
     }
@@ -1095,17 +837,18 @@ extern "C" int rpcc_fps_xyz(int B, int N, int M, const float *points, float *tem
 }
 
 // rays_soa: dev f32 [3,P] scratch (may be NULL -> brute-force kernel on the AoS table)
-static int launch_fps_range(const float *ri, const float *tm, float *temp, const int32_t *info, int B, int P, int M,
+static int launch_fps_range(const float *ri, const float *tm, float *temp, const int32_t *info, int B, int H, int W, int M,
                             int32_t *cen_pix, float *centers, float *rays_soa, const float *tiletab, hipStream_t st) {
-    const int T = (P + 63) / 64;
-    if (!g_fps_force_v1 && rays_soa != nullptr && T <= FPS_TILED_MAX_TILES) {
+    const int P = H * W;
+    const FpsTiling g = fps_tiling_range(H, W);
+    if (!g_fps_force_v1 && rays_soa != nullptr && g.T <= FPS_TILED_MAX_TILES) {
         rays_soa_kernel<<<(P + 255) / 256, 256, 0, st>>>(tm, P, rays_soa);
-        const size_t sh = fps_tiled_lds_bytes(T);
+        const size_t sh = fps_tiled_lds_bytes(g.T);
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_tiled_kernel<true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
         FpsTimer tmr(st);
         fps_tiled_kernel<true><<<B, FPS_THREADS, sh, st>>>(ri, rays_soa, rays_soa + P, rays_soa + 2 * (int64_t)P, temp, info,
-                                                        P, M, T, cen_pix, centers, tiletab);
+                                                        g, M, cen_pix, centers, tiletab);
         LAUNCH_CHECK();
         return RPCC_OK;
     }
@@ -1119,11 +862,11 @@ static int launch_fps_range(const float *ri, const float *tm, float *temp, const
     return RPCC_OK;
 }
 
-extern "C" int rpcc_fps_range(const float *ri, const float *tm, float *temp, const int32_t *info, int B, int P, int M,
-                              int32_t *cen_pix, float *centers, void *ws, const void *fps_table, void *stream) {
-    ARG_TRY(B > 0 && P > 0 && M > 0 && ri && tm && temp && info && cen_pix && centers);
+extern "C" int rpcc_fps_range(const float *ri, const float *tm, float *temp, const int32_t *info, int B, int H, int W,
+                              int M, int32_t *cen_pix, float *centers, void *ws, const void *fps_table, void *stream) {
+    ARG_TRY(B > 0 && H > 0 && W > 0 && M > 0 && ri && tm && temp && info && cen_pix && centers);
     ARG_TRY(fps_table == nullptr || ws != nullptr);  // the table is only consumed by the tiled kernel
-    return launch_fps_range(ri, tm, temp, info, B, P, M, cen_pix, centers, reinterpret_cast<float *>(ws),
+    return launch_fps_range(ri, tm, temp, info, B, H, W, M, cen_pix, centers, reinterpret_cast<float *>(ws),
                             reinterpret_cast<const float *>(fps_table), (hipStream_t)stream);
 }
 
@@ -1290,7 +1033,7 @@ extern "C" size_t rpcc_workspace_bytes(int B, int P, int M, int64_t total_points
     const size_t proj_ws = (project_scratch_bytes(total_points, B, P) + 255) & ~(size_t)255;  // carved after the model part
     return model_ws + 256 + proj_ws + (size_t)B * P * 4        // + FPS temp [B,P] f32
            + (size_t)3 * P * 4 + 256                            // + SoA copy of the ray table
-           + (size_t)B * FPS_TAB_ROWS * ((P + 63) / 64) * 4;    // + FPS tile table
+           + (size_t)B * FPS_TAB_ROWS * ((P + 31) / 32 + 4096) * 4;  // + FPS tile table (4x32 tiles; generous bound)
 }
 
 __global__ __launch_bounds__(256) void model_hist_kernel(const float *__restrict__ ri, const uint8_t *__restrict__ seg,
@@ -1722,11 +1465,11 @@ extern "C" int rpcc_compress_batch(const rpcc_batch_io *io, int B, rpcc_geom g, 
         return rc;
     float *rays_soa = temp + (size_t)B * P;
     float *tiletab = rays_soa + (size_t)3 * P + 64;
-    const bool tiled = !g_fps_force_v1 && (P + 63) / 64 <= FPS_TILED_MAX_TILES;
-    if ((rc = launch_ground_mask(io->ri, io->tm, io->ground, ground_threshold, B, P, temp, io->info,
+    const bool tiled = !g_fps_force_v1 && fps_tiling_range(g.H, g.W).T <= FPS_TILED_MAX_TILES;
+    if ((rc = launch_ground_mask(io->ri, io->tm, io->ground, ground_threshold, B, g.H, g.W, temp, io->info,
                                  tiled ? tiletab : nullptr, st, false)))
         return rc;
-    if ((rc = launch_fps_range(io->ri, io->tm, temp, io->info, B, P, M, io->cen_pix, io->centers, rays_soa,
+    if ((rc = launch_fps_range(io->ri, io->tm, temp, io->info, B, g.H, g.W, M, io->cen_pix, io->centers, rays_soa,
                                tiled ? tiletab : nullptr, st)))
         return rc;
     if ((rc = launch_assign(io->ri, io->tm, io->ground, io->centers, B, g.H, g.W, M, io->seg, st))) return rc;

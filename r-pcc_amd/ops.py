@@ -72,14 +72,14 @@ def ground_mask(ri, tm, ground, threshold, fps_table=False):
     """a3+a5.  -> (temp f32 [B,P], info i32 [B,4] = n_left, first candidate pixel, nnz, table flag).
     fps_table=True: the kernel also runs the first FPS pass and returns the tile table as third value
     (hand it to fps_range); results are identical either way."""
-    B = ri.shape[0]
-    P = ri[0].numel()
+    B, H, W = ri.shape
+    P = H * W
     temp = torch.empty((B, P), dtype=torch.float32, device=_dev(ri))
     info = torch.empty((B, 4), dtype=torch.int32, device=_dev(ri))
     tab = None
     if fps_table:
-        tab = torch.empty(_lib.lib().rpcc_fps_table_bytes(B, P) // 4, dtype=torch.float32, device=_dev(ri))
-    check(_lib.lib().rpcc_ground_mask(ptr(ri), ptr(tm), ptr(ground), float(threshold), B, P, ptr(temp), ptr(info),
+        tab = torch.empty(_lib.lib().rpcc_fps_table_bytes(B, H, W) // 4, dtype=torch.float32, device=_dev(ri))
+    check(_lib.lib().rpcc_ground_mask(ptr(ri), ptr(tm), ptr(ground), float(threshold), B, H, W, ptr(temp), ptr(info),
                                       ptr(tab), stream()))
     return (temp, info, tab) if fps_table else (temp, info)
 
@@ -96,12 +96,12 @@ def fps_xyz(points, npoint, temp=None):
 
 
 def fps_range(ri, tm, temp, info, M, fps_table=None):
-    B = ri.shape[0]
-    P = ri[0].numel()
+    B, H, W = ri.shape
+    P = H * W
     cen_pix = torch.empty((B, M), dtype=torch.int32, device=_dev(ri))
     centers = torch.empty((B, M, 3), dtype=torch.float32, device=_dev(ri))
     rays = torch.empty((3, P), dtype=torch.float32, device=_dev(ri))
-    check(_lib.lib().rpcc_fps_range(ptr(ri), ptr(tm), ptr(temp), ptr(info), B, P, M, ptr(cen_pix), ptr(centers),
+    check(_lib.lib().rpcc_fps_range(ptr(ri), ptr(tm), ptr(temp), ptr(info), B, H, W, M, ptr(cen_pix), ptr(centers),
                                     ptr(rays), ptr(fps_table), stream()))
     return cen_pix, centers
 

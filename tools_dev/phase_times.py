@@ -21,8 +21,8 @@ for which in ("ransac", "fps"):
     if which == "ransac":
         g, inl = ops.ground_ransac(ri, tm, 0)
     else:
-        temp, info = ops.ground_mask(ri, tm, g, 0.1)
-        ops.fps_range(ri, tm, temp, info, 100)
+        temp, info, tab = ops.ground_mask(ri, tm, g, 0.1, fps_table=True)
+        ops.fps_range(ri, tm, temp, info, 100, fps_table=tab)
     torch.cuda.synchronize()
     _lib.lib().rpcc_debug_stamps(None)
     s = stamps.cpu().numpy()
@@ -30,4 +30,4 @@ for which in ("ransac", "fps"):
     print(which, "stamps (cycles since first, ~100MHz or shader clk):")
     base = s[nz[0]] if len(nz) else 0
     for i in nz:
-        print("   slot %2d: %10d" % (i, s[i] - base))
+        print("   slot %2d: %10d" % (i, s[i] - base if i < 24 else s[i]))
