@@ -127,26 +127,24 @@ __device__ __forceinline__ int wave_min_i32(int v) {
 // ---------------------------------------------------------------------------------------------
 #define RPCC_DPP(old_, src_, ctrl_, rmask_) __builtin_amdgcn_update_dpp((int)(old_), (int)(src_), ctrl_, rmask_, 0xf, false)
 
-__device__ __forceinline__ float dpp_min_f32(float v) {
-    const int id = 0x7f800000;  // +inf
-#define STEP_(ctrl_, rm_) v = fminf(v, u2f((uint32_t)RPCC_DPP(id, f2u(v), ctrl_, rm_)))
-    STEP_(0x111, 0xf); STEP_(0x112, 0xf); STEP_(0x114, 0xf); STEP_(0x118, 0xf); STEP_(0x142, 0xa); STEP_(0x143, 0xc);
-#undef STEP_
-    return u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(v), 63));
-}
-__device__ __forceinline__ float dpp_max_f32(float v) {
-    const int id = (int)0xff800000;  // -inf
-#define STEP_(ctrl_, rm_) v = fmaxf(v, u2f((uint32_t)RPCC_DPP(id, f2u(v), ctrl_, rm_)))
-    STEP_(0x111, 0xf); STEP_(0x112, 0xf); STEP_(0x114, 0xf); STEP_(0x118, 0xf); STEP_(0x142, 0xa); STEP_(0x143, 0xc);
-#undef STEP_
-    return u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(v), 63));
-}
 __device__ __forceinline__ uint32_t dpp_max_u32(uint32_t v) {
 #define STEP_(ctrl_, rm_) v = max(v, (uint32_t)RPCC_DPP(0, v, ctrl_, rm_))
     STEP_(0x111, 0xf); STEP_(0x112, 0xf); STEP_(0x114, 0xf); STEP_(0x118, 0xf); STEP_(0x142, 0xa); STEP_(0x143, 0xc);
 #undef STEP_
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
+// float min / max as ONE v_max_u32_dpp per step: floats are mapped to order-preserving unsigned keys
+// (sign bit flipped for non-negative values, all bits flipped for negative ones).  -0 orders below +0;
+// NaNs are not expected here (the callers feed coordinates and +-inf identities).
+__device__ __forceinline__ uint32_t f32_order_key(float f) {
+    const uint32_t b = f2u(f);
+    return b ^ ((uint32_t)((int32_t)b >> 31) | 0x80000000u);
+}
+__device__ __forceinline__ float f32_from_order_key(uint32_t k) {
+    return u2f(k ^ ((k & 0x80000000u) ? 0x80000000u : 0xFFFFFFFFu));
+}
+__device__ __forceinline__ float dpp_max_f32(float v) { return f32_from_order_key(dpp_max_u32(f32_order_key(v))); }
+__device__ __forceinline__ float dpp_min_f32(float v) { return f32_from_order_key(~dpp_max_u32(~f32_order_key(v))); }
 __device__ __forceinline__ uint32_t dpp_min_u32(uint32_t v) {
 #define STEP_(ctrl_, rm_) v = min(v, (uint32_t)RPCC_DPP(-1, v, ctrl_, rm_))
     STEP_(0x111, 0xf); STEP_(0x112, 0xf); STEP_(0x114, 0xf); STEP_(0x118, 0xf); STEP_(0x142, 0xa); STEP_(0x143, 0xc);
