@@ -207,6 +207,9 @@ int rpcc_decode(const uint8_t *seg, const int16_t *q16, const float *model, cons
 typedef struct rpcc_batch_io {
     const float *xyz;        /* dev f32 [total,3] */
     const int64_t *offsets;  /* dev i64 [B+1] */
+    const int64_t *offsets_host; /* HOST copy of offsets, or NULL.  When given, the batch is run as a few
+                                    sub-batches on internal HIP streams (rpcc_set_batch_slices) so that the
+                                    latency-bound and the throughput-bound kernels overlap; same results. */
     int64_t total;
     const float *tm;         /* dev f32 [P,3] */
     double *ground;          /* dev f64 [B,4]  in (ground_seed < 0: injected models) / out (fitted here) */
@@ -223,6 +226,7 @@ typedef struct rpcc_batch_io {
 } rpcc_batch_io;
 
 size_t rpcc_workspace_bytes(int B, int P, int M, int64_t total_points);
+void rpcc_set_batch_slices(int n); /* 1..8 sub-batches (default 2); only used with offsets_host */
 int rpcc_compress_batch(const rpcc_batch_io *io, int B, rpcc_geom g, int M, double ground_threshold, float acc,
                         void *ws, void *stream);
 

@@ -15,7 +15,7 @@ class Geom(C.Structure):
 
 
 class BatchIO(C.Structure):
-    _fields_ = [("xyz", C.c_void_p), ("offsets", C.c_void_p), ("total", C.c_int64), ("tm", C.c_void_p),
+    _fields_ = [("xyz", C.c_void_p), ("offsets", C.c_void_p), ("offsets_host", C.c_void_p), ("total", C.c_int64), ("tm", C.c_void_p),
                 ("ground", C.c_void_p), ("ground_seed", C.c_int64), ("ri", C.c_void_p), ("seg", C.c_void_p), ("cen_pix", C.c_void_p),
                 ("centers", C.c_void_p), ("model", C.c_void_p), ("counts", C.c_void_p), ("q16", C.c_void_p),
                 ("nnz", C.c_void_p), ("info", C.c_void_p)]
@@ -55,6 +55,7 @@ _SIGS = {
     "rpcc_workspace_bytes": (C.c_size_t, [_I, _I, _I, _I64]),
     "rpcc_compress_batch": (C.c_int, [C.POINTER(BatchIO), _I, Geom, _I, _D, _F, _VP, _VP]),
     "rpcc_debug_stamps": (C.c_int, [_VP]),
+    "rpcc_set_batch_slices": (None, [_I]),
     "rpcc_fps_timing": (None, [_I]),
     "rpcc_fps_time_ms": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int)]),
 }

@@ -132,11 +132,14 @@ __device__ __forceinline__ int find_frame(const int64_t *__restrict__ offs, int 
 // Grid-stride; the flagged-only modes leave at once when no frame of the batch is flagged (flags[B]).
 template <int MODE>
 __global__ __launch_bounds__(256) void project_kernel(const float *__restrict__ xyz, const int64_t *__restrict__ offs,
-                                                      int64_t total, int B, rpcc_geom g, uint32_t *__restrict__ ri,
-                                                      int32_t *__restrict__ lastz, int32_t *__restrict__ flags) {
+                                                      int64_t total, int64_t base, int B, rpcc_geom g,
+                                                      uint32_t *__restrict__ ri, int32_t *__restrict__ lastz,
+                                                      int32_t *__restrict__ flags) {
+    // offs[] holds absolute point indices; this launch covers points base .. base+total (frames offs[0..B])
     if (MODE != 0 && flags[B] == 0) return;  // no frame of this batch holds a depth-0 point
     const int64_t P = (int64_t)g.H * g.W;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t i = base + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < base + total;
+         i += (int64_t)gridDim.x * blockDim.x) {
         // one binary search per wavefront (first active lane); lanes beyond that frame's end search again
         int b = __builtin_amdgcn_readfirstlane(find_frame(offs, B, __shfl(i, __ffsll((long long)__ballot(1)) - 1, 64)));
         if (i >= offs[b + 1]) b = find_frame(offs, B, i);
@@ -197,10 +200,11 @@ __global__ __launch_bounds__(256) void project_finalize_kernel(uint32_t *__restr
 #define BAND_THREADS 1024
 
 __global__ __launch_bounds__(256) void project_pix_kernel(const float *__restrict__ xyz, const int64_t *__restrict__ offs,
-                                                          int64_t total, int B, rpcc_geom g, uint2 *__restrict__ pd,
-                                                          int32_t *__restrict__ flags) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
+                                                          int64_t total, int64_t base, int B, rpcc_geom g,
+                                                          uint2 *__restrict__ pd, int32_t *__restrict__ flags) {
+    const int64_t il = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // record index; point index = base + il
+    if (il >= total) return;
+    const int64_t i = base + il;
     const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
     const RowCol rc = project_point(x, y, z, g);
     uint2 o = make_uint2(0xFFFFFFFFu, 0u);
@@ -212,12 +216,12 @@ __global__ __launch_bounds__(256) void project_pix_kernel(const float *__restric
             o = make_uint2((uint32_t)rc.pix, f2u(rc.depth));
         }
     }
-    pd[i] = o;
+    pd[il] = o;
 }
 
 __global__ __launch_bounds__(BAND_THREADS) void project_band_kernel(const uint2 *__restrict__ pd,
-                                                                    const int64_t *__restrict__ offs, int P,
-                                                                    uint32_t *__restrict__ ri,
+                                                                    const int64_t *__restrict__ offs, int64_t base,
+                                                                    int P, uint32_t *__restrict__ ri,
                                                                     const int32_t *__restrict__ flags) {
     extern __shared__ uint32_t band[];  // [BAND_PX]
     const int b = blockIdx.y;
@@ -226,7 +230,7 @@ __global__ __launch_bounds__(BAND_THREADS) void project_band_kernel(const uint2 
     const uint32_t npx = min((uint32_t)BAND_PX, (uint32_t)P - band0);
     for (uint32_t p = threadIdx.x; p < npx; p += BAND_THREADS) band[p] = RI_EMPTY;
     __syncthreads();
-    const int64_t n0 = offs[b], n1 = offs[b + 1];
+    const int64_t n0 = offs[b] - base, n1 = offs[b + 1] - base;  // record indices of this frame
     for (int64_t i = n0 + threadIdx.x; i < n1; i += BAND_THREADS * 8) {  // 8 records in flight per thread
         uint2 v[8];
 #pragma unroll
@@ -256,8 +260,8 @@ extern "C" size_t rpcc_project_scratch_bytes(int64_t total, int B, int P) { retu
 
 // On return ri is final (0 = empty pixel).  scratch_bytes < rpcc_project_scratch_bytes() selects the
 // atomic path, which only needs B*(P+8)*4 bytes.
-static int launch_project(const float *xyz, const int64_t *offsets, int64_t total, int B, rpcc_geom g, float *ri,
-                          void *scratch, size_t scratch_bytes, hipStream_t st) {
+static int launch_project(const float *xyz, const int64_t *offsets, int64_t total, int64_t base, int B, rpcc_geom g,
+                          float *ri, void *scratch, size_t scratch_bytes, hipStream_t st) {
     const int P = g.H * g.W;
     uint32_t *rb = reinterpret_cast<uint32_t *>(ri);
     int32_t *lastz = reinterpret_cast<int32_t *>(scratch);
@@ -269,15 +273,15 @@ static int launch_project(const float *xyz, const int64_t *offsets, int64_t tota
     if (fast) {
         uint2 *pd = reinterpret_cast<uint2 *>(reinterpret_cast<char *>(scratch) + ((size_t)B * ((size_t)P + 8)) * 4 + 256);
         HIP_TRY(hipMemsetAsync(flags, 0, (size_t)(B + 1) * 4, st));
-        if (total > 0) project_pix_kernel<<<nb, 256, 0, st>>>(xyz, offsets, total, B, g, pd, flags);
+        if (total > 0) project_pix_kernel<<<nb, 256, 0, st>>>(xyz, offsets, total, base, B, g, pd, flags);
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&project_band_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, BAND_PX * 4));
-        project_band_kernel<<<dim3((P + BAND_PX - 1) / BAND_PX, B), BAND_THREADS, BAND_PX * 4, st>>>(pd, offsets, P, rb, flags);
+        project_band_kernel<<<dim3((P + BAND_PX - 1) / BAND_PX, B), BAND_THREADS, BAND_PX * 4, st>>>(pd, offsets, base, P, rb, flags);
         LAUNCH_CHECK();
         if (total > 0) {  // exact input-order semantics for frames with depth-0 points: no-ops otherwise
             project_fill_kernel<true><<<fg, 256, 0, st>>>(rb, lastz, flags, P);
-            project_kernel<1><<<nb_small, 256, 0, st>>>(xyz, offsets, total, B, g, rb, lastz, flags);
-            project_kernel<2><<<nb_small, 256, 0, st>>>(xyz, offsets, total, B, g, rb, lastz, flags);
+            project_kernel<1><<<nb_small, 256, 0, st>>>(xyz, offsets, total, base, B, g, rb, lastz, flags);
+            project_kernel<2><<<nb_small, 256, 0, st>>>(xyz, offsets, total, base, B, g, rb, lastz, flags);
             project_finalize_kernel<true><<<fg, 256, 0, st>>>(rb, P, flags);
             LAUNCH_CHECK();
         }
@@ -286,10 +290,10 @@ static int launch_project(const float *xyz, const int64_t *offsets, int64_t tota
     project_fill_kernel<false><<<fg, 256, 0, st>>>(rb, lastz, flags, P);
     LAUNCH_CHECK();
     if (total > 0) {
-        project_kernel<0><<<nb, 256, 0, st>>>(xyz, offsets, total, B, g, rb, lastz, flags);
+        project_kernel<0><<<nb, 256, 0, st>>>(xyz, offsets, total, base, B, g, rb, lastz, flags);
         project_fill_kernel<true><<<fg, 256, 0, st>>>(rb, lastz, flags, P);
-        project_kernel<1><<<nb_small, 256, 0, st>>>(xyz, offsets, total, B, g, rb, lastz, flags);
-        project_kernel<2><<<nb_small, 256, 0, st>>>(xyz, offsets, total, B, g, rb, lastz, flags);
+        project_kernel<1><<<nb_small, 256, 0, st>>>(xyz, offsets, total, base, B, g, rb, lastz, flags);
+        project_kernel<2><<<nb_small, 256, 0, st>>>(xyz, offsets, total, base, B, g, rb, lastz, flags);
         LAUNCH_CHECK();
     }
     project_finalize_kernel<false><<<fg, 256, 0, st>>>(rb, P, flags);
@@ -303,7 +307,7 @@ extern "C" int rpcc_project(const float *xyz, const int64_t *offsets, int64_t to
     ARG_TRY(ri != nullptr && scratch != nullptr && offsets != nullptr);
     ARG_TRY(total == 0 || xyz != nullptr);
     ARG_TRY(scratch_bytes >= ((size_t)B * ((size_t)g.H * g.W + 8)) * 4);
-    return launch_project(xyz, offsets, total, B, g, ri, scratch, scratch_bytes, (hipStream_t)stream);
+    return launch_project(xyz, offsets, total, 0, B, g, ri, scratch, scratch_bytes, (hipStream_t)stream);
 }
 
 // ================================================================================================
@@ -1027,13 +1031,20 @@ static WsLayout ws_layout(void *ws, int B, int P, int M) {
     L.bytes = off;
     return L;
 }
-extern "C" size_t rpcc_workspace_bytes(int B, int P, int M, int64_t total_points) {
-    if (B <= 0 || P <= 0 || M <= 0) return 0;
+// Workspace of one (sub-)batch: [ model part | projection scratch | FPS temp | planar rays | FPS tile table ]
+static size_t slice_workspace_bytes(int B, int P, int M, int64_t total_points) {
     const size_t model_ws = ws_layout(nullptr, B, P, M).bytes;
-    const size_t proj_ws = (project_scratch_bytes(total_points, B, P) + 255) & ~(size_t)255;  // carved after the model part
+    const size_t proj_ws = (project_scratch_bytes(total_points, B, P) + 255) & ~(size_t)255;
     return model_ws + 256 + proj_ws + (size_t)B * P * 4        // + FPS temp [B,P] f32
            + (size_t)3 * P * 4 + 256                            // + SoA copy of the ray table
-           + (size_t)B * FPS_TAB_ROWS * ((P + 31) / 32 + 4096) * 4;  // + FPS tile table (4x32 tiles; generous bound)
+           + (size_t)B * FPS_TAB_ROWS * ((P + 31) / 32 + 4096) * 4 + 256;  // + FPS tile table (generous bound)
+}
+#define RPCC_MAX_SLICES 8
+extern "C" size_t rpcc_workspace_bytes(int B, int P, int M, int64_t total_points) {
+    if (B <= 0 || P <= 0 || M <= 0) return 0;
+    // the batch may be processed as up to RPCC_MAX_SLICES sub-batches on internal streams: every term is
+    // affine in (B, total_points), so one extra constant part per slice bounds the sum of the slices
+    return slice_workspace_bytes(B, P, M, total_points) + (size_t)RPCC_MAX_SLICES * (slice_workspace_bytes(1, P, M, 0) + 4096);
 }
 
 __global__ __launch_bounds__(256) void model_hist_kernel(const float *__restrict__ ri, const uint8_t *__restrict__ seg,
@@ -1445,35 +1456,82 @@ extern "C" int rpcc_plane_model(const float *ri, const float *tm, const uint8_t 
 // ================================================================================================
 // fused batch entry (uniform framework, FPS segmentation, point model): a2 .. a11
 // ================================================================================================
+// ---- sub-batch streams --------------------------------------------------------------------------------
+// Several kernels of the path are latency-bound with one workgroup per frame (FPS, ground RANSAC) while
+// others are throughput-bound; running the batch as a few independent sub-batches on internal HIP streams
+// lets the two kinds overlap.  Needs the frame offsets on the host (rpcc_batch_io.offsets_host).
+static int g_slices = 2;
+static hipStream_t g_sl_stream[RPCC_MAX_SLICES];
+static hipEvent_t g_sl_start, g_sl_done[RPCC_MAX_SLICES];
+static bool g_sl_ready = false;
+extern "C" void rpcc_set_batch_slices(int n) { g_slices = n < 1 ? 1 : (n > RPCC_MAX_SLICES ? RPCC_MAX_SLICES : n); }
+
+static int run_slice(const rpcc_batch_io *io, int b0, int Bs, int64_t pt0, int64_t npts, rpcc_geom g, int M,
+                     double ground_threshold, float acc, char *ws, hipStream_t st) {
+    const int P = g.H * g.W, K = M + 2;
+    const bool fit_ground = io->ground_seed >= 0;  // >= 0: fit the ground plane here (seed + frame index)
+    WsLayout L = ws_layout(ws, Bs, P, M);
+    char *proj_scratch = ws + L.bytes + 256;
+    const size_t proj_bytes = (project_scratch_bytes(npts, Bs, P) + 255) & ~(size_t)255;
+    float *temp = reinterpret_cast<float *>(proj_scratch + proj_bytes);
+    float *rays_soa = temp + (size_t)Bs * P;
+    float *tiletab = rays_soa + (size_t)3 * P + 64;
+    float *ri = io->ri + (size_t)b0 * P;
+    double *ground = io->ground + (size_t)b0 * 4;
+    int32_t *info = io->info + (size_t)b0 * 4;
+    float *centers = io->centers + (size_t)b0 * M * 3;
+    uint8_t *seg = io->seg + (size_t)b0 * P;
+    float *model = io->model + (size_t)b0 * K * 4;
+    int rc;
+    if ((rc = launch_project(io->xyz, io->offsets + b0, npts, pt0, Bs, g, ri, proj_scratch, proj_bytes, st))) return rc;
+    if (fit_ground &&
+        (rc = launch_ground_ransac(ri, io->tm, Bs, P, (uint32_t)(io->ground_seed + b0), false, ground, nullptr, st)))
+        return rc;
+    const bool tiled = !g_fps_force_v1 && fps_tiling_range(g.H, g.W).T <= FPS_TILED_MAX_TILES;
+    if ((rc = launch_ground_mask(ri, io->tm, ground, ground_threshold, Bs, g.H, g.W, temp, info,
+                                 tiled ? tiletab : nullptr, st, false)))
+        return rc;
+    if ((rc = launch_fps_range(ri, io->tm, temp, info, Bs, g.H, g.W, M, io->cen_pix + (size_t)b0 * M, centers, rays_soa,
+                               tiled ? tiletab : nullptr, st)))
+        return rc;
+    if ((rc = launch_assign(ri, io->tm, ground, centers, Bs, g.H, g.W, M, seg, st))) return rc;
+    if ((rc = launch_point_model(ri, seg, ground, Bs, P, M, model, io->counts + (size_t)b0 * K, io->nnz + b0, ws, st)))
+        return rc;
+    return launch_predict_quantize(ri, io->tm, seg, model, acc, nullptr, nullptr, Bs, P, M, io->q16 + (size_t)b0 * P,
+                                   nullptr, nullptr, ws, st);
+}
+
 extern "C" int rpcc_compress_batch(const rpcc_batch_io *io, int B, rpcc_geom g, int M, double ground_threshold,
                                    float acc, void *ws, void *stream) {
     ARG_TRY(io != nullptr && ws != nullptr && B > 0 && M > 0 && M <= RPCC_MAX_CLUSTERS && g.H > 1 && g.W > 0);
     ARG_TRY(io->offsets && io->tm && io->ground && io->ri && io->seg && io->cen_pix && io->centers && io->model &&
             io->counts && io->q16 && io->nnz && io->info);
-    const bool fit_ground = io->ground_seed >= 0;  // >= 0: fit the ground plane here (seed + frame index)
     const int P = g.H * g.W;
     ARG_TRY(P % 4 == 0);
     hipStream_t st = (hipStream_t)stream;
-    WsLayout L = ws_layout(ws, B, P, M);
-    char *proj_scratch = reinterpret_cast<char *>(ws) + L.bytes + 256;
-    const size_t proj_bytes = (project_scratch_bytes(io->total, B, P) + 255) & ~(size_t)255;
-    float *temp = reinterpret_cast<float *>(proj_scratch + proj_bytes);
-    int rc;
-    if ((rc = launch_project(io->xyz, io->offsets, io->total, B, g, io->ri, proj_scratch, proj_bytes, st))) return rc;
-    if (fit_ground &&
-        (rc = launch_ground_ransac(io->ri, io->tm, B, P, (uint32_t)io->ground_seed, false, io->ground, nullptr, st)))
-        return rc;
-    float *rays_soa = temp + (size_t)B * P;
-    float *tiletab = rays_soa + (size_t)3 * P + 64;
-    const bool tiled = !g_fps_force_v1 && fps_tiling_range(g.H, g.W).T <= FPS_TILED_MAX_TILES;
-    if ((rc = launch_ground_mask(io->ri, io->tm, io->ground, ground_threshold, B, g.H, g.W, temp, io->info,
-                                 tiled ? tiletab : nullptr, st, false)))
-        return rc;
-    if ((rc = launch_fps_range(io->ri, io->tm, temp, io->info, B, g.H, g.W, M, io->cen_pix, io->centers, rays_soa,
-                               tiled ? tiletab : nullptr, st)))
-        return rc;
-    if ((rc = launch_assign(io->ri, io->tm, io->ground, io->centers, B, g.H, g.W, M, io->seg, st))) return rc;
-    if ((rc = launch_point_model(io->ri, io->seg, io->ground, B, P, M, io->model, io->counts, io->nnz, ws, st))) return rc;
-    return launch_predict_quantize(io->ri, io->tm, io->seg, io->model, acc, nullptr, nullptr, B, P, M, io->q16, nullptr,
-                                   nullptr, ws, st);
+    int S = (io->offsets_host != nullptr) ? g_slices : 1;
+    if (S > B) S = B;
+    if (S <= 1) return run_slice(io, 0, B, 0, io->total, g, M, ground_threshold, acc, reinterpret_cast<char *>(ws), st);
+    if (!g_sl_ready) {
+        for (int i = 0; i < RPCC_MAX_SLICES; i++) {
+            HIP_TRY(hipStreamCreateWithFlags(&g_sl_stream[i], hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&g_sl_done[i], hipEventDisableTiming));
+        }
+        HIP_TRY(hipEventCreateWithFlags(&g_sl_start, hipEventDisableTiming));
+        g_sl_ready = true;
+    }
+    HIP_TRY(hipEventRecord(g_sl_start, st));
+    char *wp = reinterpret_cast<char *>(ws);
+    int rc = RPCC_OK;
+    for (int s = 0; s < S; s++) {
+        const int b0 = (int)((int64_t)B * s / S), b1 = (int)((int64_t)B * (s + 1) / S);
+        const int64_t pt0 = io->offsets_host[b0], npts = io->offsets_host[b1] - pt0;
+        HIP_TRY(hipStreamWaitEvent(g_sl_stream[s], g_sl_start, 0));
+        const int r = run_slice(io, b0, b1 - b0, pt0, npts, g, M, ground_threshold, acc, wp, g_sl_stream[s]);
+        if (r && !rc) rc = r;
+        HIP_TRY(hipEventRecord(g_sl_done[s], g_sl_stream[s]));
+        HIP_TRY(hipStreamWaitEvent(st, g_sl_done[s], 0));
+        wp += (slice_workspace_bytes(b1 - b0, P, M, npts) + 4095) & ~(size_t)4095;
+    }
+    return rc;
 }

@@ -260,13 +260,22 @@ class BatchBuffers:
         self.ws = workspace(B, P, M, device, self.max_points)
 
 
-def compress_batch(xyz, offsets, tm, ground, buf, ground_threshold=0.1, acc=0.04, ground_seed=-1):
+def set_batch_slices(n):
+    """Number of sub-batches (internal HIP streams) the fused entry splits a batch into (needs offsets_host)."""
+    _lib.lib().rpcc_set_batch_slices(int(n))
+
+
+def compress_batch(xyz, offsets, tm, ground, buf, ground_threshold=0.1, acc=0.04, ground_seed=-1, offsets_host=None):
     """Fused a2..a11 for a batch (uniform + FPS + point model).  ground f64 [B,4]: injected models when
     ground_seed < 0, otherwise output of the seeded ground RANSAC run inside the call."""
     if xyz.shape[0] > buf.max_points:
         buf.max_points = int(xyz.shape[0])
         buf.ws = workspace(buf.B, buf.P, buf.M, xyz.device, buf.max_points)
-    io = BatchIO(ptr(xyz).value, ptr(offsets).value, int(xyz.shape[0]), ptr(tm).value, ptr(ground).value,
+    oh = None
+    if offsets_host is not None:   # host copy of the offsets: lets the library overlap sub-batches on its own streams
+        buf._offsets_host = np.ascontiguousarray(offsets_host, dtype=np.int64)
+        oh = buf._offsets_host.ctypes.data
+    io = BatchIO(ptr(xyz).value, ptr(offsets).value, oh, int(xyz.shape[0]), ptr(tm).value, ptr(ground).value,
                  int(ground_seed), ptr(buf.ri).value, ptr(buf.seg).value, ptr(buf.cen_pix).value, ptr(buf.centers).value,
                  ptr(buf.model).value, ptr(buf.counts).value, ptr(buf.q16).value, ptr(buf.nnz).value,
                  ptr(buf.info).value)

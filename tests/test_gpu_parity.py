@@ -257,6 +257,24 @@ def test_full_size_batch_properties(env):
     ops.compress_batch(xyz, offs, d_tm, _to(env, gms), buf)
     torch.cuda.synchronize()
     assert np.array_equal(buf.q16.cpu().numpy()[:, :nnz.min()], q_first[:, :nnz.min()])
+    # sub-batches on internal streams (host offsets given) give the same bytes, for every slice count
+    for S in (1, 2, 3, 8):
+        ops.set_batch_slices(S)
+        buf2 = ops.BatchBuffers(B, geom, 100, env["dev"])
+        gfit = torch.zeros((B, 4), dtype=torch.float64, device=env["dev"])
+        ops.compress_batch(xyz, offs, d_tm, gfit, buf2, ground_seed=3, offsets_host=offs_c)
+        torch.cuda.synchronize()
+        if S == 1:
+            ref = [buf2.q16.cpu().numpy(), buf2.seg.cpu().numpy(), buf2.nnz.cpu().numpy(), gfit.cpu().numpy(),
+                   buf2.model.cpu().numpy(), buf2.cen_pix.cpu().numpy()]
+        else:
+            got = [buf2.q16.cpu().numpy(), buf2.seg.cpu().numpy(), buf2.nnz.cpu().numpy(), gfit.cpu().numpy(),
+                   buf2.model.cpu().numpy(), buf2.cen_pix.cpu().numpy()]
+            assert np.array_equal(ref[2], got[2]) and np.array_equal(ref[1], got[1]) and _beq(ref[3], got[3])
+            assert _beq(ref[4], got[4]) and np.array_equal(ref[5], got[5])
+            for b in range(B):
+                assert np.array_equal(ref[0][b, :ref[2][b]], got[0][b, :got[2][b]]), (S, b)
+    ops.set_batch_slices(2)
 
 
 def test_assign_sqrt_ties_and_duplicates(env):
