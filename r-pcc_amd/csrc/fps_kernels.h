@@ -61,17 +61,19 @@ __device__ __forceinline__ int fps_tile_of(const FpsTiling &g, int p) {
 struct FpsLds {
     float *lo[3], *hi[3], *tmax, *cx[3];
     uint32_t *targ;
+    uint32_t *torg;   // range image: (first row << 16) | first column of the tile (avoids a division per visit)
     uint16_t *work;
     __device__ FpsLds(unsigned char *base, int T) {
         float *f = reinterpret_cast<float *>(base);
         for (int a = 0; a < 3; a++) { lo[a] = f + (size_t)a * T; hi[a] = f + (size_t)(3 + a) * T; cx[a] = f + (size_t)(7 + a) * T; }
         tmax = f + (size_t)6 * T;
         targ = reinterpret_cast<uint32_t *>(f + (size_t)10 * T);
-        work = reinterpret_cast<uint16_t *>(f + (size_t)11 * T);
+        torg = reinterpret_cast<uint32_t *>(f + (size_t)11 * T);
+        work = reinterpret_cast<uint16_t *>(f + (size_t)12 * T);
     }
 };
-static inline size_t fps_tiled_lds_bytes(int T) { return (size_t)T * 46 + 64; }
-#define FPS_TILED_MAX_TILES 3400  // 46 B/tile must fit the 160 KiB LDS of one CU
+static inline size_t fps_tiled_lds_bytes(int T) { return (size_t)T * 50 + 64; }
+#define FPS_TILED_MAX_TILES 3200  // 50 B/tile must fit the 160 KiB LDS of one CU
 
 // Per-tile reductions shared by the FPS kernel and the ground-mask kernel.  x/y/z/nt: the lane's two
 // points; cand: they take part in the bounding box; valid: they exist.  Writes the 11 table values of
@@ -157,13 +159,26 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_tiled_kernel(const float *__r
         wcount = 0;
     }
 
+    if (RANGE) {
+        for (int t = tid; t < T; t += FPS_THREADS) {
+            const int tr = t / g.tcols, tc = t - tr * g.tcols;
+            L.torg[t] = ((uint32_t)(4 * tr) << 16) | (uint32_t)(32 * tc);
+        }
+    }
+    __syncthreads();
     // A tile's data in registers (loads are issued for a group of tiles before any is consumed, so the
     // memory latency of a round is paid once per group; all loads are unconditional on clamped indices).
     struct TileRegs { float x[2], y[2], z[2], tp[2]; int p[2]; };
     auto load_tile = [&](int t, TileRegs &q) {
+        const uint32_t org = RANGE ? L.torg[t] : 0u;
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-            q.p[h] = fps_tile_point<RANGE>(g, t, h, lane);
+            if (RANGE) {
+                const int row = (int)(org >> 16) + 2 * h + (lane >> 5), col = (int)(org & 0xFFFFu) + (lane & 31);
+                q.p[h] = (row < g.H && col < g.W) ? row * g.W + col : -1;
+            } else {
+                q.p[h] = fps_tile_point<RANGE>(g, t, h, lane);
+            }
             const int pc = q.p[h] < 0 ? 0 : q.p[h];
             fps_load_point<RANGE>(src, tx, ty, tz, pc, q.x[h], q.y[h], q.z[h]);
             q.tp[h] = temp[pc];
@@ -180,7 +195,7 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_tiled_kernel(const float *__r
             cand[h] = q.tp[h] >= 0.0f;
             const float dx = q.x[h] - c0, dy = q.y[h] - c1, dz = q.z[h] - c2;
             const float d = (dx * dx + dy * dy) + dz * dz;  // sampling_gpu.cu:64, un-fused
-            nt[h] = fminf(d, q.tp[h]);
+            nt[h] = d < q.tp[h] ? d : q.tp[h];  // == fminf(d, tp): a NaN distance keeps tp, tp itself is never NaN
             if (valid[h] && nt[h] != q.tp[h]) temp[q.p[h]] = nt[h];
         }
         if (with_box) {
