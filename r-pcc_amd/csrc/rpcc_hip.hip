@@ -1062,13 +1062,16 @@ __global__ __launch_bounds__(256) void model_hist_kernel(const float *__restrict
         const int p = t * TILE + j * 256 + threadIdx.x;
         int todo = -1;
         unsigned long long v = 0ull;
-        if (p < P) {
-            const int64_t gp = (int64_t)b * P + p;
-            todo = seg[gp];
-            if (todo >= 2 && ri != nullptr) {
-                const float r = ri[gp];
-                if (!(r >= 0.03125f && r < 256.0f)) inexact = true;
-                else v = (unsigned long long)(long long)(r * 268435456.0f);  // exact: r * 2^28 < 2^36
+        {
+            const int64_t gp = (int64_t)b * P + min(p, P - 1);   // unconditional (clamped) loads
+            const int l = seg[gp];
+            const float r = ri != nullptr ? ri[gp] : 1.0f;
+            if (p < P) {
+                todo = l;
+                if (todo >= 2 && ri != nullptr) {
+                    if (!(r >= 0.03125f && r < 256.0f)) inexact = true;
+                    else v = (unsigned long long)(long long)(r * 268435456.0f);  // exact: r * 2^28 < 2^36
+                }
             }
         }
         // labels are spatially coherent: aggregate per distinct label of the wavefront (ballot + DPP sums),
@@ -1202,6 +1205,24 @@ extern "C" int rpcc_point_model(const float *ri, const uint8_t *seg, const doubl
 // A 256-thread workgroup owns one 1024-pixel tile as 16 segments (4 passes x 4 waves) of 64
 // consecutive pixels.  Rank of a pixel inside its label = tile offset (model_scan_kernel) + pixels of
 // that label in earlier segments + earlier lanes of its own segment (ballot + popcount).
+// exclusive prefix over the 16 segments of every label, seeded with the tile's offset: one 16-lane DPP row per
+// label (row_shr scan), 16 labels per pass of the workgroup.  segcnt is [16][SEGP] with SEGP = KP + 1 (odd
+// stride: the 16 lanes of a row hit 16 different banks).
+__device__ __forceinline__ void segment_prefix(uint32_t *segcnt, int SEGP, const uint32_t *tile_off, int K) {
+    const int row = threadIdx.x >> 4, sgi = threadIdx.x & 15;  // 16 rows of 16 lanes in a 256-thread workgroup
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        const int k = k0 + row;
+        const bool ok = k < K;
+        const uint32_t c = ok ? segcnt[sgi * SEGP + k] : 0u;
+        uint32_t v = c;  // inclusive scan inside the 16-lane row
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+        if (ok) segcnt[sgi * SEGP + k] = tile_off[k] + v - c;
+    }
+}
+
 __global__ __launch_bounds__(256) void predict_quantize_kernel(const float *__restrict__ ri, const float *__restrict__ tm,
                                                                const uint8_t *__restrict__ seg,
                                                                const float *__restrict__ model,
@@ -1211,30 +1232,42 @@ __global__ __launch_bounds__(256) void predict_quantize_kernel(const float *__re
                                                                int KP, int T, int16_t *__restrict__ q16,
                                                                int32_t *__restrict__ q32, float *__restrict__ pred_out) {
     extern __shared__ unsigned char smem_raw[];
-    float *smodel = reinterpret_cast<float *>(smem_raw);                 // [K*4]
-    uint32_t *segcnt = reinterpret_cast<uint32_t *>(smodel + 4 * KP);    // [16][KP]
+    float *smodel = reinterpret_cast<float *>(smem_raw);                 // [KP*4]
+    uint32_t *segcnt = reinterpret_cast<uint32_t *>(smodel + 4 * KP);    // [16][KP+1]
+    const int SEGP = KP + 1;
     const int b = blockIdx.y, t = blockIdx.x, K = M + 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // all global loads first, unconditional on clamped indices (a guarded load is waited for on the spot)
+    int lab[4];
+    float rv[4], t0[4], t1[4], t2[4], rin[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int p = min(t * TILE + j * 256 + (int)threadIdx.x, P - 1);
+        const int64_t gp = (int64_t)b * P + p;
+        lab[j] = seg[gp];
+        rv[j] = ri[gp];
+        t0[j] = tm[3 * p]; t1[j] = tm[3 * p + 1]; t2[j] = tm[3 * p + 2];
+        rin[j] = residual_in ? residual_in[gp] : 0.0f;
+    }
     for (int i = threadIdx.x; i < 4 * K; i += 256) smodel[i] = model[(int64_t)b * K * 4 + i];
-    for (int i = threadIdx.x; i < 16 * KP; i += 256) segcnt[i] = 0u;
+    for (int i = threadIdx.x; i < 16 * SEGP; i += 256) segcnt[i] = 0u;
     __syncthreads();
-    int qv[4], lab[4], rank[4];
+    int qv[4], rank[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int p = t * TILE + j * 256 + threadIdx.x;
-        lab[j] = -1;
+        const int l = lab[j];
         qv[j] = 0;
         rank[j] = 0;
+        lab[j] = -1;
         if (p < P) {
             const int64_t gp = (int64_t)b * P + p;
-            const int l = seg[gp];
-            const float r = ri[gp];
             const float p0 = smodel[4 * l], p1 = smodel[4 * l + 1], p2 = smodel[4 * l + 2], p3 = smodel[4 * l + 3];
             float pr;
             if (p0 + p1 + p2 == 0.0f) pr = p3;                                        // cpp_modules.cpp:271-272
-            else pr = -p3 / (p0 * tm[3 * p] + p1 * tm[3 * p + 1] + p2 * tm[3 * p + 2]);  // :275-277
+            else pr = -p3 / (p0 * t0[j] + p1 * t1[j] + p2 * t2[j]);                    // :275-277
             if (pred_out) pred_out[gp] = pr;
-            const float res = residual_in ? residual_in[gp] : r - pr;                 // compress.py:106
+            const float res = residual_in ? rin[j] : rv[j] - pr;                      // compress.py:106
             const float step = label_acc ? label_acc[(int64_t)b * K + l] : acc;       // cpp_modules.cpp:404,419
             qv[j] = (int)roundf(res / step);                                          // cpp_modules.cpp:315
             lab[j] = (l == 1) ? -1 : l;                                               // label 1 is skipped (:314)
@@ -1245,30 +1278,22 @@ __global__ __launch_bounds__(256) void predict_quantize_kernel(const float *__re
             const unsigned long long pending = __ballot(todo >= 0);
             if (!pending) break;
             const int leader = (int)__ffsll((long long)pending) - 1;
-            const int cur = __shfl(todo, leader, 64);
+            const int cur = __builtin_amdgcn_readlane(todo, leader);
             const unsigned long long same = __ballot(todo == cur);
             if (todo == cur) {
                 rank[j] = __popcll(same & ((1ull << lane) - 1ull));
-                if (lane == leader) segcnt[(j * 4 + wave) * KP + cur] = (uint32_t)__popcll(same);
+                if (lane == leader) segcnt[(j * 4 + wave) * SEGP + cur] = (uint32_t)__popcll(same);
                 todo = -1;
             }
         }
     }
     __syncthreads();
-    // exclusive prefix over the 16 segments per label, seeded with the tile's offset
-    for (int k = threadIdx.x; k < K; k += 256) {
-        uint32_t run = hist[((int64_t)b * T + t) * KP + k];
-        for (int s = 0; s < 16; s++) {
-            const uint32_t c = segcnt[s * KP + k];
-            segcnt[s * KP + k] = run;
-            run += c;
-        }
-    }
+    segment_prefix(segcnt, SEGP, hist + ((int64_t)b * T + t) * KP, K);
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         if (lab[j] >= 0) {
-            const int64_t o = (int64_t)b * P + segcnt[(j * 4 + wave) * KP + lab[j]] + rank[j];
+            const int64_t o = (int64_t)b * P + segcnt[(j * 4 + wave) * SEGP + lab[j]] + rank[j];
             if (q16) q16[o] = (int16_t)qv[j];  // astype(np.int16): two's-complement truncation
             if (q32) q32[o] = qv[j];
         }
@@ -1280,7 +1305,7 @@ static int launch_predict_quantize(const float *ri, const float *tm, const uint8
                                    int32_t *q32, float *pred, void *ws, hipStream_t st) {
     const int KP = kpad(M), T = ntiles(P);
     WsLayout L = ws_layout(ws, B, P, M);
-    const size_t sh = (size_t)KP * 4 * 4 + (size_t)16 * KP * 4;
+    const size_t sh = (size_t)KP * 4 * 4 + (size_t)16 * (KP + 1) * 4;
     predict_quantize_kernel<<<dim3(T, B), 256, sh, st>>>(ri, tm, seg, model, L.hist, acc, label_acc, residual_in, P, M, KP,
                                                          T, q16, q32, pred);
     LAUNCH_CHECK();
@@ -1460,14 +1485,16 @@ extern "C" int rpcc_plane_model(const float *ri, const float *tm, const uint8_t 
 // Several kernels of the path are latency-bound with one workgroup per frame (FPS, ground RANSAC) while
 // others are throughput-bound; running the batch as a few independent sub-batches on internal HIP streams
 // lets the two kinds overlap.  Needs the frame offsets on the host (rpcc_batch_io.offsets_host).
-static int g_slices = 2;
+static int g_slices = 1;
 static hipStream_t g_sl_stream[RPCC_MAX_SLICES];
-static hipEvent_t g_sl_start, g_sl_done[RPCC_MAX_SLICES];
+static hipEvent_t g_sl_start, g_sl_done[RPCC_MAX_SLICES], g_sl_pre[RPCC_MAX_SLICES];
 static bool g_sl_ready = false;
 extern "C" void rpcc_set_batch_slices(int n) { g_slices = n < 1 ? 1 : (n > RPCC_MAX_SLICES ? RPCC_MAX_SLICES : n); }
 
+// pre_done (optional): recorded after the throughput-bound head of the chain (projection, ground fit, mask),
+// i.e. right before the latency-bound FPS; the next sub-batch starts there, so its head overlaps this FPS.
 static int run_slice(const rpcc_batch_io *io, int b0, int Bs, int64_t pt0, int64_t npts, rpcc_geom g, int M,
-                     double ground_threshold, float acc, char *ws, hipStream_t st) {
+                     double ground_threshold, float acc, char *ws, hipStream_t st, hipEvent_t pre_done = nullptr) {
     const int P = g.H * g.W, K = M + 2;
     const bool fit_ground = io->ground_seed >= 0;  // >= 0: fit the ground plane here (seed + frame index)
     WsLayout L = ws_layout(ws, Bs, P, M);
@@ -1491,6 +1518,7 @@ static int run_slice(const rpcc_batch_io *io, int b0, int Bs, int64_t pt0, int64
     if ((rc = launch_ground_mask(ri, io->tm, ground, ground_threshold, Bs, g.H, g.W, temp, info,
                                  tiled ? tiletab : nullptr, st, false)))
         return rc;
+    if (pre_done) HIP_TRY(hipEventRecord(pre_done, st));
     if ((rc = launch_fps_range(ri, io->tm, temp, info, Bs, g.H, g.W, M, io->cen_pix + (size_t)b0 * M, centers, rays_soa,
                                tiled ? tiletab : nullptr, st)))
         return rc;
@@ -1516,6 +1544,7 @@ extern "C" int rpcc_compress_batch(const rpcc_batch_io *io, int B, rpcc_geom g, 
         for (int i = 0; i < RPCC_MAX_SLICES; i++) {
             HIP_TRY(hipStreamCreateWithFlags(&g_sl_stream[i], hipStreamNonBlocking));
             HIP_TRY(hipEventCreateWithFlags(&g_sl_done[i], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&g_sl_pre[i], hipEventDisableTiming));
         }
         HIP_TRY(hipEventCreateWithFlags(&g_sl_start, hipEventDisableTiming));
         g_sl_ready = true;
