@@ -171,7 +171,7 @@ def main():
             pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))
             if pm["config"] == {"batch": B, "geom": a.geom, "clusters": M}:
                 traffic = pm["kernels"]["fps_tiled_kernel<true>"]["traffic_bytes_per_launch"] / pm.get("launches_per_step", 1)
-                traffic_src = "profiles/r01_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, x2 read correction)"
+                traffic_src = "profiles/r01_v4_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, x2 read correction)"
         except Exception:
             pass
         out = {
@@ -186,6 +186,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "fps_tiled_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_source": traffic_src,
+                         "traffic_GBs": (round(traffic / (fps_launch_ms * 1e-3) / 1e9, 2) if traffic else None),
                          "launch_ms": round(fps_launch_ms, 4), "alg_bytes_per_launch": fps_bytes_launch,
                          "launches_per_step": launches_per_step,
                          "whole_path_alg_GBs": round(b_alg * a.steps / dt / 1e9, 2),
