@@ -139,7 +139,9 @@ int rpcc_plane_model(const float *ri, const float *tm, const uint8_t *seg, const
  *   acc         quantisation step (= 2*accuracy, tools/compress.py:46) as C float (uniform)
  *   label_acc   dev f32 [B,K] per-label step from rpcc_salience (non-uniform), or NULL
  *   residual_in dev f32 [B,P] residual supplied by the caller (QuantizationModule.quantize_residual's
- *               own argument, utils/compress_utils.py:57), or NULL to compute ri - pred here
+ *               own argument, utils/compress_utils.py:57), or NULL to compute ri - pred here.  With
+ *               residual_in given and pred == NULL nothing is predicted: ri, tm and model may be NULL
+ *               (exactly uniform_quantize(seg_idx, residual, acc), cpp_modules.cpp:288)
  *   q16         dev i16 [B,P] out   per frame: nnz values grouped by label ascending, row-major inside
  *                                   a label, already cast to int16 (utils/compress_utils.py:142)
  *   q32         dev i32 [B,P] out   same as int32 (what the quantisers return); either may be NULL

@@ -1,0 +1,207 @@
+"""Reference-side binding of librpcc_hip.so: the stub a maintainer of StevenWang30/R-PCC would add.
+
+Self-contained on purpose (ctypes + torch for device memory only, nothing imported from this
+repository's package): every function below has the NAME and the NumPy-in / NumPy-out SIGNATURE of the
+pybind11 / torch-extension function it replaces, so the reference's call sites keep reading the same:
+
+    ops/cpp_modules/src/cpp_modules.cpp   dataset_utils_cpp.point_cloud_to_range_image_even  (:427)
+                                          segment_utils_cpp.point_modeling                    (:471)
+                                          segment_utils_cpp.intra_predict                     (:248)
+                                          quantization_utils_cpp.uniform_quantize             (:288)
+                                          quantization_utils_cpp.nonuniform_quantize          (:337)
+                                          feature_extractor_cpp.extract_features_with_segment (:28)
+                                          contour_utils_cpp.extract_contour / recover_map     (:521, :561)
+    ops/fps/fps_utils.py:10-36            furthest_point_sample
+    utils/segment_utils.py:95-170         PointCloudSegment.segment, cpu=True arithmetic  -> segment_range_image
+
+INTEGRATION.md walks through it; tests/test_gpu_integration.py runs it against the golden vectors.
+Set RPCC_HIP_LIB to the path of the library when it is not next to this repository's package.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch  # first: the library binds to the HIP runtime torch has loaded
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_l = C.CDLL(os.environ.get("RPCC_HIP_LIB", os.path.join(_HERE, "..", "r-pcc_amd", "lib", "librpcc_hip.so")))
+_l.rpcc_last_error.restype = C.c_char_p
+for _n in ("rpcc_workspace_bytes", "rpcc_project_scratch_bytes", "rpcc_fps_table_bytes", "rpcc_codec_workspace_bytes"):
+    getattr(_l, _n).restype = C.c_size_t
+
+
+class Geom(C.Structure):  # rpcc_geom (include/rpcc_hip.h)
+    _fields_ = [("H", C.c_int32), ("W", C.c_int32), ("hfov", C.c_float), ("vmax", C.c_float), ("vmin", C.c_float)]
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _s():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ok(rc):
+    if rc:
+        raise RuntimeError(_l.rpcc_last_error().decode())
+
+
+def _dev(a, dtype):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).cuda()
+
+
+def _ws(B, P, M, total=0):
+    n = _l.rpcc_workspace_bytes(B, P, M, C.c_int64(total))
+    return torch.empty((n,), dtype=torch.uint8, device="cuda")
+
+
+def _labels(seg_idx):
+    seg_idx = np.asarray(seg_idx)
+    M = max(int(seg_idx.max()) - 1, 1)
+    if M > 254:
+        raise ValueError("librpcc_hip stores labels as uint8: cluster_num <= 254")
+    return _dev(seg_idx, np.uint8).reshape(1, -1), M
+
+
+# ---- dataset_utils_cpp -------------------------------------------------------------------------------
+def point_cloud_to_range_image_even(point_cloud, H, W, horizontal_FOV, vertical_max, vertical_min):
+    xyz = _dev(np.asarray(point_cloud)[:, :3], np.float32)
+    n, P = xyz.shape[0], H * W
+    offs = torch.tensor([0, n], dtype=torch.int64, device="cuda")
+    ri = torch.empty((1, P), dtype=torch.float32, device="cuda")
+    nb = _l.rpcc_project_scratch_bytes(C.c_int64(n), 1, P)
+    scratch = torch.empty((nb,), dtype=torch.uint8, device="cuda")
+    g = Geom(H, W, horizontal_FOV, vertical_max, vertical_min)  # double -> float exactly like the pybind11 arguments
+    _ok(_l.rpcc_project(_p(xyz), _p(offs), C.c_int64(n), 1, g, _p(ri), _p(scratch), C.c_size_t(nb), _s()))
+    return ri.view(H, W, 1).cpu().numpy()
+
+
+# ---- ops/fps -----------------------------------------------------------------------------------------
+def furthest_point_sample(xyz, npoint):
+    """xyz (B,N,3) float32 CUDA tensor -> (B,npoint) int32, as pointnet2's wrapper."""
+    assert xyz.is_contiguous()
+    B, N, _ = xyz.size()
+    output = torch.empty((B, npoint), dtype=torch.int32, device=xyz.device)
+    temp = torch.full((B, N), 1e10, dtype=torch.float32, device=xyz.device)
+    _ok(_l.rpcc_fps_xyz(B, N, npoint, _p(xyz), _p(temp), _p(output), _s()))
+    return output
+
+
+# ---- PointCloudSegment.segment (FPS branch), the cpu=True arithmetic on the GPU ---------------------------
+def segment_range_image(range_image, transform_map, ground_model, cluster_num, ground_threshold):
+    """-> (seg_idx int64 [H,W], cluster_centers f32 [cluster_num,3]); ground_model fp64 [4] from the caller's RANSAC."""
+    H, W = range_image.shape[:2]
+    P, M = H * W, int(cluster_num)
+    ri, tm = _dev(range_image, np.float32).reshape(1, P), _dev(transform_map, np.float32).reshape(P, 3)
+    ground = _dev(np.asarray(ground_model).reshape(1, 4), np.float64)
+    temp = torch.empty((1, P), dtype=torch.float32, device="cuda")
+    info = torch.empty((1, 4), dtype=torch.int32, device="cuda")
+    table = torch.empty((_l.rpcc_fps_table_bytes(1, H, W),), dtype=torch.uint8, device="cuda")
+    _ok(_l.rpcc_ground_mask(_p(ri), _p(tm), _p(ground), C.c_double(ground_threshold), 1, H, W, _p(temp), _p(info),
+                            _p(table), _s()))
+    cen_pix = torch.empty((1, M), dtype=torch.int32, device="cuda")
+    centers = torch.empty((1, M, 3), dtype=torch.float32, device="cuda")
+    rays = torch.empty((3 * P + 64,), dtype=torch.float32, device="cuda")
+    _ok(_l.rpcc_fps_range(_p(ri), _p(tm), _p(temp), _p(info), 1, H, W, M, _p(cen_pix), _p(centers), _p(rays), _p(table), _s()))
+    seg = torch.empty((1, P), dtype=torch.uint8, device="cuda")
+    _ok(_l.rpcc_assign(_p(ri), _p(tm), _p(ground), _p(centers), 1, H, W, M, _p(seg), _s()))
+    return seg.view(H, W).cpu().numpy().astype(np.int64), centers[0].cpu().numpy()
+
+
+# ---- segment_utils_cpp ---------------------------------------------------------------------------------
+def point_modeling(range_image, seg_idx):
+    """-> fp32 [max(seg)+1]: 0 for labels 0 and 1, mean range of every cluster label >= 2 (cpp_modules.cpp:471-518)."""
+    seg, M = _labels(seg_idx)
+    P = seg.shape[1]
+    ri = _dev(range_image, np.float32).reshape(1, P)
+    model = torch.empty((1, M + 2, 4), dtype=torch.float32, device="cuda")
+    counts = torch.empty((1, M + 2), dtype=torch.int32, device="cuda")
+    ground = torch.zeros((1, 4), dtype=torch.float64, device="cuda")     # row 0 is assembled by the caller (segment_utils.py:183)
+    _ok(_l.rpcc_point_model(_p(ri), _p(seg), _p(ground), 1, P, M, _p(model), _p(counts), _p(_ws(1, P, M)), _s()))
+    out = model[0, :int(np.asarray(seg_idx).max()) + 1, 3].cpu().numpy()
+    out[:2] = 0.0
+    return out
+
+
+def intra_predict(seg_idx, model_param, transform_map):
+    seg, M = _labels(seg_idx)
+    H, W = np.asarray(seg_idx).shape[:2]
+    mp = np.zeros((1, M + 2, 4), np.float32)
+    rows = min(M + 2, np.asarray(model_param).shape[0])
+    mp[0, :rows] = np.asarray(model_param)[:rows]          # fp64 -> fp32: the pybind11 cast of py::array_t<float>
+    tm = _dev(transform_map, np.float32).reshape(-1, 3)
+    pred = torch.empty((1, H * W), dtype=torch.float32, device="cuda")
+    _ok(_l.rpcc_intra_predict(_p(seg), _p(_dev(mp, np.float32)), _p(tm), 1, H * W, M, _p(pred), _s()))
+    return pred.view(H, W, 1).cpu().numpy()
+
+
+# ---- quantization_utils_cpp ----------------------------------------------------------------------------
+def _quantize(seg_idx, residual, acc, label_acc):
+    seg, M = _labels(seg_idx)
+    P = seg.shape[1]
+    res = _dev(residual, np.float32).reshape(1, P)
+    q32 = torch.empty((1, P), dtype=torch.int32, device="cuda")
+    nnz = torch.empty((1,), dtype=torch.int32, device="cuda")
+    _ok(_l.rpcc_predict_quantize(None, None, _p(seg), None, _p(label_acc), _p(res), C.c_float(acc), 1, P, M, None,
+                                 _p(q32), _p(nnz), None, _p(_ws(1, P, M)), _s()))
+    return q32[0, :int(nnz[0])].cpu().numpy()
+
+
+def uniform_quantize(seg_idx, residual, acc):
+    return _quantize(seg_idx, residual, acc, None)
+
+
+def nonuniform_quantize(seg_idx, residual, key_point_map, level_kp_num, level_acc, ground_level):
+    """-> (quantized residual int32 [nnz], salience level per label int32 [max(seg)+1])."""
+    seg, M = _labels(seg_idx)
+    P, L = seg.shape[1], len(level_kp_num)
+    kp = _dev(key_point_map, np.uint8).reshape(1, P)
+    sal = torch.empty((1, M + 2), dtype=torch.uint8, device="cuda")
+    lacc = torch.empty((1, M + 2), dtype=torch.float32, device="cuda")
+    lk = (C.c_int32 * L)(*[int(v) for v in level_kp_num])
+    la = (C.c_float * L)(*[float(v) for v in level_acc])
+    _ok(_l.rpcc_salience(_p(seg), _p(kp), lk, la, L, int(ground_level), 1, P, M, _p(sal), _p(lacc), _s()))
+    q = _quantize(seg_idx, residual, float(level_acc[0]), lacc)
+    return q, sal[0, :int(np.asarray(seg_idx).max()) + 1].cpu().numpy().astype(np.int32)
+
+
+# ---- feature_extractor_cpp -----------------------------------------------------------------------------
+def extract_features_with_segment(range_image, seg_idx, feature_region, segments, sharp_num, less_sharp_num, flat_num):
+    seg, _ = _labels(seg_idx)
+    H, W = np.asarray(seg_idx).shape[:2]
+    ri = _dev(range_image, np.float32).reshape(1, H * W)
+    feat = torch.empty((1, H, W), dtype=torch.float32, device="cuda")
+    kp = torch.empty((1, H, W), dtype=torch.uint8, device="cuda")
+    _ok(_l.rpcc_extract_features(_p(ri), _p(seg), 1, H, W, feature_region, segments, sharp_num, less_sharp_num, flat_num,
+                                 _p(feat), _p(kp), _s()))
+    return feat[0].cpu().numpy(), kp[0].cpu().numpy().astype(np.int32)
+
+
+# ---- contour_utils_cpp ---------------------------------------------------------------------------------
+def extract_contour(idx_map):
+    """-> (contour_map int32 [H,W] of 0/1, idx_sequence int32 [n])."""
+    seg, M = _labels(idx_map)
+    H, W = np.asarray(idx_map).shape[:2]
+    P = H * W
+    bits = torch.empty((1, (P + 7) // 8), dtype=torch.uint8, device="cuda")
+    seq = torch.empty((1, P), dtype=torch.int16, device="cuda")   # uint16 payload
+    nseq = torch.empty((1,), dtype=torch.int32, device="cuda")
+    ws = torch.empty((_l.rpcc_codec_workspace_bytes(1, P, M),), dtype=torch.uint8, device="cuda")
+    _ok(_l.rpcc_contour_encode(_p(seg), 1, H, W, _p(bits), _p(seq), _p(nseq), _p(ws), _s()))
+    cm = np.unpackbits(bits[0].cpu().numpy())[:P].reshape(H, W).astype(np.int32)
+    return cm, seq[0, :int(nseq[0])].cpu().numpy().view(np.uint16).astype(np.int32)
+
+
+def recover_map(contour_map, idx_sequence):
+    H, W = np.asarray(contour_map).shape[:2]
+    P = H * W
+    bits = _dev(np.packbits(np.asarray(contour_map).astype(np.uint8).reshape(-1)), np.uint8).reshape(1, -1)
+    seq = torch.zeros((1, P), dtype=torch.int16, device="cuda")
+    n = len(idx_sequence)
+    seq[0, :n] = torch.from_numpy(np.asarray(idx_sequence).astype(np.uint16).view(np.int16)).cuda()
+    M = 254
+    seg = torch.empty((1, P), dtype=torch.uint8, device="cuda")
+    ws = torch.empty((_l.rpcc_codec_workspace_bytes(1, P, M),), dtype=torch.uint8, device="cuda")
+    _ok(_l.rpcc_contour_decode(_p(bits), _p(seq), 1, H, W, _p(seg), _p(ws), _s()))
+    return seg.view(H, W).cpu().numpy().astype(np.int32)

@@ -1223,6 +1223,9 @@ __device__ __forceinline__ void segment_prefix(uint32_t *segcnt, int SEGP, const
     }
 }
 
+// RESIDUAL_ONLY: the quantiser's own seam (uniform_quantize(seg_idx, residual, acc)): no prediction, so ri, tm and
+// model are not read at all (they may be NULL).
+template <bool RESIDUAL_ONLY>
 __global__ __launch_bounds__(256) void predict_quantize_kernel(const float *__restrict__ ri, const float *__restrict__ tm,
                                                                const uint8_t *__restrict__ seg,
                                                                const float *__restrict__ model,
@@ -1245,11 +1248,16 @@ __global__ __launch_bounds__(256) void predict_quantize_kernel(const float *__re
         const int p = min(t * TILE + j * 256 + (int)threadIdx.x, P - 1);
         const int64_t gp = (int64_t)b * P + p;
         lab[j] = seg[gp];
-        rv[j] = ri[gp];
-        t0[j] = tm[3 * p]; t1[j] = tm[3 * p + 1]; t2[j] = tm[3 * p + 2];
-        rin[j] = residual_in ? residual_in[gp] : 0.0f;
+        if (RESIDUAL_ONLY) {
+            rv[j] = t0[j] = t1[j] = t2[j] = 0.0f;
+            rin[j] = residual_in[gp];
+        } else {
+            rv[j] = ri[gp];
+            t0[j] = tm[3 * p]; t1[j] = tm[3 * p + 1]; t2[j] = tm[3 * p + 2];
+            rin[j] = residual_in ? residual_in[gp] : 0.0f;
+        }
     }
-    for (int i = threadIdx.x; i < 4 * K; i += 256) smodel[i] = model[(int64_t)b * K * 4 + i];
+    for (int i = threadIdx.x; i < 4 * K; i += 256) smodel[i] = RESIDUAL_ONLY ? 0.0f : model[(int64_t)b * K * 4 + i];
     for (int i = threadIdx.x; i < 16 * SEGP; i += 256) segcnt[i] = 0u;
     __syncthreads();
     int qv[4], rank[4];
@@ -1266,8 +1274,8 @@ __global__ __launch_bounds__(256) void predict_quantize_kernel(const float *__re
             float pr;
             if (p0 + p1 + p2 == 0.0f) pr = p3;                                        // cpp_modules.cpp:271-272
             else pr = -p3 / (p0 * t0[j] + p1 * t1[j] + p2 * t2[j]);                    // :275-277
-            if (pred_out) pred_out[gp] = pr;
-            const float res = residual_in ? rin[j] : rv[j] - pr;                      // compress.py:106
+            if (!RESIDUAL_ONLY && pred_out) pred_out[gp] = pr;
+            const float res = (RESIDUAL_ONLY || residual_in) ? rin[j] : rv[j] - pr;                      // compress.py:106
             const float step = label_acc ? label_acc[(int64_t)b * K + l] : acc;       // cpp_modules.cpp:404,419
             qv[j] = (int)roundf(res / step);                                          // cpp_modules.cpp:315
             lab[j] = (l == 1) ? -1 : l;                                               // label 1 is skipped (:314)
@@ -1306,8 +1314,12 @@ static int launch_predict_quantize(const float *ri, const float *tm, const uint8
     const int KP = kpad(M), T = ntiles(P);
     WsLayout L = ws_layout(ws, B, P, M);
     const size_t sh = (size_t)KP * 4 * 4 + (size_t)16 * (KP + 1) * 4;
-    predict_quantize_kernel<<<dim3(T, B), 256, sh, st>>>(ri, tm, seg, model, L.hist, acc, label_acc, residual_in, P, M, KP,
-                                                         T, q16, q32, pred);
+    if (residual_in && !pred)
+        predict_quantize_kernel<true><<<dim3(T, B), 256, sh, st>>>(ri, tm, seg, model, L.hist, acc, label_acc, residual_in, P,
+                                                                   M, KP, T, q16, q32, pred);
+    else
+        predict_quantize_kernel<false><<<dim3(T, B), 256, sh, st>>>(ri, tm, seg, model, L.hist, acc, label_acc, residual_in,
+                                                                    P, M, KP, T, q16, q32, pred);
     LAUNCH_CHECK();
     return RPCC_OK;
 }
@@ -1315,7 +1327,8 @@ static int launch_predict_quantize(const float *ri, const float *tm, const uint8
 extern "C" int rpcc_predict_quantize(const float *ri, const float *tm, const uint8_t *seg, const float *model,
                                      const float *label_acc, const float *residual_in, float acc, int B, int P, int M,
                                      int16_t *q16, int32_t *q32, int32_t *nnz, float *pred, void *ws, void *stream) {
-    ARG_TRY(B > 0 && P > 0 && M > 0 && M <= RPCC_MAX_CLUSTERS && ri && tm && seg && model && ws);
+    ARG_TRY(B > 0 && P > 0 && M > 0 && M <= RPCC_MAX_CLUSTERS && seg && ws);
+    ARG_TRY((residual_in && !pred) || (ri && tm && model));   // residual handed in, no prediction wanted: seg only
     ARG_TRY(q16 || q32);
     hipStream_t st = (hipStream_t)stream;
     // Self-contained entry: the tile offsets are rebuilt from this segmentation (histogram + scan with
