@@ -47,8 +47,15 @@ typedef struct rpcc_geom {
  *            rpcc_project_scratch_bytes(total,B,P) bytes the LDS-band path runs; with at least
  *            B*(P+8)*4 bytes the device-atomic path runs (same result).
  * Exact reference semantics incl. a depth-0 point resetting its pixel in input order.  Points
- * whose depth is not finite are skipped (reference: undefined behaviour). */
+ * whose depth is not finite are skipped (reference: undefined behaviour).
+ * The pixel of a point is first computed by a screened fast path and recomputed with the exact
+ * operation sequence whenever it is not provably the same (DESIGN.md "Projection").
+ * rpcc_project_fastpath_check (test hook): counts dev u64[5] = {points the fast path is certain
+ * about, of those the ones whose pixel differs from the exact sequence (must be 0), points sent
+ * to the exact sequence, largest |fast - exact| of the pre-rounding column and row coordinate in
+ * units of 1e-9 over the points of ordinary magnitude}. */
 size_t rpcc_project_scratch_bytes(int64_t total, int B, int P);
+int rpcc_project_fastpath_check(const float *xyz, int64_t total, rpcc_geom g, uint64_t *counts, void *stream);
 int rpcc_project(const float *xyz, const int64_t *offsets, int64_t total, int B, rpcc_geom g, float *ri,
                  void *scratch, size_t scratch_bytes, void *stream);
 

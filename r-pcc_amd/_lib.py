@@ -32,6 +32,7 @@ _SIGS = {
     "rpcc_version": (C.c_int, []),
     "rpcc_last_error": (C.c_char_p, []),
     "rpcc_project_scratch_bytes": (C.c_size_t, [_I64, _I, _I]),
+    "rpcc_project_fastpath_check": (C.c_int, [_VP, _I64, Geom, _VP, _VP]),
     "rpcc_project": (C.c_int, [_VP, _VP, _I64, _I, Geom, _VP, _VP, C.c_size_t, _VP]),
     "rpcc_ground_ransac": (C.c_int, [_VP, _VP, _I, _I, C.c_uint32, _VP, _VP, _VP]),
     "rpcc_ground_mask": (C.c_int, [_VP, _VP, _VP, _D, _I, _I, _I, _VP, _VP, _VP, _VP]),

@@ -31,28 +31,30 @@ __device__ __forceinline__ float atanf_fdlibm(float x) {
         if (ix > 0x7f800000) return x + x;
         return (hx > 0) ? hi3 + lo3 : -hi3 - lo3;
     }
-    float hi = 0.f, lo = 0.f;
-    bool reduced = true;
-    if (ix < 0x3ee00000) {
-        if (ix < 0x31000000) return x;
-        reduced = false;
-    } else {
-        x = fabsf(x);
-        if (ix < 0x3f980000) {
-            if (ix < 0x3f300000) { hi = hi0; lo = lo0; x = (2.0f * x - 1.0f) / (2.0f + x); }
-            else                 { hi = hi1; lo = lo1; x = (x - 1.0f) / (x + 1.0f); }
-        } else {
-            if (ix < 0x401c0000) { hi = hi2; lo = lo2; x = (x - 1.5f) / (1.0f + 1.5f * x); }
-            else                 { hi = hi3; lo = lo3; x = -1.0f / x; }
-        }
-    }
+    if (ix < 0x31000000) return x;
+    // The four argument reductions differ only in (numerator, denominator, hi, lo): all four are formed with
+    // the reference's own operations and selected per lane, so a wavefront whose lanes fall into different
+    // ranges executes ONE correctly rounded division instead of four divergent ones.  Without reduction
+    // (|x| < 0.4375) the division is x / 1 = x exactly.
+    const float ax = fabsf(x);
+    const bool reduced = ix >= 0x3ee00000, r0 = ix < 0x3f300000, r1 = ix < 0x3f980000, r2 = ix < 0x401c0000;
+    const float n0 = 2.0f * ax - 1.0f, d0 = 2.0f + ax;       // [0.4375, 0.6875)
+    const float n1 = ax - 1.0f, d1 = ax + 1.0f;              // [0.6875, 1.1875)
+    const float n2 = ax - 1.5f, d2 = 1.0f + 1.5f * ax;       // [1.1875, 2.4375)
+    float num = r2 ? (r1 ? (r0 ? n0 : n1) : n2) : -1.0f;     // else -1 / x
+    float den = r2 ? (r1 ? (r0 ? d0 : d1) : d2) : ax;
+    const float hi = r2 ? (r1 ? (r0 ? hi0 : hi1) : hi2) : hi3;
+    const float lo = r2 ? (r1 ? (r0 ? lo0 : lo1) : lo2) : lo3;
+    num = reduced ? num : x;
+    den = reduced ? den : 1.0f;
+    x = num / den;
     const float z = x * x;
     const float w = z * z;
     const float s1 = z * (a0 + w * (a2 + w * (a4 + w * (a6 + w * (a8 + w * a10)))));
     const float s2 = w * (a1 + w * (a3 + w * (a5 + w * (a7 + w * a9))));
-    if (!reduced) return x - x * (s1 + s2);
-    const float r = hi - ((x * (s1 + s2) - lo) - x);
-    return (hx < 0) ? -r : r;
+    const float t = x * (s1 + s2);
+    const float r = hi - ((t - lo) - x);
+    return reduced ? ((hx < 0) ? -r : r) : x - t;
 }
 
 __device__ __forceinline__ float atan2f_fdlibm(float y, float x) {

@@ -9,6 +9,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include "../../include/rpcc_hip.h"
 #include "rpcc_device.h"
 
@@ -98,6 +99,7 @@ struct FpsTimer {
 struct RowCol {
     float depth;
     int pix;
+    float colf, rowf;  // the values handed to roundf (test hook of the fast path)
 };
 
 __device__ __forceinline__ RowCol project_point(float x, float y, float z, const rpcc_geom g) {
@@ -106,10 +108,12 @@ __device__ __forceinline__ RowCol project_point(float x, float y, float z, const
     float az = atan2f_fdlibm(y, x);                               // :447
     if (az < 0) az = (float)((double)az + 2 * 3.14159265);        // :448-449 (double literal)
     const float el = atan2f_fdlibm(z, sqrtf(x * x + y * y));      // :450
-    int col = (int)roundf(az / g.horizontal_fov * (float)g.W);    // :451
-    col = col % g.W;                                              // :452
+    o.colf = az / g.horizontal_fov * (float)g.W;
+    int col = (int)roundf(o.colf);                                // :451
+    if (col < 0 || col >= g.W) col = col % g.W;                   // :452 (identity inside [0, W): skips the integer division)
     const float vres = (g.vertical_max - g.vertical_min) / (float)(g.H - 1);  // :453
-    int row = (int)roundf((el - g.vertical_min) / vres);          // :454
+    o.rowf = (el - g.vertical_min) / vres;
+    int row = (int)roundf(o.rowf);                                // :454
     row = row >= g.H ? g.H - 1 : row;                             // :455-458
     row = row < 0 ? 0 : row;
     o.pix = row * g.W + col;
@@ -199,11 +203,93 @@ __global__ __launch_bounds__(256) void project_finalize_kernel(uint32_t *__restr
 #define BAND_PX 32768  // 128 KiB of LDS
 #define BAND_THREADS 1024
 
-__global__ __launch_bounds__(256) void project_pix_kernel(const float *__restrict__ xyz, const int64_t *__restrict__ offs,
-                                                          int64_t total, int64_t base, int B, rpcc_geom g,
-                                                          uint2 *__restrict__ pd, int32_t *__restrict__ flags) {
-    const int64_t il = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // record index; point index = base + il
-    if (il >= total) return;
+// ---- screened fast path of the pixel computation -----------------------------------------------------------
+// project_point() costs ~330 VALU instructions per wavefront, almost all of it the two fdlibm atan2f
+// sequences and seven correctly rounded divisions -- but only the INTEGER pixel (row, col) is kept.  The fast
+// path computes the two angles with ~1e-6 rad accuracy (hardware rcp/sqrt, fma Horner polynomial), and
+// accepts its pixel only when both pre-rounding coordinates are farther from a rounding boundary than a
+// margin of 8x the worst-case discrepancy to the reference arithmetic (error budget: DESIGN.md "Projection").
+// Points that are not certain (about 3 % for 64x2048; every point with a special value, a zero depth or
+// column 0 / W) are queued in LDS and recomputed by the exact sequence.  The depth itself -- the payload --
+// is always the reference's sqrtf(x*x + y*y + z*z).  rpcc_project_fastpath_check() counts disagreements
+// between "certain" fast pixels and the exact ones (tests: must be 0).
+struct PixFastCfg {
+    float kcol, krow, vmin;  // W / hfov, 1 / vres
+    float ccol, crow;        // 0.5 - margin
+    int on;
+};
+#define PIX_ANGLE_ERR 2.0e-6f
+#define PIX_REL_ERR 6.0e-7f
+static PixFastCfg pix_fast_cfg(const rpcc_geom g) {
+    PixFastCfg c;
+    const float vres = (g.vertical_max - g.vertical_min) / (float)(g.H - 1);
+    c.kcol = (float)g.W / g.horizontal_fov;
+    c.krow = 1.0f / vres;
+    c.vmin = g.vertical_min;
+    const float mcol = 8.0f * (PIX_ANGLE_ERR * fabsf(c.kcol) + PIX_REL_ERR * (float)g.W);
+    const float mrow = 8.0f * ((PIX_ANGLE_ERR + 1.0e-7f) * fabsf(c.krow) + PIX_REL_ERR * ((float)g.H + fabsf(c.vmin * c.krow)));
+    c.ccol = 0.5f - mcol;
+    c.crow = 0.5f - mrow;
+    c.on = (g.H >= 2 && g.W >= 2 && g.horizontal_fov > 0.0f && vres > 0.0f && mcol < 0.2f && mrow < 0.2f &&
+            mcol == mcol && mrow == mrow) ? 1 : 0;
+    return c;
+}
+
+// atan(mn / mx) for 0 <= mn <= mx, mx > 0 (result in [0, pi/4]), absolute error < 5e-7
+__device__ __forceinline__ float fast_atan_pos(float mn, float mx) {
+    const float t = mn * __builtin_amdgcn_rcpf(mx);
+    const bool red = t > 0.41421356f;  // tan(pi/8): atan(t) = pi/4 + atan((t-1)/(t+1))
+    const float u = red ? (t - 1.0f) * __builtin_amdgcn_rcpf(t + 1.0f) : t;
+    const float z = u * u;
+    float p = 1.6285819933e-02f;
+    p = __builtin_fmaf(p, z, -3.6531571299e-02f);
+    p = __builtin_fmaf(p, z, 4.9768779427e-02f);
+    p = __builtin_fmaf(p, z, -5.8335702866e-02f);
+    p = __builtin_fmaf(p, z, 6.6610731184e-02f);
+    p = __builtin_fmaf(p, z, -7.6918758452e-02f);
+    p = __builtin_fmaf(p, z, 9.0908870101e-02f);
+    p = __builtin_fmaf(p, z, -1.1111110449e-01f);
+    p = __builtin_fmaf(p, z, 1.4285714924e-01f);
+    p = __builtin_fmaf(p, z, -2.0000000298e-01f);
+    p = __builtin_fmaf(p, z, 3.3333334327e-01f);
+    const float r = __builtin_fmaf(-u, z * p, u);
+    return red ? 0.78539816f + r : r;
+}
+
+// -> true when pix is certainly the reference's pixel
+__device__ __forceinline__ bool project_point_fast(float x, float y, float z, const rpcc_geom g, const PixFastCfg c, int &pix,
+                                                   float *colf_out = nullptr, float *rowf_out = nullptr) {
+    const float ax = fabsf(x), ay = fabsf(y), az = fabsf(z);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    // 2^-60 .. 2^60; false for NaN / inf / the origin (fmaxf drops a NaN operand, so every coordinate is tested itself)
+    bool ok = mx >= 8.7e-19f && ax <= 1.15e18f && ay <= 1.15e18f && az <= 1.15e18f;
+    float a = fast_atan_pos(mn, mx);
+    a = ay > ax ? 1.57079633f - a : a;
+    a = x < 0.0f ? 3.14159265f - a : a;
+    a = y < 0.0f ? 6.28318531f - a : a;  // = az + 2*pi of :448-449
+    const float colf = a * c.kcol;
+    const float c0 = rintf(colf);
+    ok = ok && fabsf(colf - c0) < c.ccol && c0 >= 1.0f && c0 <= (float)(g.W - 1);  // columns 0 / W (wrap) go the exact way
+    const float rho = __builtin_amdgcn_sqrtf(__builtin_fmaf(x, x, y * y));
+    float e = fast_atan_pos(fminf(az, rho), fmaxf(az, rho));
+    e = az > rho ? 1.57079633f - e : e;
+    e = z < 0.0f ? -e : e;
+    const float rowf = fminf(fmaxf((e - c.vmin) * c.krow, 0.0f), (float)(g.H - 1));  // the clamp of :455-458 first
+    const float r0 = rintf(rowf);
+    ok = ok && fabsf(rowf - r0) < c.crow;
+    pix = (int)r0 * g.W + (int)c0;
+    if (colf_out) { *colf_out = colf; *rowf_out = (e - c.vmin) * c.krow; }
+    return ok;
+}
+
+// A persistent 256-thread workgroup walks over 256-point chunks (small workgroups: the kernel shares the CUs with
+// the one-workgroup-per-frame kernels of the neighbouring batches, a 1024-thread workgroup would wait for 16 free
+// wave slots).  Uncertain points collect in an LDS queue that is drained by the exact sequence 256 at a time, i.e.
+// with full wavefronts.
+#define PIX_THREADS 256
+__device__ __forceinline__ void project_exact_record(const float *__restrict__ xyz, const int64_t *__restrict__ offs, int64_t base,
+                                                     int B, const rpcc_geom g, int64_t il, uint2 *__restrict__ pd,
+                                                     int32_t *__restrict__ flags) {
     const int64_t i = base + il;
     const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
     const RowCol rc = project_point(x, y, z, g);
@@ -217,6 +303,87 @@ __global__ __launch_bounds__(256) void project_pix_kernel(const float *__restric
         }
     }
     pd[il] = o;
+}
+
+__global__ __launch_bounds__(PIX_THREADS) void project_pix_kernel(const float *__restrict__ xyz, const int64_t *__restrict__ offs,
+                                                                  int64_t total, int64_t base, int B, rpcc_geom g, PixFastCfg cfg,
+                                                                  uint2 *__restrict__ pd, int32_t *__restrict__ flags) {
+    __shared__ int64_t queue[2 * PIX_THREADS];
+    __shared__ uint32_t qn;
+    if (threadIdx.x == 0) qn = 0u;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int64_t nchunks = (total + PIX_THREADS - 1) / PIX_THREADS;
+    for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const int64_t il = c * PIX_THREADS + threadIdx.x;  // record index; point index = base + il
+        bool slow = false;
+        if (il < total) {
+            const int64_t i = base + il;
+            const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+            int pix;
+            if (cfg.on && project_point_fast(x, y, z, g, cfg, pix))
+                pd[il] = make_uint2((uint32_t)pix, f2u(sqrtf(x * x + y * y + z * z)));  // depth: :446 (finite, > 0 here)
+            else
+                slow = true;
+        }
+        const unsigned long long sm = __ballot(slow);
+        if (sm) {
+            const int leader = (int)__ffsll((long long)sm) - 1;
+            uint32_t q0 = 0u;
+            if (lane == leader) q0 = atomicAdd(&qn, (uint32_t)__popcll(sm));
+            q0 = (uint32_t)__builtin_amdgcn_readlane((int)q0, leader);
+            if (slow) queue[q0 + __popcll(sm & ((1ull << lane) - 1ull))] = il;
+        }
+        __syncthreads();
+        const uint32_t n = qn;
+        __syncthreads();
+        if (n >= PIX_THREADS) {  // a full workgroup of uncertain points: the exact sequence
+            project_exact_record(xyz, offs, base, B, g, queue[n - PIX_THREADS + threadIdx.x], pd, flags);
+            __syncthreads();
+            if (threadIdx.x == 0) qn = n - PIX_THREADS;
+            __syncthreads();
+        }
+    }
+    const uint32_t n = qn;
+    if (threadIdx.x < n) project_exact_record(xyz, offs, base, B, g, queue[threadIdx.x], pd, flags);
+}
+
+// test hook: counts[0] = points the fast path is certain about, counts[1] = of those, points whose pixel differs
+// from the exact sequence (must be 0), counts[2] = points sent to the exact sequence, counts[3] / counts[4] = largest
+// |fast - exact| of the pre-rounding column / row coordinate over the points of ordinary magnitude, in units of 1e-9
+// (the error budget the margins are derived from)
+__global__ __launch_bounds__(256) void project_fastcheck_kernel(const float *__restrict__ xyz, int64_t total, rpcc_geom g,
+                                                                PixFastCfg cfg, unsigned long long *__restrict__ counts) {
+    unsigned long long sure = 0ull, bad = 0ull, slow = 0ull;
+    float dc = 0.0f, dr = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+        int pix;
+        float cf, rf;
+        const bool ok = project_point_fast(x, y, z, g, cfg, pix, &cf, &rf) && cfg.on;
+        const RowCol rc = project_point(x, y, z, g);
+        const float mx = fmaxf(fabsf(x), fabsf(y));
+        if (mx >= 8.7e-19f && fabsf(x) <= 1.15e18f && fabsf(y) <= 1.15e18f && fabsf(z) <= 1.15e18f) {
+            float d = fabsf(cf - rc.colf);
+            d = fminf(d, fabsf(d - (float)g.W));  // azimuth 0 == 2*pi
+            dc = fmaxf(dc, d);
+            if (fabsf(rc.rowf) < 1.0e6f) dr = fmaxf(dr, fabsf(rf - rc.rowf));
+        }
+        if (ok) {
+            sure++;
+            if (!(fabsf(rc.depth) <= 3.402823466e+38f) || rc.depth == 0.0f || rc.pix != pix) bad++;
+        } else {
+            slow++;
+        }
+    }
+    const int s = wave_sum_i32((int)sure), b2 = wave_sum_i32((int)bad), sl = wave_sum_i32((int)slow);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&counts[0], (unsigned long long)s);
+        atomicAdd(&counts[1], (unsigned long long)b2);
+        atomicAdd(&counts[2], (unsigned long long)sl);
+    }
+    atomicMax(&counts[3], (unsigned long long)(dc * 1.0e9f));
+    atomicMax(&counts[4], (unsigned long long)(dr * 1.0e9f));
 }
 
 __global__ __launch_bounds__(BAND_THREADS) void project_band_kernel(const uint2 *__restrict__ pd,
@@ -258,6 +425,15 @@ static size_t project_scratch_bytes(int64_t total, int B, int P) {
 }
 extern "C" size_t rpcc_project_scratch_bytes(int64_t total, int B, int P) { return project_scratch_bytes(total, B, P); }
 
+extern "C" int rpcc_project_fastpath_check(const float *xyz, int64_t total, rpcc_geom g, uint64_t *counts, void *stream) {
+    ARG_TRY(xyz && counts && total > 0 && g.H > 0 && g.W > 0);
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(counts, 0, 5 * sizeof(uint64_t), st));
+    project_fastcheck_kernel<<<4096, 256, 0, st>>>(xyz, total, g, pix_fast_cfg(g), reinterpret_cast<unsigned long long *>(counts));
+    LAUNCH_CHECK();
+    return RPCC_OK;
+}
+
 // On return ri is final (0 = empty pixel).  scratch_bytes < rpcc_project_scratch_bytes() selects the
 // atomic path, which only needs B*(P+8)*4 bytes.
 static int launch_project(const float *xyz, const int64_t *offsets, int64_t total, int64_t base, int B, rpcc_geom g,
@@ -273,7 +449,9 @@ static int launch_project(const float *xyz, const int64_t *offsets, int64_t tota
     if (fast) {
         uint2 *pd = reinterpret_cast<uint2 *>(reinterpret_cast<char *>(scratch) + ((size_t)B * ((size_t)P + 8)) * 4 + 256);
         HIP_TRY(hipMemsetAsync(flags, 0, (size_t)(B + 1) * 4, st));
-        if (total > 0) project_pix_kernel<<<nb, 256, 0, st>>>(xyz, offsets, total, base, B, g, pd, flags);
+        if (total > 0)
+            project_pix_kernel<<<(unsigned)std::min<int64_t>((total + PIX_THREADS - 1) / PIX_THREADS, 256 * 16), PIX_THREADS, 0, st>>>(
+                xyz, offsets, total, base, B, g, pix_fast_cfg(g), pd, flags);
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&project_band_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, BAND_PX * 4));
         project_band_kernel<<<dim3((P + BAND_PX - 1) / BAND_PX, B), BAND_THREADS, BAND_PX * 4, st>>>(pd, offsets, base, P, rb, flags);

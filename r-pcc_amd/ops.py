@@ -58,6 +58,16 @@ def project(xyz, offsets, geom, ri=None, scratch=None, atomic_path=False):
     return ri
 
 
+def project_fastpath_check(xyz, geom):
+    """Test hook of a2: (points the screened fast path is certain about, of those the ones whose pixel differs
+    from the exact sequence -- must be 0 --, points sent to the exact sequence, max column discrepancy, max row
+    discrepancy of the pre-rounding coordinates [pixels])."""
+    counts = torch.zeros((5,), dtype=torch.int64, device=_dev(xyz))
+    check(_lib.lib().rpcc_project_fastpath_check(ptr(xyz), int(xyz.shape[0]), geom, ptr(counts), stream()))
+    c = [int(v) for v in counts.cpu()]
+    return c[0], c[1], c[2], c[3] * 1e-9, c[4] * 1e-9
+
+
 def ground_ransac(ri, tm, seed=0):
     """a4: seeded ground-plane RANSAC -> (ground f64 [B,4], inlier counts i32 [B])."""
     B = ri.shape[0]

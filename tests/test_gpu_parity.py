@@ -603,3 +603,68 @@ def test_plane_model(env, case, angle):
     assert _beq(pred[0].cpu().numpy().reshape(g.H, g.W, 1), pr)
     qo = orc.uniform_quantize(seg_np.astype(np.int32), ri_np.reshape(g.H, g.W, 1) - pr, 0.04)
     assert np.array_equal(q[0, : int(nnz[0])].cpu().numpy(), qo)
+
+
+@pytest.mark.parametrize("gname", ["Velodyne64E_2048", "Velodyne64E", "Velodyne32E", "VelodyneVLP16"])
+def test_projection_fast_path_never_disagrees(env, gname):
+    """a2: the screened fast pixel computation (DESIGN.md "Projection") must agree with the exact fdlibm/IEEE sequence
+    on every point it claims to be certain about -- random, lidar-like, boundary-adversarial and special-value inputs,
+    ~1e8 points per geometry, compared on the device (rpcc_project_fastpath_check).  The exact sequence itself is
+    pinned against the oracle / golden vectors by the other projection tests."""
+    torch, ops = env["torch"], env["ops"]
+    g, geom, _ = _geom(env, gname)
+    dev = env["dev"]
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234)
+    n = 1 << 25
+
+    def rnd(*shape):
+        return torch.rand(*shape, generator=gen, device=dev, dtype=torch.float64)
+
+    def dirs(az, el, r):
+        return torch.stack((r * torch.cos(el) * torch.cos(az), r * torch.cos(el) * torch.sin(az), r * torch.sin(el)), 1).float()
+
+    vfov = g.vertical_max - g.vertical_min
+    sets = {}
+    sets["cube"] = ((rnd(n, 3) - 0.5) * 160).float()
+    # lidar-like: every direction of the sweep, jittered inside the pixel
+    az = rnd(n) * g.horizontal_FOV
+    el = g.vertical_min + rnd(n) * vfov
+    sets["sweep"] = dirs(az, el, 1 + rnd(n) * 100)
+    # adversarial: directions within +-2e-5 rad of a column / row rounding boundary
+    kc = torch.randint(0, g.W, (n,), generator=gen, device=dev).double()
+    kr = torch.randint(0, g.H, (n,), generator=gen, device=dev).double()
+    eps = (rnd(n) - 0.5) * 4e-5
+    az_b = (kc + 0.5) * (g.horizontal_FOV / g.W) + eps
+    el_b = g.vertical_min + (kr + 0.5) * (vfov / (g.H - 1)) + (rnd(n) - 0.5) * 4e-5
+    sets["col_boundary"] = dirs(az_b, el, 1 + rnd(n) * 100)
+    sets["row_boundary"] = dirs(az, el_b, 1 + rnd(n) * 100)
+    sets["above_below"] = dirs(az, (rnd(n) - 0.5) * 3.1, 1 + rnd(n) * 50)           # outside the vertical FOV: clamped rows
+    # magnitudes from 1e-30 to 1e30, signs, exact zeros, x == 1, axis-aligned points
+    mag = torch.pow(10.0, (rnd(n, 3) - 0.5) * 60)
+    sgn = torch.where(rnd(n, 3) < 0.5, -1.0, 1.0)
+    sp = (mag * sgn).float()
+    sp[::7, 0] = 0.0
+    sp[1::11, 1] = 0.0
+    sp[2::13, 2] = -0.0
+    sp[3::17, 0] = 1.0
+    sp[4::19] = 0.0
+    sp[5::23, 1] = float("inf")
+    sp[6::29, 2] = float("nan")
+    sets["special"] = sp
+    tot_sure = 0
+    for name, xyz in sets.items():
+        sure, bad, slow, dcol, drow = ops.project_fastpath_check(xyz.contiguous(), geom)
+        assert sure + slow == xyz.shape[0]
+        assert bad == 0, (name, sure, bad, slow)
+        # the margins are 8x the analytic worst case (pix_fast_cfg): the observed discrepancy must stay below the
+        # budget itself, i.e. below 1/8 of the margin
+        mcol = 8 * (2.0e-6 * g.W / g.horizontal_FOV + 6.0e-7 * g.W)
+        mrow = 8 * (2.1e-6 * (g.H - 1) / vfov + 6.0e-7 * (g.H + abs(g.vertical_min) * (g.H - 1) / vfov))
+        assert dcol < mcol / 8 and drow < mrow / 8, (name, dcol, mcol, drow, mrow)
+        print("fastpath %-13s %-16s sure %.4f  dcol %.2e (budget %.2e)  drow %.2e (budget %.2e)"
+              % (name, gname, sure / xyz.shape[0], dcol, mcol / 8, drow, mrow / 8))
+        tot_sure += sure
+        if name == "sweep":
+            assert slow < 0.1 * n, (name, slow / n)     # the fast path must carry the ordinary points
+    assert tot_sure > 0
