@@ -1069,7 +1069,60 @@ extern "C" int rpcc_fps_range(const float *ri, const float *tm, float *temp, con
 // visited in ascending index order with the two-smallest tracking below -- identical labels.
 __device__ __forceinline__ float next_up_pos(float v) { return u2f(f2u(v) + 1u); }  // v >= 0, finite
 
-#define ASSIGN_TILES_PER_WAVE 4
+// v4: a wavefront owns a 4-row x 32-column tile, two horizontally adjacent pixels per lane (the box reductions and
+// the screening of the M centres are paid once per 128 pixels), and the two rarely decisive parts are screened:
+//   * sqrt-level ties: sqrtf(m2) can equal sqrtf(m1) only if m2 <= m1 * (1 + 2^-22 + ...) -- the window U is computed
+//     only behind  m2 <= m1 * 1.0000005f;
+//   * ground versus cluster: the fp64 ground term |r - (-d / den)| is first estimated in fp32 together with a bound of
+//     its error (representation of the plane, the three roundings of den, rcp, the subtraction); the fp64 sequence
+//     runs only for pixels whose radius lies inside that error band (NaN / inf / a ray parallel to the plane fall
+//     through to it automatically because every comparison with NaN is false).
+struct AssignGround {
+    double a, b, c, d;
+    float af, bf, cf, df, S;  // S >= |a| + |b| + |c|
+};
+__device__ __forceinline__ int assign_label(float r, float tx, float ty, float tz, float x, float y, float z, float m1, float m2,
+                                            int k1, const float4 *cen4, const AssignGround &G) {
+    if (k1 < 0) return 0;
+    // radius = sqrtf(min d2).  Every squared distance that rounds to the same radius ties with it, and numpy's
+    // argmax keeps the lowest index: U = largest float whose sqrtf equals the radius.
+    const float s = sqrtf(m1);
+    int kk = k1;
+    if (m2 <= m1 * 1.0000005f) {  // another centre may tie after the square root (rare)
+        float U = m1;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const float n = next_up_pos(U);
+            if (U < 3.0e38f && sqrtf(n) == s) U = n;
+        }
+        if (m2 <= U) {  // first index with d2 <= U
+            for (int k = 0; k < kk; k++) {
+                const float4 cc = cen4[k];
+                const float dx = x - cc.x, dy = y - cc.y, dz = z - cc.z;
+                if ((dx * dx + dy * dy) + dz * dz <= U) { kk = k; break; }
+            }
+        }
+    }
+    const float denf = __builtin_fmaf(tx, G.af, __builtin_fmaf(ty, G.bf, tz * G.cf));
+    const float rinv = __builtin_amdgcn_rcpf(denf);
+    const float qf = -G.df * rinv;
+    const float agf = fabsf(r - qf);
+    const float rel = 3.0e-7f * G.S * fabsf(rinv);  // |den error| / |den|
+    const float err = fabsf(qf) * (rel + 4.0e-7f) + fabsf(r) * 1.0e-7f + agf * 1.5e-7f;
+    bool cluster;
+    if (rel < 0.01f && s < agf - err) {
+        cluster = true;
+    } else if (rel < 0.01f && s > agf + err) {
+        cluster = false;
+    } else {  // inside the error band (or not finite): the reference's fp64 sequence
+        const double den = ((double)tx * G.a + (double)ty * G.b) + (double)tz * G.c;
+        const double ag = fabs((double)r - (-G.d / den));
+        cluster = !(ag != ag) && (double)s < ag;  // ground (index 0) wins ties and NaN
+    }
+    return cluster ? kk + 2 : 0;
+}
+
+#define ASSIGN_TILES_PER_WAVE 2
 __global__ __launch_bounds__(256) void assign_kernel(const float *__restrict__ ri, const float *__restrict__ tm,
                                                      const double *__restrict__ ground,
                                                      const float *__restrict__ centers, int H, int W, int M,
@@ -1082,25 +1135,40 @@ __global__ __launch_bounds__(256) void assign_kernel(const float *__restrict__ r
         cen4[i] = make_float4(c[0], c[1], c[2], 0.0f);
     }
     __syncthreads();
-    const double a = ground[4 * b], bb = ground[4 * b + 1], c = ground[4 * b + 2], d = ground[4 * b + 3];
-    const int tcols = (W + 15) >> 4, ntile = ((H + 3) >> 2) * tcols;
+    AssignGround G;
+    G.a = ground[4 * b]; G.b = ground[4 * b + 1]; G.c = ground[4 * b + 2]; G.d = ground[4 * b + 3];
+    G.af = (float)G.a; G.bf = (float)G.b; G.cf = (float)G.c; G.df = (float)G.d;
+    G.S = (float)((fabs(G.a) + fabs(G.b) + fabs(G.c)) * 1.001);
+    const int tcols = (W + 31) >> 5, ntile = ((H + 3) >> 2) * tcols;
     const int t0 = (blockIdx.x * 4 + wave) * ASSIGN_TILES_PER_WAVE;
+    const float inf = __builtin_inff();
     for (int t = t0; t < min(t0 + ASSIGN_TILES_PER_WAVE, ntile); t++) {
-        const int row = (t / tcols) * 4 + (lane >> 4), col = (t % tcols) * 16 + (lane & 15);
-        const bool valid = row < H && col < W;
-        const int p = valid ? row * W + col : 0;
-        float r = ri[(int64_t)b * P + p];
-        if (!valid) r = 0.0f;
-        const float tx = tm[3 * p], ty = tm[3 * p + 1], tz = tm[3 * p + 2];
-        const float x = r * tx, y = r * ty, z = r * tz;
-        const bool live = valid && r != 0.0f;
-        if (__ballot(live) == 0ull) {  // nothing but empty pixels
-            if (valid) seg[(int64_t)b * P + p] = 1;
+        const int row = (t / tcols) * 4 + (lane >> 4), col0 = (t % tcols) * 32 + 2 * (lane & 15);
+        bool valid[2], live[2];
+        int p[2];
+        float r[2], tx[2], ty[2], tz[2], x[2], y[2], z[2];
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            valid[e] = row < H && col0 + e < W;
+            p[e] = valid[e] ? row * W + col0 + e : 0;
+            r[e] = ri[(int64_t)b * P + p[e]];
+            if (!valid[e]) r[e] = 0.0f;
+            tx[e] = tm[3 * p[e]]; ty[e] = tm[3 * p[e] + 1]; tz[e] = tm[3 * p[e] + 2];
+            x[e] = r[e] * tx[e]; y[e] = r[e] * ty[e]; z[e] = r[e] * tz[e];
+            live[e] = valid[e] && r[e] != 0.0f;
+        }
+        if (__ballot(live[0] || live[1]) == 0ull) {  // nothing but empty pixels
+#pragma unroll
+            for (int e = 0; e < 2; e++)
+                if (valid[e]) seg[(int64_t)b * P + p[e]] = 1;
             continue;
         }
-        const float inf = __builtin_inff();
-        const float lo0 = dpp_min_f32(live ? x : inf), lo1 = dpp_min_f32(live ? y : inf), lo2 = dpp_min_f32(live ? z : inf);
-        const float hi0 = dpp_max_f32(live ? x : -inf), hi1 = dpp_max_f32(live ? y : -inf), hi2 = dpp_max_f32(live ? z : -inf);
+        const float lo0 = dpp_min_f32(fminf(live[0] ? x[0] : inf, live[1] ? x[1] : inf));
+        const float lo1 = dpp_min_f32(fminf(live[0] ? y[0] : inf, live[1] ? y[1] : inf));
+        const float lo2 = dpp_min_f32(fminf(live[0] ? z[0] : inf, live[1] ? z[1] : inf));
+        const float hi0 = dpp_max_f32(fmaxf(live[0] ? x[0] : -inf, live[1] ? x[1] : -inf));
+        const float hi1 = dpp_max_f32(fmaxf(live[0] ? y[0] : -inf, live[1] ? y[1] : -inf));
+        const float hi2 = dpp_max_f32(fmaxf(live[0] ? z[0] : -inf, live[1] ? z[1] : -inf));
         // screen the centres: lane handles centres lane, lane+64, ...
         float my_dmin[4], upper = inf;
 #pragma unroll
@@ -1118,8 +1186,8 @@ __global__ __launch_bounds__(256) void assign_kernel(const float *__restrict__ r
         }
         upper = dpp_min_f32(upper);
         const float cut = upper * 1.000002f;
-        float m1 = inf, m2 = inf;
-        int k1 = -1;
+        float m1[2] = {inf, inf}, m2[2] = {inf, inf};
+        int k1[2] = {-1, -1};
 #pragma unroll
         for (int rd = 0; rd < 4; rd++) {
             if (rd * 64 >= M) break;
@@ -1128,45 +1196,29 @@ __global__ __launch_bounds__(256) void assign_kernel(const float *__restrict__ r
                 const int k = rd * 64 + (int)__ffsll((long long)surv) - 1;
                 surv &= surv - 1ull;
                 const float4 cc = cen4[k];
-                const float dx = x - cc.x, dy = y - cc.y, dz = z - cc.z;
-                const float d2 = (dx * dx + dy * dy) + dz * dz;
-                const bool lt = d2 < m1;
-                m2 = lt ? m1 : fminf(m2, d2);
-                k1 = lt ? k : k1;
-                m1 = lt ? d2 : m1;
-            }
-        }
-        int label = 0;
-        if (k1 >= 0) {
-            // radius = sqrtf(min d2).  Every squared distance that rounds to the same radius ties with it,
-            // and numpy's argmax keeps the lowest index: U = largest float whose sqrtf equals the radius.
-            const float s = sqrtf(m1);
-            float U = m1;
 #pragma unroll
-            for (int j = 0; j < 3; j++) {
-                const float n = next_up_pos(U);
-                if (U < 3.0e38f && sqrtf(n) == s) U = n;
-            }
-            int kk = k1;
-            if (m2 <= U) {  // another centre may tie after the square root (rare): first index with d2 <= U
-                for (int k = 0; k < kk; k++) {
-                    const float4 cc = cen4[k];
-                    const float dx = x - cc.x, dy = y - cc.y, dz = z - cc.z;
-                    if ((dx * dx + dy * dy) + dz * dz <= U) { kk = k; break; }
+                for (int e = 0; e < 2; e++) {
+                    const float dx = x[e] - cc.x, dy = y[e] - cc.y, dz = z[e] - cc.z;
+                    const float d2 = (dx * dx + dy * dy) + dz * dz;
+                    const bool lt = d2 < m1[e];
+                    m2[e] = lt ? m1[e] : fminf(m2[e], d2);
+                    k1[e] = lt ? k : k1[e];
+                    m1[e] = lt ? d2 : m1[e];
                 }
             }
-            const double den = ((double)tx * a + (double)ty * bb) + (double)tz * c;
-            const double ag = fabs((double)r - (-d / den));
-            if (!(ag != ag) && (double)s < ag) label = kk + 2;  // ground (index 0) wins ties and NaN
         }
-        if (r == 0.0f) label = 1;
-        if (valid) seg[(int64_t)b * P + p] = (uint8_t)label;
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            int label = assign_label(r[e], tx[e], ty[e], tz[e], x[e], y[e], z[e], m1[e], m2[e], k1[e], cen4, G);
+            if (r[e] == 0.0f) label = 1;
+            if (valid[e]) seg[(int64_t)b * P + p[e]] = (uint8_t)label;
+        }
     }
 }
 
 static int launch_assign(const float *ri, const float *tm, const double *ground, const float *centers, int B, int H,
                          int W, int M, uint8_t *seg, hipStream_t st) {
-    const int ntile = ((H + 3) / 4) * ((W + 15) / 16);
+    const int ntile = ((H + 3) / 4) * ((W + 31) / 32);
     const dim3 grid((ntile + 4 * ASSIGN_TILES_PER_WAVE - 1) / (4 * ASSIGN_TILES_PER_WAVE), B);
     assign_kernel<<<grid, 256, (size_t)M * sizeof(float4), st>>>(ri, tm, ground, centers, H, W, M, seg);
     LAUNCH_CHECK();

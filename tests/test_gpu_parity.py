@@ -315,6 +315,45 @@ def test_assign_sqrt_ties_and_duplicates(env):
     assert np.array_equal(exp, orc.np_assign(ri.reshape(g.H, g.W, 1), pc.reshape(g.H, g.W, 3), tm, plane, cen))
 
 
+def test_assign_ground_screen_band(env):
+    """a7: the fp32 screen of the ground term (DESIGN.md "assign") must hand every pixel whose cluster radius lies
+    inside its error band to the fp64 sequence: centres placed at a distance equal to the pixel's ground residual
+    up to relative offsets of 0 .. 1e-5, planes that are not normalised, nearly parallel to rays, through the
+    origin, or not finite."""
+    torch, ops, orc = env["torch"], env["ops"], env["orc"]
+    g, geom, tm = _geom(env, "Velodyne32E")
+    rng = np.random.default_rng(77)
+    ri = rng.uniform(3, 50, (g.H, g.W)).astype(np.float32)
+    ri[rng.random(ri.shape) < 0.05] = 0
+    pc = orc.backproject(ri, tm).reshape(-1, 3)
+    tmf = tm.reshape(-1, 3).astype(np.float64)
+    M = 100
+    planes = [np.array([0.01, -0.02, -0.9997, -1.72]), np.array([10.0, -20.0, -999.7, -1720.0]),
+              np.array([1e-3, 2e-3, -0.5e-3, -1e-3]), np.array([0.0, 0.3, -0.05, -0.4]), np.array([0.02, 0.01, -1.0, 0.0]),
+              np.array([np.nan, 0.0, -1.0, -1.7]), np.array([0.0, 0.0, -1.0, np.inf]), np.array([0.0, 0.0, 0.0, -1.7])]
+    n_band = 0
+    for plane in planes:
+        cen = pc[rng.choice(pc.shape[0], M, replace=False)].copy()
+        with np.errstate(all="ignore"):
+            den = (tmf[:, 0] * plane[0] + tmf[:, 1] * plane[1]) + tmf[:, 2] * plane[2]
+            ag = np.abs(ri.reshape(-1).astype(np.float64) - (-plane[3] / den))
+        ok = np.flatnonzero(np.isfinite(ag) & (ag > 0.05) & (ag < 30) & (ri.reshape(-1) != 0))
+        if ok.size >= M:
+            pix = rng.choice(ok, M, replace=False)
+            for j, p in enumerate(pix):
+                u = rng.normal(0, 1, 3)
+                u /= np.linalg.norm(u)
+                delta = [0.0, 1e-8, -1e-8, 1e-7, -1e-7, 1e-6, -1e-6, 1e-5, -1e-5, 3e-8][j % 10]
+                cen[j] = (pc[p].astype(np.float64) + u * ag[p] * (1 + delta)).astype(np.float32)
+            d = pc[pix].astype(np.float32) - cen
+            rad = np.sqrt(((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]).astype(np.float32)).astype(np.float64)
+            n_band += int((np.abs(rad - ag[pix]) < 1e-5 * ag[pix]).sum())
+        exp = orc.assign(ri, pc.reshape(g.H, g.W, 3), tm, plane, cen)
+        got = ops.assign(_to(env, ri[None]), _to(env, tm), _to(env, plane[None]), _to(env, cen[None]))[0].cpu().numpy()
+        assert np.array_equal(got, exp.astype(np.uint8)), plane
+    assert n_band > 100, "test inputs must contain pixels inside the screen's error band"
+
+
 def test_fps_tiled_equals_bruteforce(env):
     """The tile-pruned FPS kernels are exact: same indices, same centres AND the same final temp array
     (bit for bit) as the brute-force kernels, on range images and on explicit point lists."""
