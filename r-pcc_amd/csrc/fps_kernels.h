@@ -61,7 +61,7 @@ __device__ __forceinline__ int fps_tile_of(const FpsTiling &g, int p) {
 struct FpsLds {
     float *lo[3], *hi[3], *tmax, *cx[3];
     uint32_t *targ;
-    uint32_t *torg;   // range image: (first row << 16) | first column of the tile (avoids a division per visit)
+    uint32_t *torg;   // range image: first pixel of the tile | valid columns (1..32) << 23 | valid rows (1..4) << 29
     uint16_t *work;
     __device__ FpsLds(unsigned char *base, int T) {
         float *f = reinterpret_cast<float *>(base);
@@ -162,20 +162,23 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_tiled_kernel(const float *__r
     if (RANGE) {
         for (int t = tid; t < T; t += FPS_THREADS) {
             const int tr = t / g.tcols, tc = t - tr * g.tcols;
-            L.torg[t] = ((uint32_t)(4 * tr) << 16) | (uint32_t)(32 * tc);
+            const int ncol = min(32, g.W - 32 * tc), nrow = min(4, g.H - 4 * tr);
+            L.torg[t] = (uint32_t)(4 * tr * g.W + 32 * tc) | ((uint32_t)ncol << 23) | ((uint32_t)nrow << 29);
         }
     }
     __syncthreads();
     // A tile's data in registers (loads are issued for a group of tiles before any is consumed, so the
     // memory latency of a round is paid once per group; all loads are unconditional on clamped indices).
     struct TileRegs { float x[2], y[2], z[2], tp[2]; int p[2]; };
+    const int lrow = lane >> 5, lcol = lane & 31;
+    const int loff0 = lrow * g.W + lcol, loff1 = loff0 + 2 * g.W;  // lane's pixel offset inside a tile (halves 0 / 1)
     auto load_tile = [&](int t, TileRegs &q) {
         const uint32_t org = RANGE ? L.torg[t] : 0u;
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             if (RANGE) {
-                const int row = (int)(org >> 16) + 2 * h + (lane >> 5), col = (int)(org & 0xFFFFu) + (lane & 31);
-                q.p[h] = (row < g.H && col < g.W) ? row * g.W + col : -1;
+                const bool ok = lcol < (int)((org >> 23) & 63u) && 2 * h + lrow < (int)(org >> 29);
+                q.p[h] = ok ? (int)(org & 0x7FFFFFu) + (h ? loff1 : loff0) : -1;
             } else {
                 q.p[h] = fps_tile_point<RANGE>(g, t, h, lane);
             }
@@ -198,6 +201,8 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_tiled_kernel(const float *__r
             nt[h] = d < q.tp[h] ? d : q.tp[h];  // == fminf(d, tp): a NaN distance keeps tp, tp itself is never NaN
             if (valid[h] && nt[h] != q.tp[h]) temp[q.p[h]] = nt[h];
         }
+        // nothing changed in this tile: its table entry (maximum, arg, coordinates) is still exact
+        if (!with_box && __ballot((valid[0] && nt[0] != q.tp[0]) || (valid[1] && nt[1] != q.tp[1])) == 0ull) return;
         if (with_box) {
             float lo[3], hi[3];
             fps_tile_box(q.x, q.y, q.z, cand, lo, hi);
