@@ -341,12 +341,21 @@ __global__ __launch_bounds__(256) void ground_mask_tab_kernel(float *__restrict_
     const double a = ground[4 * b], bb = ground[4 * b + 1], c = ground[4 * b + 2], d = ground[4 * b + 3];
     // np.linalg.norm(plane_param[:, :3]) on a (1,1,4) array: all four components (segment_utils.py:47)
     const double div = sqrt(((a * a + bb * bb) + c * c) + d * d);
+    // fabs(s + d) / div > thr without the division for all but the borderline pixels: with T = thr * div (one
+    // rounding) a numerator above T * (1 + 1e-15) has a correctly rounded quotient above thr, one below
+    // T * (1 - 1e-15) a quotient below thr; everything else (incl. NaN, a degenerate plane or threshold) divides.
+    const double thr_div = thr * div;
+    const bool screen = thr >= 1e-200 && thr_div >= 1e-200 && thr_div <= 1e200;
+    const double t_hi = thr_div * (1.0 + 1e-15), t_lo = thr_div * (1.0 - 1e-15);
     auto load_px = [&](int p, float &r, float &x, float &y, float &z) -> bool {  // returns "is a candidate"
         r = ri[(int64_t)b * P + p];
         if (RAW && f2u(r) == RI_EMPTY) r = 0.0f;
         x = r * tm[3 * p]; y = r * tm[3 * p + 1]; z = r * tm[3 * p + 2];
         const double s = ((double)x * a + (double)y * bb) + (double)z * c;
-        return fabs(s + d) / div > thr;
+        const double num = fabs(s + d);
+        if (screen && num > t_hi) return true;
+        if (screen && num < t_lo) return false;
+        return num / div > thr;
     };
     bool fast;
     float c0, c1, c2;

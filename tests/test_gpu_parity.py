@@ -315,6 +315,38 @@ def test_assign_sqrt_ties_and_duplicates(env):
     assert np.array_equal(exp, orc.np_assign(ri.reshape(g.H, g.W, 1), pc.reshape(g.H, g.W, 3), tm, plane, cen))
 
 
+def test_ground_mask_threshold_boundary(env):
+    """a5: depth_dif > threshold with the threshold set exactly ON, one ulp below and one ulp above the fp64 quotient
+    of chosen pixels (the kernel screens the division and must divide for exactly these), plus degenerate planes and
+    thresholds; with and without the fused FPS table."""
+    torch, ops, orc = env["torch"], env["ops"], env["orc"]
+    g, geom, tm = _geom(env, "VelodyneVLP16")
+    rng = np.random.default_rng(5)
+    ri = rng.uniform(2, 40, (g.H, g.W)).astype(np.float32)
+    ri[rng.random(ri.shape) < 0.1] = 0
+    pc = orc.backproject(ri, tm)
+    cases = []
+    for plane in (np.array([0.01, -0.02, -0.9997, -1.72]), np.array([3.0, -1.0, -250.0, -431.0]), np.array([1e-9, 2e-9, -3e-8, -5e-8])):
+        dd = orc.vertical_residual(pc, plane).reshape(-1)
+        for p in rng.choice(dd.size, 6, replace=False):
+            for thr in (dd[p], np.nextafter(dd[p], 0), np.nextafter(dd[p], np.inf)):
+                cases.append((plane, float(thr)))
+    cases += [(np.zeros(4), 0.1), (np.array([0.0, 0.0, -1.0, -1.7]), 0.0), (np.array([0.0, 0.0, -1.0, -1.7]), -0.5),
+              (np.array([0.0, 0.0, -1e200, -1e200]), 0.1), (np.array([np.nan, 0.0, -1.0, -1.7]), 0.1),
+              (np.array([0.0, 0.0, -1.0, -1.7]), 1e-300)]
+    n_on = 0
+    for plane, thr in cases:
+        with np.errstate(all="ignore"):
+            exp = orc.vertical_residual(pc, plane).reshape(-1) > thr
+        n_on += int((orc.vertical_residual(pc, plane).reshape(-1) == thr).sum())
+        for tab in (False, True):
+            out = ops.ground_mask(_to(env, ri[None]), _to(env, tm), _to(env, plane[None]), thr, fps_table=tab)
+            temp, info = out[0], out[1]
+            assert np.array_equal(temp[0].cpu().numpy() >= 0, exp), (plane, thr, tab)
+            assert int(info[0, 0]) == int(exp.sum())
+    assert n_on >= 18
+
+
 def test_assign_ground_screen_band(env):
     """a7: the fp32 screen of the ground term (DESIGN.md "assign") must hand every pixel whose cluster radius lies
     inside its error band to the fp64 sequence: centres placed at a distance equal to the pixel's ground residual
