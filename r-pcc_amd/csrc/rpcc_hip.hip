@@ -386,10 +386,18 @@ __global__ __launch_bounds__(256) void project_fastcheck_kernel(const float *__r
     atomicMax(&counts[4], (unsigned long long)(dr * 1.0e9f));
 }
 
+// RANSAC hand-off (optional, zcnt != nullptr): while the final image leaves LDS the kernel also counts, per chunk of
+// rs_chunk pixels (the pixel range one wavefront of ground_ransac_kernel owns), the pixels with z = r * tz < zthr, i.e.
+// the first pass of the ground candidate selection.  zcnt[b][0..15] counts, zcnt[b][16] = 1 when they are valid
+// (frames with a depth-0 point are re-projected afterwards and count for themselves).
+#define RS_CHUNKS 16
+static inline int rs_chunk_px(int P) { return (((P + RS_CHUNKS - 1) / RS_CHUNKS) + 63) & ~63; }
 __global__ __launch_bounds__(BAND_THREADS) void project_band_kernel(const uint2 *__restrict__ pd,
                                                                     const int64_t *__restrict__ offs, int64_t base,
                                                                     int P, uint32_t *__restrict__ ri,
-                                                                    const int32_t *__restrict__ flags) {
+                                                                    const int32_t *__restrict__ flags,
+                                                                    const float *__restrict__ tz, float zthr, int rs_chunk,
+                                                                    int32_t *__restrict__ zcnt) {
     extern __shared__ uint32_t band[];  // [BAND_PX]
     const int b = blockIdx.y;
     if (flags[b]) return;
@@ -414,10 +422,42 @@ __global__ __launch_bounds__(BAND_THREADS) void project_band_kernel(const uint2 
     }
     __syncthreads();
     uint32_t *out = ri + (int64_t)b * P + band0;
-    for (uint32_t p = threadIdx.x; p < npx; p += BAND_THREADS) {
-        const uint32_t v = band[p];
-        out[p] = (v == RI_EMPTY) ? 0u : v;
+    if (zcnt == nullptr) {
+        for (uint32_t p = threadIdx.x; p < npx; p += BAND_THREADS) {
+            const uint32_t v = band[p];
+            out[p] = (v == RI_EMPTY) ? 0u : v;
+        }
+        return;
     }
+    // a wavefront covers 64 consecutive pixels per step; rs_chunk is a multiple of 64, so the chunk is wave-uniform
+    uint32_t g0 = band0 + (threadIdx.x & ~63u);
+    uint32_t ch = g0 / (uint32_t)rs_chunk, nb = (ch + 1u) * (uint32_t)rs_chunk;
+    int acc = 0;
+    for (uint32_t p0 = threadIdx.x; p0 < npx; p0 += BAND_THREADS * 8) {  // 8 ray loads in flight per lane
+        float zr[8];
+        uint32_t rv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t p = min(p0 + u * BAND_THREADS, npx - 1);  // unconditional (clamped) loads
+            zr[u] = tz[band0 + p];
+            const uint32_t v = band[p];
+            rv[u] = (v == RI_EMPTY) ? 0u : v;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t p = p0 + u * BAND_THREADS;
+            const bool in = p < npx;
+            if (in) out[p] = rv[u];
+            if (g0 >= nb) {
+                if (acc && (threadIdx.x & 63) == 0) atomicAdd(&zcnt[b * (RS_CHUNKS + 1) + ch], acc);
+                ch = g0 / (uint32_t)rs_chunk; nb = (ch + 1u) * (uint32_t)rs_chunk; acc = 0;
+            }
+            acc += __popcll(__ballot(in && u2f(rv[u]) * zr[u] < zthr));
+            g0 += BAND_THREADS;
+        }
+    }
+    if (acc && (threadIdx.x & 63) == 0) atomicAdd(&zcnt[b * (RS_CHUNKS + 1) + ch], acc);
+    if (blockIdx.x == 0 && threadIdx.x == 0) zcnt[b * (RS_CHUNKS + 1) + RS_CHUNKS] = 1;
 }
 
 static size_t project_scratch_bytes(int64_t total, int B, int P) {
@@ -437,7 +477,8 @@ extern "C" int rpcc_project_fastpath_check(const float *xyz, int64_t total, rpcc
 // On return ri is final (0 = empty pixel).  scratch_bytes < rpcc_project_scratch_bytes() selects the
 // atomic path, which only needs B*(P+8)*4 bytes.
 static int launch_project(const float *xyz, const int64_t *offsets, int64_t total, int64_t base, int B, rpcc_geom g,
-                          float *ri, void *scratch, size_t scratch_bytes, hipStream_t st) {
+                          float *ri, void *scratch, size_t scratch_bytes, hipStream_t st, const float *tz_plane = nullptr,
+                          int32_t *zcnt = nullptr) {
     const int P = g.H * g.W;
     uint32_t *rb = reinterpret_cast<uint32_t *>(ri);
     int32_t *lastz = reinterpret_cast<int32_t *>(scratch);
@@ -454,7 +495,9 @@ static int launch_project(const float *xyz, const int64_t *offsets, int64_t tota
                 xyz, offsets, total, base, B, g, pix_fast_cfg(g), pd, flags);
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&project_band_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, BAND_PX * 4));
-        project_band_kernel<<<dim3((P + BAND_PX - 1) / BAND_PX, B), BAND_THREADS, BAND_PX * 4, st>>>(pd, offsets, base, P, rb, flags);
+        if (zcnt) HIP_TRY(hipMemsetAsync(zcnt, 0, (size_t)B * (RS_CHUNKS + 1) * 4, st));
+        project_band_kernel<<<dim3((P + BAND_PX - 1) / BAND_PX, B), BAND_THREADS, BAND_PX * 4, st>>>(
+            pd, offsets, base, P, rb, flags, tz_plane, -1.5f, rs_chunk_px(P), tz_plane ? zcnt : nullptr);
         LAUNCH_CHECK();
         if (total > 0) {  // exact input-order semantics for frames with depth-0 points: no-ops otherwise
             project_fill_kernel<true><<<fg, 256, 0, st>>>(rb, lastz, flags, P);
@@ -465,6 +508,7 @@ static int launch_project(const float *xyz, const int64_t *offsets, int64_t tota
         }
         return RPCC_OK;
     }
+    if (zcnt) HIP_TRY(hipMemsetAsync(zcnt, 0, (size_t)B * (RS_CHUNKS + 1) * 4, st));
     project_fill_kernel<false><<<fg, 256, 0, st>>>(rb, lastz, flags, P);
     LAUNCH_CHECK();
     if (total > 0) {
@@ -692,12 +736,14 @@ __device__ int ransac_plane_wg(const RsPoints &pts, int iters, double thr, uint3
     return wcnt;
 }
 
+#define RS_CU 16  // pixels per lane in flight during the compaction pass
 __global__ __launch_bounds__(RS_THREADS) void ground_ransac_kernel(const float *__restrict__ ri_all,
                                                                    const float *__restrict__ tm, int P, float zthr,
                                                                    int max_pts, int min_pts, int ransac_n, int iters,
                                                                    double thr, uint32_t seed0, int raw,
                                                                    double *__restrict__ ground,
-                                                                   int32_t *__restrict__ ninl) {
+                                                                   int32_t *__restrict__ ninl,
+                                                                   const int32_t *__restrict__ zcnt) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rs_smem[];
     double *sred = reinterpret_cast<double *>(rs_smem);          // [6*256]
     double *swin = sred + 6 * RS_NT;                             // [64] + [RS_MAX_HYP*4] fp64 hypotheses
@@ -708,15 +754,16 @@ __global__ __launch_bounds__(RS_THREADS) void ground_ransac_kernel(const float *
     const float *ri = ri_all + (int64_t)b * P;
     DBG_STAMP(0);
     // each wave owns a contiguous run of pixels (rounded up to whole 64-pixel steps)
-    const int per_wave = (((P + 15) / 16) + 63) & ~63;
+    const int per_wave = (((P + RS_CHUNKS - 1) / RS_CHUNKS) + 63) & ~63;  // == rs_chunk_px(P)
     const int w0 = wave * per_wave, w1 = min(P, w0 + per_wave);
+    const bool have_cnt = zcnt != nullptr && zcnt[b * (RS_CHUNKS + 1) + RS_CHUNKS] != 0;  // counted by project_band_kernel
     auto zval = [&](int p) -> float {
         float r = ri[p];
         if (raw && f2u(r) == RI_EMPTY) r = 0.0f;  // projection bits not finalised yet
         return r * tm[3 * p + 2];
     };
-    int cnt = 0;
-    for (int p0 = w0; p0 < w1; p0 += 64 * 8) {  // 8 independent loads in flight per lane
+    int cnt = have_cnt ? zcnt[b * (RS_CHUNKS + 1) + wave] : 0;
+    for (int p0 = w0; p0 < w1 && !have_cnt; p0 += 64 * 8) {  // 8 independent loads in flight per lane
         float zv[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) zv[u] = zval(min(p0 + u * 64 + lane, P - 1));  // unconditional loads (clamped)
@@ -732,17 +779,17 @@ __global__ __launch_bounds__(RS_THREADS) void ground_ransac_kernel(const float *
     pts.ri = ri; pts.tm = tm; pts.lds = nullptr; pts.n = P; pts.raw = raw;
     if (nc >= min_pts) {
         int run = base;
-        for (int p00 = w0; p00 < w1; p00 += 64 * 8) {  // all loads of 8 steps are issued before any is used
-            float xv[8], yv[8], zv[8];
+        for (int p00 = w0; p00 < w1; p00 += 64 * RS_CU) {  // all loads of RS_CU steps are issued before any is used
+            float xv[RS_CU], yv[RS_CU], zv[RS_CU];
 #pragma unroll
-            for (int u = 0; u < 8; u++) {  // unconditional (clamped) loads: a guarded load would be waited for at once
+            for (int u = 0; u < RS_CU; u++) {  // unconditional (clamped) loads: a guarded load would be waited for at once
                 const int p = min(p00 + u * 64 + lane, P - 1);
                 float r = ri[p];
                 if (raw && f2u(r) == RI_EMPTY) r = 0.0f;
                 xv[u] = r * tm[3 * p]; yv[u] = r * tm[3 * p + 1]; zv[u] = r * tm[3 * p + 2];
             }
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
+            for (int u = 0; u < RS_CU; u++) {
                 const int p = p00 + u * 64 + lane;
                 const bool c = p < w1 && zv[u] < zthr;
                 const unsigned long long m = __ballot(c);
@@ -775,13 +822,13 @@ __global__ __launch_bounds__(RS_THREADS) void ground_ransac_kernel(const float *
 }
 
 static int launch_ground_ransac(const float *ri, const float *tm, int B, int P, uint32_t seed0, bool raw, double *ground,
-                                int32_t *ninl, hipStream_t st) {
+                                int32_t *ninl, hipStream_t st, const int32_t *zcnt = nullptr) {
     const int max_pts = 5000, min_pts = 800;
     const size_t sh = (size_t)6 * RS_NT * 8 + (64 + RS_MAX_HYP * 4) * 8 + 32 * 4 + 16 * 4 + (size_t)max_pts * 3 * 4;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&ground_ransac_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
     ground_ransac_kernel<<<B, RS_THREADS, sh, st>>>(ri, tm, P, -1.5f, max_pts, min_pts, 10, 100, 0.1, seed0, raw ? 1 : 0,
-                                                    ground, ninl);
+                                                    ground, ninl, zcnt);
     LAUNCH_CHECK();
     return RPCC_OK;
 }
@@ -1020,11 +1067,12 @@ extern "C" int rpcc_fps_xyz(int B, int N, int M, const float *points, float *tem
 
 // rays_soa: dev f32 [3,P] scratch (may be NULL -> brute-force kernel on the AoS table)
 static int launch_fps_range(const float *ri, const float *tm, float *temp, const int32_t *info, int B, int H, int W, int M,
-                            int32_t *cen_pix, float *centers, float *rays_soa, const float *tiletab, hipStream_t st) {
+                            int32_t *cen_pix, float *centers, float *rays_soa, const float *tiletab, hipStream_t st,
+                            bool rays_ready = false) {
     const int P = H * W;
     const FpsTiling g = fps_tiling_range(H, W);
     if (!g_fps_force_v1 && rays_soa != nullptr && g.T <= FPS_TILED_MAX_TILES) {
-        rays_soa_kernel<<<(P + 255) / 256, 256, 0, st>>>(tm, P, rays_soa);
+        if (!rays_ready) rays_soa_kernel<<<(P + 255) / 256, 256, 0, st>>>(tm, P, rays_soa);
         const size_t sh = fps_tiled_lds_bytes(g.T);
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_tiled_kernel<true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
@@ -1753,9 +1801,14 @@ static int run_slice(const rpcc_batch_io *io, int b0, int Bs, int64_t pt0, int64
     uint8_t *seg = io->seg + (size_t)b0 * P;
     float *model = io->model + (size_t)b0 * K * 4;
     int rc;
-    if ((rc = launch_project(io->xyz, io->offsets + b0, npts, pt0, Bs, g, ri, proj_scratch, proj_bytes, st))) return rc;
+    int32_t *zcnt = fit_ground ? reinterpret_cast<int32_t *>(tiletab) : nullptr;  // the tile table is written later
+    rays_soa_kernel<<<(P + 255) / 256, 256, 0, st>>>(io->tm, P, rays_soa);  // planar ray table: band kernel (z), FPS
+    LAUNCH_CHECK();
+    if ((rc = launch_project(io->xyz, io->offsets + b0, npts, pt0, Bs, g, ri, proj_scratch, proj_bytes, st,
+                             rays_soa + 2 * (int64_t)P, zcnt)))
+        return rc;
     if (fit_ground &&
-        (rc = launch_ground_ransac(ri, io->tm, Bs, P, (uint32_t)(io->ground_seed + b0), false, ground, nullptr, st)))
+        (rc = launch_ground_ransac(ri, io->tm, Bs, P, (uint32_t)(io->ground_seed + b0), false, ground, nullptr, st, zcnt)))
         return rc;
     const bool tiled = !g_fps_force_v1 && fps_tiling_range(g.H, g.W).T <= FPS_TILED_MAX_TILES;
     if ((rc = launch_ground_mask(ri, io->tm, ground, ground_threshold, Bs, g.H, g.W, temp, info,
@@ -1763,7 +1816,7 @@ static int run_slice(const rpcc_batch_io *io, int b0, int Bs, int64_t pt0, int64
         return rc;
     if (pre_done) HIP_TRY(hipEventRecord(pre_done, st));
     if ((rc = launch_fps_range(ri, io->tm, temp, info, Bs, g.H, g.W, M, io->cen_pix + (size_t)b0 * M, centers, rays_soa,
-                               tiled ? tiletab : nullptr, st)))
+                               tiled ? tiletab : nullptr, st, true)))
         return rc;
     if ((rc = launch_assign(ri, io->tm, ground, centers, Bs, g.H, g.W, M, seg, st))) return rc;
     if ((rc = launch_point_model(ri, seg, ground, Bs, P, M, model, io->counts + (size_t)b0 * K, io->nnz + b0, ws, st)))

@@ -476,11 +476,13 @@ def test_ground_ransac_matches_specification(env):
         assert abs(abs(ground[0][2]) - 1) < 0.01 and abs(abs(ground[0][3]) - 1.73) < 0.1
     # fused entry with the ground fit inside == stage-by-stage with that model injected
     g, geom, tm = _geom(env, "Velodyne64E_2048")
-    frames = [f0, f2]
-    offs = np.zeros(3, np.int64)
+    fz = f0.copy()
+    fz[100] = 0                                     # depth-0 point: exact re-projection, the fit counts for itself
+    frames = [f0, f2, fz, f2[:500].copy()]          # the band kernel hands the candidate counts to the fit (zcnt)
+    offs = np.zeros(len(frames) + 1, np.int64)
     offs[1:] = np.cumsum([f.shape[0] for f in frames])
-    buf = ops.BatchBuffers(2, geom, 100, env["dev"])
-    gfit = torch.zeros((2, 4), dtype=torch.float64, device=env["dev"])
+    buf = ops.BatchBuffers(len(frames), geom, 100, env["dev"])
+    gfit = torch.zeros((len(frames), 4), dtype=torch.float64, device=env["dev"])
     ops.compress_batch(_to(env, np.concatenate(frames)), _to(env, offs), _to(env, tm), gfit, buf, ground_seed=7)
     torch.cuda.synchronize()
     for i, f in enumerate(frames):
