@@ -8,129 +8,178 @@
 // (cpp_modules.cpp:38-43): feat / key_point_map are zero-filled before the kernel runs.
 #pragma once
 
-// One wavefront (= one workgroup of 64 threads) owns one image row:
-//   compaction of the row's pixels with label >= 2 (ballot scan), curvature on the compacted sequence,
-//   `segments` equal chunks; per chunk a bitonic sort of (curvature, position) keys in LDS, the sequential
-//   "largest first" pick loop on lane 0, a second sort and the "smallest first" loop.
-// LDS (dynamic): row f32[W] | v f32[W] | cbuf f32[W] | keys u64[NS] | vidx u16[W] | picked u8[W]
+// One wavefront (= one workgroup of 64 threads) owns one image row.
+//
+// What the reference's loops compute (cpp_modules.cpp:74-112), restated without their sequential form:
+//   * cloud_neighbors_picked is dead state: mark_as_picked only ever sets the entry of the pixel it is called for, every
+//     compacted position belongs to exactly one chunk and is examined at most once (the second loop skips what the first
+//     one visited), so "picked == 0" always holds when it is tested.  What remains of mark_as_picked is the pure
+//     predicate  A(col) = no neighbour within +-feature_region is more than 0.3 m closer.
+//   * both sorts order the chunk by the pair (curvature, position) -- a total order, positions are unique.  The first loop
+//     walks it downwards: the n-th accepted entry gets 3 (n < sharp_num) or 2 (n < less_sharp_num) and the loop stops at
+//     the less_sharp_num-th accepted entry; everything from the top down to that entry is "visited" (first = 0).  If
+//     fewer entries are accepted the whole chunk is visited.
+//   * the second sort moves the visited entries (and genuine zero curvatures) to the front, where the second loop skips
+//     them, and leaves the others in their old relative order: the loop walks the unvisited non-zero entries upwards, the
+//     n-th accepted one gets 1 (n < flat_num) and it stops at the flat_num-th.
+// So per chunk: the less_sharp_num largest and then the flat_num smallest accepted keys, found by repeated wave-wide
+// arg-max / arg-min over keys held in registers (no sort, no single-lane loop).  The row's outputs are assembled in LDS
+// and written once, coalesced (no memset of the output images).
+// LDS (dynamic): row f32[W] | v f32[W] (later the feat row) | cbuf f32[W] | vidx u16[W] | accf u8[W] | kprow u8[W]
 struct FeatParams {
     int feature_region, segments, sharp_num, less_sharp_num, flat_num;
 };
 
-__device__ __forceinline__ bool feat_mark_picked(const float *row, uint8_t *picked, int w_i, int fr) {
-    // cpp_modules.cpp:10-25: always marks the pixel itself (dif = 0 at i = 0); a neighbour more than
-    // 0.3 m closer rejects it
-    bool ret = true;
-    const float r = row[w_i];
-    for (int i = -fr; i <= fr; i++) {
-        const float dif = r - row[w_i + i];
-        if (fabsf(dif) < 0.2f) picked[w_i] = 1;
-        if (dif > 0.3f) ret = false;
-    }
-    return ret;
+// wave-wide maximum of 64-bit keys (hi, lo); 0 = "no key".  Two 32-bit DPP reductions.
+__device__ __forceinline__ void feat_wave_max(uint32_t hi, uint32_t lo, uint32_t &mh, uint32_t &ml) {
+    mh = dpp_max_u32(hi);
+    ml = dpp_max_u32(hi == mh ? lo : 0u);
+}
+__device__ __forceinline__ void feat_wave_min(uint32_t hi, uint32_t lo, uint32_t &mh, uint32_t &ml) {
+    mh = dpp_min_u32(hi);
+    ml = dpp_min_u32(hi == mh ? lo : 0xFFFFFFFFu);
 }
 
-__device__ __forceinline__ void feat_bitonic_sort(unsigned long long *keys, int NS, int lane) {
-    for (int k = 2; k <= NS; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = lane; i < NS; i += 64) {
-                const int l = i ^ j;
-                if (l > i) {
-                    const unsigned long long a = keys[i], b = keys[l];
-                    const bool up = (i & k) == 0;
-                    if ((a > b) == up) { keys[i] = b; keys[l] = a; }
-                }
-            }
-            __syncthreads();  // single-wavefront workgroup: orders the LDS traffic of consecutive stages
-        }
-    }
-}
-
+#define FEAT_MAX_PER_LANE 8  // chunk <= 512 entries
+#define FEAT_CP 4           // chunks processed together
+typedef unsigned long long feat_key;  // curvature bits << 32 | compacted position + 1; 0 = no key
+template <int Q>                      // keys per lane: chunk <= 64 * Q
 __global__ __launch_bounds__(64) void features_kernel(const float *__restrict__ ri, const uint8_t *__restrict__ seg, int H,
-                                                      int W, int NS, FeatParams fp, float *__restrict__ feat,
+                                                      int W, FeatParams fp, float *__restrict__ feat,
                                                       uint8_t *__restrict__ kp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
     float *row = reinterpret_cast<float *>(fsm);
     float *v = row + W;
     float *cbuf = v + W;
-    unsigned long long *keys = reinterpret_cast<unsigned long long *>(cbuf + W + (W & 1));
-    uint16_t *vidx = reinterpret_cast<uint16_t *>(keys + NS);
-    uint8_t *picked = reinterpret_cast<uint8_t *>(vidx + W);
+    uint16_t *vidx = reinterpret_cast<uint16_t *>(cbuf + W);
+    uint8_t *accf = reinterpret_cast<uint8_t *>(vidx + W);
+    uint8_t *kprow = accf + W;
     const int h = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
     const int64_t base = ((int64_t)b * H + h) * W;
     const int fr = fp.feature_region;
     int vl = 0;
-    for (int c0 = 0; c0 < W; c0 += 64) {
-        const int col = c0 + lane;
-        const bool in = col < W;
-        const int cc = in ? col : W - 1;
-        const float r = ri[base + cc];
-        const int lab = seg[base + cc];
-        if (in) { row[col] = r; picked[col] = 0; }
-        const bool ok = in && lab != 0 && lab != 1;
-        const unsigned long long m = __ballot(ok);
-        if (ok) {
-            const int pos = vl + __popcll(m & ((1ull << lane) - 1ull));
-            v[pos] = r;
-            vidx[pos] = (uint16_t)col;
+    for (int c00 = 0; c00 < W; c00 += 64 * 8) {  // 8 column groups in flight (unconditional, clamped loads)
+        float rr[8];
+        int ll[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int cc = min(c00 + 64 * u + lane, W - 1);
+            rr[u] = ri[base + cc];
+            ll[u] = seg[base + cc];
         }
-        vl += __popcll(m);
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int col = c00 + 64 * u + lane;
+            const bool in = col < W;
+            if (in) { row[col] = rr[u]; kprow[col] = 0; }
+            const bool ok = in && ll[u] != 0 && ll[u] != 1;
+            const unsigned long long m = __ballot(ok);
+            if (ok) {
+                const int pos = vl + __popcll(m & ((1ull << lane) - 1ull));
+                v[pos] = rr[u];
+                vidx[pos] = (uint16_t)col;
+            }
+            vl += __popcll(m);
+        }
     }
     __syncthreads();
-    if (vl < fp.segments + fr * 2 + 1) return;  // cpp_modules.cpp:59
+    const bool active = vl >= fp.segments + fr * 2 + 1;  // cpp_modules.cpp:59
     const int L = vl - 2 * fr;
-    for (int s = fr + lane; s < vl - fr; s += 64) {  // cpp_modules.cpp:64-72, fp32 in that operation order
-        float f = 0.0f;
-        const float vs = v[s];
-        for (int k = -fr; k <= fr; k++) f += v[s + k] - vs;
-        f = f * f;
-        f /= (float)(2 * fr);
-        f /= vs;
-        feat[base + vidx[s]] = f;
-        cbuf[s - fr] = f;
+    if (active) {
+        for (int s = fr + lane; s < vl - fr; s += 64) {  // cpp_modules.cpp:64-72, fp32 in that operation order
+            float f = 0.0f;
+            const float vs = v[s];
+            for (int k = -fr; k <= fr; k++) f += v[s + k] - vs;
+            f = f * f;
+            f /= (float)(2 * fr);
+            f /= vs;
+            cbuf[s - fr] = f;
+            // mark_as_picked's return value (cpp_modules.cpp:10-25); fr <= s <= col <= W-1-fr, so col +- fr is inside the row
+            const int col = vidx[s];
+            const float r = row[col];
+            bool ok = true;
+            for (int k = -fr; k <= fr; k++) ok = ok && !(r - row[col + k] > 0.3f);
+            accf[s - fr] = ok ? 1 : 0;
+        }
     }
     __syncthreads();
-    const int chunk = L / fp.segments;
-    for (int j = 0; j < fp.segments; j++) {
-        const int sp = chunk * j;
-        // keys: (curvature bits, compacted position); curvature >= 0 so its bit pattern orders like the value
-        for (int i = lane; i < NS; i += 64)
-            keys[i] = i < chunk ? (((unsigned long long)f2u(cbuf[sp + i]) << 32) | (unsigned)(sp + i + fr)) : ~0ull;
-        __syncthreads();
-        feat_bitonic_sort(keys, NS, lane);
-        if (lane == 0) {  // cpp_modules.cpp:79-95
-            int n = 0;
-            for (int i = chunk - 1; i >= 0; i--) {
-                const int s = (int)(unsigned)keys[i];
-                keys[i] = (unsigned long long)(unsigned)s;  // first = 0
-                const int col = vidx[s];
-                if (picked[col] == 0)
-                    if (feat_mark_picked(row, picked, col, fr)) {
-                        n += 1;
-                        if (n < fp.sharp_num) kp[base + col] = 3;
-                        else if (n < fp.less_sharp_num) kp[base + col] = 2;
-                        else break;
+    // feat row (aliases v, which is dead now): zero, then the curvatures at their columns
+    for (int c = lane; c < W; c += 64) v[c] = 0.0f;
+    __syncthreads();
+    if (active)
+        for (int i = lane; i < L; i += 64) v[vidx[i + fr]] = cbuf[i];
+    if (active) {
+        const int chunk = L / fp.segments;
+        // the less_sharp_num largest, then the flat_num smallest accepted keys of every chunk, FEAT_CP chunks interleaved
+        // (independent dependency chains hide the latency of the DPP reductions)
+        const int stop_n = max(1, max(fp.sharp_num, fp.less_sharp_num));  // the first loop breaks at this accepted entry
+        for (int j0 = 0; j0 < fp.segments; j0 += FEAT_CP) {
+            feat_key key[FEAT_CP][Q], prev[FEAT_CP], thr[FEAT_CP];
+            bool alive[FEAT_CP];
+#pragma unroll
+            for (int cI = 0; cI < FEAT_CP; cI++) {
+                const int sp = chunk * (j0 + cI);
+                alive[cI] = j0 + cI < fp.segments;
+#pragma unroll
+                for (int q = 0; q < Q; q++) {  // curvature bits (>= 0: order like the value) << 32 | compacted position + 1
+                    const int i = lane + 64 * q;
+                    const bool have = alive[cI] && i < chunk;
+                    const int ii = have ? sp + i : 0;
+                    key[cI][q] = (have && accf[ii] != 0) ? ((feat_key)f2u(cbuf[ii]) << 32) | (feat_key)(uint32_t)(ii + fr + 1) : 0ull;
+                }
+                prev[cI] = ~0ull;  // previous winner (exclusive upper bound)
+                thr[cI] = 0ull;    // keys >= thr are visited; 0 = the whole chunk
+            }
+            for (int n = 1; n <= stop_n; n++) {  // largest first: labels 3 / 2
+#pragma unroll
+                for (int cI = 0; cI < FEAT_CP; cI++) {
+                    feat_key best = 0ull;
+#pragma unroll
+                    for (int q = 0; q < Q; q++) {
+                        const feat_key c = key[cI][q] < prev[cI] ? key[cI][q] : 0ull;
+                        best = c > best ? c : best;
                     }
+                    uint32_t mh, ml;
+                    feat_wave_max((uint32_t)(best >> 32), (uint32_t)best, mh, ml);
+                    const feat_key m = ((feat_key)mh << 32) | ml;
+                    if (!alive[cI] || ml == 0u) { alive[cI] = false; continue; }  // fewer accepted entries: all visited
+                    if (n == stop_n) { thr[cI] = m; continue; }
+                    if (lane == 0) kprow[vidx[ml - 1u]] = n < fp.sharp_num ? 3 : 2;
+                    prev[cI] = m;
+                }
+            }
+            feat_key ek[FEAT_CP][Q];
+#pragma unroll
+            for (int cI = 0; cI < FEAT_CP; cI++) {
+                alive[cI] = thr[cI] != 0ull;
+                prev[cI] = 0ull;  // previous winner (exclusive lower bound; every key is > 0)
+#pragma unroll
+                for (int q = 0; q < Q; q++)  // "first == 0" is skipped (cpp_modules.cpp:99): visited, or a zero curvature
+                    ek[cI][q] = (key[cI][q] != 0ull && key[cI][q] < thr[cI] && u2f((uint32_t)(key[cI][q] >> 32)) != 0.0f)
+                                    ? key[cI][q] : ~0ull;
+            }
+            for (int n = 1; n < fp.flat_num; n++) {  // smallest first among the unvisited non-zero entries: label 1
+#pragma unroll
+                for (int cI = 0; cI < FEAT_CP; cI++) {
+                    feat_key best = ~0ull;
+#pragma unroll
+                    for (int q = 0; q < Q; q++) {
+                        const feat_key c = ek[cI][q] > prev[cI] ? ek[cI][q] : ~0ull;
+                        best = c < best ? c : best;
+                    }
+                    uint32_t mh, ml;
+                    feat_wave_min((uint32_t)(best >> 32), (uint32_t)best, mh, ml);
+                    if (!alive[cI] || (mh == 0xFFFFFFFFu && ml == 0xFFFFFFFFu)) { alive[cI] = false; continue; }
+                    if (lane == 0) kprow[vidx[ml - 1u]] = 1;
+                    prev[cI] = ((feat_key)mh << 32) | ml;
+                }
             }
         }
-        __syncthreads();
-        feat_bitonic_sort(keys, NS, lane);
-        if (lane == 0) {  // cpp_modules.cpp:97-112
-            int n = 0;
-            for (int i = 0; i < chunk; i++) {
-                if ((keys[i] >> 32) == 0ull) continue;  // first == 0 (visited, or a genuinely zero curvature)
-                const int s = (int)(unsigned)keys[i];
-                keys[i] = (unsigned long long)(unsigned)s;
-                const int col = vidx[s];
-                if (picked[col] == 0)
-                    if (feat_mark_picked(row, picked, col, fr)) {
-                        n += 1;
-                        if (n < fp.flat_num) kp[base + col] = 1;
-                        else break;
-                    }
-            }
-        }
-        __syncthreads();
+    }
+    __syncthreads();
+    for (int c = lane; c < W; c += 64) {
+        feat[base + c] = v[c];
+        kp[base + c] = kprow[c];
     }
 }
 

@@ -1700,17 +1700,22 @@ extern "C" int rpcc_extract_features(const float *ri, const uint8_t *seg, int B,
     ARG_TRY(B > 0 && H > 0 && W > 0 && ri && seg && feat && key_point_map);
     ARG_TRY(feature_region >= 1 && feature_region <= 16 && segments >= 1 && W < 65536);
     hipStream_t st = (hipStream_t)stream;
-    const int64_t n = (int64_t)B * H * W;
-    HIP_TRY(hipMemsetAsync(feat, 0, (size_t)n * 4, st));
-    HIP_TRY(hipMemsetAsync(key_point_map, 0, (size_t)n, st));
-    int NS = 64;
-    while (NS < (W + segments - 1) / segments) NS <<= 1;
-    const size_t sh = (size_t)(3 * W + (W & 1)) * 4 + (size_t)NS * 8 + (size_t)W * 2 + (size_t)W + 16;
+    const size_t sh = (size_t)3 * W * 4 + (size_t)W * 2 + (size_t)W * 2 + 16;
     ARG_TRY(sh <= 160 * 1024);
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&features_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+    ARG_TRY((W - 2 * feature_region) / segments <= 64 * FEAT_MAX_PER_LANE);  // a chunk's keys live in registers
     FeatParams fp = {feature_region, segments, sharp_num, less_sharp_num, flat_num};
-    features_kernel<<<dim3(H, B), 64, sh, st>>>(ri, seg, H, W, NS, fp, feat, key_point_map);
+    const int need = ((W - 2 * feature_region) / segments + 63) / 64;  // keys per lane
+#define FEAT_LAUNCH(Q_)                                                                                          \
+    do {                                                                                                         \
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&features_kernel<Q_>),                        \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));                       \
+        features_kernel<Q_><<<dim3(H, B), 64, sh, st>>>(ri, seg, H, W, fp, feat, key_point_map);                 \
+    } while (0)
+    if (need <= 2) FEAT_LAUNCH(2);
+    else if (need <= 4) FEAT_LAUNCH(4);
+    else if (need <= 6) FEAT_LAUNCH(6);
+    else FEAT_LAUNCH(8);
+#undef FEAT_LAUNCH
     LAUNCH_CHECK();
     return RPCC_OK;
 }
