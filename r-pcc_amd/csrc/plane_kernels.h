@@ -15,8 +15,12 @@
 
 // label-ordered pixel list: order[b][pos] = pixel index, labels ascending (label 1 skipped), row-major
 // inside a label -- the same positions the quantiser's ordered scatter uses.
+// pts4 (optional): the same list as points (x, y, z, r) so that the plane model streams a label's points instead of
+// gathering them through the pixel index.
 __global__ __launch_bounds__(256) void label_order_kernel(const uint8_t *__restrict__ seg, const uint32_t *__restrict__ hist,
-                                                          int P, int M, int KP, int T, uint32_t *__restrict__ order) {
+                                                          int P, int M, int KP, int T, uint32_t *__restrict__ order,
+                                                          const float *__restrict__ ri, const float *__restrict__ tm,
+                                                          float4 *__restrict__ pts4) {
     extern __shared__ unsigned char smem_raw[];
     uint32_t *segcnt = reinterpret_cast<uint32_t *>(smem_raw);  // [16][KP]
     const int b = blockIdx.y, t = blockIdx.x, K = M + 2;
@@ -59,20 +63,24 @@ __global__ __launch_bounds__(256) void label_order_kernel(const uint8_t *__restr
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 4; j++)
-        if (lab[j] >= 0)
-            order[(int64_t)b * P + segcnt[(j * 4 + wave) * KP + lab[j]] + rank[j]] = (uint32_t)(t * TILE + j * 256 + threadIdx.x);
+        if (lab[j] >= 0) {
+            const int p = t * TILE + j * 256 + threadIdx.x;
+            const int64_t o = (int64_t)b * P + segcnt[(j * 4 + wave) * KP + lab[j]] + rank[j];
+            order[o] = (uint32_t)p;
+            if (pts4) {
+                const float r = ri[(int64_t)b * P + p];
+                pts4[o] = make_float4(r * tm[3 * p], r * tm[3 * p + 1], r * tm[3 * p + 2], r);  // transformer.py:94-101
+            }
+        }
 }
 
 // points of one label, through the ordered pixel list
 struct LabelPoints {
-    const uint32_t *order;  // this label's slice
-    const float *ri;        // this frame's range image
-    const float *tm;
+    const float4 *pts;  // this label's slice of the ordered point list (x, y, z, r)
     int n;
     __device__ __forceinline__ void getf(int i, float &x, float &y, float &z) const {
-        const uint32_t p = order[i];
-        const float r = ri[p];
-        x = r * tm[3 * p]; y = r * tm[3 * p + 1]; z = r * tm[3 * p + 2];
+        const float4 q = pts[i];
+        x = q.x; y = q.y; z = q.z;
     }
     __device__ __forceinline__ void get(int i, double &x, double &y, double &z) const {
         float a, b, c;
@@ -81,139 +89,9 @@ struct LabelPoints {
     }
 };
 
-// hypothesis h of the specification: RN distinct sample indices from the counter-based hash, plane by
-// centroid + centred moments (fp64, sequential sums over the sample)
-template <int RN, class PTS>
-__device__ __forceinline__ bool ransac_fit_hypothesis(const PTS &pts, int n, uint32_t seed, int h, double pl[4]) {
-    int idx[RN];
-#pragma unroll
-    for (int k = 0; k < RN; k++) {
-        uint32_t a = 0;
-        int cand;
-        bool dup;
-        do {
-            cand = (int)(mix32(seed, (uint32_t)(h * 16 + k), a++) % (uint32_t)n);
-            dup = false;
-#pragma unroll
-            for (int j = 0; j < RN; j++) dup |= (j < k) && (idx[j] == cand);
-        } while (dup);
-        idx[k] = cand;
-    }
-    double px[RN], py[RN], pz[RN];
-    double c[3] = {0, 0, 0};
-#pragma unroll
-    for (int k = 0; k < RN; k++) { pts.get(idx[k], px[k], py[k], pz[k]); c[0] += px[k]; c[1] += py[k]; c[2] += pz[k]; }
-    c[0] /= (double)RN; c[1] /= (double)RN; c[2] /= (double)RN;
-    double xx = 0, xy = 0, xz = 0, yy = 0, yz = 0, zz = 0;
-#pragma unroll
-    for (int k = 0; k < RN; k++) {
-        const double rx = px[k] - c[0], ry = py[k] - c[1], rz = pz[k] - c[2];
-        xx += rx * rx; xy += rx * ry; xz += rx * rz; yy += ry * ry; yz += ry * rz; zz += rz * rz;
-    }
-    pl[0] = pl[1] = pl[2] = pl[3] = 0.0;
-    return plane_from_moments(c, xx, xy, xz, yy, yz, zz, pl);
-}
-
-// ordered fp64 sum of the specification evaluated by ONE wavefront: lane l owns partials l, l+64, l+128,
-// l+192 (the 256 strided partials), then the binary tree partial[t] += partial[t+stride].
-__device__ __forceinline__ double wave_treesum256(double p0, double p1, double p2, double p3, int lane) {
-    p0 += p2;  // stride 128: t = l      += l+128 ; t = l+64 += l+192
-    p1 += p3;
-    p0 += p1;  // stride 64
-    double v = p0;
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) {
-        const double o = __shfl_down(v, s, 64);
-        if (lane < s) v += o;
-    }
-    return __shfl(v, 0, 64);
-}
-
-// Single-wavefront RANSAC (workgroup = 64 threads).  iters <= 64.  hyp: LDS [iters*5] floats + [iters*4] doubles.
-template <int RN, int HMAX, class PTS>
-__device__ int ransac_plane_wave(const PTS &pts, int iters, float thr_f, uint32_t seed, double plane[4], float *hypf,
-                                 double *hypd) {
-    const int lane = threadIdx.x & 63, n = pts.n;
-    plane[0] = 0; plane[1] = 0; plane[2] = 1; plane[3] = 0;
-    if (n < RN || iters > HMAX) return 0;
-    if (lane < iters) {
-        double pl[4];
-        const bool ok = ransac_fit_hypothesis<RN>(pts, n, seed, lane, pl);
-        hypf[5 * lane] = (float)pl[0]; hypf[5 * lane + 1] = (float)pl[1]; hypf[5 * lane + 2] = (float)pl[2];
-        hypf[5 * lane + 3] = ok ? (float)pl[3] : __builtin_inff();
-        hypf[5 * lane + 4] = ok ? 1.0f : 0.0f;
-        hypd[4 * lane] = pl[0]; hypd[4 * lane + 1] = pl[1]; hypd[4 * lane + 2] = pl[2]; hypd[4 * lane + 3] = pl[3];
-    }
-    __syncthreads();
-    float pf[HMAX][4];
-    int cnt[HMAX];
-#pragma unroll
-    for (int q = 0; q < HMAX; q++) {
-        const int hh = q < iters ? q : 0;
-        pf[q][0] = hypf[5 * hh]; pf[q][1] = hypf[5 * hh + 1]; pf[q][2] = hypf[5 * hh + 2];
-        pf[q][3] = q < iters ? hypf[5 * hh + 3] : __builtin_inff();
-        cnt[q] = 0;
-    }
-    for (int i = lane; i < n; i += 64) {
-        float x, y, z;
-        pts.getf(i, x, y, z);
-#pragma unroll
-        for (int q = 0; q < HMAX; q++) cnt[q] += plane_inlier(pf[q], x, y, z, thr_f);
-    }
-    int best_cnt = -1, best_h = 0;
-#pragma unroll
-    for (int q = 0; q < HMAX; q++) {
-        const int c = (int)dpp_sum_u32((uint32_t)cnt[q]);
-        if (q < iters && hypf[5 * q + 4] != 0.0f && c > best_cnt) { best_cnt = c; best_h = q; }
-    }
-    if (best_cnt < 0) return 0;
-    plane[0] = hypd[4 * best_h]; plane[1] = hypd[4 * best_h + 1]; plane[2] = hypd[4 * best_h + 2]; plane[3] = hypd[4 * best_h + 3];
-    if (best_cnt < 3) return best_cnt;
-    const float wf[4] = {(float)plane[0], (float)plane[1], (float)plane[2], (float)plane[3]};
-    double c[3];
-    {
-        double s[3][4];
-#pragma unroll
-        for (int a = 0; a < 3; a++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) s[a][j] = 0.0;
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-            for (int i = lane + 64 * j; i < n; i += 256) {
-                float x, y, z;
-                pts.getf(i, x, y, z);
-                if (plane_inlier(wf, x, y, z, thr_f)) { s[0][j] += (double)x; s[1][j] += (double)y; s[2][j] += (double)z; }
-            }
-#pragma unroll
-        for (int a = 0; a < 3; a++) c[a] = wave_treesum256(s[a][0], s[a][1], s[a][2], s[a][3], lane) / (double)best_cnt;
-    }
-    double m[6];
-    {
-        double s[6][4];
-#pragma unroll
-        for (int a = 0; a < 6; a++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) s[a][j] = 0.0;
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-            for (int i = lane + 64 * j; i < n; i += 256) {
-                float x, y, z;
-                pts.getf(i, x, y, z);
-                if (plane_inlier(wf, x, y, z, thr_f)) {
-                    const double rx = (double)x - c[0], ry = (double)y - c[1], rz = (double)z - c[2];
-                    s[0][j] += rx * rx; s[1][j] += rx * ry; s[2][j] += rx * rz; s[3][j] += ry * ry; s[4][j] += ry * rz; s[5][j] += rz * rz;
-                }
-            }
-#pragma unroll
-        for (int a = 0; a < 6; a++) m[a] = wave_treesum256(s[a][0], s[a][1], s[a][2], s[a][3], lane);
-    }
-    double pl[4];
-    if (plane_from_moments(c, m[0], m[1], m[2], m[3], m[4], m[5], pl)) { plane[0] = pl[0]; plane[1] = pl[1]; plane[2] = pl[2]; plane[3] = pl[3]; }
-    return best_cnt;
-}
-
 // NumPy fp32 pairwise sum of v[0..len) held in LDS (len <= 128): the leaf of the recursion.
-__device__ __forceinline__ float np_leaf_sum(const float *leaf, float *acc8, int len, int lane) {
+__device__ __forceinline__ float np_leaf_sum(const float *leaf, float *acc8, int len) {
+    const int lane = threadIdx.x;  // the first 8 threads of the workgroup do the leaf (every thread takes the barriers)
     float res = 0.0f;
     if (len < 8) {
         if (lane == 0) {
@@ -241,8 +119,8 @@ __device__ __forceinline__ float np_leaf_sum(const float *leaf, float *acc8, int
     return res;
 }
 
-// NumPy fp32 mean of the label's ranges (row-major order through `order`), one wavefront.
-__device__ float np_mean_wave(const uint32_t *order, const float *ri, int n, float *leaf, float *acc8, int lane) {
+// NumPy fp32 mean of the label's ranges (row-major order through the ordered list); every thread of the workgroup calls it.
+__device__ float np_mean_wg(const float4 *pts, int n, float *leaf, float *acc8) {
     if (n == 0) return u2f(0xFFC00000u);
     float total = 0.0f;
     for (int blk = 0; blk < n; blk += 8192) {
@@ -257,9 +135,9 @@ __device__ float np_mean_wave(const uint32_t *order, const float *ri, int n, flo
             float v;
             bool done = false;
             if (len[t] <= 128) {
-                for (int i = lane; i < len[t]; i += 64) leaf[i] = ri[order[off[t] + i]];
+                for (int i = threadIdx.x; i < len[t]; i += blockDim.x) leaf[i] = pts[off[t] + i].w;
                 __syncthreads();
-                v = np_leaf_sum(leaf, acc8, len[t], lane);
+                v = np_leaf_sum(leaf, acc8, len[t]);
                 done = true;
             } else if (phase[t] == 0) {
                 int n2 = len[t] / 2;
@@ -298,41 +176,48 @@ struct PlaneParams {
     uint32_t seed;
 };
 
-__global__ __launch_bounds__(64) void plane_model_kernel(const float *__restrict__ ri_all, const float *__restrict__ tm,
-                                                         const uint32_t *__restrict__ order_all,
-                                                         const uint32_t *__restrict__ hist, const int32_t *__restrict__ counts,
-                                                         const double *__restrict__ ground, int P, int M, int KP, int T,
-                                                         PlaneParams pp, float *__restrict__ model) {
+#define PL_THREADS 256
+#define PL_MAXH 16
+// One 256-thread workgroup per (label, frame): the workgroup form of the RANSAC specification (ransac_plane_wg: thread t
+// owns the strided partial t of the ordered fp64 sums), four wavefronts share the point loops.
+__global__ __launch_bounds__(PL_THREADS) void plane_model_kernel(const float *__restrict__ tm,
+                                                                 const uint32_t *__restrict__ order_all,
+                                                                 const float4 *__restrict__ pts_all,
+                                                                 const uint32_t *__restrict__ hist,
+                                                                 const int32_t *__restrict__ counts,
+                                                                 const double *__restrict__ ground, int P, int M, int KP, int T,
+                                                                 PlaneParams pp, float *__restrict__ model) {
     __shared__ float leaf[128];
     __shared__ float acc8[8];
-    __shared__ float hypf[16 * 5];
-    __shared__ double hypd[16 * 4];
-    const int k = blockIdx.x, b = blockIdx.y, K = M + 2, lane = threadIdx.x;
+    __shared__ double sred[6 * RS_NT];
+    __shared__ double swin[64 + PL_MAXH * 4];
+    __shared__ int sbest[32];
+    const int k = blockIdx.x, b = blockIdx.y, K = M + 2, tid = threadIdx.x;
     float *row = model + ((int64_t)b * K + k) * 4;
     if (k == 0) {
-        if (lane < 4) row[lane] = ground ? (float)ground[4 * b + lane] : 0.0f;
+        if (tid < 4) row[tid] = ground ? (float)ground[4 * b + tid] : 0.0f;
         return;
     }
     if (k == 1) {
-        if (lane < 4) row[lane] = 0.0f;
+        if (tid < 4) row[tid] = 0.0f;
         return;
     }
     const int n = counts[(int64_t)b * K + k];
     const uint32_t base = hist[((int64_t)b * T) * KP + k];  // tile 0 offset = start of label k in the ordered list
     const uint32_t *order = order_all + (int64_t)b * P + base;
-    const float *ri = ri_all + (int64_t)b * P;
+    const float4 *pl_pts = pts_all + (int64_t)b * P + base;
     bool use_plane = false;
     double plane[4] = {0, 0, 0, 0};
     if (n >= pp.min_points) {
         LabelPoints pts;
-        pts.order = order; pts.ri = ri; pts.tm = tm; pts.n = n;
+        pts.pts = pl_pts; pts.n = n;
         const uint32_t seed = mix32(pp.seed, (uint32_t)b, (uint32_t)k);
-        ransac_plane_wave<4, 10>(pts, pp.iters, pp.thr, seed, plane, hypf, hypd);
+        ransac_plane_wg<4, PL_THREADS, PL_MAXH>(pts, pp.iters, (double)pp.thr, seed, plane, sred, swin, sbest);
         // plane_angle_validation (segment_utils.py:84-93)
         const double a = plane[0], bb = plane[1], c = plane[2];
         const double nrm = sqrt((a * a + bb * bb) + c * c);
         bool bad = false, nan = false;
-        for (int i = lane; i < n; i += 64) {
+        for (int i = tid; i < n; i += PL_THREADS) {
             const uint32_t p = order[i];
             const float tx = tm[3 * p], ty = tm[3 * p + 1], tz = tm[3 * p + 2];
             const double dot = fabs(((double)tx * a + (double)ty * bb) + (double)tz * c);
@@ -341,12 +226,13 @@ __global__ __launch_bounds__(64) void plane_model_kernel(const float *__restrict
             nan |= (v != v) || v > 1.0;   // arccos gives NaN, alpha.max() is NaN, NaN > threshold is False
             bad |= v <= pp.cos_cut;
         }
-        use_plane = __any(nan) || !__any(bad);
+        const int any_nan = __syncthreads_or(nan ? 1 : 0), any_bad = __syncthreads_or(bad ? 1 : 0);
+        use_plane = any_nan || !any_bad;
     }
     if (use_plane) {
-        if (lane < 4) row[lane] = (float)plane[lane];
+        if (tid < 4) row[tid] = (float)plane[tid];
     } else {
-        const float mean = np_mean_wave(order, ri, n, leaf, acc8, lane);
-        if (lane < 4) row[lane] = lane == 3 ? mean : 0.0f;
+        const float mean = np_mean_wg(pl_pts, n, leaf, acc8);
+        if (tid < 4) row[tid] = tid == 3 ? mean : 0.0f;
     }
 }

@@ -619,16 +619,17 @@ __device__ __forceinline__ void rs_treesum(double (&v)[NV], double *sred) {
     for (int q = 0; q < NV; q++) v[q] = sred[q * RS_NT];
 }
 
-// Workgroup-wide RANSAC on `pts` (RN = sample size); all RS_THREADS threads call it.  Returns the
+// Workgroup-wide RANSAC on `pts` (RN = sample size, NTH = threads of the workgroup (>= RS_NT), MAXH = most
+// hypotheses); every thread calls it.  Returns the
 // winner's inlier count.  sred [6*RS_NT] doubles, swin [16*4] doubles, sbest [16*2] ints.
-template <int RN>
-__device__ int ransac_plane_wg(const RsPoints &pts, int iters, double thr, uint32_t seed, double plane[4], double *sred,
+template <int RN, int NTH, int MAXH, class PTS>
+__device__ int ransac_plane_wg(const PTS &pts, int iters, double thr, uint32_t seed, double plane[4], double *sred,
                                double *swin, int *sbest) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = pts.n;
     const float thr_f = (float)thr;
     plane[0] = 0; plane[1] = 0; plane[2] = 1; plane[3] = 0;
-    if (n < RN || iters > RS_MAX_HYP) return 0;
+    if (n < RN || iters > MAXH) return 0;
     // (1) fits: one hypothesis per lane (iters <= RS_MAX_HYP), results narrowed to fp32 in LDS
     float *hyp = reinterpret_cast<float *>(sred);  // [iters][4] fp32 planes + validity, reused before the sums
     double *hypd = swin + 64;                      // [iters][4] fp64 planes (winner is read back from here)
@@ -668,12 +669,12 @@ __device__ int ransac_plane_wg(const RsPoints &pts, int iters, double thr, uint3
     __syncthreads();
     // (2) scoring: wavefront w counts the inliers of hypotheses w, w+16, ... -- all of them in one pass
     // over the points (a point is read from LDS once and tested against up to RS_HPW planes)
-    constexpr int RS_HPW = RS_MAX_HYP / (RS_THREADS / 64);
+    constexpr int RS_HPW = (MAXH + NTH / 64 - 1) / (NTH / 64);
     float pf[RS_HPW][4];
     int cnt[RS_HPW];
 #pragma unroll
     for (int q = 0; q < RS_HPW; q++) {
-        const int h = wave + q * (RS_THREADS / 64);
+        const int h = wave + q * (NTH / 64);
         const bool ok = h < iters && hyp[5 * (h < iters ? h : 0) + 4] != 0.0f;
         const int hh = h < iters ? h : 0;
         pf[q][0] = hyp[5 * hh]; pf[q][1] = hyp[5 * hh + 1]; pf[q][2] = hyp[5 * hh + 2];
@@ -688,7 +689,7 @@ __device__ int ransac_plane_wg(const RsPoints &pts, int iters, double thr, uint3
     int best_cnt = -1, best_h = 0x7fffffff;
 #pragma unroll
     for (int q = 0; q < RS_HPW; q++) {
-        const int h = wave + q * (RS_THREADS / 64);
+        const int h = wave + q * (NTH / 64);
         const int c = (int)dpp_sum_u32((uint32_t)cnt[q]);
         if (h < iters && hyp[5 * h + 4] != 0.0f && c > best_cnt) { best_cnt = c; best_h = h; }
     }
@@ -702,7 +703,7 @@ __device__ int ransac_plane_wg(const RsPoints &pts, int iters, double thr, uint3
     }
     __syncthreads();
     int wbest = -1, wcnt = -1, wh = 0x7fffffff;
-    for (int w = 0; w < RS_THREADS / 64; w++) {
+    for (int w = 0; w < NTH / 64; w++) {
         const int c = sbest[2 * w], hh = sbest[2 * w + 1];
         if (c > wcnt || (c == wcnt && c >= 0 && hh < wh)) { wcnt = c; wh = hh; wbest = w; }
     }
@@ -813,7 +814,7 @@ __global__ __launch_bounds__(RS_THREADS) void ground_ransac_kernel(const float *
     DBG_STAMP(2);
     double plane[4];
     (void)ransac_n;  // the ground fit samples 10 points (utils/segment_utils.py:75)
-    const int inl = ransac_plane_wg<10>(pts, iters, thr, seed0 + (uint32_t)b, plane, sred, swin, sbest);
+    const int inl = ransac_plane_wg<10, RS_THREADS, RS_MAX_HYP>(pts, iters, thr, seed0 + (uint32_t)b, plane, sred, swin, sbest);
     DBG_STAMP(6);
     if (tid == 0) {
         ground[4 * b] = plane[0]; ground[4 * b + 1] = plane[1]; ground[4 * b + 2] = plane[2]; ground[4 * b + 3] = plane[3];
@@ -1749,7 +1750,8 @@ extern "C" int rpcc_intra_predict(const uint8_t *seg, const float *model, const 
 
 extern "C" size_t rpcc_plane_workspace_bytes(int B, int P, int M) {
     if (B <= 0 || P <= 0 || M <= 0) return 0;
-    return ws_layout(nullptr, B, P, M).bytes + 256 + (size_t)B * P * 4;
+    // model part | label-ordered pixel list u32 [B,P] | the same list as points (x, y, z, r) float4 [B,P]
+    return ws_layout(nullptr, B, P, M).bytes + 256 + (((size_t)B * P * 4 + 255) & ~(size_t)255) + (size_t)B * P * 16;
 }
 
 extern "C" int rpcc_plane_model(const float *ri, const float *tm, const uint8_t *seg, const double *ground, int B, int P,
@@ -1766,10 +1768,11 @@ extern "C" int rpcc_plane_model(const float *ri, const float *tm, const uint8_t 
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     model_scan_kernel<<<B, 256, scan_lds_bytes(P, M), st>>>(nullptr, seg, nullptr, P, M, KP, T, L.sums, L.flags, L.hist,
                                                             nullptr, counts, nullptr);
-    label_order_kernel<<<dim3(T, B), 256, (size_t)16 * KP * 4, st>>>(seg, L.hist, P, M, KP, T, order);
+    float4 *pts4 = reinterpret_cast<float4 *>(reinterpret_cast<char *>(order) + (((size_t)B * P * 4 + 255) & ~(size_t)255));
+    label_order_kernel<<<dim3(T, B), 256, (size_t)16 * KP * 4, st>>>(seg, L.hist, P, M, KP, T, order, ri, tm, pts4);
     PlaneParams pp;
     pp.cos_cut = cos_cut; pp.thr = 0.1f; pp.min_points = 30; pp.iters = 10; pp.seed = seed;
-    plane_model_kernel<<<dim3(K, B), 64, 0, st>>>(ri, tm, order, L.hist, counts, ground, P, M, KP, T, pp, model);
+    plane_model_kernel<<<dim3(K, B), PL_THREADS, 0, st>>>(tm, order, pts4, L.hist, counts, ground, P, M, KP, T, pp, model);
     LAUNCH_CHECK();
     return RPCC_OK;
 }
