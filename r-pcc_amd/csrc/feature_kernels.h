@@ -8,7 +8,7 @@
 // (cpp_modules.cpp:38-43): feat / key_point_map are zero-filled before the kernel runs.
 #pragma once
 
-// One wavefront (= one workgroup of 64 threads) owns one image row.
+// One workgroup of four wavefronts owns one image row.
 //
 // What the reference's loops compute (cpp_modules.cpp:74-112), restated without their sequential form:
 //   * cloud_neighbors_picked is dead state: mark_as_picked only ever sets the entry of the pixel it is called for, every
@@ -41,52 +41,65 @@ __device__ __forceinline__ void feat_wave_min(uint32_t hi, uint32_t lo, uint32_t
 }
 
 #define FEAT_MAX_PER_LANE 8  // chunk <= 512 entries
-#define FEAT_CP 4           // chunks processed together
+#define FEAT_CP 2            // chunks a wavefront processes together
+#define FEAT_THREADS 256     // one workgroup (4 wavefronts) per image row
+#define FEAT_GPW 16          // 64-column groups per wavefront: W <= 4096
 typedef unsigned long long feat_key;  // curvature bits << 32 | compacted position + 1; 0 = no key
 template <int Q>                      // keys per lane: chunk <= 64 * Q
-__global__ __launch_bounds__(64) void features_kernel(const float *__restrict__ ri, const uint8_t *__restrict__ seg, int H,
-                                                      int W, FeatParams fp, float *__restrict__ feat,
-                                                      uint8_t *__restrict__ kp) {
+__global__ __launch_bounds__(FEAT_THREADS) void features_kernel(const float *__restrict__ ri, const uint8_t *__restrict__ seg,
+                                                                int H, int W, FeatParams fp, float *__restrict__ feat,
+                                                                uint8_t *__restrict__ kp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
+    __shared__ int wcnt[FEAT_THREADS / 64];
     float *row = reinterpret_cast<float *>(fsm);
     float *v = row + W;
     float *cbuf = v + W;
     uint16_t *vidx = reinterpret_cast<uint16_t *>(cbuf + W);
     uint8_t *accf = reinterpret_cast<uint8_t *>(vidx + W);
     uint8_t *kprow = accf + W;
-    const int h = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t base = ((int64_t)b * H + h) * W;
     const int fr = fp.feature_region;
-    int vl = 0;
-    for (int c00 = 0; c00 < W; c00 += 64 * 8) {  // 8 column groups in flight (unconditional, clamped loads)
-        float rr[8];
-        int ll[8];
+    // compaction of the row's pixels with label >= 2: every wavefront takes a contiguous run of 64-column groups, keeps
+    // them in registers (all loads in flight at once), counts, and after the prefix over the wavefronts writes its part
+    const int ngroups = (W + 63) >> 6, gpw = (ngroups + FEAT_THREADS / 64 - 1) / (FEAT_THREADS / 64);
+    float rr[FEAT_GPW];
+    int ll[FEAT_GPW];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int cc = min(c00 + 64 * u + lane, W - 1);
-            rr[u] = ri[base + cc];
-            ll[u] = seg[base + cc];
-        }
+    for (int u = 0; u < FEAT_GPW; u++) {  // unconditional (clamped) loads
+        const int cc = min((wave * gpw + u) * 64 + lane, W - 1);
+        rr[u] = ri[base + cc];
+        ll[u] = seg[base + cc];
+    }
+    int cnt = 0;
+    unsigned long long okm[FEAT_GPW];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int col = c00 + 64 * u + lane;
-            const bool in = col < W;
-            if (in) { row[col] = rr[u]; kprow[col] = 0; }
-            const bool ok = in && ll[u] != 0 && ll[u] != 1;
-            const unsigned long long m = __ballot(ok);
-            if (ok) {
-                const int pos = vl + __popcll(m & ((1ull << lane) - 1ull));
-                v[pos] = rr[u];
-                vidx[pos] = (uint16_t)col;
-            }
-            vl += __popcll(m);
+    for (int u = 0; u < FEAT_GPW; u++) {
+        const int col = (wave * gpw + u) * 64 + lane;
+        const bool in = u < gpw && col < W;
+        if (in) { row[col] = rr[u]; kprow[col] = 0; }
+        okm[u] = __ballot(in && ll[u] != 0 && ll[u] != 1);
+        cnt += __popcll(okm[u]);
+    }
+    if (lane == 0) wcnt[wave] = cnt;
+    __syncthreads();
+    int vl = 0, run = 0;
+#pragma unroll
+    for (int w = 0; w < FEAT_THREADS / 64; w++) { run += w < wave ? wcnt[w] : 0; vl += wcnt[w]; }
+#pragma unroll
+    for (int u = 0; u < FEAT_GPW; u++) {
+        if ((okm[u] >> lane) & 1ull) {
+            const int pos = run + __popcll(okm[u] & ((1ull << lane) - 1ull));
+            v[pos] = rr[u];
+            vidx[pos] = (uint16_t)((wave * gpw + u) * 64 + lane);
         }
+        run += __popcll(okm[u]);
     }
     __syncthreads();
     const bool active = vl >= fp.segments + fr * 2 + 1;  // cpp_modules.cpp:59
     const int L = vl - 2 * fr;
     if (active) {
-        for (int s = fr + lane; s < vl - fr; s += 64) {  // cpp_modules.cpp:64-72, fp32 in that operation order
+        for (int s = fr + tid; s < vl - fr; s += FEAT_THREADS) {  // cpp_modules.cpp:64-72, fp32 in that operation order
             float f = 0.0f;
             const float vs = v[s];
             for (int k = -fr; k <= fr; k++) f += v[s + k] - vs;
@@ -104,16 +117,16 @@ __global__ __launch_bounds__(64) void features_kernel(const float *__restrict__ 
     }
     __syncthreads();
     // feat row (aliases v, which is dead now): zero, then the curvatures at their columns
-    for (int c = lane; c < W; c += 64) v[c] = 0.0f;
+    for (int c = tid; c < W; c += FEAT_THREADS) v[c] = 0.0f;
     __syncthreads();
     if (active)
-        for (int i = lane; i < L; i += 64) v[vidx[i + fr]] = cbuf[i];
+        for (int i = tid; i < L; i += FEAT_THREADS) v[vidx[i + fr]] = cbuf[i];
     if (active) {
         const int chunk = L / fp.segments;
         // the less_sharp_num largest, then the flat_num smallest accepted keys of every chunk, FEAT_CP chunks interleaved
         // (independent dependency chains hide the latency of the DPP reductions)
         const int stop_n = max(1, max(fp.sharp_num, fp.less_sharp_num));  // the first loop breaks at this accepted entry
-        for (int j0 = 0; j0 < fp.segments; j0 += FEAT_CP) {
+        for (int j0 = wave * FEAT_CP; j0 < fp.segments; j0 += FEAT_CP * (FEAT_THREADS / 64)) {
             feat_key key[FEAT_CP][Q], prev[FEAT_CP], thr[FEAT_CP];
             bool alive[FEAT_CP];
 #pragma unroll
@@ -177,7 +190,7 @@ __global__ __launch_bounds__(64) void features_kernel(const float *__restrict__ 
         }
     }
     __syncthreads();
-    for (int c = lane; c < W; c += 64) {
+    for (int c = tid; c < W; c += FEAT_THREADS) {
         feat[base + c] = v[c];
         kp[base + c] = kprow[c];
     }
@@ -192,25 +205,25 @@ struct SalienceParams {
     int levels, ground_level;
 };
 
-__global__ __launch_bounds__(256) void salience_kernel(const uint8_t *__restrict__ seg, const uint8_t *__restrict__ kp, int P,
+#define SAL_THREADS 1024  // one workgroup per frame: 16 wavefronts hide the latency of the frame-long scan
+__global__ __launch_bounds__(SAL_THREADS) void salience_kernel(const uint8_t *__restrict__ seg, const uint8_t *__restrict__ kp, int P,
                                                        int M, SalienceParams sp, uint8_t *__restrict__ salience,
                                                        float *__restrict__ label_acc) {
     __shared__ int kpn[256], pn[256];
     const int b = blockIdx.x, K = M + 2;
-    kpn[threadIdx.x] = 0;
-    pn[threadIdx.x] = 0;
+    if (threadIdx.x < 256) { kpn[threadIdx.x] = 0; pn[threadIdx.x] = 0; }
     __syncthreads();
     const uint8_t *sg = seg + (int64_t)b * P, *kk = kp + (int64_t)b * P;
-    for (int p0 = 0; p0 < P; p0 += 256 * 4) {
+    for (int p0 = 0; p0 < P; p0 += SAL_THREADS * 4) {
         int lab[4], key[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const int p = min(p0 + u * 256 + (int)threadIdx.x, P - 1);
+            const int p = min(p0 + u * SAL_THREADS + (int)threadIdx.x, P - 1);
             lab[u] = sg[p]; key[u] = kk[p];
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            if (p0 + u * 256 + (int)threadIdx.x >= P) lab[u] = -1;
+            if (p0 + u * SAL_THREADS + (int)threadIdx.x >= P) lab[u] = -1;
             // pixel counts: aggregate the wavefront's lanes per distinct label
             int todo = lab[u];
             while (true) {

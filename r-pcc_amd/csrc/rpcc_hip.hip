@@ -1704,13 +1704,14 @@ extern "C" int rpcc_extract_features(const float *ri, const uint8_t *seg, int B,
     const size_t sh = (size_t)3 * W * 4 + (size_t)W * 2 + (size_t)W * 2 + 16;
     ARG_TRY(sh <= 160 * 1024);
     ARG_TRY((W - 2 * feature_region) / segments <= 64 * FEAT_MAX_PER_LANE);  // a chunk's keys live in registers
+    ARG_TRY(W <= 64 * FEAT_GPW * (FEAT_THREADS / 64));                        // and so does a wavefront's part of the row
     FeatParams fp = {feature_region, segments, sharp_num, less_sharp_num, flat_num};
     const int need = ((W - 2 * feature_region) / segments + 63) / 64;  // keys per lane
 #define FEAT_LAUNCH(Q_)                                                                                          \
     do {                                                                                                         \
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&features_kernel<Q_>),                        \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));                       \
-        features_kernel<Q_><<<dim3(H, B), 64, sh, st>>>(ri, seg, H, W, fp, feat, key_point_map);                 \
+        features_kernel<Q_><<<dim3(H, B), FEAT_THREADS, sh, st>>>(ri, seg, H, W, fp, feat, key_point_map);                 \
     } while (0)
     if (need <= 2) FEAT_LAUNCH(2);
     else if (need <= 4) FEAT_LAUNCH(4);
@@ -1730,7 +1731,7 @@ extern "C" int rpcc_salience(const uint8_t *seg, const uint8_t *key_point_map, c
     for (int i = 0; i < 8; i++) { sp.level_kp_num[i] = i < levels ? level_kp_num[i] : 0; sp.level_acc[i] = i < levels ? level_acc[i] : 0.f; }
     sp.levels = levels;
     sp.ground_level = ground_level;
-    salience_kernel<<<B, 256, 0, (hipStream_t)stream>>>(seg, key_point_map, P, M, sp, salience, label_acc);
+    salience_kernel<<<B, SAL_THREADS, 0, (hipStream_t)stream>>>(seg, key_point_map, P, M, sp, salience, label_acc);
     LAUNCH_CHECK();
     return RPCC_OK;
 }
