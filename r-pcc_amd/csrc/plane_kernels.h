@@ -212,19 +212,27 @@ __global__ __launch_bounds__(PL_THREADS) void plane_model_kernel(const float *__
         LabelPoints pts;
         pts.pts = pl_pts; pts.n = n;
         const uint32_t seed = mix32(pp.seed, (uint32_t)b, (uint32_t)k);
-        ransac_plane_wg<4, PL_THREADS, PL_MAXH>(pts, pp.iters, (double)pp.thr, seed, plane, sred, swin, sbest);
+        ransac_plane_wg<4, PL_THREADS, PL_MAXH, 4>(pts, pp.iters, (double)pp.thr, seed, plane, sred, swin, sbest);
         // plane_angle_validation (segment_utils.py:84-93)
         const double a = plane[0], bb = plane[1], c = plane[2];
         const double nrm = sqrt((a * a + bb * bb) + c * c);
         bool bad = false, nan = false;
-        for (int i = tid; i < n; i += PL_THREADS) {
-            const uint32_t p = order[i];
-            const float tx = tm[3 * p], ty = tm[3 * p + 1], tz = tm[3 * p + 2];
-            const double dot = fabs(((double)tx * a + (double)ty * bb) + (double)tz * c);
-            const float tn = sqrtf((tx * tx + ty * ty) + tz * tz);
-            const double v = dot / nrm * (double)tn;
-            nan |= (v != v) || v > 1.0;   // arccos gives NaN, alpha.max() is NaN, NaN > threshold is False
-            bad |= v <= pp.cos_cut;
+        for (int i0 = tid; i0 < n; i0 += PL_THREADS * 4) {  // 4 pixels per thread in flight (index, then ray gather)
+            uint32_t p[4];
+            float tx[4], ty[4], tz[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) p[u] = order[min(i0 + PL_THREADS * u, n - 1)];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { tx[u] = tm[3 * p[u]]; ty[u] = tm[3 * p[u] + 1]; tz[u] = tm[3 * p[u] + 2]; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const double dot = fabs(((double)tx[u] * a + (double)ty[u] * bb) + (double)tz[u] * c);
+                const float tn = sqrtf((tx[u] * tx[u] + ty[u] * ty[u]) + tz[u] * tz[u]);
+                const double v = dot / nrm * (double)tn;
+                const bool in = i0 + PL_THREADS * u < n;
+                nan |= in && ((v != v) || v > 1.0);   // arccos gives NaN, alpha.max() is NaN, NaN > threshold is False
+                bad |= in && v <= pp.cos_cut;
+            }
         }
         const int any_nan = __syncthreads_or(nan ? 1 : 0), any_bad = __syncthreads_or(bad ? 1 : 0);
         use_plane = any_nan || !any_bad;

@@ -622,7 +622,8 @@ __device__ __forceinline__ void rs_treesum(double (&v)[NV], double *sred) {
 // Workgroup-wide RANSAC on `pts` (RN = sample size, NTH = threads of the workgroup (>= RS_NT), MAXH = most
 // hypotheses); every thread calls it.  Returns the
 // winner's inlier count.  sred [6*RS_NT] doubles, swin [16*4] doubles, sbest [16*2] ints.
-template <int RN, int NTH, int MAXH, class PTS>
+// RS_PU: points per lane in flight in the scoring / refit loops (1 for points in LDS, more for points in global memory)
+template <int RN, int NTH, int MAXH, int RS_PU, class PTS>
 __device__ int ransac_plane_wg(const PTS &pts, int iters, double thr, uint32_t seed, double plane[4], double *sred,
                                double *swin, int *sbest) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -681,10 +682,16 @@ __device__ int ransac_plane_wg(const PTS &pts, int iters, double thr, uint32_t s
         pf[q][3] = ok ? hyp[5 * hh + 3] : __builtin_inff();  // invalid -> never an inlier
         cnt[q] = 0;
     }
-    for (int i = lane; i < n; i += 64) {
-        float x, y, z; pts.getf(i, x, y, z);
+    for (int i0 = lane; i0 < n; i0 += 64 * RS_PU) {  // RS_PU points per lane in flight (unconditional, clamped loads)
+        float x[RS_PU], y[RS_PU], z[RS_PU];
 #pragma unroll
-        for (int q = 0; q < RS_HPW; q++) cnt[q] += plane_inlier(pf[q], x, y, z, thr_f);
+        for (int u = 0; u < RS_PU; u++) pts.getf(min(i0 + 64 * u, n - 1), x[u], y[u], z[u]);
+#pragma unroll
+        for (int u = 0; u < RS_PU; u++) {
+            const bool in = i0 + 64 * u < n;
+#pragma unroll
+            for (int q = 0; q < RS_HPW; q++) cnt[q] += in && plane_inlier(pf[q], x[u], y[u], z[u], thr_f);
+        }
     }
     int best_cnt = -1, best_h = 0x7fffffff;
 #pragma unroll
@@ -714,9 +721,13 @@ __device__ int ransac_plane_wg(const PTS &pts, int iters, double thr, uint32_t s
     // refit on the winner's inliers (fp64 moments, ordered sums)
     double c[3] = {0, 0, 0};
     if (tid < RS_NT)
-        for (int i = tid; i < n; i += RS_NT) {
-            float x, y, z; pts.getf(i, x, y, z);
-            if (plane_inlier(wf, x, y, z, thr_f)) { c[0] += (double)x; c[1] += (double)y; c[2] += (double)z; }
+        for (int i0 = tid; i0 < n; i0 += RS_NT * RS_PU) {  // partial tid accumulates its points in index order
+            float x[RS_PU], y[RS_PU], z[RS_PU];
+#pragma unroll
+            for (int u = 0; u < RS_PU; u++) pts.getf(min(i0 + RS_NT * u, n - 1), x[u], y[u], z[u]);
+#pragma unroll
+            for (int u = 0; u < RS_PU; u++)
+                if (i0 + RS_NT * u < n && plane_inlier(wf, x[u], y[u], z[u], thr_f)) { c[0] += (double)x[u]; c[1] += (double)y[u]; c[2] += (double)z[u]; }
         }
     DBG_STAMP(4);
     rs_treesum<3>(c, sred);
@@ -724,12 +735,16 @@ __device__ int ransac_plane_wg(const PTS &pts, int iters, double thr, uint32_t s
     c[0] /= (double)wcnt; c[1] /= (double)wcnt; c[2] /= (double)wcnt;
     double m[6] = {0, 0, 0, 0, 0, 0};
     if (tid < RS_NT)
-        for (int i = tid; i < n; i += RS_NT) {
-            float x, y, z; pts.getf(i, x, y, z);
-            if (plane_inlier(wf, x, y, z, thr_f)) {
-                const double rx = (double)x - c[0], ry = (double)y - c[1], rz = (double)z - c[2];
-                m[0] += rx * rx; m[1] += rx * ry; m[2] += rx * rz; m[3] += ry * ry; m[4] += ry * rz; m[5] += rz * rz;
-            }
+        for (int i0 = tid; i0 < n; i0 += RS_NT * RS_PU) {
+            float x[RS_PU], y[RS_PU], z[RS_PU];
+#pragma unroll
+            for (int u = 0; u < RS_PU; u++) pts.getf(min(i0 + RS_NT * u, n - 1), x[u], y[u], z[u]);
+#pragma unroll
+            for (int u = 0; u < RS_PU; u++)
+                if (i0 + RS_NT * u < n && plane_inlier(wf, x[u], y[u], z[u], thr_f)) {
+                    const double rx = (double)x[u] - c[0], ry = (double)y[u] - c[1], rz = (double)z[u] - c[2];
+                    m[0] += rx * rx; m[1] += rx * ry; m[2] += rx * rz; m[3] += ry * ry; m[4] += ry * rz; m[5] += rz * rz;
+                }
         }
     rs_treesum<6>(m, sred);
     double pl[4];
@@ -814,7 +829,7 @@ __global__ __launch_bounds__(RS_THREADS) void ground_ransac_kernel(const float *
     DBG_STAMP(2);
     double plane[4];
     (void)ransac_n;  // the ground fit samples 10 points (utils/segment_utils.py:75)
-    const int inl = ransac_plane_wg<10, RS_THREADS, RS_MAX_HYP>(pts, iters, thr, seed0 + (uint32_t)b, plane, sred, swin, sbest);
+    const int inl = ransac_plane_wg<10, RS_THREADS, RS_MAX_HYP, 1>(pts, iters, thr, seed0 + (uint32_t)b, plane, sred, swin, sbest);
     DBG_STAMP(6);
     if (tid == 0) {
         ground[4 * b] = plane[0]; ground[4 * b + 1] = plane[1]; ground[4 * b + 2] = plane[2]; ground[4 * b + 3] = plane[3];
