@@ -741,3 +741,40 @@ def test_projection_fast_path_never_disagrees(env, gname):
         if name == "sweep":
             assert slow < 0.1 * n, (name, slow / n)     # the fast path must carry the ordinary points
     assert tot_sure > 0
+
+
+@pytest.mark.parametrize("H,W,M", [(5, 300, 7), (8, 512, 20), (33, 1000, 100), (16, 4000, 50)])
+def test_odd_geometries_fused(env, H, W, M):
+    """Fused entry (ground fit inside) on image shapes that are no multiple of any tile size the kernels use
+    (4x32 FPS / assign tiles, 1024-pixel scatter tiles, 32768-pixel projection bands, RANSAC chunks), with
+    cluster counts from 7 to 100: every output equals the oracle's."""
+    torch, ops, orc, synth = env["torch"], env["ops"], env["orc"], env["synth"]
+    g = orc.LidarGeom(H, W, 360.0, 3.0, -25.0)
+    tm = ops.transform_map(g.H, g.W, g.horizontal_FOV, g.vertical_max, g.vertical_min)
+    assert np.array_equal(tm, orc.transform_map(g))
+    geom = ops.make_geom(g.H, g.W, g.horizontal_FOV, g.vertical_max, g.vertical_min)
+    frames = [synth.make_frame(300 + i, H, W, vmax_deg=3.0, vmin_deg=-25.0).numpy() for i in range(3)]
+    frames.append(frames[0][:40].copy())                          # nearly empty frame: fewer candidates than clusters
+    offs = np.zeros(len(frames) + 1, np.int64)
+    offs[1:] = np.cumsum([f.shape[0] for f in frames])
+    B = len(frames)
+    buf = ops.BatchBuffers(B, geom, M, env["dev"])
+    gfit = torch.zeros((B, 4), dtype=torch.float64, device=env["dev"])
+    ops.compress_batch(_to(env, np.concatenate(frames)), _to(env, offs), _to(env, tm), gfit, buf, ground_seed=11)
+    torch.cuda.synchronize()
+    cfg = dict(orc.DEFAULT_CFG)
+    cfg["cluster_num"] = M
+    for i, f in enumerate(frames[:3]):
+        gm = orc.ground_model(orc.project(f, g), tm, seed=11 + i)
+        assert _beq(gfit[i].cpu().numpy(), gm), (H, W, i)
+        o = orc.compress_frame(f, g, tm, gm, cfg)
+        n = int(buf.nnz[i])
+        assert _beq(buf.ri[i].cpu().numpy(), o["range_image"])
+        assert np.array_equal(buf.cen_pix[i].cpu().numpy(), o["fps_pix"]), (H, W, i)
+        assert np.array_equal(buf.seg[i].cpu().numpy(), o["seg_idx"].astype(np.uint8)), (H, W, i)
+        assert n == o["q"].shape[0] and np.array_equal(buf.q16[i, :n].cpu().numpy(), o["q"].astype(np.int16))
+    # the sparse frame: projection and ground fit still agree (FPS with fewer candidates than clusters is undefined
+    # in the reference -- indices repeat -- so only the stages before it are compared)
+    gm = orc.ground_model(orc.project(frames[3], g), tm, seed=11 + 3)
+    assert _beq(gfit[3].cpu().numpy(), gm)
+    assert _beq(buf.ri[3].cpu().numpy(), orc.project(frames[3], g))
