@@ -127,8 +127,12 @@ __device__ __forceinline__ void fps_load_point(const float *__restrict__ src, co
 
 #define FPS_THREADS 1024
 
+// Threads of the tile-pruned FPS workgroup (one workgroup per frame).  512, not 1024: alone the kernel is 20 % slower
+// (540 -> 645 us per 256 frames), but with several batches in flight two such workgroups no longer fill every wave
+// slot of a CU and the step gets 8 % shorter (1.31 -> 1.21 ms); 256 threads lose both ways.
+#define FPS_TT 512
 template <bool RANGE>
-__global__ __launch_bounds__(FPS_THREADS) void fps_tiled_kernel(const float *__restrict__ src,
+__global__ __launch_bounds__(FPS_TT) void fps_tiled_kernel(const float *__restrict__ src,
                                                                 const float *__restrict__ tx,
                                                                 const float *__restrict__ ty,
                                                                 const float *__restrict__ tz, float *__restrict__ temp,
@@ -137,8 +141,8 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_tiled_kernel(const float *__r
                                                                 float *__restrict__ out_cen,
                                                                 const float *__restrict__ tiletab) {
     extern __shared__ __attribute__((aligned(16))) unsigned char fps_smem[];
-    __shared__ unsigned long long red[16];
-    __shared__ int redt[16];
+    __shared__ unsigned long long red[FPS_TT / 64];
+    __shared__ int redt[FPS_TT / 64];
     __shared__ int wcount;
     const int T = g.T, N = g.N;
     FpsLds L(fps_smem, T);
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_tiled_kernel(const float *__r
     }
 
     if (RANGE) {
-        for (int t = tid; t < T; t += FPS_THREADS) {
+        for (int t = tid; t < T; t += FPS_TT) {
             const int tr = t / g.tcols, tc = t - tr * g.tcols;
             const int ncol = min(32, g.W - 32 * tc), nrow = min(4, g.H - 4 * tr);
             L.torg[t] = (uint32_t)(4 * tr * g.W + 32 * tc) | ((uint32_t)ncol << 23) | ((uint32_t)nrow << 29);
@@ -218,7 +222,7 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_tiled_kernel(const float *__r
     auto select_next = [&]() {
         uint32_t hi = 0u, ix = 0xFFFFFFFFu;  // orderable value, index
         int bt = 0;
-        for (int t = tid; t < T; t += FPS_THREADS) {
+        for (int t = tid; t < T; t += FPS_TT) {
             const float v = L.tmax[t];
             const uint32_t h = (v < 0.0f) ? 0u : f2u(v) + 1u, i = L.targ[t];
             if (h > hi || (h == hi && i < ix)) { hi = h; ix = i; bt = t; }
@@ -232,8 +236,8 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_tiled_kernel(const float *__r
             if (lane == 0) { red[wave] = ((unsigned long long)vmax << 32) | imin; redt[wave] = wt_; }
         }
         __syncthreads();
-        const unsigned long long k = red[lane & 15];
-        const int kt = redt[lane & 15];
+        const unsigned long long k = red[lane & (FPS_TT / 64 - 1)];
+        const int kt = redt[lane & (FPS_TT / 64 - 1)];
         hi = (uint32_t)(k >> 32); ix = (uint32_t)k;
         vmax = dpp_max_u32(hi);
         imin = dpp_min_u32(hi == vmax ? ix : 0xFFFFFFFFu);
@@ -249,7 +253,7 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_tiled_kernel(const float *__r
         }
     };
 
-    constexpr int NW = FPS_THREADS / 64, GROUP = 4;
+    constexpr int NW = FPS_TT / 64, GROUP = 4;  // tiles per wavefront in flight (2 and 8 measured: no better)
     DBG_STAMP(8);
     // first centre: every tile is visited once (also builds the boxes) -- unless ground_mask already did
     // that pass and left the tile table (info[b][3] == 1)
@@ -257,7 +261,7 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_tiled_kernel(const float *__r
     if (M > 1 && have_tab) {
         const float *tab = tiletab + (int64_t)b * FPS_TAB_ROWS * T;
         float *dst = reinterpret_cast<float *>(fps_smem);
-        for (int i = tid; i < FPS_TAB_ROWS * T; i += FPS_THREADS) dst[i] = tab[i];
+        for (int i = tid; i < FPS_TAB_ROWS * T; i += FPS_TT) dst[i] = tab[i];
         __syncthreads();
     } else if (M > 1) {
         for (int t = wave; t < T; t += NW * GROUP) {
@@ -280,7 +284,7 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_tiled_kernel(const float *__r
     for (int j = 2; j < M; j++) {
         if (prof) tq = (long long)__builtin_readcyclecounter();
         // tile test against the new centre; active tiles go to the work list
-        for (int t = tid; t < T; t += FPS_THREADS) {
+        for (int t = tid; t < T; t += FPS_TT) {
             const float g0 = fmaxf(fmaxf(L.lo[0][t] - c0, c0 - L.hi[0][t]), 0.0f);
             const float g1 = fmaxf(fmaxf(L.lo[1][t] - c1, c1 - L.hi[1][t]), 0.0f);
             const float g2 = fmaxf(fmaxf(L.lo[2][t] - c2, c2 - L.hi[2][t]), 0.0f);

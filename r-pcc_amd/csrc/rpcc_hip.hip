@@ -770,7 +770,8 @@ __global__ __launch_bounds__(RS_THREADS) void ground_ransac_kernel(const float *
     const float *ri = ri_all + (int64_t)b * P;
     DBG_STAMP(0);
     // each wave owns a contiguous run of pixels (rounded up to whole 64-pixel steps)
-    const int per_wave = (((P + RS_CHUNKS - 1) / RS_CHUNKS) + 63) & ~63;  // == rs_chunk_px(P)
+    constexpr int CPW = RS_CHUNKS / (RS_THREADS / 64);  // chunks (of the band kernel's hand-off) per wavefront
+    const int per_wave = CPW * ((((P + RS_CHUNKS - 1) / RS_CHUNKS) + 63) & ~63);  // CPW * rs_chunk_px(P)
     const int w0 = wave * per_wave, w1 = min(P, w0 + per_wave);
     const bool have_cnt = zcnt != nullptr && zcnt[b * (RS_CHUNKS + 1) + RS_CHUNKS] != 0;  // counted by project_band_kernel
     auto zval = [&](int p) -> float {
@@ -778,7 +779,9 @@ __global__ __launch_bounds__(RS_THREADS) void ground_ransac_kernel(const float *
         if (raw && f2u(r) == RI_EMPTY) r = 0.0f;  // projection bits not finalised yet
         return r * tm[3 * p + 2];
     };
-    int cnt = have_cnt ? zcnt[b * (RS_CHUNKS + 1) + wave] : 0;
+    int cnt = 0;
+    if (have_cnt)
+        for (int q = 0; q < CPW; q++) cnt += zcnt[b * (RS_CHUNKS + 1) + wave * CPW + q];
     for (int p0 = w0; p0 < w1 && !have_cnt; p0 += 64 * 8) {  // 8 independent loads in flight per lane
         float zv[8];
 #pragma unroll
@@ -790,7 +793,7 @@ __global__ __launch_bounds__(RS_THREADS) void ground_ransac_kernel(const float *
     __syncthreads();
     DBG_STAMP(1);
     int nc = 0, base = 0;
-    for (int w = 0; w < 16; w++) { if (w < wave) base += swave[w]; nc += swave[w]; }
+    for (int w = 0; w < RS_THREADS / 64; w++) { if (w < wave) base += swave[w]; nc += swave[w]; }
     RsPoints pts;
     pts.ri = ri; pts.tm = tm; pts.lds = nullptr; pts.n = P; pts.raw = raw;
     if (nc >= min_pts) {
@@ -1072,7 +1075,7 @@ extern "C" int rpcc_fps_xyz(int B, int N, int M, const float *points, float *tem
         const size_t sh = fps_tiled_lds_bytes(g.T);
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_tiled_kernel<false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-        fps_tiled_kernel<false><<<B, FPS_THREADS, sh, st>>>(points, nullptr, nullptr, nullptr, temp, nullptr, g, M, idx,
+        fps_tiled_kernel<false><<<B, FPS_TT, sh, st>>>(points, nullptr, nullptr, nullptr, temp, nullptr, g, M, idx,
                                                          nullptr, nullptr);
     } else {
         fps_xyz_kernel<<<B, FPS_THREADS, 0, st>>>(N, M, points, temp, idx);
@@ -1093,7 +1096,7 @@ static int launch_fps_range(const float *ri, const float *tm, float *temp, const
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_tiled_kernel<true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
         FpsTimer tmr(st);
-        fps_tiled_kernel<true><<<B, FPS_THREADS, sh, st>>>(ri, rays_soa, rays_soa + P, rays_soa + 2 * (int64_t)P, temp, info,
+        fps_tiled_kernel<true><<<B, FPS_TT, sh, st>>>(ri, rays_soa, rays_soa + P, rays_soa + 2 * (int64_t)P, temp, info,
                                                         g, M, cen_pix, centers, tiletab);
         LAUNCH_CHECK();
         return RPCC_OK;
