@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void tile_scan_kernel(uint32_t *__restrict__ t
         sh[threadIdx.x] = v;
         __syncthreads();
         for (int o = 1; o < 256; o <<= 1) {  // Hillis-Steele inclusive scan
-            const uint32_t add = threadIdx.x >= o ? sh[threadIdx.x - o] : 0u;
+            const uint32_t add = (int)threadIdx.x >= o ? sh[threadIdx.x - o] : 0u;
             __syncthreads();
             sh[threadIdx.x] += add;
             __syncthreads();

@@ -78,15 +78,15 @@ struct FpsTimer {
     explicit FpsTimer(hipStream_t st) : s(st), on(g_fps_timing && g_ev_n < 64) {
         if (!on) return;
         while (g_ev_alloc <= g_ev_n) {
-            hipEventCreate(&g_ev0[g_ev_alloc]);
-            hipEventCreate(&g_ev1[g_ev_alloc]);
+            (void)hipEventCreate(&g_ev0[g_ev_alloc]);
+            (void)hipEventCreate(&g_ev1[g_ev_alloc]);
             g_ev_alloc++;
         }
-        hipEventRecord(g_ev0[g_ev_n], s);
+        (void)hipEventRecord(g_ev0[g_ev_n], s);
     }
     ~FpsTimer() {
         if (!on) return;
-        hipEventRecord(g_ev1[g_ev_n], s);
+        (void)hipEventRecord(g_ev1[g_ev_n], s);
         g_ev_n++;
     }
 };
@@ -887,10 +887,9 @@ __global__ __launch_bounds__(256) void ground_mask_kernel(float *__restrict__ ri
     // np.linalg.norm(plane_param[:, :3]) on a (1,1,4) array: all four components (segment_utils.py:47)
     const double div = sqrt(((a * a + bb * bb) + c * c) + d * d);
     int cnt = 0, nzc = 0, first = P;
-#pragma unroll 2
     for (int it = 0; it < GM_PIX / 256; it++) {
         const int p = blockIdx.x * GM_PIX + it * 256 + threadIdx.x;
-        if (blockIdx.x * GM_PIX + it * 256 >= P) break;  // whole workgroup past the image (uniform)
+        if ((int)(blockIdx.x * GM_PIX) + it * 256 >= P) break;  // whole workgroup past the image (uniform)
         const bool valid = p < P;
         const int pc = valid ? p : P - 1;
         float r = ri[(int64_t)b * P + pc];
