@@ -394,14 +394,20 @@ __global__ __launch_bounds__(256) void project_fastcheck_kernel(const float *__r
 static inline int rs_chunk_px(int P) { return (((P + RS_CHUNKS - 1) / RS_CHUNKS) + 63) & ~63; }
 __global__ __launch_bounds__(BAND_THREADS) void project_band_kernel(const uint2 *__restrict__ pd,
                                                                     const int64_t *__restrict__ offs, int64_t base,
-                                                                    int P, uint32_t *__restrict__ ri,
+                                                                    int B, int P, uint32_t *__restrict__ ri,
                                                                     const int32_t *__restrict__ flags,
                                                                     const float *__restrict__ tz, float zthr, int rs_chunk,
                                                                     int32_t *__restrict__ zcnt) {
     extern __shared__ uint32_t band[];  // [BAND_PX]
-    const int b = blockIdx.y;
+    // XCD-aware mapping: consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2).  The nbands
+    // workgroups of a frame all stream the same record list, so they are placed on ONE XCD (ids x, x+8, x+16, ...):
+    // XCD x serves the frames b = x (mod 8), and the list is fetched into that L2 once instead of nbands times.
+    const int nbands = (P + BAND_PX - 1) / BAND_PX;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int b = xcd + 8 * (slot / nbands), kband = slot % nbands;
+    if (b >= B) return;
     if (flags[b]) return;
-    const uint32_t band0 = blockIdx.x * BAND_PX;
+    const uint32_t band0 = (uint32_t)kband * BAND_PX;
     const uint32_t npx = min((uint32_t)BAND_PX, (uint32_t)P - band0);
     for (uint32_t p = threadIdx.x; p < npx; p += BAND_THREADS) band[p] = RI_EMPTY;
     __syncthreads();
@@ -457,7 +463,7 @@ __global__ __launch_bounds__(BAND_THREADS) void project_band_kernel(const uint2 
         }
     }
     if (acc && (threadIdx.x & 63) == 0) atomicAdd(&zcnt[b * (RS_CHUNKS + 1) + ch], acc);
-    if (blockIdx.x == 0 && threadIdx.x == 0) zcnt[b * (RS_CHUNKS + 1) + RS_CHUNKS] = 1;
+    if (kband == 0 && threadIdx.x == 0) zcnt[b * (RS_CHUNKS + 1) + RS_CHUNKS] = 1;
 }
 
 static size_t project_scratch_bytes(int64_t total, int B, int P) {
@@ -496,8 +502,8 @@ static int launch_project(const float *xyz, const int64_t *offsets, int64_t tota
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&project_band_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, BAND_PX * 4));
         if (zcnt) HIP_TRY(hipMemsetAsync(zcnt, 0, (size_t)B * (RS_CHUNKS + 1) * 4, st));
-        project_band_kernel<<<dim3((P + BAND_PX - 1) / BAND_PX, B), BAND_THREADS, BAND_PX * 4, st>>>(
-            pd, offsets, base, P, rb, flags, tz_plane, -1.5f, rs_chunk_px(P), tz_plane ? zcnt : nullptr);
+        project_band_kernel<<<8 * ((B + 7) / 8) * ((P + BAND_PX - 1) / BAND_PX), BAND_THREADS, BAND_PX * 4, st>>>(
+            pd, offsets, base, B, P, rb, flags, tz_plane, -1.5f, rs_chunk_px(P), tz_plane ? zcnt : nullptr);
         LAUNCH_CHECK();
         if (total > 0) {  // exact input-order semantics for frames with depth-0 points: no-ops otherwise
             project_fill_kernel<true><<<fg, 256, 0, st>>>(rb, lastz, flags, P);
