@@ -466,6 +466,42 @@ __global__ __launch_bounds__(BAND_THREADS) void project_band_kernel(const uint2 
     if (kband == 0 && threadIdx.x == 0) zcnt[b * (RS_CHUNKS + 1) + RS_CHUNKS] = 1;
 }
 
+// Exact input-order projection of the frames that hold a depth-0 point (flags), as ONE launch: a 256-thread workgroup
+// per frame does what project_fill<true> / project_kernel<1> / project_kernel<2> / project_finalize<true> do grid-wide
+// (all dependencies are inside a frame).  Frames without a flag -- the normal case -- leave at once, so the fast path
+// pays one empty launch instead of four.  Loads that follow this kernel's own atomics bypass the CU's L1 (agent scope).
+#define FIXUP_THREADS 256
+__global__ __launch_bounds__(FIXUP_THREADS) void project_fixup_kernel(const float *__restrict__ xyz, const int64_t *__restrict__ offs,
+                                                                      int B, rpcc_geom g, uint32_t *__restrict__ ri,
+                                                                      int32_t *__restrict__ lastz,
+                                                                      const int32_t *__restrict__ flags) {
+    const int b = blockIdx.x;
+    if (flags[b] == 0) return;
+    const int P = g.H * g.W;
+    uint32_t *img = ri + (int64_t)b * P;
+    int32_t *lz = lastz + (int64_t)b * P;
+    for (int p = threadIdx.x; p < P; p += FIXUP_THREADS) { img[p] = RI_EMPTY; lz[p] = 0; }
+    __threadfence();
+    __syncthreads();
+    const int64_t i0 = offs[b], i1 = offs[b + 1];
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += FIXUP_THREADS) {  // last input position of a depth-0 point per pixel
+        const RowCol rc = project_point(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], g);
+        if (fabsf(rc.depth) <= 3.402823466e+38f && rc.depth == 0.0f) atomicMax(&lz[rc.pix], (int32_t)(i - i0) + 1);
+    }
+    __threadfence();
+    __syncthreads();
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += FIXUP_THREADS) {  // minimum over the points after that position
+        const RowCol rc = project_point(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], g);
+        if (!(fabsf(rc.depth) <= 3.402823466e+38f) || rc.depth == 0.0f) continue;
+        const int32_t last = __hip_atomic_load(&lz[rc.pix], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((int32_t)(i - i0) + 1 > last) atomicMin(&img[rc.pix], f2u(rc.depth));
+    }
+    __threadfence();
+    __syncthreads();
+    for (int p = threadIdx.x; p < P; p += FIXUP_THREADS)
+        if (__hip_atomic_load(&img[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == RI_EMPTY) img[p] = 0u;
+}
+
 static size_t project_scratch_bytes(int64_t total, int B, int P) {
     return ((size_t)B * ((size_t)P + 8)) * 4 + 256 + (size_t)(total > 0 ? total : 0) * 8;
 }
@@ -505,11 +541,8 @@ static int launch_project(const float *xyz, const int64_t *offsets, int64_t tota
         project_band_kernel<<<8 * ((B + 7) / 8) * ((P + BAND_PX - 1) / BAND_PX), BAND_THREADS, BAND_PX * 4, st>>>(
             pd, offsets, base, B, P, rb, flags, tz_plane, -1.5f, rs_chunk_px(P), tz_plane ? zcnt : nullptr);
         LAUNCH_CHECK();
-        if (total > 0) {  // exact input-order semantics for frames with depth-0 points: no-ops otherwise
-            project_fill_kernel<true><<<fg, 256, 0, st>>>(rb, lastz, flags, P);
-            project_kernel<1><<<nb_small, 256, 0, st>>>(xyz, offsets, total, base, B, g, rb, lastz, flags);
-            project_kernel<2><<<nb_small, 256, 0, st>>>(xyz, offsets, total, base, B, g, rb, lastz, flags);
-            project_finalize_kernel<true><<<fg, 256, 0, st>>>(rb, P, flags);
+        if (total > 0) {  // exact input-order semantics for frames with depth-0 points: a no-op otherwise
+            project_fixup_kernel<<<B, FIXUP_THREADS, 0, st>>>(xyz, offsets, B, g, rb, lastz, flags);
             LAUNCH_CHECK();
         }
         return RPCC_OK;
@@ -928,9 +961,10 @@ __global__ __launch_bounds__(256) void ground_mask_kernel(float *__restrict__ ri
 
 // tiletab: dev f32 [B][11][T] (T = tiles of fps_tiling_range(H,W)) or NULL
 static int launch_ground_mask(float *ri, const float *tm, const double *ground, double thr, int B, int H, int W,
-                              float *temp, int32_t *info, float *tiletab, hipStream_t st, bool raw) {
+                              float *temp, int32_t *info, float *tiletab, hipStream_t st, bool raw,
+                              bool info_ready = false) {
     const int P = H * W;
-    info_init_kernel<<<(B + 255) / 256, 256, 0, st>>>(info, B, P);
+    if (!info_ready) info_init_kernel<<<(B + 255) / 256, 256, 0, st>>>(info, B, P);
     if (tiletab) {
         const FpsTiling g = fps_tiling_range(H, W);
         const dim3 grid((g.T + 4 * TAB_TPW - 1) / (4 * TAB_TPW), B);
@@ -1062,9 +1096,12 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_range_kernel(const float *__r
 }
 
 // AoS transform_map [P,3] -> three planes (frame-invariant; 12 B/pixel once per call)
-__global__ __launch_bounds__(256) void rays_soa_kernel(const float *__restrict__ tm, int P, float *__restrict__ soa) {
+// info (optional): also initialises the per-frame counters that the ground-mask kernel accumulates (one launch less)
+__global__ __launch_bounds__(256) void rays_soa_kernel(const float *__restrict__ tm, int P, float *__restrict__ soa,
+                                                       int32_t *__restrict__ info = nullptr, int B = 0) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p < P) { soa[p] = tm[3 * p]; soa[P + p] = tm[3 * p + 1]; soa[2 * (int64_t)P + p] = tm[3 * p + 2]; }
+    if (info != nullptr && p < B) { info[4 * p] = 0; info[4 * p + 1] = P; info[4 * p + 2] = 0; info[4 * p + 3] = 0; }
 }
 
 static bool g_fps_force_v1 = false;
@@ -1834,7 +1871,8 @@ static int run_slice(const rpcc_batch_io *io, int b0, int Bs, int64_t pt0, int64
     float *model = io->model + (size_t)b0 * K * 4;
     int rc;
     int32_t *zcnt = fit_ground ? reinterpret_cast<int32_t *>(tiletab) : nullptr;  // the tile table is written later
-    rays_soa_kernel<<<(P + 255) / 256, 256, 0, st>>>(io->tm, P, rays_soa);  // planar ray table: band kernel (z), FPS
+    // planar ray table (band kernel's z, FPS) + the info counters of the ground mask
+    rays_soa_kernel<<<(std::max(P, Bs) + 255) / 256, 256, 0, st>>>(io->tm, P, rays_soa, info, Bs);
     LAUNCH_CHECK();
     if ((rc = launch_project(io->xyz, io->offsets + b0, npts, pt0, Bs, g, ri, proj_scratch, proj_bytes, st,
                              rays_soa + 2 * (int64_t)P, zcnt)))
@@ -1844,7 +1882,7 @@ static int run_slice(const rpcc_batch_io *io, int b0, int Bs, int64_t pt0, int64
         return rc;
     const bool tiled = !g_fps_force_v1 && fps_tiling_range(g.H, g.W).T <= FPS_TILED_MAX_TILES;
     if ((rc = launch_ground_mask(ri, io->tm, ground, ground_threshold, Bs, g.H, g.W, temp, info,
-                                 tiled ? tiletab : nullptr, st, false)))
+                                 tiled ? tiletab : nullptr, st, false, true)))
         return rc;
     if (pre_done) HIP_TRY(hipEventRecord(pre_done, st));
     if ((rc = launch_fps_range(ri, io->tm, temp, info, Bs, g.H, g.W, M, io->cen_pix + (size_t)b0 * M, centers, rays_soa,
