@@ -235,7 +235,8 @@ typedef struct rpcc_batch_io {
 } rpcc_batch_io;
 
 size_t rpcc_workspace_bytes(int B, int P, int M, int64_t total_points);
-void rpcc_set_batch_slices(int n); /* 1..8 sub-batches (default 1 = off); only used with offsets_host */
+void rpcc_set_batch_slices(int n); /* 1..8 sub-batches (default 1 = off); only used with offsets_host.  Measured
+                                      slower than whole batches on MI355X: leave it off. */
 int rpcc_compress_batch(const rpcc_batch_io *io, int B, rpcc_geom g, int M, double ground_threshold, float acc,
                         void *ws, void *stream);
 

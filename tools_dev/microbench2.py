@@ -39,6 +39,6 @@ print("contour_encode    %.3f ms" % timeit(lambda: ops.contour_encode(seg, M, ws
 bits, seq, nseq = ops.contour_encode(seg, M, ws=cws)
 print("contour_decode    %.3f ms" % timeit(lambda: ops.contour_decode(bits, seq, H, W, M, ws=cws)))
 q, nnz, _ = ops.predict_quantize(ri, tm, seg, model, 0.04, M, int16=True, ws=buf.ws)
-print("decode            %.3f ms" % timeit(lambda: ops.decode(seg, q, model, tm, [0.04], want_points=True, ws=cws)))
+print("decode            %.3f ms" % timeit(lambda: ops.decode(seg, q, model, tm, 0.04, want_points=True, ws=cws)))
 print("backproject       %.3f ms" % timeit(lambda: ops.backproject(ri, tm)))
 print("intra_predict     %.3f ms" % timeit(lambda: ops.intra_predict(seg, model, tm)))
