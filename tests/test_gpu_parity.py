@@ -778,3 +778,32 @@ def test_odd_geometries_fused(env, H, W, M):
     gm = orc.ground_model(orc.project(frames[3], g), tm, seed=11 + 3)
     assert _beq(gfit[3].cpu().numpy(), gm)
     assert _beq(buf.ri[3].cpu().numpy(), orc.project(frames[3], g))
+
+
+@pytest.mark.parametrize("gname,nframes", [("VelodyneVLP16", 40), ("Velodyne32E", 16)])
+def test_fused_batch_many_frames_vs_oracle(env, gname, nframes):
+    """Breadth check of the exact screens (projection fast path, assign ground / tie screens, ground-mask division): every
+    frame of a larger batch of different synthetic scenes, ground plane fitted inside the call, equals the oracle in
+    range image, FPS pixels, labels and quantised integers."""
+    torch, ops, orc, synth = env["torch"], env["ops"], env["orc"], env["synth"]
+    g, geom, tm = _geom(env, gname)
+    gd = orc.GEOMS[gname]
+    frames = [synth.make_frame(1000 + 7 * i, g.H, g.W, vmax_deg=gd["vmax_deg"], vmin_deg=gd["vmin_deg"]).numpy() for i in range(nframes)]
+    offs = np.zeros(nframes + 1, np.int64)
+    offs[1:] = np.cumsum([f.shape[0] for f in frames])
+    buf = ops.BatchBuffers(nframes, geom, 100, env["dev"])
+    gfit = torch.zeros((nframes, 4), dtype=torch.float64, device=env["dev"])
+    ops.compress_batch(_to(env, np.concatenate(frames)), _to(env, offs), _to(env, tm), gfit, buf, ground_seed=500)
+    torch.cuda.synchronize()
+    gf = gfit.cpu().numpy()
+    ri, seg, cen, q16, nnz = (buf.ri.cpu().numpy(), buf.seg.cpu().numpy(), buf.cen_pix.cpu().numpy(), buf.q16.cpu().numpy(),
+                              buf.nnz.cpu().numpy())
+    for i, f in enumerate(frames):
+        gm = orc.ground_model(orc.project(f, g), tm, seed=500 + i)
+        assert _beq(gf[i], gm), (gname, i)
+        o = orc.compress_frame(f, g, tm, gm)
+        assert _beq(ri[i], o["range_image"]), (gname, i)
+        assert np.array_equal(cen[i], o["fps_pix"]), (gname, i)
+        assert np.array_equal(seg[i], o["seg_idx"].astype(np.uint8)), (gname, i)
+        n = int(nnz[i])
+        assert n == o["q"].shape[0] and np.array_equal(q16[i, :n], o["q"].astype(np.int16)), (gname, i)
