@@ -104,12 +104,10 @@ __device__ __forceinline__ void fps_tile_argmax(const float (&x)[2], const float
 __device__ __forceinline__ void fps_tile_box(const float (&x)[2], const float (&y)[2], const float (&z)[2],
                                              const bool (&cand)[2], float (&lo)[3], float (&hi)[3]) {
     const float inf = __builtin_inff();
-    lo[0] = dpp_min_f32(fminf(cand[0] ? x[0] : inf, cand[1] ? x[1] : inf));
-    lo[1] = dpp_min_f32(fminf(cand[0] ? y[0] : inf, cand[1] ? y[1] : inf));
-    lo[2] = dpp_min_f32(fminf(cand[0] ? z[0] : inf, cand[1] ? z[1] : inf));
-    hi[0] = dpp_max_f32(fmaxf(cand[0] ? x[0] : -inf, cand[1] ? x[1] : -inf));
-    hi[1] = dpp_max_f32(fmaxf(cand[0] ? y[0] : -inf, cand[1] ? y[1] : -inf));
-    hi[2] = dpp_max_f32(fmaxf(cand[0] ? z[0] : -inf, cand[1] ? z[1] : -inf));
+    lo[0] = fminf(cand[0] ? x[0] : inf, cand[1] ? x[1] : inf); hi[0] = fmaxf(cand[0] ? x[0] : -inf, cand[1] ? x[1] : -inf);
+    lo[1] = fminf(cand[0] ? y[0] : inf, cand[1] ? y[1] : inf); hi[1] = fmaxf(cand[0] ? y[0] : -inf, cand[1] ? y[1] : -inf);
+    lo[2] = fminf(cand[0] ? z[0] : inf, cand[1] ? z[1] : inf); hi[2] = fmaxf(cand[0] ? z[0] : -inf, cand[1] ? z[1] : -inf);
+    dpp_box6(lo[0], lo[1], lo[2], hi[0], hi[1], hi[2]);
 }
 
 // RANGE: point k = (ri[k]*tx[k], ri[k]*ty[k], ri[k]*tz[k]) with SoA rays; else AoS xyz[k*3..].

@@ -161,6 +161,50 @@ __device__ __forceinline__ uint32_t dpp_sum_u32(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+// Bounding box of a wavefront in ONE block of native float DPP instructions: three minima and three maxima reduced
+// together, the six chains interleaved step by step (five independent instructions between two dependent ones cover
+// the DPP read-after-write wait states, so no s_nop and no order-key conversion: 36 + 6 instructions instead of 6 x 13).
+// Lanes without a DPP source keep their value (bound_ctrl off), which is the identity of min / max.  All 64 lanes must be
+// active; the inputs are coordinates or +-inf, never NaN.
+#define RPCC_BOX6_STEP_(ctrl_)                                  \
+    "v_min_f32_dpp %0, %0, %0 " ctrl_ "\n\t"                     \
+    "v_min_f32_dpp %1, %1, %1 " ctrl_ "\n\t"                     \
+    "v_min_f32_dpp %2, %2, %2 " ctrl_ "\n\t"                     \
+    "v_max_f32_dpp %3, %3, %3 " ctrl_ "\n\t"                     \
+    "v_max_f32_dpp %4, %4, %4 " ctrl_ "\n\t"                     \
+    "v_max_f32_dpp %5, %5, %5 " ctrl_ "\n\t"
+__device__ __forceinline__ void dpp_box6(float &lo0, float &lo1, float &lo2, float &hi0, float &hi1, float &hi2) {
+    asm volatile("s_nop 1\n\t"
+                 RPCC_BOX6_STEP_("row_shr:1 row_mask:0xf bank_mask:0xf")
+                 RPCC_BOX6_STEP_("row_shr:2 row_mask:0xf bank_mask:0xf")
+                 RPCC_BOX6_STEP_("row_shr:4 row_mask:0xf bank_mask:0xf")
+                 RPCC_BOX6_STEP_("row_shr:8 row_mask:0xf bank_mask:0xf")
+                 RPCC_BOX6_STEP_("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                 RPCC_BOX6_STEP_("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                 "s_nop 1"
+                 : "+v"(lo0), "+v"(lo1), "+v"(lo2), "+v"(hi0), "+v"(hi1), "+v"(hi2));
+    lo0 = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(lo0), 63));
+    lo1 = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(lo1), 63));
+    lo2 = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(lo2), 63));
+    hi0 = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(hi0), 63));
+    hi1 = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(hi1), 63));
+    hi2 = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(hi2), 63));
+}
+
+// single minimum, native float DPP (a dependent chain: s_nop covers the wait states; still 6 VALU instructions
+// instead of 13 with the order keys).  Same conditions as dpp_box6.
+__device__ __forceinline__ float dpp_min_f32_native(float v) {
+    asm volatile("s_nop 1\n\t"
+                 "v_min_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_min_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_min_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_min_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_min_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_min_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
+                 : "+v"(v));
+    return u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(v), 63));
+}
+
 // FPS arg-max key: larger squared distance first, then LOWER index (the sequential strict-'>' scan of
 // ops/fps/src/sampling_gpu.cu:67-68 restated as a total order).  value < 0 means "not a candidate".
 __device__ __forceinline__ unsigned long long fps_key(float v, uint32_t idx) {

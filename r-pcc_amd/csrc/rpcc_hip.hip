@@ -1272,12 +1272,10 @@ __global__ __launch_bounds__(256) void assign_kernel(const float *__restrict__ r
                 if (valid[e]) seg[(int64_t)b * P + p[e]] = 1;
             continue;
         }
-        const float lo0 = dpp_min_f32(fminf(live[0] ? x[0] : inf, live[1] ? x[1] : inf));
-        const float lo1 = dpp_min_f32(fminf(live[0] ? y[0] : inf, live[1] ? y[1] : inf));
-        const float lo2 = dpp_min_f32(fminf(live[0] ? z[0] : inf, live[1] ? z[1] : inf));
-        const float hi0 = dpp_max_f32(fmaxf(live[0] ? x[0] : -inf, live[1] ? x[1] : -inf));
-        const float hi1 = dpp_max_f32(fmaxf(live[0] ? y[0] : -inf, live[1] ? y[1] : -inf));
-        const float hi2 = dpp_max_f32(fmaxf(live[0] ? z[0] : -inf, live[1] ? z[1] : -inf));
+        float lo0 = fminf(live[0] ? x[0] : inf, live[1] ? x[1] : inf), hi0 = fmaxf(live[0] ? x[0] : -inf, live[1] ? x[1] : -inf);
+        float lo1 = fminf(live[0] ? y[0] : inf, live[1] ? y[1] : inf), hi1 = fmaxf(live[0] ? y[0] : -inf, live[1] ? y[1] : -inf);
+        float lo2 = fminf(live[0] ? z[0] : inf, live[1] ? z[1] : inf), hi2 = fmaxf(live[0] ? z[0] : -inf, live[1] ? z[1] : -inf);
+        dpp_box6(lo0, lo1, lo2, hi0, hi1, hi2);
         // screen the centres: lane handles centres lane, lane+64, ...
         float my_dmin[4], upper = inf;
 #pragma unroll
@@ -1293,7 +1291,7 @@ __global__ __launch_bounds__(256) void assign_kernel(const float *__restrict__ r
                 upper = fminf(upper, (f0 * f0 + f1 * f1) + f2 * f2);
             }
         }
-        upper = dpp_min_f32(upper);
+        upper = dpp_min_f32_native(upper);
         const float cut = upper * 1.000002f;
         float m1[2] = {inf, inf}, m2[2] = {inf, inf};
         int k1[2] = {-1, -1};
