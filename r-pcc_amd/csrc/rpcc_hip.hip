@@ -1577,13 +1577,21 @@ __global__ __launch_bounds__(256) void predict_quantize_kernel(const float *__re
     const int SEGP = KP + 1;
     const int b = blockIdx.y, t = blockIdx.x, K = M + 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // per-frame bases (wave-uniform): scalar base + 32-bit lane offset instead of 64-bit address arithmetic per access
+    seg += (int64_t)b * P;
+    if (!RESIDUAL_ONLY) ri += (int64_t)b * P;
+    if (residual_in) residual_in += (int64_t)b * P;
+    if (pred_out) pred_out += (int64_t)b * P;
+    if (q16) q16 += (int64_t)b * P;
+    if (q32) q32 += (int64_t)b * P;
+    if (label_acc) label_acc += (int64_t)b * K;
     // all global loads first, unconditional on clamped indices (a guarded load is waited for on the spot)
     int lab[4];
     float rv[4], t0[4], t1[4], t2[4], rin[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int p = min(t * TILE + j * 256 + (int)threadIdx.x, P - 1);
-        const int64_t gp = (int64_t)b * P + p;
+        const int gp = p;
         lab[j] = seg[gp];
         if (RESIDUAL_ONLY) {
             rv[j] = t0[j] = t1[j] = t2[j] = 0.0f;
@@ -1606,14 +1614,14 @@ __global__ __launch_bounds__(256) void predict_quantize_kernel(const float *__re
         rank[j] = 0;
         lab[j] = -1;
         if (p < P) {
-            const int64_t gp = (int64_t)b * P + p;
+            const int gp = p;
             const float p0 = smodel[4 * l], p1 = smodel[4 * l + 1], p2 = smodel[4 * l + 2], p3 = smodel[4 * l + 3];
             float pr;
             if (p0 + p1 + p2 == 0.0f) pr = p3;                                        // cpp_modules.cpp:271-272
             else pr = -p3 / (p0 * t0[j] + p1 * t1[j] + p2 * t2[j]);                    // :275-277
             if (!RESIDUAL_ONLY && pred_out) pred_out[gp] = pr;
             const float res = (RESIDUAL_ONLY || residual_in) ? rin[j] : rv[j] - pr;                      // compress.py:106
-            const float step = label_acc ? label_acc[(int64_t)b * K + l] : acc;       // cpp_modules.cpp:404,419
+            const float step = label_acc ? label_acc[l] : acc;       // cpp_modules.cpp:404,419
             qv[j] = (int)roundf(res / step);                                          // cpp_modules.cpp:315
             lab[j] = (l == 1) ? -1 : l;                                               // label 1 is skipped (:314)
         }
@@ -1638,7 +1646,7 @@ __global__ __launch_bounds__(256) void predict_quantize_kernel(const float *__re
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         if (lab[j] >= 0) {
-            const int64_t o = (int64_t)b * P + segcnt[(j * 4 + wave) * SEGP + lab[j]] + rank[j];
+            const uint32_t o = segcnt[(j * 4 + wave) * SEGP + lab[j]] + rank[j];
             if (q16) q16[o] = (int16_t)qv[j];  // astype(np.int16): two's-complement truncation
             if (q32) q32[o] = qv[j];
         }
