@@ -835,6 +835,7 @@ __global__ __launch_bounds__(RS_THREADS) void ground_ransac_kernel(const float *
     for (int w = 0; w < RS_THREADS / 64; w++) { if (w < wave) base += swave[w]; nc += swave[w]; }
     RsPoints pts;
     pts.ri = ri; pts.tm = tm; pts.lds = nullptr; pts.n = P; pts.raw = raw;
+    const bool small_prod = (unsigned long long)nc * (unsigned long long)max_pts < (1ull << 32);
     if (nc >= min_pts) {
         int run = base;
         for (int p00 = w0; p00 < w1; p00 += 64 * RS_CU) {  // all loads of RS_CU steps are issued before any is used
@@ -856,8 +857,15 @@ __global__ __launch_bounds__(RS_THREADS) void ground_ransac_kernel(const float *
                     bool keep = true;
                     long long slot = i;
                     if (nc > max_pts) {
-                        slot = (i * max_pts) / nc;
-                        keep = ((i + 1) * max_pts) / nc > slot;
+                        if (small_prod) {  // i * max_pts < nc * max_pts < 2^32: 32-bit divisions (a 64-bit one costs ~10x)
+                            const uint32_t a = (uint32_t)i * (uint32_t)max_pts;
+                            const uint32_t sl = a / (uint32_t)nc;
+                            slot = sl;
+                            keep = (a + (uint32_t)max_pts) / (uint32_t)nc > sl;
+                        } else {
+                            slot = (i * max_pts) / nc;
+                            keep = ((i + 1) * max_pts) / nc > slot;
+                        }
                     }
                     if (keep) { list[3 * slot] = xv[u]; list[3 * slot + 1] = yv[u]; list[3 * slot + 2] = zv[u]; }
                 }
