@@ -631,6 +631,7 @@ struct RsPoints {
     }
 };
 
+typedef float rs_v2f __attribute__((ext_vector_type(2)));
 // inlier test of the specification: fp32, un-fused, plane narrowed to fp32
 __device__ __forceinline__ bool plane_inlier(const float pl[4], float x, float y, float z, float thr) {
     return fabsf(((pl[0] * x + pl[1] * y) + pl[2] * z) + pl[3]) < thr;
@@ -707,6 +708,7 @@ __device__ int ransac_plane_wg(const PTS &pts, int iters, double thr, uint32_t s
         hypd[4 * h] = pl[0]; hypd[4 * h + 1] = pl[1]; hypd[4 * h + 2] = pl[2]; hypd[4 * h + 3] = pl[3];
     }
     __syncthreads();
+    DBG_STAMP(7);
     // (2) scoring: wavefront w counts the inliers of hypotheses w, w+16, ... -- all of them in one pass
     // over the points (a point is read from LDS once and tested against up to RS_HPW planes)
     constexpr int RS_HPW = (MAXH + NTH / 64 - 1) / (NTH / 64);
@@ -728,8 +730,18 @@ __device__ int ransac_plane_wg(const PTS &pts, int iters, double thr, uint32_t s
 #pragma unroll
         for (int u = 0; u < RS_PU; u++) {
             const bool in = i0 + 64 * u < n;
+            // two hypotheses per packed-fp32 instruction (v_pk_mul_f32 / v_pk_add_f32: each half rounds like the scalar
+            // operation, so this is plane_inlier() twice)
+            const rs_v2f xx = {x[u], x[u]}, yy = {y[u], y[u]}, zz = {z[u], z[u]};
 #pragma unroll
-            for (int q = 0; q < RS_HPW; q++) cnt[q] += in && plane_inlier(pf[q], x[u], y[u], z[u], thr_f);
+            for (int q = 0; q + 1 < RS_HPW; q += 2) {
+                const rs_v2f a = {pf[q][0], pf[q + 1][0]}, b2 = {pf[q][1], pf[q + 1][1]}, c2 = {pf[q][2], pf[q + 1][2]},
+                             d2 = {pf[q][3], pf[q + 1][3]};
+                const rs_v2f dd = ((a * xx + b2 * yy) + c2 * zz) + d2;
+                cnt[q] += in && fabsf(dd.x) < thr_f;
+                cnt[q + 1] += in && fabsf(dd.y) < thr_f;
+            }
+            if (RS_HPW & 1) cnt[RS_HPW - 1] += in && plane_inlier(pf[RS_HPW - 1], x[u], y[u], z[u], thr_f);
         }
     }
     int best_cnt = -1, best_h = 0x7fffffff;
