@@ -1315,6 +1315,7 @@ __global__ __launch_bounds__(256) void assign_kernel(const float *__restrict__ r
         const float cut = upper * 1.000002f;
         float m1[2] = {inf, inf}, m2[2] = {inf, inf};
         int k1[2] = {-1, -1};
+        const rs_v2f xv = {x[0], x[1]}, yv = {y[0], y[1]}, zv = {z[0], z[1]};
 #pragma unroll
         for (int rd = 0; rd < 4; rd++) {
             if (rd * 64 >= M) break;
@@ -1323,10 +1324,12 @@ __global__ __launch_bounds__(256) void assign_kernel(const float *__restrict__ r
                 const int k = rd * 64 + (int)__ffsll((long long)surv) - 1;
                 surv &= surv - 1ull;
                 const float4 cc = cen4[k];
+                // both pixels of the lane in packed fp32 (v_pk_add / v_pk_mul: each half rounds like the scalar operation)
+                const rs_v2f dx = xv - rs_v2f{cc.x, cc.x}, dy = yv - rs_v2f{cc.y, cc.y}, dz = zv - rs_v2f{cc.z, cc.z};
+                const rs_v2f dd = (dx * dx + dy * dy) + dz * dz;
 #pragma unroll
                 for (int e = 0; e < 2; e++) {
-                    const float dx = x[e] - cc.x, dy = y[e] - cc.y, dz = z[e] - cc.z;
-                    const float d2 = (dx * dx + dy * dy) + dz * dz;
+                    const float d2 = e ? dd.y : dd.x;
                     const bool lt = d2 < m1[e];
                     m2[e] = lt ? m1[e] : fminf(m2[e], d2);
                     k1[e] = lt ? k : k1[e];
