@@ -305,42 +305,55 @@ __device__ __forceinline__ void project_exact_record(const float *__restrict__ x
     pd[il] = o;
 }
 
+#define PIX_PPT 4  // points per thread and iteration: loads in flight, and one pair of barriers per PIX_PPT * 256 points
 __global__ __launch_bounds__(PIX_THREADS) void project_pix_kernel(const float *__restrict__ xyz, const int64_t *__restrict__ offs,
                                                                   int64_t total, int64_t base, int B, rpcc_geom g, PixFastCfg cfg,
                                                                   uint2 *__restrict__ pd, int32_t *__restrict__ flags) {
-    __shared__ int64_t queue[2 * PIX_THREADS];
+    __shared__ int64_t queue[(PIX_PPT + 1) * PIX_THREADS];
     __shared__ uint32_t qn;
     if (threadIdx.x == 0) qn = 0u;
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    const int64_t nchunks = (total + PIX_THREADS - 1) / PIX_THREADS;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const int64_t nchunks = (total + PIX_PPT * PIX_THREADS - 1) / (PIX_PPT * PIX_THREADS);
     for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
-        const int64_t il = c * PIX_THREADS + threadIdx.x;  // record index; point index = base + il
-        bool slow = false;
-        if (il < total) {
-            const int64_t i = base + il;
-            const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
-            int pix;
-            if (cfg.on && project_point_fast(x, y, z, g, cfg, pix))
-                pd[il] = make_uint2((uint32_t)pix, f2u(sqrtf(x * x + y * y + z * z)));  // depth: :446 (finite, > 0 here)
-            else
-                slow = true;
+        float x[PIX_PPT], y[PIX_PPT], z[PIX_PPT];
+#pragma unroll
+        for (int u = 0; u < PIX_PPT; u++) {  // unconditional (clamped) loads, all in flight
+            const int64_t il = (c * PIX_PPT + u) * PIX_THREADS + threadIdx.x;  // record index; point index = base + il
+            const int64_t i = base + (il < total ? il : total - 1);
+            x[u] = xyz[3 * i]; y[u] = xyz[3 * i + 1]; z[u] = xyz[3 * i + 2];
         }
-        const unsigned long long sm = __ballot(slow);
-        if (sm) {
-            const int leader = (int)__ffsll((long long)sm) - 1;
-            uint32_t q0 = 0u;
-            if (lane == leader) q0 = atomicAdd(&qn, (uint32_t)__popcll(sm));
-            q0 = (uint32_t)__builtin_amdgcn_readlane((int)q0, leader);
-            if (slow) queue[q0 + __popcll(sm & ((1ull << lane) - 1ull))] = il;
+#pragma unroll
+        for (int u = 0; u < PIX_PPT; u++) {
+            const int64_t il = (c * PIX_PPT + u) * PIX_THREADS + threadIdx.x;
+            bool slow = false;
+            if (il < total) {
+                int pix;
+                if (cfg.on && project_point_fast(x[u], y[u], z[u], g, cfg, pix))
+                    pd[il] = make_uint2((uint32_t)pix, f2u(sqrtf(x[u] * x[u] + y[u] * y[u] + z[u] * z[u])));  // depth: :446
+                else
+                    slow = true;
+            }
+            const unsigned long long sm = __ballot(slow);
+            if (sm) {
+                const int leader = (int)__ffsll((long long)sm) - 1;
+                uint32_t q0 = 0u;
+                if (lane == leader) q0 = atomicAdd(&qn, (uint32_t)__popcll(sm));
+                q0 = (uint32_t)__builtin_amdgcn_readlane((int)q0, leader);
+                if (slow) queue[q0 + __popcll(sm & lt)] = il;
+            }
         }
         __syncthreads();
-        const uint32_t n = qn;
+        uint32_t n = qn;
         __syncthreads();
-        if (n >= PIX_THREADS) {  // a full workgroup of uncertain points: the exact sequence
-            project_exact_record(xyz, offs, base, B, g, queue[n - PIX_THREADS + threadIdx.x], pd, flags);
+        if (n >= PIX_THREADS) {  // full workgroups of uncertain points: the exact sequence
+            while (n >= PIX_THREADS) {
+                project_exact_record(xyz, offs, base, B, g, queue[n - PIX_THREADS + threadIdx.x], pd, flags);
+                n -= PIX_THREADS;
+            }
             __syncthreads();
-            if (threadIdx.x == 0) qn = n - PIX_THREADS;
+            if (threadIdx.x == 0) qn = n;
             __syncthreads();
         }
     }
@@ -533,7 +546,7 @@ static int launch_project(const float *xyz, const int64_t *offsets, int64_t tota
         uint2 *pd = reinterpret_cast<uint2 *>(reinterpret_cast<char *>(scratch) + ((size_t)B * ((size_t)P + 8)) * 4 + 256);
         HIP_TRY(hipMemsetAsync(flags, 0, (size_t)(B + 1) * 4, st));
         if (total > 0)
-            project_pix_kernel<<<(unsigned)std::min<int64_t>((total + PIX_THREADS - 1) / PIX_THREADS, 256 * 16), PIX_THREADS, 0, st>>>(
+            project_pix_kernel<<<(unsigned)std::min<int64_t>((total + PIX_PPT * PIX_THREADS - 1) / (PIX_PPT * PIX_THREADS), 256 * 16), PIX_THREADS, 0, st>>>(
                 xyz, offsets, total, base, B, g, pix_fast_cfg(g), pd, flags);
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&project_band_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, BAND_PX * 4));
