@@ -305,7 +305,7 @@ __device__ __forceinline__ void project_exact_record(const float *__restrict__ x
     pd[il] = o;
 }
 
-#define PIX_PPT 4  // points per thread and iteration: loads in flight, and one pair of barriers per PIX_PPT * 256 points
+#define PIX_PPT 8  // points per thread and iteration: loads in flight, and one pair of barriers per PIX_PPT * 256 points
 __global__ __launch_bounds__(PIX_THREADS) void project_pix_kernel(const float *__restrict__ xyz, const int64_t *__restrict__ offs,
                                                                   int64_t total, int64_t base, int B, rpcc_geom g, PixFastCfg cfg,
                                                                   uint2 *__restrict__ pd, int32_t *__restrict__ flags) {
@@ -1430,15 +1430,22 @@ __global__ __launch_bounds__(256) void model_hist_kernel(const float *__restrict
     for (int k = threadIdx.x; k < KP; k += blockDim.x) { ssum[k] = 0ull; scnt[k] = 0u; }
     __syncthreads();
     bool inexact = false;
+    int lab_in[TILE / 256];
+    float r_in[TILE / 256];
+#pragma unroll
+    for (int j = 0; j < TILE / 256; j++) {  // all loads of the tile first (unconditional, clamped): one latency, not four
+        const int64_t gp = (int64_t)b * P + min(t * TILE + j * 256 + (int)threadIdx.x, P - 1);
+        lab_in[j] = seg[gp];
+        r_in[j] = ri != nullptr ? ri[gp] : 1.0f;
+    }
 #pragma unroll
     for (int j = 0; j < TILE / 256; j++) {
         const int p = t * TILE + j * 256 + threadIdx.x;
         int todo = -1;
         unsigned long long v = 0ull;
         {
-            const int64_t gp = (int64_t)b * P + min(p, P - 1);   // unconditional (clamped) loads
-            const int l = seg[gp];
-            const float r = ri != nullptr ? ri[gp] : 1.0f;
+            const int l = lab_in[j];
+            const float r = r_in[j];
             if (p < P) {
                 todo = l;
                 if (todo >= 2 && ri != nullptr) {
