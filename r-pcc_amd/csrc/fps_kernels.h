@@ -349,15 +349,19 @@ __global__ __launch_bounds__(256) void ground_mask_tab_kernel(float *__restrict_
     const double thr_div = thr * div;
     const bool screen = thr >= 1e-200 && thr_div >= 1e-200 && thr_div <= 1e200;
     const double t_hi = thr_div * (1.0 + 1e-15), t_lo = thr_div * (1.0 - 1e-15);
-    auto load_px = [&](int p, float &r, float &x, float &y, float &z) -> bool {  // returns "is a candidate"
-        r = ri[(int64_t)b * P + p];
+    // classify one pixel from its loaded range and ray: back-projection, "is a candidate"
+    auto classify = [&](float &r, float tx, float ty, float tz, float &x, float &y, float &z) -> bool {
         if (RAW && f2u(r) == RI_EMPTY) r = 0.0f;
-        x = r * tm[3 * p]; y = r * tm[3 * p + 1]; z = r * tm[3 * p + 2];
+        x = r * tx; y = r * ty; z = r * tz;
         const double s = ((double)x * a + (double)y * bb) + (double)z * c;
         const double num = fabs(s + d);
         if (screen && num > t_hi) return true;
         if (screen && num < t_lo) return false;
         return num / div > thr;
+    };
+    auto load_px = [&](int p, float &r, float &x, float &y, float &z) -> bool {
+        r = ri[(int64_t)b * P + p];
+        return classify(r, tm[3 * p], tm[3 * p + 1], tm[3 * p + 2], x, y, z);
     };
     bool fast;
     float c0, c1, c2;
@@ -375,17 +379,31 @@ __global__ __launch_bounds__(256) void ground_mask_tab_kernel(float *__restrict_
     float *tab = tiletab + (int64_t)b * FPS_TAB_ROWS * T;
     int cnt = 0, nzc = 0, first = P;
     const int t0 = (blockIdx.x * 4 + wave) * TAB_TPW;
-    for (int t = t0; t < min(t0 + TAB_TPW, T); t++) {
+    // the loads of all TAB_TPW tiles of this wavefront first (unconditional, clamped): one memory latency, not TAB_TPW
+    float pr[TAB_TPW][2], ptx[TAB_TPW][2], pty[TAB_TPW][2], ptz[TAB_TPW][2];
+    int ppix[TAB_TPW][2];
+#pragma unroll
+    for (int q = 0; q < TAB_TPW; q++)
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            ppix[q][h] = fps_tile_point<true>(g, min(t0 + q, T - 1), h, lane);
+            const int pc = ppix[q][h] >= 0 ? ppix[q][h] : 0;
+            pr[q][h] = ri[(int64_t)b * P + pc];
+            ptx[q][h] = tm[3 * pc]; pty[q][h] = tm[3 * pc + 1]; ptz[q][h] = tm[3 * pc + 2];
+        }
+#pragma unroll
+    for (int q = 0; q < TAB_TPW; q++) {
+        const int t = t0 + q;
+        if (t >= T) break;
         float x[2], y[2], z[2], nt[2];
         bool valid[2], cand[2];
         int pidx[2];
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-            pidx[h] = fps_tile_point<true>(g, t, h, lane);
+            pidx[h] = ppix[q][h];
             valid[h] = pidx[h] >= 0;
-            const int pc = valid[h] ? pidx[h] : 0;
-            float r;
-            cand[h] = load_px(pc, r, x[h], y[h], z[h]) && valid[h];
+            float r = pr[q][h];
+            cand[h] = classify(r, ptx[q][h], pty[q][h], ptz[q][h], x[h], y[h], z[h]) && valid[h];
             const bool nz = valid[h] && r != 0.0f;
             nt[h] = cand[h] ? 1e10f : -1.0f;
             if (fast) {
