@@ -1490,15 +1490,17 @@ __global__ __launch_bounds__(256) void model_scan_kernel(const float *__restrict
                                                          const int32_t *__restrict__ flags, uint32_t *__restrict__ hist,
                                                          float *__restrict__ model, int32_t *__restrict__ counts,
                                                          int32_t *__restrict__ nnz) {
-    extern __shared__ uint32_t sh[];  // [T*KP] when it fits in LDS (use_lds), else unused
+    extern __shared__ __attribute__((aligned(16))) uint32_t sh[];  // [T*KP] when it fits in LDS (use_lds), else unused
     __shared__ uint32_t tot[256];
     __shared__ uint32_t base[256];
     const int b = blockIdx.x, k = threadIdx.x, K = M + 2;
     uint32_t *gh = hist + (int64_t)b * T * KP;
     const bool use_lds = (size_t)T * KP * 4 <= 96 * 1024;
     uint32_t *h = use_lds ? sh : gh;
-    if (use_lds) {  // coalesced copy in; the per-label walks below then run at LDS latency
-        for (int i = threadIdx.x; i < T * KP; i += blockDim.x) sh[i] = gh[i];
+    if (use_lds) {  // coalesced 16-byte copy in (KP is a multiple of 64); the per-label walks below then run at LDS latency
+        const uint4 *g4 = reinterpret_cast<const uint4 *>(gh);
+        uint4 *s4 = reinterpret_cast<uint4 *>(sh);
+        for (int i = threadIdx.x; i < T * KP / 4; i += blockDim.x) s4[i] = g4[i];
         __syncthreads();
     }
     uint32_t total = 0;
@@ -1524,7 +1526,9 @@ __global__ __launch_bounds__(256) void model_scan_kernel(const float *__restrict
     }
     if (use_lds) {
         __syncthreads();
-        for (int i = threadIdx.x; i < T * KP; i += blockDim.x) gh[i] = sh[i];
+        uint4 *g4 = reinterpret_cast<uint4 *>(gh);
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(sh);
+        for (int i = threadIdx.x; i < T * KP / 4; i += blockDim.x) g4[i] = s4[i];
     }
     if (k < K && model != nullptr) {
         float *row = model + ((int64_t)b * K + k) * 4;
