@@ -259,7 +259,13 @@ __global__ __launch_bounds__(FPS_TT) void fps_tiled_kernel(const float *__restri
     if (M > 1 && have_tab) {
         const float *tab = tiletab + (int64_t)b * FPS_TAB_ROWS * T;
         float *dst = reinterpret_cast<float *>(fps_smem);
-        for (int i = tid; i < FPS_TAB_ROWS * T; i += FPS_TT) dst[i] = tab[i];
+        if ((T & 3) == 0) {  // 16-byte copies (the table of a frame starts at a multiple of 16 bytes then)
+            const float4 *t4 = reinterpret_cast<const float4 *>(tab);
+            float4 *d4 = reinterpret_cast<float4 *>(dst);
+            for (int i = tid; i < FPS_TAB_ROWS * T / 4; i += FPS_TT) d4[i] = t4[i];
+        } else {
+            for (int i = tid; i < FPS_TAB_ROWS * T; i += FPS_TT) dst[i] = tab[i];
+        }
         __syncthreads();
     } else if (M > 1) {
         for (int t = wave; t < T; t += NW * GROUP) {
