@@ -533,7 +533,7 @@ extern "C" int rpcc_project_fastpath_check(const float *xyz, int64_t total, rpcc
 // atomic path, which only needs B*(P+8)*4 bytes.
 static int launch_project(const float *xyz, const int64_t *offsets, int64_t total, int64_t base, int B, rpcc_geom g,
                           float *ri, void *scratch, size_t scratch_bytes, hipStream_t st, const float *tz_plane = nullptr,
-                          int32_t *zcnt = nullptr) {
+                          int32_t *zcnt = nullptr, bool cleared = false) {
     const int P = g.H * g.W;
     uint32_t *rb = reinterpret_cast<uint32_t *>(ri);
     int32_t *lastz = reinterpret_cast<int32_t *>(scratch);
@@ -544,13 +544,13 @@ static int launch_project(const float *xyz, const int64_t *offsets, int64_t tota
     const bool fast = scratch_bytes >= project_scratch_bytes(total, B, P);
     if (fast) {
         uint2 *pd = reinterpret_cast<uint2 *>(reinterpret_cast<char *>(scratch) + ((size_t)B * ((size_t)P + 8)) * 4 + 256);
-        HIP_TRY(hipMemsetAsync(flags, 0, (size_t)(B + 1) * 4, st));
+        if (!cleared) HIP_TRY(hipMemsetAsync(flags, 0, (size_t)(B + 1) * 4, st));
         if (total > 0)
             project_pix_kernel<<<(unsigned)std::min<int64_t>((total + PIX_PPT * PIX_THREADS - 1) / (PIX_PPT * PIX_THREADS), 256 * 16), PIX_THREADS, 0, st>>>(
                 xyz, offsets, total, base, B, g, pix_fast_cfg(g), pd, flags);
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&project_band_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, BAND_PX * 4));
-        if (zcnt) HIP_TRY(hipMemsetAsync(zcnt, 0, (size_t)B * (RS_CHUNKS + 1) * 4, st));
+        if (zcnt && !cleared) HIP_TRY(hipMemsetAsync(zcnt, 0, (size_t)B * (RS_CHUNKS + 1) * 4, st));
         project_band_kernel<<<8 * ((B + 7) / 8) * ((P + BAND_PX - 1) / BAND_PX), BAND_THREADS, BAND_PX * 4, st>>>(
             pd, offsets, base, B, P, rb, flags, tz_plane, -1.5f, rs_chunk_px(P), tz_plane ? zcnt : nullptr);
         LAUNCH_CHECK();
@@ -560,7 +560,7 @@ static int launch_project(const float *xyz, const int64_t *offsets, int64_t tota
         }
         return RPCC_OK;
     }
-    if (zcnt) HIP_TRY(hipMemsetAsync(zcnt, 0, (size_t)B * (RS_CHUNKS + 1) * 4, st));
+    if (zcnt && !cleared) HIP_TRY(hipMemsetAsync(zcnt, 0, (size_t)B * (RS_CHUNKS + 1) * 4, st));
     project_fill_kernel<false><<<fg, 256, 0, st>>>(rb, lastz, flags, P);
     LAUNCH_CHECK();
     if (total > 0) {
@@ -1129,12 +1129,20 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_range_kernel(const float *__r
 }
 
 // AoS transform_map [P,3] -> three planes (frame-invariant; 12 B/pixel once per call)
-// info (optional): also initialises the per-frame counters that the ground-mask kernel accumulates (one launch less)
+// The fused entry uses it as the first kernel of a batch and lets it also do the batch's small initialisations (instead
+// of four more launches): info = the per-frame counters of the ground mask; z0 / z1 / z2 = dword ranges to clear
+// (projection flags, RANSAC candidate counts, label sums of the point model).
+struct ZeroRange { uint32_t *p; int n; };
 __global__ __launch_bounds__(256) void rays_soa_kernel(const float *__restrict__ tm, int P, float *__restrict__ soa,
-                                                       int32_t *__restrict__ info = nullptr, int B = 0) {
+                                                       int32_t *__restrict__ info = nullptr, int B = 0,
+                                                       ZeroRange z0 = {nullptr, 0}, ZeroRange z1 = {nullptr, 0},
+                                                       ZeroRange z2 = {nullptr, 0}) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p < P) { soa[p] = tm[3 * p]; soa[P + p] = tm[3 * p + 1]; soa[2 * (int64_t)P + p] = tm[3 * p + 2]; }
     if (info != nullptr && p < B) { info[4 * p] = 0; info[4 * p + 1] = P; info[4 * p + 2] = 0; info[4 * p + 3] = 0; }
+    if (p < z0.n) z0.p[p] = 0u;
+    if (p < z1.n) z1.p[p] = 0u;
+    if (p < z2.n) z2.p[p] = 0u;
 }
 
 static bool g_fps_force_v1 = false;
@@ -1563,10 +1571,10 @@ static size_t scan_lds_bytes(int P, int M) {
 }
 
 static int launch_point_model(const float *ri, const uint8_t *seg, const double *ground, int B, int P, int M,
-                              float *model, int32_t *counts, int32_t *nnz, void *ws, hipStream_t st) {
+                              float *model, int32_t *counts, int32_t *nnz, void *ws, hipStream_t st, bool cleared = false) {
     const int KP = kpad(M), T = ntiles(P);
     WsLayout L = ws_layout(ws, B, P, M);
-    HIP_TRY(hipMemsetAsync(L.sums, 0, (size_t)((char *)L.hist - (char *)L.sums), st));
+    if (!cleared) HIP_TRY(hipMemsetAsync(L.sums, 0, (size_t)((char *)L.hist - (char *)L.sums), st));
     model_hist_kernel<<<dim3(T, B), 256, (size_t)KP * 12, st>>>(ri, seg, P, KP, T, L.sums, L.flags, L.hist);
     LAUNCH_CHECK();
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&model_scan_kernel),
@@ -1924,11 +1932,16 @@ static int run_slice(const rpcc_batch_io *io, int b0, int Bs, int64_t pt0, int64
     float *model = io->model + (size_t)b0 * K * 4;
     int rc;
     int32_t *zcnt = fit_ground ? reinterpret_cast<int32_t *>(tiletab) : nullptr;  // the tile table is written later
-    // planar ray table (band kernel's z, FPS) + the info counters of the ground mask
-    rays_soa_kernel<<<(std::max(P, Bs) + 255) / 256, 256, 0, st>>>(io->tm, P, rays_soa, info, Bs);
+    // first kernel of the batch: planar ray table (band kernel's z, FPS), the info counters of the ground mask, and the
+    // cleared projection flags / RANSAC candidate counts / label sums
+    const ZeroRange zflags = {reinterpret_cast<uint32_t *>(proj_scratch) + (size_t)Bs * P, Bs + 1};
+    const ZeroRange zzcnt = {reinterpret_cast<uint32_t *>(zcnt), zcnt ? Bs * (RS_CHUNKS + 1) : 0};
+    const ZeroRange zsums = {reinterpret_cast<uint32_t *>(L.sums), (int)(((char *)L.hist - (char *)L.sums) / 4)};
+    const int init_n = std::max(std::max(P, Bs * (RS_CHUNKS + 1)), zsums.n);
+    rays_soa_kernel<<<(init_n + 255) / 256, 256, 0, st>>>(io->tm, P, rays_soa, info, Bs, zflags, zzcnt, zsums);
     LAUNCH_CHECK();
     if ((rc = launch_project(io->xyz, io->offsets + b0, npts, pt0, Bs, g, ri, proj_scratch, proj_bytes, st,
-                             rays_soa + 2 * (int64_t)P, zcnt)))
+                             rays_soa + 2 * (int64_t)P, zcnt, true)))
         return rc;
     if (fit_ground &&
         (rc = launch_ground_ransac(ri, io->tm, Bs, P, (uint32_t)(io->ground_seed + b0), false, ground, nullptr, st, zcnt)))
@@ -1942,7 +1955,7 @@ static int run_slice(const rpcc_batch_io *io, int b0, int Bs, int64_t pt0, int64
                                tiled ? tiletab : nullptr, st, true)))
         return rc;
     if ((rc = launch_assign(ri, io->tm, ground, centers, Bs, g.H, g.W, M, seg, st))) return rc;
-    if ((rc = launch_point_model(ri, seg, ground, Bs, P, M, model, io->counts + (size_t)b0 * K, io->nnz + b0, ws, st)))
+    if ((rc = launch_point_model(ri, seg, ground, Bs, P, M, model, io->counts + (size_t)b0 * K, io->nnz + b0, ws, st, true)))
         return rc;
     return launch_predict_quantize(ri, io->tm, seg, model, acc, nullptr, nullptr, Bs, P, M, io->q16 + (size_t)b0 * P,
                                    nullptr, nullptr, ws, st);
