@@ -116,8 +116,9 @@ __device__ __forceinline__ void fps_load_point(const float *__restrict__ src, co
                                                const float *__restrict__ ty, const float *__restrict__ tz, int k,
                                                float &x, float &y, float &z) {
     if (RANGE) {
-        const float r = src[k];
-        x = r * tx[k]; y = r * ty[k]; z = r * tz[k];
+        const uint32_t o = (uint32_t)k * 4u;  // byte offset from the wave-uniform bases (P * 4 < 2^32)
+        const float r = ld_f32(src, o);
+        x = r * ld_f32(tx, o); y = r * ld_f32(ty, o); z = r * ld_f32(tz, o);
     } else {
         x = src[3 * (int64_t)k]; y = src[3 * (int64_t)k + 1]; z = src[3 * (int64_t)k + 2];
     }
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(FPS_TT) void fps_tiled_kernel(const float *__restri
             }
             const int pc = q.p[h] < 0 ? 0 : q.p[h];
             fps_load_point<RANGE>(src, tx, ty, tz, pc, q.x[h], q.y[h], q.z[h]);
-            q.tp[h] = temp[pc];
+            q.tp[h] = ld_f32(temp, (uint32_t)pc * 4u);
             if (q.p[h] < 0) { q.x[h] = 0.f; q.y[h] = 0.f; q.z[h] = 0.f; q.tp[h] = -1.0f; }
         }
     };
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(FPS_TT) void fps_tiled_kernel(const float *__restri
             const float dx = q.x[h] - c0, dy = q.y[h] - c1, dz = q.z[h] - c2;
             const float d = (dx * dx + dy * dy) + dz * dz;  // sampling_gpu.cu:64, un-fused
             nt[h] = d < q.tp[h] ? d : q.tp[h];  // == fminf(d, tp): a NaN distance keeps tp, tp itself is never NaN
-            if (valid[h] && nt[h] != q.tp[h]) temp[q.p[h]] = nt[h];
+            if (valid[h] && nt[h] != q.tp[h]) st_f32(temp, (uint32_t)q.p[h] * 4u, nt[h]);
         }
         // nothing changed in this tile: its table entry (maximum, arg, coordinates) is still exact
         if (!with_box && __ballot((valid[0] && nt[0] != q.tp[0]) || (valid[1] && nt[1] != q.tp[1])) == 0ull) return;

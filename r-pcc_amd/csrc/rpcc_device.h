@@ -101,6 +101,18 @@ __device__ __forceinline__ float atan2f_fdlibm(float y, float x) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Loads / stores at "wave-uniform base + 32-bit byte offset".  Written with an explicit unsigned byte offset so that the
+// compiler can use the scalar-base addressing mode (global_load v, v_offset, s[base]) instead of building a 64-bit
+// address in VGPRs for every access (index * 4 as a 64-bit shift-add): the caller guarantees offset < 2^32.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float ld_f32(const float *base, uint32_t byte_off) {
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+__device__ __forceinline__ void st_f32(float *base, uint32_t byte_off, float v) {
+    *reinterpret_cast<float *>(reinterpret_cast<char *>(base) + byte_off) = v;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Wavefront (64 lanes) reductions.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
