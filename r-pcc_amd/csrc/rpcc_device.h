@@ -111,6 +111,15 @@ __device__ __forceinline__ float ld_f32(const float *base, uint32_t byte_off) {
 __device__ __forceinline__ void st_f32(float *base, uint32_t byte_off, float v) {
     *reinterpret_cast<float *>(reinterpret_cast<char *>(base) + byte_off) = v;
 }
+struct f32x3 { float x, y, z; };  // one ray of the transform map: a single 12-byte load
+template <class T>
+__device__ __forceinline__ T ld_at(const T *base, uint32_t byte_off) {
+    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+template <class T>
+__device__ __forceinline__ void st_at(T *base, uint32_t byte_off, T v) {
+    *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + byte_off) = v;
+}
 
 // ---------------------------------------------------------------------------------------------
 // Wavefront (64 lanes) reductions.

@@ -1646,15 +1646,16 @@ __global__ __launch_bounds__(256) void predict_quantize_kernel(const float *__re
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int p = min(t * TILE + j * 256 + (int)threadIdx.x, P - 1);
-        const int gp = p;
-        lab[j] = seg[gp];
+        const uint32_t up = (uint32_t)p;  // byte offsets from wave-uniform bases (scalar-base addressing, P * 12 < 2^32)
+        lab[j] = ld_at(seg, up);
         if (RESIDUAL_ONLY) {
             rv[j] = t0[j] = t1[j] = t2[j] = 0.0f;
-            rin[j] = residual_in[gp];
+            rin[j] = ld_at(residual_in, up * 4u);
         } else {
-            rv[j] = ri[gp];
-            t0[j] = tm[3 * p]; t1[j] = tm[3 * p + 1]; t2[j] = tm[3 * p + 2];
-            rin[j] = residual_in ? residual_in[gp] : 0.0f;
+            rv[j] = ld_at(ri, up * 4u);
+            const f32x3 ray = ld_at(reinterpret_cast<const f32x3 *>(tm), up * 12u);
+            t0[j] = ray.x; t1[j] = ray.y; t2[j] = ray.z;
+            rin[j] = residual_in ? ld_at(residual_in, up * 4u) : 0.0f;
         }
     }
     for (int i = threadIdx.x; i < 4 * K; i += 256) smodel[i] = RESIDUAL_ONLY ? 0.0f : model[(int64_t)b * K * 4 + i];
@@ -1674,7 +1675,7 @@ __global__ __launch_bounds__(256) void predict_quantize_kernel(const float *__re
             float pr;
             if (p0 + p1 + p2 == 0.0f) pr = p3;                                        // cpp_modules.cpp:271-272
             else pr = -p3 / (p0 * t0[j] + p1 * t1[j] + p2 * t2[j]);                    // :275-277
-            if (!RESIDUAL_ONLY && pred_out) pred_out[gp] = pr;
+            if (!RESIDUAL_ONLY && pred_out) st_at(pred_out, (uint32_t)gp * 4u, pr);
             const float res = (RESIDUAL_ONLY || residual_in) ? rin[j] : rv[j] - pr;                      // compress.py:106
             const float step = label_acc ? label_acc[l] : acc;       // cpp_modules.cpp:404,419
             qv[j] = (int)roundf(res / step);                                          // cpp_modules.cpp:315
@@ -1702,8 +1703,8 @@ __global__ __launch_bounds__(256) void predict_quantize_kernel(const float *__re
     for (int j = 0; j < 4; j++) {
         if (lab[j] >= 0) {
             const uint32_t o = segcnt[(j * 4 + wave) * SEGP + lab[j]] + rank[j];
-            if (q16) q16[o] = (int16_t)qv[j];  // astype(np.int16): two's-complement truncation
-            if (q32) q32[o] = qv[j];
+            if (q16) st_at(q16, o * 2u, (int16_t)qv[j]);  // astype(np.int16): two's-complement truncation
+            if (q32) st_at(q32, o * 4u, (int32_t)qv[j]);
         }
     }
 }
