@@ -384,6 +384,7 @@ __global__ __launch_bounds__(256) void ground_mask_tab_kernel(float *__restrict_
         if (blockIdx.x == 0 && threadIdx.x == 0) info[4 * b + 3] = fast ? 1 : 0;
     }
     float *tab = tiletab + (int64_t)b * FPS_TAB_ROWS * T;
+    float *ri_b = ri + (int64_t)b * P, *temp_b = temp + (int64_t)b * P;
     int cnt = 0, nzc = 0, first = P;
     const int t0 = (blockIdx.x * 4 + wave) * TAB_TPW;
     // the loads of all TAB_TPW tiles of this wavefront first (unconditional, clamped): one memory latency, not TAB_TPW
@@ -394,9 +395,10 @@ __global__ __launch_bounds__(256) void ground_mask_tab_kernel(float *__restrict_
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             ppix[q][h] = fps_tile_point<true>(g, min(t0 + q, T - 1), h, lane);
-            const int pc = ppix[q][h] >= 0 ? ppix[q][h] : 0;
-            pr[q][h] = ri[(int64_t)b * P + pc];
-            ptx[q][h] = tm[3 * pc]; pty[q][h] = tm[3 * pc + 1]; ptz[q][h] = tm[3 * pc + 2];
+            const uint32_t pc = ppix[q][h] >= 0 ? (uint32_t)ppix[q][h] : 0u;  // byte offsets from wave-uniform bases
+            pr[q][h] = ld_at(ri_b, pc * 4u);
+            const f32x3 ray = ld_at(reinterpret_cast<const f32x3 *>(tm), pc * 12u);
+            ptx[q][h] = ray.x; pty[q][h] = ray.y; ptz[q][h] = ray.z;
         }
 #pragma unroll
     for (int q = 0; q < TAB_TPW; q++) {
@@ -419,8 +421,8 @@ __global__ __launch_bounds__(256) void ground_mask_tab_kernel(float *__restrict_
                 nt[h] = cand[h] ? fminf(dist, 1e10f) : -1.0f;
             }
             if (valid[h]) {
-                if (RAW) ri[(int64_t)b * P + pidx[h]] = r;
-                temp[(int64_t)b * P + pidx[h]] = nt[h];
+                if (RAW) st_at(ri_b, (uint32_t)pidx[h] * 4u, r);
+                st_at(temp_b, (uint32_t)pidx[h] * 4u, nt[h]);
             }
             const unsigned long long mc = __ballot(cand[h]), mz = __ballot(nz);
             cnt += __popcll(mc);

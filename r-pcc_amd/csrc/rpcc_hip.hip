@@ -867,10 +867,11 @@ __global__ __launch_bounds__(RS_THREADS) void ground_ransac_kernel(const float *
             float xv[RS_CU], yv[RS_CU], zv[RS_CU];
 #pragma unroll
             for (int u = 0; u < RS_CU; u++) {  // unconditional (clamped) loads: a guarded load would be waited for at once
-                const int p = min(p00 + u * 64 + lane, P - 1);
-                float r = ri[p];
+                const uint32_t p = (uint32_t)min(p00 + u * 64 + lane, P - 1);  // byte offsets from wave-uniform bases
+                float r = ld_at(ri, p * 4u);
                 if (raw && f2u(r) == RI_EMPTY) r = 0.0f;
-                xv[u] = r * tm[3 * p]; yv[u] = r * tm[3 * p + 1]; zv[u] = r * tm[3 * p + 2];
+                const f32x3 ray = ld_at(reinterpret_cast<const f32x3 *>(tm), p * 12u);
+                xv[u] = r * ray.x; yv[u] = r * ray.y; zv[u] = r * ray.z;
             }
 #pragma unroll
             for (int u = 0; u < RS_CU; u++) {
