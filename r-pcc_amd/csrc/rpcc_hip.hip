@@ -1292,6 +1292,8 @@ __global__ __launch_bounds__(256) void assign_kernel(const float *__restrict__ r
     G.S = (float)((fabs(G.a) + fabs(G.b) + fabs(G.c)) * 1.001);
     const int tcols = (W + 31) >> 5, ntile = ((H + 3) >> 2) * tcols;
     const int t0 = (blockIdx.x * 4 + wave) * ASSIGN_TILES_PER_WAVE;
+    const float *ri_b = ri + (int64_t)b * P;
+    uint8_t *seg_b = seg + (int64_t)b * P;
     const float inf = __builtin_inff();
     for (int t = t0; t < min(t0 + ASSIGN_TILES_PER_WAVE, ntile); t++) {
         const int row = (t / tcols) * 4 + (lane >> 4), col0 = (t % tcols) * 32 + 2 * (lane & 15);
@@ -1302,16 +1304,17 @@ __global__ __launch_bounds__(256) void assign_kernel(const float *__restrict__ r
         for (int e = 0; e < 2; e++) {
             valid[e] = row < H && col0 + e < W;
             p[e] = valid[e] ? row * W + col0 + e : 0;
-            r[e] = ri[(int64_t)b * P + p[e]];
+            r[e] = ld_at(ri_b, (uint32_t)p[e] * 4u);  // byte offsets from the frame's bases (scalar-base addressing)
             if (!valid[e]) r[e] = 0.0f;
-            tx[e] = tm[3 * p[e]]; ty[e] = tm[3 * p[e] + 1]; tz[e] = tm[3 * p[e] + 2];
+            const f32x3 ray = ld_at(reinterpret_cast<const f32x3 *>(tm), (uint32_t)p[e] * 12u);
+            tx[e] = ray.x; ty[e] = ray.y; tz[e] = ray.z;
             x[e] = r[e] * tx[e]; y[e] = r[e] * ty[e]; z[e] = r[e] * tz[e];
             live[e] = valid[e] && r[e] != 0.0f;
         }
         if (__ballot(live[0] || live[1]) == 0ull) {  // nothing but empty pixels
 #pragma unroll
             for (int e = 0; e < 2; e++)
-                if (valid[e]) seg[(int64_t)b * P + p[e]] = 1;
+                if (valid[e]) st_at(seg_b, (uint32_t)p[e], (uint8_t)1);
             continue;
         }
         float lo0 = fminf(live[0] ? x[0] : inf, live[1] ? x[1] : inf), hi0 = fmaxf(live[0] ? x[0] : -inf, live[1] ? x[1] : -inf);
@@ -1363,7 +1366,7 @@ __global__ __launch_bounds__(256) void assign_kernel(const float *__restrict__ r
         for (int e = 0; e < 2; e++) {
             int label = assign_label(r[e], tx[e], ty[e], tz[e], x[e], y[e], z[e], m1[e], m2[e], k1[e], cen4, G);
             if (r[e] == 0.0f) label = 1;
-            if (valid[e]) seg[(int64_t)b * P + p[e]] = (uint8_t)label;
+            if (valid[e]) st_at(seg_b, (uint32_t)p[e], (uint8_t)label);
         }
     }
 }
@@ -1439,13 +1442,15 @@ __global__ __launch_bounds__(256) void model_hist_kernel(const float *__restrict
     for (int k = threadIdx.x; k < KP; k += blockDim.x) { ssum[k] = 0ull; scnt[k] = 0u; }
     __syncthreads();
     bool inexact = false;
+    const uint8_t *seg_b = seg + (int64_t)b * P;
+    const float *ri_b = ri != nullptr ? ri + (int64_t)b * P : nullptr;
     int lab_in[TILE / 256];
     float r_in[TILE / 256];
 #pragma unroll
     for (int j = 0; j < TILE / 256; j++) {  // all loads of the tile first (unconditional, clamped): one latency, not four
-        const int64_t gp = (int64_t)b * P + min(t * TILE + j * 256 + (int)threadIdx.x, P - 1);
-        lab_in[j] = seg[gp];
-        r_in[j] = ri != nullptr ? ri[gp] : 1.0f;
+        const uint32_t gp = (uint32_t)min(t * TILE + j * 256 + (int)threadIdx.x, P - 1);  // offsets from the frame's bases
+        lab_in[j] = ld_at(seg_b, gp);
+        r_in[j] = ri != nullptr ? ld_at(ri_b, gp * 4u) : 1.0f;
     }
 #pragma unroll
     for (int j = 0; j < TILE / 256; j++) {
