@@ -90,15 +90,20 @@ __device__ __forceinline__ void fps_tile_argmax(const float (&x)[2], const float
     const uint32_t vmax = dpp_max_u32(o0 > o1 ? o0 : o1);
     const unsigned long long m0 = __ballot(o0 == vmax);
     const unsigned long long m1 = __ballot(o1 == vmax);
-    const int half = m0 ? 0 : 1;
     const int wl = __builtin_amdgcn_readfirstlane((int)__ffsll((long long)(m0 ? m0 : m1)) - 1);
-    const float st = half ? nt[1] : nt[0], sx = half ? x[1] : x[0], sy = half ? y[1] : y[0], sz = half ? z[1] : z[0];
-    const int sp = half ? pidx[1] : pidx[0];
-    wt = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(st), wl));
-    wx = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(sx), wl));
-    wy = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(sy), wl));
-    wz = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(sz), wl));
-    widx = (uint32_t)__builtin_amdgcn_readlane(sp, wl);
+    if (m0) {  // wave-uniform: a scalar branch instead of five per-lane selects
+        wt = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(nt[0]), wl));
+        wx = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(x[0]), wl));
+        wy = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(y[0]), wl));
+        wz = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(z[0]), wl));
+        widx = (uint32_t)__builtin_amdgcn_readlane(pidx[0], wl);
+    } else {
+        wt = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(nt[1]), wl));
+        wx = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(x[1]), wl));
+        wy = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(y[1]), wl));
+        wz = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(z[1]), wl));
+        widx = (uint32_t)__builtin_amdgcn_readlane(pidx[1], wl);
+    }
     if (vmax == 0u) wt = -1.0f;
 }
 __device__ __forceinline__ void fps_tile_box(const float (&x)[2], const float (&y)[2], const float (&z)[2],
@@ -188,7 +193,7 @@ __global__ __launch_bounds__(FPS_TT) void fps_tiled_kernel(const float *__restri
             const int pc = q.p[h] < 0 ? 0 : q.p[h];
             fps_load_point<RANGE>(src, tx, ty, tz, pc, q.x[h], q.y[h], q.z[h]);
             q.tp[h] = ld_f32(temp, (uint32_t)pc * 4u);
-            if (q.p[h] < 0) { q.x[h] = 0.f; q.y[h] = 0.f; q.z[h] = 0.f; q.tp[h] = -1.0f; }
+            if (q.p[h] < 0) q.tp[h] = -1.0f;  // not a candidate; its (clamped-load) coordinates are never used
         }
     };
     // distance update against the current centre, tile maximum, (optionally) bounding box
