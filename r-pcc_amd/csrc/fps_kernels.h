@@ -19,7 +19,11 @@
 #pragma once
 
 #define FPS_TAB_ROWS 11  // lo[3], hi[3], tmax, cx[3], targ
-#define FPS_TILE 128
+#ifndef FPS_NH
+#define FPS_NH 4  // wavefront-loads ("halves") per tile: 64 * FPS_NH points, 2 * FPS_NH rows x 32 columns of a range image
+#endif
+#define FPS_TILE (64 * FPS_NH)
+#define FPS_TROWS (2 * FPS_NH)
 
 struct FpsTiling {
     int N;      // points per frame (P for a range image)
@@ -29,7 +33,7 @@ struct FpsTiling {
 };
 static inline FpsTiling fps_tiling_range(int H, int W) {
     FpsTiling g;
-    g.N = H * W; g.W = W; g.H = H; g.tcols = (W + 31) / 32; g.T = ((H + 3) / 4) * g.tcols;
+    g.N = H * W; g.W = W; g.H = H; g.tcols = (W + 31) / 32; g.T = ((H + FPS_TROWS - 1) / FPS_TROWS) * g.tcols;
     return g;
 }
 static inline FpsTiling fps_tiling_list(int N) {
@@ -43,7 +47,7 @@ template <bool RANGE>
 __device__ __forceinline__ int fps_tile_point(const FpsTiling &g, int t, int half, int lane) {
     if (RANGE) {
         const int tr = t / g.tcols, tc = t - tr * g.tcols;
-        const int row = 4 * tr + 2 * half + (lane >> 5), col = 32 * tc + (lane & 31);
+        const int row = FPS_TROWS * tr + 2 * half + (lane >> 5), col = 32 * tc + (lane & 31);
         return (row < g.H && col < g.W) ? row * g.W + col : -1;
     }
     const int p = t * FPS_TILE + half * 64 + lane;
@@ -53,7 +57,7 @@ template <bool RANGE>
 __device__ __forceinline__ int fps_tile_of(const FpsTiling &g, int p) {
     if (RANGE) {
         const int row = p / g.W, col = p - row * g.W;
-        return (row >> 2) * g.tcols + (col >> 5);
+        return (row / FPS_TROWS) * g.tcols + (col >> 5);
     }
     return p / FPS_TILE;
 }
@@ -61,7 +65,7 @@ __device__ __forceinline__ int fps_tile_of(const FpsTiling &g, int p) {
 struct FpsLds {
     float *lo[3], *hi[3], *tmax, *cx[3];
     uint32_t *targ;
-    uint32_t *torg;   // range image: first pixel of the tile | valid columns (1..32) << 23 | valid rows (1..4) << 29
+    uint32_t *torg;   // range image: first pixel of the tile (22 bits) | valid columns (1..32) << 22 | valid rows (1..8) << 28
     uint16_t *work;
     __device__ FpsLds(unsigned char *base, int T) {
         float *f = reinterpret_cast<float *>(base);
@@ -81,37 +85,47 @@ static inline size_t fps_tiled_lds_bytes(int T) { return (size_t)T * 50 + 64; }
 struct TileStats {
     float v[FPS_TAB_ROWS];
 };
-__device__ __forceinline__ void fps_tile_argmax(const float (&x)[2], const float (&y)[2], const float (&z)[2],
-                                                const float (&nt)[2], const bool (&valid)[2], const int (&pidx)[2],
-                                                float &wt, float &wx, float &wy, float &wz, uint32_t &widx) {
+__device__ __forceinline__ void fps_tile_argmax(const float (&x)[FPS_NH], const float (&y)[FPS_NH], const float (&z)[FPS_NH],
+                                                const float (&nt)[FPS_NH], const bool (&valid)[FPS_NH],
+                                                const int (&pidx)[FPS_NH], float &wt, float &wx, float &wy, float &wz,
+                                                uint32_t &widx) {
     // largest value, lowest (half, lane) among equals
-    const uint32_t o0 = (!valid[0] || nt[0] < 0.0f) ? 0u : f2u(nt[0]) + 1u;
-    const uint32_t o1 = (!valid[1] || nt[1] < 0.0f) ? 0u : f2u(nt[1]) + 1u;
-    const uint32_t vmax = dpp_max_u32(o0 > o1 ? o0 : o1);
-    const unsigned long long m0 = __ballot(o0 == vmax);
-    const unsigned long long m1 = __ballot(o1 == vmax);
-    const int wl = __builtin_amdgcn_readfirstlane((int)__ffsll((long long)(m0 ? m0 : m1)) - 1);
-    if (m0) {  // wave-uniform: a scalar branch instead of five per-lane selects
-        wt = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(nt[0]), wl));
-        wx = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(x[0]), wl));
-        wy = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(y[0]), wl));
-        wz = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(z[0]), wl));
-        widx = (uint32_t)__builtin_amdgcn_readlane(pidx[0], wl);
-    } else {
-        wt = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(nt[1]), wl));
-        wx = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(x[1]), wl));
-        wy = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(y[1]), wl));
-        wz = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(z[1]), wl));
-        widx = (uint32_t)__builtin_amdgcn_readlane(pidx[1], wl);
+    uint32_t o[FPS_NH], om = 0u;
+#pragma unroll
+    for (int h = 0; h < FPS_NH; h++) {
+        o[h] = (!valid[h] || nt[h] < 0.0f) ? 0u : f2u(nt[h]) + 1u;
+        om = o[h] > om ? o[h] : om;
+    }
+    const uint32_t vmax = dpp_max_u32(om);
+    bool done = false;
+    wt = wx = wy = wz = 0.0f;
+    widx = 0u;
+#pragma unroll
+    for (int h = 0; h < FPS_NH; h++) {
+        const unsigned long long m = __ballot(o[h] == vmax);
+        if (!done && m) {  // wave-uniform: a scalar branch instead of per-lane selects
+            const int wl = (int)__ffsll((long long)m) - 1;
+            wt = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(nt[h]), wl));
+            wx = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(x[h]), wl));
+            wy = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(y[h]), wl));
+            wz = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(z[h]), wl));
+            widx = (uint32_t)__builtin_amdgcn_readlane(pidx[h], wl);
+            done = true;
+        }
     }
     if (vmax == 0u) wt = -1.0f;
 }
-__device__ __forceinline__ void fps_tile_box(const float (&x)[2], const float (&y)[2], const float (&z)[2],
-                                             const bool (&cand)[2], float (&lo)[3], float (&hi)[3]) {
+__device__ __forceinline__ void fps_tile_box(const float (&x)[FPS_NH], const float (&y)[FPS_NH], const float (&z)[FPS_NH],
+                                             const bool (&cand)[FPS_NH], float (&lo)[3], float (&hi)[3]) {
     const float inf = __builtin_inff();
-    lo[0] = fminf(cand[0] ? x[0] : inf, cand[1] ? x[1] : inf); hi[0] = fmaxf(cand[0] ? x[0] : -inf, cand[1] ? x[1] : -inf);
-    lo[1] = fminf(cand[0] ? y[0] : inf, cand[1] ? y[1] : inf); hi[1] = fmaxf(cand[0] ? y[0] : -inf, cand[1] ? y[1] : -inf);
-    lo[2] = fminf(cand[0] ? z[0] : inf, cand[1] ? z[1] : inf); hi[2] = fmaxf(cand[0] ? z[0] : -inf, cand[1] ? z[1] : -inf);
+    lo[0] = lo[1] = lo[2] = inf;
+    hi[0] = hi[1] = hi[2] = -inf;
+#pragma unroll
+    for (int h = 0; h < FPS_NH; h++) {
+        lo[0] = fminf(lo[0], cand[h] ? x[h] : inf); hi[0] = fmaxf(hi[0], cand[h] ? x[h] : -inf);
+        lo[1] = fminf(lo[1], cand[h] ? y[h] : inf); hi[1] = fmaxf(hi[1], cand[h] ? y[h] : -inf);
+        lo[2] = fminf(lo[2], cand[h] ? z[h] : inf); hi[2] = fmaxf(hi[2], cand[h] ? z[h] : -inf);
+    }
     dpp_box6(lo[0], lo[1], lo[2], hi[0], hi[1], hi[2]);
 }
 
@@ -170,23 +184,23 @@ __global__ __launch_bounds__(FPS_TT) void fps_tiled_kernel(const float *__restri
     if (RANGE) {
         for (int t = tid; t < T; t += FPS_TT) {
             const int tr = t / g.tcols, tc = t - tr * g.tcols;
-            const int ncol = min(32, g.W - 32 * tc), nrow = min(4, g.H - 4 * tr);
-            L.torg[t] = (uint32_t)(4 * tr * g.W + 32 * tc) | ((uint32_t)ncol << 23) | ((uint32_t)nrow << 29);
+            const int ncol = min(32, g.W - 32 * tc), nrow = min(FPS_TROWS, g.H - FPS_TROWS * tr);
+            L.torg[t] = (uint32_t)(FPS_TROWS * tr * g.W + 32 * tc) | ((uint32_t)ncol << 22) | ((uint32_t)nrow << 28);
         }
     }
     __syncthreads();
     // A tile's data in registers (loads are issued for a group of tiles before any is consumed, so the
     // memory latency of a round is paid once per group; all loads are unconditional on clamped indices).
-    struct TileRegs { float x[2], y[2], z[2], tp[2]; int p[2]; };
+    struct TileRegs { float x[FPS_NH], y[FPS_NH], z[FPS_NH], tp[FPS_NH]; int p[FPS_NH]; };
     const int lrow = lane >> 5, lcol = lane & 31;
-    const int loff0 = lrow * g.W + lcol, loff1 = loff0 + 2 * g.W;  // lane's pixel offset inside a tile (halves 0 / 1)
+    const int loff0 = lrow * g.W + lcol;  // lane's pixel offset inside a tile, half 0 (half h: + 2 * h * W)
     auto load_tile = [&](int t, TileRegs &q) {
         const uint32_t org = RANGE ? L.torg[t] : 0u;
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
+        for (int h = 0; h < FPS_NH; h++) {
             if (RANGE) {
-                const bool ok = lcol < (int)((org >> 23) & 63u) && 2 * h + lrow < (int)(org >> 29);
-                q.p[h] = ok ? (int)(org & 0x7FFFFFu) + (h ? loff1 : loff0) : -1;
+                const bool ok = lcol < (int)((org >> 22) & 63u) && 2 * h + lrow < (int)(org >> 28);
+                q.p[h] = ok ? (int)(org & 0x3FFFFFu) + loff0 + 2 * h * g.W : -1;
             } else {
                 q.p[h] = fps_tile_point<RANGE>(g, t, h, lane);
             }
@@ -198,10 +212,10 @@ __global__ __launch_bounds__(FPS_TT) void fps_tiled_kernel(const float *__restri
     };
     // distance update against the current centre, tile maximum, (optionally) bounding box
     auto compute_tile = [&](int t, const TileRegs &q, bool with_box) {
-        bool valid[2], cand[2];
-        float nt[2];
+        bool valid[FPS_NH], cand[FPS_NH];
+        float nt[FPS_NH];
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
+        for (int h = 0; h < FPS_NH; h++) {
             valid[h] = q.p[h] >= 0;
             cand[h] = q.tp[h] >= 0.0f;
             const float dx = q.x[h] - c0, dy = q.y[h] - c1, dz = q.z[h] - c2;
@@ -210,7 +224,10 @@ __global__ __launch_bounds__(FPS_TT) void fps_tiled_kernel(const float *__restri
             if (valid[h] && nt[h] != q.tp[h]) st_f32(temp, (uint32_t)q.p[h] * 4u, nt[h]);
         }
         // nothing changed in this tile: its table entry (maximum, arg, coordinates) is still exact
-        if (!with_box && __ballot((valid[0] && nt[0] != q.tp[0]) || (valid[1] && nt[1] != q.tp[1])) == 0ull) return;
+        bool changed = false;
+#pragma unroll
+        for (int h = 0; h < FPS_NH; h++) changed |= valid[h] && nt[h] != q.tp[h];
+        if (!with_box && __ballot(changed) == 0ull) return;
         if (with_box) {
             float lo[3], hi[3];
             fps_tile_box(q.x, q.y, q.z, cand, lo, hi);
@@ -257,7 +274,7 @@ __global__ __launch_bounds__(FPS_TT) void fps_tiled_kernel(const float *__restri
         }
     };
 
-    constexpr int NW = FPS_TT / 64, GROUP = 4;  // tiles per wavefront in flight (2 and 8 measured: no better)
+    constexpr int NW = FPS_TT / 64, GROUP = 8 / FPS_NH;  // tiles per wavefront in flight: 512 points (256 and 1024 measured: no better)
     DBG_STAMP(8);
     // first centre: every tile is visited once (also builds the boxes) -- unless ground_mask already did
     // that pass and left the tile table (info[b][3] == 1)
@@ -343,7 +360,7 @@ __global__ __launch_bounds__(FPS_TT) void fps_tiled_kernel(const float *__restri
 // Otherwise info[b][3] stays 0, the classic temp = 1e10 / -1 is written and the FPS kernel does its own
 // first pass.  Same arithmetic either way.  One wavefront per 4x32 tile, TAB_TPW tiles per wavefront.
 // ------------------------------------------------------------------------------------------------
-#define TAB_TPW 4
+#define TAB_TPW (8 / FPS_NH)
 template <bool RAW>
 __global__ __launch_bounds__(256) void ground_mask_tab_kernel(float *__restrict__ ri, const float *__restrict__ tm,
                                                               const double *__restrict__ ground, double thr, FpsTiling g,
@@ -393,12 +410,12 @@ __global__ __launch_bounds__(256) void ground_mask_tab_kernel(float *__restrict_
     int cnt = 0, nzc = 0, first = P;
     const int t0 = (blockIdx.x * 4 + wave) * TAB_TPW;
     // the loads of all TAB_TPW tiles of this wavefront first (unconditional, clamped): one memory latency, not TAB_TPW
-    float pr[TAB_TPW][2], ptx[TAB_TPW][2], pty[TAB_TPW][2], ptz[TAB_TPW][2];
-    int ppix[TAB_TPW][2];
+    float pr[TAB_TPW][FPS_NH], ptx[TAB_TPW][FPS_NH], pty[TAB_TPW][FPS_NH], ptz[TAB_TPW][FPS_NH];
+    int ppix[TAB_TPW][FPS_NH];
 #pragma unroll
     for (int q = 0; q < TAB_TPW; q++)
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
+        for (int h = 0; h < FPS_NH; h++) {
             ppix[q][h] = fps_tile_point<true>(g, min(t0 + q, T - 1), h, lane);
             const uint32_t pc = ppix[q][h] >= 0 ? (uint32_t)ppix[q][h] : 0u;  // byte offsets from wave-uniform bases
             pr[q][h] = ld_at(ri_b, pc * 4u);
@@ -409,11 +426,11 @@ __global__ __launch_bounds__(256) void ground_mask_tab_kernel(float *__restrict_
     for (int q = 0; q < TAB_TPW; q++) {
         const int t = t0 + q;
         if (t >= T) break;
-        float x[2], y[2], z[2], nt[2];
-        bool valid[2], cand[2];
-        int pidx[2];
+        float x[FPS_NH], y[FPS_NH], z[FPS_NH], nt[FPS_NH];
+        bool valid[FPS_NH], cand[FPS_NH];
+        int pidx[FPS_NH];
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
+        for (int h = 0; h < FPS_NH; h++) {
             pidx[h] = ppix[q][h];
             valid[h] = pidx[h] >= 0;
             float r = pr[q][h];
