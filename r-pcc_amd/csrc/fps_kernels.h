@@ -1,12 +1,15 @@
 // fps_kernels.h -- exact tile-pruned farthest point sampling (a6) and the ground-mask kernel that performs
 // its first pass (a3+a5 + FPS pass 1); included by rpcc_hip.hip.
 //
-// Tiles hold 128 points = 2 per lane of one wavefront, "half" h in {0,1}:
-//   range image:  tile t = (tr, tc) covers rows 4*tr .. 4*tr+3, columns 32*tc .. 32*tc+31 (compact in 3-D);
-//                 lane l, half h  ->  row 4*tr + 2*h + (l >> 5), column 32*tc + (l & 31)
-//   point list:   tile t covers indices 128*t .. 128*t+127; lane l, half h -> 128*t + 64*h + l
+// Tiles hold 64 * FPS_NH points = FPS_NH per lane of one wavefront ("half" h in 0 .. FPS_NH-1; FPS_NH = 4: 256 points):
+//   range image:  tile t = (tr, tc) covers rows 2*FPS_NH*tr .. +2*FPS_NH-1, columns 32*tc .. 32*tc+31 (compact in 3-D);
+//                 lane l, half h  ->  row 2*FPS_NH*tr + 2*h + (l >> 5), column 32*tc + (l & 31)
+//   point list:   tile t covers indices 64*FPS_NH*t ..; lane l, half h -> 64*FPS_NH*t + 64*h + l
 // In both layouts (half, lane) in lexicographic order is increasing point index, which is what the
-// lowest-index tie rule of the arg-max needs.
+// lowest-index tie rule of the arg-max needs.  Measured on 64x2048 (FPS alone / step with batches in flight): 128-point
+// tiles 583 us / 1.10 ms, 256-point tiles 527 us / 1.06 ms, 512-point tiles 536 us / 1.10 ms -- larger tiles re-read a
+// little more per visit (+10 % points) but halve the per-tile work of the test / select phases and of the box and
+// arg-max reductions, and the tile table shrinks to 25 KB of LDS.
 //
 // Per tile the workgroup keeps in LDS (FpsLds, 11 dwords): the bounding box of the tile's candidates, the
 // tile's current maximum of temp with its (lowest) index, and that point's coordinates.  For a new centre
@@ -65,7 +68,7 @@ __device__ __forceinline__ int fps_tile_of(const FpsTiling &g, int p) {
 struct FpsLds {
     float *lo[3], *hi[3], *tmax, *cx[3];
     uint32_t *targ;
-    uint32_t *torg;   // range image: first pixel of the tile (22 bits) | valid columns (1..32) << 22 | valid rows (1..8) << 28
+    uint32_t *torg;   // range image: first pixel of the tile (22 bits) | valid columns - 1 (5 bits) << 22 | valid rows - 1 (5 bits) << 27
     uint16_t *work;
     __device__ FpsLds(unsigned char *base, int T) {
         float *f = reinterpret_cast<float *>(base);
@@ -185,7 +188,7 @@ __global__ __launch_bounds__(FPS_TT) void fps_tiled_kernel(const float *__restri
         for (int t = tid; t < T; t += FPS_TT) {
             const int tr = t / g.tcols, tc = t - tr * g.tcols;
             const int ncol = min(32, g.W - 32 * tc), nrow = min(FPS_TROWS, g.H - FPS_TROWS * tr);
-            L.torg[t] = (uint32_t)(FPS_TROWS * tr * g.W + 32 * tc) | ((uint32_t)ncol << 22) | ((uint32_t)nrow << 28);
+            L.torg[t] = (uint32_t)(FPS_TROWS * tr * g.W + 32 * tc) | ((uint32_t)(ncol - 1) << 22) | ((uint32_t)(nrow - 1) << 27);
         }
     }
     __syncthreads();
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(FPS_TT) void fps_tiled_kernel(const float *__restri
 #pragma unroll
         for (int h = 0; h < FPS_NH; h++) {
             if (RANGE) {
-                const bool ok = lcol < (int)((org >> 22) & 63u) && 2 * h + lrow < (int)(org >> 28);
+                const bool ok = lcol <= (int)((org >> 22) & 31u) && 2 * h + lrow <= (int)(org >> 27);
                 q.p[h] = ok ? (int)(org & 0x3FFFFFu) + loff0 + 2 * h * g.W : -1;
             } else {
                 q.p[h] = fps_tile_point<RANGE>(g, t, h, lane);
@@ -274,7 +277,7 @@ __global__ __launch_bounds__(FPS_TT) void fps_tiled_kernel(const float *__restri
         }
     };
 
-    constexpr int NW = FPS_TT / 64, GROUP = 8 / FPS_NH;  // tiles per wavefront in flight: 512 points (256 and 1024 measured: no better)
+    constexpr int NW = FPS_TT / 64, GROUP = FPS_NH >= 8 ? 1 : 8 / FPS_NH;  // tiles per wavefront in flight: 512 points (256 and 1024 measured: no better)
     DBG_STAMP(8);
     // first centre: every tile is visited once (also builds the boxes) -- unless ground_mask already did
     // that pass and left the tile table (info[b][3] == 1)
@@ -360,7 +363,7 @@ __global__ __launch_bounds__(FPS_TT) void fps_tiled_kernel(const float *__restri
 // Otherwise info[b][3] stays 0, the classic temp = 1e10 / -1 is written and the FPS kernel does its own
 // first pass.  Same arithmetic either way.  One wavefront per 4x32 tile, TAB_TPW tiles per wavefront.
 // ------------------------------------------------------------------------------------------------
-#define TAB_TPW (8 / FPS_NH)
+#define TAB_TPW (FPS_NH >= 8 ? 1 : 8 / FPS_NH)
 template <bool RAW>
 __global__ __launch_bounds__(256) void ground_mask_tab_kernel(float *__restrict__ ri, const float *__restrict__ tm,
                                                               const double *__restrict__ ground, double thr, FpsTiling g,
