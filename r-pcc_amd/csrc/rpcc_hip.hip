@@ -1273,7 +1273,9 @@ __device__ __forceinline__ int assign_label(float r, float tx, float ty, float t
     return cluster ? kk + 2 : 0;
 }
 
-#define ASSIGN_TILES_PER_WAVE 2
+#define ASSIGN_PX 4     // pixels per lane: a tile is (2 * ASSIGN_PX) rows x 32 columns, lane l pixel e -> row (l >> 4) + 4 * (e >> 1), column 2 * (l & 15) + (e & 1)
+#define ASSIGN_ROWS (2 * ASSIGN_PX)
+#define ASSIGN_TILES_PER_WAVE (4 / ASSIGN_PX)
 __global__ __launch_bounds__(256) void assign_kernel(const float *__restrict__ ri, const float *__restrict__ tm,
                                                      const double *__restrict__ ground,
                                                      const float *__restrict__ centers, int H, int W, int M,
@@ -1290,36 +1292,43 @@ __global__ __launch_bounds__(256) void assign_kernel(const float *__restrict__ r
     G.a = ground[4 * b]; G.b = ground[4 * b + 1]; G.c = ground[4 * b + 2]; G.d = ground[4 * b + 3];
     G.af = (float)G.a; G.bf = (float)G.b; G.cf = (float)G.c; G.df = (float)G.d;
     G.S = (float)((fabs(G.a) + fabs(G.b) + fabs(G.c)) * 1.001);
-    const int tcols = (W + 31) >> 5, ntile = ((H + 3) >> 2) * tcols;
+    const int tcols = (W + 31) >> 5, ntile = ((H + ASSIGN_ROWS - 1) / ASSIGN_ROWS) * tcols;
     const int t0 = (blockIdx.x * 4 + wave) * ASSIGN_TILES_PER_WAVE;
     const float *ri_b = ri + (int64_t)b * P;
     uint8_t *seg_b = seg + (int64_t)b * P;
     const float inf = __builtin_inff();
     for (int t = t0; t < min(t0 + ASSIGN_TILES_PER_WAVE, ntile); t++) {
-        const int row = (t / tcols) * 4 + (lane >> 4), col0 = (t % tcols) * 32 + 2 * (lane & 15);
-        bool valid[2], live[2];
-        int p[2];
-        float r[2], tx[2], ty[2], tz[2], x[2], y[2], z[2];
+        const int row0 = (t / tcols) * ASSIGN_ROWS + (lane >> 4), col0 = (t % tcols) * 32 + 2 * (lane & 15);
+        bool valid[ASSIGN_PX], live[ASSIGN_PX];
+        int p[ASSIGN_PX];
+        float r[ASSIGN_PX], tx[ASSIGN_PX], ty[ASSIGN_PX], tz[ASSIGN_PX], x[ASSIGN_PX], y[ASSIGN_PX], z[ASSIGN_PX];
+        bool any_live = false;
 #pragma unroll
-        for (int e = 0; e < 2; e++) {
-            valid[e] = row < H && col0 + e < W;
-            p[e] = valid[e] ? row * W + col0 + e : 0;
+        for (int e = 0; e < ASSIGN_PX; e++) {
+            const int row = row0 + 4 * (e >> 1), col = col0 + (e & 1);
+            valid[e] = row < H && col < W;
+            p[e] = valid[e] ? row * W + col : 0;
             r[e] = ld_at(ri_b, (uint32_t)p[e] * 4u);  // byte offsets from the frame's bases (scalar-base addressing)
             if (!valid[e]) r[e] = 0.0f;
             const f32x3 ray = ld_at(reinterpret_cast<const f32x3 *>(tm), (uint32_t)p[e] * 12u);
             tx[e] = ray.x; ty[e] = ray.y; tz[e] = ray.z;
             x[e] = r[e] * tx[e]; y[e] = r[e] * ty[e]; z[e] = r[e] * tz[e];
             live[e] = valid[e] && r[e] != 0.0f;
+            any_live |= live[e];
         }
-        if (__ballot(live[0] || live[1]) == 0ull) {  // nothing but empty pixels
+        if (__ballot(any_live) == 0ull) {  // nothing but empty pixels
 #pragma unroll
-            for (int e = 0; e < 2; e++)
+            for (int e = 0; e < ASSIGN_PX; e++)
                 if (valid[e]) st_at(seg_b, (uint32_t)p[e], (uint8_t)1);
             continue;
         }
-        float lo0 = fminf(live[0] ? x[0] : inf, live[1] ? x[1] : inf), hi0 = fmaxf(live[0] ? x[0] : -inf, live[1] ? x[1] : -inf);
-        float lo1 = fminf(live[0] ? y[0] : inf, live[1] ? y[1] : inf), hi1 = fmaxf(live[0] ? y[0] : -inf, live[1] ? y[1] : -inf);
-        float lo2 = fminf(live[0] ? z[0] : inf, live[1] ? z[1] : inf), hi2 = fmaxf(live[0] ? z[0] : -inf, live[1] ? z[1] : -inf);
+        float lo0 = inf, lo1 = inf, lo2 = inf, hi0 = -inf, hi1 = -inf, hi2 = -inf;
+#pragma unroll
+        for (int e = 0; e < ASSIGN_PX; e++) {
+            lo0 = fminf(lo0, live[e] ? x[e] : inf); hi0 = fmaxf(hi0, live[e] ? x[e] : -inf);
+            lo1 = fminf(lo1, live[e] ? y[e] : inf); hi1 = fmaxf(hi1, live[e] ? y[e] : -inf);
+            lo2 = fminf(lo2, live[e] ? z[e] : inf); hi2 = fmaxf(hi2, live[e] ? z[e] : -inf);
+        }
         dpp_box6(lo0, lo1, lo2, hi0, hi1, hi2);
         // screen the centres: lane handles centres lane, lane+64, ...
         float my_dmin[4], upper = inf;
@@ -1338,9 +1347,15 @@ __global__ __launch_bounds__(256) void assign_kernel(const float *__restrict__ r
         }
         upper = dpp_min_f32_native(upper);
         const float cut = upper * 1.000002f;
-        float m1[2] = {inf, inf}, m2[2] = {inf, inf};
-        int k1[2] = {-1, -1};
-        const rs_v2f xv = {x[0], x[1]}, yv = {y[0], y[1]}, zv = {z[0], z[1]};
+        float m1[ASSIGN_PX], m2[ASSIGN_PX];
+        int k1[ASSIGN_PX];
+        rs_v2f xv[ASSIGN_PX / 2], yv[ASSIGN_PX / 2], zv[ASSIGN_PX / 2];
+#pragma unroll
+        for (int e = 0; e < ASSIGN_PX; e++) { m1[e] = inf; m2[e] = inf; k1[e] = -1; }
+#pragma unroll
+        for (int e2 = 0; e2 < ASSIGN_PX / 2; e2++) {
+            xv[e2] = rs_v2f{x[2 * e2], x[2 * e2 + 1]}; yv[e2] = rs_v2f{y[2 * e2], y[2 * e2 + 1]}; zv[e2] = rs_v2f{z[2 * e2], z[2 * e2 + 1]};
+        }
 #pragma unroll
         for (int rd = 0; rd < 4; rd++) {
             if (rd * 64 >= M) break;
@@ -1349,21 +1364,25 @@ __global__ __launch_bounds__(256) void assign_kernel(const float *__restrict__ r
                 const int k = rd * 64 + (int)__ffsll((long long)surv) - 1;
                 surv &= surv - 1ull;
                 const float4 cc = cen4[k];
-                // both pixels of the lane in packed fp32 (v_pk_add / v_pk_mul: each half rounds like the scalar operation)
-                const rs_v2f dx = xv - rs_v2f{cc.x, cc.x}, dy = yv - rs_v2f{cc.y, cc.y}, dz = zv - rs_v2f{cc.z, cc.z};
-                const rs_v2f dd = (dx * dx + dy * dy) + dz * dz;
+                // the lane's pixels in pairs of packed fp32 (v_pk_add / v_pk_mul: each half rounds like the scalar operation)
 #pragma unroll
-                for (int e = 0; e < 2; e++) {
-                    const float d2 = e ? dd.y : dd.x;
-                    const bool lt = d2 < m1[e];
-                    m2[e] = lt ? m1[e] : fminf(m2[e], d2);
-                    k1[e] = lt ? k : k1[e];
-                    m1[e] = lt ? d2 : m1[e];
+                for (int e2 = 0; e2 < ASSIGN_PX / 2; e2++) {
+                    const rs_v2f dx = xv[e2] - rs_v2f{cc.x, cc.x}, dy = yv[e2] - rs_v2f{cc.y, cc.y}, dz = zv[e2] - rs_v2f{cc.z, cc.z};
+                    const rs_v2f dd = (dx * dx + dy * dy) + dz * dz;
+#pragma unroll
+                    for (int e1 = 0; e1 < 2; e1++) {
+                        const int e = 2 * e2 + e1;
+                        const float d2 = e1 ? dd.y : dd.x;
+                        const bool lt = d2 < m1[e];
+                        m2[e] = lt ? m1[e] : fminf(m2[e], d2);
+                        k1[e] = lt ? k : k1[e];
+                        m1[e] = lt ? d2 : m1[e];
+                    }
                 }
             }
         }
 #pragma unroll
-        for (int e = 0; e < 2; e++) {
+        for (int e = 0; e < ASSIGN_PX; e++) {
             int label = assign_label(r[e], tx[e], ty[e], tz[e], x[e], y[e], z[e], m1[e], m2[e], k1[e], cen4, G);
             if (r[e] == 0.0f) label = 1;
             if (valid[e]) st_at(seg_b, (uint32_t)p[e], (uint8_t)label);
@@ -1373,7 +1392,7 @@ __global__ __launch_bounds__(256) void assign_kernel(const float *__restrict__ r
 
 static int launch_assign(const float *ri, const float *tm, const double *ground, const float *centers, int B, int H,
                          int W, int M, uint8_t *seg, hipStream_t st) {
-    const int ntile = ((H + 3) / 4) * ((W + 31) / 32);
+    const int ntile = ((H + ASSIGN_ROWS - 1) / ASSIGN_ROWS) * ((W + 31) / 32);
     const dim3 grid((ntile + 4 * ASSIGN_TILES_PER_WAVE - 1) / (4 * ASSIGN_TILES_PER_WAVE), B);
     assign_kernel<<<grid, 256, (size_t)M * sizeof(float4), st>>>(ri, tm, ground, centers, H, W, M, seg);
     LAUNCH_CHECK();
