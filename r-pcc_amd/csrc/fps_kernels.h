@@ -148,9 +148,10 @@ __device__ __forceinline__ void fps_load_point(const float *__restrict__ src, co
 
 #define FPS_THREADS 1024
 
-// Threads of the tile-pruned FPS workgroup (one workgroup per frame).  512, not 1024: alone the kernel is 20 % slower
-// (540 -> 645 us per 256 frames), but with several batches in flight two such workgroups no longer fill every wave
-// slot of a CU and the step gets 8 % shorter (1.31 -> 1.21 ms); 256 threads lose both ways.
+// Threads of the tile-pruned FPS workgroup (one workgroup per frame).  Measured with 256-point tiles on 64x2048 (kernel
+// alone / step with three batches in flight): 1024 threads 452 us / 1.14 ms, 768 threads 474 us / 1.12 ms, 512 threads
+// 527 us / 1.07 ms, 384 threads 636 us / 1.10 ms.  Alone the wide workgroup wins; with batches in flight two narrow ones
+// leave wave slots to the throughput kernels of the other batches, and the step is what counts.
 #define FPS_TT 512
 template <bool RANGE>
 __global__ __launch_bounds__(FPS_TT) void fps_tiled_kernel(const float *__restrict__ src,
@@ -260,8 +261,8 @@ __global__ __launch_bounds__(FPS_TT) void fps_tiled_kernel(const float *__restri
             if (lane == 0) { red[wave] = ((unsigned long long)vmax << 32) | imin; redt[wave] = wt_; }
         }
         __syncthreads();
-        const unsigned long long k = red[lane & (FPS_TT / 64 - 1)];
-        const int kt = redt[lane & (FPS_TT / 64 - 1)];
+        const unsigned long long k = red[lane % (FPS_TT / 64)];
+        const int kt = redt[lane % (FPS_TT / 64)];
         hi = (uint32_t)(k >> 32); ix = (uint32_t)k;
         vmax = dpp_max_u32(hi);
         imin = dpp_min_u32(hi == vmax ? ix : 0xFFFFFFFFu);
