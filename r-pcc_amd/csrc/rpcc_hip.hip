@@ -1458,8 +1458,6 @@ __global__ __launch_bounds__(256) void model_hist_kernel(const float *__restrict
     unsigned long long *ssum = reinterpret_cast<unsigned long long *>(smem_raw);  // [KP]
     uint32_t *scnt = reinterpret_cast<uint32_t *>(ssum + KP);                      // [KP]
     const int b = blockIdx.y, t = blockIdx.x, lane = threadIdx.x & 63;
-    for (int k = threadIdx.x; k < KP; k += blockDim.x) { ssum[k] = 0ull; scnt[k] = 0u; }
-    __syncthreads();
     bool inexact = false;
     const uint8_t *seg_b = seg + (int64_t)b * P;
     const float *ri_b = ri != nullptr ? ri + (int64_t)b * P : nullptr;
@@ -1471,6 +1469,8 @@ __global__ __launch_bounds__(256) void model_hist_kernel(const float *__restrict
         lab_in[j] = ld_at(seg_b, gp);
         r_in[j] = ri != nullptr ? ld_at(ri_b, gp * 4u) : 1.0f;
     }
+    for (int k = threadIdx.x; k < KP; k += blockDim.x) { ssum[k] = 0ull; scnt[k] = 0u; }  // while the loads are in flight
+    __syncthreads();
 #pragma unroll
     for (int j = 0; j < TILE / 256; j++) {
         const int p = t * TILE + j * 256 + threadIdx.x;
