@@ -1237,9 +1237,9 @@ __device__ __forceinline__ int assign_label(float r, float tx, float ty, float t
     if (k1 < 0) return 0;
     // radius = sqrtf(min d2).  Every squared distance that rounds to the same radius ties with it, and numpy's
     // argmax keeps the lowest index: U = largest float whose sqrtf equals the radius.
-    const float s = sqrtf(m1);
     int kk = k1;
     if (m2 <= m1 * 1.0000005f) {  // another centre may tie after the square root (rare)
+        const float s = sqrtf(m1);
         float U = m1;
 #pragma unroll
         for (int j = 0; j < 3; j++) {
@@ -1259,16 +1259,19 @@ __device__ __forceinline__ int assign_label(float r, float tx, float ty, float t
     const float qf = -G.df * rinv;
     const float agf = fabsf(r - qf);
     const float rel = 3.0e-7f * G.S * fabsf(rinv);  // |den error| / |den|
-    const float err = fabsf(qf) * (rel + 4.0e-7f) + fabsf(r) * 1.0e-7f + agf * 1.5e-7f;
+    // the radius enters the screen as the hardware square root (1 ulp) with its error added to the band; the correctly
+    // rounded sqrtf of the reference is evaluated only inside the band
+    const float sa = __builtin_amdgcn_sqrtf(m1);
+    const float err = fabsf(qf) * (rel + 4.0e-7f) + fabsf(r) * 1.0e-7f + agf * 1.5e-7f + sa * 2.5e-7f;
     bool cluster;
-    if (rel < 0.01f && s < agf - err) {
+    if (rel < 0.01f && sa < agf - err) {
         cluster = true;
-    } else if (rel < 0.01f && s > agf + err) {
+    } else if (rel < 0.01f && sa > agf + err) {
         cluster = false;
     } else {  // inside the error band (or not finite): the reference's fp64 sequence
         const double den = ((double)tx * G.a + (double)ty * G.b) + (double)tz * G.c;
         const double ag = fabs((double)r - (-G.d / den));
-        cluster = !(ag != ag) && (double)s < ag;  // ground (index 0) wins ties and NaN
+        cluster = !(ag != ag) && (double)sqrtf(m1) < ag;  // ground (index 0) wins ties and NaN
     }
     return cluster ? kk + 2 : 0;
 }
