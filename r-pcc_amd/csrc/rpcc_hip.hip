@@ -1658,6 +1658,7 @@ __global__ __launch_bounds__(256) void predict_quantize_kernel(const float *__re
     float *smodel = reinterpret_cast<float *>(smem_raw);                 // [KP*4]
     uint32_t *segcnt = reinterpret_cast<uint32_t *>(smodel + 4 * KP);    // [16][KP+1]
     const int SEGP = KP + 1;
+    uint32_t *soff = segcnt + 16 * SEGP;                                 // [KP] this tile's output offsets per label
     const int b = blockIdx.y, t = blockIdx.x, K = M + 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // per-frame bases (wave-uniform): scalar base + 32-bit lane offset instead of 64-bit address arithmetic per access
@@ -1687,6 +1688,8 @@ __global__ __launch_bounds__(256) void predict_quantize_kernel(const float *__re
         }
     }
     for (int i = threadIdx.x; i < 4 * K; i += 256) smodel[i] = RESIDUAL_ONLY ? 0.0f : model[(int64_t)b * K * 4 + i];
+    // staged with the first loads: read inside segment_prefix they cost a dependent global round trip per 16 labels
+    for (int i = threadIdx.x; i < K; i += 256) soff[i] = hist[((int64_t)b * T + t) * KP + i];
     for (int i = threadIdx.x; i < 16 * SEGP; i += 256) segcnt[i] = 0u;
     __syncthreads();
     int qv[4], rank[4];
@@ -1725,7 +1728,7 @@ __global__ __launch_bounds__(256) void predict_quantize_kernel(const float *__re
         }
     }
     __syncthreads();
-    segment_prefix(segcnt, SEGP, hist + ((int64_t)b * T + t) * KP, K);
+    segment_prefix(segcnt, SEGP, soff, K);
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -1742,7 +1745,7 @@ static int launch_predict_quantize(const float *ri, const float *tm, const uint8
                                    int32_t *q32, float *pred, void *ws, hipStream_t st) {
     const int KP = kpad(M), T = ntiles(P);
     WsLayout L = ws_layout(ws, B, P, M);
-    const size_t sh = (size_t)KP * 4 * 4 + (size_t)16 * (KP + 1) * 4;
+    const size_t sh = (size_t)KP * 4 * 4 + (size_t)16 * (KP + 1) * 4 + (size_t)KP * 4;
     if (residual_in && !pred)
         predict_quantize_kernel<true><<<dim3(T, B), 256, sh, st>>>(ri, tm, seg, model, L.hist, acc, label_acc, residual_in, P,
                                                                    M, KP, T, q16, q32, pred);
