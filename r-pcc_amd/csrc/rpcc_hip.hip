@@ -1492,23 +1492,30 @@ __global__ __launch_bounds__(256) void model_hist_kernel(const float *__restrict
         }
         // labels are spatially coherent: aggregate per distinct label of the wavefront (ballot + DPP sums),
         // one LDS atomic pair per (wavefront, label) instead of one per pixel
-        while (true) {
+        // (the label of the first pending lane -- usually the majority of the 64 pixels -- that way; the lanes of the
+        // other labels, few, add themselves to LDS directly: integer sums, any order)
+        {
             const unsigned long long pending = __ballot(todo >= 0);
-            if (!pending) break;
-            const int leader = (int)__ffsll((long long)pending) - 1;
-            const int cur = __builtin_amdgcn_readlane(todo, leader);
-            const bool mine = todo == cur;
-            const unsigned long long same = __ballot(mine);
-            uint32_t lo = 0u, hi = 0u;
-            if (cur >= 2) {
-                lo = dpp_sum_u32(mine ? (uint32_t)(v & 0x3FFFFull) : 0u);
-                hi = dpp_sum_u32(mine ? (uint32_t)(v >> 18) : 0u);
+            if (pending) {
+                const int leader = (int)__ffsll((long long)pending) - 1;
+                const int cur = __builtin_amdgcn_readlane(todo, leader);
+                const bool mine = todo == cur;
+                const unsigned long long same = __ballot(mine);
+                uint32_t lo = 0u, hi = 0u;
+                if (cur >= 2) {
+                    lo = dpp_sum_u32(mine ? (uint32_t)(v & 0x3FFFFull) : 0u);
+                    hi = dpp_sum_u32(mine ? (uint32_t)(v >> 18) : 0u);
+                }
+                if (lane == leader) {
+                    atomicAdd(&scnt[cur], (uint32_t)__popcll(same));
+                    if (cur >= 2) atomicAdd(&ssum[cur], (unsigned long long)lo + ((unsigned long long)hi << 18));
+                }
+                if (mine) todo = -1;
             }
-            if (lane == leader) {
-                atomicAdd(&scnt[cur], (uint32_t)__popcll(same));
-                if (cur >= 2) atomicAdd(&ssum[cur], (unsigned long long)lo + ((unsigned long long)hi << 18));
+            if (todo >= 0) {
+                atomicAdd(&scnt[todo], 1u);
+                if (todo >= 2) atomicAdd(&ssum[todo], v);
             }
-            if (mine) todo = -1;
         }
     }
     if (__any(inexact) && lane == 0) flags[4 * b] = 1;
