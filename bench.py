@@ -171,7 +171,7 @@ def main():
             pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))
             if pm["config"] == {"batch": B, "geom": a.geom, "clusters": M}:
                 traffic = pm["kernels"]["fps_tiled_kernel<true>"]["traffic_bytes_per_launch"] / pm.get("launches_per_step", 1)
-                traffic_src = "profiles/r01_v12_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, x2 read correction)"
+                traffic_src = "profiles/r01_v13_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, x2 read correction)"
         except Exception:
             pass
         out = {
