@@ -177,65 +177,75 @@ __global__ __launch_bounds__(256) void decode_kernel(const uint8_t *__restrict__
                                                      float *__restrict__ ri_rec, float *__restrict__ pc_rec) {
     extern __shared__ unsigned char smem_raw[];
     float *smodel = reinterpret_cast<float *>(smem_raw);                 // [KP*4]
-    uint32_t *segcnt = reinterpret_cast<uint32_t *>(smodel + 4 * KP);    // [16][KP]
+    uint32_t *segcnt = reinterpret_cast<uint32_t *>(smodel + 4 * KP);    // [16][KP+1]
+    const int SEGP = KP + 1;
+    uint32_t *soff = segcnt + 16 * SEGP;                                 // [KP] this tile's input offsets per label
     const int b = blockIdx.y, t = blockIdx.x, K = M + 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // per-frame bases (wave-uniform) + byte offsets; all loads of the tile are issued first (unconditional, clamped)
+    seg += (int64_t)b * P;
+    q16 += (int64_t)b * P;
+    ri_rec += (int64_t)b * P;
+    if (pc_rec) pc_rec += (int64_t)b * P * 3;
+    int lab[4], rank[4], lraw[4];
+    f32x3 ray[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t p = (uint32_t)min(t * TILE + j * 256 + (int)threadIdx.x, P - 1);
+        lraw[j] = ld_at(seg, p);
+        ray[j] = ld_at(reinterpret_cast<const f32x3 *>(tm), p * 12u);
+    }
     for (int i = threadIdx.x; i < 4 * K; i += 256) smodel[i] = model[(int64_t)b * K * 4 + i];
-    for (int i = threadIdx.x; i < 16 * KP; i += 256) segcnt[i] = 0u;
+    for (int i = threadIdx.x; i < K; i += 256) soff[i] = hist[((int64_t)b * T + t) * KP + i];
+    for (int i = threadIdx.x; i < 16 * SEGP; i += 256) segcnt[i] = 0u;
     __syncthreads();
-    int lab[4], rank[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int p = t * TILE + j * 256 + threadIdx.x;
-        lab[j] = -1;
+        lab[j] = (p < P && lraw[j] != 1) ? lraw[j] : -1;
         rank[j] = 0;
-        if (p < P) {
-            const int l = seg[(int64_t)b * P + p];
-            lab[j] = (l == 1) ? -1 : l;
-        }
         int todo = lab[j];
         while (true) {
             const unsigned long long pending = __ballot(todo >= 0);
             if (!pending) break;
             const int leader = (int)__ffsll((long long)pending) - 1;
-            const int cur = __shfl(todo, leader, 64);
+            const int cur = __builtin_amdgcn_readlane(todo, leader);
             const unsigned long long same = __ballot(todo == cur);
             if (todo == cur) {
                 rank[j] = __popcll(same & ((1ull << lane) - 1ull));
-                if (lane == leader) segcnt[(j * 4 + wave) * KP + cur] = (uint32_t)__popcll(same);
+                if (lane == leader) segcnt[(j * 4 + wave) * SEGP + cur] = (uint32_t)__popcll(same);
                 todo = -1;
             }
         }
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < K; k += 256) {
-        uint32_t run = hist[((int64_t)b * T + t) * KP + k];
-        for (int s = 0; s < 16; s++) {
-            const uint32_t c = segcnt[s * KP + k];
-            segcnt[s * KP + k] = run;
-            run += c;
-        }
-    }
+    segment_prefix(segcnt, SEGP, soff, K);
     __syncthreads();
+    int16_t qv[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++)  // gather of the label-ordered integers (clamped: unused for label 1 / outside)
+        qv[j] = ld_at(q16, (lab[j] >= 0 ? segcnt[(j * 4 + wave) * SEGP + lab[j]] + (uint32_t)rank[j] : 0u) * 2u);
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int p = t * TILE + j * 256 + threadIdx.x;
         if (p >= P) continue;
-        const int64_t gp = (int64_t)b * P + p;
-        const int l = seg[gp];
+        const int l = lraw[j];
         const float p0 = smodel[4 * l], p1 = smodel[4 * l + 1], p2 = smodel[4 * l + 2], p3 = smodel[4 * l + 3];
         float pr;
         if (p0 + p1 + p2 == 0.0f) pr = p3;
-        else pr = -p3 / (p0 * tm[3 * p] + p1 * tm[3 * p + 1] + p2 * tm[3 * p + 2]);
+        else pr = -p3 / (p0 * ray[j].x + p1 * ray[j].y + p2 * ray[j].z);
         float res = 0.0f;  // label 1 keeps the zero of np.zeros_like (compress_utils.py:115)
         if (lab[j] >= 0) {
-            const int16_t q = q16[(int64_t)b * P + segcnt[(j * 4 + wave) * KP + lab[j]] + rank[j]];
             const double st = steps.levels ? steps.acc[salience[(int64_t)b * K + l]] : steps.acc[0];
-            res = (float)((double)q * st);  // int16 * python float -> float64 -> stored into a float32 array
+            res = (float)((double)qv[j] * st);  // int16 * python float -> float64 -> stored into a float32 array
         }
         const float rec = pr + res;          // tools/decompress.py:104
-        ri_rec[gp] = rec;
-        if (pc_rec) { pc_rec[3 * gp] = rec * tm[3 * p]; pc_rec[3 * gp + 1] = rec * tm[3 * p + 1]; pc_rec[3 * gp + 2] = rec * tm[3 * p + 2]; }
+        st_at(ri_rec, (uint32_t)p * 4u, rec);
+        if (pc_rec) {
+            f32x3 o;
+            o.x = rec * ray[j].x; o.y = rec * ray[j].y; o.z = rec * ray[j].z;
+            st_at(reinterpret_cast<f32x3 *>(pc_rec), (uint32_t)p * 12u, o);
+        }
     }
 }
 

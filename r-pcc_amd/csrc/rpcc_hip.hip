@@ -1837,7 +1837,7 @@ extern "C" int rpcc_decode(const uint8_t *seg, const int16_t *q16, const float *
     DecodeSteps steps;
     steps.levels = levels;
     for (int i = 0; i < 8; i++) steps.acc[i] = i < (levels ? levels : 1) ? level_acc[i] : 0.0;
-    const size_t sh = (size_t)KP * 4 * 4 + (size_t)16 * KP * 4;
+    const size_t sh = (size_t)KP * 4 * 4 + (size_t)16 * (KP + 1) * 4 + (size_t)KP * 4;
     decode_kernel<<<dim3(T, B), 256, sh, st>>>(seg, q16, model, tm, L.hist, salience, steps, P, M, KP, T, ri_rec, pc_rec);
     LAUNCH_CHECK();
     return RPCC_OK;
