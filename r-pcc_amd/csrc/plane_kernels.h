@@ -22,55 +22,57 @@ __global__ __launch_bounds__(256) void label_order_kernel(const uint8_t *__restr
                                                           const float *__restrict__ ri, const float *__restrict__ tm,
                                                           float4 *__restrict__ pts4) {
     extern __shared__ unsigned char smem_raw[];
-    uint32_t *segcnt = reinterpret_cast<uint32_t *>(smem_raw);  // [16][KP]
+    uint32_t *segcnt = reinterpret_cast<uint32_t *>(smem_raw);  // [16][KP+1]
+    const int SEGP = KP + 1;
+    uint32_t *soff = segcnt + 16 * SEGP;                        // [KP] this tile's offsets per label
     const int b = blockIdx.y, t = blockIdx.x, K = M + 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < 16 * KP; i += 256) segcnt[i] = 0u;
+    // per-frame bases + byte offsets; all loads of the tile first (unconditional, clamped)
+    seg += (int64_t)b * P;
+    order += (int64_t)b * P;
+    if (pts4) { ri += (int64_t)b * P; pts4 += (int64_t)b * P; }
+    int lraw[4];
+    float rr[4];
+    f32x3 ray[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t p = (uint32_t)min(t * TILE + j * 256 + (int)threadIdx.x, P - 1);
+        lraw[j] = ld_at(seg, p);
+        if (pts4) { rr[j] = ld_at(ri, p * 4u); ray[j] = ld_at(reinterpret_cast<const f32x3 *>(tm), p * 12u); }
+    }
+    for (int i = threadIdx.x; i < K; i += 256) soff[i] = hist[((int64_t)b * T + t) * KP + i];
+    for (int i = threadIdx.x; i < 16 * SEGP; i += 256) segcnt[i] = 0u;
     __syncthreads();
     int lab[4], rank[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int p = t * TILE + j * 256 + threadIdx.x;
-        lab[j] = -1;
+        lab[j] = (p < P && lraw[j] != 1) ? lraw[j] : -1;
         rank[j] = 0;
-        if (p < P) {
-            const int l = seg[(int64_t)b * P + p];
-            lab[j] = (l == 1) ? -1 : l;
-        }
         int todo = lab[j];
         while (true) {
             const unsigned long long pending = __ballot(todo >= 0);
             if (!pending) break;
             const int leader = (int)__ffsll((long long)pending) - 1;
-            const int cur = __shfl(todo, leader, 64);
+            const int cur = __builtin_amdgcn_readlane(todo, leader);
             const unsigned long long same = __ballot(todo == cur);
             if (todo == cur) {
                 rank[j] = __popcll(same & ((1ull << lane) - 1ull));
-                if (lane == leader) segcnt[(j * 4 + wave) * KP + cur] = (uint32_t)__popcll(same);
+                if (lane == leader) segcnt[(j * 4 + wave) * SEGP + cur] = (uint32_t)__popcll(same);
                 todo = -1;
             }
         }
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < K; k += 256) {
-        uint32_t run = hist[((int64_t)b * T + t) * KP + k];
-        for (int s = 0; s < 16; s++) {
-            const uint32_t c = segcnt[s * KP + k];
-            segcnt[s * KP + k] = run;
-            run += c;
-        }
-    }
+    segment_prefix(segcnt, SEGP, soff, K);
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 4; j++)
         if (lab[j] >= 0) {
             const int p = t * TILE + j * 256 + threadIdx.x;
-            const int64_t o = (int64_t)b * P + segcnt[(j * 4 + wave) * KP + lab[j]] + rank[j];
+            const uint32_t o = segcnt[(j * 4 + wave) * SEGP + lab[j]] + (uint32_t)rank[j];
             order[o] = (uint32_t)p;
-            if (pts4) {
-                const float r = ri[(int64_t)b * P + p];
-                pts4[o] = make_float4(r * tm[3 * p], r * tm[3 * p + 1], r * tm[3 * p + 2], r);  // transformer.py:94-101
-            }
+            if (pts4) pts4[o] = make_float4(rr[j] * ray[j].x, rr[j] * ray[j].y, rr[j] * ray[j].z, rr[j]);  // transformer.py:94-101
         }
 }
 

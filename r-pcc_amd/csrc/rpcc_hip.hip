@@ -1930,7 +1930,7 @@ extern "C" int rpcc_plane_model(const float *ri, const float *tm, const uint8_t 
     model_scan_kernel<<<B, 256, scan_lds_bytes(P, M), st>>>(nullptr, seg, nullptr, P, M, KP, T, L.sums, L.flags, L.hist,
                                                             nullptr, counts, nullptr);
     float4 *pts4 = reinterpret_cast<float4 *>(reinterpret_cast<char *>(order) + (((size_t)B * P * 4 + 255) & ~(size_t)255));
-    label_order_kernel<<<dim3(T, B), 256, (size_t)16 * KP * 4, st>>>(seg, L.hist, P, M, KP, T, order, ri, tm, pts4);
+    label_order_kernel<<<dim3(T, B), 256, (size_t)16 * (KP + 1) * 4 + (size_t)KP * 4, st>>>(seg, L.hist, P, M, KP, T, order, ri, tm, pts4);
     PlaneParams pp;
     pp.cos_cut = cos_cut; pp.thr = 0.1f; pp.min_points = 30; pp.iters = 10; pp.seed = seed;
     plane_model_kernel<<<dim3(K, B), PL_THREADS, 0, st>>>(tm, order, pts4, L.hist, counts, ground, P, M, KP, T, pp, model);
