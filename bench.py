@@ -8,8 +8,8 @@ intra-prediction -> quantisation + ordered scatter; entropy coder and file I/O e
 batch of synthetic 64x2048 sweeps (BASELINE.json configs[1]: batch = 256 frames per GPU, uniform + FPS +
 point model, accuracy 0.02).  Inputs are resident in HBM before the timed region.  N > 1: one process
 per GPU (torch.distributed / RCCL), frames sharded across ranks (weak scaling, no data-path
-collective); the compressed payloads are gathered to rank 0 over RCCL after the timed hot path of
-each step (configs[3]).  Rank 0 prints ONE JSON line.
+collective); each step ends with the exchange of configs[3]: the frames' residual streams, packed back to
+back on the device, are gathered to rank 0 over RCCL (inside the timed region, overlapped with the next steps).  Rank 0 prints ONE JSON line.
 """
 import argparse
 import ctypes as C
@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--accuracy", type=float, default=0.02)
     ap.add_argument("--cpu-sample", type=int, default=24, help="frames timed on the host for cpu_baseline (0 = skip)")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL payload gather")
+    ap.add_argument("--force-gather", action="store_true",
+                    help="N=1: run the exchange step as well (single-rank RCCL group) -- exercises the N>1 code path on one GPU")
     ap.add_argument("--slices", type=int, default=None, help="sub-batches on internal streams (library default 1)")
     ap.add_argument("--pipeline", type=int, default=3, help="batches in flight (streams); 1 = strictly serial steps")
     return ap.parse_args()
@@ -66,9 +68,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or a.force_gather:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     torch.cuda.set_device(local)
@@ -100,13 +103,22 @@ def main():
     streams = [torch.cuda.Stream(device=dev) for _ in range(depth)] if depth > 1 else [torch.cuda.current_stream()]
     buf, gms = bufs[0], gms_l[0]
 
-    gather = world > 1 and not a.no_gather
+    gather = (world > 1 or a.force_gather) and not a.no_gather
     if gather:
+        # the exchange step: per step every rank packs its frames' residual runs back to back
+        # (rpcc_pack_payload: sum(nnz) <= its point count, so `cap` entries always fit) and rank 0 receives the packed
+        # streams + the per-frame lengths.  cap = the largest rank's point count, agreed on once, outside the timing.
         import torch.distributed as dist
+        cap_t = torch.tensor([int(offs_host[-1] - offs_host[0])], dtype=torch.int64, device=dev)
+        dist.all_reduce(cap_t, op=dist.ReduceOp.MAX)
+        cap = int(cap_t.item())
+        packed_l = [torch.zeros((cap,), dtype=torch.int16, device=dev) for _ in range(depth)]
         nnz_all = [torch.empty_like(buf.nnz) for _ in range(world)]
-        pay_all = [torch.empty_like(buf.q16) for _ in range(world)] if rank == 0 else None
+        # RCCL has no int16 type ("Unconvertible NCCL type Short"): the streams travel as bytes
+        pay_all = [torch.empty((2 * cap,), dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
 
     step_no = [0]
+    pack_tot = torch.zeros((1,), dtype=torch.int64, device=dev)
 
     def step():
         k = step_no[0] % depth
@@ -115,12 +127,13 @@ def main():
             ops.compress_batch(xyz, offs, tm, gms_l[k], bufs[k], ground_threshold=0.1, acc=acc, ground_seed=rank * B,
                                offsets_host=offs_host)
             if gather:
+                ops.pack_payload(bufs[k].q16, bufs[k].nnz, packed=packed_l[k], capacity=cap, total=pack_tot)
                 dist.all_gather(nnz_all, bufs[k].nnz)
-                dist.gather(bufs[k].q16, pay_all, dst=0)
+                dist.gather(packed_l[k].view(torch.uint8), pay_all, dst=0)
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or a.force_gather:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -182,7 +195,7 @@ def main():
             "config": {"workload": "configs[1]: batch=%d synthetic Velodyne-64E frames (%dx%d) per GPU, uniform + FPS + "
                                    "point-model, accuracy=%g, cluster_num=%d, ground plane by seeded RANSAC inside the step" % (B, H, W, a.accuracy, M),
                        "frames_per_gpu_per_step": B, "batches_in_flight": depth, "sharding": "frames over ranks, no data-path collective"
-                       + (", RCCL gather of payloads to rank 0 per step" if gather else "")},
+                       + (", per step RCCL all_gather of the frame lengths + gather of the packed residual streams to rank 0" if gather else "")},
             "roofline": {"bound": "hbm", "kernel": "fps_tiled_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_source": traffic_src,
@@ -207,7 +220,7 @@ def main():
                                    "sample": "%d of the same synthetic frames, C port of the reference cpu=True path "
                                              "(oracle/), frame-parallel over %d threads" % (S, threads)}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or a.force_gather:
         dist.barrier()
         dist.destroy_process_group()
 

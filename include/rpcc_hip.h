@@ -210,6 +210,18 @@ int rpcc_decode(const uint8_t *seg, const int16_t *q16, const float *model, cons
                 int levels, const uint8_t *salience, int B, int P, int M, float *ri_rec, float *pc_rec, void *ws,
                 void *stream);
 
+/* ---- f2: the batch's residual stream, frames back to back ------------------------------------ *
+ * replaces the per-frame `residual_quantized` arrays of compress_point_cloud (utils/compress_utils.py:142,160)
+ * for a batch: packed = concat_b q16[b][:nnz[b]] (prefix sums taken on the device; no host round trip).
+ *   q16      dev i16 [B,P]   label-ordered residuals (rpcc_predict_quantize / rpcc_compress_batch)
+ *   nnz      dev i32 [B]     entries per frame
+ *   packed   dev i16 [capacity] out   entries past `capacity` are dropped (capacity >= sum of the frames' input
+ *                                     points is always enough: a pixel holds at least one point)
+ *   total    dev i64 [1] out (may be NULL)  sum of nnz = entries written
+ * What a rank hands to the D2H copy or to the RCCL gather of payloads instead of the padded array. */
+int rpcc_pack_payload(const int16_t *q16, const int32_t *nnz, int B, int P, int16_t *packed, int64_t capacity,
+                      int64_t *total, void *stream);
+
 /* ---- fused batch entry: a2..a11 for B frames (uniform framework, FPS, point model) ----------- *
  * The batched counterpart of the body of tools/compress.py:93-125 /
  * tools/compress_datalist.py:91-125 with the ground model supplied by the caller. */

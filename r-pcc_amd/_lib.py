@@ -51,6 +51,7 @@ _SIGS = {
     "rpcc_contour_encode": (C.c_int, [_VP, _I, _I, _I, _VP, _VP, _VP, _VP, _VP]),
     "rpcc_contour_decode": (C.c_int, [_VP, _VP, _I, _I, _I, _VP, _VP, _VP]),
     "rpcc_decode": (C.c_int, [_VP, _VP, _VP, _VP, C.POINTER(C.c_double), _I, _VP, _I, _I, _I, _VP, _VP, _VP, _VP]),
+    "rpcc_pack_payload": (C.c_int, [_VP, _VP, _I, _I, _VP, _I64, _VP, _VP]),
     "rpcc_plane_workspace_bytes": (C.c_size_t, [_I, _I, _I]),
     "rpcc_plane_model": (C.c_int, [_VP, _VP, _VP, _VP, _I, _I, _I, _D, C.c_uint32, _VP, _VP, _VP, _VP]),
     "rpcc_workspace_bytes": (C.c_size_t, [_I, _I, _I, _I64]),

@@ -260,3 +260,40 @@ __global__ __launch_bounds__(256) void backproject_kernel(const float *__restric
         o[0] = r * tm[3 * p]; o[1] = r * tm[3 * p + 1]; o[2] = r * tm[3 * p + 2];
     }
 }
+
+// f2: the batch's residual stream as the container holds it -- the frames' label-ordered int16 runs back to back
+// (`residual_quantized` of compress_point_cloud, utils/compress_utils.py:142,160: one array of nnz entries per
+// frame).  packed[prefix(b) + i] = q16[b][i] for i < nnz[b], prefix(b) = nnz[0] + ... + nnz[b-1] computed on the
+// device, so neither the D2H copy nor the RCCL gather of a rank's payloads moves the B*P padded array.
+// One workgroup copies PACK_EPW entries: 2-byte accesses, lane-consecutive (the destination has no alignment),
+// PACK_EPT loads in flight per lane.
+#define PACK_EPT 8
+#define PACK_EPW (256 * PACK_EPT)
+__global__ __launch_bounds__(256) void pack_payload_kernel(const int16_t *__restrict__ q16, const int32_t *__restrict__ nnz,
+                                                           int P, int64_t capacity, int16_t *__restrict__ packed,
+                                                           int64_t *__restrict__ total) {
+    const int b = blockIdx.y, B = gridDim.y;
+    const int n = min(max(nnz[b], 0), P);
+    const int i0 = blockIdx.x * PACK_EPW;
+    const bool last = b == B - 1 && blockIdx.x == 0 && total != nullptr;
+    if (i0 >= n && !last) return;
+    // prefix over the earlier frames: every wavefront computes it for itself (B is a few hundred values)
+    const int lane = threadIdx.x & 63;
+    int64_t pre = 0;
+    for (int j = lane; j < b; j += 64) pre += min(max(nnz[j], 0), P);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) pre += __shfl_xor(pre, o, RPCC_WAVE);
+    if (last && threadIdx.x == 0) *total = pre + n;
+    const int16_t *src = q16 + (int64_t)b * P;
+    int16_t v[PACK_EPT];
+#pragma unroll
+    for (int k = 0; k < PACK_EPT; k++) {
+        const int i = i0 + k * 256 + (int)threadIdx.x;
+        v[k] = src[min(i, P - 1)];
+    }
+#pragma unroll
+    for (int k = 0; k < PACK_EPT; k++) {
+        const int i = i0 + k * 256 + (int)threadIdx.x;
+        if (i < n && pre + i < capacity) packed[pre + i] = v[k];
+    }
+}

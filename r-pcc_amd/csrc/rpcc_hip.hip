@@ -1843,6 +1843,15 @@ extern "C" int rpcc_decode(const uint8_t *seg, const int16_t *q16, const float *
     return RPCC_OK;
 }
 
+extern "C" int rpcc_pack_payload(const int16_t *q16, const int32_t *nnz, int B, int P, int16_t *packed, int64_t capacity,
+                                 int64_t *total, void *stream) {
+    ARG_TRY(B > 0 && P > 0 && q16 && nnz && packed && capacity >= 0);
+    pack_payload_kernel<<<dim3((P + PACK_EPW - 1) / PACK_EPW, B), 256, 0, (hipStream_t)stream>>>(q16, nnz, P, capacity, packed,
+                                                                                              total);
+    LAUNCH_CHECK();
+    return RPCC_OK;
+}
+
 extern "C" int rpcc_backproject(const float *ri, const float *tm, int B, int P, float *pc, void *stream) {
     ARG_TRY(B > 0 && P > 0 && ri && tm && pc);
     backproject_kernel<<<dim3((P + 255) / 256, B), 256, 0, (hipStream_t)stream>>>(ri, tm, P, pc);

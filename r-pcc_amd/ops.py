@@ -248,6 +248,22 @@ def decode(seg, q16, model, tm, level_acc, salience=None, want_points=False, ws=
     return rec, pc
 
 
+def pack_payload(q16, nnz, packed=None, capacity=None, total=None):
+    """f2: the batch's residual stream with the frames back to back (what the container / the payload gather holds):
+    packed[:sum(nnz)] = concat_b q16[b][:nnz[b]].  `packed` (i16, >= capacity entries) and `total` (i64 [1]) are
+    allocated when not given; capacity defaults to B*P.  -> (packed, total)."""
+    B = q16.shape[0]
+    P = q16.numel() // B
+    if packed is None:
+        packed = torch.zeros((B * P if capacity is None else int(capacity),), dtype=torch.int16, device=_dev(q16))
+    capacity = packed.numel() if capacity is None else int(capacity)
+    assert packed.numel() >= capacity and packed.dtype == torch.int16
+    if total is None:
+        total = torch.zeros((1,), dtype=torch.int64, device=_dev(q16))
+    check(_lib.lib().rpcc_pack_payload(ptr(q16), ptr(nnz), B, P, ptr(packed), capacity, ptr(total), stream()))
+    return packed, total
+
+
 class BatchBuffers:
     """Device buffers of one batch (B frames, one geometry), allocated once and reused."""
 

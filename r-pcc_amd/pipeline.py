@@ -54,19 +54,26 @@ class BatchCompressor:
         xyz = torch.from_numpy(np.ascontiguousarray(np.concatenate([f[:, :3] for f in frames]), dtype=np.float32)).to(self.device)
         gnd = None if ground is None else torch.from_numpy(np.asarray(ground, np.float64).reshape(-1, 4)).to(self.device)
         buf, g, bits, seq, nseq, sal = self.compress_device(xyz, torch.from_numpy(offs).to(self.device), gnd)
+        # the two variable-length 16-bit streams leave the device with the frames back to back (rpcc_pack_payload), not
+        # as the padded [B,P] arrays: nnz <= points of the frame, one index per contour start <= pixels
+        qp, qtot = ops.pack_payload(buf.q16, buf.nnz, capacity=int(offs[-1]))
+        sp, stot = ops.pack_payload(seq.view(torch.int16), nseq)
         torch.cuda.synchronize()
         nnz, nseq_h = buf.nnz.cpu().numpy(), nseq.cpu().numpy()
         seg_max = buf.counts.cpu().numpy()
-        q16, bits_h, seq_h, model = buf.q16.cpu().numpy(), bits.cpu().numpy(), seq.cpu().numpy(), buf.model.cpu().numpy()
+        q16 = qp[: int(qtot.item())].cpu().numpy()
+        seq_h = sp[: int(stot.item())].cpu().numpy().view(np.uint16)
+        qo, so = np.concatenate([[0], np.cumsum(nnz)]), np.concatenate([[0], np.cumsum(nseq_h)])
+        bits_h, model = bits.cpu().numpy(), buf.model.cpu().numpy()
         sal_h = None if sal is None else sal.cpu().numpy()
         out = []
         for b in range(len(frames)):
             nrow = int(np.flatnonzero(seg_max[b])[-1]) + 1          # max(seg)+1 rows (tools/compress.py:102)
-            od = {"residual_quantized": q16[b, : nnz[b]]}
+            od = {"residual_quantized": q16[qo[b]: qo[b + 1]]}
             if sal_h is not None:
                 od["salience_level"] = sal_h[b, :nrow]
             od["contour_map"] = bits_h[b]
-            od["idx_sequence"] = seq_h[b, : nseq_h[b]]
+            od["idx_sequence"] = seq_h[so[b]: so[b + 1]]
             od["plane_param"] = model[b, :nrow]
             out.append(pack_bitstream(self.bc.compress_dict(od), uniform=self.uniform))
         return out

@@ -807,3 +807,27 @@ def test_fused_batch_many_frames_vs_oracle(env, gname, nframes):
         assert np.array_equal(seg[i], o["seg_idx"].astype(np.uint8)), (gname, i)
         n = int(nnz[i])
         assert n == o["q"].shape[0] and np.array_equal(q16[i, :n], o["q"].astype(np.int16)), (gname, i)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,P", [(1, 7), (3, 2048), (37, 4099), (256, 131072)])
+def test_pack_payload(env, B, P):
+    """f2: the frames' int16 runs back to back (prefix sums on the device), incl. empty frames, full frames, a capacity
+    that cuts the stream, and -- at the bench size -- the stream of a real batch."""
+    torch, ops = env["torch"], env["ops"]
+    rng = np.random.default_rng(B * 1000 + P)
+    q = rng.integers(-32768, 32768, (B, P), dtype=np.int64).astype(np.int16)
+    nnz = rng.integers(0, P + 1, B).astype(np.int32)
+    nnz[0] = P
+    if B > 2:
+        nnz[1], nnz[-1] = 0, P
+    want = np.concatenate([q[b, : nnz[b]] for b in range(B)])
+    packed, total = ops.pack_payload(_to(env, q), _to(env, nnz))
+    assert int(total.item()) == want.shape[0]
+    assert np.array_equal(packed[: want.shape[0]].cpu().numpy(), want)
+    assert not packed[want.shape[0]:].any().item()                      # nothing written past the stream
+    cap = max(want.shape[0] // 2, 1)
+    buf = torch.full((cap + 64,), 77, dtype=torch.int16, device=packed.device)
+    ops.pack_payload(_to(env, q), _to(env, nnz), packed=buf, capacity=cap, total=total)
+    assert int(total.item()) == want.shape[0]                           # total is the stream length, not what fitted
+    assert np.array_equal(buf[:cap].cpu().numpy(), want[:cap]) and (buf[cap:] == 77).all().item()
