@@ -91,85 +91,6 @@ struct LabelPoints {
     }
 };
 
-// NumPy fp32 pairwise sum of v[0..len) held in LDS (len <= 128): the leaf of the recursion.
-__device__ __forceinline__ float np_leaf_sum(const float *leaf, float *acc8, int len) {
-    const int lane = threadIdx.x;  // the first 8 threads of the workgroup do the leaf (every thread takes the barriers)
-    float res = 0.0f;
-    if (len < 8) {
-        if (lane == 0) {
-            res = -0.0f;
-            for (int i = 0; i < len; i++) res += leaf[i];
-            acc8[0] = res;
-        }
-    } else {
-        const int body = len - (len % 8);
-        if (lane < 8) {
-            float r = leaf[lane];
-            for (int i = 8 + lane; i < body; i += 8) r += leaf[i];
-            acc8[lane] = r;
-        }
-        __syncthreads();
-        if (lane == 0) {
-            res = ((acc8[0] + acc8[1]) + (acc8[2] + acc8[3])) + ((acc8[4] + acc8[5]) + (acc8[6] + acc8[7]));
-            for (int i = body; i < len; i++) res += leaf[i];
-            acc8[0] = res;
-        }
-    }
-    __syncthreads();
-    res = acc8[0];
-    __syncthreads();
-    return res;
-}
-
-// NumPy fp32 mean of the label's ranges (row-major order through the ordered list); every thread of the workgroup calls it.
-__device__ float np_mean_wg(const float4 *pts, int n, float *leaf, float *acc8) {
-    if (n == 0) return u2f(0xFFC00000u);
-    float total = 0.0f;
-    for (int blk = 0; blk < n; blk += 8192) {
-        const int bl = min(8192, n - blk);
-        // post-order walk of the pairwise recursion (split at len/2 rounded down to a multiple of 8)
-        int off[12], len[12], phase[12], sp = 0;
-        float lv[12];
-        off[0] = blk; len[0] = bl; phase[0] = 0; sp = 1;
-        float result = 0.0f;
-        while (sp > 0) {
-            const int t = sp - 1;
-            float v;
-            bool done = false;
-            if (len[t] <= 128) {
-                for (int i = threadIdx.x; i < len[t]; i += blockDim.x) leaf[i] = pts[off[t] + i].w;
-                __syncthreads();
-                v = np_leaf_sum(leaf, acc8, len[t]);
-                done = true;
-            } else if (phase[t] == 0) {
-                int n2 = len[t] / 2;
-                n2 -= n2 % 8;
-                phase[t] = 1;
-                off[sp] = off[t]; len[sp] = n2; phase[sp] = 0; sp++;
-            } else if (phase[t] == 1) {
-                int n2 = len[t] / 2;
-                n2 -= n2 % 8;
-                phase[t] = 2;
-                off[sp] = off[t] + n2; len[sp] = len[t] - n2; phase[sp] = 0; sp++;
-            } else {
-                v = lv[t];  // left + right already combined below
-                done = true;
-            }
-            if (done) {
-                sp--;
-                if (sp == 0) result = v;
-                else {
-                    const int par = sp - 1;
-                    if (phase[par] == 1) lv[par] = v;       // left child finished
-                    else lv[par] = lv[par] + v;             // right child finished: left + right
-                }
-            }
-        }
-        total = (blk == 0) ? result : total + result;
-    }
-    return total / (float)n;
-}
-
 struct PlaneParams {
     double cos_cut;      // reject when some pixel has v <= cos_cut (v = |n.t|/|n| * |t|); from the host's arccos
     float thr;           // RANSAC inlier distance
@@ -178,43 +99,280 @@ struct PlaneParams {
     uint32_t seed;
 };
 
+// ------------------------------------------------------------------------------------------------------------------
+// One WAVEFRONT per (label, frame).  A label has ~1000 points: as a 256-thread workgroup its chain of short passes is
+// mostly barriers (two 8-level tree sums, the leaves of the mean) and three of the four wavefronts idle during the fits.
+// A single wavefront needs no barrier and no LDS, and four times as many labels are in flight per CU.  The arithmetic is
+// the workgroup form's (ransac_plane_wg), operation by operation:
+//   * ordered fp64 sums: the specification's 256 strided partials, lane l owns partials l, l+64, l+128, l+192 -- the
+//     strides 128 and 64 of the halving tree are lane-local additions, 32 .. 1 are lane shifts;
+//   * hypotheses: lane h fits hypothesis h, the planes are broadcast with v_readlane (wave-uniform operands of the
+//     packed-fp32 scoring);
+//   * NumPy's pairwise fp32 mean: eight leaves at a time, eight lanes (= the eight accumulators) per leaf.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_bcast_f64(double v, int src) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)u, src, 64), hi = (uint32_t)__shfl((int)(uint32_t)(u >> 32), src, 64);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+template <int NV>
+__device__ __forceinline__ void wave_treesum(const double (&a)[4][NV], double (&out)[NV]) {
+#pragma unroll
+    for (int q = 0; q < NV; q++) {
+        double v = (a[0][q] + a[2][q]) + (a[1][q] + a[3][q]);  // strides 128, then 64
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v = v + __shfl_down(v, o, 64);  // lanes below the stride are the specification's
+        out[q] = wave_bcast_f64(v, 0);
+    }
+}
+
+template <int RN, int MAXH>
+__device__ int ransac_plane_wave(const float4 *__restrict__ pts, int n, int iters, float thr_f, uint32_t seed, double plane[4]) {
+    const int lane = threadIdx.x & 63;
+    plane[0] = 0; plane[1] = 0; plane[2] = 1; plane[3] = 0;
+    if (n < RN || iters > MAXH) return 0;
+    // (1) fits: hypothesis h on lane h
+    double pl[4] = {0, 0, 0, 0};
+    bool ok = false;
+    if (lane < iters) {
+        const int h = lane;
+        int idx[RN];
+#pragma unroll
+        for (int k = 0; k < RN; k++) {
+            uint32_t a = 0;
+            int cand;
+            bool dup;
+            do {
+                cand = (int)(mix32(seed, (uint32_t)(h * 16 + k), a++) % (uint32_t)n);
+                dup = false;
+#pragma unroll
+                for (int j = 0; j < RN; j++) dup |= (j < k) && (idx[j] == cand);
+            } while (dup);
+            idx[k] = cand;
+        }
+        double px[RN], py[RN], pz[RN];
+        double c[3] = {0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < RN; k++) {
+            const float4 q = pts[idx[k]];
+            px[k] = (double)q.x; py[k] = (double)q.y; pz[k] = (double)q.z;
+            c[0] += px[k]; c[1] += py[k]; c[2] += pz[k];
+        }
+        c[0] /= (double)RN; c[1] /= (double)RN; c[2] /= (double)RN;
+        double xx = 0, xy = 0, xz = 0, yy = 0, yz = 0, zz = 0;
+#pragma unroll
+        for (int k = 0; k < RN; k++) {
+            const double rx = px[k] - c[0], ry = py[k] - c[1], rz = pz[k] - c[2];
+            xx += rx * rx; xy += rx * ry; xz += rx * rz; yy += ry * ry; yz += ry * rz; zz += rz * rz;
+        }
+        ok = plane_from_moments(c, xx, xy, xz, yy, yz, zz, pl);
+    }
+    const unsigned long long okmask = __ballot(ok);
+    // (2) scoring: every hypothesis in one pass over the points
+    const float pfl[4] = {(float)pl[0], (float)pl[1], (float)pl[2], (float)pl[3]};
+    float pf[MAXH][4];
+    int cnt[MAXH];
+#pragma unroll
+    for (int q = 0; q < MAXH; q++) {
+        const bool v = q < iters && ((okmask >> q) & 1ull);
+        pf[q][0] = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(pfl[0]), q));
+        pf[q][1] = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(pfl[1]), q));
+        pf[q][2] = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(pfl[2]), q));
+        const float d = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(pfl[3]), q));
+        pf[q][3] = v ? d : __builtin_inff();  // invalid -> never an inlier
+        cnt[q] = 0;
+    }
+    for (int i0 = 0; i0 < n; i0 += 256) {
+        float4 p[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) p[u] = pts[min(i0 + 64 * u + lane, n - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const bool in = i0 + 64 * u + lane < n;
+            const rs_v2f xx = {p[u].x, p[u].x}, yy = {p[u].y, p[u].y}, zz = {p[u].z, p[u].z};
+#pragma unroll
+            for (int q = 0; q + 1 < MAXH; q += 2) {
+                const rs_v2f a = {pf[q][0], pf[q + 1][0]}, b2 = {pf[q][1], pf[q + 1][1]}, c2 = {pf[q][2], pf[q + 1][2]},
+                             d2 = {pf[q][3], pf[q + 1][3]};
+                const rs_v2f dd = ((a * xx + b2 * yy) + c2 * zz) + d2;
+                cnt[q] += in && fabsf(dd.x) < thr_f;
+                cnt[q + 1] += in && fabsf(dd.y) < thr_f;
+            }
+            if (MAXH & 1) cnt[MAXH - 1] += in && plane_inlier(pf[MAXH - 1], p[u].x, p[u].y, p[u].z, thr_f);
+        }
+    }
+    int wcnt = -1, wh = 0;
+#pragma unroll
+    for (int q = 0; q < MAXH; q++) {
+        const int c = (int)dpp_sum_u32((uint32_t)cnt[q]);
+        if (q < iters && ((okmask >> q) & 1ull) && c > wcnt) { wcnt = c; wh = q; }  // most inliers, lowest h among equals
+    }
+    if (wcnt < 0) return 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) plane[j] = wave_bcast_f64(pl[j], wh);
+    if (wcnt < 3) return wcnt;
+    const float wf[4] = {(float)plane[0], (float)plane[1], (float)plane[2], (float)plane[3]};
+    // (3) refit on the winner's inliers: ordered fp64 sums, centroid, then moments
+    double a3[4][3];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { a3[u][0] = 0; a3[u][1] = 0; a3[u][2] = 0; }
+    for (int i0 = 0; i0 < n; i0 += 256) {
+        float4 p[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) p[u] = pts[min(i0 + 64 * u + lane, n - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (i0 + 64 * u + lane < n && plane_inlier(wf, p[u].x, p[u].y, p[u].z, thr_f)) {
+                a3[u][0] += (double)p[u].x; a3[u][1] += (double)p[u].y; a3[u][2] += (double)p[u].z;
+            }
+    }
+    double c[3];
+    wave_treesum<3>(a3, c);
+    c[0] /= (double)wcnt; c[1] /= (double)wcnt; c[2] /= (double)wcnt;
+    double a6[4][6];
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int q = 0; q < 6; q++) a6[u][q] = 0;
+    for (int i0 = 0; i0 < n; i0 += 256) {
+        float4 p[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) p[u] = pts[min(i0 + 64 * u + lane, n - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (i0 + 64 * u + lane < n && plane_inlier(wf, p[u].x, p[u].y, p[u].z, thr_f)) {
+                const double rx = (double)p[u].x - c[0], ry = (double)p[u].y - c[1], rz = (double)p[u].z - c[2];
+                a6[u][0] += rx * rx; a6[u][1] += rx * ry; a6[u][2] += rx * rz; a6[u][3] += ry * ry; a6[u][4] += ry * rz; a6[u][5] += rz * rz;
+            }
+    }
+    double m[6];
+    wave_treesum<6>(a6, m);
+    double r[4];
+    if (plane_from_moments(c, m[0], m[1], m[2], m[3], m[4], m[5], r)) { plane[0] = r[0]; plane[1] = r[1]; plane[2] = r[2]; plane[3] = r[3]; }
+    return wcnt;
+}
+
+// NumPy's fp32 pairwise sum of one block (<= 8192 elements) of a label's ranges, by one wavefront, without walking the
+// recursion: its call tree (split at len/2 rounded down to a multiple of 8 until len <= 128; at most 7 splits deep for 8192
+// elements) is laid out as a binary heap in LDS -- node h has children 2h, 2h+1 --
+//   top-down, one level per step, lanes = nodes:  (offset, length) of every node;
+//   the leaves (0 < length <= 128), eight at a time: lane group g = leaf, lane j of the group = accumulator j of NumPy's
+//   unrolled-by-8 loop, then ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) and the tail elements in order;
+//   bottom-up, one level per step:  value(h) = value(2h) + value(2h+1).
+struct NpwLds {
+    int off[256], len[256];
+    float val[256];
+    unsigned char list[128];
+};
+__device__ __forceinline__ void npw_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ float np_block_sum_wave(const float4 *__restrict__ pts, int blk_off, int bl, NpwLds &W) {
+    const int lane = threadIdx.x & 63, g = lane >> 3, j = lane & 7;
+    npw_sync();
+    if (lane == 0) { W.off[1] = blk_off; W.len[1] = bl; }
+    for (int d = 0; d < 7; d++) {
+        npw_sync();
+        for (int h = (1 << d) + lane; h < (2 << d); h += 64) {
+            const int l = W.len[h], o = W.off[h];
+            int n2 = l / 2;
+            n2 -= n2 % 8;
+            const bool split = l > 128;
+            W.off[2 * h] = o; W.len[2 * h] = split ? n2 : 0;
+            W.off[2 * h + 1] = o + n2; W.len[2 * h + 1] = split ? l - n2 : 0;
+        }
+    }
+    npw_sync();
+    int nl = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const int h = c * 64 + lane;
+        const int l = h >= 1 ? W.len[h] : 0;
+        const bool leaf = l > 0 && l <= 128;
+        const unsigned long long m = __ballot(leaf);
+        if (leaf) W.list[nl + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned char)h;
+        nl += __popcll(m);
+    }
+    npw_sync();
+    for (int l0 = 0; l0 < nl; l0 += 8) {
+        const int h = W.list[min(l0 + g, nl - 1)];
+        const int o = W.off[h], l = W.len[h];
+        float res;
+        if (l < 8) {
+            res = -0.0f;
+            for (int i = 0; i < l; i++) res += pts[o + i].w;
+        } else {
+            const int body = l - (l % 8);
+            float v[16];
+#pragma unroll
+            for (int q = 0; q < 16; q++) v[q] = pts[o + min(8 * q + j, l - 1)].w;
+            float r = v[0];
+#pragma unroll
+            for (int q = 1; q < 16; q++) if (8 * q + j < body) r += v[q];
+            const float r1 = r + __shfl_xor(r, 1, 64);       // (r0+r1), (r2+r3), ...
+            const float r2 = r1 + __shfl_xor(r1, 2, 64);     // (r0+r1)+(r2+r3), ...
+            res = r2 + __shfl_xor(r2, 4, 64);                // fp addition commutes bit for bit: every lane of the group holds NumPy's value
+            for (int i = body; i < l; i++) res += pts[o + i].w;
+        }
+        if (j == 0 && l0 + g < nl) W.val[h] = res;
+    }
+    for (int d = 6; d >= 0; d--) {
+        npw_sync();
+        for (int h = (1 << d) + lane; h < (2 << d); h += 64)
+            if (W.len[h] > 128) W.val[h] = W.val[2 * h] + W.val[2 * h + 1];
+    }
+    npw_sync();
+    return W.val[1];
+}
+// NumPy fp32 mean of a label's ranges by one wavefront: 8192-element blocks added in sequence.
+__device__ float np_mean_wave(const float4 *__restrict__ pts, int n, NpwLds &W) {
+    if (n == 0) return u2f(0xFFC00000u);
+    float total = 0.0f;
+    for (int blk = 0; blk < n; blk += 8192) {
+        const float r = np_block_sum_wave(pts, blk, min(8192, n - blk), W);
+        total = (blk == 0) ? r : total + r;
+    }
+    return total / (float)n;
+}
+// ... by a workgroup: the wavefronts take a block each, the block sums are added in block order.
+__device__ float np_mean_wg(const float4 *__restrict__ pts, int n, NpwLds *W, float *part) {
+    if (n == 0) return u2f(0xFFC00000u);
+    const int wave = threadIdx.x >> 6, NW = blockDim.x >> 6;
+    float total = 0.0f;
+    for (int blk0 = 0; blk0 < n; blk0 += 8192 * NW) {
+        const int blk = blk0 + 8192 * wave;
+        if (blk < n) {
+            const float r = np_block_sum_wave(pts, blk, min(8192, n - blk), W[wave]);
+            if ((threadIdx.x & 63) == 0) part[wave] = r;
+        }
+        __syncthreads();
+        for (int w = 0; w < NW && blk0 + 8192 * w < n; w++) total = (blk0 == 0 && w == 0) ? part[0] : total + part[w];
+        __syncthreads();
+    }
+    return total / (float)n;
+}
+
 #define PL_THREADS 256
 #define PL_MAXH 16
-// One 256-thread workgroup per (label, frame): the workgroup form of the RANSAC specification (ransac_plane_wg: thread t
-// owns the strided partial t of the ordered fp64 sums), four wavefronts share the point loops.
-__global__ __launch_bounds__(PL_THREADS) void plane_model_kernel(const float *__restrict__ tm,
-                                                                 const uint32_t *__restrict__ order_all,
-                                                                 const float4 *__restrict__ pts_all,
-                                                                 const uint32_t *__restrict__ hist,
-                                                                 const int32_t *__restrict__ counts,
-                                                                 const double *__restrict__ ground, int P, int M, int KP, int T,
-                                                                 PlaneParams pp, float *__restrict__ model) {
-    __shared__ float leaf[128];
-    __shared__ float acc8[8];
-    __shared__ double sred[6 * RS_NT];
-    __shared__ double swin[64 + PL_MAXH * 4];
-    __shared__ int sbest[32];
-    const int k = blockIdx.x, b = blockIdx.y, K = M + 2, tid = threadIdx.x;
-    float *row = model + ((int64_t)b * K + k) * 4;
-    if (k == 0) {
-        if (tid < 4) row[tid] = ground ? (float)ground[4 * b + tid] : 0.0f;
-        return;
-    }
-    if (k == 1) {
-        if (tid < 4) row[tid] = 0.0f;
-        return;
-    }
-    const int n = counts[(int64_t)b * K + k];
-    const uint32_t base = hist[((int64_t)b * T) * KP + k];  // tile 0 offset = start of label k in the ordered list
-    const uint32_t *order = order_all + (int64_t)b * P + base;
-    const float4 *pl_pts = pts_all + (int64_t)b * P + base;
+// Workgroup form for one label (all 256 threads call it): ransac_plane_wg with thread t owning the strided partial t of the
+// ordered fp64 sums, four wavefronts sharing the point loops.  Used for the large labels, where one wavefront alone would be
+// the tail of the launch.
+struct PlaneWgLds {
+    float part[8];
+    double sred[6 * RS_NT];
+    double swin[64 + PL_MAXH * 4];
+    int sbest[32];
+};
+__device__ void plane_label_wg(const float *__restrict__ tm, const uint32_t *__restrict__ order, const float4 *__restrict__ pl_pts,
+                               int n, uint32_t seed, const PlaneParams &pp, PlaneWgLds &S, NpwLds *NW_, float *__restrict__ row) {
+    const int tid = threadIdx.x;
     bool use_plane = false;
     double plane[4] = {0, 0, 0, 0};
     if (n >= pp.min_points) {
         LabelPoints pts;
         pts.pts = pl_pts; pts.n = n;
-        const uint32_t seed = mix32(pp.seed, (uint32_t)b, (uint32_t)k);
-        ransac_plane_wg<4, PL_THREADS, PL_MAXH, 4>(pts, pp.iters, (double)pp.thr, seed, plane, sred, swin, sbest);
+        ransac_plane_wg<4, PL_THREADS, PL_MAXH, 4>(pts, pp.iters, (double)pp.thr, seed, plane, S.sred, S.swin, S.sbest);
         // plane_angle_validation (segment_utils.py:84-93)
         const double a = plane[0], bb = plane[1], c = plane[2];
         const double nrm = sqrt((a * a + bb * bb) + c * c);
@@ -242,7 +400,88 @@ __global__ __launch_bounds__(PL_THREADS) void plane_model_kernel(const float *__
     if (use_plane) {
         if (tid < 4) row[tid] = (float)plane[tid];
     } else {
-        const float mean = np_mean_wg(pl_pts, n, leaf, acc8);
+        const float mean = np_mean_wg(pl_pts, n, NW_, S.part);
         if (tid < 4) row[tid] = tid == 3 ? mean : 0.0f;
+    }
+    __syncthreads();  // the next label of the workgroup reuses S
+}
+
+// One 256-thread workgroup per four consecutive labels of a frame.  Labels with more than `big` points are taken one after
+// the other by the whole workgroup (first: they are the tail), the others by one wavefront each, all four at once.
+// Measured on 256 frames of 64x2048 (26 k labels: 48 % below 30 points, median 35, 90 % below 900, largest 43 k), whole
+// rpcc_plane_model call: workgroup per label with the recursive mean 1.41 ms; this kernel 0.72 ms for big = 512 .. 8192
+// (0.74 at 256, 0.98 with every label on one wavefront: the 43 k label is the tail then); register budget for 6 waves per
+// SIMD 0.67 ms (default 4 waves: 0.72, 8 waves: 0.73).
+#define PL_BIG 2048
+template <int MAXH>
+__global__ __launch_bounds__(PL_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8))) void plane_model_kernel(const float *__restrict__ tm,
+                                                                 const uint32_t *__restrict__ order_all,
+                                                                 const float4 *__restrict__ pts_all,
+                                                                 const uint32_t *__restrict__ hist,
+                                                                 const int32_t *__restrict__ counts,
+                                                                 const double *__restrict__ ground, int P, int M, int KP, int T,
+                                                                 PlaneParams pp, int big, float *__restrict__ model) {
+    __shared__ PlaneWgLds S;
+    __shared__ NpwLds npw[PL_THREADS / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y, K = M + 2, k0 = blockIdx.x * (PL_THREADS / 64);
+    for (int w = 0; w < PL_THREADS / 64; w++) {   // workgroup-uniform
+        const int kk = k0 + w;
+        if (kk < 2 || kk >= K) continue;
+        const int nn = counts[(int64_t)b * K + kk];
+        if (nn <= big) continue;
+        const uint32_t base = hist[((int64_t)b * T) * KP + kk];  // tile 0 offset = start of label kk in the ordered list
+        plane_label_wg(tm, order_all + (int64_t)b * P + base, pts_all + (int64_t)b * P + base, nn, mix32(pp.seed, (uint32_t)b, (uint32_t)kk),
+                       pp, S, npw, model + ((int64_t)b * K + kk) * 4);
+    }
+    const int k = k0 + wave;
+    if (k >= K) return;
+    float *row = model + ((int64_t)b * K + k) * 4;
+    if (k == 0) {
+        if (lane < 4) row[lane] = ground ? (float)ground[4 * b + lane] : 0.0f;
+        return;
+    }
+    if (k == 1) {
+        if (lane < 4) row[lane] = 0.0f;
+        return;
+    }
+    const int n = counts[(int64_t)b * K + k];
+    if (n > big) return;
+    const uint32_t base = hist[((int64_t)b * T) * KP + k];
+    const uint32_t *order = order_all + (int64_t)b * P + base;
+    const float4 *pts = pts_all + (int64_t)b * P + base;
+    bool use_plane = false;
+    double plane[4] = {0, 0, 0, 0};
+    if (n >= pp.min_points) {
+        const uint32_t seed = mix32(pp.seed, (uint32_t)b, (uint32_t)k);
+        ransac_plane_wave<4, MAXH>(pts, n, pp.iters, pp.thr, seed, plane);
+        // plane_angle_validation (segment_utils.py:84-93)
+        const double a = plane[0], bb = plane[1], c = plane[2];
+        const double nrm = sqrt((a * a + bb * bb) + c * c);
+        bool bad = false, nan = false;
+        for (int i0 = 0; i0 < n; i0 += 256) {
+            uint32_t p[4];
+            float tx[4], ty[4], tz[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) p[u] = order[min(i0 + 64 * u + lane, n - 1)];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { tx[u] = tm[3 * p[u]]; ty[u] = tm[3 * p[u] + 1]; tz[u] = tm[3 * p[u] + 2]; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const double dot = fabs(((double)tx[u] * a + (double)ty[u] * bb) + (double)tz[u] * c);
+                const float tn = sqrtf((tx[u] * tx[u] + ty[u] * ty[u]) + tz[u] * tz[u]);
+                const double v = dot / nrm * (double)tn;
+                const bool in = i0 + 64 * u + lane < n;
+                nan |= in && ((v != v) || v > 1.0);   // arccos gives NaN, alpha.max() is NaN, NaN > threshold is False
+                bad |= in && v <= pp.cos_cut;
+            }
+        }
+        use_plane = __ballot(nan) != 0ull || __ballot(bad) == 0ull;
+    }
+    if (use_plane) {
+        if (lane < 4) row[lane] = (float)plane[lane];
+    } else {
+        const float mean = np_mean_wave(pts, n, npw[wave]);
+        if (lane < 4) row[lane] = lane == 3 ? mean : 0.0f;
     }
 }

@@ -1942,7 +1942,8 @@ extern "C" int rpcc_plane_model(const float *ri, const float *tm, const uint8_t 
     label_order_kernel<<<dim3(T, B), 256, (size_t)16 * (KP + 1) * 4 + (size_t)KP * 4, st>>>(seg, L.hist, P, M, KP, T, order, ri, tm, pts4);
     PlaneParams pp;
     pp.cos_cut = cos_cut; pp.thr = 0.1f; pp.min_points = 30; pp.iters = 10; pp.seed = seed;
-    plane_model_kernel<<<dim3(K, B), PL_THREADS, 0, st>>>(tm, order, pts4, L.hist, counts, ground, P, M, KP, T, pp, model);
+    plane_model_kernel<10><<<dim3((K + PL_THREADS / 64 - 1) / (PL_THREADS / 64), B), PL_THREADS, 0, st>>>(tm, order, pts4, L.hist, counts, ground, P, M,
+                                                                                                     KP, T, pp, PL_BIG, model);
     LAUNCH_CHECK();
     return RPCC_OK;
 }

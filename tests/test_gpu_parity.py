@@ -831,3 +831,33 @@ def test_pack_payload(env, B, P):
     ops.pack_payload(_to(env, q), _to(env, nnz), packed=buf, capacity=cap, total=total)
     assert int(total.item()) == want.shape[0]                           # total is the stream length, not what fitted
     assert np.array_equal(buf[:cap].cpu().numpy(), want[:cap]) and (buf[cap:] == 77).all().item()
+
+
+@pytest.mark.parametrize("angle", [75, 0.001])
+def test_plane_model_large_labels(env, angle):
+    """a9 on labels of every size class of the kernel: merged labels of tens of thousands of pixels (workgroup path, several
+    8192-element blocks of NumPy's pairwise mean), a few thousand (around the workgroup / wavefront switch) and the
+    ordinary small ones; angle 0.001 rejects every plane, so every label goes through the fp32 mean."""
+    torch, ops, orc = env["torch"], env["ops"], env["orc"]
+    case = "synth_64x2048"
+    c = MAN["cases"][case]
+    z = np.load(os.path.join(HERE, "golden", case + ".npz"))
+    g, geom, tm = _geom(env, c["geom"])
+    ri_np = orc.project(z["xyz"], g)
+    seg_np = z["seg_idx"].copy()
+    seg_np[seg_np >= 60] = 60
+    seg_np[(seg_np >= 10) & (seg_np < 20)] = 10
+    seg_np[(seg_np >= 30) & (seg_np < 33)] = 30
+    cnt = np.bincount(seg_np.reshape(-1), minlength=102)
+    assert cnt[60] > 3 * 8192 and cnt[2:].min() == 0 and (cnt[2:] > 2048).sum() >= 2
+    pc = orc.backproject(ri_np, tm)
+    gm = z["ground_model"][None]
+    model = ops.plane_model(_to(env, ri_np[None]), _to(env, tm), _to(env, seg_np[None]), 100, angle_threshold=angle, seed=9,
+                            ground=_to(env, gm)).cpu().numpy()
+    exp = orc.cluster_modeling_plane(pc, ri_np, seg_np.astype(np.int64), tm, angle_deg=angle, seed=9, frame=0).astype(np.float32)
+    nrow = int(seg_np.max()) + 1
+    assert _beq(model[0, 1:nrow], exp)
+    if angle < 1:
+        assert not (exp[1:, :3] != 0).any()
+    else:
+        assert (exp[:, :3] != 0).any(1).sum() > 5

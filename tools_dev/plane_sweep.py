@@ -22,3 +22,5 @@ for ang in (89.9, 75, 40, 0.001):
     m = ops.plane_model(buf.ri, tm, buf.seg, M, angle_threshold=ang, ground=g)
     frac = float((m[:, 2:, :3] != 0).any(-1).float().mean())
     print("angle %5.1f  plane rows %.2f  %.3f ms" % (ang, frac, timeit(lambda: ops.plane_model(buf.ri, tm, buf.seg, M, angle_threshold=ang, ground=g))))
+c = ops.plane_model(buf.ri, tm, buf.seg, M, angle_threshold=75, ground=g, want_counts=True)[1][:, 2:].flatten().float()
+print("label sizes: mean %.0f  <30: %.2f  quantiles 50/90/99/99.9/max: %s" % (c.mean(), (c < 30).float().mean(), [int(torch.quantile(c, q)) for q in (0.5, 0.9, 0.99, 0.999, 1.0)]))
