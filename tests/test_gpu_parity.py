@@ -852,7 +852,8 @@ def test_plane_model_large_labels(env, angle):
     assert cnt[60] > 3 * 8192 and cnt[2:].min() == 0 and (cnt[2:] > 2048).sum() >= 2
     pc = orc.backproject(ri_np, tm)
     gm = z["ground_model"][None]
-    model = ops.plane_model(_to(env, ri_np[None]), _to(env, tm), _to(env, seg_np[None]), 100, angle_threshold=angle, seed=9,
+    # cluster_num 59 -> 61 model rows: the last workgroup of the frame (four labels each) is partly empty
+    model = ops.plane_model(_to(env, ri_np[None]), _to(env, tm), _to(env, seg_np[None]), 59, angle_threshold=angle, seed=9,
                             ground=_to(env, gm)).cpu().numpy()
     exp = orc.cluster_modeling_plane(pc, ri_np, seg_np.astype(np.int64), tm, angle_deg=angle, seed=9, frame=0).astype(np.float32)
     nrow = int(seg_np.max()) + 1
