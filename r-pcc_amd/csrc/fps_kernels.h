@@ -65,16 +65,11 @@ __device__ __forceinline__ int fps_tile_of(const FpsTiling &g, int p) {
     return p / FPS_TILE;
 }
 
-#define FPS_PEND 8  // deferred centres a tile can hold before it is visited regardless
-#define FPS_PF 3    // of which this many are prefetched into registers with the tile
 struct FpsLds {
     float *lo[3], *hi[3], *tmax, *cx[3];
     uint32_t *targ;
     uint32_t *torg;   // range image: first pixel of the tile (22 bits) | valid columns - 1 (5 bits) << 22 | valid rows - 1 (5 bits) << 27
     uint16_t *work;
-    uint16_t *plist;  // [T][FPS_PEND] deferred centres (sample numbers) of the tile
-    uint8_t *pcnt;    // [T] how many
-    float *cen;       // [M][3] coordinates of the samples taken so far
     __device__ FpsLds(unsigned char *base, int T) {
         float *f = reinterpret_cast<float *>(base);
         for (int a = 0; a < 3; a++) { lo[a] = f + (size_t)a * T; hi[a] = f + (size_t)(3 + a) * T; cx[a] = f + (size_t)(7 + a) * T; }
@@ -82,15 +77,10 @@ struct FpsLds {
         targ = reinterpret_cast<uint32_t *>(f + (size_t)10 * T);
         torg = reinterpret_cast<uint32_t *>(f + (size_t)11 * T);
         work = reinterpret_cast<uint16_t *>(f + (size_t)12 * T);
-        plist = work + T;
-        pcnt = reinterpret_cast<uint8_t *>(plist + (size_t)T * FPS_PEND);
-        cen = reinterpret_cast<float *>(base + (((size_t)T * (51 + 2 * FPS_PEND) + 15) & ~(size_t)15));
     }
 };
-static inline size_t fps_tiled_lds_bytes(int T, int M) { return (((size_t)T * (51 + 2 * FPS_PEND) + 15) & ~(size_t)15) + (size_t)M * 12 + 64; }
-// the tile table (67 B/tile) and the sample coordinates (12 B each) must fit the 160 KiB LDS of one CU next to the static part
-static inline bool fps_tiled_fits(int T, int M) { return M <= 65535 && fps_tiled_lds_bytes(T, M) <= 156 * 1024; }
-#define FPS_TILED_MAX_TILES 2300  // bound used for workspace sizing; the launch checks fps_tiled_fits(T, M)
+static inline size_t fps_tiled_lds_bytes(int T) { return (size_t)T * 50 + 64; }
+#define FPS_TILED_MAX_TILES 3200  // 50 B/tile must fit the 160 KiB LDS of one CU
 
 // Per-tile reductions shared by the FPS kernel and the ground-mask kernel.  x/y/z/nt: the lane's two
 // points; cand: they take part in the bounding box; valid: they exist.  Writes the 11 table values of
@@ -171,11 +161,11 @@ __global__ __launch_bounds__(FPS_TT) void fps_tiled_kernel(const float *__restri
                                                                 const int32_t *__restrict__ info, FpsTiling g, int M,
                                                                 int32_t *__restrict__ out_idx,
                                                                 float *__restrict__ out_cen,
-                                                                const float *__restrict__ tiletab, int flush) {
+                                                                const float *__restrict__ tiletab) {
     extern __shared__ __attribute__((aligned(16))) unsigned char fps_smem[];
     __shared__ unsigned long long red[FPS_TT / 64];
-    __shared__ unsigned long long wbest;
-    __shared__ int wcount2[2];
+    __shared__ int redt[FPS_TT / 64];
+    __shared__ int wcount;
     const int T = g.T, N = g.N;
     FpsLds L(fps_smem, T);
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -192,14 +182,9 @@ __global__ __launch_bounds__(FPS_TT) void fps_tiled_kernel(const float *__restri
     if (tid == 0) {
         out_idx[0] = old;
         if (out_cen) { out_cen[0] = c0; out_cen[1] = c1; out_cen[2] = c2; }
-        wcount2[0] = 0; wcount2[1] = 0;
+        wcount = 0;
     }
 
-    for (int t = tid; t < T; t += FPS_TT) {
-        L.pcnt[t] = 0;
-#pragma unroll
-        for (int i = 0; i < FPS_PF; i++) L.plist[t * FPS_PEND + i] = 0;  // prefetched unconditionally
-    }
     if (RANGE) {
         for (int t = tid; t < T; t += FPS_TT) {
             const int tr = t / g.tcols, tc = t - tr * g.tcols;
@@ -258,82 +243,38 @@ __global__ __launch_bounds__(FPS_TT) void fps_tiled_kernel(const float *__restri
         if (lane == 0) { L.tmax[t] = wt; L.targ[t] = widx; L.cx[0][t] = wx; L.cx[1][t] = wy; L.cx[2][t] = wz; }
     };
 
-    // Deferred updates.  A tile that a new sample could change (bound < tile maximum) is not visited at once: the sample
-    // number is appended to the tile's pending list, and the tile's stored maximum stays an UPPER bound of its true maximum
-    // (distances only shrink).  The next sample is the arg-max over the true maxima, so per iteration only the pending tiles
-    // whose upper bound reaches the best EXACT tile (no pending samples) have to be brought up to date -- all of them in one
-    // go, after which every tile that could hold the maximum is exact.  The others keep their lists (merged into one visit
-    // later, or never needed).  Skipping stays exact: bound >= stored maximum >= every true temp of the tile.
-    // key of a (maximum, index) pair: larger value first, then lower index; 0 = no candidate
-    auto make_key = [&](float v, uint32_t i) -> unsigned long long {
-        const uint32_t h = (v < 0.0f) ? 0u : f2u(v) + 1u;
-        return h ? (((unsigned long long)h << 32) | (unsigned long long)(0xFFFFFFFFu - i)) : 0ull;
-    };
-    auto wg_max_key = [&](unsigned long long k) -> unsigned long long {  // one barrier
-        uint32_t hi = (uint32_t)(k >> 32), lo = (uint32_t)k;
-        uint32_t mh = dpp_max_u32(hi), ml = dpp_max_u32(hi == mh ? lo : 0u);
-        if (lane == 0) red[wave] = ((unsigned long long)mh << 32) | ml;
+    // arg-max over the tile table -> next centre (index and coordinates)
+    auto select_next = [&]() {
+        uint32_t hi = 0u, ix = 0xFFFFFFFFu;  // orderable value, index
+        int bt = 0;
+        for (int t = tid; t < T; t += FPS_TT) {
+            const float v = L.tmax[t];
+            const uint32_t h = (v < 0.0f) ? 0u : f2u(v) + 1u, i = L.targ[t];
+            if (h > hi || (h == hi && i < ix)) { hi = h; ix = i; bt = t; }
+        }
+        uint32_t vmax = dpp_max_u32(hi);
+        uint32_t imin = dpp_min_u32(hi == vmax ? ix : 0xFFFFFFFFu);
+        {
+            const unsigned long long mm = __ballot(hi == vmax && ix == imin);
+            const int wl = __builtin_amdgcn_readfirstlane((int)__ffsll((long long)mm) - 1);
+            const int wt_ = __builtin_amdgcn_readlane(bt, wl < 0 ? 0 : wl);
+            if (lane == 0) { red[wave] = ((unsigned long long)vmax << 32) | imin; redt[wave] = wt_; }
+        }
         __syncthreads();
-        const unsigned long long r = red[lane % (FPS_TT / 64)];
-        hi = (uint32_t)(r >> 32); lo = (uint32_t)r;
-        mh = dpp_max_u32(hi); ml = dpp_max_u32(hi == mh ? lo : 0u);
-        return ((unsigned long long)mh << 32) | ml;
-    };
-    // bring a tile up to date: apply its pending samples, write the changed temps, refresh the table entry
-    // a tile's pending samples, fetched from LDS while the tile's global loads are in flight (the first FPS_PF of them)
-    struct PendRegs { int cnt; float kx[FPS_PF], ky[FPS_PF], kz[FPS_PF]; };
-    auto load_pending = [&](int t, PendRegs &pr) {
-        pr.cnt = L.pcnt[t];
-#pragma unroll
-        for (int i = 0; i < FPS_PF; i++) {
-            const int k = L.plist[t * FPS_PEND + i];  // slots past cnt hold stale sample numbers (< M): harmless, unused
-            pr.kx[i] = L.cen[3 * k]; pr.ky[i] = L.cen[3 * k + 1]; pr.kz[i] = L.cen[3 * k + 2];
-        }
-    };
-    auto apply_tile = [&](int t, const TileRegs &q, const PendRegs &pr, bool publish) {
-        const int cnt = pr.cnt;
-        bool valid[FPS_NH];
-        float nt[FPS_NH];
-#pragma unroll
-        for (int h = 0; h < FPS_NH; h++) { valid[h] = q.p[h] >= 0; nt[h] = q.tp[h]; }
-#pragma unroll
-        for (int i = 0; i < FPS_PF; i++) {
-            if (i < cnt) {  // wave-uniform
-#pragma unroll
-                for (int h = 0; h < FPS_NH; h++) {
-                    const float dx = q.x[h] - pr.kx[i], dy = q.y[h] - pr.ky[i], dz = q.z[h] - pr.kz[i];
-                    const float d = (dx * dx + dy * dy) + dz * dz;  // sampling_gpu.cu:64, un-fused
-                    nt[h] = d < nt[h] ? d : nt[h];                   // == fminf(d, temp); min is order-independent
-                }
-            }
-        }
-        for (int i = FPS_PF; i < cnt; i++) {
-            const int k = L.plist[t * FPS_PEND + i];
-            const float k0 = L.cen[3 * k], k1 = L.cen[3 * k + 1], k2 = L.cen[3 * k + 2];
-#pragma unroll
-            for (int h = 0; h < FPS_NH; h++) {
-                const float dx = q.x[h] - k0, dy = q.y[h] - k1, dz = q.z[h] - k2;
-                const float d = (dx * dx + dy * dy) + dz * dz;
-                nt[h] = d < nt[h] ? d : nt[h];
-            }
-        }
-        bool changed = false;
-#pragma unroll
-        for (int h = 0; h < FPS_NH; h++) {
-            const bool ch = valid[h] && nt[h] != q.tp[h];
-            if (ch) st_f32(temp, (uint32_t)q.p[h] * 4u, nt[h]);
-            changed |= ch;
-        }
-        float wt = L.tmax[t];
-        uint32_t widx = L.targ[t];
-        if (__ballot(changed) != 0ull) {
-            float wx, wy, wz;
-            fps_tile_argmax(q.x, q.y, q.z, nt, valid, q.p, wt, wx, wy, wz, widx);
-            if (lane == 0) { L.tmax[t] = wt; L.targ[t] = widx; L.cx[0][t] = wx; L.cx[1][t] = wy; L.cx[2][t] = wz; }
-        }
-        if (lane == 0) {
-            L.pcnt[t] = 0;
-            if (publish) atomicMax(&wbest, make_key(wt, widx));
+        const unsigned long long k = red[lane % (FPS_TT / 64)];
+        const int kt = redt[lane % (FPS_TT / 64)];
+        hi = (uint32_t)(k >> 32); ix = (uint32_t)k;
+        vmax = dpp_max_u32(hi);
+        imin = dpp_min_u32(hi == vmax ? ix : 0xFFFFFFFFu);
+        const unsigned long long mm = __ballot(hi == vmax && ix == imin);
+        const int wl = __builtin_amdgcn_readfirstlane((int)__ffsll((long long)mm) - 1);
+        const int t = __builtin_amdgcn_readlane(kt, wl < 0 ? 0 : wl);
+        if (imin == 0xFFFFFFFFu) {  // no candidate anywhere: keep indices defined (the reference would fail)
+            old = 0;
+            fps_load_point<RANGE>(src, tx, ty, tz, 0, c0, c1, c2);
+        } else {
+            old = (int)imin;
+            c0 = L.cx[0][t]; c1 = L.cx[1][t]; c2 = L.cx[2][t];
         }
     };
 
@@ -363,121 +304,55 @@ __global__ __launch_bounds__(FPS_TT) void fps_tiled_kernel(const float *__restri
         }
         __syncthreads();
     }
-    long long acc_a = 0, acc_b = 0, acc_c = 0, acc_n = 0, tq = 0, acc_d = 0, acc_e = 0, acc_r = 0;
-    const bool prof = g_dbg_stamps != nullptr && blockIdx.x == 0 && tid == 0;
-    DBG_STAMP(9);
-    for (int j = 1; j < M; j++) {
-        if (prof) tq = (long long)__builtin_readcyclecounter();
-        // sample j-1 = (old, c).  j == 1: the first pass applied it to every tile; later samples are deferred
-        const bool mark = j > 1;
-        if (tid == 0) { L.cen[3 * (j - 1)] = c0; L.cen[3 * (j - 1) + 1] = c1; L.cen[3 * (j - 1) + 2] = c2; }
-        unsigned long long kb = 0ull;
-        for (int t = tid; t < T; t += FPS_TT) {
-            const float tmx = L.tmax[t];
-            int cnt = L.pcnt[t];
-            if (mark) {
-                const float g0 = fmaxf(fmaxf(L.lo[0][t] - c0, c0 - L.hi[0][t]), 0.0f);
-                const float g1 = fmaxf(fmaxf(L.lo[1][t] - c1, c1 - L.hi[1][t]), 0.0f);
-                const float g2 = fmaxf(fmaxf(L.lo[2][t] - c2, c2 - L.hi[2][t]), 0.0f);
-                const float bound = (g0 * g0 + g1 * g1) + g2 * g2;
-                if (bound < tmx) {  // cnt < FPS_PEND here: a full list is emptied in the iteration that fills it
-                    L.plist[t * FPS_PEND + cnt] = (uint16_t)(j - 1);
-                    cnt++;
-                    L.pcnt[t] = (uint8_t)cnt;
-                }
-            }
-            if (cnt == 0) {
-                const unsigned long long k = make_key(tmx, L.targ[t]);
-                kb = k > kb ? k : kb;
-            }
-        }
-        const unsigned long long best = wg_max_key(kb);  // best exact tile (0: none)
-        const uint32_t bv = (uint32_t)(best >> 32);
-        int *wc = &wcount2[j & 1];
-        for (int t = tid; t < T; t += FPS_TT) {
-            const int cnt = L.pcnt[t];
-            const float tmx = L.tmax[t];
-            const uint32_t hv = (tmx < 0.0f) ? 0u : f2u(tmx) + 1u;
-            const bool act = cnt > 0 && (hv >= bv || cnt == FPS_PEND);
-            const unsigned long long m = __ballot(act);
-            if (m) {
-                int base = 0;
-                if (lane == (int)__ffsll((long long)m) - 1) base = atomicAdd(wc, __popcll(m));
-                base = __shfl(base, (int)__ffsll((long long)m) - 1, 64);
-                if (act) L.work[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)t;
-            }
-        }
-        if (tid == 0) wbest = best;
-        __syncthreads();
-        const int n = *wc;
-        if (tid == 0) wcount2[(j + 1) & 1] = 0;  // the other counter: last read before this barrier, next used after the next one
-        if (prof) { const long long t1 = (long long)__builtin_readcyclecounter(); acc_a += t1 - tq; tq = t1; acc_n += n; }
-        if (n > 0) {
-            for (int e = wave; e < n; e += NW * GROUP) {
-                TileRegs q[GROUP];
-                PendRegs pr[GROUP];
-                int tt[GROUP];
-                long long ta = 0;
-                if (prof) ta = (long long)__builtin_readcyclecounter();
-#pragma unroll
-                for (int gi = 0; gi < GROUP; gi++) {
-                    const int ee = e + gi * NW;
-                    tt[gi] = (int)L.work[ee < n ? ee : n - 1];
-                    load_tile(tt[gi], q[gi]);   // unconditional (a repeated tile for the tail is harmless and unused)
-                }
-#pragma unroll
-                for (int gi = 0; gi < GROUP; gi++) load_pending(tt[gi], pr[gi]);
-                if (prof) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const long long t1 = (long long)__builtin_readcyclecounter(); acc_d += t1 - ta; ta = t1; acc_r++; }
-#pragma unroll
-                for (int gi = 0; gi < GROUP; gi++) if (e + gi * NW < n) apply_tile(tt[gi], q[gi], pr[gi], true);
-                if (prof) { const long long t1 = (long long)__builtin_readcyclecounter(); acc_e += t1 - ta; }
-            }
-            __syncthreads();
-        }
-        if (prof) { const long long t1 = (long long)__builtin_readcyclecounter(); acc_b += t1 - tq; tq = t1; }
-        const unsigned long long w = wbest;
-        if (w == 0ull) {  // no candidate anywhere: keep indices defined (the reference would fail)
-            old = 0;
-            fps_load_point<RANGE>(src, tx, ty, tz, 0, c0, c1, c2);
-        } else {
-            old = (int)(0xFFFFFFFFu - (uint32_t)w);
-            const int t = fps_tile_of<RANGE>(g, old);
-            c0 = L.cx[0][t]; c1 = L.cx[1][t]; c2 = L.cx[2][t];
-        }
-        if (prof) { const long long t1 = (long long)__builtin_readcyclecounter(); acc_c += t1 - tq; tq = t1; }
-        if (tid == 0) { out_idx[j] = old; if (out_cen) { out_cen[3 * j] = c0; out_cen[3 * j + 1] = c1; out_cen[3 * j + 2] = c2; } }
+    if (M > 1) {
+        DBG_STAMP(9);
+        select_next();
+        DBG_STAMP(10);
+        if (tid == 0) { out_idx[1] = old; if (out_cen) { out_cen[3] = c0; out_cen[4] = c1; out_cen[5] = c2; } }
     }
-    DBG_STAMP(16);
-    if (prof) { g_dbg_stamps[24] = acc_a; g_dbg_stamps[25] = acc_b; g_dbg_stamps[26] = acc_c; g_dbg_stamps[27] = acc_n; g_dbg_stamps[28] = acc_d; g_dbg_stamps[29] = acc_e; g_dbg_stamps[30] = acc_r; }
-    if (flush && M > 2) {  // the caller wants temp = the brute-force result: bring every tile up to date
-        int *wc = &wcount2[M & 1];  // zeroed in the last iteration and not used since
+    long long acc_a = 0, acc_b = 0, acc_c = 0, acc_n = 0, tq = 0;
+    const bool prof = g_dbg_stamps != nullptr && blockIdx.x == 0 && tid == 0;
+    for (int j = 2; j < M; j++) {
+        if (prof) tq = (long long)__builtin_readcyclecounter();
+        // tile test against the new centre; active tiles go to the work list
         for (int t = tid; t < T; t += FPS_TT) {
-            const bool act = L.pcnt[t] > 0;
+            const float g0 = fmaxf(fmaxf(L.lo[0][t] - c0, c0 - L.hi[0][t]), 0.0f);
+            const float g1 = fmaxf(fmaxf(L.lo[1][t] - c1, c1 - L.hi[1][t]), 0.0f);
+            const float g2 = fmaxf(fmaxf(L.lo[2][t] - c2, c2 - L.hi[2][t]), 0.0f);
+            const float bound = (g0 * g0 + g1 * g1) + g2 * g2;
+            const bool act = bound < L.tmax[t];
             const unsigned long long m = __ballot(act);
             if (m) {
                 int base = 0;
-                if (lane == (int)__ffsll((long long)m) - 1) base = atomicAdd(wc, __popcll(m));
+                if (lane == (int)__ffsll((long long)m) - 1) base = atomicAdd(&wcount, __popcll(m));
                 base = __shfl(base, (int)__ffsll((long long)m) - 1, 64);
                 if (act) L.work[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)t;
             }
         }
         __syncthreads();
-        const int n = *wc;
+        const int n = wcount;
+        if (prof) { const long long t1 = (long long)__builtin_readcyclecounter(); acc_a += t1 - tq; tq = t1; acc_n += n; }
         for (int e = wave; e < n; e += NW * GROUP) {
             TileRegs q[GROUP];
-            PendRegs pr[GROUP];
             int tt[GROUP];
 #pragma unroll
             for (int gi = 0; gi < GROUP; gi++) {
                 const int ee = e + gi * NW;
                 tt[gi] = (int)L.work[ee < n ? ee : n - 1];
-                load_tile(tt[gi], q[gi]);
-                load_pending(tt[gi], pr[gi]);
+                load_tile(tt[gi], q[gi]);   // unconditional (a repeated tile for the tail is harmless and unused)
             }
 #pragma unroll
-            for (int gi = 0; gi < GROUP; gi++) if (e + gi * NW < n) apply_tile(tt[gi], q[gi], pr[gi], false);
+            for (int gi = 0; gi < GROUP; gi++) if (e + gi * NW < n) compute_tile(tt[gi], q[gi], false);
         }
+        __syncthreads();
+        if (prof) { const long long t1 = (long long)__builtin_readcyclecounter(); acc_b += t1 - tq; tq = t1; }
+        if (tid == 0) wcount = 0;
+        select_next();
+        if (prof) { const long long t1 = (long long)__builtin_readcyclecounter(); acc_c += t1 - tq; tq = t1; }
+        if (tid == 0) { out_idx[j] = old; if (out_cen) { out_cen[3 * j] = c0; out_cen[3 * j + 1] = c1; out_cen[3 * j + 2] = c2; } }
     }
+    DBG_STAMP(16);
+    if (prof) { g_dbg_stamps[24] = acc_a; g_dbg_stamps[25] = acc_b; g_dbg_stamps[26] = acc_c; g_dbg_stamps[27] = acc_n; }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1155,12 +1155,12 @@ extern "C" int rpcc_fps_xyz(int B, int N, int M, const float *points, float *tem
     hipStream_t st = (hipStream_t)stream;
     FpsTimer tmr(st);
     const FpsTiling g = fps_tiling_list(N);
-    if (!g_fps_force_v1 && fps_tiled_fits(g.T, M) && N < (1 << 30) / 3) {
-        const size_t sh = fps_tiled_lds_bytes(g.T, M);
+    if (!g_fps_force_v1 && g.T <= FPS_TILED_MAX_TILES && N < (1 << 30) / 3) {
+        const size_t sh = fps_tiled_lds_bytes(g.T);
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_tiled_kernel<false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
         fps_tiled_kernel<false><<<B, FPS_TT, sh, st>>>(points, nullptr, nullptr, nullptr, temp, nullptr, g, M, idx,
-                                                         nullptr, nullptr, 1);
+                                                         nullptr, nullptr);
     } else {
         fps_xyz_kernel<<<B, FPS_THREADS, 0, st>>>(N, M, points, temp, idx);
     }
@@ -1171,17 +1171,17 @@ extern "C" int rpcc_fps_xyz(int B, int N, int M, const float *points, float *tem
 // rays_soa: dev f32 [3,P] scratch (may be NULL -> brute-force kernel on the AoS table)
 static int launch_fps_range(const float *ri, const float *tm, float *temp, const int32_t *info, int B, int H, int W, int M,
                             int32_t *cen_pix, float *centers, float *rays_soa, const float *tiletab, hipStream_t st,
-                            bool rays_ready = false, bool exact_temp = true) {
+                            bool rays_ready = false) {
     const int P = H * W;
     const FpsTiling g = fps_tiling_range(H, W);
-    if (!g_fps_force_v1 && rays_soa != nullptr && g.T <= FPS_TILED_MAX_TILES && fps_tiled_fits(g.T, M)) {
+    if (!g_fps_force_v1 && rays_soa != nullptr && g.T <= FPS_TILED_MAX_TILES) {
         if (!rays_ready) rays_soa_kernel<<<(P + 255) / 256, 256, 0, st>>>(tm, P, rays_soa);
-        const size_t sh = fps_tiled_lds_bytes(g.T, M);
+        const size_t sh = fps_tiled_lds_bytes(g.T);
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_tiled_kernel<true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
         FpsTimer tmr(st);
         fps_tiled_kernel<true><<<B, FPS_TT, sh, st>>>(ri, rays_soa, rays_soa + P, rays_soa + 2 * (int64_t)P, temp, info,
-                                                        g, M, cen_pix, centers, tiletab, exact_temp ? 1 : 0);
+                                                        g, M, cen_pix, centers, tiletab);
         LAUNCH_CHECK();
         return RPCC_OK;
     }
@@ -1995,13 +1995,13 @@ static int run_slice(const rpcc_batch_io *io, int b0, int Bs, int64_t pt0, int64
     if (fit_ground &&
         (rc = launch_ground_ransac(ri, io->tm, Bs, P, (uint32_t)(io->ground_seed + b0), false, ground, nullptr, st, zcnt)))
         return rc;
-    const bool tiled = !g_fps_force_v1 && fps_tiling_range(g.H, g.W).T <= FPS_TILED_MAX_TILES && fps_tiled_fits(fps_tiling_range(g.H, g.W).T, M);
+    const bool tiled = !g_fps_force_v1 && fps_tiling_range(g.H, g.W).T <= FPS_TILED_MAX_TILES;
     if ((rc = launch_ground_mask(ri, io->tm, ground, ground_threshold, Bs, g.H, g.W, temp, info,
                                  tiled ? tiletab : nullptr, st, false, true)))
         return rc;
     if (pre_done) HIP_TRY(hipEventRecord(pre_done, st));
     if ((rc = launch_fps_range(ri, io->tm, temp, info, Bs, g.H, g.W, M, io->cen_pix + (size_t)b0 * M, centers, rays_soa,
-                               tiled ? tiletab : nullptr, st, true, /*exact_temp=*/false)))  // temp is workspace here
+                               tiled ? tiletab : nullptr, st, true)))
         return rc;
     if ((rc = launch_assign(ri, io->tm, ground, centers, Bs, g.H, g.W, M, seg, st))) return rc;
     if ((rc = launch_point_model(ri, seg, ground, Bs, P, M, model, io->counts + (size_t)b0 * K, io->nnz + b0, ws, st, true)))
