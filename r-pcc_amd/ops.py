@@ -105,11 +105,11 @@ def fps_xyz(points, npoint, temp=None):
     return idx
 
 
-def fps_range(ri, tm, temp, info, M, fps_table=None):
+def fps_range(ri, tm, temp, info, M, fps_table=None, cen_pix=None, centers=None):
     B, H, W = ri.shape
     P = H * W
-    cen_pix = torch.empty((B, M), dtype=torch.int32, device=_dev(ri))
-    centers = torch.empty((B, M, 3), dtype=torch.float32, device=_dev(ri))
+    cen_pix = torch.empty((B, M), dtype=torch.int32, device=_dev(ri)) if cen_pix is None else cen_pix
+    centers = torch.empty((B, M, 3), dtype=torch.float32, device=_dev(ri)) if centers is None else centers
     rays = torch.empty((3, P), dtype=torch.float32, device=_dev(ri))
     check(_lib.lib().rpcc_fps_range(ptr(ri), ptr(tm), ptr(temp), ptr(info), B, H, W, M, ptr(cen_pix), ptr(centers),
                                     ptr(rays), ptr(fps_table), stream()))
@@ -121,10 +121,10 @@ def fps_force_bruteforce(on):
     _lib.lib().rpcc_fps_force_bruteforce(1 if on else 0)
 
 
-def assign(ri, tm, ground, centers):
+def assign(ri, tm, ground, centers, out=None):
     B, H, W = ri.shape
     M = centers.shape[1]
-    seg = torch.empty((B, H, W), dtype=torch.uint8, device=_dev(ri))
+    seg = torch.empty((B, H, W), dtype=torch.uint8, device=_dev(ri)) if out is None else out
     check(_lib.lib().rpcc_assign(ptr(ri), ptr(tm), ptr(ground), ptr(centers), B, H, W, M, ptr(seg), stream()))
     return seg
 
@@ -147,14 +147,17 @@ def point_model(ri, seg, ground, M, ws=None):
 
 
 def predict_quantize(ri, tm, seg, model, acc, M, want_pred=False, int16=False, ws=None, label_acc=None,
-                     residual=None):
+                     residual=None, q_out=None, nnz_out=None):
     """a10+a11(+a13).  label_acc f32 [B,K]: per-label steps (non-uniform); residual f32 [B,P]: use this
-    residual instead of ri - pred.  -> (q [B,P] label-ordered, nnz [B], pred or None)."""
+    residual instead of ri - pred.  -> (q [B,P] label-ordered, nnz [B], pred or None).  q_out / nnz_out: write into
+    these buffers (entries of q past nnz are left as they are) instead of fresh zero-filled ones."""
     B = ri.shape[0]
     P = ri[0].numel()
     ws = workspace(B, P, M, _dev(ri)) if ws is None else ws
-    q = torch.zeros((B, P), dtype=torch.int16 if int16 else torch.int32, device=_dev(ri))
-    nnz = torch.empty((B,), dtype=torch.int32, device=_dev(ri))
+    if q_out is not None:
+        assert q_out.dtype == (torch.int16 if int16 else torch.int32) and q_out.numel() == B * P
+    q = torch.zeros((B, P), dtype=torch.int16 if int16 else torch.int32, device=_dev(ri)) if q_out is None else q_out
+    nnz = torch.empty((B,), dtype=torch.int32, device=_dev(ri)) if nnz_out is None else nnz_out
     pred = torch.empty((B, P), dtype=torch.float32, device=_dev(ri)) if want_pred else None
     check(_lib.lib().rpcc_predict_quantize(ptr(ri), ptr(tm), ptr(seg), ptr(model), ptr(label_acc), ptr(residual),
                                            float(acc), B, P, M, ptr(q) if int16 else None,
@@ -353,11 +356,8 @@ def compress_batch_general(xyz, offsets, tm, ground, buf, cc, fit_ground):
         ground.copy_(g)
     temp, info, tab = ground_mask(buf.ri, tm, ground, cc.ground_threshold, fps_table=True)
     buf.info.copy_(info)
-    cen_pix, centers = fps_range(buf.ri, tm, temp, info, M, fps_table=tab)
-    buf.cen_pix.copy_(cen_pix)
-    buf.centers.copy_(centers)
-    seg = assign(buf.ri, tm, ground, centers)
-    buf.seg.copy_(seg)
+    _, centers = fps_range(buf.ri, tm, temp, info, M, fps_table=tab, cen_pix=buf.cen_pix, centers=buf.centers)
+    assign(buf.ri, tm, ground, centers, out=buf.seg)
     if cc.model_method == "point":
         model, counts = point_model(buf.ri, buf.seg, ground, M, ws=buf.ws)
     else:
@@ -373,7 +373,6 @@ def compress_batch_general(xyz, offsets, tm, ground, buf, cc, fit_ground):
         lk = c.get("level_key_point_num", (30, 10, 3, 0))
         la = np.array([cc.acc] * len(lk)) + np.array(c.get("level_delta_acc", (0, 0.02, 0.04, 0.06)))
         sal, label_acc = salience(buf.seg, kp, lk, la.astype(np.float32), c.get("ground_salience_level", 2), M)
-    q, nnz, _ = predict_quantize(buf.ri, tm, buf.seg, buf.model, cc.acc, M, int16=True, ws=buf.ws, label_acc=label_acc)
-    buf.q16.copy_(q)
-    buf.nnz.copy_(nnz)
+    predict_quantize(buf.ri, tm, buf.seg, buf.model, cc.acc, M, int16=True, ws=buf.ws, label_acc=label_acc,
+                     q_out=buf.q16, nnz_out=buf.nnz)
     return sal
