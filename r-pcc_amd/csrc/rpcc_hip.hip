@@ -2016,7 +2016,8 @@ extern "C" int rpcc_compress_batch(const rpcc_batch_io *io, int B, rpcc_geom g, 
     ARG_TRY(io->offsets && io->tm && io->ground && io->ri && io->seg && io->cen_pix && io->centers && io->model &&
             io->counts && io->q16 && io->nnz && io->info);
     const int P = g.H * g.W;
-    ARG_TRY(P % 4 == 0);
+    // only the brute-force FPS kernel (16-byte loads at frame bases) needs P % 4 == 0; the tile-pruned one does not
+    ARG_TRY(P % 4 == 0 || (!g_fps_force_v1 && fps_tiling_range(g.H, g.W).T <= FPS_TILED_MAX_TILES));
     hipStream_t st = (hipStream_t)stream;
     int S = (io->offsets_host != nullptr) ? g_slices : 1;
     if (S > B) S = B;

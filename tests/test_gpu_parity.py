@@ -809,6 +809,66 @@ def test_fused_batch_many_frames_vs_oracle(env, gname, nframes):
         assert n == o["q"].shape[0] and np.array_equal(q16[i, :n], o["q"].astype(np.int16)), (gname, i)
 
 
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_fuzz_fused_vs_oracle(env, seed):
+    """Randomised breadth: image shape, fields of view, cluster count, accuracy and ground threshold drawn per seed; the
+    synthetic scene is rescaled / tilted and salted with duplicates, far points, points at the origin and on the optical
+    axis.  Three frames per draw through the fused entry; every integer output and the range image equal the oracle's."""
+    torch, ops, orc, synth = env["torch"], env["ops"], env["orc"], env["synth"]
+    rng = np.random.default_rng(9000 + seed)
+    H = int(rng.integers(4, 41))
+    W = int(rng.integers(96, 1500))
+    vmax = float(rng.uniform(1.0, 16.0))
+    vmin = float(-rng.uniform(10.0, 31.0))
+    hfov = float(rng.choice([360.0, 360.0, 180.0, 90.0]))
+    M = int(rng.integers(3, 61))
+    accuracy = float(rng.choice([0.01, 0.02, 0.05, 0.1]))
+    thr = float(rng.choice([0.05, 0.1, 0.2]))
+    g = orc.LidarGeom(H, W, hfov, vmax, vmin)
+    tm = ops.transform_map(g.H, g.W, g.horizontal_FOV, g.vertical_max, g.vertical_min)
+    assert np.array_equal(tm, orc.transform_map(g))
+    geom = ops.make_geom(g.H, g.W, g.horizontal_FOV, g.vertical_max, g.vertical_min)
+    frames = []
+    for i in range(3):
+        f = synth.make_frame(7000 + 10 * seed + i, H, W, vmax_deg=vmax, vmin_deg=vmin, hfov_deg=hfov).numpy()
+        f = f * np.float32(rng.uniform(0.5, 1.5))                                   # nearer / farther scene
+        a = np.float32(rng.uniform(-0.03, 0.03))                                    # small roll
+        f = np.stack([f[:, 0], f[:, 1] * np.cos(a) - f[:, 2] * np.sin(a), f[:, 1] * np.sin(a) + f[:, 2] * np.cos(a)], 1).astype(np.float32)
+        extra = [f[rng.integers(0, len(f), 50)],                                    # exact duplicates
+                 f[rng.integers(0, len(f), 50)] * np.float32(1.0000001),            # near-duplicates (same pixel, other depth)
+                 (rng.normal(size=(20, 3)) * 300).astype(np.float32),               # far points, any direction
+                 np.zeros((3, 3), np.float32),                                      # the origin (depth 0)
+                 np.array([[0, 0, 5], [0, 0, -5], [1e-30, 0, 1]], np.float32)]      # on / next to the vertical axis
+        f = np.concatenate([f] + extra).astype(np.float32)
+        frames.append(f[rng.permutation(len(f))])
+    offs = np.zeros(len(frames) + 1, np.int64)
+    offs[1:] = np.cumsum([f.shape[0] for f in frames])
+    B = len(frames)
+    buf = ops.BatchBuffers(B, geom, M, env["dev"])
+    gfit = torch.zeros((B, 4), dtype=torch.float64, device=env["dev"])
+    ops.compress_batch(_to(env, np.concatenate(frames)), _to(env, offs), _to(env, tm), gfit, buf, ground_threshold=thr,
+                       acc=2 * accuracy, ground_seed=40 + seed)
+    torch.cuda.synchronize()
+    cfg = dict(orc.DEFAULT_CFG, cluster_num=M, accuracy=accuracy, ground_threshold=thr)
+    tag = (seed, H, W, M)
+    compared = 0
+    for i, f in enumerate(frames):
+        ri_o = orc.project(f, g)
+        assert _beq(buf.ri[i].cpu().numpy(), ri_o), tag
+        gm = orc.ground_model(ri_o, tm, seed=40 + seed + i)
+        assert _beq(gfit[i].cpu().numpy(), gm), tag
+        o = orc.compress_frame(f, g, tm, gm, cfg)
+        if len(set(o["fps_pix"].tolist())) < M:
+            continue                                                               # fewer candidates than clusters: undefined in the reference
+        n = int(buf.nnz[i])
+        assert np.array_equal(buf.cen_pix[i].cpu().numpy(), o["fps_pix"]), tag
+        assert np.array_equal(buf.seg[i].cpu().numpy(), o["seg_idx"].astype(np.uint8)), tag
+        assert _beq(buf.model[i, : o["model_param"].shape[0]].cpu().numpy(), o["model_param"].astype(np.float32)), tag
+        assert n == o["q"].shape[0] and np.array_equal(buf.q16[i, :n].cpu().numpy(), o["q"].astype(np.int16)), tag
+        compared += 1
+    assert compared >= 1, tag
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,P", [(1, 7), (3, 2048), (37, 4099), (256, 131072)])
 def test_pack_payload(env, B, P):
