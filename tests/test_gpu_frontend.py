@@ -148,3 +148,69 @@ def test_nonuniform_plane_batches_mixed_lidars(fe, lidar, geom, accuracy):
         assert np.array_equal(seg_rec, seg.astype(np.uint8))
         err = np.abs(rec - ri)[ri != 0]
         assert err.max() <= step + 0.06 + 1e-5
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_fuzz_general_path_vs_oracle(fe, seed):
+    """Randomised breadth for the stage-by-stage batch path (configs[2]/[4] shape): image shape, fields of view, cluster
+    count, accuracy and framework / model combination drawn per seed; segmentation, plane or point models, key points +
+    salience + quantised integers, the .rpcc bytes and the decoded labels / error bound equal the oracle's."""
+    from oracle import oracle as orc
+    from rpcc_amd import synth
+    from rpcc_amd.tools.decompress import decode_frame
+    from rpcc_amd.transformer import PCTransformer
+    rng = np.random.default_rng(5000 + seed)
+    H, W = int(rng.integers(6, 41)), int(rng.integers(200, 1600))
+    vmax, vmin = float(rng.uniform(1.0, 16.0)), float(-rng.uniform(10.0, 31.0))
+    M = int(rng.integers(5, 61))
+    accuracy = float(rng.choice([0.01, 0.02, 0.05]))
+    uniform = bool(rng.integers(0, 2))
+    method = "plane" if (rng.integers(0, 3) > 0 or uniform) else "point"   # uniform + point is the fused entry's test
+    angle = float(rng.choice([75, 75, 40]))
+    T = PCTransformer(dict(HORIZONTAL_FOV=360, VERTICAL_ANGLE_MAX=vmax, VERTICAL_ANGLE_MIN=vmin, RANGE_IMAGE_HEIGHT=H,
+                           RANGE_IMAGE_WIDTH=W))
+    g = orc.LidarGeom(H, W, 360, vmax, vmin)
+    tm = orc.transform_map(g)
+    assert np.array_equal(T.transform_map, tm)
+    frames = [synth.make_frame(8000 + 10 * seed + i, H, W, vmax_deg=vmax, vmin_deg=vmin).numpy() for i in range(2)]
+    cfg = dict(orc.DEFAULT_CFG, accuracy=accuracy, cluster_num=M, plane_angle_threshold=angle)
+    bc = fe.pl.BatchCompressor(T, cluster_num=M, accuracy=accuracy, uniform=uniform, model_method=method, compressor_cfg=cfg,
+                               seed=21)
+    blobs = bc.compress(frames)
+    buf = bc._buf
+    step = accuracy * 2
+    lacc = np.array([step] * 4) + np.array([0, 0.02, 0.04, 0.06])
+    tag = (seed, H, W, M, uniform, method)
+    compared = 0
+    for b, f in enumerate(frames):
+        ri = orc.project(f, g)
+        gm = orc.ground_model(ri, tm, seed=21 + b)
+        s = orc.segment(ri, tm, gm, cfg)
+        seg = s["seg_idx"]
+        if len(set(s["fps_pix"].tolist())) < M:
+            continue
+        assert np.array_equal(buf.seg[b].cpu().numpy(), seg.astype(np.uint8)), tag
+        if method == "plane":
+            mp = np.concatenate((gm.reshape(1, 4), orc.cluster_modeling_plane(s["pc"], ri, seg, tm, angle, 21, b)), 0)
+        else:
+            mp = orc.point_model_param(ri, seg, gm)
+        nrow = mp.shape[0]
+        assert np.array_equal(buf.model[b, :nrow].cpu().numpy().view(np.uint32), mp.astype(np.float32).view(np.uint32)), tag
+        pred = orc.intra_predict(seg, mp.astype(np.float32), tm)
+        res = ri.reshape(H, W, 1) - pred
+        if uniform:
+            q, sal = orc.uniform_quantize(seg.astype(np.int32), res, step), None
+        else:
+            _, kp = orc.extract_features_with_segment(ri, seg)
+            q, sal = orc.nonuniform_quantize(seg, res, kp, np.array([30, 10, 3, 0]), lacc, 2)
+        n = int(buf.nnz[b])
+        assert n == q.shape[0] and np.array_equal(buf.q16[b, :n].cpu().numpy(), q.astype(np.int16)), tag
+        od = orc.pack_payload(mp, seg, sal, q)
+        assert blobs[b] == orc.bitstream_bytes(od, uniform=uniform), tag
+        rec, pc, seg_rec = decode_frame(fe.cu.unpack_bitstream(blobs[b], uniform=uniform), fe.cu.BasicCompressor(method_name="bzip2"),
+                                        T, M, step, lacc, uniform=uniform)
+        assert np.array_equal(seg_rec, seg.astype(np.uint8)), tag
+        err = np.abs(rec - ri)[ri != 0]
+        assert err.max() <= (step / 2 if uniform else step + 0.06) + 1e-5, tag
+        compared += 1
+    assert compared >= 1, tag
