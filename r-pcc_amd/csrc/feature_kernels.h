@@ -126,8 +126,50 @@ __global__ __launch_bounds__(FEAT_THREADS) void features_kernel(const float *__r
         // the less_sharp_num largest, then the flat_num smallest accepted keys of every chunk, FEAT_CP chunks interleaved
         // (independent dependency chains hide the latency of the DPP reductions)
         const int stop_n = max(1, max(fp.sharp_num, fp.less_sharp_num));  // the first loop breaks at this accepted entry
+        if constexpr (Q == 0) {
+            // chunks of more than 64 * FEAT_MAX_PER_LANE entries (few segments on a wide image): the same selection with the
+            // keys rebuilt from LDS in every round instead of held in registers, one chunk per wavefront at a time
+            for (int j = wave; j < fp.segments; j += FEAT_THREADS / 64) {
+                const int sp = chunk * j;
+                auto key_at = [&](int i) -> feat_key {
+                    const int ii = sp + i;
+                    return accf[ii] != 0 ? ((feat_key)f2u(cbuf[ii]) << 32) | (feat_key)(uint32_t)(ii + fr + 1) : 0ull;
+                };
+                feat_key prev = ~0ull, thr = 0ull;
+                for (int n = 1; n <= stop_n; n++) {
+                    feat_key best = 0ull;
+                    for (int i = lane; i < chunk; i += 64) {
+                        const feat_key k = key_at(i), c = k < prev ? k : 0ull;
+                        best = c > best ? c : best;
+                    }
+                    uint32_t mh, ml;
+                    feat_wave_max((uint32_t)(best >> 32), (uint32_t)best, mh, ml);
+                    const feat_key m = ((feat_key)mh << 32) | ml;
+                    if (ml == 0u) break;                   // fewer accepted entries: all visited
+                    if (n == stop_n) { thr = m; break; }
+                    if (lane == 0) kprow[vidx[ml - 1u]] = n < fp.sharp_num ? 3 : 2;
+                    prev = m;
+                }
+                if (thr == 0ull) continue;
+                prev = 0ull;
+                for (int n = 1; n < fp.flat_num; n++) {
+                    feat_key best = ~0ull;
+                    for (int i = lane; i < chunk; i += 64) {
+                        const feat_key k = key_at(i);
+                        const feat_key e = (k != 0ull && k < thr && u2f((uint32_t)(k >> 32)) != 0.0f) ? k : ~0ull;
+                        const feat_key c = e > prev ? e : ~0ull;
+                        best = c < best ? c : best;
+                    }
+                    uint32_t mh, ml;
+                    feat_wave_min((uint32_t)(best >> 32), (uint32_t)best, mh, ml);
+                    if (mh == 0xFFFFFFFFu && ml == 0xFFFFFFFFu) break;
+                    if (lane == 0) kprow[vidx[ml - 1u]] = 1;
+                    prev = ((feat_key)mh << 32) | ml;
+                }
+            }
+        } else
         for (int j0 = wave * FEAT_CP; j0 < fp.segments; j0 += FEAT_CP * (FEAT_THREADS / 64)) {
-            feat_key key[FEAT_CP][Q], prev[FEAT_CP], thr[FEAT_CP];
+            feat_key key[FEAT_CP][Q ? Q : 1], prev[FEAT_CP], thr[FEAT_CP];
             bool alive[FEAT_CP];
 #pragma unroll
             for (int cI = 0; cI < FEAT_CP; cI++) {
@@ -161,7 +203,7 @@ __global__ __launch_bounds__(FEAT_THREADS) void features_kernel(const float *__r
                     prev[cI] = m;
                 }
             }
-            feat_key ek[FEAT_CP][Q];
+            feat_key ek[FEAT_CP][Q ? Q : 1];
 #pragma unroll
             for (int cI = 0; cI < FEAT_CP; cI++) {
                 alive[cI] = thr[cI] != 0ull;

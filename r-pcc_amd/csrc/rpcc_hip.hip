@@ -1872,7 +1872,6 @@ extern "C" int rpcc_extract_features(const float *ri, const uint8_t *seg, int B,
     hipStream_t st = (hipStream_t)stream;
     const size_t sh = (size_t)3 * W * 4 + (size_t)W * 2 + (size_t)W * 2 + 16;
     ARG_TRY(sh <= 160 * 1024);
-    ARG_TRY((W - 2 * feature_region) / segments <= 64 * FEAT_MAX_PER_LANE);  // a chunk's keys live in registers
     ARG_TRY(W <= 64 * FEAT_GPW * (FEAT_THREADS / 64));                        // and so does a wavefront's part of the row
     FeatParams fp = {feature_region, segments, sharp_num, less_sharp_num, flat_num};
     const int need = ((W - 2 * feature_region) / segments + 63) / 64;  // keys per lane
@@ -1885,7 +1884,8 @@ extern "C" int rpcc_extract_features(const float *ri, const uint8_t *seg, int B,
     if (need <= 2) FEAT_LAUNCH(2);
     else if (need <= 4) FEAT_LAUNCH(4);
     else if (need <= 6) FEAT_LAUNCH(6);
-    else FEAT_LAUNCH(8);
+    else if (need <= 8) FEAT_LAUNCH(8);
+    else FEAT_LAUNCH(0);  // long chunks: keys stay in LDS
 #undef FEAT_LAUNCH
     LAUNCH_CHECK();
     return RPCC_OK;

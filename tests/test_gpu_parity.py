@@ -634,6 +634,46 @@ def test_features_edge_rows(env):
         assert k_o.max() >= 1
 
 
+FEATURE_PARAM_DRAWS = [(3, 8, 4, 8, 6)] + [tuple(int(v) for v in r) for r in np.stack([
+    np.random.default_rng(77).integers(1, 6, 14), np.random.default_rng(78).integers(2, 13, 14),
+    np.random.default_rng(79).integers(0, 7, 14), np.random.default_rng(80).integers(0, 13, 14),
+    np.random.default_rng(81).integers(0, 11, 14)], 1)]     # the draws tests/test_oracle_vs_ref.py pins against the reference's C++
+
+
+@pytest.mark.parametrize("params", FEATURE_PARAM_DRAWS)
+def test_features_and_salience_parameter_sweep(env, params):
+    """a12 / a13 away from the YAML defaults: feature_region, segments, sharp / less_sharp / flat counts (zeros and
+    less_sharp < sharp included), then salience levels with drawn key-point thresholds, level count and ground level."""
+    torch, ops, orc = env["torch"], env["ops"], env["orc"]
+    fr, segments, sharp, less, flat = params
+    rng = np.random.default_rng(1000 + 7 * fr + segments)
+    for (h, w) in [(48, 1500), (7, 333)]:
+        seg = np.repeat(rng.integers(0, 30, (h, (w + 5) // 6)), 6, axis=1)[:, :w].astype(np.int32)
+        ri = (20 + 5 * np.sin(np.arange(w) / 23.0)[None, :] + rng.normal(0, 0.04, (h, w))).astype(np.float32)
+        ri[:, ::61] += 2.0
+        ri[3, :] = 17.0
+        seg[5, 40:] = 1
+        ri[seg == 1] = 0
+        f_o, k_o = orc.extract_features_with_segment(ri, seg, fr, segments, sharp, less, flat)
+        seg_d = _to(env, seg.astype(np.uint8)[None])
+        feat, kp = ops.extract_features(_to(env, ri[None]), seg_d, fr, segments, sharp, less, flat)
+        assert np.array_equal(kp[0].cpu().numpy(), k_o.astype(np.uint8)), (params, h, w)
+        assert _beq(feat[0].cpu().numpy(), f_o), (params, h, w)
+        levels = int(rng.integers(1, 7))
+        lk = np.sort(rng.integers(0, 40, levels))[::-1].astype(np.int32)
+        lk[-1] = 0                                                       # the last level accepts everything
+        la = (0.04 + np.sort(rng.uniform(0, 0.1, levels))).astype(np.float32)
+        gl = int(rng.integers(0, levels))
+        res = rng.normal(0, 0.3, (h, w, 1)).astype(np.float32)
+        q_o, s_o = orc.nonuniform_quantize(seg, res, k_o, lk, la, gl)
+        sal, label_acc = ops.salience(seg_d, kp, lk, la, gl, 100)
+        assert np.array_equal(sal[0, : s_o.shape[0]].cpu().numpy(), s_o.astype(np.uint8)), (params, h, w)
+        q, nnz, _ = ops.predict_quantize(_to(env, ri[None]), None, seg_d, None, 0.04, 100, label_acc=label_acc,
+                                         residual=_to(env, res.reshape(1, -1)))
+        n = int(nnz[0])
+        assert n == q_o.shape[0] and np.array_equal(q[0, :n].cpu().numpy(), q_o), (params, h, w)
+
+
 @pytest.mark.parametrize("case,angle", [("example_64E", 75), ("synth_64x2048", 75), ("synth_vlp16", 75), ("synth_32E", 40),
                                         ("example_64E", 20)])
 def test_plane_model(env, case, angle):

@@ -140,6 +140,51 @@ def test_features_match_on_written_cells(ref):
     assert k_o.max() == 3 and (k_o == 1).any() and (k_o == 2).any()
 
 
+FEATURE_PARAM_DRAWS = [(3, 8, 4, 8, 6)] + [tuple(int(v) for v in r) for r in np.stack([
+    np.random.default_rng(77).integers(1, 6, 14), np.random.default_rng(78).integers(2, 13, 14),
+    np.random.default_rng(79).integers(0, 7, 14), np.random.default_rng(80).integers(0, 13, 14),
+    np.random.default_rng(81).integers(0, 11, 14)], 1)]
+
+
+_FEAT_CHILD = """
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+import feature_extractor_cpp as fe
+z = np.load(sys.argv[2])
+p = [int(v) for v in sys.argv[4:9]]
+f, k = fe.extract_features_with_segment(z['ri'], z['seg'], *p)      # first call of a fresh process
+np.savez(sys.argv[3], f=f, k=k)
+"""
+
+
+@needs_ref
+@pytest.mark.parametrize("params", FEATURE_PARAM_DRAWS)
+def test_features_parameter_sweep_matches(params, tmp_path):
+    """Key-point extraction with non-default feature_region / segments / sharp / less_sharp / flat counts (incl. zeros and
+    less_sharp < sharp): the restatement against the reference's C++.  The reference leaves unwritten cells uninitialised
+    (cpp_modules.cpp:38-43), so it runs once in a fresh process with outputs large enough (288 KB) to be mmap'd zero pages:
+    then the whole key point map can be compared, not only the cells the restatement writes."""
+    import subprocess
+    fr, segments, sharp, less, flat = params
+    rng = np.random.default_rng(1000 + 7 * fr + segments)
+    h, w = 48, 1500
+    seg = np.repeat(rng.integers(0, 30, (h, (w + 5) // 6)), 6, axis=1)[:, :w].astype(np.int32)
+    ri = (20 + 5 * np.sin(np.arange(w) / 23.0)[None, :] + rng.normal(0, 0.04, (h, w))).astype(np.float32)
+    ri[:, ::61] += 2.0
+    ri[3, :] = 17.0                                                      # constant row: zero curvatures, ties
+    seg[5, 40:] = 1                                                      # too few valid pixels
+    ri[seg == 1] = 0
+    f_o, k_o = orc.extract_features_with_segment(ri, seg, fr, segments, sharp, less, flat)
+    np.savez(tmp_path / "in.npz", ri=ri, seg=seg)
+    subprocess.check_call([sys.executable, "-c", _FEAT_CHILD, REFDIR, str(tmp_path / "in.npz"), str(tmp_path / "out.npz")]
+                          + [str(v) for v in params])
+    z = np.load(tmp_path / "out.npz")
+    f_r, k_r = z["f"], z["k"]
+    wrote = f_o != 0
+    assert np.array_equal(f_o[wrote].view(np.uint32), f_r[wrote].view(np.uint32)), params
+    assert np.array_equal(k_o, k_r), params
+
+
 @needs_ref
 def test_contour_roundtrip_matches(ref):
     rng = np.random.default_rng(6)
