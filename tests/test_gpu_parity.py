@@ -156,7 +156,8 @@ def test_fps_xyz_operator(env):
     """The reference FPS operator signature (B,N,3)->(B,M): ragged N, duplicates (exact ties), N<M."""
     torch, ops, orc = env["torch"], env["ops"], env["orc"]
     rng = np.random.default_rng(5)
-    for (B, N, M) in [(3, 5000, 100), (2, 1023, 64), (1, 70, 100), (2, 4097, 17), (1, 1, 1), (1, 90000, 100)]:
+    for (B, N, M) in [(3, 5000, 100), (2, 1023, 64), (1, 70, 100), (2, 4097, 17), (1, 1, 1), (1, 90000, 100), (2, 30000, 700),
+                      (1, 2000, 2000)]:
         pts = rng.normal(0, 10, (B, N, 3)).astype(np.float32)
         pts[:, N // 2:] = pts[:, : N - N // 2]                    # exact duplicates -> distance ties
         pts[0, :min(N, 40)] = 0.0
@@ -881,6 +882,7 @@ def test_fuzz_fused_vs_oracle(env, seed):
                  np.array([[0, 0, 5], [0, 0, -5], [1e-30, 0, 1]], np.float32)]      # on / next to the vertical axis
         f = np.concatenate([f] + extra).astype(np.float32)
         frames.append(f[rng.permutation(len(f))])
+    frames.insert(int(rng.integers(0, 4)), np.zeros((0, 3), np.float32))            # a frame without any point, anywhere in the batch
     offs = np.zeros(len(frames) + 1, np.int64)
     offs[1:] = np.cumsum([f.shape[0] for f in frames])
     B = len(frames)
@@ -893,6 +895,9 @@ def test_fuzz_fused_vs_oracle(env, seed):
     tag = (seed, H, W, M)
     compared = 0
     for i, f in enumerate(frames):
+        if len(f) == 0:                                                            # empty sweep: empty image, every pixel label 1, no payload
+            assert not buf.ri[i].any().item() and (buf.seg[i] == 1).all().item() and int(buf.nnz[i]) == 0, tag
+            continue
         ri_o = orc.project(f, g)
         assert _beq(buf.ri[i].cpu().numpy(), ri_o), tag
         gm = orc.ground_model(ri_o, tm, seed=40 + seed + i)
