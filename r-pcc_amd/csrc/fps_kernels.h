@@ -152,8 +152,10 @@ __device__ __forceinline__ void fps_load_point(const float *__restrict__ src, co
 // alone / step with three batches in flight): 1024 threads 452 us / 1.14 ms, 768 threads 474 us / 1.12 ms, 512 threads
 // 527 us / 1.07 ms, 384 threads 636 us / 1.10 ms.  Alone the wide workgroup wins; with batches in flight two narrow ones
 // leave wave slots to the throughput kernels of the other batches, and the step is what counts.
-#define FPS_TT 512
-template <bool RANGE>
+// Small batches (fewer frames than half the CUs) have nothing to co-schedule with and take the 1024-thread form.
+#define FPS_TT_BATCH 512
+#define FPS_TT_SMALL 1024
+template <bool RANGE, int FPS_TT>
 __global__ __launch_bounds__(FPS_TT) void fps_tiled_kernel(const float *__restrict__ src,
                                                                 const float *__restrict__ tx,
                                                                 const float *__restrict__ ty,

@@ -1157,10 +1157,17 @@ extern "C" int rpcc_fps_xyz(int B, int N, int M, const float *points, float *tem
     const FpsTiling g = fps_tiling_list(N);
     if (!g_fps_force_v1 && g.T <= FPS_TILED_MAX_TILES && N < (1 << 30) / 3) {
         const size_t sh = fps_tiled_lds_bytes(g.T);
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_tiled_kernel<false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-        fps_tiled_kernel<false><<<B, FPS_TT, sh, st>>>(points, nullptr, nullptr, nullptr, temp, nullptr, g, M, idx,
-                                                         nullptr, nullptr);
+        if (B <= 128) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_tiled_kernel<false, FPS_TT_SMALL>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+            fps_tiled_kernel<false, FPS_TT_SMALL><<<B, FPS_TT_SMALL, sh, st>>>(points, nullptr, nullptr, nullptr, temp, nullptr, g,
+                                                                            M, idx, nullptr, nullptr);
+        } else {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_tiled_kernel<false, FPS_TT_BATCH>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+            fps_tiled_kernel<false, FPS_TT_BATCH><<<B, FPS_TT_BATCH, sh, st>>>(points, nullptr, nullptr, nullptr, temp, nullptr, g,
+                                                                            M, idx, nullptr, nullptr);
+        }
     } else {
         fps_xyz_kernel<<<B, FPS_THREADS, 0, st>>>(N, M, points, temp, idx);
     }
@@ -1177,11 +1184,18 @@ static int launch_fps_range(const float *ri, const float *tm, float *temp, const
     if (!g_fps_force_v1 && rays_soa != nullptr && g.T <= FPS_TILED_MAX_TILES) {
         if (!rays_ready) rays_soa_kernel<<<(P + 255) / 256, 256, 0, st>>>(tm, P, rays_soa);
         const size_t sh = fps_tiled_lds_bytes(g.T);
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_tiled_kernel<true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
         FpsTimer tmr(st);
-        fps_tiled_kernel<true><<<B, FPS_TT, sh, st>>>(ri, rays_soa, rays_soa + P, rays_soa + 2 * (int64_t)P, temp, info,
-                                                        g, M, cen_pix, centers, tiletab);
+        if (B <= 128) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_tiled_kernel<true, FPS_TT_SMALL>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+            fps_tiled_kernel<true, FPS_TT_SMALL><<<B, FPS_TT_SMALL, sh, st>>>(ri, rays_soa, rays_soa + P, rays_soa + 2 * (int64_t)P,
+                                                                           temp, info, g, M, cen_pix, centers, tiletab);
+        } else {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_tiled_kernel<true, FPS_TT_BATCH>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+            fps_tiled_kernel<true, FPS_TT_BATCH><<<B, FPS_TT_BATCH, sh, st>>>(ri, rays_soa, rays_soa + P, rays_soa + 2 * (int64_t)P,
+                                                                           temp, info, g, M, cen_pix, centers, tiletab);
+        }
         LAUNCH_CHECK();
         return RPCC_OK;
     }
