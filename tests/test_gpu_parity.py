@@ -850,7 +850,7 @@ def test_fused_batch_many_frames_vs_oracle(env, gname, nframes):
         assert n == o["q"].shape[0] and np.array_equal(q16[i, :n], o["q"].astype(np.int16)), (gname, i)
 
 
-@pytest.mark.parametrize("seed", list(range(24)))
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("RPCC_FUZZ_SEEDS", "24")))))
 def test_fuzz_fused_vs_oracle(env, seed):
     """Randomised breadth: image shape, fields of view, cluster count, accuracy and ground threshold drawn per seed; the
     synthetic scene is rescaled / tilted and salted with duplicates, far points, points at the origin and on the optical
