@@ -47,8 +47,8 @@ class BatchCompressor:
         bits, seq, nseq = ops.contour_encode(buf.seg, self.M, ws=self._codec_ws)
         return buf, g, bits, seq, nseq, sal
 
-    def compress(self, frames, ground=None):
-        """frames: list of [N,3] arrays.  -> list of .rpcc byte strings (one per frame)."""
+    def submit(self, frames, ground=None):
+        """Device part of compress() on the current stream, nothing waited for.  -> a context for collect()."""
         offs = np.zeros(len(frames) + 1, np.int64)
         offs[1:] = np.cumsum([f.shape[0] for f in frames])
         xyz = torch.from_numpy(np.ascontiguousarray(np.concatenate([f[:, :3] for f in frames]), dtype=np.float32)).to(self.device)
@@ -58,16 +58,22 @@ class BatchCompressor:
         # as the padded [B,P] arrays: nnz <= points of the frame, one index per contour start <= pixels
         qp, qtot = ops.pack_payload(buf.q16, buf.nnz, capacity=int(offs[-1]))
         sp, stot = ops.pack_payload(seq.view(torch.int16), nseq)
-        torch.cuda.synchronize()
+        return dict(n=len(frames), buf=buf, bits=bits, nseq=nseq, sal=sal, qp=qp, qtot=qtot, sp=sp, stot=stot,
+                    stream=torch.cuda.current_stream(self.device), keep=(xyz, g, seq))
+
+    def collect(self, ctx):
+        """Waits for submit()'s stream and assembles the .rpcc byte strings (host part: casts, container, entropy coder)."""
+        ctx["stream"].synchronize()
+        buf, bits, nseq, sal = ctx["buf"], ctx["bits"], ctx["nseq"], ctx["sal"]
         nnz, nseq_h = buf.nnz.cpu().numpy(), nseq.cpu().numpy()
         seg_max = buf.counts.cpu().numpy()
-        q16 = qp[: int(qtot.item())].cpu().numpy()
-        seq_h = sp[: int(stot.item())].cpu().numpy().view(np.uint16)
+        q16 = ctx["qp"][: int(ctx["qtot"].item())].cpu().numpy()
+        seq_h = ctx["sp"][: int(ctx["stot"].item())].cpu().numpy().view(np.uint16)
         qo, so = np.concatenate([[0], np.cumsum(nnz)]), np.concatenate([[0], np.cumsum(nseq_h)])
         bits_h, model = bits.cpu().numpy(), buf.model.cpu().numpy()
         sal_h = None if sal is None else sal.cpu().numpy()
         out = []
-        for b in range(len(frames)):
+        for b in range(ctx["n"]):
             nrow = int(np.flatnonzero(seg_max[b])[-1]) + 1          # max(seg)+1 rows (tools/compress.py:102)
             od = {"residual_quantized": q16[qo[b]: qo[b + 1]]}
             if sal_h is not None:
@@ -76,4 +82,35 @@ class BatchCompressor:
             od["idx_sequence"] = seq_h[so[b]: so[b + 1]]
             od["plane_param"] = model[b, :nrow]
             out.append(pack_bitstream(self.bc.compress_dict(od), uniform=self.uniform))
+        return out
+
+    def compress(self, frames, ground=None):
+        """frames: list of [N,3] arrays.  -> list of .rpcc byte strings (one per frame)."""
+        return self.collect(self.submit(frames, ground))
+
+
+class MixedBatchCompressor:
+    """BASELINE configs[4]: one batch holding sweeps of several lidar geometries (variable H x W).  The frames are grouped
+    by geometry, every group runs as its own batch on its own HIP stream -- the small images are latency-bound (one
+    workgroup per frame in FPS / RANSAC), so the groups overlap -- and the results come back in input order.
+    transformers: {lidar name: PCTransformer}; the other arguments are BatchCompressor's."""
+
+    def __init__(self, transformers, **kw):
+        self.bcs = {name: BatchCompressor(t, **kw) for name, t in transformers.items()}
+        dev = next(iter(self.bcs.values())).device
+        self.streams = {name: torch.cuda.Stream(device=dev) for name in self.bcs}
+
+    def compress(self, frames, lidars):
+        """frames: list of [N,3] arrays; lidars: the lidar name of every frame.  -> list of .rpcc byte strings."""
+        groups = {}
+        for i, name in enumerate(lidars):
+            groups.setdefault(name, []).append(i)
+        ctxs = {}
+        for name, idx in groups.items():                       # all device work is queued before anything is waited for
+            with torch.cuda.stream(self.streams[name]):
+                ctxs[name] = self.bcs[name].submit([frames[i] for i in idx])
+        out = [None] * len(frames)
+        for name, idx in groups.items():
+            for i, blob in zip(idx, self.bcs[name].collect(ctxs[name])):
+                out[i] = blob
         return out

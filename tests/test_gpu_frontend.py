@@ -214,3 +214,25 @@ def test_fuzz_general_path_vs_oracle(fe, seed):
         assert err.max() <= (step / 2 if uniform else step + 0.06) + 1e-5, tag
         compared += 1
     assert compared >= 1, tag
+
+
+def test_mixed_lidar_batch(fe):
+    """configs[4]: one call with sweeps of three lidar geometries interleaved (variable H x W), non-uniform framework + plane
+    model: every frame's .rpcc equals what the single-geometry batch path gives for it (which the tests above pin to the oracle),
+    whatever the grouping and the order."""
+    from oracle import oracle as orc
+    from rpcc_amd import synth
+    names = ["VelodyneVLP16", "Velodyne64E", "Velodyne32E", "VelodyneVLP16", "Velodyne32E", "VelodyneVLP16", "Velodyne64E"]
+    T = {n: fe.ds.build_dataset(lidar_type=n).PCTransformer for n in set(names)}
+    frames = []
+    for i, n in enumerate(names):
+        gd = orc.GEOMS[n]
+        frames.append(synth.make_frame(4000 + i, gd["H"], gd["W"], vmax_deg=gd["vmax_deg"], vmin_deg=gd["vmin_deg"]).numpy())
+    kw = dict(accuracy=0.02, uniform=False, model_method="plane", seed=3)
+    mixed = fe.pl.MixedBatchCompressor(T, **kw).compress(frames, names)
+    assert all(isinstance(b, bytes) and len(b) > 1000 for b in mixed)
+    for n in set(names):
+        idx = [i for i, m in enumerate(names) if m == n]
+        single = fe.pl.BatchCompressor(T[n], **kw).compress([frames[i] for i in idx])
+        for i, blob in zip(idx, single):
+            assert mixed[i] == blob, (n, i)
