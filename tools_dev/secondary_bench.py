@@ -44,3 +44,20 @@ tot = torch.zeros((1,), dtype=torch.int64, device=dev)
 timed("pack_payload (residual stream)", lambda: ops.pack_payload(buf.q16, buf.nnz, packed=packed, capacity=packed.numel(), total=tot))
 la = (np.array([bc.acc] * 4) + np.array((0, 0.02, 0.04, 0.06))).astype(np.float32)
 timed("decode (non-uniform steps, with points)", lambda: ops.decode(buf.seg, buf.q16, buf.model, T.tm_dev, la, salience=sal, want_points=True, ws=cws))
+
+# three calls in flight (own buffers, own streams), like bench.py does for the headline configuration
+for uniform, mm in ((True, "plane"), (False, "point"), (False, "plane")):
+    bcs = [BatchCompressor(T, uniform=uniform, model_method=mm, device=dev) for _ in range(3)]
+    sts = [torch.cuda.Stream(device=dev) for _ in range(3)]
+    for bcx, st in zip(bcs, sts):
+        with torch.cuda.stream(st):
+            bcx.compress_device(xyz, offs)
+    torch.cuda.synchronize()
+    R = 12
+    t0 = time.perf_counter()
+    for i in range(R):
+        with torch.cuda.stream(sts[i % 3]):
+            bcs[i % 3].compress_device(xyz, offs)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / R
+    print("3 in flight: uniform=%s model=%s  %.3f ms per %d frames (%.0f frames/s)" % (uniform, mm, dt * 1e3, B, B / dt), flush=True)
