@@ -183,8 +183,9 @@ def main():
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))
             if pm["config"] == {"batch": B, "geom": a.geom, "clusters": M}:
-                traffic = pm["kernels"]["fps_tiled_kernel<true>"]["traffic_bytes_per_launch"] / pm.get("launches_per_step", 1)
-                traffic_src = "profiles/r01_v13_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, x2 read correction)"
+                key = [k for k in pm["kernels"] if k.startswith("fps_tiled_kernel<true")][0]   # template arguments vary
+                traffic = pm["kernels"][key]["traffic_bytes_per_launch"] / pm.get("launches_per_step", 1)
+                traffic_src = "profiles/%s_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, x2 read correction)" % pm.get("tag", "r01_v14")
         except Exception:
             pass
         out = {

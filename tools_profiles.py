@@ -50,9 +50,9 @@ tot = sum(v["traffic_bytes_per_launch"] for v in js.values())
 L += ["", "Whole step: %.2f GB of HBM-side traffic per 256-frame batch = %.1f MB per frame, against B_alg = 195 MB per frame of the" % (tot / 1e9, tot / 256 / 1e6),
       "stream-once model (SURVEY.md section 8d)."]
 open(f"{P}/{tag}_pmc.md", 'w').write("\n".join(L) + "\n")
-json.dump({"config": {"batch": 256, "geom": "64x2048", "clusters": 100}, "launches_per_step": 1, "kernels": js,
+json.dump({"tag": tag, "config": {"batch": 256, "geom": "64x2048", "clusters": 100}, "launches_per_step": 1, "kernels": js,
            "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, serial steps; read = 2 x FETCH_SIZE (gfx950, calibrated)"},
           open(f"{P}/r01_pmc.json", 'w'), indent=1)
 print(open(f"{P}/{tag}_kernel_stats_serial.md").read())
-print("FPS traffic MB:", js["fps_tiled_kernel<true>"]["traffic_bytes_per_launch"] / 1e6, "total GB:", tot / 1e9)
-print("pipelined fps avg us:", d.get("fps_tiled_kernel<true>"), " bench launch_ms:", json.loads(open(f"{P}/{tag}_p_default_bench.json").read())["roofline"]["launch_ms"])
+print("FPS traffic MB:", [v for k, v in js.items() if k.startswith("fps_tiled_kernel<true")][0]["traffic_bytes_per_launch"] / 1e6, "total GB:", tot / 1e9)
+print("pipelined fps avg us:", [v for k, v in d.items() if k.startswith("fps_tiled_kernel<true")], " bench launch_ms:", json.loads(open(f"{P}/{tag}_p_default_bench.json").read())["roofline"]["launch_ms"])
