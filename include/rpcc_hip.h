@@ -25,6 +25,7 @@ extern "C" {
 #define RPCC_ERR_ARG (-1)
 #define RPCC_ERR_HIP (-2)
 #define RPCC_MAX_CLUSTERS 254 /* labels are stored as uint8 */
+#define RPCC_MAX_BATCH 65535   /* frames per call: the frame index is a grid dimension */
 
 int rpcc_version(void);
 const char *rpcc_last_error(void);

@@ -577,7 +577,7 @@ static int launch_project(const float *xyz, const int64_t *offsets, int64_t tota
 
 extern "C" int rpcc_project(const float *xyz, const int64_t *offsets, int64_t total, int B, rpcc_geom g, float *ri,
                             void *scratch, size_t scratch_bytes, void *stream) {
-    ARG_TRY(B > 0 && g.H > 1 && g.W > 0 && total >= 0);
+    ARG_TRY(B > 0 && B <= RPCC_MAX_BATCH && g.H > 1 && g.W > 0 && total >= 0);
     ARG_TRY(ri != nullptr && scratch != nullptr && offsets != nullptr);
     ARG_TRY(total == 0 || xyz != nullptr);
     ARG_TRY(scratch_bytes >= ((size_t)B * ((size_t)g.H * g.W + 8)) * 4);
@@ -927,7 +927,7 @@ static int launch_ground_ransac(const float *ri, const float *tm, int B, int P, 
 
 extern "C" int rpcc_ground_ransac(const float *ri, const float *tm, int B, int P, uint32_t seed, double *ground,
                                   int32_t *inliers, void *stream) {
-    ARG_TRY(B > 0 && P > 0 && ri && tm && ground);
+    ARG_TRY(B > 0 && B <= RPCC_MAX_BATCH && P > 0 && ri && tm && ground);
     return launch_ground_ransac(ri, tm, B, P, seed, false, ground, inliers, (hipStream_t)stream);
 }
 
@@ -1019,7 +1019,7 @@ extern "C" size_t rpcc_fps_table_bytes(int B, int H, int W) {
 
 extern "C" int rpcc_ground_mask(const float *ri, const float *tm, const double *ground, double threshold, int B, int H,
                                 int W, float *temp, int32_t *info, void *fps_table, void *stream) {
-    ARG_TRY(B > 0 && H > 0 && W > 0 && ri && tm && ground && temp && info);
+    ARG_TRY(B > 0 && B <= RPCC_MAX_BATCH && H > 0 && W > 0 && ri && tm && ground && temp && info);
     ARG_TRY(fps_table == nullptr || fps_tiling_range(H, W).T <= FPS_TILED_MAX_TILES);
     return launch_ground_mask(const_cast<float *>(ri), tm, ground, threshold, B, H, W, temp, info,
                               reinterpret_cast<float *>(fps_table), (hipStream_t)stream, false);
@@ -1150,7 +1150,7 @@ static bool g_fps_force_v1 = false;
 extern "C" void rpcc_fps_force_bruteforce(int on) { g_fps_force_v1 = on != 0; }
 
 extern "C" int rpcc_fps_xyz(int B, int N, int M, const float *points, float *temp, int32_t *idx, void *stream) {
-    ARG_TRY(B > 0 && N > 0 && M >= 0 && points && temp && idx);
+    ARG_TRY(B > 0 && B <= RPCC_MAX_BATCH && N > 0 && M >= 0 && points && temp && idx);
     if (M == 0) return RPCC_OK;
     hipStream_t st = (hipStream_t)stream;
     FpsTimer tmr(st);
@@ -1211,7 +1211,7 @@ static int launch_fps_range(const float *ri, const float *tm, float *temp, const
 
 extern "C" int rpcc_fps_range(const float *ri, const float *tm, float *temp, const int32_t *info, int B, int H, int W,
                               int M, int32_t *cen_pix, float *centers, void *ws, const void *fps_table, void *stream) {
-    ARG_TRY(B > 0 && H > 0 && W > 0 && M > 0 && ri && tm && temp && info && cen_pix && centers);
+    ARG_TRY(B > 0 && B <= RPCC_MAX_BATCH && H > 0 && W > 0 && M > 0 && ri && tm && temp && info && cen_pix && centers);
     ARG_TRY(fps_table == nullptr || ws != nullptr);  // the table is only consumed by the tiled kernel
     return launch_fps_range(ri, tm, temp, info, B, H, W, M, cen_pix, centers, reinterpret_cast<float *>(ws),
                             reinterpret_cast<const float *>(fps_table), (hipStream_t)stream);
@@ -1418,7 +1418,7 @@ static int launch_assign(const float *ri, const float *tm, const double *ground,
 
 extern "C" int rpcc_assign(const float *ri, const float *tm, const double *ground, const float *centers, int B, int H,
                            int W, int M, uint8_t *seg, void *stream) {
-    ARG_TRY(B > 0 && H > 0 && W > 0 && M > 0 && M <= RPCC_MAX_CLUSTERS && ri && tm && ground && centers && seg);
+    ARG_TRY(B > 0 && B <= RPCC_MAX_BATCH && H > 0 && W > 0 && M > 0 && M <= RPCC_MAX_CLUSTERS && ri && tm && ground && centers && seg);
     return launch_assign(ri, tm, ground, centers, B, H, W, M, seg, (hipStream_t)stream);
 }
 
@@ -1635,7 +1635,7 @@ static int launch_point_model(const float *ri, const uint8_t *seg, const double 
 
 extern "C" int rpcc_point_model(const float *ri, const uint8_t *seg, const double *ground, int B, int P, int M,
                                 float *model, int32_t *counts, void *ws, void *stream) {
-    ARG_TRY(B > 0 && P > 0 && M > 0 && M <= RPCC_MAX_CLUSTERS && ri && seg && ground && model && ws);
+    ARG_TRY(B > 0 && B <= RPCC_MAX_BATCH && P > 0 && M > 0 && M <= RPCC_MAX_CLUSTERS && ri && seg && ground && model && ws);
     return launch_point_model(ri, seg, ground, B, P, M, model, counts, nullptr, ws, (hipStream_t)stream);
 }
 
@@ -1780,7 +1780,7 @@ static int launch_predict_quantize(const float *ri, const float *tm, const uint8
 extern "C" int rpcc_predict_quantize(const float *ri, const float *tm, const uint8_t *seg, const float *model,
                                      const float *label_acc, const float *residual_in, float acc, int B, int P, int M,
                                      int16_t *q16, int32_t *q32, int32_t *nnz, float *pred, void *ws, void *stream) {
-    ARG_TRY(B > 0 && P > 0 && M > 0 && M <= RPCC_MAX_CLUSTERS && seg && ws);
+    ARG_TRY(B > 0 && B <= RPCC_MAX_BATCH && P > 0 && M > 0 && M <= RPCC_MAX_CLUSTERS && seg && ws);
     ARG_TRY((residual_in && !pred) || (ri && tm && model));   // residual handed in, no prediction wanted: seg only
     ARG_TRY(q16 || q32);
     hipStream_t st = (hipStream_t)stream;
@@ -1810,7 +1810,7 @@ extern "C" size_t rpcc_codec_workspace_bytes(int B, int P, int M) {
 
 extern "C" int rpcc_contour_encode(const uint8_t *seg, int B, int H, int W, uint8_t *contour_bits, uint16_t *idx_sequence,
                                    int32_t *nseq, void *ws, void *stream) {
-    ARG_TRY(B > 0 && H > 0 && W > 0 && seg && contour_bits && idx_sequence && nseq && ws);
+    ARG_TRY(B > 0 && B <= RPCC_MAX_BATCH && H > 0 && W > 0 && seg && contour_bits && idx_sequence && nseq && ws);
     hipStream_t st = (hipStream_t)stream;
     const int P = H * W, T = ntiles(P);
     uint32_t *tile_cnt = reinterpret_cast<uint32_t *>(ws);
@@ -1823,7 +1823,7 @@ extern "C" int rpcc_contour_encode(const uint8_t *seg, int B, int H, int W, uint
 
 extern "C" int rpcc_contour_decode(const uint8_t *contour_bits, const uint16_t *idx_sequence, int B, int H, int W,
                                    uint8_t *seg, void *ws, void *stream) {
-    ARG_TRY(B > 0 && H > 0 && W > 0 && seg && contour_bits && idx_sequence && ws);
+    ARG_TRY(B > 0 && B <= RPCC_MAX_BATCH && H > 0 && W > 0 && seg && contour_bits && idx_sequence && ws);
     hipStream_t st = (hipStream_t)stream;
     const int P = H * W, T = ntiles(P);
     uint32_t *tile_cnt = reinterpret_cast<uint32_t *>(ws);
@@ -1837,7 +1837,7 @@ extern "C" int rpcc_contour_decode(const uint8_t *contour_bits, const uint16_t *
 extern "C" int rpcc_decode(const uint8_t *seg, const int16_t *q16, const float *model, const float *tm,
                            const double *level_acc, int levels, const uint8_t *salience, int B, int P, int M,
                            float *ri_rec, float *pc_rec, void *ws, void *stream) {
-    ARG_TRY(B > 0 && P > 0 && M > 0 && M <= RPCC_MAX_CLUSTERS && seg && q16 && model && tm && level_acc && ri_rec && ws);
+    ARG_TRY(B > 0 && B <= RPCC_MAX_BATCH && P > 0 && M > 0 && M <= RPCC_MAX_CLUSTERS && seg && q16 && model && tm && level_acc && ri_rec && ws);
     ARG_TRY(levels >= 0 && levels <= 8 && (levels == 0 || salience != nullptr));
     hipStream_t st = (hipStream_t)stream;
     const int KP = kpad(M), T = ntiles(P);
@@ -1859,7 +1859,7 @@ extern "C" int rpcc_decode(const uint8_t *seg, const int16_t *q16, const float *
 
 extern "C" int rpcc_pack_payload(const int16_t *q16, const int32_t *nnz, int B, int P, int16_t *packed, int64_t capacity,
                                  int64_t *total, void *stream) {
-    ARG_TRY(B > 0 && P > 0 && q16 && nnz && packed && capacity >= 0);
+    ARG_TRY(B > 0 && B <= RPCC_MAX_BATCH && P > 0 && q16 && nnz && packed && capacity >= 0);
     pack_payload_kernel<<<dim3((P + PACK_EPW - 1) / PACK_EPW, B), 256, 0, (hipStream_t)stream>>>(q16, nnz, P, capacity, packed,
                                                                                               total);
     LAUNCH_CHECK();
@@ -1867,7 +1867,7 @@ extern "C" int rpcc_pack_payload(const int16_t *q16, const int32_t *nnz, int B, 
 }
 
 extern "C" int rpcc_backproject(const float *ri, const float *tm, int B, int P, float *pc, void *stream) {
-    ARG_TRY(B > 0 && P > 0 && ri && tm && pc);
+    ARG_TRY(B > 0 && B <= RPCC_MAX_BATCH && P > 0 && ri && tm && pc);
     backproject_kernel<<<dim3((P + 255) / 256, B), 256, 0, (hipStream_t)stream>>>(ri, tm, P, pc);
     LAUNCH_CHECK();
     return RPCC_OK;
@@ -1881,7 +1881,7 @@ extern "C" int rpcc_backproject(const float *ri, const float *tm, int B, int P, 
 extern "C" int rpcc_extract_features(const float *ri, const uint8_t *seg, int B, int H, int W, int feature_region,
                                      int segments, int sharp_num, int less_sharp_num, int flat_num, float *feat,
                                      uint8_t *key_point_map, void *stream) {
-    ARG_TRY(B > 0 && H > 0 && W > 0 && ri && seg && feat && key_point_map);
+    ARG_TRY(B > 0 && B <= RPCC_MAX_BATCH && H > 0 && W > 0 && ri && seg && feat && key_point_map);
     ARG_TRY(feature_region >= 1 && feature_region <= 16 && segments >= 1 && W < 65536);
     hipStream_t st = (hipStream_t)stream;
     const size_t sh = (size_t)3 * W * 4 + (size_t)W * 2 + (size_t)W * 2 + 16;
@@ -1908,7 +1908,7 @@ extern "C" int rpcc_extract_features(const float *ri, const uint8_t *seg, int B,
 extern "C" int rpcc_salience(const uint8_t *seg, const uint8_t *key_point_map, const int32_t *level_kp_num,
                              const float *level_acc, int levels, int ground_level, int B, int P, int M,
                              uint8_t *salience, float *label_acc, void *stream) {
-    ARG_TRY(B > 0 && P > 0 && M > 0 && M <= RPCC_MAX_CLUSTERS && seg && key_point_map && salience && label_acc);
+    ARG_TRY(B > 0 && B <= RPCC_MAX_BATCH && P > 0 && M > 0 && M <= RPCC_MAX_CLUSTERS && seg && key_point_map && salience && label_acc);
     ARG_TRY(level_kp_num && level_acc && levels >= 1 && levels <= 8 && ground_level >= 0 && ground_level < levels);
     SalienceParams sp;
     for (int i = 0; i < 8; i++) { sp.level_kp_num[i] = i < levels ? level_kp_num[i] : 0; sp.level_acc[i] = i < levels ? level_acc[i] : 0.f; }
@@ -1921,7 +1921,7 @@ extern "C" int rpcc_salience(const uint8_t *seg, const uint8_t *key_point_map, c
 
 extern "C" int rpcc_intra_predict(const uint8_t *seg, const float *model, const float *tm, int B, int P, int M, float *pred,
                                   void *stream) {
-    ARG_TRY(B > 0 && P > 0 && M > 0 && seg && model && tm && pred);
+    ARG_TRY(B > 0 && B <= RPCC_MAX_BATCH && P > 0 && M > 0 && seg && model && tm && pred);
     intra_predict_kernel<<<dim3((P + 255) / 256, B), 256, 0, (hipStream_t)stream>>>(seg, model, tm, P, M + 2, pred);
     LAUNCH_CHECK();
     return RPCC_OK;
@@ -1941,7 +1941,7 @@ extern "C" size_t rpcc_plane_workspace_bytes(int B, int P, int M) {
 extern "C" int rpcc_plane_model(const float *ri, const float *tm, const uint8_t *seg, const double *ground, int B, int P,
                                 int M, double cos_cut, uint32_t seed, float *model, int32_t *counts, void *ws,
                                 void *stream) {
-    ARG_TRY(B > 0 && P > 0 && M > 0 && M <= RPCC_MAX_CLUSTERS && ri && tm && seg && model && counts && ws);
+    ARG_TRY(B > 0 && B <= RPCC_MAX_BATCH && P > 0 && M > 0 && M <= RPCC_MAX_CLUSTERS && ri && tm && seg && model && counts && ws);
     hipStream_t st = (hipStream_t)stream;
     const int KP = kpad(M), T = ntiles(P), K = M + 2;
     WsLayout L = ws_layout(ws, B, P, M);
@@ -2026,7 +2026,7 @@ static int run_slice(const rpcc_batch_io *io, int b0, int Bs, int64_t pt0, int64
 
 extern "C" int rpcc_compress_batch(const rpcc_batch_io *io, int B, rpcc_geom g, int M, double ground_threshold,
                                    float acc, void *ws, void *stream) {
-    ARG_TRY(io != nullptr && ws != nullptr && B > 0 && M > 0 && M <= RPCC_MAX_CLUSTERS && g.H > 1 && g.W > 0);
+    ARG_TRY(io != nullptr && ws != nullptr && B > 0 && B <= RPCC_MAX_BATCH && M > 0 && M <= RPCC_MAX_CLUSTERS && g.H > 1 && g.W > 0);
     ARG_TRY(io->offsets && io->tm && io->ground && io->ri && io->seg && io->cen_pix && io->centers && io->model &&
             io->counts && io->q16 && io->nnz && io->info);
     const int P = g.H * g.W;
