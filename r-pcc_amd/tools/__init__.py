@@ -1,0 +1,1 @@
+"""Command-line tools mirroring the reference's tools/ (compress, decompress, datalist drivers) on the HIP path."""
