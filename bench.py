@@ -27,6 +27,13 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
+def _flush_c_stdio():
+    try:
+        C.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -109,13 +116,10 @@ def main():
         # (rpcc_pack_payload: sum(nnz) <= its point count, so `cap` entries always fit) and rank 0 receives the packed
         # streams + the per-frame lengths.  cap = the largest rank's point count, agreed on once, outside the timing.
         import torch.distributed as dist
-        cap_t = torch.tensor([int(offs_host[-1] - offs_host[0])], dtype=torch.int64, device=dev)
-        dist.all_reduce(cap_t, op=dist.ReduceOp.MAX)
-        cap = int(cap_t.item())
+        from rpcc_amd.sharding import PackedExchange
+        cap = PackedExchange.agree_capacity(int(offs_host[-1] - offs_host[0]), dev)
         packed_l = [torch.zeros((cap,), dtype=torch.int16, device=dev) for _ in range(depth)]
-        nnz_all = [torch.empty_like(buf.nnz) for _ in range(world)]
-        # RCCL has no int16 type ("Unconvertible NCCL type Short"): the streams travel as bytes
-        pay_all = [torch.empty((2 * cap,), dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
+        exch = PackedExchange(B, cap, dev)
 
     step_no = [0]
     pack_tot = torch.zeros((1,), dtype=torch.int64, device=dev)
@@ -128,8 +132,7 @@ def main():
                                offsets_host=offs_host)
             if gather:
                 ops.pack_payload(bufs[k].q16, bufs[k].nnz, packed=packed_l[k], capacity=cap, total=pack_tot)
-                dist.all_gather(nnz_all, bufs[k].nnz)
-                dist.gather(packed_l[k].view(torch.uint8), pay_all, dst=0)
+                exch.step(packed_l[k], bufs[k].nnz)
 
     def barrier():
         torch.cuda.synchronize()
@@ -220,10 +223,14 @@ def main():
             out["cpu_baseline"] = {"value": round(v, 3), "unit": "frames/s", "cores": threads, "kind": "port",
                                    "sample": "%d of the same synthetic frames, C port of the reference cpu=True path "
                                              "(oracle/), frame-parallel over %d threads" % (S, threads)}
-        print(json.dumps(out), flush=True)
     if world > 1 or a.force_gather:
         dist.barrier()
         dist.destroy_process_group()
+    if out is not None:
+        # the ONE JSON line must be the last thing on stdout: libraries write there through C stdio as well (RCCL prints its
+        # version banner to stdout under NCCL_DEBUG=VERSION, and a pipe delays it until the buffer is flushed)
+        _flush_c_stdio()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -59,3 +59,34 @@ def gather_payloads(local_payloads, device, group=None, dst=0):
         for k, item in enumerate(per_rank[r]):
             out[r + k * world] = item
     return out
+
+
+class PackedExchange:
+    """The per-step exchange of bench.py / the batch drivers: every rank holds its frames' residual stream
+    packed back to back (rpcc_pack_payload; int16 entries, at most `cap` of them, cap = the largest rank's point count,
+    agreed on once with agree_capacity) plus the per-frame lengths nnz.  One step = all_gather of nnz + gather of the packed
+    stream to `dst`, as BYTES (RCCL has no 16-bit integer type).  The receive buffers are allocated once."""
+
+    def __init__(self, frames_per_rank, cap, device, group=None, dst=0):
+        self.world, self.rank, self.group, self.dst, self.cap = dist.get_world_size(group), dist.get_rank(group), group, dst, int(cap)
+        self.nnz_all = [torch.empty((frames_per_rank,), dtype=torch.int32, device=device) for _ in range(self.world)]
+        self.pay_all = ([torch.empty((2 * self.cap,), dtype=torch.uint8, device=device) for _ in range(self.world)]
+                        if self.rank == dst else None)
+
+    @staticmethod
+    def agree_capacity(local_points, device, group=None):
+        t = torch.tensor([int(local_points)], dtype=torch.int64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        return int(t.item())
+
+    def step(self, packed_i16, nnz_i32):
+        """packed_i16: int16 [cap] (this rank's stream, frames back to back), nnz_i32: int32 [frames_per_rank]."""
+        assert packed_i16.dtype == torch.int16 and packed_i16.numel() == self.cap
+        dist.all_gather(self.nnz_all, nnz_i32, group=self.group)
+        dist.gather(packed_i16.view(torch.uint8), self.pay_all, dst=self.dst, group=self.group)
+
+    def frame_stream(self, rank, frame):
+        """On dst, after step() completed: the int16 residual run of `frame` of `rank` (a view into the receive buffer)."""
+        nnz = self.nnz_all[rank].to(torch.int64)
+        start = int(nnz[:frame].sum().item())
+        return self.pay_all[rank].view(torch.int16)[start:start + int(nnz[frame].item())]

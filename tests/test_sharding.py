@@ -56,3 +56,55 @@ def test_shard_indices_partition():
             parts = [shard_indices(n, r, w) for r in range(w)]
             assert sorted(sum(parts, [])) == list(range(n))
             assert all(owner_of(i, w) == r for r in range(w) for i in parts[r])
+
+
+def _stream_of(rank, frame):
+    import numpy as np
+    rng = np.random.default_rng(1000 * rank + frame)
+    return rng.integers(-3000, 3000, int(rng.integers(0, 40)), dtype=np.int64).astype(np.int16)
+
+
+def _exchange_worker(rank, world, port, frames, q):
+    """What bench.py does per step at N > 1, with the device-side packing emulated on the CPU."""
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    import rpcc_amd  # noqa: F401
+    from rpcc_amd.sharding import PackedExchange
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cpu")
+    runs = [_stream_of(rank, f) for f in range(frames)]
+    points = sum(len(r) for r in runs) + 5 * (rank + 1)            # point counts differ between ranks; nnz <= points
+    cap = PackedExchange.agree_capacity(points, dev)
+    ex = PackedExchange(frames, cap, dev)
+    ok = []
+    for step in range(3):                                           # three steps reuse the receive buffers
+        packed = torch.zeros((cap,), dtype=torch.int16)
+        cat = np.concatenate([np.roll(r, step) for r in runs]) if runs else np.zeros(0, np.int16)
+        packed[: cat.shape[0]] = torch.from_numpy(cat)
+        nnz = torch.tensor([len(r) for r in runs], dtype=torch.int32)
+        ex.step(packed, nnz)
+        if rank == 0:
+            for r in range(world):
+                for f in range(frames):
+                    ok.append(np.array_equal(ex.frame_stream(r, f).numpy(), np.roll(_stream_of(r, f), step)))
+    if rank == 0:
+        q.put(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_packed_exchange():
+    """bench.py's exchange step (sharding.PackedExchange: capacity agreement, all_gather of the lengths, gather of the packed
+    int16 streams as bytes) between two gloo ranks: rank 0 can cut every frame's stream of every rank out of what it received."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, 2, 29655, 6, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert len(res) == 3 * 2 * 6 and all(res)
