@@ -915,7 +915,7 @@ def test_fuzz_fused_vs_oracle(env, seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,P", [(1, 7), (3, 2048), (37, 4099), (256, 131072)])
+@pytest.mark.parametrize("B,P", [(1, 7), (3, 2048), (37, 4099), (5, 4096), (6, 8192), (256, 131072)])
 def test_pack_payload(env, B, P):
     """f2: the frames' int16 runs back to back (prefix sums on the device), incl. empty frames, full frames, a capacity
     that cuts the stream, and -- at the bench size -- the stream of a real batch."""
@@ -926,6 +926,8 @@ def test_pack_payload(env, B, P):
     nnz[0] = P
     if B > 2:
         nnz[1], nnz[-1] = 0, P
+    if B > 4:
+        nnz[2], nnz[3] = P - 1, P                                          # odd prefix in front of a full frame
     want = np.concatenate([q[b, : nnz[b]] for b in range(B)])
     packed, total = ops.pack_payload(_to(env, q), _to(env, nnz))
     assert int(total.item()) == want.shape[0]
