@@ -167,7 +167,9 @@ int rpcc_intra_predict(const uint8_t *seg, const float *model, const float *tm, 
  * replaces feature_extractor_cpp.extract_features_with_segment (cpp_modules.cpp:28-121, mark_as_picked
  * :10-25) with zero-initialised outputs (the reference leaves unwritten cells uninitialised).
  *   feat          dev f32 [B,H,W] out   curvature feature
- *   key_point_map dev u8  [B,H,W] out   0 none, 1 flat, 2 less sharp, 3 sharp                         */
+ *   key_point_map dev u8  [B,H,W] out   0 none, 1 flat, 2 less sharp, 3 sharp
+ * Limits: W <= 4096 (a row lives in one workgroup's registers / LDS), 1 <= feature_region <= 16, segments >= 1;
+ * any chunk length (W / segments) and any sharp / less_sharp / flat counts.                            */
 int rpcc_extract_features(const float *ri, const uint8_t *seg, int B, int H, int W, int feature_region, int segments,
                           int sharp_num, int less_sharp_num, int flat_num, float *feat, uint8_t *key_point_map,
                           void *stream);
