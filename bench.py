@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL payload gather")
     ap.add_argument("--force-gather", action="store_true",
                     help="N=1: run the exchange step as well (single-rank RCCL group) -- exercises the N>1 code path on one GPU")
+    ap.add_argument("--fps-bruteforce", action="store_true",
+                    help="run the brute-force FPS kernel (streams every candidate for every sample: the reference algorithm's "
+                         "roofline case) instead of the exact tile-pruned one; same results")
     ap.add_argument("--slices", type=int, default=None, help="sub-batches on internal streams (library default 1)")
     ap.add_argument("--pipeline", type=int, default=3, help="batches in flight (streams); 1 = strictly serial steps")
     return ap.parse_args()
@@ -100,6 +103,8 @@ def main():
     offs_host = offs.cpu().numpy()      # frame boundaries are host knowledge (file sizes); enables sub-batch streams
     if a.slices is not None:
         ops.set_batch_slices(a.slices)
+    if a.fps_bruteforce:
+        ops.fps_force_bruteforce(True)
     tm = torch.from_numpy(tm_np).to(dev)
     # Two batches in flight (software pipeline, depth --pipeline): step n runs on stream n % depth with its own
     # output buffers, so the latency-bound kernels of one step (FPS, ground fit: one workgroup per frame)
@@ -185,7 +190,7 @@ def main():
         traffic, traffic_src = None, None
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))
-            if pm["config"] == {"batch": B, "geom": a.geom, "clusters": M}:
+            if pm["config"] == {"batch": B, "geom": a.geom, "clusters": M} and not a.fps_bruteforce:
                 key = [k for k in pm["kernels"] if k.startswith("fps_tiled_kernel<true")][0]   # template arguments vary
                 traffic = pm["kernels"][key]["traffic_bytes_per_launch"] / pm.get("launches_per_step", 1)
                 traffic_src = "profiles/%s_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, x2 read correction)" % pm.get("tag", "r01_v14")
@@ -200,7 +205,7 @@ def main():
                                    "point-model, accuracy=%g, cluster_num=%d, ground plane by seeded RANSAC inside the step" % (B, H, W, a.accuracy, M),
                        "frames_per_gpu_per_step": B, "batches_in_flight": depth, "sharding": "frames over ranks, no data-path collective"
                        + (", per step RCCL all_gather of the frame lengths + gather of the packed residual streams to rank 0" if gather else "")},
-            "roofline": {"bound": "hbm", "kernel": "fps_tiled_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "fps_range_kernel (brute force)" if a.fps_bruteforce else "fps_tiled_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_source": traffic_src,
                          "traffic_GBs": (round(traffic / (fps_launch_ms * 1e-3) / 1e9, 2) if traffic else None),
