@@ -128,6 +128,7 @@ def main():
 
     step_no = [0]
     pack_tot = torch.zeros((1,), dtype=torch.int64, device=dev)
+    exchange_note = None
 
     def step():
         k = step_no[0] % depth
@@ -152,6 +153,21 @@ def main():
             ops.compress_batch(xyz, offs, tm, gms_l[k], bufs[k], ground_threshold=0.1, acc=acc, ground_seed=rank * B,
                                offsets_host=offs_host)
     torch.cuda.synchronize()
+    if gather:
+        # one untimed trial of the exchange with a content check on rank 0 (its own frames must come back as they were
+        # packed).  An error that every rank sees alike (an unsupported dtype, a missing backend feature) switches the
+        # exchange off instead of killing the run -- and says so in the JSON line.
+        try:
+            ops.pack_payload(bufs[0].q16, bufs[0].nnz, packed=packed_l[0], capacity=cap, total=pack_tot)
+            exch.step(packed_l[0], bufs[0].nnz)
+            torch.cuda.synchronize()
+            if rank == 0:
+                for f in (0, B // 2, B - 1):
+                    n = int(bufs[0].nnz[f])
+                    assert torch.equal(exch.frame_stream(0, f), bufs[0].q16[f, :n]), "exchange returned other data than packed"
+        except Exception as e:  # noqa: BLE001
+            gather = False
+            exchange_note = "exchange disabled after its trial failed: %s" % (str(e).splitlines()[0][:200],)
     for _ in range(a.warmup):
         step()
     barrier()
@@ -204,7 +220,8 @@ def main():
             "config": {"workload": "configs[1]: batch=%d synthetic Velodyne-64E frames (%dx%d) per GPU, uniform + FPS + "
                                    "point-model, accuracy=%g, cluster_num=%d, ground plane by seeded RANSAC inside the step" % (B, H, W, a.accuracy, M),
                        "frames_per_gpu_per_step": B, "batches_in_flight": depth, "sharding": "frames over ranks, no data-path collective"
-                       + (", per step RCCL all_gather of the frame lengths + gather of the packed residual streams to rank 0" if gather else "")},
+                       + (", per step RCCL all_gather of the frame lengths + gather of the packed residual streams to rank 0" if gather else "")
+                       + ("; " + exchange_note if exchange_note else "")},
             "roofline": {"bound": "hbm", "kernel": "fps_range_kernel (brute force)" if a.fps_bruteforce else "fps_tiled_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_source": traffic_src,
