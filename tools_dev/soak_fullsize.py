@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Soak check at the bench geometry: N synthetic 64x2048 frames through the fused entry (ground fitted inside) against the
-CPU oracle frame by frame -- range image, FPS pixels, labels, model rows, quantised integers.  usage: soak_fullsize.py [N] [first_id]"""
+CPU oracle frame by frame -- range image, FPS pixels, labels, model rows, quantised integers.  usage: soak_fullsize.py [N] [first_id] [geometry]"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from concurrent.futures import ThreadPoolExecutor
@@ -11,9 +11,11 @@ from oracle import oracle as orc
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 100000
+gname = sys.argv[3] if len(sys.argv) > 3 else "Velodyne64E_2048"      # a key of oracle.GEOMS
 dev = torch.device("cuda:0")
-H, W, M = 64, 2048, 100
-g = orc.LidarGeom(H=H, W=W, hfov_deg=360, vmax_deg=2.0, vmin_deg=-24.9)
+gd = orc.GEOMS[gname]
+H, W, M = gd["H"], gd["W"], 100
+g = orc.LidarGeom(**gd)
 tm = orc.transform_map(g)
 geom = ops.make_geom(H, W, g.horizontal_FOV, g.vertical_max, g.vertical_min)
 orc.lib()
@@ -21,7 +23,7 @@ bad = 0
 t0 = time.time()
 for c0 in range(0, N, 256):
     ids = list(range(first + c0, first + min(c0 + 256, N)))
-    xyz, offs = synth.make_batch(ids, H, W, device=dev)
+    xyz, offs = synth.make_batch(ids, H, W, device=dev, vmax_deg=gd["vmax_deg"], vmin_deg=gd["vmin_deg"])
     B = len(ids)
     buf = ops.BatchBuffers(B, geom, M, dev, max_points=xyz.shape[0])
     gfit = torch.zeros((B, 4), dtype=torch.float64, device=dev)
@@ -46,5 +48,5 @@ for c0 in range(0, N, 256):
         res = list(ex.map(check, range(B)))
     bad += res.count(False)
     print("frames %d..%d: %d mismatching" % (ids[0], ids[-1], res.count(False)), flush=True)
-print("soak: %d frames, %d mismatching, %.0f s" % (N, bad, time.time() - t0))
+print("soak %s: %d frames, %d mismatching, %.0f s" % (gname, N, bad, time.time() - t0))
 sys.exit(1 if bad else 0)
