@@ -61,8 +61,10 @@ class BatchCompressor:
         return dict(n=len(frames), buf=buf, bits=bits, nseq=nseq, sal=sal, qp=qp, qtot=qtot, sp=sp, stot=stot,
                     stream=torch.cuda.current_stream(self.device), keep=(xyz, g, seq))
 
-    def collect(self, ctx):
-        """Waits for submit()'s stream and assembles the .rpcc byte strings (host part: casts, container, entropy coder)."""
+    def collect(self, ctx, pool=None):
+        """Waits for submit()'s stream and assembles the .rpcc byte strings (host part: casts, container, entropy coder).
+        pool: a concurrent.futures executor -- the frames' entropy coding then runs on its threads (bz2 / zlib / lz4
+        release the GIL), like the reference's --workers ThreadPoolExecutor (tools/compress_datalist.py:202-206)."""
         ctx["stream"].synchronize()
         buf, bits, nseq, sal = ctx["buf"], ctx["bits"], ctx["nseq"], ctx["sal"]
         nnz, nseq_h = buf.nnz.cpu().numpy(), nseq.cpu().numpy()
@@ -72,8 +74,7 @@ class BatchCompressor:
         qo, so = np.concatenate([[0], np.cumsum(nnz)]), np.concatenate([[0], np.cumsum(nseq_h)])
         bits_h, model = bits.cpu().numpy(), buf.model.cpu().numpy()
         sal_h = None if sal is None else sal.cpu().numpy()
-        out = []
-        for b in range(ctx["n"]):
+        def assemble(b):
             nrow = int(np.flatnonzero(seg_max[b])[-1]) + 1          # max(seg)+1 rows (tools/compress.py:102)
             od = {"residual_quantized": q16[qo[b]: qo[b + 1]]}
             if sal_h is not None:
@@ -81,12 +82,14 @@ class BatchCompressor:
             od["contour_map"] = bits_h[b]
             od["idx_sequence"] = seq_h[so[b]: so[b + 1]]
             od["plane_param"] = model[b, :nrow]
-            out.append(pack_bitstream(self.bc.compress_dict(od), uniform=self.uniform))
-        return out
+            return pack_bitstream(self.bc.compress_dict(od), uniform=self.uniform)
+        if pool is not None:
+            return list(pool.map(assemble, range(ctx["n"])))
+        return [assemble(b) for b in range(ctx["n"])]
 
-    def compress(self, frames, ground=None):
+    def compress(self, frames, ground=None, pool=None):
         """frames: list of [N,3] arrays.  -> list of .rpcc byte strings (one per frame)."""
-        return self.collect(self.submit(frames, ground))
+        return self.collect(self.submit(frames, ground), pool=pool)
 
 
 class MixedBatchCompressor:

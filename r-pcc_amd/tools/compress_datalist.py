@@ -52,7 +52,7 @@ def compress(args):
             idx = mine[s:s + args.batch]
             names = [dataset.data_list[i] for i in idx]
             frames = list(pool.map(dataset.load_data, names))
-            blobs = bc.compress(frames)
+            blobs = bc.compress(frames, pool=pool)       # device part, then the entropy coder on the pool's threads
 
             def write(job):
                 name, blob = job

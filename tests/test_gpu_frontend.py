@@ -236,3 +236,18 @@ def test_mixed_lidar_batch(fe):
         single = fe.pl.BatchCompressor(T[n], **kw).compress([frames[i] for i in idx])
         for i, blob in zip(idx, single):
             assert mixed[i] == blob, (n, i)
+
+
+def test_entropy_coding_on_a_thread_pool(fe):
+    """collect(pool=...) -- the frames' entropy coding on executor threads, as the reference's --workers pool does -- gives the
+    same .rpcc strings in the same order."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as orc
+    from rpcc_amd import synth
+    gd = orc.GEOMS["VelodyneVLP16"]
+    T = fe.ds.build_dataset(lidar_type="VelodyneVLP16").PCTransformer
+    frames = [synth.make_frame(6000 + i, gd["H"], gd["W"], vmax_deg=gd["vmax_deg"], vmin_deg=gd["vmin_deg"]).numpy() for i in range(9)]
+    bc = fe.pl.BatchCompressor(T, accuracy=0.02, seed=2)
+    serial = bc.compress(frames)
+    with ThreadPoolExecutor(4) as pool:
+        assert bc.compress(frames, pool=pool) == serial
