@@ -21,3 +21,7 @@ with ThreadPoolExecutor(os.cpu_count() or 8) as pool:
 assert blobs == blobs2
 print("%d frames end to end: entropy coder serial %.2f s (%.0f frames/s), on %d threads %.2f s (%.0f frames/s); %.1f KB per frame"
       % (B, t1, B / t1, os.cpu_count(), t2, B / t2, sum(map(len, blobs)) / B / 1024))
+with ThreadPoolExecutor(os.cpu_count() or 8) as pool:
+    t0 = time.perf_counter(); ctx = bc.submit(frames); torch.cuda.synchronize(); ts = time.perf_counter() - t0
+    t0 = time.perf_counter(); bc.collect(ctx, pool=pool); tc = time.perf_counter() - t0
+print("split: submit (concatenate + H2D + device part) %.3f s, collect (D2H + entropy coding + container) %.3f s" % (ts, tc))
