@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL payload gather")
     ap.add_argument("--force-gather", action="store_true",
                     help="N=1: run the exchange step as well (single-rank RCCL group) -- exercises the N>1 code path on one GPU")
+    ap.add_argument("--h2d", action="store_true",
+                    help="copy the batch's points from pinned host memory to the device inside every step (PCIe-inclusive rate; "
+                         "NOT the headline configuration, which has its inputs resident in HBM)")
     ap.add_argument("--fps-bruteforce", action="store_true",
                     help="run the brute-force FPS kernel (streams every candidate for every sample: the reference algorithm's "
                          "roofline case) instead of the exact tile-pruned one; same results")
@@ -115,6 +118,9 @@ def main():
     streams = [torch.cuda.Stream(device=dev) for _ in range(depth)] if depth > 1 else [torch.cuda.current_stream()]
     buf, gms = bufs[0], gms_l[0]
 
+    if a.h2d:
+        xyz_host = xyz.cpu().pin_memory()
+        xyz_l = [torch.empty_like(xyz) for _ in range(depth)]
     gather = (world > 1 or a.force_gather) and not a.no_gather
     if gather:
         # the exchange step: per step every rank packs its frames' residual runs back to back
@@ -134,7 +140,11 @@ def main():
         k = step_no[0] % depth
         step_no[0] += 1
         with torch.cuda.stream(streams[k]):
-            ops.compress_batch(xyz, offs, tm, gms_l[k], bufs[k], ground_threshold=0.1, acc=acc, ground_seed=rank * B,
+            src = xyz
+            if a.h2d:
+                xyz_l[k].copy_(xyz_host, non_blocking=True)
+                src = xyz_l[k]
+            ops.compress_batch(src, offs, tm, gms_l[k], bufs[k], ground_threshold=0.1, acc=acc, ground_seed=rank * B,
                                offsets_host=offs_host)
             if gather:
                 ops.pack_payload(bufs[k].q16, bufs[k].nnz, packed=packed_l[k], capacity=cap, total=pack_tot)
@@ -219,7 +229,10 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[1]: batch=%d synthetic Velodyne-64E frames (%dx%d) per GPU, uniform + FPS + "
                                    "point-model, accuracy=%g, cluster_num=%d, ground plane by seeded RANSAC inside the step" % (B, H, W, a.accuracy, M),
-                       "frames_per_gpu_per_step": B, "batches_in_flight": depth, "sharding": "frames over ranks, no data-path collective"
+                       "frames_per_gpu_per_step": B, "batches_in_flight": depth,
+                       "inputs": ("copied from pinned host memory inside every step (PCIe-inclusive run, not the headline)" if a.h2d
+                                  else "resident in HBM before the timed region"),
+                       "sharding": "frames over ranks, no data-path collective"
                        + (", per step RCCL all_gather of the frame lengths + gather of the packed residual streams to rank 0" if gather else "")
                        + ("; " + exchange_note if exchange_note else "")},
             "roofline": {"bound": "hbm", "kernel": "fps_range_kernel (brute force)" if a.fps_bruteforce else "fps_tiled_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
