@@ -37,8 +37,8 @@ def _flush_c_stdio():
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)   # three batches in flight: the drain at the end of the timed region costs
+    ap.add_argument("--warmup", type=int, default=5)   # about one step, so very short runs under-report (5 steps: -8 %, 20: -2 %)
     ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
     ap.add_argument("--geom", default="64x2048")
     ap.add_argument("--clusters", type=int, default=100)
