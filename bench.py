@@ -81,6 +81,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world and rank == 0:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d -- N > 1 needs one process per GPU (python -m torch.distributed.run "
+              "--nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N); measuring %d GPU(s)" % (a.gpus, world, world),
+              file=sys.stderr)
     if world > 1 or a.force_gather:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
