@@ -3,28 +3,31 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path (projection -> ground mask -> FPS segmentation -> point model ->
+One "step" = one pass of the hot path (projection -> ground fit + mask -> FPS segmentation -> model ->
 intra-prediction -> quantisation + ordered scatter; entropy coder and file I/O excluded) over one
 batch of synthetic 64x2048 sweeps (BASELINE.json configs[1]: batch = 256 frames per GPU, uniform + FPS +
-point model, accuracy 0.02).  Inputs are resident in HBM before the timed region.  N > 1: one process
-per GPU (torch.distributed / RCCL), frames sharded across ranks (weak scaling, no data-path
-collective); each step ends with the exchange of configs[3]: the frames' residual streams, packed back to
-back on the device, are gathered to rank 0 over RCCL (inside the timed region, overlapped with the next steps).  Rank 0 prints ONE JSON line.
+point model, accuracy 0.02).  Inputs are resident in HBM before the timed region.
+
+N > 1: one process per GPU (torch.distributed / RCCL), frames sharded across ranks (weak scaling, no data-path
+collective).  Started without a launcher (`python bench.py --gpus N`) the parent spawns the N rank processes itself --
+before it touches the GPU -- and relays rank 0's JSON line; under `python -m torch.distributed.run` the ranks are the
+launcher's.  Per step the ranks exchange what rank 0 needs (SURVEY 8e): the per-frame payload lengths (all_gather);
+`--gather-payloads` additionally gathers the packed residual streams to rank 0 (configs[3] read literally).
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+VALU_PEAK_WAVE_INSTS_PER_S = 1024 * 2.4e9 / 2  # 1024 SIMDs, one wave64 VALU instruction per 2 cycles at 2.4 GHz
 
 
 def _flush_c_stdio():
@@ -40,11 +43,18 @@ def parse():
     ap.add_argument("--steps", type=int, default=50)   # three batches in flight: the drain at the end of the timed region costs
     ap.add_argument("--warmup", type=int, default=5)   # about one step, so very short runs under-report (5 steps: -8 %, 20: -2 %)
     ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
-    ap.add_argument("--geom", default="64x2048")
+    ap.add_argument("--geom", default=None, help="HxW (default 64x2048; 64x2000 with --input)")
     ap.add_argument("--clusters", type=int, default=100)
     ap.add_argument("--accuracy", type=float, default=0.02)
+    ap.add_argument("--config", type=int, default=1, choices=(1, 2),
+                    help="BASELINE.json configs[]: 1 = uniform + point model (headline), 2 = non-uniform + plane model")
+    ap.add_argument("--input", default=None,
+                    help="real sweep (.npz with 'xyz', .bin or .npy): the batch is this frame replicated with a per-copy yaw "
+                         "rotation and point shuffle instead of the synthetic scene (64x2000 unless --geom)")
     ap.add_argument("--cpu-sample", type=int, default=24, help="frames timed on the host for cpu_baseline (0 = skip)")
-    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL payload gather")
+    ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the outputs after the timed region")
+    ap.add_argument("--gather-payloads", action="store_true", help="N>1: also gather the packed residual streams to rank 0 every step")
+    ap.add_argument("--no-gather", action="store_true", help="N>1: no exchange at all")
     ap.add_argument("--force-gather", action="store_true",
                     help="N=1: run the exchange step as well (single-rank RCCL group) -- exercises the N>1 code path on one GPU")
     ap.add_argument("--h2d", action="store_true",
@@ -53,38 +63,93 @@ def parse():
     ap.add_argument("--fps-bruteforce", action="store_true",
                     help="run the brute-force FPS kernel (streams every candidate for every sample: the reference algorithm's "
                          "roofline case) instead of the exact tile-pruned one; same results")
-    ap.add_argument("--slices", type=int, default=None, help="sub-batches on internal streams (library default 1)")
     ap.add_argument("--pipeline", type=int, default=3, help="batches in flight (streams); 1 = strictly serial steps")
     return ap.parse_args()
 
 
-def cpu_baseline(frames, gms, g, tm, cfg, threads):
-    """The CPU oracle (plain-C port of the reference's cpu=True path, validated bit-exact against the
-    reference) on a bounded sample, frame-parallel like the reference's --workers ThreadPool
-    (tools/compress_datalist.py:202-206).  ctypes releases the GIL inside the C calls."""
-    from concurrent.futures import ThreadPoolExecutor
-    from oracle import oracle as orc
-    orc.lib()
-    def run(i):   # ground RANSAC (sequential form of the same specification) + the reference hot path
-        gm = orc.ground_model(orc.project(frames[i], g), tm, seed=i)
-        return orc.compress_frame(frames[i], g, tm, gm, cfg)["q"].shape[0]
-    run(0)
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(threads) as ex:
-        list(ex.map(run, range(len(frames))))
-    dt = time.perf_counter() - t0
-    return len(frames) / dt
+# ----------------------------------------------------------------------------------------------------------------------
+# N > 1 without a launcher: spawn the ranks.  The parent never initialises the GPU (torch.cuda.device_count() does not).
+# ----------------------------------------------------------------------------------------------------------------------
+def spawn_ranks(n):
+    import socket
+    import torch
+    have = torch.cuda.device_count()
+    if have < n:
+        print("bench.py: --gpus %d but only %d GPU(s) are visible" % (n, have), file=sys.stderr)
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].stdout.read().decode(errors="replace")
+    rcs = [p.wait() for p in procs]
+    if any(rcs):
+        sys.stdout.write(out0)
+        print("bench.py: rank exit codes %s" % rcs, file=sys.stderr)
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        return 1
+    lines = [ln for ln in out0.splitlines() if ln.startswith("{")]
+    if not lines:
+        print("bench.py: rank 0 printed no JSON line", file=sys.stderr)
+        return 1
+    rec = json.loads(lines[-1])
+    if rec.get("n_gpus") != n:
+        print("bench.py: asked for %d GPUs, %s ranks joined" % (n, rec.get("n_gpus")), file=sys.stderr)
+        return 1
+    for ln in out0.splitlines():           # the JSON line stays the last line on stdout
+        if ln is not lines[-1]:
+            print(ln)
+    print(lines[-1], flush=True)
+    return 0
+
+
+def load_real_batch(path, ids, H, W, dev):
+    """The real sweep replicated: copy i = the frame rotated about z by i * 2pi/|ids| (+ a little) and shuffled."""
+    import numpy as np
+    import torch
+    if path.endswith(".npz"):
+        xyz = np.load(path)["xyz"]
+    elif path.endswith(".bin"):
+        xyz = np.fromfile(path, dtype=np.float32).reshape(-1, 4)[:, :3]
+    else:
+        xyz = np.load(path)[:, :3]
+    xyz = np.ascontiguousarray(xyz[:, :3], dtype=np.float32)
+    frames = []
+    for i in ids:
+        rng = np.random.Generator(np.random.PCG64(77_000 + int(i)))
+        a = 2 * np.pi * ((int(i) * 0.61803398875) % 1.0)
+        c, s = np.float32(np.cos(a)), np.float32(np.sin(a))
+        f = xyz[rng.permutation(xyz.shape[0])]
+        frames.append(np.stack([c * f[:, 0] - s * f[:, 1], s * f[:, 0] + c * f[:, 1], f[:, 2]], 1).astype(np.float32))
+    offs = np.zeros(len(frames) + 1, np.int64)
+    offs[1:] = np.cumsum([f.shape[0] for f in frames])
+    return torch.from_numpy(np.concatenate(frames)).to(dev), torch.from_numpy(offs).to(dev)
 
 
 def main():
     a = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and a.gpus > 1:
+        sys.exit(spawn_ranks(a.gpus))
+    world = int(env_world or "1")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus != world and rank == 0:
-        print("bench.py: --gpus %d but WORLD_SIZE=%d -- N > 1 needs one process per GPU (python -m torch.distributed.run "
-              "--nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N); measuring %d GPU(s)" % (a.gpus, world, world),
-              file=sys.stderr)
+    if a.gpus != world:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d" % (a.gpus, world), file=sys.stderr)
+        sys.exit(2)
+
+    import numpy as np
+    import torch
+    dist = None
     if world > 1 or a.force_gather:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -96,49 +161,61 @@ def main():
 
     import rpcc_amd  # noqa: F401
     from rpcc_amd import ops, synth, _lib
+    from rpcc_amd.pipeline import BatchCompressor  # noqa: F401
 
-    H, W = (int(v) for v in a.geom.split("x"))
+    geom_s = a.geom or ("64x2000" if a.input else "64x2048")
+    H, W = (int(v) for v in geom_s.split("x"))
     hfov, vmax, vmin = 360 * (np.pi / 180), 2.0 * (np.pi / 180), -24.9 * (np.pi / 180)
     geom = ops.make_geom(H, W, hfov, vmax, vmin)
     tm_np = ops.transform_map(H, W, hfov, vmax, vmin)
     P, M, B = H * W, a.clusters, a.batch
     acc = a.accuracy * 2
+    general = a.config == 2            # non-uniform framework + plane model
 
-    # synthetic batch for this rank: frame ids are disjoint across ranks (frame-sharded datalist)
-    ids = range(rank * B, rank * B + B)
-    xyz, offs = synth.make_batch(ids, H, W, device=dev)
-    offs_host = offs.cpu().numpy()      # frame boundaries are host knowledge (file sizes); enables sub-batch streams
-    if a.slices is not None:
-        ops.set_batch_slices(a.slices)
-    if a.fps_bruteforce:
-        ops.fps_force_bruteforce(True)
+    # this rank's batch: frame ids are disjoint across ranks (frame-sharded datalist)
+    ids = list(range(rank * B, rank * B + B))
+    if a.input:
+        xyz, offs = load_real_batch(a.input, ids, H, W, dev)
+    else:
+        xyz, offs = synth.make_batch(ids, H, W, device=dev)
+    offs_host = offs.cpu().numpy()
+    fid = torch.as_tensor(np.asarray(ids, np.int64), device=dev)
     tm = torch.from_numpy(tm_np).to(dev)
-    # Two batches in flight (software pipeline, depth --pipeline): step n runs on stream n % depth with its own
+    # batches in flight (software pipeline, depth --pipeline): step n runs on stream n % depth with its own
     # output buffers, so the latency-bound kernels of one step (FPS, ground fit: one workgroup per frame)
     # overlap the throughput-bound kernels of the next.  Every step is complete when the timed region ends.
     depth = max(1, a.pipeline)
-    bufs = [ops.BatchBuffers(B, geom, M, dev) for _ in range(depth)]
+    bufs = [ops.BatchBuffers(B, geom, M, dev, general=general) for _ in range(depth)]
     gms_l = [torch.zeros((B, 4), dtype=torch.float64, device=dev) for _ in range(depth)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(depth)] if depth > 1 else [torch.cuda.current_stream()]
-    buf, gms = bufs[0], gms_l[0]
+    timer = ops.FpsTimer()
+    nu = ops.nonuniform_cfg(acc) if general else None    # compressor.yaml defaults (levels 30/10/3/0, +0/.02/.04/.06 m)
 
     if a.h2d:
         xyz_host = xyz.cpu().pin_memory()
         xyz_l = [torch.empty_like(xyz) for _ in range(depth)]
-    gather = (world > 1 or a.force_gather) and not a.no_gather
-    if gather:
-        # the exchange step: per step every rank packs its frames' residual runs back to back
-        # (rpcc_pack_payload: sum(nnz) <= its point count, so `cap` entries always fit) and rank 0 receives the packed
-        # streams + the per-frame lengths.  cap = the largest rank's point count, agreed on once, outside the timing.
-        import torch.distributed as dist
+    exchange = (world > 1 or a.force_gather) and not a.no_gather
+    exch = None
+    exchange_bytes = 0
+    if exchange:
+        # the exchange step.  Default: what rank 0 needs to index the job -- the per-frame payload lengths
+        # (the payload bytes stay with the rank that made them and writes its own .rpcc files, as
+        # tools/compress_datalist.py does).  --gather-payloads: every rank also packs its frames' residual runs back to
+        # back (rpcc_pack_payload: sum(nnz) <= its point count, so `cap` entries always fit) and rank 0 receives them.
         from rpcc_amd.sharding import PackedExchange
-        cap = PackedExchange.agree_capacity(int(offs_host[-1] - offs_host[0]), dev)
-        packed_l = [torch.zeros((cap,), dtype=torch.int16, device=dev) for _ in range(depth)]
-        exch = PackedExchange(B, cap, dev)
+        cap = PackedExchange.agree_capacity(int(offs_host[-1] - offs_host[0]), dev) if a.gather_payloads else 0
+        packed_l = [torch.zeros((max(cap, 1),), dtype=torch.int16, device=dev) for _ in range(depth)]
+        exch = PackedExchange(B, cap, dev, payloads=a.gather_payloads)
+        exchange_bytes = exch.bytes_per_step()
 
     step_no = [0]
     pack_tot = torch.zeros((1,), dtype=torch.int64, device=dev)
     exchange_note = None
+
+    def run(k, src, timed=True):
+        ops.compress_batch(src, offs, tm, gms_l[k], bufs[k], ground_threshold=0.1, acc=acc, ground_seed=0, frame_ids=fid,
+                           fps_bruteforce=a.fps_bruteforce, timer=timer if timed else None,
+                           model_method="plane" if general else "point", angle_threshold=75, plane_seed=0, nonuniform=nu)
 
     def step():
         k = step_no[0] % depth
@@ -148,15 +225,15 @@ def main():
             if a.h2d:
                 xyz_l[k].copy_(xyz_host, non_blocking=True)
                 src = xyz_l[k]
-            ops.compress_batch(src, offs, tm, gms_l[k], bufs[k], ground_threshold=0.1, acc=acc, ground_seed=rank * B,
-                               offsets_host=offs_host)
-            if gather:
-                ops.pack_payload(bufs[k].q16, bufs[k].nnz, packed=packed_l[k], capacity=cap, total=pack_tot)
+            run(k, src)
+            if exchange:
+                if a.gather_payloads:
+                    ops.pack_payload(bufs[k].q16, bufs[k].nnz, packed=packed_l[k], capacity=cap, total=pack_tot)
                 exch.step(packed_l[k], bufs[k].nnz)
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1 or a.force_gather:
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -164,105 +241,171 @@ def main():
     # kernel attribute calls and page faults of its buffers are not billed to a timed step
     for k in range(depth):
         with torch.cuda.stream(streams[k]):
-            ops.compress_batch(xyz, offs, tm, gms_l[k], bufs[k], ground_threshold=0.1, acc=acc, ground_seed=rank * B,
-                               offsets_host=offs_host)
+            run(k, xyz, timed=False)
     torch.cuda.synchronize()
-    if gather:
+    if exchange:
         # one untimed trial of the exchange with a content check on rank 0 (its own frames must come back as they were
         # packed).  An error that every rank sees alike (an unsupported dtype, a missing backend feature) switches the
         # exchange off instead of killing the run -- and says so in the JSON line.
         try:
-            ops.pack_payload(bufs[0].q16, bufs[0].nnz, packed=packed_l[0], capacity=cap, total=pack_tot)
+            if a.gather_payloads:
+                ops.pack_payload(bufs[0].q16, bufs[0].nnz, packed=packed_l[0], capacity=cap, total=pack_tot)
             exch.step(packed_l[0], bufs[0].nnz)
             torch.cuda.synchronize()
             if rank == 0:
-                for f in (0, B // 2, B - 1):
-                    n = int(bufs[0].nnz[f])
-                    assert torch.equal(exch.frame_stream(0, f), bufs[0].q16[f, :n]), "exchange returned other data than packed"
+                assert torch.equal(exch.nnz_all[0], bufs[0].nnz), "exchange returned other lengths than sent"
+                if a.gather_payloads:
+                    for f in (0, B // 2, B - 1):
+                        n = int(bufs[0].nnz[f])
+                        assert torch.equal(exch.frame_stream(0, f), bufs[0].q16[f, :n]), "exchange returned other data than packed"
         except Exception as e:  # noqa: BLE001
-            gather = False
+            exchange = False
             exchange_note = "exchange disabled after its trial failed: %s" % (str(e).splitlines()[0][:200],)
     for _ in range(a.warmup):
         step()
     barrier()
-    lib = _lib.lib()
-    lib.rpcc_fps_timing(1)
+    timer.read()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
     barrier()
     dt = time.perf_counter() - t0
-    fps_ms, fps_n = C.c_double(0), C.c_int(0)
-    lib.rpcc_fps_time_ms(C.byref(fps_ms), C.byref(fps_n))
-    lib.rpcc_fps_timing(0)
+    fps_ms, fps_n = timer.read()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    buf = bufs[0]
     info = buf.info.cpu().numpy()
     n_left, nnz = info[:, 0].astype(np.int64), info[:, 2].astype(np.int64)
-    n_in = np.diff(offs.cpu().numpy())
+    n_in = np.diff(offs_host)
     # algorithmic bytes (stream-once model per stage)
     fps_bytes = 20.0 * (M - 1) * n_left.sum()
     b_alg = 12.0 * n_in.sum() + 92.0 * P * B + 2.0 * nnz.sum() + fps_bytes
 
+    # ---- after the timed region: the outputs of EVERY pipeline slot against the CPU oracle (sampled frames) ------------
+    from oracle import oracle as orc
+    g_o = orc.LidarGeom(H=H, W=W, hfov_deg=360, vmax_deg=2.0, vmin_deg=-24.9)
+    cfg_o = dict(orc.DEFAULT_CFG, accuracy=a.accuracy, cluster_num=M)
+    threads = os.cpu_count() or 1
+    want_cpu = a.cpu_sample > 0 and world == 1 and rank == 0
+    S = min(B, max(a.cpu_sample, 2 * threads)) if want_cpu else min(B, 8)
+    frames_h = [xyz[offs_host[i]:offs_host[i + 1]].cpu().numpy() for i in range(S)]
+    oracle_out = [None] * S
+
+    def oracle_frame(i):  # ground RANSAC (sequential form of the same specification) + the reference hot path
+        ri = orc.project(frames_h[i], g_o)
+        gm = orc.ground_model(ri, tm_np, seed=ids[i])
+        if general:
+            o = orc.compress_frame(frames_h[i], g_o, tm_np, gm, cfg_o, uniform=False, plane=dict(angle_deg=75, seed=0, frame=ids[i]))
+        else:
+            o = orc.compress_frame(frames_h[i], g_o, tm_np, gm, cfg_o)
+        oracle_out[i] = dict(ri=o["range_image"], gm=gm, pix=o["fps_pix"], seg=o["seg_idx"].astype(np.uint8),
+                             model=np.asarray(o["model_param"]).astype(np.float32), q=o["q"].astype(np.int16),
+                             sal=o.get("salience"))
+        return 1
+
+    verified, cpu_rate = None, None
+    if not a.no_verify or want_cpu:
+        from concurrent.futures import ThreadPoolExecutor
+        orc.lib()
+        oracle_frame(0)
+        t1 = time.perf_counter()
+        with ThreadPoolExecutor(threads) as ex:       # frame-parallel like the reference's --workers pool; ctypes releases the GIL
+            list(ex.map(oracle_frame, range(S)))
+        cpu_rate = S / (time.perf_counter() - t1)
+    if not a.no_verify:
+        verified = True
+        why = None
+        for k in range(depth):
+            bk = bufs[k]
+            ri_d, seg_d, pix_d = bk.ri[:S].cpu().numpy(), bk.seg[:S].cpu().numpy(), bk.cen_pix[:S].cpu().numpy()
+            gm_d, q_d, nz_d, mo_d = gms_l[k][:S].cpu().numpy(), bk.q16[:S].cpu().numpy(), bk.nnz[:S].cpu().numpy(), bk.model[:S].cpu().numpy()
+            for i in range(S):
+                o = oracle_out[i]
+                nrow = o["model"].shape[0]
+                ok = (np.array_equal(ri_d[i].view(np.uint32), o["ri"].view(np.uint32)) and
+                      np.array_equal(gm_d[i].view(np.uint64), np.asarray(o["gm"], np.float64).view(np.uint64)) and
+                      np.array_equal(pix_d[i], o["pix"]) and np.array_equal(seg_d[i].reshape(-1), o["seg"].reshape(-1)) and
+                      np.array_equal(mo_d[i, :nrow].view(np.uint32), o["model"].view(np.uint32)) and
+                      int(nz_d[i]) == o["q"].shape[0] and np.array_equal(q_d[i, :nz_d[i]], o["q"]))
+                if ok and general and o["sal"] is not None:
+                    ok = np.array_equal(bufs[k].salience[i, :nrow].cpu().numpy(), o["sal"].astype(np.uint8))
+                if not ok:
+                    verified, why = False, "slot %d frame %d differs from the oracle" % (k, i)
+                    break
+            if not verified:
+                break
+        if world > 1:
+            t = torch.tensor([1 if verified else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            verified = bool(int(t.item()))
+        if why and rank == 0:
+            print("bench.py: VERIFICATION FAILED: " + why, file=sys.stderr)
+
     out = None
     if rank == 0:
         frames_per_s = world * B * a.steps / dt
-        # the FPS kernel is launched once per sub-batch: average launch = (algorithmic bytes of its frames) / its time
-        fps_launch_ms = fps_ms.value / max(fps_n.value, 1)
-        launches_per_step = max(fps_n.value, 1) / a.steps
-        fps_bytes_launch = fps_bytes / launches_per_step
-        achieved = fps_bytes_launch / (fps_launch_ms * 1e-3) / 1e9 if fps_n.value else 0.0
-        # HBM-side bytes per FPS launch from the committed PMC pass (rocprofv3 cannot run inside this process);
-        # only reported when that pass was taken on this very configuration
-        traffic, traffic_src = None, None
+        fps_launch_ms = fps_ms / max(fps_n, 1)
+        achieved = fps_bytes / (fps_launch_ms * 1e-3) / 1e9 if fps_n else 0.0
+        # HBM-side bytes and wave-level VALU instructions per FPS launch from the committed PMC passes (rocprofv3 cannot
+        # run inside this process); only reported when those passes were taken on this very configuration
+        traffic = traffic_src = valu = step_traffic = None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))
-            if pm["config"] == {"batch": B, "geom": a.geom, "clusters": M} and not a.fps_bruteforce:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_current.json")))
+            if pm["config"] == {"batch": B, "geom": geom_s, "clusters": M, "config": a.config, "input": bool(a.input)} and not a.fps_bruteforce:
                 key = [k for k in pm["kernels"] if k.startswith("fps_tiled_kernel<true")][0]   # template arguments vary
-                traffic = pm["kernels"][key]["traffic_bytes_per_launch"] / pm.get("launches_per_step", 1)
-                traffic_src = "profiles/%s_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, x2 read correction)" % pm.get("tag", "r01_v14")
+                traffic = pm["kernels"][key]["traffic_bytes_per_launch"]
+                valu = pm["kernels"][key].get("valu_wave_insts_per_launch")
+                step_traffic = pm.get("step_traffic_bytes")
+                traffic_src = "profiles/%s_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU, separate passes, x2 read correction)" % pm.get("tag", "?")
         except Exception:
             pass
+        lt = fps_launch_ms * 1e-3
+        workload = ("configs[%d]: batch=%d %s Velodyne-64E frames (%dx%d) per GPU, %s, accuracy=%g, cluster_num=%d, ground plane by "
+                    "seeded RANSAC inside the step" % (a.config, B, "real (%s, rotated + shuffled copies)" % os.path.basename(a.input) if a.input else "synthetic",
+                                                       H, W, "non-uniform + FPS + plane-model" if general else "uniform + FPS + point-model", a.accuracy, M))
         out = {
             "metric": "frames/s (64E, 64x2048 range img), projection->segmentation->model->quantise",
             "value": round(frames_per_s, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: batch=%d synthetic Velodyne-64E frames (%dx%d) per GPU, uniform + FPS + "
-                                   "point-model, accuracy=%g, cluster_num=%d, ground plane by seeded RANSAC inside the step" % (B, H, W, a.accuracy, M),
-                       "frames_per_gpu_per_step": B, "batches_in_flight": depth,
+            "vs_baseline": None, "dtype": "f32", "data": "real sweep replicated" if a.input else "synthetic",
+            "verified": verified,
+            "config": {"workload": workload, "frames_per_gpu_per_step": B, "batches_in_flight": depth,
                        "inputs": ("copied from pinned host memory inside every step (PCIe-inclusive run, not the headline)" if a.h2d
                                   else "resident in HBM before the timed region"),
                        "sharding": "frames over ranks, no data-path collective"
-                       + (", per step RCCL all_gather of the frame lengths + gather of the packed residual streams to rank 0" if gather else "")
-                       + ("; " + exchange_note if exchange_note else "")},
-            "roofline": {"bound": "hbm", "kernel": "fps_range_kernel (brute force)" if a.fps_bruteforce else "fps_tiled_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "traffic_source": traffic_src,
-                         "traffic_GBs": (round(traffic / (fps_launch_ms * 1e-3) / 1e9, 2) if traffic else None),
-                         "launch_ms": round(fps_launch_ms, 4), "alg_bytes_per_launch": fps_bytes_launch,
-                         "launches_per_step": launches_per_step,
+                       + ((", per step RCCL all_gather of the per-frame payload lengths"
+                           + (" + gather of the packed residual streams to rank 0" if a.gather_payloads else
+                              " (payload bytes stay with the rank that writes the files)")) if exchange else "")
+                       + ("; " + exchange_note if exchange_note else ""),
+                       "exchange_bytes_per_step": exchange_bytes if exchange else 0,
+                       "verified_frames_per_slot": (S if verified is not None else 0)},
+            "roofline": {"bound": "hbm", "kernel": "fps_range_kernel (brute force)" if a.fps_bruteforce else "fps_tiled_kernel",
+                         "model": "stream-once (SURVEY 8d): 20*(M-1)*n_left bytes per frame, the bytes the reference algorithm streams",
+                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_GBs": (round(traffic / lt / 1e9, 2) if traffic and fps_n else None),
+                         "traffic_frac": (round(traffic / lt / 1e9 / HBM_PEAK_GBS, 4) if traffic and fps_n else None),
+                         "valu_wave_insts": valu,
+                         "valu_frac": (round(valu / lt / VALU_PEAK_WAVE_INSTS_PER_S, 4) if valu and fps_n else None),
+                         "launch_ms": round(fps_launch_ms, 4), "launches_timed": fps_n, "alg_bytes_per_launch": fps_bytes,
+                         "critical_path": {"dependent_iterations": M - 1, "us_per_iteration": round(fps_launch_ms * 1e3 / max(M - 1, 1), 3),
+                                           "note": "one workgroup per frame selects the M centres one after the other: the launch "
+                                                   "time is (M-1) x the per-iteration chain (tile test -> tile loads -> min/arg-max -> select)"},
                          "whole_path_alg_GBs": round(b_alg * a.steps / dt / 1e9, 2),
-                         "note": "achieved = algorithmic bytes of the brute-force stream model (20*(M-1)*n_left per frame, "
-                                 "SURVEY 8d) / measured launch time; the exact tile-pruned kernel skips most of those bytes, "
-                                 "so frac > 1 is expected; traffic = PMC-measured HBM-side bytes per launch"},
+                         "whole_path_traffic_frac": (round(step_traffic * a.steps / dt / 1e9 / HBM_PEAK_GBS, 4) if step_traffic else None),
+                         "note": "frac is the stream-once figure of SURVEY 8d (algorithmic bytes / launch time); the exact tile-pruned "
+                                 "kernel does not move those bytes, so frac > 1 is possible and bounds nothing.  traffic_frac (PMC HBM-side "
+                                 "bytes / launch time / 8 TB/s) and valu_frac (wave-level VALU instructions / launch time / chip issue "
+                                 "rate) are the utilisation figures; the kernel is bound by its dependency chain (critical_path)"},
         }
-        if a.cpu_sample > 0 and world == 1:
-            S = min(B, max(a.cpu_sample, 2 * (os.cpu_count() or 1)))
-            o = offs.cpu().numpy()
-            frames = [xyz[o[i]:o[i + 1]].cpu().numpy() for i in range(S)]
-            from oracle import oracle as orc
-            g = orc.LidarGeom(H=H, W=W, hfov_deg=360, vmax_deg=2.0, vmin_deg=-24.9)
-            cfg = dict(orc.DEFAULT_CFG, accuracy=a.accuracy, cluster_num=M)
-            threads = os.cpu_count() or 1
-            v = cpu_baseline(frames, gms.cpu().numpy(), g, tm_np, cfg, threads)
-            out["cpu_baseline"] = {"value": round(v, 3), "unit": "frames/s", "cores": threads, "kind": "port",
-                                   "sample": "%d of the same synthetic frames, C port of the reference cpu=True path "
+        if want_cpu:
+            out["cpu_baseline"] = {"value": round(cpu_rate, 3), "unit": "frames/s", "cores": threads, "kind": "port",
+                                   "sample": "%d of the same frames, C port of the reference cpu=True path "
                                              "(oracle/), frame-parallel over %d threads" % (S, threads)}
-    if world > 1 or a.force_gather:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if out is not None:
@@ -270,6 +413,8 @@ def main():
         # version banner to stdout under NCCL_DEBUG=VERSION, and a pipe delays it until the buffer is flushed)
         _flush_c_stdio()
         print(json.dumps(out), flush=True)
+    if verified is False:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

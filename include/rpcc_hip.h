@@ -26,6 +26,13 @@ extern "C" {
 #define RPCC_ERR_HIP (-2)
 #define RPCC_MAX_CLUSTERS 254 /* labels are stored as uint8 */
 #define RPCC_MAX_BATCH 65535   /* frames per call: the frame index is a grid dimension */
+#define RPCC_INFO_INTS 8       /* int32 per frame in the `info` arrays below */
+#define RPCC_FPS_BRUTEFORCE 1  /* flag: farthest point sampling by the one-pass-per-centre kernel (test reference) */
+
+/* Re-entrancy: the library keeps no per-call state of its own (a cache of kernel attributes already set, behind a
+ * mutex, is all it holds); every call works on the caller's buffers and stream, so host threads may call concurrently
+ * on different streams with different buffers (the reference's ThreadPoolExecutor front-end,
+ * tools/compress_datalist.py:202-206).  The one developer hook that is process-wide is rpcc_debug_stamps. */
 
 int rpcc_version(void);
 const char *rpcc_last_error(void);
@@ -66,10 +73,13 @@ int rpcc_project(const float *xyz, const int64_t *offsets, int64_t total, int B,
  * np.random.choice subsample (third-party, random); this is the build's deterministic seeded
  * definition (DESIGN.md "RANSAC"): z < -1.5 candidates, systematic subsample to 5000, all pixels if
  * fewer than 800, 100 hypotheses of 10 points, 0.1 m inlier distance, refit on the inliers.
- *   ground   dev f64 [B,4] out   plane a,b,c,d (unit normal) per frame; frame b uses seed + b
+ *   frame_ids dev i64 [B] or NULL a stable identity per frame (its datalist index): frame b draws with
+ *                                seed + (uint32)frame_ids[b] (NULL: seed + b), so a file's plane -- and its
+ *                                bitstream -- does not depend on the batch it travels in
+ *   ground   dev f64 [B,4] out   plane a,b,c,d (unit normal) per frame
  *   inliers  dev i32 [B]   out   inlier count of the winning hypothesis (may be NULL)            */
-int rpcc_ground_ransac(const float *ri, const float *tm, int B, int P, uint32_t seed, double *ground,
-                       int32_t *inliers, void *stream);
+int rpcc_ground_ransac(const float *ri, const float *tm, int B, int P, uint32_t seed, const int64_t *frame_ids,
+                       double *ground, int32_t *inliers, void *stream);
 
 /* ---- a3+a5: back-projection + vertical ground residual + FPS state init -------------------- *
  * replaces PCTransformer.range_image_to_point_cloud (dataset/transformer.py:94-101) and
@@ -80,7 +90,8 @@ int rpcc_ground_ransac(const float *ri, const float *tm, int B, int P, uint32_t 
  *   tm       dev f32 [P,3]       transform_map (dataset/transformer.py:41-54)
  *   ground   dev f64 [B,4]       plane a,b,c,d per frame
  *   temp     dev f32 [B,P]  out
- *   info     dev i32 [B,4]  out  {n_left, first candidate pixel (P if none), nnz, fps_table valid}  */
+ *   info     dev i32 [B,8]  out  {n_left, first candidate pixel (P if none), nnz, fps_table valid,
+ *                                 first EMPTY pixel that is a candidate (P if none), 3 spare}       */
 int rpcc_ground_mask(const float *ri, const float *tm, const double *ground, double threshold, int B, int H, int W,
                      float *temp, int32_t *info, void *fps_table, void *stream);
 /* fps_table (optional, rpcc_fps_table_bytes(B,H,W) bytes, or NULL): when given, the kernel also runs the
@@ -99,17 +110,18 @@ int rpcc_fps_xyz(int B, int N, int M, const float *points, float *temp, int32_t 
 /* rpcc_fps_range is the same sampling run directly on the range image (xyz = ri * tm recomputed in
  * registers; pixels with temp < 0 are not candidates).  It selects the pixels the reference selects
  * on the compacted candidate list (utils/segment_utils.py:120-124).
- *   info     dev i32 [B,4]       from rpcc_ground_mask (first candidate = start point)
+ *   temp     dev f32 [B,P] in/out from rpcc_ground_mask (candidates share one initial value, others < 0); on return
+ *                                the running minimum distance of every candidate, as the reference kernel leaves it
+ *   info     dev i32 [B,8]       from rpcc_ground_mask (first candidate = start point; first empty candidate)
  *   cen_pix  dev i32 [B,M]  out  pixel index of each centre
  *   centers  dev f32 [B,M,3] out cluster_centers
- *   ws       dev scratch for a planar copy of tm (12*P bytes); NULL selects the brute-force kernel */
+ *   flags    0, or RPCC_FPS_BRUTEFORCE for the one-pass-per-centre kernel (identical results)         */
 int rpcc_fps_range(const float *ri, const float *tm, float *temp, const int32_t *info, int B, int H, int W, int M,
-                   int32_t *cen_pix, float *centers, void *ws /* dev, >= 12*P bytes, or NULL */,
+                   int32_t *cen_pix, float *centers, int flags,
                    const void *fps_table /* from rpcc_ground_mask, or NULL */, void *stream);
 
-/* Test hook: force the brute-force FPS kernels (one full pass per centre) instead of the exact
- * tile-pruned ones; both give identical results. */
-void rpcc_fps_force_bruteforce(int on);
+/* The brute-force form of rpcc_fps_xyz (one full pass per centre): the test reference of the tile-pruned kernels. */
+int rpcc_fps_xyz_bruteforce(int B, int N, int M, const float *points, float *temp, int32_t *idx, void *stream);
 
 /* ---- a7: ground / cluster assignment + relabel ---------------------------------------------- *
  * replaces calc_plane_residual_depth, calc_cluster_residual_radius, concatenate + argmax and the
@@ -131,14 +143,16 @@ int rpcc_point_model(const float *ri, const uint8_t *seg, const double *ground, 
 /* ---- a9: plane model --------------------------------------------------------------------------- *
  * replaces cluster_modeling('plane') (utils/segment_utils.py:188-216) incl. plane_angle_validation
  * (:84-93) and the fp32 numpy-mean fallbacks.  RANSAC (ransac_n = 4, 10 iterations, 0.1 m) is the
- * build's seeded specification (Open3D in the reference); label k of frame b uses hash(seed, b, k).
+ * build's seeded specification (Open3D in the reference); label k of frame b uses hash(seed, id_b, k) with
+ * id_b = frame_ids[b] (dev i64 [B]) or b when frame_ids is NULL.
  *   ground   dev f64 [B,4] or NULL   copied (as fp32) into row 0
  *   cos_cut  HOST double: a plane is rejected when some pixel has |n.t|/|n|*|t| <= cos_cut, i.e.
  *            arccos(.) > angle threshold; the caller derives it from its own arccos (ops.plane_model)
  *   model    dev f32 [B,K,4] out;  counts dev i32 [B,K] out;  ws rpcc_plane_workspace_bytes(B,P,M)   */
 size_t rpcc_plane_workspace_bytes(int B, int P, int M);
 int rpcc_plane_model(const float *ri, const float *tm, const uint8_t *seg, const double *ground, int B, int P, int M,
-                     double cos_cut, uint32_t seed, float *model, int32_t *counts, void *ws, void *stream);
+                     double cos_cut, uint32_t seed, const int64_t *frame_ids, float *model, int32_t *counts, void *ws,
+                     void *stream);
 
 /* ---- a10+a11(+a13): intra-prediction + residual + quantisation + ordered scatter ------------- *
  * replaces segment_utils_cpp.intra_predict (cpp_modules.cpp:248-285), residual = ri - pred
@@ -225,19 +239,26 @@ int rpcc_decode(const uint8_t *seg, const int16_t *q16, const float *model, cons
 int rpcc_pack_payload(const int16_t *q16, const int32_t *nnz, int B, int P, int16_t *packed, int64_t capacity,
                       int64_t *total, void *stream);
 
-/* ---- fused batch entry: a2..a11 for B frames (uniform framework, FPS, point model) ----------- *
+/* ---- fused batch entry: a2..a13 for B frames (FPS segmentation; uniform / non-uniform framework; point / plane model) *
  * The batched counterpart of the body of tools/compress.py:93-125 /
- * tools/compress_datalist.py:91-125 with the ground model supplied by the caller. */
+ * tools/compress_datalist.py:91-125 with the ground model supplied by the caller or fitted inside. */
+/* QuantizationModule's non-uniform settings (utils/compress_utils.py:36-54, cfgs/compressor.yaml:26-36) */
+typedef struct rpcc_nonuniform_cfg {
+    int32_t levels;              /* 1..8 */
+    int32_t level_kp_num[8];     /* level_key_point_num */
+    float level_acc[8];          /* base step + level_delta_acc, as C float (utils/compress_utils.py:48) */
+    int32_t ground_level;        /* ground_salience_level */
+    int32_t feature_region, segments, sharp_num, less_sharp_num, flat_num;
+} rpcc_nonuniform_cfg;
+
 typedef struct rpcc_batch_io {
     const float *xyz;        /* dev f32 [total,3] */
     const int64_t *offsets;  /* dev i64 [B+1] */
-    const int64_t *offsets_host; /* HOST copy of offsets, or NULL.  When given, the batch is run as a few
-                                    sub-batches on internal HIP streams (rpcc_set_batch_slices) so that the
-                                    latency-bound and the throughput-bound kernels overlap; same results. */
     int64_t total;
     const float *tm;         /* dev f32 [P,3] */
     double *ground;          /* dev f64 [B,4]  in (ground_seed < 0: injected models) / out (fitted here) */
-    int64_t ground_seed;     /* >= 0: fit the ground plane with rpcc_ground_ransac(seed = ground_seed) */
+    int64_t ground_seed;     /* >= 0: fit the ground plane with rpcc_ground_ransac(seed = ground_seed, frame_ids) */
+    const int64_t *frame_ids;/* dev i64 [B] or NULL: stable identity of every frame (seeds; see rpcc_ground_ransac) */
     float *ri;               /* dev f32 [B,P] out */
     uint8_t *seg;            /* dev u8  [B,P] out */
     int32_t *cen_pix;        /* dev i32 [B,M] out */
@@ -246,12 +267,22 @@ typedef struct rpcc_batch_io {
     int32_t *counts;         /* dev i32 [B,K] out */
     int16_t *q16;            /* dev i16 [B,P] out */
     int32_t *nnz;            /* dev i32 [B] out */
-    int32_t *info;           /* dev i32 [B,4] out */
+    int32_t *info;           /* dev i32 [B,8] out */
+    int32_t flags;           /* 0 or RPCC_FPS_BRUTEFORCE */
+    void *timer;             /* rpcc_timer_create() handle or NULL: times this call's FPS launch (bench.py) */
+    /* framework / model selection (tools/compress.py:109-124, cfgs/compressor.yaml: compress_framework, modeling_method) */
+    int32_t model_method;    /* 0: point model (a8);  1: plane model (a9: rpcc_plane_model with plane_cos_cut, plane_seed,
+                                frame_ids); ws must then hold rpcc_workspace_bytes_general() bytes */
+    double plane_cos_cut;    /* see rpcc_plane_model */
+    int64_t plane_seed;
+    const rpcc_nonuniform_cfg *nonuniform; /* HOST, NULL: uniform framework (step = acc); else key points + salience
+                                levels + per-label steps (a12, a13), ws of rpcc_workspace_bytes_general() bytes */
+    uint8_t *salience;       /* dev u8 [B,K] out (non-uniform) */
+    uint8_t *key_point_map;  /* dev u8 [B,P] out (non-uniform) */
 } rpcc_batch_io;
 
 size_t rpcc_workspace_bytes(int B, int P, int M, int64_t total_points);
-void rpcc_set_batch_slices(int n); /* 1..8 sub-batches (default 1 = off); only used with offsets_host.  Measured
-                                      slower than whole batches on MI355X: leave it off. */
+size_t rpcc_workspace_bytes_general(int B, int P, int M, int64_t total_points); /* plane model and / or non-uniform framework */
 int rpcc_compress_batch(const rpcc_batch_io *io, int B, rpcc_geom g, int M, double ground_threshold, float acc,
                         void *ws, void *stream);
 
@@ -259,11 +290,12 @@ int rpcc_compress_batch(const rpcc_batch_io *io, int B, rpcc_geom g, int M, doub
  * phase boundaries (block 0 only).  NULL disables it (default). */
 int rpcc_debug_stamps(void *dev_i64_buffer);
 
-/* Timing hook for bench.py: records hipEvents around the FPS launch of the next
- * rpcc_compress_batch / rpcc_fps_* calls on that stream; rpcc_fps_time_ms returns the accumulated
- * milliseconds and launch count since the last reset (synchronises the events). */
-void rpcc_fps_timing(int enable);
-int rpcc_fps_time_ms(double *ms, int *launches);
+/* Timer objects for bench.py: a handle given in rpcc_batch_io.timer makes the call record hipEvents around its FPS
+ * launch on the call's stream; rpcc_timer_read returns the accumulated milliseconds and the launch count since the
+ * last read (synchronises the events).  One handle per measuring thread; the library keeps no global timing state. */
+void *rpcc_timer_create(void);
+void rpcc_timer_destroy(void *timer);
+int rpcc_timer_read(void *timer, double *ms, int *launches);
 
 #ifdef __cplusplus
 }

@@ -96,14 +96,13 @@ def segment_range_image(range_image, transform_map, ground_model, cluster_num, g
     ri, tm = _dev(range_image, np.float32).reshape(1, P), _dev(transform_map, np.float32).reshape(P, 3)
     ground = _dev(np.asarray(ground_model).reshape(1, 4), np.float64)
     temp = torch.empty((1, P), dtype=torch.float32, device="cuda")
-    info = torch.empty((1, 4), dtype=torch.int32, device="cuda")
+    info = torch.empty((1, 8), dtype=torch.int32, device="cuda")   # RPCC_INFO_INTS
     table = torch.empty((_l.rpcc_fps_table_bytes(1, H, W),), dtype=torch.uint8, device="cuda")
     _ok(_l.rpcc_ground_mask(_p(ri), _p(tm), _p(ground), C.c_double(ground_threshold), 1, H, W, _p(temp), _p(info),
                             _p(table), _s()))
     cen_pix = torch.empty((1, M), dtype=torch.int32, device="cuda")
     centers = torch.empty((1, M, 3), dtype=torch.float32, device="cuda")
-    rays = torch.empty((3 * P + 64,), dtype=torch.float32, device="cuda")
-    _ok(_l.rpcc_fps_range(_p(ri), _p(tm), _p(temp), _p(info), 1, H, W, M, _p(cen_pix), _p(centers), _p(rays), _p(table), _s()))
+    _ok(_l.rpcc_fps_range(_p(ri), _p(tm), _p(temp), _p(info), 1, H, W, M, _p(cen_pix), _p(centers), 0, _p(table), _s()))
     seg = torch.empty((1, P), dtype=torch.uint8, device="cuda")
     _ok(_l.rpcc_assign(_p(ri), _p(tm), _p(ground), _p(centers), 1, H, W, M, _p(seg), _s()))
     return seg.view(H, W).cpu().numpy().astype(np.int64), centers[0].cpu().numpy()

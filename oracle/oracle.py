@@ -325,12 +325,16 @@ def point_model_param(ri, seg, ground_model):
     return np.concatenate((np.asarray(ground_model, np.float64).reshape(1, 4), cm), 0)
 
 
-def compress_frame(xyz, g, tm, ground_model, cfg=DEFAULT_CFG, uniform=True, model_param=None):
+def compress_frame(xyz, g, tm, ground_model, cfg=DEFAULT_CFG, uniform=True, model_param=None, plane=None):
     """Whole hot path for one frame (tools/compress.py:93-125), ground model injected.  When
-    `model_param` is given it replaces cluster_modeling (plane-mode injection)."""
+    `model_param` is given it replaces cluster_modeling (plane-mode injection); plane = dict(angle_deg, seed, frame)
+    selects cluster_modeling('plane') with the build's seeded RANSAC (cluster_modeling_plane)."""
     ri = project(xyz, g)
     s = segment(ri, tm, ground_model, cfg)
     seg = s["seg_idx"]
+    if model_param is None and plane is not None:
+        model_param = np.concatenate((np.asarray(ground_model, np.float64).reshape(1, 4),
+                                      cluster_modeling_plane(s["pc"], ri, seg, tm, plane["angle_deg"], plane["seed"], plane["frame"])), 0)
     if model_param is None:
         model_param = point_model_param(ri, seg, ground_model)
     pred = intra_predict(seg, model_param, tm)

@@ -15,10 +15,22 @@ class Geom(C.Structure):
 
 
 class BatchIO(C.Structure):
-    _fields_ = [("xyz", C.c_void_p), ("offsets", C.c_void_p), ("offsets_host", C.c_void_p), ("total", C.c_int64), ("tm", C.c_void_p),
-                ("ground", C.c_void_p), ("ground_seed", C.c_int64), ("ri", C.c_void_p), ("seg", C.c_void_p), ("cen_pix", C.c_void_p),
-                ("centers", C.c_void_p), ("model", C.c_void_p), ("counts", C.c_void_p), ("q16", C.c_void_p),
-                ("nnz", C.c_void_p), ("info", C.c_void_p)]
+    _fields_ = [("xyz", C.c_void_p), ("offsets", C.c_void_p), ("total", C.c_int64), ("tm", C.c_void_p),
+                ("ground", C.c_void_p), ("ground_seed", C.c_int64), ("frame_ids", C.c_void_p), ("ri", C.c_void_p),
+                ("seg", C.c_void_p), ("cen_pix", C.c_void_p), ("centers", C.c_void_p), ("model", C.c_void_p),
+                ("counts", C.c_void_p), ("q16", C.c_void_p), ("nnz", C.c_void_p), ("info", C.c_void_p),
+                ("flags", C.c_int32), ("timer", C.c_void_p), ("model_method", C.c_int32), ("plane_cos_cut", C.c_double),
+                ("plane_seed", C.c_int64), ("nonuniform", C.c_void_p), ("salience", C.c_void_p), ("key_point_map", C.c_void_p)]
+
+
+class NonuniformCfg(C.Structure):
+    _fields_ = [("levels", C.c_int32), ("level_kp_num", C.c_int32 * 8), ("level_acc", C.c_float * 8), ("ground_level", C.c_int32),
+                ("feature_region", C.c_int32), ("segments", C.c_int32), ("sharp_num", C.c_int32), ("less_sharp_num", C.c_int32),
+                ("flat_num", C.c_int32)]
+
+
+INFO_INTS = 8          # RPCC_INFO_INTS
+FPS_BRUTEFORCE = 1     # RPCC_FPS_BRUTEFORCE
 
 
 class RpccError(RuntimeError):
@@ -34,12 +46,12 @@ _SIGS = {
     "rpcc_project_scratch_bytes": (C.c_size_t, [_I64, _I, _I]),
     "rpcc_project_fastpath_check": (C.c_int, [_VP, _I64, Geom, _VP, _VP]),
     "rpcc_project": (C.c_int, [_VP, _VP, _I64, _I, Geom, _VP, _VP, C.c_size_t, _VP]),
-    "rpcc_ground_ransac": (C.c_int, [_VP, _VP, _I, _I, C.c_uint32, _VP, _VP, _VP]),
+    "rpcc_ground_ransac": (C.c_int, [_VP, _VP, _I, _I, C.c_uint32, _VP, _VP, _VP, _VP]),
     "rpcc_ground_mask": (C.c_int, [_VP, _VP, _VP, _D, _I, _I, _I, _VP, _VP, _VP, _VP]),
     "rpcc_fps_table_bytes": (C.c_size_t, [_I, _I, _I]),
     "rpcc_fps_xyz": (C.c_int, [_I, _I, _I, _VP, _VP, _VP, _VP]),
-    "rpcc_fps_range": (C.c_int, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP, _VP, _VP, _VP]),
-    "rpcc_fps_force_bruteforce": (None, [_I]),
+    "rpcc_fps_xyz_bruteforce": (C.c_int, [_I, _I, _I, _VP, _VP, _VP, _VP]),
+    "rpcc_fps_range": (C.c_int, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP, _I, _VP, _VP]),
     "rpcc_assign": (C.c_int, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP]),
     "rpcc_point_model": (C.c_int, [_VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP]),
     "rpcc_predict_quantize": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _F, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
@@ -53,13 +65,14 @@ _SIGS = {
     "rpcc_decode": (C.c_int, [_VP, _VP, _VP, _VP, C.POINTER(C.c_double), _I, _VP, _I, _I, _I, _VP, _VP, _VP, _VP]),
     "rpcc_pack_payload": (C.c_int, [_VP, _VP, _I, _I, _VP, _I64, _VP, _VP]),
     "rpcc_plane_workspace_bytes": (C.c_size_t, [_I, _I, _I]),
-    "rpcc_plane_model": (C.c_int, [_VP, _VP, _VP, _VP, _I, _I, _I, _D, C.c_uint32, _VP, _VP, _VP, _VP]),
+    "rpcc_plane_model": (C.c_int, [_VP, _VP, _VP, _VP, _I, _I, _I, _D, C.c_uint32, _VP, _VP, _VP, _VP, _VP]),
     "rpcc_workspace_bytes": (C.c_size_t, [_I, _I, _I, _I64]),
+    "rpcc_workspace_bytes_general": (C.c_size_t, [_I, _I, _I, _I64]),
     "rpcc_compress_batch": (C.c_int, [C.POINTER(BatchIO), _I, Geom, _I, _D, _F, _VP, _VP]),
     "rpcc_debug_stamps": (C.c_int, [_VP]),
-    "rpcc_set_batch_slices": (None, [_I]),
-    "rpcc_fps_timing": (None, [_I]),
-    "rpcc_fps_time_ms": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "rpcc_timer_create": (_VP, []),
+    "rpcc_timer_destroy": (None, [_VP]),
+    "rpcc_timer_read": (C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
 }
 
 

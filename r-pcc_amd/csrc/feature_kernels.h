@@ -233,7 +233,7 @@ __global__ __launch_bounds__(FEAT_THREADS) void features_kernel(const float *__r
     }
     __syncthreads();
     for (int c = tid; c < W; c += FEAT_THREADS) {
-        feat[base + c] = v[c];
+        if (feat) feat[base + c] = v[c];
         kp[base + c] = kprow[c];
     }
 }

@@ -1,17 +1,16 @@
 // fps_kernels.h -- exact tile-pruned farthest point sampling (a6) and the ground-mask kernel that performs
 // its first pass (a3+a5 + FPS pass 1); included by rpcc_hip.hip.
 //
-// Tiles hold 64 * FPS_NH points = FPS_NH per lane of one wavefront ("half" h in 0 .. FPS_NH-1; FPS_NH = 4: 256 points):
-//   range image:  tile t = (tr, tc) covers rows 2*FPS_NH*tr .. +2*FPS_NH-1, columns 32*tc .. 32*tc+31 (compact in 3-D);
-//                 lane l, half h  ->  row 2*FPS_NH*tr + 2*h + (l >> 5), column 32*tc + (l & 31)
-//   point list:   tile t covers indices 64*FPS_NH*t ..; lane l, half h -> 64*FPS_NH*t + 64*h + l
-// In both layouts (half, lane) in lexicographic order is increasing point index, which is what the
-// lowest-index tie rule of the arg-max needs.  Measured on 64x2048 (FPS alone / step with batches in flight): 128-point
-// tiles 583 us / 1.10 ms, 256-point tiles 527 us / 1.06 ms, 512-point tiles 536 us / 1.10 ms -- larger tiles re-read a
-// little more per visit (+10 % points) but halve the per-tile work of the test / select phases and of the box and
-// arg-max reductions, and the tile table shrinks to 25 KB of LDS.
+// Tiles hold 256 points, four CONSECUTIVE points per lane of one wavefront (16-byte loads):
+//   range image:  tile t = (tr, tc) covers rows 8*tr .. 8*tr+7, columns 32*tc .. 32*tc+31 (compact in 3-D);
+//                 lane l, element e  ->  row 8*tr + (l >> 3), column 32*tc + 4*(l & 7) + e
+//   point list:   tile t covers indices 256*t ..; lane l, element e -> 256*t + 4*l + e
+// In both layouts (lane, element) in lexicographic order is increasing point index, which is what the
+// lowest-index tie rule of the arg-max needs.  With W % 4 == 0 (N % 4 == 0 for lists) a lane's four points are one
+// 16-byte load of the range image, one of temp and three of the [P,3] ray table (VEC); otherwise the same layout is
+// read with scalar loads.
 //
-// Per tile the workgroup keeps in LDS (FpsLds, 11 dwords): the bounding box of the tile's candidates, the
+// Per tile the workgroup keeps in LDS (FpsLds, three float4): the bounding box of the tile's candidates, the
 // tile's current maximum of temp with its (lowest) index, and that point's coordinates.  For a new centre
 // c a tile can only change if some point is closer to c than its temp, i.e. only if
 //     bound(c, box) < tile_max,   bound = ((bx*bx)+(by*by))+(bz*bz),  b* = per-axis gap to the box.
@@ -19,14 +18,20 @@
 // are <= every candidate's |d*| (rounding is monotone), so bound <= computed distance of every candidate
 // and skipping is bit-exact, not approximate (DESIGN.md "FPS").  Everything else -- min with temp, strict
 // '>' arg-max with lowest-index ties -- is the brute-force definition.
+//
+// The origin class (range images).  Empty pixels back-project to (0,0,0) and ARE candidates of the reference
+// (utils/segment_utils.py:119-120: their vertical residual is |d| / divisor > threshold), about 15-20 % of a sweep,
+// scattered over every tile.  Kept in the tiles they would stretch every bounding box to the sensor and defeat the
+// pruning.  They all have the same coordinates, hence the same distance to every centre and the same temp: the
+// kernel carries them as ONE scalar (t_org) with the index of the first of them, leaves them out of the tile boxes
+// and maxima, and lets the scalar compete in the arg-max with its (value, index) key.  Identical selections; the
+// empty pixels' temp entries are brought up to date at the end when the caller reads temp (finalize_temp).
 #pragma once
 
-#define FPS_TAB_ROWS 11  // lo[3], hi[3], tmax, cx[3], targ
-#ifndef FPS_NH
-#define FPS_NH 4  // wavefront-loads ("halves") per tile: 64 * FPS_NH points, 2 * FPS_NH rows x 32 columns of a range image
-#endif
-#define FPS_TILE (64 * FPS_NH)
-#define FPS_TROWS (2 * FPS_NH)
+#define FPS_TAB_ROWS 12  // three float4 per tile: (lo.xyz, tmax) (hi.xyz, targ) (cx.xyz, tile origin)
+#define FPS_TILE 256
+#define FPS_TROWS 8
+#define RPCC_INFO 8      // int32 per frame in `info`: n_left, first candidate, nnz, table valid, first empty candidate, 3 spare
 
 struct FpsTiling {
     int N;      // points per frame (P for a range image)
@@ -45,102 +50,116 @@ static inline FpsTiling fps_tiling_list(int N) {
     return g;
 }
 
-// index of (tile, half, lane); -1 when outside
-template <bool RANGE>
-__device__ __forceinline__ int fps_tile_point(const FpsTiling &g, int t, int half, int lane) {
-    if (RANGE) {
-        const int tr = t / g.tcols, tc = t - tr * g.tcols;
-        const int row = FPS_TROWS * tr + 2 * half + (lane >> 5), col = 32 * tc + (lane & 31);
-        return (row < g.H && col < g.W) ? row * g.W + col : -1;
-    }
-    const int p = t * FPS_TILE + half * 64 + lane;
-    return p < g.N ? p : -1;
-}
-template <bool RANGE>
-__device__ __forceinline__ int fps_tile_of(const FpsTiling &g, int p) {
-    if (RANGE) {
-        const int row = p / g.W, col = p - row * g.W;
-        return (row / FPS_TROWS) * g.tcols + (col >> 5);
-    }
-    return p / FPS_TILE;
-}
-
 struct FpsLds {
-    float *lo[3], *hi[3], *tmax, *cx[3];
-    uint32_t *targ;
-    uint32_t *torg;   // range image: first pixel of the tile (22 bits) | valid columns - 1 (5 bits) << 22 | valid rows - 1 (5 bits) << 27
+    float4 *lo4;   // [T] (lo0, lo1, lo2, tmax)
+    float4 *hi4;   // [T] (hi0, hi1, hi2, bits of targ)
+    float4 *cx4;   // [T] (cx0, cx1, cx2, bits of torg: first pixel of the tile (22 bits) | valid columns - 1 (5 bits) << 22 | valid rows - 1 (3 bits) << 27)
     uint16_t *work;
     __device__ FpsLds(unsigned char *base, int T) {
-        float *f = reinterpret_cast<float *>(base);
-        for (int a = 0; a < 3; a++) { lo[a] = f + (size_t)a * T; hi[a] = f + (size_t)(3 + a) * T; cx[a] = f + (size_t)(7 + a) * T; }
-        tmax = f + (size_t)6 * T;
-        targ = reinterpret_cast<uint32_t *>(f + (size_t)10 * T);
-        torg = reinterpret_cast<uint32_t *>(f + (size_t)11 * T);
-        work = reinterpret_cast<uint16_t *>(f + (size_t)12 * T);
+        lo4 = reinterpret_cast<float4 *>(base);
+        hi4 = lo4 + T;
+        cx4 = hi4 + T;
+        work = reinterpret_cast<uint16_t *>(cx4 + T);
     }
 };
 static inline size_t fps_tiled_lds_bytes(int T) { return (size_t)T * 50 + 64; }
 #define FPS_TILED_MAX_TILES 3200  // 50 B/tile must fit the 160 KiB LDS of one CU
 
-// Per-tile reductions shared by the FPS kernel and the ground-mask kernel.  x/y/z/nt: the lane's two
-// points; cand: they take part in the bounding box; valid: they exist.  Writes the 11 table values of
-// tile t through `put(row, value)` from lanes 0..10 (one dword each).
-struct TileStats {
-    float v[FPS_TAB_ROWS];
+// One lane's share of a tile: four consecutive points.
+struct FpsQuad {
+    float r[4];     // ranges (RANGE)
+    float tp[4];    // temp as loaded
+    float t[12];    // RANGE: rays (tx,ty,tz) x 4; else xyz x 4
+    int p0;         // index of element 0 (clamped to 0 for a lane outside the frame)
+    int nval;       // valid elements: e < nval
 };
-__device__ __forceinline__ void fps_tile_argmax(const float (&x)[FPS_NH], const float (&y)[FPS_NH], const float (&z)[FPS_NH],
-                                                const float (&nt)[FPS_NH], const bool (&valid)[FPS_NH],
-                                                const int (&pidx)[FPS_NH], float &wt, float &wx, float &wy, float &wz,
-                                                uint32_t &widx) {
-    // largest value, lowest (half, lane) among equals
-    uint32_t o[FPS_NH], om = 0u;
+
+__device__ __forceinline__ void fps_quad_xyz(const FpsQuad &q, bool range, float (&x)[4], float (&y)[4], float (&z)[4]) {
 #pragma unroll
-    for (int h = 0; h < FPS_NH; h++) {
-        o[h] = (!valid[h] || nt[h] < 0.0f) ? 0u : f2u(nt[h]) + 1u;
-        om = o[h] > om ? o[h] : om;
+    for (int e = 0; e < 4; e++) {
+        if (range) { x[e] = q.r[e] * q.t[3 * e]; y[e] = q.r[e] * q.t[3 * e + 1]; z[e] = q.r[e] * q.t[3 * e + 2]; }
+        else { x[e] = q.t[3 * e]; y[e] = q.t[3 * e + 1]; z[e] = q.t[3 * e + 2]; }
     }
-    const uint32_t vmax = dpp_max_u32(om);
-    bool done = false;
-    wt = wx = wy = wz = 0.0f;
-    widx = 0u;
+}
+
+// loads of one lane's quad: src = range image (RANGE) or xyz list; rays = [P,3] table (RANGE)
+template <bool RANGE, bool VEC>
+__device__ __forceinline__ void fps_quad_load(const float *__restrict__ src, const float *__restrict__ rays,
+                                              const float *__restrict__ temp, FpsQuad &q) {
+    const uint32_t p0 = (uint32_t)q.p0;
+    if (VEC) {  // 16-byte loads at wave-uniform base + 32-bit byte offset
+        const float4 tp = ld_at(reinterpret_cast<const float4 *>(temp), p0 * 4u);
+        q.tp[0] = tp.x; q.tp[1] = tp.y; q.tp[2] = tp.z; q.tp[3] = tp.w;
+        const float *tb = RANGE ? rays : src;
+        const float4 a = ld_at(reinterpret_cast<const float4 *>(tb), p0 * 12u);
+        const float4 b = ld_at(reinterpret_cast<const float4 *>(tb), p0 * 12u + 16u);
+        const float4 c = ld_at(reinterpret_cast<const float4 *>(tb), p0 * 12u + 32u);
+        q.t[0] = a.x; q.t[1] = a.y; q.t[2] = a.z; q.t[3] = a.w; q.t[4] = b.x; q.t[5] = b.y; q.t[6] = b.z; q.t[7] = b.w;
+        q.t[8] = c.x; q.t[9] = c.y; q.t[10] = c.z; q.t[11] = c.w;
+        if (RANGE) {
+            const float4 r = ld_at(reinterpret_cast<const float4 *>(src), p0 * 4u);
+            q.r[0] = r.x; q.r[1] = r.y; q.r[2] = r.z; q.r[3] = r.w;
+        }
+    } else {
 #pragma unroll
-    for (int h = 0; h < FPS_NH; h++) {
-        const unsigned long long m = __ballot(o[h] == vmax);
-        if (!done && m) {  // wave-uniform: a scalar branch instead of per-lane selects
-            const int wl = (int)__ffsll((long long)m) - 1;
-            wt = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(nt[h]), wl));
-            wx = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(x[h]), wl));
-            wy = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(y[h]), wl));
-            wz = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(z[h]), wl));
-            widx = (uint32_t)__builtin_amdgcn_readlane(pidx[h], wl);
-            done = true;
+        for (int e = 0; e < 4; e++) {
+            const uint32_t p = p0 + (uint32_t)(e < q.nval ? e : 0);  // unconditional loads on clamped indices
+            q.tp[e] = ld_f32(temp, p * 4u);
+            const float *tb = RANGE ? rays : src;
+            q.t[3 * e] = ld_f32(tb, p * 12u); q.t[3 * e + 1] = ld_f32(tb, p * 12u + 4u); q.t[3 * e + 2] = ld_f32(tb, p * 12u + 8u);
+            if (RANGE) q.r[e] = ld_f32(src, p * 4u);
         }
     }
-    if (vmax == 0u) wt = -1.0f;
 }
-__device__ __forceinline__ void fps_tile_box(const float (&x)[FPS_NH], const float (&y)[FPS_NH], const float (&z)[FPS_NH],
-                                             const bool (&cand)[FPS_NH], float (&lo)[3], float (&hi)[3]) {
+
+// order-preserving key of a temp value: 0 = not a candidate, else bits + 1 (non-negative floats order as integers)
+__device__ __forceinline__ uint32_t fps_val_key(float v) { return v < 0.0f ? 0u : f2u(v) + 1u; }
+__device__ __forceinline__ float fps_key_val(uint32_t k) { return k == 0u ? -1.0f : u2f(k - 1u); }
+
+// arg-max of a tile: largest key, lowest (lane, element) among equals -> value, coordinates, point index
+__device__ __forceinline__ void fps_tile_argmax(const float (&x)[4], const float (&y)[4], const float (&z)[4],
+                                                const uint32_t (&key)[4], int p0, float &wt, float &wx, float &wy, float &wz,
+                                                uint32_t &widx) {
+    uint32_t m = key[0];
+    int em = 0;
+    float sx = x[0], sy = y[0], sz = z[0];
+#pragma unroll
+    for (int e = 1; e < 4; e++) {
+        const bool gt = key[e] > m;
+        m = gt ? key[e] : m; em = gt ? e : em;
+        sx = gt ? x[e] : sx; sy = gt ? y[e] : sy; sz = gt ? z[e] : sz;
+    }
+    const uint32_t vmax = dpp_max_u32(m);
+    const unsigned long long bm = __ballot(m == vmax);
+    const int wl = (int)__ffsll((long long)bm) - 1;
+    wt = fps_key_val(vmax);
+    wx = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(sx), wl));
+    wy = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(sy), wl));
+    wz = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(sz), wl));
+    widx = (uint32_t)__builtin_amdgcn_readlane(p0 + em, wl);
+    if (vmax == 0u) { wx = wy = wz = 0.0f; widx = 0u; }
+}
+__device__ __forceinline__ void fps_tile_box(const float (&x)[4], const float (&y)[4], const float (&z)[4],
+                                             const bool (&cand)[4], float (&lo)[3], float (&hi)[3]) {
     const float inf = __builtin_inff();
     lo[0] = lo[1] = lo[2] = inf;
     hi[0] = hi[1] = hi[2] = -inf;
 #pragma unroll
-    for (int h = 0; h < FPS_NH; h++) {
-        lo[0] = fminf(lo[0], cand[h] ? x[h] : inf); hi[0] = fmaxf(hi[0], cand[h] ? x[h] : -inf);
-        lo[1] = fminf(lo[1], cand[h] ? y[h] : inf); hi[1] = fmaxf(hi[1], cand[h] ? y[h] : -inf);
-        lo[2] = fminf(lo[2], cand[h] ? z[h] : inf); hi[2] = fmaxf(hi[2], cand[h] ? z[h] : -inf);
+    for (int e = 0; e < 4; e++) {
+        lo[0] = fminf(lo[0], cand[e] ? x[e] : inf); hi[0] = fmaxf(hi[0], cand[e] ? x[e] : -inf);
+        lo[1] = fminf(lo[1], cand[e] ? y[e] : inf); hi[1] = fmaxf(hi[1], cand[e] ? y[e] : -inf);
+        lo[2] = fminf(lo[2], cand[e] ? z[e] : inf); hi[2] = fmaxf(hi[2], cand[e] ? z[e] : -inf);
     }
     dpp_box6(lo[0], lo[1], lo[2], hi[0], hi[1], hi[2]);
 }
 
-// RANGE: point k = (ri[k]*tx[k], ri[k]*ty[k], ri[k]*tz[k]) with SoA rays; else AoS xyz[k*3..].
+// RANGE point k = ri[k] * rays[k]; else AoS xyz[k*3..]
 template <bool RANGE>
-__device__ __forceinline__ void fps_load_point(const float *__restrict__ src, const float *__restrict__ tx,
-                                               const float *__restrict__ ty, const float *__restrict__ tz, int k,
+__device__ __forceinline__ void fps_load_point(const float *__restrict__ src, const float *__restrict__ rays, int k,
                                                float &x, float &y, float &z) {
     if (RANGE) {
-        const uint32_t o = (uint32_t)k * 4u;  // byte offset from the wave-uniform bases (P * 4 < 2^32)
-        const float r = ld_f32(src, o);
-        x = r * ld_f32(tx, o); y = r * ld_f32(ty, o); z = r * ld_f32(tz, o);
+        const float r = ld_f32(src, (uint32_t)k * 4u);
+        x = r * ld_f32(rays, (uint32_t)k * 12u); y = r * ld_f32(rays, (uint32_t)k * 12u + 4u); z = r * ld_f32(rays, (uint32_t)k * 12u + 8u);
     } else {
         x = src[3 * (int64_t)k]; y = src[3 * (int64_t)k + 1]; z = src[3 * (int64_t)k + 2];
     }
@@ -148,26 +167,25 @@ __device__ __forceinline__ void fps_load_point(const float *__restrict__ src, co
 
 #define FPS_THREADS 1024
 
-// Threads of the tile-pruned FPS workgroup (one workgroup per frame).  Measured with 256-point tiles on 64x2048 (kernel
-// alone / step with three batches in flight): 1024 threads 452 us / 1.14 ms, 768 threads 474 us / 1.12 ms, 512 threads
-// 527 us / 1.07 ms, 384 threads 636 us / 1.10 ms.  Alone the wide workgroup wins; with batches in flight two narrow ones
-// leave wave slots to the throughput kernels of the other batches, and the step is what counts.
-// Small batches (fewer frames than half the CUs) have nothing to co-schedule with and take the 1024-thread form.
+// Threads of the tile-pruned FPS workgroup (one workgroup per frame): FPS_TT_BATCH for batches that fill the chip
+// (several batches in flight share the CUs), FPS_TT_SMALL for small batches (nothing to co-schedule with).
+// Measurements: DESIGN.md section 5.
+#ifndef FPS_TT_BATCH
 #define FPS_TT_BATCH 512
+#endif
 #define FPS_TT_SMALL 1024
-template <bool RANGE, int FPS_TT>
-__global__ __launch_bounds__(FPS_TT) void fps_tiled_kernel(const float *__restrict__ src,
-                                                                const float *__restrict__ tx,
-                                                                const float *__restrict__ ty,
-                                                                const float *__restrict__ tz, float *__restrict__ temp,
-                                                                const int32_t *__restrict__ info, FpsTiling g, int M,
-                                                                int32_t *__restrict__ out_idx,
-                                                                float *__restrict__ out_cen,
-                                                                const float *__restrict__ tiletab) {
+#define FPS_FLAG_FINALIZE_TEMP 1  // write the origin class's value back to the empty pixels' temp entries at the end
+
+template <bool RANGE, bool VEC, int FPS_TT>
+__global__ __launch_bounds__(FPS_TT) void fps_tiled_kernel(const float *__restrict__ src, const float *__restrict__ rays,
+                                                           float *__restrict__ temp, const int32_t *__restrict__ info,
+                                                           FpsTiling g, int M, int flags, int32_t *__restrict__ out_idx,
+                                                           float *__restrict__ out_cen,
+                                                           const float *__restrict__ tiletab) {
     extern __shared__ __attribute__((aligned(16))) unsigned char fps_smem[];
     __shared__ unsigned long long red[FPS_TT / 64];
     __shared__ int redt[FPS_TT / 64];
-    __shared__ int wcount;
+    __shared__ int wcount, s_viol;
     const int T = g.T, N = g.N;
     FpsLds L(fps_smem, T);
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -178,80 +196,103 @@ __global__ __launch_bounds__(FPS_TT) void fps_tiled_kernel(const float *__restri
     if (M <= 0) return;
 
     int old = 0;
-    if (RANGE) { old = info[4 * b + 1]; if (old >= N) old = 0; }
+    if (RANGE) { old = info[RPCC_INFO * b + 1]; if (old >= N) old = 0; }
     float c0, c1, c2;
-    fps_load_point<RANGE>(src, tx, ty, tz, old, c0, c1, c2);
+    fps_load_point<RANGE>(src, rays, old, c0, c1, c2);
     if (tid == 0) {
         out_idx[0] = old;
         if (out_cen) { out_cen[0] = c0; out_cen[1] = c1; out_cen[2] = c2; }
         wcount = 0;
+        s_viol = 0;
     }
+    // origin class: every empty pixel that is a candidate (see the header)
+    int org_idx = N;
+    if (RANGE) { org_idx = info[RPCC_INFO * b + 4]; if (org_idx < 0 || org_idx > N) org_idx = N; }
+    bool org_on = RANGE && org_idx < N;
+    float ox = 0.0f, oy = 0.0f, oz = 0.0f, t_org = -1.0f;
+    if (org_on) {
+        fps_load_point<RANGE>(src, rays, org_idx, ox, oy, oz);   // 0 * ray: signed zeros
+        t_org = ld_f32(temp, (uint32_t)org_idx * 4u);
+        if (!(t_org >= 0.0f) || ld_f32(src, (uint32_t)org_idx * 4u) != 0.0f) { org_on = false; t_org = -1.0f; }
+    }
+    const float t_org0 = t_org;
 
-    if (RANGE) {
-        for (int t = tid; t < T; t += FPS_TT) {
+    for (int t = tid; t < T; t += FPS_TT) {
+        uint32_t org = 0u;
+        if (RANGE) {
             const int tr = t / g.tcols, tc = t - tr * g.tcols;
             const int ncol = min(32, g.W - 32 * tc), nrow = min(FPS_TROWS, g.H - FPS_TROWS * tr);
-            L.torg[t] = (uint32_t)(FPS_TROWS * tr * g.W + 32 * tc) | ((uint32_t)(ncol - 1) << 22) | ((uint32_t)(nrow - 1) << 27);
+            org = (uint32_t)(FPS_TROWS * tr * g.W + 32 * tc) | ((uint32_t)(ncol - 1) << 22) | ((uint32_t)(nrow - 1) << 27);
         }
+        L.cx4[t].w = u2f(org);
     }
     __syncthreads();
-    // A tile's data in registers (loads are issued for a group of tiles before any is consumed, so the
-    // memory latency of a round is paid once per group; all loads are unconditional on clamped indices).
-    struct TileRegs { float x[FPS_NH], y[FPS_NH], z[FPS_NH], tp[FPS_NH]; int p[FPS_NH]; };
-    const int lrow = lane >> 5, lcol = lane & 31;
-    const int loff0 = lrow * g.W + lcol;  // lane's pixel offset inside a tile, half 0 (half h: + 2 * h * W)
-    auto load_tile = [&](int t, TileRegs &q) {
-        const uint32_t org = RANGE ? L.torg[t] : 0u;
-#pragma unroll
-        for (int h = 0; h < FPS_NH; h++) {
-            if (RANGE) {
-                const bool ok = lcol <= (int)((org >> 22) & 31u) && 2 * h + lrow <= (int)(org >> 27);
-                q.p[h] = ok ? (int)(org & 0x3FFFFFu) + loff0 + 2 * h * g.W : -1;
-            } else {
-                q.p[h] = fps_tile_point<RANGE>(g, t, h, lane);
-            }
-            const int pc = q.p[h] < 0 ? 0 : q.p[h];
-            fps_load_point<RANGE>(src, tx, ty, tz, pc, q.x[h], q.y[h], q.z[h]);
-            q.tp[h] = ld_f32(temp, (uint32_t)pc * 4u);
-            if (q.p[h] < 0) q.tp[h] = -1.0f;  // not a candidate; its (clamped-load) coordinates are never used
+    const int lrow = lane >> 3, lcol = 4 * (lane & 7);
+    auto locate = [&](int t, FpsQuad &q) {
+        if (RANGE) {
+            const uint32_t org = f2u(L.cx4[t].w);
+            const int ncol = (int)((org >> 22) & 31u) + 1, nrow = (int)(org >> 27) + 1;
+            const int nv = lrow < nrow ? min(max(ncol - lcol, 0), 4) : 0;
+            q.nval = nv;
+            q.p0 = nv > 0 ? (int)(org & 0x3FFFFFu) + lrow * g.W + lcol : 0;
+        } else {
+            const int p = t * FPS_TILE + 4 * lane;
+            q.nval = min(max(N - p, 0), 4);
+            q.p0 = q.nval > 0 ? p : 0;
         }
     };
-    // distance update against the current centre, tile maximum, (optionally) bounding box
-    auto compute_tile = [&](int t, const TileRegs &q, bool with_box) {
-        bool valid[FPS_NH], cand[FPS_NH];
-        float nt[FPS_NH];
+    // distance update against the current centre, tile maximum, (optionally) bounding box and the check that the
+    // origin class is what the header says (all empty pixels candidates with one common temp)
+    auto compute_tile = [&](int t, const FpsQuad &q, bool with_box) {
+        float x[4], y[4], z[4], nt[4];
+        uint32_t key[4];
+        bool cand[4], ch = false, viol = false;
+        fps_quad_xyz(q, RANGE, x, y, z);
 #pragma unroll
-        for (int h = 0; h < FPS_NH; h++) {
-            valid[h] = q.p[h] >= 0;
-            cand[h] = q.tp[h] >= 0.0f;
-            const float dx = q.x[h] - c0, dy = q.y[h] - c1, dz = q.z[h] - c2;
+        for (int e = 0; e < 4; e++) {
+            float tp = e < q.nval ? q.tp[e] : -1.0f;
+            if (RANGE && org_on && q.r[e] == 0.0f) {   // member of the origin class: carried by t_org
+                if (with_box) viol |= e < q.nval && tp != t_org0;
+                tp = -1.0f;
+            }
+            cand[e] = tp >= 0.0f;
+            const float dx = x[e] - c0, dy = y[e] - c1, dz = z[e] - c2;
             const float d = (dx * dx + dy * dy) + dz * dz;  // sampling_gpu.cu:64, un-fused
-            nt[h] = d < q.tp[h] ? d : q.tp[h];  // == fminf(d, tp): a NaN distance keeps tp, tp itself is never NaN
-            if (valid[h] && nt[h] != q.tp[h]) st_f32(temp, (uint32_t)q.p[h] * 4u, nt[h]);
+            nt[e] = d < tp ? d : tp;  // == fminf(d, tp): a NaN distance keeps tp, tp itself is never NaN
+            key[e] = fps_val_key(nt[e]);
+            const bool c = nt[e] != tp;
+            ch |= c;
+            if (!VEC && c) st_f32(temp, (uint32_t)(q.p0 + e) * 4u, nt[e]);
+            if (!c) nt[e] = q.tp[e];   // value to write back for an unchanged element
         }
+        if (VEC && ch) st_at(reinterpret_cast<float4 *>(temp), (uint32_t)q.p0 * 4u, make_float4(nt[0], nt[1], nt[2], nt[3]));
+        if (with_box && __ballot(viol) != 0ull && lane == 0) s_viol = 1;
         // nothing changed in this tile: its table entry (maximum, arg, coordinates) is still exact
-        bool changed = false;
-#pragma unroll
-        for (int h = 0; h < FPS_NH; h++) changed |= valid[h] && nt[h] != q.tp[h];
-        if (!with_box && __ballot(changed) == 0ull) return;
+        if (!with_box && __ballot(ch) == 0ull) return;
         if (with_box) {
             float lo[3], hi[3];
-            fps_tile_box(q.x, q.y, q.z, cand, lo, hi);
-            if (lane == 0) { L.lo[0][t] = lo[0]; L.lo[1][t] = lo[1]; L.lo[2][t] = lo[2]; L.hi[0][t] = hi[0]; L.hi[1][t] = hi[1]; L.hi[2][t] = hi[2]; }
+            fps_tile_box(x, y, z, cand, lo, hi);
+            if (lane == 0) { L.lo4[t].x = lo[0]; L.lo4[t].y = lo[1]; L.lo4[t].z = lo[2]; L.hi4[t].x = hi[0]; L.hi4[t].y = hi[1]; L.hi4[t].z = hi[2]; }
         }
         float wt, wx, wy, wz;
         uint32_t widx;
-        fps_tile_argmax(q.x, q.y, q.z, nt, valid, q.p, wt, wx, wy, wz, widx);
-        if (lane == 0) { L.tmax[t] = wt; L.targ[t] = widx; L.cx[0][t] = wx; L.cx[1][t] = wy; L.cx[2][t] = wz; }
+        fps_tile_argmax(x, y, z, key, q.p0, wt, wx, wy, wz, widx);
+        if (lane == 0) { L.lo4[t].w = wt; L.hi4[t].w = u2f(widx); L.cx4[t].x = wx; L.cx4[t].y = wy; L.cx4[t].z = wz; }
+    };
+    auto update_origin = [&]() {
+        if (org_on) {
+            const float dx = ox - c0, dy = oy - c1, dz = oz - c2;
+            const float d = (dx * dx + dy * dy) + dz * dz;
+            t_org = d < t_org ? d : t_org;
+        }
     };
 
-    // arg-max over the tile table -> next centre (index and coordinates)
+    // arg-max over the tile table and the origin class -> next centre (index and coordinates)
     auto select_next = [&]() {
         uint32_t hi = 0u, ix = 0xFFFFFFFFu;  // orderable value, index
         int bt = 0;
         for (int t = tid; t < T; t += FPS_TT) {
-            const float v = L.tmax[t];
-            const uint32_t h = (v < 0.0f) ? 0u : f2u(v) + 1u, i = L.targ[t];
+            const uint32_t h = fps_val_key(L.lo4[t].w), i = f2u(L.hi4[t].w);
             if (h > hi || (h == hi && i < ix)) { hi = h; ix = i; bt = t; }
         }
         uint32_t vmax = dpp_max_u32(hi);
@@ -271,40 +312,52 @@ __global__ __launch_bounds__(FPS_TT) void fps_tiled_kernel(const float *__restri
         const unsigned long long mm = __ballot(hi == vmax && ix == imin);
         const int wl = __builtin_amdgcn_readfirstlane((int)__ffsll((long long)mm) - 1);
         const int t = __builtin_amdgcn_readlane(kt, wl < 0 ? 0 : wl);
-        if (imin == 0xFFFFFFFFu) {  // no candidate anywhere: keep indices defined (the reference would fail)
+        const uint32_t okey = org_on ? fps_val_key(t_org) : 0u;
+        if (okey != 0u && (okey > vmax || (okey == vmax && (uint32_t)org_idx < imin))) {
+            old = org_idx;
+            c0 = ox; c1 = oy; c2 = oz;
+        } else if (vmax == 0u || imin == 0xFFFFFFFFu) {  // no candidate anywhere: keep indices defined (the reference would fail)
             old = 0;
-            fps_load_point<RANGE>(src, tx, ty, tz, 0, c0, c1, c2);
+            fps_load_point<RANGE>(src, rays, 0, c0, c1, c2);
         } else {
             old = (int)imin;
-            c0 = L.cx[0][t]; c1 = L.cx[1][t]; c2 = L.cx[2][t];
+            const float4 cc = L.cx4[t];
+            c0 = cc.x; c1 = cc.y; c2 = cc.z;
         }
     };
 
-    constexpr int NW = FPS_TT / 64, GROUP = FPS_NH >= 8 ? 1 : 8 / FPS_NH;  // tiles per wavefront in flight: 512 points (256 and 1024 measured: no better)
+    constexpr int NW = FPS_TT / 64, GROUP = 2;  // tiles per wavefront in flight
     DBG_STAMP(8);
     // first centre: every tile is visited once (also builds the boxes) -- unless ground_mask already did
     // that pass and left the tile table (info[b][3] == 1)
-    const bool have_tab = RANGE && tiletab != nullptr && info[4 * b + 3] == 1;
+    const bool have_tab = RANGE && tiletab != nullptr && info[RPCC_INFO * b + 3] == 1;
     if (M > 1 && have_tab) {
-        const float *tab = tiletab + (int64_t)b * FPS_TAB_ROWS * T;
-        float *dst = reinterpret_cast<float *>(fps_smem);
-        if ((T & 3) == 0) {  // 16-byte copies (the table of a frame starts at a multiple of 16 bytes then)
-            const float4 *t4 = reinterpret_cast<const float4 *>(tab);
-            float4 *d4 = reinterpret_cast<float4 *>(dst);
-            for (int i = tid; i < FPS_TAB_ROWS * T / 4; i += FPS_TT) d4[i] = t4[i];
-        } else {
-            for (int i = tid; i < FPS_TAB_ROWS * T; i += FPS_TT) dst[i] = tab[i];
-        }
+        const float4 *t4 = reinterpret_cast<const float4 *>(tiletab + (int64_t)b * FPS_TAB_ROWS * T);
+        float4 *d4 = reinterpret_cast<float4 *>(fps_smem);
+        for (int i = tid; i < 2 * T; i += FPS_TT) d4[i] = t4[i];
+        for (int i = tid; i < T; i += FPS_TT) { const float4 v = t4[2 * T + i]; L.cx4[i].x = v.x; L.cx4[i].y = v.y; L.cx4[i].z = v.z; }
+        update_origin();  // (idempotent: temp of the empty pixels already holds the first centre's distance)
         __syncthreads();
     } else if (M > 1) {
-        for (int t = wave; t < T; t += NW * GROUP) {
-            TileRegs q[GROUP];
+        for (int pass = 0; pass < 2; pass++) {
+            for (int t = wave; t < T; t += NW * GROUP) {
+                FpsQuad q[GROUP];
 #pragma unroll
-            for (int gi = 0; gi < GROUP; gi++) if (t + gi * NW < T) load_tile(t + gi * NW, q[gi]);
+                for (int gi = 0; gi < GROUP; gi++) {
+                    locate(min(t + gi * NW, T - 1), q[gi]);
+                    fps_quad_load<RANGE, VEC>(src, rays, temp, q[gi]);
+                }
 #pragma unroll
-            for (int gi = 0; gi < GROUP; gi++) if (t + gi * NW < T) compute_tile(t + gi * NW, q[gi], true);
+                for (int gi = 0; gi < GROUP; gi++) if (t + gi * NW < T) compute_tile(t + gi * NW, q[gi], true);
+            }
+            __syncthreads();
+            // the origin class must be uniform (it is when temp comes from rpcc_ground_mask); a caller-made temp that
+            // treats the empty pixels individually is handled by a second pass without the class
+            if (!(org_on && s_viol)) break;
+            org_on = false; t_org = -1.0f;
+            __threadfence_block();
         }
-        __syncthreads();
+        update_origin();
     }
     if (M > 1) {
         DBG_STAMP(9);
@@ -318,11 +371,12 @@ __global__ __launch_bounds__(FPS_TT) void fps_tiled_kernel(const float *__restri
         if (prof) tq = (long long)__builtin_readcyclecounter();
         // tile test against the new centre; active tiles go to the work list
         for (int t = tid; t < T; t += FPS_TT) {
-            const float g0 = fmaxf(fmaxf(L.lo[0][t] - c0, c0 - L.hi[0][t]), 0.0f);
-            const float g1 = fmaxf(fmaxf(L.lo[1][t] - c1, c1 - L.hi[1][t]), 0.0f);
-            const float g2 = fmaxf(fmaxf(L.lo[2][t] - c2, c2 - L.hi[2][t]), 0.0f);
+            const float4 lo = L.lo4[t], hi = L.hi4[t];
+            const float g0 = fmaxf(fmaxf(lo.x - c0, c0 - hi.x), 0.0f);
+            const float g1 = fmaxf(fmaxf(lo.y - c1, c1 - hi.y), 0.0f);
+            const float g2 = fmaxf(fmaxf(lo.z - c2, c2 - hi.z), 0.0f);
             const float bound = (g0 * g0 + g1 * g1) + g2 * g2;
-            const bool act = bound < L.tmax[t];
+            const bool act = bound < lo.w;
             const unsigned long long m = __ballot(act);
             if (m) {
                 int base = 0;
@@ -331,17 +385,19 @@ __global__ __launch_bounds__(FPS_TT) void fps_tiled_kernel(const float *__restri
                 if (act) L.work[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)t;
             }
         }
+        update_origin();
         __syncthreads();
         const int n = wcount;
         if (prof) { const long long t1 = (long long)__builtin_readcyclecounter(); acc_a += t1 - tq; tq = t1; acc_n += n; }
         for (int e = wave; e < n; e += NW * GROUP) {
-            TileRegs q[GROUP];
+            FpsQuad q[GROUP];
             int tt[GROUP];
 #pragma unroll
             for (int gi = 0; gi < GROUP; gi++) {
                 const int ee = e + gi * NW;
                 tt[gi] = (int)L.work[ee < n ? ee : n - 1];
-                load_tile(tt[gi], q[gi]);   // unconditional (a repeated tile for the tail is harmless and unused)
+                locate(tt[gi], q[gi]);
+                fps_quad_load<RANGE, VEC>(src, rays, temp, q[gi]);   // unconditional (a repeated tile for the tail is harmless and unused)
             }
 #pragma unroll
             for (int gi = 0; gi < GROUP; gi++) if (e + gi * NW < n) compute_tile(tt[gi], q[gi], false);
@@ -355,6 +411,13 @@ __global__ __launch_bounds__(FPS_TT) void fps_tiled_kernel(const float *__restri
     }
     DBG_STAMP(16);
     if (prof) { g_dbg_stamps[24] = acc_a; g_dbg_stamps[25] = acc_b; g_dbg_stamps[26] = acc_c; g_dbg_stamps[27] = acc_n; }
+    if (RANGE && org_on && (flags & FPS_FLAG_FINALIZE_TEMP)) {
+        // the empty pixels' temp entries were not touched while the class was carried as a scalar
+        for (int p = tid; p < N; p += FPS_TT) {
+            const float r = ld_f32(src, (uint32_t)p * 4u), tv = ld_f32(temp, (uint32_t)p * 4u);
+            if (r == 0.0f && tv >= 0.0f && tv != t_org) st_f32(temp, (uint32_t)p * 4u, t_org);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -364,15 +427,16 @@ __global__ __launch_bounds__(FPS_TT) void fps_tiled_kernel(const float *__restri
 // empty pixels are candidates) the kernel writes temp = min(1e10, d(pixel, first centre)) instead of
 // 1e10 and fills the FPS tile table (FpsLds layout) so the FPS kernel starts at the second centre.
 // Otherwise info[b][3] stays 0, the classic temp = 1e10 / -1 is written and the FPS kernel does its own
-// first pass.  Same arithmetic either way.  One wavefront per 4x32 tile, TAB_TPW tiles per wavefront.
+// first pass.  Same arithmetic either way.  One wavefront per tile, TAB_TPW tiles per wavefront.
+// info[b][4] = first empty pixel that is a candidate (the representative of the FPS kernel's origin class).
 // ------------------------------------------------------------------------------------------------
-#define TAB_TPW (FPS_NH >= 8 ? 1 : 8 / FPS_NH)
-template <bool RAW>
+#define TAB_TPW 2
+template <bool RAW, bool VEC>
 __global__ __launch_bounds__(256) void ground_mask_tab_kernel(float *__restrict__ ri, const float *__restrict__ tm,
                                                               const double *__restrict__ ground, double thr, FpsTiling g,
                                                               float *__restrict__ temp, int32_t *__restrict__ info,
                                                               float *__restrict__ tiletab) {
-    __shared__ int s_cnt[4], s_nz[4], s_first[4];
+    __shared__ int s_cnt[4], s_nz[4], s_first[4], s_forg[4];
     const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int P = g.N, T = g.T;
     const double a = ground[4 * b], bb = ground[4 * b + 1], c = ground[4 * b + 2], d = ground[4 * b + 3];
@@ -394,90 +458,113 @@ __global__ __launch_bounds__(256) void ground_mask_tab_kernel(float *__restrict_
         if (screen && num < t_lo) return false;
         return num / div > thr;
     };
-    auto load_px = [&](int p, float &r, float &x, float &y, float &z) -> bool {
-        r = ri[(int64_t)b * P + p];
-        return classify(r, tm[3 * p], tm[3 * p + 1], tm[3 * p + 2], x, y, z);
-    };
+    float *ri_b = ri + (int64_t)b * P, *temp_b = temp + (int64_t)b * P;
     bool fast;
     float c0, c1, c2;
     {
-        float r, x, y, z;
-        const bool cd = load_px(min(lane, P - 1), r, x, y, z) && lane < P;
+        const int p = min(lane, P - 1);
+        float r = ri_b[p], x, y, z;
+        const bool cd = classify(r, tm[3 * p], tm[3 * p + 1], tm[3 * p + 2], x, y, z) && lane < P;
         const unsigned long long m = __ballot(cd);
         fast = m != 0ull;
         const int f0 = fast ? (int)__ffsll((long long)m) - 1 : 0;
         c0 = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(x), f0));
         c1 = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(y), f0));
         c2 = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(z), f0));
-        if (blockIdx.x == 0 && threadIdx.x == 0) info[4 * b + 3] = fast ? 1 : 0;
+        if (blockIdx.x == 0 && threadIdx.x == 0) info[RPCC_INFO * b + 3] = fast ? 1 : 0;
     }
-    float *tab = tiletab + (int64_t)b * FPS_TAB_ROWS * T;
-    float *ri_b = ri + (int64_t)b * P, *temp_b = temp + (int64_t)b * P;
-    int cnt = 0, nzc = 0, first = P;
+    float4 *tab4 = reinterpret_cast<float4 *>(tiletab + (int64_t)b * FPS_TAB_ROWS * T);
+    int cnt = 0, nzc = 0, first = P, forg = P;
     const int t0 = (blockIdx.x * 4 + wave) * TAB_TPW;
+    const int lrow = lane >> 3, lcol = 4 * (lane & 7);
     // the loads of all TAB_TPW tiles of this wavefront first (unconditional, clamped): one memory latency, not TAB_TPW
-    float pr[TAB_TPW][FPS_NH], ptx[TAB_TPW][FPS_NH], pty[TAB_TPW][FPS_NH], ptz[TAB_TPW][FPS_NH];
-    int ppix[TAB_TPW][FPS_NH];
+    FpsQuad q[TAB_TPW];
 #pragma unroll
-    for (int q = 0; q < TAB_TPW; q++)
+    for (int k = 0; k < TAB_TPW; k++) {
+        const int t = min(t0 + k, T - 1);
+        const int tr = t / g.tcols, tc = t - tr * g.tcols;
+        const int row = FPS_TROWS * tr + lrow, col = 32 * tc + lcol;
+        q[k].nval = row < g.H ? min(max(g.W - col, 0), 4) : 0;
+        q[k].p0 = q[k].nval > 0 ? row * g.W + col : 0;
+        const uint32_t p0 = (uint32_t)q[k].p0;
+        if (VEC) {
+            const float4 r = ld_at(reinterpret_cast<const float4 *>(ri_b), p0 * 4u);
+            q[k].r[0] = r.x; q[k].r[1] = r.y; q[k].r[2] = r.z; q[k].r[3] = r.w;
+            const float4 ra = ld_at(reinterpret_cast<const float4 *>(tm), p0 * 12u);
+            const float4 rb = ld_at(reinterpret_cast<const float4 *>(tm), p0 * 12u + 16u);
+            const float4 rc = ld_at(reinterpret_cast<const float4 *>(tm), p0 * 12u + 32u);
+            q[k].t[0] = ra.x; q[k].t[1] = ra.y; q[k].t[2] = ra.z; q[k].t[3] = ra.w; q[k].t[4] = rb.x; q[k].t[5] = rb.y;
+            q[k].t[6] = rb.z; q[k].t[7] = rb.w; q[k].t[8] = rc.x; q[k].t[9] = rc.y; q[k].t[10] = rc.z; q[k].t[11] = rc.w;
+        } else {
 #pragma unroll
-        for (int h = 0; h < FPS_NH; h++) {
-            ppix[q][h] = fps_tile_point<true>(g, min(t0 + q, T - 1), h, lane);
-            const uint32_t pc = ppix[q][h] >= 0 ? (uint32_t)ppix[q][h] : 0u;  // byte offsets from wave-uniform bases
-            pr[q][h] = ld_at(ri_b, pc * 4u);
-            const f32x3 ray = ld_at(reinterpret_cast<const f32x3 *>(tm), pc * 12u);
-            ptx[q][h] = ray.x; pty[q][h] = ray.y; ptz[q][h] = ray.z;
+            for (int e = 0; e < 4; e++) {
+                const uint32_t p = p0 + (uint32_t)(e < q[k].nval ? e : 0);
+                q[k].r[e] = ld_f32(ri_b, p * 4u);
+                q[k].t[3 * e] = ld_f32(tm, p * 12u); q[k].t[3 * e + 1] = ld_f32(tm, p * 12u + 4u); q[k].t[3 * e + 2] = ld_f32(tm, p * 12u + 8u);
+            }
         }
+    }
 #pragma unroll
-    for (int q = 0; q < TAB_TPW; q++) {
-        const int t = t0 + q;
+    for (int k = 0; k < TAB_TPW; k++) {
+        const int t = t0 + k;
         if (t >= T) break;
-        float x[FPS_NH], y[FPS_NH], z[FPS_NH], nt[FPS_NH];
-        bool valid[FPS_NH], cand[FPS_NH];
-        int pidx[FPS_NH];
+        float x[4], y[4], z[4], nt[4], rr[4];
+        uint32_t key[4];
+        bool boxc[4];
 #pragma unroll
-        for (int h = 0; h < FPS_NH; h++) {
-            pidx[h] = ppix[q][h];
-            valid[h] = pidx[h] >= 0;
-            float r = pr[q][h];
-            cand[h] = classify(r, ptx[q][h], pty[q][h], ptz[q][h], x[h], y[h], z[h]) && valid[h];
-            const bool nz = valid[h] && r != 0.0f;
-            nt[h] = cand[h] ? 1e10f : -1.0f;
+        for (int e = 0; e < 4; e++) {
+            const bool valid = e < q[k].nval;
+            float r = q[k].r[e];
+            const bool cand = classify(r, q[k].t[3 * e], q[k].t[3 * e + 1], q[k].t[3 * e + 2], x[e], y[e], z[e]) && valid;
+            rr[e] = r;
+            const bool nz = valid && r != 0.0f;
+            nt[e] = cand ? 1e10f : -1.0f;
             if (fast) {
-                const float dx = x[h] - c0, dy = y[h] - c1, dz = z[h] - c2;
+                const float dx = x[e] - c0, dy = y[e] - c1, dz = z[e] - c2;
                 const float dist = (dx * dx + dy * dy) + dz * dz;  // sampling_gpu.cu:64, un-fused
-                nt[h] = cand[h] ? fminf(dist, 1e10f) : -1.0f;
+                nt[e] = cand ? fminf(dist, 1e10f) : -1.0f;
             }
-            if (valid[h]) {
-                if (RAW) st_at(ri_b, (uint32_t)pidx[h] * 4u, r);
-                st_at(temp_b, (uint32_t)pidx[h] * 4u, nt[h]);
+            boxc[e] = cand && nz;                 // empty pixels belong to the origin class, not to the tile
+            key[e] = boxc[e] ? fps_val_key(nt[e]) : 0u;
+            if (!VEC && valid) {
+                if (RAW) st_f32(ri_b, (uint32_t)(q[k].p0 + e) * 4u, r);
+                st_f32(temp_b, (uint32_t)(q[k].p0 + e) * 4u, nt[e]);
             }
-            const unsigned long long mc = __ballot(cand[h]), mz = __ballot(nz);
+            const unsigned long long mc = __ballot(cand), mz = __ballot(nz), mo = __ballot(cand && !nz);
             cnt += __popcll(mc);
             nzc += __popcll(mz);
-            if (mc) first = min(first, (int)__builtin_amdgcn_readlane(pidx[h], (int)__ffsll((long long)mc) - 1));
+            // candidates of one element slot are not in index order across lanes of different rows: take the minimum
+            if (mc) first = min(first, cand ? q[k].p0 + e : P);
+            if (mo) forg = min(forg, (cand && !nz) ? q[k].p0 + e : P);
+        }
+        if (VEC && q[k].nval > 0) {
+            if (RAW) st_at(reinterpret_cast<float4 *>(ri_b), (uint32_t)q[k].p0 * 4u, make_float4(rr[0], rr[1], rr[2], rr[3]));
+            st_at(reinterpret_cast<float4 *>(temp_b), (uint32_t)q[k].p0 * 4u, make_float4(nt[0], nt[1], nt[2], nt[3]));
         }
         if (fast) {
             float lo[3], hi[3], wt, wx, wy, wz;
             uint32_t widx;
-            fps_tile_box(x, y, z, cand, lo, hi);
-            fps_tile_argmax(x, y, z, nt, valid, pidx, wt, wx, wy, wz, widx);
-            if (lane < FPS_TAB_ROWS) {
-                float v = lo[0];
-                v = lane == 1 ? lo[1] : v; v = lane == 2 ? lo[2] : v; v = lane == 3 ? hi[0] : v; v = lane == 4 ? hi[1] : v;
-                v = lane == 5 ? hi[2] : v; v = lane == 6 ? wt : v; v = lane == 7 ? wx : v; v = lane == 8 ? wy : v;
-                v = lane == 9 ? wz : v; v = lane == 10 ? u2f(widx) : v;
-                tab[(int64_t)lane * T + t] = v;
+            fps_tile_box(x, y, z, boxc, lo, hi);
+            fps_tile_argmax(x, y, z, key, q[k].p0, wt, wx, wy, wz, widx);
+            if (lane < 3) {
+                float4 v = make_float4(lo[0], lo[1], lo[2], wt);
+                if (lane == 1) v = make_float4(hi[0], hi[1], hi[2], u2f(widx));
+                if (lane == 2) v = make_float4(wx, wy, wz, 0.0f);
+                tab4[(int64_t)lane * T + t] = v;
             }
         }
     }
-    if (lane == 0) { s_cnt[wave] = cnt; s_nz[wave] = nzc; s_first[wave] = first; }
+    first = wave_min_i32(first);
+    forg = wave_min_i32(forg);
+    if (lane == 0) { s_cnt[wave] = cnt; s_nz[wave] = nzc; s_first[wave] = first; s_forg[wave] = forg; }
     __syncthreads();
     if (threadIdx.x == 0) {
         const int tc = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
         const int tz = s_nz[0] + s_nz[1] + s_nz[2] + s_nz[3];
         const int tf = min(min(s_first[0], s_first[1]), min(s_first[2], s_first[3]));
-        if (tc) { atomicAdd(&info[4 * b + 0], tc); atomicMin(&info[4 * b + 1], tf); }
-        if (tz) atomicAdd(&info[4 * b + 2], tz);
+        const int to = min(min(s_forg[0], s_forg[1]), min(s_forg[2], s_forg[3]));
+        if (tc) { atomicAdd(&info[RPCC_INFO * b + 0], tc); atomicMin(&info[RPCC_INFO * b + 1], tf); }
+        if (tz) atomicAdd(&info[RPCC_INFO * b + 2], tz);
+        if (to < P) atomicMin(&info[RPCC_INFO * b + 4], to);
     }
 }

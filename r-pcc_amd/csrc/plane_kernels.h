@@ -97,6 +97,7 @@ struct PlaneParams {
     int min_points;      // 30
     int iters;           // 10
     uint32_t seed;
+    const int64_t *frame_ids;  // dev i64 [B] or nullptr: the frame's identity for seeding (nullptr: its index in the batch)
 };
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -425,13 +426,14 @@ __global__ __launch_bounds__(PL_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8
     __shared__ NpwLds npw[PL_THREADS / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.y, K = M + 2, k0 = blockIdx.x * (PL_THREADS / 64);
+    const uint32_t fid = pp.frame_ids ? (uint32_t)pp.frame_ids[b] : (uint32_t)b;
     for (int w = 0; w < PL_THREADS / 64; w++) {   // workgroup-uniform
         const int kk = k0 + w;
         if (kk < 2 || kk >= K) continue;
         const int nn = counts[(int64_t)b * K + kk];
         if (nn <= big) continue;
         const uint32_t base = hist[((int64_t)b * T) * KP + kk];  // tile 0 offset = start of label kk in the ordered list
-        plane_label_wg(tm, order_all + (int64_t)b * P + base, pts_all + (int64_t)b * P + base, nn, mix32(pp.seed, (uint32_t)b, (uint32_t)kk),
+        plane_label_wg(tm, order_all + (int64_t)b * P + base, pts_all + (int64_t)b * P + base, nn, mix32(pp.seed, fid, (uint32_t)kk),
                        pp, S, npw, model + ((int64_t)b * K + kk) * 4);
     }
     const int k = k0 + wave;
@@ -453,7 +455,7 @@ __global__ __launch_bounds__(PL_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8
     bool use_plane = false;
     double plane[4] = {0, 0, 0, 0};
     if (n >= pp.min_points) {
-        const uint32_t seed = mix32(pp.seed, (uint32_t)b, (uint32_t)k);
+        const uint32_t seed = mix32(pp.seed, fid, (uint32_t)k);
         ransac_plane_wave<4, MAXH>(pts, n, pp.iters, pp.thr, seed, plane);
         // plane_angle_validation (segment_utils.py:84-93)
         const double a = plane[0], bb = plane[1], c = plane[2];

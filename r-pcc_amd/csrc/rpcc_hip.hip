@@ -10,6 +10,10 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
+#include <new>
+#include <utility>
+#include <vector>
 #include "../../include/rpcc_hip.h"
 #include "rpcc_device.h"
 
@@ -51,43 +55,76 @@ extern "C" int rpcc_debug_stamps(void *dev_i64_buffer) {
             g_dbg_stamps[slot_] = (long long)__builtin_readcyclecounter();                   \
     } while (0)
 
-// FPS timing hook (bench.py): hipEvents on the stream the kernel is launched on.
-static bool g_fps_timing = false;
-static hipEvent_t g_ev0[64], g_ev1[64];
-static int g_ev_n = 0, g_ev_alloc = 0;
-extern "C" void rpcc_fps_timing(int enable) {
-    g_fps_timing = enable != 0;
-    g_ev_n = 0;
+// Kernel attributes (dynamic LDS size) are set once per (device, kernel), not per launch.
+static std::mutex g_attr_mu;
+struct AttrDone { int dev; const void *fn; int bytes; };
+static std::vector<AttrDone> g_attr_done;
+static hipError_t ensure_dyn_lds(const void *fn, int bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lk(g_attr_mu);
+    AttrDone *slot = nullptr;
+    for (auto &d : g_attr_done)
+        if (d.dev == dev && d.fn == fn) slot = &d;
+    if (slot && slot->bytes >= bytes) return hipSuccess;   // the largest size asked for so far is in force
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return e;
+    if (slot) slot->bytes = bytes; else g_attr_done.push_back({dev, fn, bytes});
+    return hipSuccess;
 }
-extern "C" int rpcc_fps_time_ms(double *ms, int *launches) {
+
+// Timer object (bench.py): hipEvents around the FPS launches of the calls it is handed to, on the stream the kernel is
+// launched on.  State lives in the object (created by the caller, one per measuring thread), not in the library.
+struct rpcc_timer {
+    std::mutex mu;
+    std::vector<hipEvent_t> ev0, ev1;
+    size_t used = 0;
+};
+extern "C" void *rpcc_timer_create(void) { return new (std::nothrow) rpcc_timer(); }
+extern "C" void rpcc_timer_destroy(void *t) {
+    rpcc_timer *tm = reinterpret_cast<rpcc_timer *>(t);
+    if (!tm) return;
+    for (size_t i = 0; i < tm->ev0.size(); i++) { (void)hipEventDestroy(tm->ev0[i]); (void)hipEventDestroy(tm->ev1[i]); }
+    delete tm;
+}
+extern "C" int rpcc_timer_read(void *t, double *ms, int *launches) {
+    rpcc_timer *tm = reinterpret_cast<rpcc_timer *>(t);
+    ARG_TRY(tm != nullptr);
+    std::lock_guard<std::mutex> lk(tm->mu);
     double tot = 0;
-    for (int i = 0; i < g_ev_n; i++) {
-        float t = 0;
-        HIP_TRY(hipEventSynchronize(g_ev1[i]));
-        HIP_TRY(hipEventElapsedTime(&t, g_ev0[i], g_ev1[i]));
-        tot += t;
+    for (size_t i = 0; i < tm->used; i++) {
+        float v = 0;
+        HIP_TRY(hipEventSynchronize(tm->ev1[i]));
+        HIP_TRY(hipEventElapsedTime(&v, tm->ev0[i], tm->ev1[i]));
+        tot += v;
     }
     if (ms) *ms = tot;
-    if (launches) *launches = g_ev_n;
-    g_ev_n = 0;
+    if (launches) *launches = (int)tm->used;
+    tm->used = 0;
     return RPCC_OK;
 }
 struct FpsTimer {
     hipStream_t s;
-    bool on;
-    explicit FpsTimer(hipStream_t st) : s(st), on(g_fps_timing && g_ev_n < 64) {
-        if (!on) return;
-        while (g_ev_alloc <= g_ev_n) {
-            (void)hipEventCreate(&g_ev0[g_ev_alloc]);
-            (void)hipEventCreate(&g_ev1[g_ev_alloc]);
-            g_ev_alloc++;
+    rpcc_timer *tm;
+    size_t slot = 0;
+    FpsTimer(hipStream_t st, void *timer) : s(st), tm(reinterpret_cast<rpcc_timer *>(timer)) {
+        if (!tm) return;
+        std::lock_guard<std::mutex> lk(tm->mu);
+        slot = tm->used++;
+        while (tm->ev0.size() <= slot) {
+            hipEvent_t a, b;
+            (void)hipEventCreate(&a);
+            (void)hipEventCreate(&b);
+            tm->ev0.push_back(a);
+            tm->ev1.push_back(b);
         }
-        (void)hipEventRecord(g_ev0[g_ev_n], s);
+        (void)hipEventRecord(tm->ev0[slot], s);
     }
     ~FpsTimer() {
-        if (!on) return;
-        (void)hipEventRecord(g_ev1[g_ev_n], s);
-        g_ev_n++;
+        if (!tm) return;
+        std::lock_guard<std::mutex> lk(tm->mu);
+        (void)hipEventRecord(tm->ev1[slot], s);
     }
 };
 
@@ -548,8 +585,7 @@ static int launch_project(const float *xyz, const int64_t *offsets, int64_t tota
         if (total > 0)
             project_pix_kernel<<<(unsigned)std::min<int64_t>((total + PIX_PPT * PIX_THREADS - 1) / (PIX_PPT * PIX_THREADS), 256 * 16), PIX_THREADS, 0, st>>>(
                 xyz, offsets, total, base, B, g, pix_fast_cfg(g), pd, flags);
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&project_band_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, BAND_PX * 4));
+        HIP_TRY(ensure_dyn_lds(reinterpret_cast<const void *>(&project_band_kernel), BAND_PX * 4));
         if (zcnt && !cleared) HIP_TRY(hipMemsetAsync(zcnt, 0, (size_t)B * (RS_CHUNKS + 1) * 4, st));
         project_band_kernel<<<8 * ((B + 7) / 8) * ((P + BAND_PX - 1) / BAND_PX), BAND_THREADS, BAND_PX * 4, st>>>(
             pd, offsets, base, B, P, rb, flags, tz_plane, -1.5f, rs_chunk_px(P), tz_plane ? zcnt : nullptr);
@@ -823,7 +859,8 @@ __global__ __launch_bounds__(RS_THREADS) void ground_ransac_kernel(const float *
                                                                    double thr, uint32_t seed0, int raw,
                                                                    double *__restrict__ ground,
                                                                    int32_t *__restrict__ ninl,
-                                                                   const int32_t *__restrict__ zcnt) {
+                                                                   const int32_t *__restrict__ zcnt,
+                                                                   const int64_t *__restrict__ frame_ids) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rs_smem[];
     double *sred = reinterpret_cast<double *>(rs_smem);          // [6*256]
     double *swin = sred + 6 * RS_NT;                             // [64] + [RS_MAX_HYP*4] fp64 hypotheses
@@ -905,7 +942,9 @@ __global__ __launch_bounds__(RS_THREADS) void ground_ransac_kernel(const float *
     DBG_STAMP(2);
     double plane[4];
     (void)ransac_n;  // the ground fit samples 10 points (utils/segment_utils.py:75)
-    const int inl = ransac_plane_wg<10, RS_THREADS, RS_MAX_HYP, 1>(pts, iters, thr, seed0 + (uint32_t)b, plane, sred, swin, sbest);
+    // the frame's seed follows its identity (datalist index), not its position in the batch
+    const uint32_t fid = frame_ids ? (uint32_t)frame_ids[b] : (uint32_t)b;
+    const int inl = ransac_plane_wg<10, RS_THREADS, RS_MAX_HYP, 1>(pts, iters, thr, seed0 + fid, plane, sred, swin, sbest);
     DBG_STAMP(6);
     if (tid == 0) {
         ground[4 * b] = plane[0]; ground[4 * b + 1] = plane[1]; ground[4 * b + 2] = plane[2]; ground[4 * b + 3] = plane[3];
@@ -914,34 +953,38 @@ __global__ __launch_bounds__(RS_THREADS) void ground_ransac_kernel(const float *
 }
 
 static int launch_ground_ransac(const float *ri, const float *tm, int B, int P, uint32_t seed0, bool raw, double *ground,
-                                int32_t *ninl, hipStream_t st, const int32_t *zcnt = nullptr) {
+                                int32_t *ninl, hipStream_t st, const int32_t *zcnt = nullptr,
+                                const int64_t *frame_ids = nullptr) {
     const int max_pts = 5000, min_pts = 800;
     const size_t sh = (size_t)6 * RS_NT * 8 + (64 + RS_MAX_HYP * 4) * 8 + 32 * 4 + 16 * 4 + (size_t)max_pts * 3 * 4;
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&ground_ransac_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+    HIP_TRY(ensure_dyn_lds(reinterpret_cast<const void *>(&ground_ransac_kernel), (int)sh));
     ground_ransac_kernel<<<B, RS_THREADS, sh, st>>>(ri, tm, P, -1.5f, max_pts, min_pts, 10, 100, 0.1, seed0, raw ? 1 : 0,
-                                                    ground, ninl, zcnt);
+                                                    ground, ninl, zcnt, frame_ids);
     LAUNCH_CHECK();
     return RPCC_OK;
 }
 
-extern "C" int rpcc_ground_ransac(const float *ri, const float *tm, int B, int P, uint32_t seed, double *ground,
-                                  int32_t *inliers, void *stream) {
+extern "C" int rpcc_ground_ransac(const float *ri, const float *tm, int B, int P, uint32_t seed, const int64_t *frame_ids,
+                                  double *ground, int32_t *inliers, void *stream) {
     ARG_TRY(B > 0 && B <= RPCC_MAX_BATCH && P > 0 && ri && tm && ground);
-    return launch_ground_ransac(ri, tm, B, P, seed, false, ground, inliers, (hipStream_t)stream);
+    return launch_ground_ransac(ri, tm, B, P, seed, false, ground, inliers, (hipStream_t)stream, nullptr, frame_ids);
 }
 
 // ================================================================================================
 // a3 + a5  back-projection, vertical ground residual, candidate mask, FPS state init
 //          (dataset/transformer.py:94-101, utils/segment_utils.py:44-47,119-120)
 // ================================================================================================
+#include "fps_kernels.h"
+
 __global__ void info_init_kernel(int32_t *__restrict__ info, int B, int P) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < B) {
-        info[4 * b + 0] = 0;
-        info[4 * b + 1] = P;
-        info[4 * b + 2] = 0;
-        info[4 * b + 3] = 0;
+        info[RPCC_INFO * b + 0] = 0;
+        info[RPCC_INFO * b + 1] = P;
+        info[RPCC_INFO * b + 2] = 0;
+        info[RPCC_INFO * b + 3] = 0;
+        info[RPCC_INFO * b + 4] = P;
+        info[RPCC_INFO * b + 5] = 0; info[RPCC_INFO * b + 6] = 0; info[RPCC_INFO * b + 7] = 0;
     }
 }
 
@@ -954,12 +997,12 @@ template <bool RAW>
 __global__ __launch_bounds__(256) void ground_mask_kernel(float *__restrict__ ri, const float *__restrict__ tm,
                                                           const double *__restrict__ ground, double thr, int P,
                                                           float *__restrict__ temp, int32_t *__restrict__ info) {
-    __shared__ int s_cnt[4], s_nz[4], s_first[4];
+    __shared__ int s_cnt[4], s_nz[4], s_first[4], s_forg[4];
     const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const double a = ground[4 * b], bb = ground[4 * b + 1], c = ground[4 * b + 2], d = ground[4 * b + 3];
     // np.linalg.norm(plane_param[:, :3]) on a (1,1,4) array: all four components (segment_utils.py:47)
     const double div = sqrt(((a * a + bb * bb) + c * c) + d * d);
-    int cnt = 0, nzc = 0, first = P;
+    int cnt = 0, nzc = 0, first = P, forg = P;
     for (int it = 0; it < GM_PIX / 256; it++) {
         const int p = blockIdx.x * GM_PIX + it * 256 + threadIdx.x;
         if ((int)(blockIdx.x * GM_PIX) + it * 256 >= P) break;  // whole workgroup past the image (uniform)
@@ -975,25 +1018,27 @@ __global__ __launch_bounds__(256) void ground_mask_kernel(float *__restrict__ ri
             if (RAW) ri[(int64_t)b * P + p] = r;
             temp[(int64_t)b * P + p] = cand ? 1e10f : -1.0f;
         }
-        const unsigned long long mc = __ballot(cand), mz = __ballot(nz);
+        const unsigned long long mc = __ballot(cand), mz = __ballot(nz), mo = __ballot(cand && !nz);
         cnt += __popcll(mc);
         nzc += __popcll(mz);
         if (mc && first == P) first = (p - lane) + (int)__ffsll((long long)mc) - 1;
+        if (mo && forg == P) forg = (p - lane) + (int)__ffsll((long long)mo) - 1;  // first empty pixel that is a candidate
     }
-    if (lane == 0) { s_cnt[wave] = cnt; s_nz[wave] = nzc; s_first[wave] = first; }
+    if (lane == 0) { s_cnt[wave] = cnt; s_nz[wave] = nzc; s_first[wave] = first; s_forg[wave] = forg; }
     __syncthreads();
     if (threadIdx.x == 0) {
         const int tc = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
         const int tz = s_nz[0] + s_nz[1] + s_nz[2] + s_nz[3];
         const int tf = min(min(s_first[0], s_first[1]), min(s_first[2], s_first[3]));
-        if (tc) { atomicAdd(&info[4 * b + 0], tc); atomicMin(&info[4 * b + 1], tf); }
-        if (tz) atomicAdd(&info[4 * b + 2], tz);
+        const int to = min(min(s_forg[0], s_forg[1]), min(s_forg[2], s_forg[3]));
+        if (tc) { atomicAdd(&info[RPCC_INFO * b + 0], tc); atomicMin(&info[RPCC_INFO * b + 1], tf); }
+        if (tz) atomicAdd(&info[RPCC_INFO * b + 2], tz);
+        if (to < P) atomicMin(&info[RPCC_INFO * b + 4], to);
     }
 }
 
-#include "fps_kernels.h"
-
-// tiletab: dev f32 [B][11][T] (T = tiles of fps_tiling_range(H,W)) or NULL
+// tiletab: dev float4 [B][3][T] (T = tiles of fps_tiling_range(H,W)) or NULL
+static inline bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
 static int launch_ground_mask(float *ri, const float *tm, const double *ground, double thr, int B, int H, int W,
                               float *temp, int32_t *info, float *tiletab, hipStream_t st, bool raw,
                               bool info_ready = false) {
@@ -1002,8 +1047,11 @@ static int launch_ground_mask(float *ri, const float *tm, const double *ground, 
     if (tiletab) {
         const FpsTiling g = fps_tiling_range(H, W);
         const dim3 grid((g.T + 4 * TAB_TPW - 1) / (4 * TAB_TPW), B);
-        if (raw) ground_mask_tab_kernel<true><<<grid, 256, 0, st>>>(ri, tm, ground, thr, g, temp, info, tiletab);
-        else     ground_mask_tab_kernel<false><<<grid, 256, 0, st>>>(ri, tm, ground, thr, g, temp, info, tiletab);
+        const bool vec = (W % 4 == 0) && aligned16(ri) && aligned16(temp) && aligned16(tm);
+#define GM_LAUNCH(RAW_, VEC_) ground_mask_tab_kernel<RAW_, VEC_><<<grid, 256, 0, st>>>(ri, tm, ground, thr, g, temp, info, tiletab)
+        if (raw) { if (vec) GM_LAUNCH(true, true); else GM_LAUNCH(true, false); }
+        else     { if (vec) GM_LAUNCH(false, true); else GM_LAUNCH(false, false); }
+#undef GM_LAUNCH
     } else {
         const dim3 grid((P + GM_PIX - 1) / GM_PIX, B);
         if (raw) ground_mask_kernel<true><<<grid, 256, 0, st>>>(ri, tm, ground, thr, P, temp, info);
@@ -1081,7 +1129,7 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_range_kernel(const float *__r
     cen_pix += (int64_t)b * M;
     centers += (int64_t)b * M * 3;
     const int tid = threadIdx.x;
-    int old = info[4 * b + 1];
+    int old = info[RPCC_INFO * b + 1];
     if (old >= P) old = 0;  // no candidate at all: the reference would fail; keep indices defined
     const int P4 = P & ~3;
     for (int j = 0; j < M; j++) {
@@ -1140,81 +1188,78 @@ __global__ __launch_bounds__(256) void rays_soa_kernel(const float *__restrict__
                                                        ZeroRange z2 = {nullptr, 0}) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p < P) { soa[p] = tm[3 * p]; soa[P + p] = tm[3 * p + 1]; soa[2 * (int64_t)P + p] = tm[3 * p + 2]; }
-    if (info != nullptr && p < B) { info[4 * p] = 0; info[4 * p + 1] = P; info[4 * p + 2] = 0; info[4 * p + 3] = 0; }
+    if (info != nullptr && p < B) {
+        info[RPCC_INFO * p] = 0; info[RPCC_INFO * p + 1] = P; info[RPCC_INFO * p + 2] = 0; info[RPCC_INFO * p + 3] = 0;
+        info[RPCC_INFO * p + 4] = P; info[RPCC_INFO * p + 5] = 0; info[RPCC_INFO * p + 6] = 0; info[RPCC_INFO * p + 7] = 0;
+    }
     if (p < z0.n) z0.p[p] = 0u;
     if (p < z1.n) z1.p[p] = 0u;
     if (p < z2.n) z2.p[p] = 0u;
 }
 
-static bool g_fps_force_v1 = false;
-extern "C" void rpcc_fps_force_bruteforce(int on) { g_fps_force_v1 = on != 0; }
-
-extern "C" int rpcc_fps_xyz(int B, int N, int M, const float *points, float *temp, int32_t *idx, void *stream) {
-    ARG_TRY(B > 0 && B <= RPCC_MAX_BATCH && N > 0 && M >= 0 && points && temp && idx);
-    if (M == 0) return RPCC_OK;
-    hipStream_t st = (hipStream_t)stream;
-    FpsTimer tmr(st);
-    const FpsTiling g = fps_tiling_list(N);
-    if (!g_fps_force_v1 && g.T <= FPS_TILED_MAX_TILES && N < (1 << 30) / 3) {
-        const size_t sh = fps_tiled_lds_bytes(g.T);
-        if (B <= 128) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_tiled_kernel<false, FPS_TT_SMALL>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-            fps_tiled_kernel<false, FPS_TT_SMALL><<<B, FPS_TT_SMALL, sh, st>>>(points, nullptr, nullptr, nullptr, temp, nullptr, g,
-                                                                            M, idx, nullptr, nullptr);
-        } else {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_tiled_kernel<false, FPS_TT_BATCH>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-            fps_tiled_kernel<false, FPS_TT_BATCH><<<B, FPS_TT_BATCH, sh, st>>>(points, nullptr, nullptr, nullptr, temp, nullptr, g,
-                                                                            M, idx, nullptr, nullptr);
-        }
-    } else {
-        fps_xyz_kernel<<<B, FPS_THREADS, 0, st>>>(N, M, points, temp, idx);
-    }
+template <bool RANGE>
+static int launch_fps_tiled(const float *src, const float *rays, float *temp, const int32_t *info, int B, const FpsTiling &g,
+                            int M, int kflags, int32_t *idx, float *cen, const float *tiletab, bool vec, hipStream_t st) {
+    const size_t sh = fps_tiled_lds_bytes(g.T);
+#define FPS_LAUNCH(VEC_, TT_)                                                                                        \
+    do {                                                                                                             \
+        HIP_TRY(ensure_dyn_lds(reinterpret_cast<const void *>(&fps_tiled_kernel<RANGE, VEC_, TT_>), (int)sh));       \
+        fps_tiled_kernel<RANGE, VEC_, TT_><<<B, TT_, sh, st>>>(src, rays, temp, info, g, M, kflags, idx, cen, tiletab); \
+    } while (0)
+    if (B <= 128) { if (vec) FPS_LAUNCH(true, FPS_TT_SMALL); else FPS_LAUNCH(false, FPS_TT_SMALL); }
+    else          { if (vec) FPS_LAUNCH(true, FPS_TT_BATCH); else FPS_LAUNCH(false, FPS_TT_BATCH); }
+#undef FPS_LAUNCH
     LAUNCH_CHECK();
     return RPCC_OK;
 }
 
-// rays_soa: dev f32 [3,P] scratch (may be NULL -> brute-force kernel on the AoS table)
+static int fps_xyz_impl(int B, int N, int M, const float *points, float *temp, int32_t *idx, bool brute, hipStream_t st) {
+    ARG_TRY(B > 0 && B <= RPCC_MAX_BATCH && N > 0 && M >= 0 && points && temp && idx);
+    if (M == 0) return RPCC_OK;
+    const FpsTiling g = fps_tiling_list(N);
+    if (!brute && g.T <= FPS_TILED_MAX_TILES && N < (1 << 30) / 3) {
+        const bool vec = (N % 4 == 0) && aligned16(points) && aligned16(temp);
+        return launch_fps_tiled<false>(points, nullptr, temp, nullptr, B, g, M, 0, idx, nullptr, nullptr, vec, st);
+    }
+    fps_xyz_kernel<<<B, FPS_THREADS, 0, st>>>(N, M, points, temp, idx);
+    LAUNCH_CHECK();
+    return RPCC_OK;
+}
+extern "C" int rpcc_fps_xyz(int B, int N, int M, const float *points, float *temp, int32_t *idx, void *stream) {
+    return fps_xyz_impl(B, N, M, points, temp, idx, false, (hipStream_t)stream);
+}
+extern "C" int rpcc_fps_xyz_bruteforce(int B, int N, int M, const float *points, float *temp, int32_t *idx, void *stream) {
+    return fps_xyz_impl(B, N, M, points, temp, idx, true, (hipStream_t)stream);
+}
+
+// flags: RPCC_FPS_BRUTEFORCE -> the one-pass-per-centre kernel; finalize_temp: temp is read by the caller afterwards
 static int launch_fps_range(const float *ri, const float *tm, float *temp, const int32_t *info, int B, int H, int W, int M,
-                            int32_t *cen_pix, float *centers, float *rays_soa, const float *tiletab, hipStream_t st,
-                            bool rays_ready = false) {
+                            int32_t *cen_pix, float *centers, int flags, bool finalize_temp, const float *tiletab,
+                            void *timer, hipStream_t st) {
     const int P = H * W;
     const FpsTiling g = fps_tiling_range(H, W);
-    if (!g_fps_force_v1 && rays_soa != nullptr && g.T <= FPS_TILED_MAX_TILES) {
-        if (!rays_ready) rays_soa_kernel<<<(P + 255) / 256, 256, 0, st>>>(tm, P, rays_soa);
-        const size_t sh = fps_tiled_lds_bytes(g.T);
-        FpsTimer tmr(st);
-        if (B <= 128) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_tiled_kernel<true, FPS_TT_SMALL>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-            fps_tiled_kernel<true, FPS_TT_SMALL><<<B, FPS_TT_SMALL, sh, st>>>(ri, rays_soa, rays_soa + P, rays_soa + 2 * (int64_t)P,
-                                                                           temp, info, g, M, cen_pix, centers, tiletab);
-        } else {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_tiled_kernel<true, FPS_TT_BATCH>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-            fps_tiled_kernel<true, FPS_TT_BATCH><<<B, FPS_TT_BATCH, sh, st>>>(ri, rays_soa, rays_soa + P, rays_soa + 2 * (int64_t)P,
-                                                                           temp, info, g, M, cen_pix, centers, tiletab);
-        }
-        LAUNCH_CHECK();
-        return RPCC_OK;
+    const bool brute = (flags & RPCC_FPS_BRUTEFORCE) != 0;
+    if (!brute && g.T <= FPS_TILED_MAX_TILES && P < (1 << 22)) {
+        const bool vec = (W % 4 == 0) && aligned16(ri) && aligned16(temp) && aligned16(tm);
+        FpsTimer tmr(st, timer);
+        return launch_fps_tiled<true>(ri, tm, temp, info, B, g, M, finalize_temp ? FPS_FLAG_FINALIZE_TEMP : 0, cen_pix, centers,
+                                      tiletab, vec, st);
     }
-    if (tiletab != nullptr && !g_fps_force_v1)
+    if (tiletab != nullptr && !brute)
         return set_err(RPCC_ERR_ARG, "fps_range: an FPS table was produced but the tiled kernel cannot run (image too large)%s%s");
-    if (P % 4 != 0 || ((uintptr_t)ri % 16) || ((uintptr_t)temp % 16) || ((uintptr_t)tm % 16))
+    if (P % 4 != 0 || !aligned16(ri) || !aligned16(temp) || !aligned16(tm))
         return set_err(RPCC_ERR_ARG, "fps_range brute-force path needs 16-byte aligned buffers and P %% 4 == 0%s%s");
-    FpsTimer tmr(st);
+    FpsTimer tmr(st, timer);
     fps_range_kernel<<<B, FPS_THREADS, 0, st>>>(ri, tm, temp, info, P, M, cen_pix, centers);
     LAUNCH_CHECK();
     return RPCC_OK;
 }
 
 extern "C" int rpcc_fps_range(const float *ri, const float *tm, float *temp, const int32_t *info, int B, int H, int W,
-                              int M, int32_t *cen_pix, float *centers, void *ws, const void *fps_table, void *stream) {
+                              int M, int32_t *cen_pix, float *centers, int flags, const void *fps_table, void *stream) {
     ARG_TRY(B > 0 && B <= RPCC_MAX_BATCH && H > 0 && W > 0 && M > 0 && ri && tm && temp && info && cen_pix && centers);
-    ARG_TRY(fps_table == nullptr || ws != nullptr);  // the table is only consumed by the tiled kernel
-    return launch_fps_range(ri, tm, temp, info, B, H, W, M, cen_pix, centers, reinterpret_cast<float *>(ws),
-                            reinterpret_cast<const float *>(fps_table), (hipStream_t)stream);
+    return launch_fps_range(ri, tm, temp, info, B, H, W, M, cen_pix, centers, flags, true,
+                            reinterpret_cast<const float *>(fps_table), nullptr, (hipStream_t)stream);
 }
 
 // ================================================================================================
@@ -1452,7 +1497,10 @@ static WsLayout ws_layout(void *ws, int B, int P, int M) {
     L.bytes = off;
     return L;
 }
-// Workspace of one (sub-)batch: [ model part | projection scratch | FPS temp | planar rays | FPS tile table ]
+// Workspace of one batch: [ model part | projection scratch | FPS temp | planar rays | FPS tile table ]
+static size_t plane_extra_bytes(int B, int P, int M) {   // label-ordered pixel list u32 [B,P] | points float4 [B,P] | label steps f32 [B,K]
+    return (((size_t)B * P * 4 + 255) & ~(size_t)255) + (size_t)B * P * 16 + (((size_t)B * (M + 2) * 4 + 255) & ~(size_t)255) + 256;
+}
 static size_t slice_workspace_bytes(int B, int P, int M, int64_t total_points) {
     const size_t model_ws = ws_layout(nullptr, B, P, M).bytes;
     const size_t proj_ws = (project_scratch_bytes(total_points, B, P) + 255) & ~(size_t)255;
@@ -1460,12 +1508,13 @@ static size_t slice_workspace_bytes(int B, int P, int M, int64_t total_points) {
            + (size_t)3 * P * 4 + 256                            // + SoA copy of the ray table
            + (size_t)B * FPS_TAB_ROWS * ((P + 31) / 32 + 4096) * 4 + 256;  // + FPS tile table (generous bound)
 }
-#define RPCC_MAX_SLICES 8
 extern "C" size_t rpcc_workspace_bytes(int B, int P, int M, int64_t total_points) {
     if (B <= 0 || P <= 0 || M <= 0) return 0;
-    // the batch may be processed as up to RPCC_MAX_SLICES sub-batches on internal streams: every term is
-    // affine in (B, total_points), so one extra constant part per slice bounds the sum of the slices
-    return slice_workspace_bytes(B, P, M, total_points) + (size_t)RPCC_MAX_SLICES * (slice_workspace_bytes(1, P, M, 0) + 4096);
+    return slice_workspace_bytes(B, P, M, total_points) + 4096;
+}
+extern "C" size_t rpcc_workspace_bytes_general(int B, int P, int M, int64_t total_points) {
+    if (B <= 0 || P <= 0 || M <= 0) return 0;
+    return slice_workspace_bytes(B, P, M, total_points) + 4096 + plane_extra_bytes(B, P, M);
 }
 
 __global__ __launch_bounds__(256) void model_hist_kernel(const float *__restrict__ ri, const uint8_t *__restrict__ seg,
@@ -1626,8 +1675,7 @@ static int launch_point_model(const float *ri, const uint8_t *seg, const double 
     if (!cleared) HIP_TRY(hipMemsetAsync(L.sums, 0, (size_t)((char *)L.hist - (char *)L.sums), st));
     model_hist_kernel<<<dim3(T, B), 256, (size_t)KP * 12, st>>>(ri, seg, P, KP, T, L.sums, L.flags, L.hist);
     LAUNCH_CHECK();
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&model_scan_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    HIP_TRY(ensure_dyn_lds(reinterpret_cast<const void *>(&model_scan_kernel), 96 * 1024));
     model_scan_kernel<<<B, 256, scan_lds_bytes(P, M), st>>>(ri, seg, ground, P, M, KP, T, L.sums, L.flags, L.hist, model, counts, nnz);
     LAUNCH_CHECK();
     return RPCC_OK;
@@ -1791,8 +1839,7 @@ extern "C" int rpcc_predict_quantize(const float *ri, const float *tm, const uin
     HIP_TRY(hipMemsetAsync(L.sums, 0, (size_t)((char *)L.hist - (char *)L.sums), st));
     model_hist_kernel<<<dim3(T, B), 256, (size_t)KP * 12, st>>>(ri, seg, P, KP, T, L.sums, L.flags, L.hist);
     LAUNCH_CHECK();
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&model_scan_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    HIP_TRY(ensure_dyn_lds(reinterpret_cast<const void *>(&model_scan_kernel), 96 * 1024));
     model_scan_kernel<<<B, 256, scan_lds_bytes(P, M), st>>>(ri, seg, nullptr, P, M, KP, T, L.sums, L.flags, L.hist, nullptr, nullptr, nnz);
     LAUNCH_CHECK();
     return launch_predict_quantize(ri, tm, seg, model, acc, label_acc, residual_in, B, P, M, q16, q32, pred, ws, st);
@@ -1844,8 +1891,7 @@ extern "C" int rpcc_decode(const uint8_t *seg, const int16_t *q16, const float *
     WsLayout L = ws_layout(ws, B, P, M);
     HIP_TRY(hipMemsetAsync(L.sums, 0, (size_t)((char *)L.hist - (char *)L.sums), st));
     model_hist_kernel<<<dim3(T, B), 256, (size_t)KP * 12, st>>>(nullptr, seg, P, KP, T, L.sums, L.flags, L.hist);
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&model_scan_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    HIP_TRY(ensure_dyn_lds(reinterpret_cast<const void *>(&model_scan_kernel), 96 * 1024));
     model_scan_kernel<<<B, 256, scan_lds_bytes(P, M), st>>>(nullptr, seg, nullptr, P, M, KP, T, L.sums, L.flags, L.hist,
                                                             nullptr, nullptr, nullptr);
     DecodeSteps steps;
@@ -1878,12 +1924,11 @@ extern "C" int rpcc_backproject(const float *ri, const float *tm, int B, int P, 
 // ================================================================================================
 #include "feature_kernels.h"
 
-extern "C" int rpcc_extract_features(const float *ri, const uint8_t *seg, int B, int H, int W, int feature_region,
-                                     int segments, int sharp_num, int less_sharp_num, int flat_num, float *feat,
-                                     uint8_t *key_point_map, void *stream) {
-    ARG_TRY(B > 0 && B <= RPCC_MAX_BATCH && H > 0 && W > 0 && ri && seg && feat && key_point_map);
+// feat may be NULL (the fused entry only needs the key-point map)
+static int launch_features(const float *ri, const uint8_t *seg, int B, int H, int W, int feature_region, int segments,
+                           int sharp_num, int less_sharp_num, int flat_num, float *feat, uint8_t *key_point_map,
+                           hipStream_t st) {
     ARG_TRY(feature_region >= 1 && feature_region <= 16 && segments >= 1 && W < 65536);
-    hipStream_t st = (hipStream_t)stream;
     const size_t sh = (size_t)3 * W * 4 + (size_t)W * 2 + (size_t)W * 2 + 16;
     ARG_TRY(sh <= 160 * 1024);
     ARG_TRY(W <= 64 * FEAT_GPW * (FEAT_THREADS / 64));                        // and so does a wavefront's part of the row
@@ -1891,8 +1936,7 @@ extern "C" int rpcc_extract_features(const float *ri, const uint8_t *seg, int B,
     const int need = ((W - 2 * feature_region) / segments + 63) / 64;  // keys per lane
 #define FEAT_LAUNCH(Q_)                                                                                          \
     do {                                                                                                         \
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&features_kernel<Q_>),                        \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));                       \
+        HIP_TRY(ensure_dyn_lds(reinterpret_cast<const void *>(&features_kernel<Q_>), (int)sh));                       \
         features_kernel<Q_><<<dim3(H, B), FEAT_THREADS, sh, st>>>(ri, seg, H, W, fp, feat, key_point_map);                 \
     } while (0)
     if (need <= 2) FEAT_LAUNCH(2);
@@ -1903,6 +1947,13 @@ extern "C" int rpcc_extract_features(const float *ri, const uint8_t *seg, int B,
 #undef FEAT_LAUNCH
     LAUNCH_CHECK();
     return RPCC_OK;
+}
+extern "C" int rpcc_extract_features(const float *ri, const uint8_t *seg, int B, int H, int W, int feature_region,
+                                     int segments, int sharp_num, int less_sharp_num, int flat_num, float *feat,
+                                     uint8_t *key_point_map, void *stream) {
+    ARG_TRY(B > 0 && B <= RPCC_MAX_BATCH && H > 0 && W > 0 && ri && seg && feat && key_point_map);
+    return launch_features(ri, seg, B, H, W, feature_region, segments, sharp_num, less_sharp_num, flat_num, feat,
+                           key_point_map, (hipStream_t)stream);
 }
 
 extern "C" int rpcc_salience(const uint8_t *seg, const uint8_t *key_point_map, const int32_t *level_kp_num,
@@ -1938,64 +1989,66 @@ extern "C" size_t rpcc_plane_workspace_bytes(int B, int P, int M) {
     return ws_layout(nullptr, B, P, M).bytes + 256 + (((size_t)B * P * 4 + 255) & ~(size_t)255) + (size_t)B * P * 16;
 }
 
-extern "C" int rpcc_plane_model(const float *ri, const float *tm, const uint8_t *seg, const double *ground, int B, int P,
-                                int M, double cos_cut, uint32_t seed, float *model, int32_t *counts, void *ws,
-                                void *stream) {
-    ARG_TRY(B > 0 && B <= RPCC_MAX_BATCH && P > 0 && M > 0 && M <= RPCC_MAX_CLUSTERS && ri && tm && seg && model && counts && ws);
-    hipStream_t st = (hipStream_t)stream;
+// hist / scan for a segmentation without the point sums: tile offsets (ordered scatter), counts, nnz
+static int launch_label_scan(const uint8_t *seg, int B, int P, int M, int32_t *counts, int32_t *nnz, void *ws, hipStream_t st,
+                             bool cleared) {
+    const int KP = kpad(M), T = ntiles(P);
+    WsLayout L = ws_layout(ws, B, P, M);
+    if (!cleared) HIP_TRY(hipMemsetAsync(L.sums, 0, (size_t)((char *)L.hist - (char *)L.sums), st));
+    model_hist_kernel<<<dim3(T, B), 256, (size_t)KP * 12, st>>>(nullptr, seg, P, KP, T, L.sums, L.flags, L.hist);
+    HIP_TRY(ensure_dyn_lds(reinterpret_cast<const void *>(&model_scan_kernel), 96 * 1024));
+    model_scan_kernel<<<B, 256, scan_lds_bytes(P, M), st>>>(nullptr, seg, nullptr, P, M, KP, T, L.sums, L.flags, L.hist,
+                                                            nullptr, counts, nnz);
+    LAUNCH_CHECK();
+    return RPCC_OK;
+}
+// plane rows from a segmentation whose tile offsets (launch_label_scan) are in ws; extra = order | pts4 scratch
+static int launch_plane_rows(const float *ri, const float *tm, const uint8_t *seg, const double *ground, int B, int P, int M,
+                             double cos_cut, uint32_t seed, const int64_t *frame_ids, float *model, const int32_t *counts,
+                             void *ws, void *extra, hipStream_t st) {
     const int KP = kpad(M), T = ntiles(P), K = M + 2;
     WsLayout L = ws_layout(ws, B, P, M);
-    uint32_t *order = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(ws) + L.bytes + 256);
-    HIP_TRY(hipMemsetAsync(L.sums, 0, (size_t)((char *)L.hist - (char *)L.sums), st));
-    model_hist_kernel<<<dim3(T, B), 256, (size_t)KP * 12, st>>>(nullptr, seg, P, KP, T, L.sums, L.flags, L.hist);
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&model_scan_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-    model_scan_kernel<<<B, 256, scan_lds_bytes(P, M), st>>>(nullptr, seg, nullptr, P, M, KP, T, L.sums, L.flags, L.hist,
-                                                            nullptr, counts, nullptr);
+    uint32_t *order = reinterpret_cast<uint32_t *>(extra);
     float4 *pts4 = reinterpret_cast<float4 *>(reinterpret_cast<char *>(order) + (((size_t)B * P * 4 + 255) & ~(size_t)255));
     label_order_kernel<<<dim3(T, B), 256, (size_t)16 * (KP + 1) * 4 + (size_t)KP * 4, st>>>(seg, L.hist, P, M, KP, T, order, ri, tm, pts4);
     PlaneParams pp;
-    pp.cos_cut = cos_cut; pp.thr = 0.1f; pp.min_points = 30; pp.iters = 10; pp.seed = seed;
+    pp.cos_cut = cos_cut; pp.thr = 0.1f; pp.min_points = 30; pp.iters = 10; pp.seed = seed; pp.frame_ids = frame_ids;
     plane_model_kernel<10><<<dim3((K + PL_THREADS / 64 - 1) / (PL_THREADS / 64), B), PL_THREADS, 0, st>>>(tm, order, pts4, L.hist, counts, ground, P, M,
                                                                                                      KP, T, pp, PL_BIG, model);
     LAUNCH_CHECK();
     return RPCC_OK;
 }
 
+extern "C" int rpcc_plane_model(const float *ri, const float *tm, const uint8_t *seg, const double *ground, int B, int P,
+                                int M, double cos_cut, uint32_t seed, const int64_t *frame_ids, float *model,
+                                int32_t *counts, void *ws, void *stream) {
+    ARG_TRY(B > 0 && B <= RPCC_MAX_BATCH && P > 0 && M > 0 && M <= RPCC_MAX_CLUSTERS && ri && tm && seg && model && counts && ws);
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if ((rc = launch_label_scan(seg, B, P, M, counts, nullptr, ws, st, false))) return rc;
+    return launch_plane_rows(ri, tm, seg, ground, B, P, M, cos_cut, seed, frame_ids, model, counts, ws,
+                             reinterpret_cast<char *>(ws) + ws_layout(nullptr, B, P, M).bytes + 256, st);
+}
+
 // ================================================================================================
 // fused batch entry (uniform framework, FPS segmentation, point model): a2 .. a11
 // ================================================================================================
-// ---- sub-batch streams --------------------------------------------------------------------------------
-// Several kernels of the path are latency-bound with one workgroup per frame (FPS, ground RANSAC) while
-// others are throughput-bound; running the batch as a few independent sub-batches on internal HIP streams
-// lets the two kinds overlap.  Needs the frame offsets on the host (rpcc_batch_io.offsets_host).
-static int g_slices = 1;
-static hipStream_t g_sl_stream[RPCC_MAX_SLICES];
-static hipEvent_t g_sl_start, g_sl_done[RPCC_MAX_SLICES], g_sl_pre[RPCC_MAX_SLICES];
-static bool g_sl_ready = false;
-extern "C" void rpcc_set_batch_slices(int n) { g_slices = n < 1 ? 1 : (n > RPCC_MAX_SLICES ? RPCC_MAX_SLICES : n); }
-
-// pre_done (optional): recorded after the throughput-bound head of the chain (projection, ground fit, mask),
-// i.e. right before the latency-bound FPS; the next sub-batch starts there, so its head overlaps this FPS.
-static int run_slice(const rpcc_batch_io *io, int b0, int Bs, int64_t pt0, int64_t npts, rpcc_geom g, int M,
-                     double ground_threshold, float acc, char *ws, hipStream_t st, hipEvent_t pre_done = nullptr) {
-    const int P = g.H * g.W, K = M + 2;
-    const bool fit_ground = io->ground_seed >= 0;  // >= 0: fit the ground plane here (seed + frame index)
+static int run_batch(const rpcc_batch_io *io, int Bs, int64_t npts, rpcc_geom g, int M, double ground_threshold, float acc,
+                     char *ws, hipStream_t st) {
+    const int P = g.H * g.W;
+    const bool fit_ground = io->ground_seed >= 0;  // >= 0: fit the ground plane here (seed + frame identity)
     WsLayout L = ws_layout(ws, Bs, P, M);
     char *proj_scratch = ws + L.bytes + 256;
     const size_t proj_bytes = (project_scratch_bytes(npts, Bs, P) + 255) & ~(size_t)255;
     float *temp = reinterpret_cast<float *>(proj_scratch + proj_bytes);
     float *rays_soa = temp + (size_t)Bs * P;
     float *tiletab = rays_soa + (size_t)3 * P + 64;
-    float *ri = io->ri + (size_t)b0 * P;
-    double *ground = io->ground + (size_t)b0 * 4;
-    int32_t *info = io->info + (size_t)b0 * 4;
-    float *centers = io->centers + (size_t)b0 * M * 3;
-    uint8_t *seg = io->seg + (size_t)b0 * P;
-    float *model = io->model + (size_t)b0 * K * 4;
+    float *ri = io->ri;
+    double *ground = io->ground;
+    int32_t *info = io->info;
     int rc;
     int32_t *zcnt = fit_ground ? reinterpret_cast<int32_t *>(tiletab) : nullptr;  // the tile table is written later
-    // first kernel of the batch: planar ray table (band kernel's z, FPS), the info counters of the ground mask, and the
+    // first kernel of the batch: planar ray table (band kernel's z), the info counters of the ground mask, and the
     // cleared projection flags / RANSAC candidate counts / label sums
     const ZeroRange zflags = {reinterpret_cast<uint32_t *>(proj_scratch) + (size_t)Bs * P, Bs + 1};
     const ZeroRange zzcnt = {reinterpret_cast<uint32_t *>(zcnt), zcnt ? Bs * (RS_CHUNKS + 1) : 0};
@@ -2003,24 +2056,46 @@ static int run_slice(const rpcc_batch_io *io, int b0, int Bs, int64_t pt0, int64
     const int init_n = std::max(std::max(P, Bs * (RS_CHUNKS + 1)), zsums.n);
     rays_soa_kernel<<<(init_n + 255) / 256, 256, 0, st>>>(io->tm, P, rays_soa, info, Bs, zflags, zzcnt, zsums);
     LAUNCH_CHECK();
-    if ((rc = launch_project(io->xyz, io->offsets + b0, npts, pt0, Bs, g, ri, proj_scratch, proj_bytes, st,
+    if ((rc = launch_project(io->xyz, io->offsets, npts, 0, Bs, g, ri, proj_scratch, proj_bytes, st,
                              rays_soa + 2 * (int64_t)P, zcnt, true)))
         return rc;
     if (fit_ground &&
-        (rc = launch_ground_ransac(ri, io->tm, Bs, P, (uint32_t)(io->ground_seed + b0), false, ground, nullptr, st, zcnt)))
+        (rc = launch_ground_ransac(ri, io->tm, Bs, P, (uint32_t)io->ground_seed, false, ground, nullptr, st, zcnt, io->frame_ids)))
         return rc;
-    const bool tiled = !g_fps_force_v1 && fps_tiling_range(g.H, g.W).T <= FPS_TILED_MAX_TILES;
+    const bool brute = (io->flags & RPCC_FPS_BRUTEFORCE) != 0;
+    const bool tiled = !brute && fps_tiling_range(g.H, g.W).T <= FPS_TILED_MAX_TILES;
     if ((rc = launch_ground_mask(ri, io->tm, ground, ground_threshold, Bs, g.H, g.W, temp, info,
                                  tiled ? tiletab : nullptr, st, false, true)))
         return rc;
-    if (pre_done) HIP_TRY(hipEventRecord(pre_done, st));
-    if ((rc = launch_fps_range(ri, io->tm, temp, info, Bs, g.H, g.W, M, io->cen_pix + (size_t)b0 * M, centers, rays_soa,
-                               tiled ? tiletab : nullptr, st, true)))
+    if ((rc = launch_fps_range(ri, io->tm, temp, info, Bs, g.H, g.W, M, io->cen_pix, io->centers, io->flags, false,
+                               tiled ? tiletab : nullptr, io->timer, st)))
         return rc;
-    if ((rc = launch_assign(ri, io->tm, ground, centers, Bs, g.H, g.W, M, seg, st))) return rc;
-    if ((rc = launch_point_model(ri, seg, ground, Bs, P, M, model, io->counts + (size_t)b0 * K, io->nnz + b0, ws, st, true)))
-        return rc;
-    return launch_predict_quantize(ri, io->tm, seg, model, acc, nullptr, nullptr, Bs, P, M, io->q16 + (size_t)b0 * P,
+    if ((rc = launch_assign(ri, io->tm, ground, io->centers, Bs, g.H, g.W, M, io->seg, st))) return rc;
+    // model rows + the tile offsets of the ordered scatter (built once, used by the plane list and by the quantiser)
+    char *extra = reinterpret_cast<char *>(tiletab) + (((size_t)Bs * FPS_TAB_ROWS * ((P + 31) / 32 + 4096) * 4 + 255) & ~(size_t)255) + 256;
+    if (io->model_method == 0) {
+        if ((rc = launch_point_model(ri, io->seg, ground, Bs, P, M, io->model, io->counts, io->nnz, ws, st, true))) return rc;
+    } else {
+        if ((rc = launch_label_scan(io->seg, Bs, P, M, io->counts, io->nnz, ws, st, true))) return rc;
+        if ((rc = launch_plane_rows(ri, io->tm, io->seg, ground, Bs, P, M, io->plane_cos_cut, (uint32_t)io->plane_seed,
+                                    io->frame_ids, io->model, io->counts, ws, extra, st)))
+            return rc;
+    }
+    float *label_acc = nullptr;
+    if (io->nonuniform) {   // key points -> salience level and quantisation step per label
+        const rpcc_nonuniform_cfg *nu = io->nonuniform;
+        label_acc = reinterpret_cast<float *>(extra + plane_extra_bytes(Bs, P, M) - 256 - (((size_t)Bs * (M + 2) * 4 + 255) & ~(size_t)255));
+        if ((rc = launch_features(ri, io->seg, Bs, g.H, g.W, nu->feature_region, nu->segments, nu->sharp_num, nu->less_sharp_num,
+                                  nu->flat_num, nullptr, io->key_point_map, st)))
+            return rc;
+        SalienceParams sp;
+        for (int i = 0; i < 8; i++) { sp.level_kp_num[i] = i < nu->levels ? nu->level_kp_num[i] : 0; sp.level_acc[i] = i < nu->levels ? nu->level_acc[i] : 0.f; }
+        sp.levels = nu->levels;
+        sp.ground_level = nu->ground_level;
+        salience_kernel<<<Bs, SAL_THREADS, 0, st>>>(io->seg, io->key_point_map, P, M, sp, io->salience, label_acc);
+        LAUNCH_CHECK();
+    }
+    return launch_predict_quantize(ri, io->tm, io->seg, io->model, acc, label_acc, nullptr, Bs, P, M, io->q16,
                                    nullptr, nullptr, ws, st);
 }
 
@@ -2031,32 +2106,11 @@ extern "C" int rpcc_compress_batch(const rpcc_batch_io *io, int B, rpcc_geom g, 
             io->counts && io->q16 && io->nnz && io->info);
     const int P = g.H * g.W;
     // only the brute-force FPS kernel (16-byte loads at frame bases) needs P % 4 == 0; the tile-pruned one does not
-    ARG_TRY(P % 4 == 0 || (!g_fps_force_v1 && fps_tiling_range(g.H, g.W).T <= FPS_TILED_MAX_TILES));
-    hipStream_t st = (hipStream_t)stream;
-    int S = (io->offsets_host != nullptr) ? g_slices : 1;
-    if (S > B) S = B;
-    if (S <= 1) return run_slice(io, 0, B, 0, io->total, g, M, ground_threshold, acc, reinterpret_cast<char *>(ws), st);
-    if (!g_sl_ready) {
-        for (int i = 0; i < RPCC_MAX_SLICES; i++) {
-            HIP_TRY(hipStreamCreateWithFlags(&g_sl_stream[i], hipStreamNonBlocking));
-            HIP_TRY(hipEventCreateWithFlags(&g_sl_done[i], hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&g_sl_pre[i], hipEventDisableTiming));
-        }
-        HIP_TRY(hipEventCreateWithFlags(&g_sl_start, hipEventDisableTiming));
-        g_sl_ready = true;
+    ARG_TRY(P % 4 == 0 || (!(io->flags & RPCC_FPS_BRUTEFORCE) && fps_tiling_range(g.H, g.W).T <= FPS_TILED_MAX_TILES));
+    ARG_TRY(io->model_method == 0 || io->model_method == 1);
+    if (io->nonuniform) {
+        const rpcc_nonuniform_cfg *nu = io->nonuniform;
+        ARG_TRY(io->salience && io->key_point_map && nu->levels >= 1 && nu->levels <= 8 && nu->ground_level >= 0 && nu->ground_level < nu->levels);
     }
-    HIP_TRY(hipEventRecord(g_sl_start, st));
-    char *wp = reinterpret_cast<char *>(ws);
-    int rc = RPCC_OK;
-    for (int s = 0; s < S; s++) {
-        const int b0 = (int)((int64_t)B * s / S), b1 = (int)((int64_t)B * (s + 1) / S);
-        const int64_t pt0 = io->offsets_host[b0], npts = io->offsets_host[b1] - pt0;
-        HIP_TRY(hipStreamWaitEvent(g_sl_stream[s], g_sl_start, 0));
-        const int r = run_slice(io, b0, b1 - b0, pt0, npts, g, M, ground_threshold, acc, wp, g_sl_stream[s]);
-        if (r && !rc) rc = r;
-        HIP_TRY(hipEventRecord(g_sl_done[s], g_sl_stream[s]));
-        HIP_TRY(hipStreamWaitEvent(st, g_sl_done[s], 0));
-        wp += (slice_workspace_bytes(b1 - b0, P, M, npts) + 4095) & ~(size_t)4095;
-    }
-    return rc;
+    return run_batch(io, B, io->total, g, M, ground_threshold, acc, reinterpret_cast<char *>(ws), (hipStream_t)stream);
 }

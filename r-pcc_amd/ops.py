@@ -68,24 +68,39 @@ def project_fastpath_check(xyz, geom):
     return c[0], c[1], c[2], c[3] * 1e-9, c[4] * 1e-9
 
 
-def ground_ransac(ri, tm, seed=0):
-    """a4: seeded ground-plane RANSAC -> (ground f64 [B,4], inlier counts i32 [B])."""
+def _frame_ids(frame_ids, B, device):
+    """Stable per-frame identities (datalist indices) as a device i64 [B] tensor, or None."""
+    if frame_ids is None:
+        return None
+    if not torch.is_tensor(frame_ids):
+        frame_ids = torch.as_tensor(np.asarray(frame_ids, dtype=np.int64))
+    frame_ids = frame_ids.to(device=device, dtype=torch.int64).contiguous()
+    assert frame_ids.numel() == B, "one identity per frame"
+    return frame_ids
+
+
+def ground_ransac(ri, tm, seed=0, frame_ids=None):
+    """a4: seeded ground-plane RANSAC -> (ground f64 [B,4], inlier counts i32 [B]).  Frame b draws with
+    seed + frame_ids[b] (its datalist index; default: its position b in the batch)."""
     B = ri.shape[0]
     P = ri[0].numel()
     ground = torch.empty((B, 4), dtype=torch.float64, device=_dev(ri))
     inl = torch.empty((B,), dtype=torch.int32, device=_dev(ri))
-    check(_lib.lib().rpcc_ground_ransac(ptr(ri), ptr(tm), B, P, int(seed), ptr(ground), ptr(inl), stream()))
+    fid = _frame_ids(frame_ids, B, _dev(ri))
+    check(_lib.lib().rpcc_ground_ransac(ptr(ri), ptr(tm), B, P, int(seed) & 0xFFFFFFFF, ptr(fid), ptr(ground), ptr(inl),
+                                        stream()))
     return ground, inl
 
 
 def ground_mask(ri, tm, ground, threshold, fps_table=False):
-    """a3+a5.  -> (temp f32 [B,P], info i32 [B,4] = n_left, first candidate pixel, nnz, table flag).
+    """a3+a5.  -> (temp f32 [B,P], info i32 [B,8] = n_left, first candidate pixel, nnz, table flag, first empty
+    candidate pixel, 3 spare).
     fps_table=True: the kernel also runs the first FPS pass and returns the tile table as third value
     (hand it to fps_range); results are identical either way."""
     B, H, W = ri.shape
     P = H * W
     temp = torch.empty((B, P), dtype=torch.float32, device=_dev(ri))
-    info = torch.empty((B, 4), dtype=torch.int32, device=_dev(ri))
+    info = torch.empty((B, _lib.INFO_INTS), dtype=torch.int32, device=_dev(ri))
     tab = None
     if fps_table:
         tab = torch.empty(_lib.lib().rpcc_fps_table_bytes(B, H, W) // 4, dtype=torch.float32, device=_dev(ri))
@@ -94,31 +109,26 @@ def ground_mask(ri, tm, ground, threshold, fps_table=False):
     return (temp, info, tab) if fps_table else (temp, info)
 
 
-def fps_xyz(points, npoint, temp=None):
+def fps_xyz(points, npoint, temp=None, bruteforce=False):
     """a6 on an explicit point list: furthest_point_sampling_wrapper(b,n,m,points,temp,idx)
-    (ops/fps/src/sampling.cpp:24-37).  points f32 [B,N,3] -> idx i32 [B,npoint]."""
+    (ops/fps/src/sampling.cpp:24-37).  points f32 [B,N,3] -> idx i32 [B,npoint].  bruteforce=True: the
+    one-pass-per-centre kernel (test reference of the tile-pruned one; identical results)."""
     B, N, _ = points.shape
     if temp is None:
         temp = torch.full((B, N), 1e10, dtype=torch.float32, device=_dev(points))
     idx = torch.empty((B, npoint), dtype=torch.int32, device=_dev(points))
-    check(_lib.lib().rpcc_fps_xyz(B, N, npoint, ptr(points), ptr(temp), ptr(idx), stream()))
+    fn = _lib.lib().rpcc_fps_xyz_bruteforce if bruteforce else _lib.lib().rpcc_fps_xyz
+    check(fn(B, N, npoint, ptr(points), ptr(temp), ptr(idx), stream()))
     return idx
 
 
-def fps_range(ri, tm, temp, info, M, fps_table=None, cen_pix=None, centers=None):
+def fps_range(ri, tm, temp, info, M, fps_table=None, cen_pix=None, centers=None, bruteforce=False):
     B, H, W = ri.shape
-    P = H * W
     cen_pix = torch.empty((B, M), dtype=torch.int32, device=_dev(ri)) if cen_pix is None else cen_pix
     centers = torch.empty((B, M, 3), dtype=torch.float32, device=_dev(ri)) if centers is None else centers
-    rays = torch.empty((3, P), dtype=torch.float32, device=_dev(ri))
     check(_lib.lib().rpcc_fps_range(ptr(ri), ptr(tm), ptr(temp), ptr(info), B, H, W, M, ptr(cen_pix), ptr(centers),
-                                    ptr(rays), ptr(fps_table), stream()))
+                                    _lib.FPS_BRUTEFORCE if bruteforce else 0, ptr(fps_table), stream()))
     return cen_pix, centers
-
-
-def fps_force_bruteforce(on):
-    """Test hook: route FPS calls to the brute-force kernels (identical results, one pass per centre)."""
-    _lib.lib().rpcc_fps_force_bruteforce(1 if on else 0)
 
 
 def assign(ri, tm, ground, centers, out=None):
@@ -129,8 +139,10 @@ def assign(ri, tm, ground, centers, out=None):
     return seg
 
 
-def workspace(B, P, M, device, total_points=0):
-    n = _lib.lib().rpcc_workspace_bytes(B, P, M, int(total_points))
+def workspace(B, P, M, device, total_points=0, general=False):
+    """Work buffer of the fused entry; general=True: large enough for the plane model / the non-uniform framework too."""
+    fn = _lib.lib().rpcc_workspace_bytes_general if general else _lib.lib().rpcc_workspace_bytes
+    n = fn(B, P, M, int(total_points))
     return torch.empty((n + 255) // 256 * 256, dtype=torch.uint8, device=device)
 
 
@@ -268,9 +280,10 @@ def pack_payload(q16, nnz, packed=None, capacity=None, total=None):
 
 
 class BatchBuffers:
-    """Device buffers of one batch (B frames, one geometry), allocated once and reused."""
+    """Device buffers of one batch (B frames, one geometry), allocated once and reused.  general=True adds what the
+    plane model / the non-uniform framework need (salience levels, key-point map, the larger work buffer)."""
 
-    def __init__(self, B, geom, M, device, max_points=None):
+    def __init__(self, B, geom, M, device, max_points=None, general=False):
         P = geom.H * geom.W
         K = M + 2
         self.B, self.P, self.M, self.K, self.geom = B, P, M, K, geom
@@ -283,31 +296,79 @@ class BatchBuffers:
         self.counts = torch.empty((B, K), dtype=i32, device=device)
         self.q16 = torch.empty((B, P), dtype=torch.int16, device=device)
         self.nnz = torch.empty((B,), dtype=i32, device=device)
-        self.info = torch.empty((B, 4), dtype=i32, device=device)
+        self.info = torch.empty((B, _lib.INFO_INTS), dtype=i32, device=device)
         # max_points: capacity (sum of N over the batch) for the projection's record list; default 2 per pixel
         self.max_points = int(max_points) if max_points is not None else 2 * B * P
-        self.ws = workspace(B, P, M, device, self.max_points)
+        self.general = bool(general)
+        self.ws = workspace(B, P, M, device, self.max_points, general=self.general)
+        self.salience = torch.zeros((B, K), dtype=torch.uint8, device=device) if general else None
+        self.key_point_map = torch.empty((B, geom.H, geom.W), dtype=torch.uint8, device=device) if general else None
 
 
-def set_batch_slices(n):
-    """Number of sub-batches (internal HIP streams) the fused entry splits a batch into (needs offsets_host)."""
-    _lib.lib().rpcc_set_batch_slices(int(n))
+class FpsTimer:
+    """rpcc_timer handle (bench.py): pass as compress_batch(timer=...) to time that call's FPS launch with HIP events."""
+
+    def __init__(self):
+        self.h = C.c_void_p(_lib.lib().rpcc_timer_create())
+        assert self.h.value, "rpcc_timer_create failed"
+
+    def read(self):
+        """-> (accumulated ms, launches) since the last read; synchronises the recorded events."""
+        ms, n = C.c_double(0), C.c_int(0)
+        check(_lib.lib().rpcc_timer_read(self.h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def __del__(self):
+        try:
+            _lib.lib().rpcc_timer_destroy(self.h)
+        except Exception:
+            pass
 
 
-def compress_batch(xyz, offsets, tm, ground, buf, ground_threshold=0.1, acc=0.04, ground_seed=-1, offsets_host=None):
-    """Fused a2..a11 for a batch (uniform + FPS + point model).  ground f64 [B,4]: injected models when
-    ground_seed < 0, otherwise output of the seeded ground RANSAC run inside the call."""
+def nonuniform_cfg(acc, cfg=None):
+    """QuantizationModule's non-uniform settings (utils/compress_utils.py:36-54) as the C struct: acc = base step
+    (2 * accuracy), cfg = compressor.yaml keys (level_key_point_num, level_delta_acc, ground_salience_level,
+    feature_region, segments, sharp_num, less_sharp_num, flat_num)."""
+    c = cfg or {}
+    lk = list(c.get("level_key_point_num", (30, 10, 3, 0)))
+    la = (np.array([acc] * len(lk)) + np.array(c.get("level_delta_acc", (0, 0.02, 0.04, 0.06)))).astype(np.float32)
+    assert 1 <= len(lk) <= 8
+    nu = _lib.NonuniformCfg()
+    nu.levels = len(lk)
+    for i, v in enumerate(lk):
+        nu.level_kp_num[i] = int(v)
+        nu.level_acc[i] = float(la[i])
+    nu.ground_level = int(c.get("ground_salience_level", 2))
+    nu.feature_region, nu.segments = int(c.get("feature_region", 3)), int(c.get("segments", 8))
+    nu.sharp_num, nu.less_sharp_num, nu.flat_num = int(c.get("sharp_num", 4)), int(c.get("less_sharp_num", 8)), int(c.get("flat_num", 6))
+    return nu
+
+
+def compress_batch(xyz, offsets, tm, ground, buf, ground_threshold=0.1, acc=0.04, ground_seed=-1, frame_ids=None,
+                   fps_bruteforce=False, timer=None, model_method="point", angle_threshold=75, plane_seed=0, nonuniform=None):
+    """Fused a2..a13 for a batch, one call: FPS segmentation, point or plane model, uniform or non-uniform framework
+    (tools/compress.py:93-125).  ground f64 [B,4]: injected models when ground_seed < 0, otherwise output of the seeded
+    ground RANSAC run inside the call (frame b draws with ground_seed + frame_ids[b]; frame_ids: stable identities,
+    e.g. utils.frame_identity(path); default the batch position).  model_method "plane": rpcc_plane_model's seeded fits
+    (plane_seed, frame_ids) with the reference's angle validation.  nonuniform: a nonuniform_cfg() struct -> key points,
+    salience levels (buf.salience) and per-label steps; None = uniform framework with step `acc`."""
+    general = model_method != "point" or nonuniform is not None
+    assert not general or buf.general, "BatchBuffers(..., general=True) is needed for the plane model / non-uniform framework"
     if xyz.shape[0] > buf.max_points:
         buf.max_points = int(xyz.shape[0])
-        buf.ws = workspace(buf.B, buf.P, buf.M, xyz.device, buf.max_points)
-    oh = None
-    if offsets_host is not None:   # host copy of the offsets: lets the library overlap sub-batches on its own streams
-        buf._offsets_host = np.ascontiguousarray(offsets_host, dtype=np.int64)
-        oh = buf._offsets_host.ctypes.data
-    io = BatchIO(ptr(xyz).value, ptr(offsets).value, oh, int(xyz.shape[0]), ptr(tm).value, ptr(ground).value,
-                 int(ground_seed), ptr(buf.ri).value, ptr(buf.seg).value, ptr(buf.cen_pix).value, ptr(buf.centers).value,
-                 ptr(buf.model).value, ptr(buf.counts).value, ptr(buf.q16).value, ptr(buf.nnz).value,
-                 ptr(buf.info).value)
+        buf.ws = workspace(buf.B, buf.P, buf.M, xyz.device, buf.max_points, general=buf.general)
+    fid = _frame_ids(frame_ids, buf.B, xyz.device)
+    buf._frame_ids = fid          # keep the tensor alive until the stream has consumed it
+    buf._nonuniform = nonuniform  # (host struct read during the call only; kept for symmetry)
+    io = BatchIO(ptr(xyz).value, ptr(offsets).value, int(xyz.shape[0]), ptr(tm).value, ptr(ground).value,
+                 int(ground_seed), ptr(fid).value if fid is not None else None, ptr(buf.ri).value, ptr(buf.seg).value,
+                 ptr(buf.cen_pix).value, ptr(buf.centers).value, ptr(buf.model).value, ptr(buf.counts).value,
+                 ptr(buf.q16).value, ptr(buf.nnz).value, ptr(buf.info).value,
+                 _lib.FPS_BRUTEFORCE if fps_bruteforce else 0, timer.h if timer is not None else None,
+                 0 if model_method == "point" else 1, angle_cos_cut(angle_threshold) if model_method != "point" else 0.0,
+                 int(plane_seed), C.addressof(nonuniform) if nonuniform is not None else None,
+                 ptr(buf.salience).value if nonuniform is not None else None,
+                 ptr(buf.key_point_map).value if nonuniform is not None else None)
     check(_lib.lib().rpcc_compress_batch(C.byref(io), buf.B, buf.geom, buf.M, float(ground_threshold), float(acc),
                                          ptr(buf.ws), stream()))
     return buf
@@ -332,27 +393,28 @@ def angle_cos_cut(angle_threshold_deg):
     return float(lo)
 
 
-def plane_model(ri, tm, seg, M, angle_threshold=75, seed=0, ground=None, want_counts=False):
-    """a9 -> model f32 [B,K,4] (and counts i32 [B,K])."""
+def plane_model(ri, tm, seg, M, angle_threshold=75, seed=0, ground=None, want_counts=False, frame_ids=None):
+    """a9 -> model f32 [B,K,4] (and counts i32 [B,K]).  Label k of frame b draws with hash(seed, frame_ids[b], k)."""
     B = ri.shape[0]
     P = ri[0].numel()
     K = M + 2
     ws = torch.empty(_lib.lib().rpcc_plane_workspace_bytes(B, P, M), dtype=torch.uint8, device=_dev(ri))
     model = torch.empty((B, K, 4), dtype=torch.float32, device=_dev(ri))
     counts = torch.empty((B, K), dtype=torch.int32, device=_dev(ri))
+    fid = _frame_ids(frame_ids, B, _dev(ri))
     check(_lib.lib().rpcc_plane_model(ptr(ri), ptr(tm), ptr(seg), ptr(ground), B, P, M, angle_cos_cut(angle_threshold),
-                                      int(seed) & 0xFFFFFFFF, ptr(model), ptr(counts), ptr(ws), stream()))
+                                      int(seed) & 0xFFFFFFFF, ptr(fid), ptr(model), ptr(counts), ptr(ws), stream()))
     return (model, counts) if want_counts else model
 
 
-def compress_batch_general(xyz, offsets, tm, ground, buf, cc, fit_ground):
+def compress_batch_general(xyz, offsets, tm, ground, buf, cc, fit_ground, frame_ids=None):
     """Stage-by-stage batch path for the configurations the fused entry does not cover (non-uniform
     framework and / or plane model).  `cc` is a pipeline.BatchCompressor (settings holder).  Fills `buf`
     like compress_batch and returns the salience levels u8 [B,K] (None for the uniform framework)."""
     B, M, geom = buf.B, buf.M, buf.geom
     project(xyz, offsets, geom, ri=buf.ri)
     if fit_ground:
-        g, _ = ground_ransac(buf.ri, tm, seed=cc.seed)
+        g, _ = ground_ransac(buf.ri, tm, seed=cc.seed, frame_ids=frame_ids)
         ground.copy_(g)
     temp, info, tab = ground_mask(buf.ri, tm, ground, cc.ground_threshold, fps_table=True)
     buf.info.copy_(info)
@@ -362,7 +424,7 @@ def compress_batch_general(xyz, offsets, tm, ground, buf, cc, fit_ground):
         model, counts = point_model(buf.ri, buf.seg, ground, M, ws=buf.ws)
     else:
         model, counts = plane_model(buf.ri, tm, buf.seg, M, angle_threshold=cc.cfg.get("plane_angle_threshold", 75),
-                                    seed=cc.seed, ground=ground, want_counts=True)
+                                    seed=cc.seed, ground=ground, want_counts=True, frame_ids=frame_ids)
     buf.model.copy_(model)
     buf.counts.copy_(counts)
     sal = label_acc = None

@@ -25,35 +25,40 @@ class BatchCompressor:
         self._buf = None
         self._codec_ws = None
 
+    @property
+    def general(self):
+        return not (self.uniform and self.model_method == "point")
+
     def _buffers(self, B):
         if self._buf is None or self._buf.B != B:
-            self._buf = ops.BatchBuffers(B, self.T.geom, self.M, self.device)
+            self._buf = ops.BatchBuffers(B, self.T.geom, self.M, self.device, general=self.general)
             self._codec_ws = ops.codec_workspace(B, self.T.H * self.T.W, self.M, self.device)
         return self._buf
 
-    def compress_device(self, xyz, offsets, ground=None):
+    def compress_device(self, xyz, offsets, ground=None, frame_ids=None):
         """Device part.  xyz f32 [sum N,3], offsets i64 [B+1] on the device.  Returns the BatchBuffers plus
-        contour bits / index sequences (and salience for the non-uniform framework), all still in HBM."""
+        contour bits / index sequences (and salience for the non-uniform framework), all still in HBM.
+        frame_ids: stable identities of the frames (utils.frame_identity) for the seeded plane fits."""
         B = offsets.numel() - 1
         buf = self._buffers(B)
         fit = ground is None
         g = torch.zeros((B, 4), dtype=torch.float64, device=self.device) if fit else ground
-        if self.uniform and self.model_method == "point":
-            ops.compress_batch(xyz, offsets, self.T.tm_dev, g, buf, self.ground_threshold, self.acc,
-                               ground_seed=self.seed if fit else -1)
-            sal = None
-        else:
-            sal = ops.compress_batch_general(xyz, offsets, self.T.tm_dev, g, buf, self, fit)
+        # one fused call for all four framework / model combinations (tools/compress.py:109-124)
+        nu = None if self.uniform else ops.nonuniform_cfg(self.acc, self.cfg)
+        ops.compress_batch(xyz, offsets, self.T.tm_dev, g, buf, self.ground_threshold, self.acc,
+                           ground_seed=self.seed if fit else -1, frame_ids=frame_ids, model_method=self.model_method,
+                           angle_threshold=self.cfg.get("plane_angle_threshold", 75), plane_seed=self.seed, nonuniform=nu)
+        sal = None if self.uniform else buf.salience
         bits, seq, nseq = ops.contour_encode(buf.seg, self.M, ws=self._codec_ws)
         return buf, g, bits, seq, nseq, sal
 
-    def submit(self, frames, ground=None):
+    def submit(self, frames, ground=None, frame_ids=None):
         """Device part of compress() on the current stream, nothing waited for.  -> a context for collect()."""
         offs = np.zeros(len(frames) + 1, np.int64)
         offs[1:] = np.cumsum([f.shape[0] for f in frames])
         xyz = torch.from_numpy(np.ascontiguousarray(np.concatenate([f[:, :3] for f in frames]), dtype=np.float32)).to(self.device)
         gnd = None if ground is None else torch.from_numpy(np.asarray(ground, np.float64).reshape(-1, 4)).to(self.device)
-        buf, g, bits, seq, nseq, sal = self.compress_device(xyz, torch.from_numpy(offs).to(self.device), gnd)
+        buf, g, bits, seq, nseq, sal = self.compress_device(xyz, torch.from_numpy(offs).to(self.device), gnd, frame_ids)
         # the two variable-length 16-bit streams leave the device with the frames back to back (rpcc_pack_payload), not
         # as the padded [B,P] arrays: nnz <= points of the frame, one index per contour start <= pixels
         qp, qtot = ops.pack_payload(buf.q16, buf.nnz, capacity=int(offs[-1]))
@@ -87,9 +92,9 @@ class BatchCompressor:
             return list(pool.map(assemble, range(ctx["n"])))
         return [assemble(b) for b in range(ctx["n"])]
 
-    def compress(self, frames, ground=None, pool=None):
+    def compress(self, frames, ground=None, pool=None, frame_ids=None):
         """frames: list of [N,3] arrays.  -> list of .rpcc byte strings (one per frame)."""
-        return self.collect(self.submit(frames, ground), pool=pool)
+        return self.collect(self.submit(frames, ground, frame_ids), pool=pool)
 
 
 class MixedBatchCompressor:

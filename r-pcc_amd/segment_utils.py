@@ -18,11 +18,12 @@ from . import ops
 
 
 class PointCloudSegment:
-    def __init__(self, transform_map, plane_num=1, device="cuda:0", seed=0):
+    def __init__(self, transform_map, plane_num=1, device="cuda:0", seed=0, frame_id=0):
         self.plane_num = plane_num
         self.transform_map = transform_map
         self.device = torch.device(device)
         self.seed = int(seed)
+        self.frame_id = int(frame_id)   # identity of the frame for the seeded RANSACs (utils.frame_identity(path))
         self._tm = torch.from_numpy(np.ascontiguousarray(transform_map, dtype=np.float32)).to(self.device)
         self._cache = {}
 
@@ -58,7 +59,7 @@ class PointCloudSegment:
             _, gm = inject(pc_filter)
             ground = torch.from_numpy(np.asarray(gm, np.float64).reshape(1, 4)).to(self.device)
         else:
-            ground, _ = ops.ground_ransac(ri, self._tm, seed=self.seed)
+            ground, _ = ops.ground_ransac(ri, self._tm, seed=self.seed, frame_ids=[self.frame_id])
         temp, info, tab = ops.ground_mask(ri, self._tm, ground, thr, fps_table=True)
         cen_pix, centers = ops.fps_range(ri, self._tm, temp, info, M, fps_table=tab)
         seg = ops.assign(ri, self._tm, ground, centers)
@@ -76,7 +77,8 @@ class PointCloudSegment:
         if method == "point":
             model, _ = ops.point_model(ri, seg, ground, M)
         else:
-            model = ops.plane_model(ri, self._tm, seg, M, angle_threshold=model_cfg["angle_threshold"], seed=self.seed)
+            model = ops.plane_model(ri, self._tm, seg, M, angle_threshold=model_cfg["angle_threshold"], seed=self.seed,
+                                    frame_ids=[self.frame_id])
         return model[0, 1:nrow].cpu().numpy().astype(np.float64)
 
     def intra_predict(self, seg_idx, model_param):

@@ -62,16 +62,19 @@ def gather_payloads(local_payloads, device, group=None, dst=0):
 
 
 class PackedExchange:
-    """The per-step exchange of bench.py / the batch drivers: every rank holds its frames' residual stream
-    packed back to back (rpcc_pack_payload; int16 entries, at most `cap` of them, cap = the largest rank's point count,
-    agreed on once with agree_capacity) plus the per-frame lengths nnz.  One step = all_gather of nnz + gather of the packed
-    stream to `dst`, as BYTES (RCCL has no 16-bit integer type).  The receive buffers are allocated once."""
+    """The per-step exchange of bench.py / the batch drivers.  Every step the ranks all_gather the per-frame
+    payload lengths nnz (what rank `dst` needs to index the job; B * 4 bytes per rank).  With payloads=True every rank also
+    sends its frames' residual stream, packed back to back (rpcc_pack_payload; int16 entries, at most `cap` of them, cap =
+    the largest rank's point count, agreed on once with agree_capacity), to `dst` as BYTES (RCCL has no 16-bit integer
+    type); with payloads=False the payload stays with the rank that produced it (each rank writes its own .rpcc files,
+    tools/compress_datalist.py).  The receive buffers are allocated once."""
 
-    def __init__(self, frames_per_rank, cap, device, group=None, dst=0):
+    def __init__(self, frames_per_rank, cap, device, group=None, dst=0, payloads=True):
         self.world, self.rank, self.group, self.dst, self.cap = dist.get_world_size(group), dist.get_rank(group), group, dst, int(cap)
+        self.payloads = bool(payloads)
         self.nnz_all = [torch.empty((frames_per_rank,), dtype=torch.int32, device=device) for _ in range(self.world)]
         self.pay_all = ([torch.empty((2 * self.cap,), dtype=torch.uint8, device=device) for _ in range(self.world)]
-                        if self.rank == dst else None)
+                        if self.rank == dst and self.payloads else None)
 
     @staticmethod
     def agree_capacity(local_points, device, group=None):
@@ -79,11 +82,18 @@ class PackedExchange:
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
         return int(t.item())
 
+    def bytes_per_step(self):
+        """Bytes this exchange moves per step over all ranks (lengths to everyone, payloads to dst)."""
+        n = self.nnz_all[0].numel() * 4 * self.world
+        return n + (2 * self.cap * (self.world - 1) if self.payloads else 0)
+
     def step(self, packed_i16, nnz_i32):
-        """packed_i16: int16 [cap] (this rank's stream, frames back to back), nnz_i32: int32 [frames_per_rank]."""
-        assert packed_i16.dtype == torch.int16 and packed_i16.numel() == self.cap
+        """packed_i16: int16 [cap] (this rank's stream, frames back to back; ignored without payloads),
+        nnz_i32: int32 [frames_per_rank]."""
         dist.all_gather(self.nnz_all, nnz_i32, group=self.group)
-        dist.gather(packed_i16.view(torch.uint8), self.pay_all, dst=self.dst, group=self.group)
+        if self.payloads:
+            assert packed_i16.dtype == torch.int16 and packed_i16.numel() == self.cap
+            dist.gather(packed_i16.view(torch.uint8), self.pay_all, dst=self.dst, group=self.group)
 
     def frame_stream(self, rank, frame):
         """On dst, after step() completed: the int16 residual run of `frame` of `rank` (a view into the receive buffer)."""

@@ -17,7 +17,7 @@ from rpcc_amd.compress_utils import (BasicCompressor, QuantizationModule, compre
                                      decompress_point_cloud, read_compressed_bitstream, save_compressed_bitstream)
 from rpcc_amd.dataset import build_dataset  # noqa: E402
 from rpcc_amd.segment_utils import PointCloudSegment  # noqa: E402
-from rpcc_amd.utils import load_compressor_cfg  # noqa: E402
+from rpcc_amd.utils import frame_identity, load_compressor_cfg  # noqa: E402
 
 PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -83,7 +83,7 @@ def compress(args):
     cfg, accuracy, segment_cfg, model_cfg, basic_compressor, uniform = resolve_cfg(args)
     dataset = build_dataset(lidar_type=args.lidar)
     model_num = segment_cfg["cluster_num"] + 1
-    pc_seg = PointCloudSegment(dataset.transform_map, seed=args.seed)
+    pc_seg = PointCloudSegment(dataset.transform_map, seed=args.seed, frame_id=frame_identity(args.input))
 
     t_init = time.time()
     point_cloud, range_image, original_point_cloud = dataset.load_range_image_points_from_file(args.input)

@@ -22,6 +22,7 @@ from rpcc_amd.dataset import build_dataset  # noqa: E402
 from rpcc_amd.pipeline import BatchCompressor  # noqa: E402
 from rpcc_amd.sharding import shard_indices  # noqa: E402
 from rpcc_amd.tools.compress import make_parser, resolve_cfg  # noqa: E402
+from rpcc_amd.utils import frame_identity  # noqa: E402
 
 
 def output_path_for(output_dir, file_name):
@@ -52,7 +53,7 @@ def compress(args):
             idx = mine[s:s + args.batch]
             names = [dataset.data_list[i] for i in idx]
             frames = list(pool.map(dataset.load_data, names))
-            blobs = bc.compress(frames, pool=pool)       # device part, then the entropy coder on the pool's threads
+            blobs = bc.compress(frames, pool=pool, frame_ids=[frame_identity(n) for n in names])   # device part, then the entropy coder on the pool's threads
 
             def write(job):
                 name, blob = job

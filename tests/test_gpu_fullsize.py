@@ -1,0 +1,263 @@
+"""-m gpu: BASELINE configs[1] at its stated size -- every frame of a 256-frame (and a 129-frame) batch of 64x2048 sweeps
+against the CPU oracle, serially and as bench.py runs it (three batches in flight on three streams, ground RANSAC inside
+the call); the tile-pruned FPS against the brute-force kernel at B = 256 (the 512-thread instantiation); host threads
+calling the library concurrently; the RCCL exchange as a single-rank group; the fused entry of the non-uniform / plane
+combinations against the stage-by-stage path; seeds that follow the frame, not its position in the batch."""
+import os
+import threading
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    assert torch.cuda.is_available(), "-m gpu tests need a GPU"
+    import rpcc_amd  # noqa: F401
+    from rpcc_amd import ops, synth
+    from oracle import oracle as orc
+    orc.lib()
+    g = orc.LidarGeom(**orc.GEOMS["Velodyne64E_2048"])
+    tm = ops.transform_map(g.H, g.W, g.horizontal_FOV, g.vertical_max, g.vertical_min)
+    assert np.array_equal(tm, orc.transform_map(g))
+    dev = torch.device("cuda:0")
+    return dict(torch=torch, ops=ops, synth=synth, orc=orc, dev=dev, g=g, tm=tm, d_tm=torch.from_numpy(tm).to(dev),
+                geom=ops.make_geom(g.H, g.W, g.horizontal_FOV, g.vertical_max, g.vertical_min))
+
+
+def _oracle_batch(env, xyz_h, offs_h, ids, seed, plane_seed=None, **kw):
+    """The oracle on every frame of a batch, frame-parallel (ctypes releases the GIL).  plane_seed: plane model rows by
+    the seeded specification (label k of frame i: hash(plane_seed, ids[i], k))."""
+    orc, g, tm = env["orc"], env["g"], env["tm"]
+
+    def one(i):
+        f = xyz_h[offs_h[i]:offs_h[i + 1]]
+        gm = orc.ground_model(orc.project(f, g), tm, seed=seed + ids[i])
+        plane = None if plane_seed is None else dict(angle_deg=75, seed=plane_seed, frame=ids[i])
+        o = orc.compress_frame(f, g, tm, gm, plane=plane, **kw)
+        return dict(ri=o["range_image"], gm=gm, pix=o["fps_pix"], cen=o["centers"], seg=o["seg_idx"].astype(np.uint8),
+                    model=np.asarray(o["model_param"]).astype(np.float32), q=o["q"].astype(np.int16), sal=o.get("salience"))
+    with ThreadPoolExecutor(os.cpu_count() or 8) as ex:
+        return list(ex.map(one, range(len(ids))))
+
+
+def _check_all(buf, gms, exp, tag):
+    ri, seg, pix, cen = buf.ri.cpu().numpy(), buf.seg.cpu().numpy(), buf.cen_pix.cpu().numpy(), buf.centers.cpu().numpy()
+    gm, q, nz, mo = gms.cpu().numpy(), buf.q16.cpu().numpy(), buf.nnz.cpu().numpy(), buf.model.cpu().numpy()
+    for i, o in enumerate(exp):
+        nrow = o["model"].shape[0]
+        assert np.array_equal(ri[i].view(np.uint32), o["ri"].view(np.uint32)), (tag, i, "range image")
+        assert np.array_equal(gm[i].view(np.uint64), np.asarray(o["gm"], np.float64).view(np.uint64)), (tag, i, "ground plane")
+        assert np.array_equal(pix[i], o["pix"]), (tag, i, "FPS pixels")
+        assert np.array_equal(cen[i].view(np.uint32), o["cen"].view(np.uint32)), (tag, i, "centres")
+        assert np.array_equal(seg[i].reshape(-1), o["seg"].reshape(-1)), (tag, i, "labels")
+        assert np.array_equal(mo[i, :nrow].view(np.uint32), o["model"].view(np.uint32)), (tag, i, "model rows")
+        assert int(nz[i]) == o["q"].shape[0] and np.array_equal(q[i, :nz[i]], o["q"]), (tag, i, "quantised residuals")
+
+
+@pytest.mark.parametrize("B", [256, 129])
+def test_bench_configuration_every_frame(env, B):
+    """configs[1] at batch 256 (the 512-thread FPS instantiation) and 129: every frame's range image, fitted ground plane,
+    FPS pixels, centres, labels, model rows and quantised integers equal the oracle's -- one call at a time and with three
+    calls in flight on three streams with their own buffers (what bench.py times)."""
+    torch, ops, synth = env["torch"], env["ops"], env["synth"]
+    ids = list(range(6000, 6000 + B))
+    xyz, offs = synth.make_batch(ids, env["g"].H, env["g"].W, device=env["dev"])
+    fid = torch.as_tensor(np.asarray(ids, np.int64), device=env["dev"])
+    exp = _oracle_batch(env, xyz.cpu().numpy(), offs.cpu().numpy(), ids, seed=7)
+    buf = ops.BatchBuffers(B, env["geom"], 100, env["dev"])
+    gms = torch.zeros((B, 4), dtype=torch.float64, device=env["dev"])
+    ops.compress_batch(xyz, offs, env["d_tm"], gms, buf, ground_seed=7, frame_ids=fid)
+    torch.cuda.synchronize()
+    _check_all(buf, gms, exp, "serial")
+    depth = 3
+    bufs = [ops.BatchBuffers(B, env["geom"], 100, env["dev"]) for _ in range(depth)]
+    gml = [torch.zeros((B, 4), dtype=torch.float64, device=env["dev"]) for _ in range(depth)]
+    streams = [torch.cuda.Stream(device=env["dev"]) for _ in range(depth)]
+    for step in range(3 * depth):                       # nothing is waited for between the calls
+        k = step % depth
+        with torch.cuda.stream(streams[k]):
+            ops.compress_batch(xyz, offs, env["d_tm"], gml[k], bufs[k], ground_seed=7, frame_ids=fid)
+    torch.cuda.synchronize()
+    for k in range(depth):
+        _check_all(bufs[k], gml[k], exp, "in flight, slot %d" % k)
+
+
+def test_fps_tiled_equals_bruteforce_at_batch_256(env):
+    """The tile-pruned FPS (origin class, 16-byte tile loads, 512-thread workgroups) against the brute-force kernel on the
+    256-frame batch: indices, centres and the final temp array, with and without the tile-table hand-off."""
+    torch, ops, synth = env["torch"], env["ops"], env["synth"]
+    B = 256
+    xyz, offs = synth.make_batch(range(9000, 9000 + B), env["g"].H, env["g"].W, device=env["dev"])
+    ri = ops.project(xyz, offs, env["geom"])
+    gms, _ = ops.ground_ransac(ri, env["d_tm"], seed=1)
+    res = {}
+    for mode in ("brute", "tiled", "tiled+table"):
+        if mode == "tiled+table":
+            temp, info, tab = ops.ground_mask(ri, env["d_tm"], gms, 0.1, fps_table=True)
+        else:
+            (temp, info), tab = ops.ground_mask(ri, env["d_tm"], gms, 0.1), None
+        pix, cen = ops.fps_range(ri, env["d_tm"], temp, info, 100, fps_table=tab, bruteforce=(mode == "brute"))
+        res[mode] = (pix.cpu().numpy(), cen.cpu().numpy().view(np.uint32), temp.cpu().numpy().view(np.uint32))
+    for mode in ("tiled", "tiled+table"):
+        for a, b, what in zip(res["brute"], res[mode], ("indices", "centres", "temp")):
+            assert np.array_equal(a, b), (mode, what, np.flatnonzero((a != b).reshape(B, -1).any(1))[:8])
+
+
+def test_concurrent_host_threads(env):
+    """Four host threads, each with its own stream and buffers, call rpcc_compress_batch at the same time (the reference's
+    ThreadPoolExecutor front-end): results equal the same calls made one after the other."""
+    torch, ops, synth = env["torch"], env["ops"], env["synth"]
+    B, NT, ROUNDS = 24, 4, 6
+    data = []
+    for t in range(NT):
+        ids = list(range(12000 + 100 * t, 12000 + 100 * t + B))
+        xyz, offs = synth.make_batch(ids, env["g"].H, env["g"].W, device=env["dev"])
+        data.append((xyz, offs, torch.as_tensor(np.asarray(ids, np.int64), device=env["dev"])))
+
+    def snapshot(buf, gms):
+        torch.cuda.synchronize()
+        return [x.cpu().numpy().copy() for x in (buf.ri, gms, buf.cen_pix, buf.seg, buf.model.view(torch.int32), buf.nnz, buf.q16)]
+
+    ref = []
+    for xyz, offs, fid in data:
+        buf = ops.BatchBuffers(B, env["geom"], 100, env["dev"])
+        gms = torch.zeros((B, 4), dtype=torch.float64, device=env["dev"])
+        ops.compress_batch(xyz, offs, env["d_tm"], gms, buf, ground_seed=3, frame_ids=fid)
+        ref.append(snapshot(buf, gms))
+    out, errs = [None] * NT, []
+    gate = threading.Barrier(NT)
+
+    def worker(t):
+        try:
+            xyz, offs, fid = data[t]
+            st = torch.cuda.Stream(device=env["dev"])
+            buf = ops.BatchBuffers(B, env["geom"], 100, env["dev"])
+            gms = torch.zeros((B, 4), dtype=torch.float64, device=env["dev"])
+            gate.wait()
+            with torch.cuda.stream(st):
+                for _ in range(ROUNDS):
+                    ops.compress_batch(xyz, offs, env["d_tm"], gms, buf, ground_seed=3, frame_ids=fid)
+            st.synchronize()
+            out[t] = [x.cpu().numpy().copy() for x in (buf.ri, gms, buf.cen_pix, buf.seg, buf.model.view(torch.int32), buf.nnz, buf.q16)]
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(NT)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert not errs, errs
+    for t in range(NT):
+        nz = ref[t][5]
+        for k, (a, b) in enumerate(zip(ref[t][:6], out[t][:6])):
+            assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), (t, k)
+        for i in range(B):
+            assert np.array_equal(ref[t][6][i, :nz[i]], out[t][6][i, :nz[i]]), (t, i)
+
+
+def test_seed_follows_the_frame_not_the_batch(env):
+    """A frame's fitted ground plane, plane rows and quantised integers do not depend on the batch it travels in or on
+    its position there (frame_ids = stable identities)."""
+    torch, ops, synth = env["torch"], env["ops"], env["synth"]
+    g = env["g"]
+    frames = {i: synth.make_frame(15000 + i, g.H, g.W).numpy() for i in range(5)}
+
+    def run(order):
+        offs = np.zeros(len(order) + 1, np.int64)
+        offs[1:] = np.cumsum([frames[i].shape[0] for i in order])
+        xyz = torch.from_numpy(np.concatenate([frames[i] for i in order])).to(env["dev"])
+        buf = ops.BatchBuffers(len(order), env["geom"], 100, env["dev"], general=True)
+        gms = torch.zeros((len(order), 4), dtype=torch.float64, device=env["dev"])
+        ops.compress_batch(xyz, torch.from_numpy(offs).to(env["dev"]), env["d_tm"], gms, buf, ground_seed=5,
+                           frame_ids=[1000 + i for i in order], model_method="plane", plane_seed=5, nonuniform=ops.nonuniform_cfg(0.04))
+        torch.cuda.synchronize()
+        nz = buf.nnz.cpu().numpy()
+        return {i: (gms[k].cpu().numpy().tobytes(), buf.model[k].cpu().numpy().tobytes(), buf.q16[k, :nz[k]].cpu().numpy().tobytes(),
+                    buf.salience[k].cpu().numpy().tobytes()) for k, i in enumerate(order)}
+    a = run([0, 1, 2, 3, 4])
+    b = run([3, 1])
+    c = run([4, 2, 0, 3])
+    for i in (1, 3):
+        assert a[i] == b[i], i
+    for i in (0, 2, 3, 4):
+        assert a[i] == c[i], i
+
+
+@pytest.mark.parametrize("uniform,method", [(False, "plane"), (True, "plane"), (False, "point")])
+def test_fused_general_entry_equals_staged_path_and_oracle(env, uniform, method):
+    """configs[2]: the one-call entry for the non-uniform framework / plane model equals the stage-by-stage entries
+    (rpcc_plane_model, rpcc_extract_features, rpcc_salience, rpcc_predict_quantize) and the oracle."""
+    torch, ops, synth, orc = env["torch"], env["ops"], env["synth"], env["orc"]
+    B = 12
+    ids = list(range(17000, 17000 + B))
+    xyz, offs = synth.make_batch(ids, env["g"].H, env["g"].W, device=env["dev"])
+    nu = None if uniform else ops.nonuniform_cfg(0.04)
+    buf = ops.BatchBuffers(B, env["geom"], 100, env["dev"], general=True)
+    gms = torch.zeros((B, 4), dtype=torch.float64, device=env["dev"])
+    ops.compress_batch(xyz, offs, env["d_tm"], gms, buf, ground_seed=9, frame_ids=ids, model_method=method, plane_seed=9, nonuniform=nu)
+    torch.cuda.synchronize()
+
+    class CC:   # settings holder of the staged path
+        pass
+    cc = CC()
+    cc.seed, cc.ground_threshold, cc.model_method, cc.uniform, cc.acc, cc.cfg = 9, 0.1, method, uniform, 0.04, {}
+    buf2 = ops.BatchBuffers(B, env["geom"], 100, env["dev"], general=True)
+    gms2 = torch.zeros((B, 4), dtype=torch.float64, device=env["dev"])
+    sal2 = ops.compress_batch_general(xyz, offs, env["d_tm"], gms2, buf2, cc, True, frame_ids=ids)
+    torch.cuda.synchronize()
+    nz = buf.nnz.cpu().numpy()
+    assert np.array_equal(nz, buf2.nnz.cpu().numpy())
+    assert torch.equal(gms, gms2) and torch.equal(buf.seg, buf2.seg)
+    assert np.array_equal(buf.model.cpu().numpy().view(np.uint32), buf2.model.cpu().numpy().view(np.uint32))
+    for i in range(B):
+        assert torch.equal(buf.q16[i, :nz[i]], buf2.q16[i, :nz[i]]), i
+    if not uniform:
+        assert torch.equal(buf.salience, sal2)
+    exp = _oracle_batch(env, xyz.cpu().numpy(), offs.cpu().numpy(), ids, seed=9, uniform=uniform,
+                        plane_seed=9 if method == "plane" else None)
+    _check_all(buf, gms, exp, "fused %s %s" % ("uniform" if uniform else "non-uniform", method))
+    if not uniform:
+        sal = buf.salience.cpu().numpy()
+        for i, o in enumerate(exp):
+            assert np.array_equal(sal[i, :o["model"].shape[0]], o["sal"].astype(np.uint8)), i
+
+
+def test_rccl_single_rank_exchange(env):
+    """The N > 1 exchange of bench.py / the datalist driver (sharding.PackedExchange over torch.distributed 'nccl' = RCCL)
+    as a single-rank group on this GPU: lengths and packed residual streams come back as they were sent."""
+    torch, ops, synth = env["torch"], env["ops"], env["synth"]
+    import torch.distributed as dist
+    from rpcc_amd.sharding import PackedExchange
+    B = 8
+    xyz, offs = synth.make_batch(range(19000, 19000 + B), env["g"].H, env["g"].W, device=env["dev"])
+    buf = ops.BatchBuffers(B, env["geom"], 100, env["dev"])
+    gms = torch.zeros((B, 4), dtype=torch.float64, device=env["dev"])
+    ops.compress_batch(xyz, offs, env["d_tm"], gms, buf, ground_seed=1)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29581")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=env["dev"])
+    try:
+        cap = PackedExchange.agree_capacity(int(xyz.shape[0]), env["dev"])
+        assert cap == xyz.shape[0]
+        for payloads in (False, True):
+            ex = PackedExchange(B, cap, env["dev"], payloads=payloads)
+            packed, tot = ops.pack_payload(buf.q16, buf.nnz, capacity=cap)
+            for _ in range(2):
+                ex.step(packed, buf.nnz)
+            torch.cuda.synchronize()
+            assert torch.equal(ex.nnz_all[0], buf.nnz)
+            assert ex.bytes_per_step() == B * 4 + 0
+            if payloads:
+                assert int(tot.item()) == int(buf.nnz.sum().item())
+                for f in range(B):
+                    assert torch.equal(ex.frame_stream(0, f), buf.q16[f, :int(buf.nnz[f])]), f
+    finally:
+        if created:
+            dist.destroy_process_group()

@@ -258,24 +258,6 @@ def test_full_size_batch_properties(env):
     ops.compress_batch(xyz, offs, d_tm, _to(env, gms), buf)
     torch.cuda.synchronize()
     assert np.array_equal(buf.q16.cpu().numpy()[:, :nnz.min()], q_first[:, :nnz.min()])
-    # sub-batches on internal streams (host offsets given) give the same bytes, for every slice count
-    for S in (1, 2, 3, 8):
-        ops.set_batch_slices(S)
-        buf2 = ops.BatchBuffers(B, geom, 100, env["dev"])
-        gfit = torch.zeros((B, 4), dtype=torch.float64, device=env["dev"])
-        ops.compress_batch(xyz, offs, d_tm, gfit, buf2, ground_seed=3, offsets_host=offs_c)
-        torch.cuda.synchronize()
-        if S == 1:
-            ref = [buf2.q16.cpu().numpy(), buf2.seg.cpu().numpy(), buf2.nnz.cpu().numpy(), gfit.cpu().numpy(),
-                   buf2.model.cpu().numpy(), buf2.cen_pix.cpu().numpy()]
-        else:
-            got = [buf2.q16.cpu().numpy(), buf2.seg.cpu().numpy(), buf2.nnz.cpu().numpy(), gfit.cpu().numpy(),
-                   buf2.model.cpu().numpy(), buf2.cen_pix.cpu().numpy()]
-            assert np.array_equal(ref[2], got[2]) and np.array_equal(ref[1], got[1]) and _beq(ref[3], got[3])
-            assert _beq(ref[4], got[4]) and np.array_equal(ref[5], got[5])
-            for b in range(B):
-                assert np.array_equal(ref[0][b, :ref[2][b]], got[0][b, :got[2][b]]), (S, b)
-    ops.set_batch_slices(2)
 
 
 def test_assign_sqrt_ties_and_duplicates(env):
@@ -410,21 +392,22 @@ def test_fps_tiled_equals_bruteforce(env):
             gms = torch.cat([gms, gms[:1]], 0)
         res = {}
         for mode in ("brute", "tiled", "tiled+table"):
-            ops.fps_force_bruteforce(mode == "brute")
-            try:
-                if mode == "tiled+table":
-                    temp, info, tab = ops.ground_mask(ri, _to(env, tm), gms, 0.1, fps_table=True)
-                    flags = info[:, 3].cpu().numpy()
-                    assert flags[0] == 1
-                    if name == "Velodyne64E_2048":
-                        assert flags[-1] == 0
-                else:
-                    temp, info = ops.ground_mask(ri, _to(env, tm), gms, 0.1)
-                    tab = None
-                cen_pix, centers = ops.fps_range(ri, _to(env, tm), temp, info, 100, fps_table=tab)
-                res[mode] = (cen_pix.cpu().numpy(), centers.cpu().numpy(), temp.cpu().numpy())
-            finally:
-                ops.fps_force_bruteforce(False)
+            if mode == "tiled+table":
+                temp, info, tab = ops.ground_mask(ri, _to(env, tm), gms, 0.1, fps_table=True)
+                flags = info[:, 3].cpu().numpy()
+                assert flags[0] == 1
+                if name == "Velodyne64E_2048":
+                    assert flags[-1] == 0
+            else:
+                temp, info = ops.ground_mask(ri, _to(env, tm), gms, 0.1)
+                tab = None
+            # info[:, 4]: the first empty pixel that is a candidate (the representative of the FPS origin class)
+            ri_h, t_h = ri.cpu().numpy().reshape(len(gms), -1), temp.cpu().numpy()
+            for i in range(len(gms)):
+                e = np.flatnonzero((ri_h[i] == 0) & (t_h[i] >= 0))
+                assert int(info[i, 4]) == (int(e[0]) if e.size else g.H * g.W), (name, mode, i)
+            cen_pix, centers = ops.fps_range(ri, _to(env, tm), temp, info, 100, fps_table=tab, bruteforce=(mode == "brute"))
+            res[mode] = (cen_pix.cpu().numpy(), centers.cpu().numpy(), temp.cpu().numpy())
         for mode in ("tiled", "tiled+table"):
             for a, b in zip(res["brute"], res[mode]):
                 assert _beq(a, b), (name, mode)
@@ -438,13 +421,9 @@ def test_fps_tiled_equals_bruteforce(env):
         pts[:, N // 3: 2 * (N // 3)] = pts[:, : N // 3]
         out = {}
         for mode in (True, False):
-            ops.fps_force_bruteforce(mode)
-            try:
-                temp = torch.full((B, N), 1e10, dtype=torch.float32, device=env["dev"])
-                idx = ops.fps_xyz(_to(env, pts), M, temp=temp)
-                out[mode] = (idx.cpu().numpy(), temp.cpu().numpy())
-            finally:
-                ops.fps_force_bruteforce(False)
+            temp = torch.full((B, N), 1e10, dtype=torch.float32, device=env["dev"])
+            idx = ops.fps_xyz(_to(env, pts), M, temp=temp, bruteforce=mode)
+            out[mode] = (idx.cpu().numpy(), temp.cpu().numpy())
         assert _beq(out[True][0], out[False][0]) and _beq(out[True][1], out[False][1]), (B, N, M)
         if N <= 30000:
             assert np.array_equal(out[False][0][0], orc.fps(pts[0], M))
