@@ -8,7 +8,9 @@ DEPS = [os.path.join(_HERE, "csrc", f) for f in sorted(os.listdir(os.path.join(_
        [os.path.join(os.path.dirname(_HERE), "include", "rpcc_hip.h")]
 LIB = os.path.join(_HERE, "lib", "librpcc_hip.so")
 
-# -ffp-contract=off: the reference arithmetic is un-fused x86 SSE; a contracted FMA changes results.
+# -ffp-contract=off: the reference's C++ (projection, models, prediction, quantisation) is un-fused x86 SSE arithmetic and a
+# contracted FMA changes results.  (The reference's CUDA FPS kernel is a different matter: nvcc contracts its distance into
+# FMAs by default; the build's FPS follows its own un-fused specification, see DESIGN.md section 2 "parity unpinned".)
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC",
                "-shared", "-Wno-unused-value"]
 
@@ -18,7 +20,8 @@ def build(force=False, verbose=False):
     if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in DEPS):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + HIPCC_FLAGS + [SRC, "-o", LIB]
+    extra = os.environ.get("RPCC_EXTRA_FLAGS", "").split()   # developer knob: -D switches of the tuning experiments (tools_dev/)
+    cmd = [hipcc] + HIPCC_FLAGS + extra + [SRC, "-o", LIB]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -174,6 +174,9 @@ __device__ __forceinline__ void fps_load_point(const float *__restrict__ src, co
 #define FPS_TT_BATCH 512
 #endif
 #define FPS_TT_SMALL 1024
+#ifndef FPS_GROUP
+#define FPS_GROUP 2
+#endif
 #define FPS_FLAG_FINALIZE_TEMP 1  // write the origin class's value back to the empty pixels' temp entries at the end
 
 template <bool RANGE, bool VEC, int FPS_TT>
@@ -326,7 +329,7 @@ __global__ __launch_bounds__(FPS_TT) void fps_tiled_kernel(const float *__restri
         }
     };
 
-    constexpr int NW = FPS_TT / 64, GROUP = 2;  // tiles per wavefront in flight
+    constexpr int NW = FPS_TT / 64, GROUP = FPS_GROUP;  // tiles per wavefront in flight
     DBG_STAMP(8);
     // first centre: every tile is visited once (also builds the boxes) -- unless ground_mask already did
     // that pass and left the tile table (info[b][3] == 1)
