@@ -145,14 +145,17 @@ int rpcc_point_model(const float *ri, const uint8_t *seg, const double *ground, 
  * (:84-93) and the fp32 numpy-mean fallbacks.  RANSAC (ransac_n = 4, 10 iterations, 0.1 m) is the
  * build's seeded specification (Open3D in the reference); label k of frame b uses hash(seed, id_b, k) with
  * id_b = frame_ids[b] (dev i64 [B]) or b when frame_ids is NULL.
+ *   inject_planes dev f64 [B,K,4] or NULL: test hook -- row (b,k) replaces the RANSAC result of label k (what the
+ *            fixtures of tests/golden/pins_*.npz do to the reference through ransac_plane_segmentation), so that the
+ *            angle validation and the mean fallbacks can be compared with the genuine cluster_modeling('plane')
  *   ground   dev f64 [B,4] or NULL   copied (as fp32) into row 0
  *   cos_cut  HOST double: a plane is rejected when some pixel has |n.t|/|n|*|t| <= cos_cut, i.e.
  *            arccos(.) > angle threshold; the caller derives it from its own arccos (ops.plane_model)
  *   model    dev f32 [B,K,4] out;  counts dev i32 [B,K] out;  ws rpcc_plane_workspace_bytes(B,P,M)   */
 size_t rpcc_plane_workspace_bytes(int B, int P, int M);
 int rpcc_plane_model(const float *ri, const float *tm, const uint8_t *seg, const double *ground, int B, int P, int M,
-                     double cos_cut, uint32_t seed, const int64_t *frame_ids, float *model, int32_t *counts, void *ws,
-                     void *stream);
+                     double cos_cut, uint32_t seed, const int64_t *frame_ids, const double *inject_planes, float *model,
+                     int32_t *counts, void *ws, void *stream);
 
 /* ---- a10+a11(+a13): intra-prediction + residual + quantisation + ordered scatter ------------- *
  * replaces segment_utils_cpp.intra_predict (cpp_modules.cpp:248-285), residual = ri - pred

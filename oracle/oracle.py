@@ -270,10 +270,13 @@ def plane_angle_ok(plane_model, scan_vector, angle_deg):
     return not (alpha.max() > np.pi * (angle_deg / 180))
 
 
-def cluster_modeling_plane(pc, ri, seg, tm, angle_deg=75, seed=0, frame=0):
+def cluster_modeling_plane(pc, ri, seg, tm, angle_deg=75, seed=0, frame=0, inject=None):
     """a9: cluster_modeling('plane') (utils/segment_utils.py:188-216) with the build's seeded RANSAC in
-    place of Open3D: label k of frame b uses seed mix32(seed, b, k).  -> float64 [max, 4] (rows for labels 1..max)."""
+    place of Open3D: label k of frame b uses seed mix32(seed, b, k).  -> float64 [max, 4] (rows for labels 1..max).
+    inject: list of plane rows handed out, in call order, INSTEAD of the RANSAC result (what gen_golden_pins.py does to
+    the genuine reference through ransac_plane_segmentation): pins the glue around the fit."""
     rows = []
+    inject = None if inject is None else [np.asarray(r, np.float64) for r in inject]
     ri3 = ri.reshape(seg.shape[0], seg.shape[1], 1)
     for i in range(int(seg.max()) + 1):
         if i == 0:
@@ -286,7 +289,10 @@ def cluster_modeling_plane(pc, ri, seg, tm, angle_deg=75, seed=0, frame=0):
         if idx[0].shape[0] < 30:
             rows.append([0, 0, 0, np_mean_f32(cur)])
             continue
-        plane, _ = ransac_plane(pc[idx], 4, 10, 0.1, mix32(seed, frame, i))
+        if inject is not None:
+            plane = inject.pop(0)
+        else:
+            plane, _ = ransac_plane(pc[idx], 4, 10, 0.1, mix32(seed, frame, i))
         if plane_angle_ok(plane, tm[idx], angle_deg):
             rows.append(list(plane))
         else:
@@ -377,3 +383,48 @@ def bitstream_bytes(od, uniform=True):
         parts.append(struct.pack("i", len(comp[k])))
         parts.append(comp[k])
     return b"".join(parts)
+
+
+# ------------------------------------------------------------------------------------------------
+# f3: decoder (utils/compress_utils.py:199-214 decompress_point_cloud, :114-132 dequantize_residual,
+#     tools/decompress.py:88-112)
+# ------------------------------------------------------------------------------------------------
+def unpack_bitstream(blob, uniform=True):
+    """read_compressed_bitstream (utils/compress_utils.py:181-196) on bytes + bz2 -> dict of raw byte strings."""
+    keys = ([] if uniform else ["salience_level"]) + ["contour_map", "idx_sequence", "plane_param", "residual_quantized"]
+    out, off = {}, 0
+    for k in keys:
+        (n,) = struct.unpack("i", blob[off:off + 4])
+        out[k] = bz2.decompress(blob[off + 4:off + 4 + n])
+        off += 4 + n
+    assert off == len(blob)
+    return out
+
+
+def decode_frame(blob, g, tm, accuracy=0.02, uniform=True, level_delta_acc=(0, 0.02, 0.04, 0.06)):
+    """The reference decoder on one .rpcc byte string -> dict(seg_idx, residual f32 [H,W,1], pred, ri_rec, pc_rec)."""
+    d = unpack_bitstream(blob, uniform)
+    plane_param = np.frombuffer(d["plane_param"], dtype=np.float32).reshape(-1, 4)   # all rows (the reference's shape
+    #                                  (cluster_num+1, 4) is one row short but aliases the same buffer: SURVEY 8c)
+    contour = np.unpackbits(np.frombuffer(d["contour_map"], dtype=np.uint8))[: g.H * g.W].reshape(g.H, g.W)
+    seq = np.frombuffer(d["idx_sequence"], dtype=np.uint16)
+    seg = recover_map(contour.astype(np.int32), seq.astype(np.int32))
+    rq = np.frombuffer(d["residual_quantized"], dtype=np.int16)
+    step = accuracy * 2                                   # tools/decompress.py:58: python float
+    acc = step if uniform else np.array([step] * len(level_delta_acc)) + np.array(level_delta_acc)
+    sal = None if uniform else np.frombuffer(d["salience_level"], dtype=np.uint8)
+    residual = np.zeros(seg.shape, dtype=np.float32)      # compress_utils.py:115
+    start = 0
+    for m in range(int(seg.max()) + 1):
+        idx = np.where(seg == m)
+        if m == 1:
+            continue
+        cur = acc if uniform else acc[sal[m]]
+        residual[idx] = rq[start:start + idx[0].shape[0]] * cur     # int16 * python float / np.float64 -> fp64, stored fp32
+        start += idx[0].shape[0]
+    assert start == rq.shape[0]
+    residual = np.expand_dims(residual, -1)
+    pred = intra_predict(seg, plane_param.astype(np.float64), tm)
+    ri_rec = pred + residual
+    pc_rec = ri_rec * tm                                   # dataset/transformer.py:94-101
+    return dict(seg_idx=seg, residual=residual, pred=pred, ri_rec=ri_rec, pc_rec=pc_rec.astype(np.float32))

@@ -65,7 +65,7 @@ _SIGS = {
     "rpcc_decode": (C.c_int, [_VP, _VP, _VP, _VP, C.POINTER(C.c_double), _I, _VP, _I, _I, _I, _VP, _VP, _VP, _VP]),
     "rpcc_pack_payload": (C.c_int, [_VP, _VP, _I, _I, _VP, _I64, _VP, _VP]),
     "rpcc_plane_workspace_bytes": (C.c_size_t, [_I, _I, _I]),
-    "rpcc_plane_model": (C.c_int, [_VP, _VP, _VP, _VP, _I, _I, _I, _D, C.c_uint32, _VP, _VP, _VP, _VP, _VP]),
+    "rpcc_plane_model": (C.c_int, [_VP, _VP, _VP, _VP, _I, _I, _I, _D, C.c_uint32, _VP, _VP, _VP, _VP, _VP, _VP]),
     "rpcc_workspace_bytes": (C.c_size_t, [_I, _I, _I, _I64]),
     "rpcc_workspace_bytes_general": (C.c_size_t, [_I, _I, _I, _I64]),
     "rpcc_compress_batch": (C.c_int, [C.POINTER(BatchIO), _I, Geom, _I, _D, _F, _VP, _VP]),

@@ -112,9 +112,11 @@ __device__ __forceinline__ void fps_quad_load(const float *__restrict__ src, con
     }
 }
 
-// order-preserving key of a temp value: 0 = not a candidate, else bits + 1 (non-negative floats order as integers)
-__device__ __forceinline__ uint32_t fps_val_key(float v) { return v < 0.0f ? 0u : f2u(v) + 1u; }
-__device__ __forceinline__ float fps_key_val(uint32_t k) { return k == 0u ? -1.0f : u2f(k - 1u); }
+// order-preserving key of a temp value: non-negative floats order as integers, so flipping the sign bit gives an unsigned
+// key >= FPS_KEY_MIN for every candidate value and a key below it for the negative "not a candidate" marker
+#define FPS_KEY_MIN 0x80000000u
+__device__ __forceinline__ uint32_t fps_val_key(float v) { return f2u(v) ^ 0x80000000u; }
+__device__ __forceinline__ float fps_key_val(uint32_t k) { return k >= FPS_KEY_MIN ? u2f(k ^ 0x80000000u) : -1.0f; }
 
 // arg-max of a tile: largest key, lowest (lane, element) among equals -> value, coordinates, point index
 __device__ __forceinline__ void fps_tile_argmax(const float (&x)[4], const float (&y)[4], const float (&z)[4],
@@ -137,7 +139,7 @@ __device__ __forceinline__ void fps_tile_argmax(const float (&x)[4], const float
     wy = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(sy), wl));
     wz = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(sz), wl));
     widx = (uint32_t)__builtin_amdgcn_readlane(p0 + em, wl);
-    if (vmax == 0u) { wx = wy = wz = 0.0f; widx = 0u; }
+    if (vmax < FPS_KEY_MIN) { wx = wy = wz = 0.0f; widx = 0u; }
 }
 __device__ __forceinline__ void fps_tile_box(const float (&x)[4], const float (&y)[4], const float (&z)[4],
                                              const bool (&cand)[4], float (&lo)[3], float (&hi)[3]) {
@@ -316,10 +318,10 @@ __global__ __launch_bounds__(FPS_TT) void fps_tiled_kernel(const float *__restri
         const int wl = __builtin_amdgcn_readfirstlane((int)__ffsll((long long)mm) - 1);
         const int t = __builtin_amdgcn_readlane(kt, wl < 0 ? 0 : wl);
         const uint32_t okey = org_on ? fps_val_key(t_org) : 0u;
-        if (okey != 0u && (okey > vmax || (okey == vmax && (uint32_t)org_idx < imin))) {
+        if (okey >= FPS_KEY_MIN && (okey > vmax || (okey == vmax && (uint32_t)org_idx < imin))) {
             old = org_idx;
             c0 = ox; c1 = oy; c2 = oz;
-        } else if (vmax == 0u || imin == 0xFFFFFFFFu) {  // no candidate anywhere: keep indices defined (the reference would fail)
+        } else if (vmax < FPS_KEY_MIN || imin == 0xFFFFFFFFu) {  // no candidate anywhere: keep indices defined (the reference would fail)
             old = 0;
             fps_load_point<RANGE>(src, rays, 0, c0, c1, c2);
         } else {
@@ -369,6 +371,9 @@ __global__ __launch_bounds__(FPS_TT) void fps_tiled_kernel(const float *__restri
         if (tid == 0) { out_idx[1] = old; if (out_cen) { out_cen[3] = c0; out_cen[4] = c1; out_cen[5] = c2; } }
     }
     long long acc_a = 0, acc_b = 0, acc_c = 0, acc_n = 0, tq = 0;
+#ifdef FPS_PROF2
+    long long acc_p1 = 0, acc_p2 = 0, acc_p3 = 0;
+#endif
     const bool prof = g_dbg_stamps != nullptr && blockIdx.x == 0 && tid == 0;
     for (int j = 2; j < M; j++) {
         if (prof) tq = (long long)__builtin_readcyclecounter();
@@ -392,6 +397,9 @@ __global__ __launch_bounds__(FPS_TT) void fps_tiled_kernel(const float *__restri
         __syncthreads();
         const int n = wcount;
         if (prof) { const long long t1 = (long long)__builtin_readcyclecounter(); acc_a += t1 - tq; tq = t1; acc_n += n; }
+#ifdef FPS_PROF2
+        if (prof) { g_dbg_stamps[64 + 8 * j] = n; g_dbg_stamps[64 + 8 * j + 1] = acc_a; }
+#endif
         for (int e = wave; e < n; e += NW * GROUP) {
             FpsQuad q[GROUP];
             int tt[GROUP];
@@ -402,20 +410,277 @@ __global__ __launch_bounds__(FPS_TT) void fps_tiled_kernel(const float *__restri
                 locate(tt[gi], q[gi]);
                 fps_quad_load<RANGE, VEC>(src, rays, temp, q[gi]);   // unconditional (a repeated tile for the tail is harmless and unused)
             }
+#ifdef FPS_PROF2
+            if (prof && e == wave) g_dbg_stamps[64 + 8 * j + 2] = (long long)__builtin_readcyclecounter() - tq;   // loads issued
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (prof && e == wave) g_dbg_stamps[64 + 8 * j + 3] = (long long)__builtin_readcyclecounter() - tq;   // data arrived
+#endif
 #pragma unroll
             for (int gi = 0; gi < GROUP; gi++) if (e + gi * NW < n) compute_tile(tt[gi], q[gi], false);
+#ifdef FPS_PROF2
+            if (prof && e == wave) g_dbg_stamps[64 + 8 * j + 4] = (long long)__builtin_readcyclecounter() - tq;   // round 1 computed
+#endif
         }
         __syncthreads();
+#ifdef FPS_PROF2
+        if (prof) g_dbg_stamps[64 + 8 * j + 5] = (long long)__builtin_readcyclecounter() - tq;   // barrier 2 passed
+#endif
         if (prof) { const long long t1 = (long long)__builtin_readcyclecounter(); acc_b += t1 - tq; tq = t1; }
         if (tid == 0) wcount = 0;
         select_next();
+#ifdef FPS_PROF2
+        if (prof) g_dbg_stamps[64 + 8 * j + 6] = (long long)__builtin_readcyclecounter() - tq;   // select done
+#endif
         if (prof) { const long long t1 = (long long)__builtin_readcyclecounter(); acc_c += t1 - tq; tq = t1; }
         if (tid == 0) { out_idx[j] = old; if (out_cen) { out_cen[3 * j] = c0; out_cen[3 * j + 1] = c1; out_cen[3 * j + 2] = c2; } }
     }
     DBG_STAMP(16);
     if (prof) { g_dbg_stamps[24] = acc_a; g_dbg_stamps[25] = acc_b; g_dbg_stamps[26] = acc_c; g_dbg_stamps[27] = acc_n; }
+#ifdef FPS_PROF2
+    if (prof) { g_dbg_stamps[28] = acc_p1; g_dbg_stamps[29] = acc_p2; g_dbg_stamps[30] = acc_p3; }
+#endif
     if (RANGE && org_on && (flags & FPS_FLAG_FINALIZE_TEMP)) {
         // the empty pixels' temp entries were not touched while the class was carried as a scalar
+        for (int p = tid; p < N; p += FPS_TT) {
+            const float r = ld_f32(src, (uint32_t)p * 4u), tv = ld_f32(temp, (uint32_t)p * 4u);
+            if (r == 0.0f && tv >= 0.0f && tv != t_org) st_f32(temp, (uint32_t)p * 4u, t_org);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Register-table form (the default whenever the frame has at most 64 tiles per wavefront of the workgroup).
+// The per-iteration chain of the kernel above is  test -> work list -> barrier -> tile loads -> update -> barrier ->
+// table scan -> barrier: three barriers and five dependent LDS round trips around ~1200 cycles of load latency.  Here
+// every tile belongs to ONE lane of ONE wavefront for the whole launch: its box, maximum, arg and coordinates live in that
+// lane's registers, the wavefront tests its own 64 tiles (no LDS), updates the ones the new centre can change (their
+// results are wave-uniform scalars, written back into the owner lane), reduces its own maxima with DPP and publishes one
+// candidate; ONE barrier later every wavefront picks the winner among the NW candidates.  The candidates are double
+// buffered by iteration parity, so a fast wavefront may run ahead into its next test + loads while the others still read.
+// Tiles are dealt to the wavefronts round-robin in an order that is skewed from tile-row to tile-row, so the tiles around
+// a new centre (horizontal and vertical neighbours) belong to different wavefronts.  Same arithmetic, same results.
+// ------------------------------------------------------------------------------------------------------------------
+struct FpsTileOut { float lo[3], hi[3], wt, wx, wy, wz; uint32_t widx; };
+
+// update of one tile against centre (c0,c1,c2): returns true (wave-uniform) when its table entry changed (always with
+// with_box); the new entry comes back in `o`.  viol: an empty pixel is not what the origin class assumes (first pass only).
+template <bool RANGE, bool VEC>
+__device__ __forceinline__ bool fps_tile_update(const FpsQuad &q, bool org_on, float t_org0, float c0, float c1, float c2,
+                                                float *__restrict__ temp, bool with_box, FpsTileOut &o, bool &viol) {
+    float x[4], y[4], z[4], nt[4];
+    uint32_t key[4];
+    bool cand[4], ch = false;
+    fps_quad_xyz(q, RANGE, x, y, z);
+    const bool lane_ok = q.nval > 0;   // VEC: a lane's four elements are inside the frame together
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        float tp = (VEC ? lane_ok : e < q.nval) ? q.tp[e] : -1.0f;
+        if (RANGE && org_on && q.r[e] == 0.0f) {   // member of the origin class: carried by t_org
+            if (with_box) viol |= (VEC ? lane_ok : e < q.nval) && tp != t_org0;
+            tp = -1.0f;
+        }
+        cand[e] = tp >= 0.0f;
+        const float dx = x[e] - c0, dy = y[e] - c1, dz = z[e] - c2;
+        const float d = (dx * dx + dy * dy) + dz * dz;  // sampling_gpu.cu:64, un-fused
+        nt[e] = d < tp ? d : tp;  // == fminf(d, tp): a NaN distance keeps tp, tp itself is never NaN
+        key[e] = fps_val_key(nt[e]);
+        const bool c = nt[e] != tp;
+        ch |= c;
+        if (!VEC && c) st_f32(temp, (uint32_t)(q.p0 + e) * 4u, nt[e]);
+        if (!c) nt[e] = q.tp[e];   // value to write back for an unchanged element
+    }
+    if (VEC && ch) st_at(reinterpret_cast<float4 *>(temp), (uint32_t)q.p0 * 4u, make_float4(nt[0], nt[1], nt[2], nt[3]));
+    if (!with_box && __ballot(ch) == 0ull) return false;
+    if (with_box) fps_tile_box(x, y, z, cand, o.lo, o.hi);
+    fps_tile_argmax(x, y, z, key, q.p0, o.wt, o.wx, o.wy, o.wz, o.widx);
+    return true;
+}
+
+template <bool RANGE, bool VEC, int FPS_TT>
+__global__ __launch_bounds__(FPS_TT) void fps_regtab_kernel(const float *__restrict__ src, const float *__restrict__ rays,
+                                                            float *__restrict__ temp, const int32_t *__restrict__ info,
+                                                            FpsTiling g, int M, int flags, int32_t *__restrict__ out_idx,
+                                                            float *__restrict__ out_cen, const float *__restrict__ tiletab) {
+    constexpr int NW = FPS_TT / 64;
+    __shared__ uint2 slot_k[2][NW];    // candidate of a wavefront: (value key, point index)
+    __shared__ float4 slot_c[2][NW];   //                          its coordinates
+    __shared__ int s_viol;
+    const int T = g.T, N = g.N;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    src += (int64_t)b * N * (RANGE ? 1 : 3);
+    temp += (int64_t)b * N;
+    out_idx += (int64_t)b * M;
+    if (out_cen) out_cen += (int64_t)b * M * 3;
+    if (M <= 0) return;
+
+    int old = 0;
+    if (RANGE) { old = info[RPCC_INFO * b + 1]; if (old >= N) old = 0; }
+    float c0, c1, c2;
+    fps_load_point<RANGE>(src, rays, old, c0, c1, c2);
+    if (tid == 0) {
+        out_idx[0] = old;
+        if (out_cen) { out_cen[0] = c0; out_cen[1] = c1; out_cen[2] = c2; }
+        s_viol = 0;
+    }
+    // origin class: every empty pixel that is a candidate (header of this file)
+    int org_idx = N;
+    if (RANGE) { org_idx = info[RPCC_INFO * b + 4]; if (org_idx < 0 || org_idx > N) org_idx = N; }
+    bool org_on = RANGE && org_idx < N;
+    float ox = 0.0f, oy = 0.0f, oz = 0.0f, t_org = -1.0f;
+    if (org_on) {
+        fps_load_point<RANGE>(src, rays, org_idx, ox, oy, oz);   // 0 * ray: signed zeros
+        t_org = ld_f32(temp, (uint32_t)org_idx * 4u);
+        if (!(t_org >= 0.0f) || ld_f32(src, (uint32_t)org_idx * 4u) != 0.0f) { org_on = false; t_org = -1.0f; }
+    }
+    const float t_org0 = t_org;
+
+    // this lane's tile: position pos = lane * NW + wave in the skewed order -> tile id, packed origin
+    const int pos = lane * NW + wave;
+    const bool have = pos < T;
+    int my_t = 0;
+    uint32_t my_org = 0u;
+    if (have) {
+        if (RANGE) {
+            const int tr = pos / g.tcols, q = pos - tr * g.tcols;
+            int tc = q - (3 * tr) % g.tcols;
+            if (tc < 0) tc += g.tcols;
+            my_t = tr * g.tcols + tc;
+            const int ncol = min(32, g.W - 32 * tc), nrow = min(FPS_TROWS, g.H - FPS_TROWS * tr);
+            my_org = (uint32_t)(FPS_TROWS * tr * g.W + 32 * tc) | ((uint32_t)(ncol - 1) << 22) | ((uint32_t)(nrow - 1) << 27);
+        } else {
+            my_t = pos;
+        }
+    }
+    const float inf = __builtin_inff();
+    float lo0 = inf, lo1 = inf, lo2 = inf, hi0 = -inf, hi1 = -inf, hi2 = -inf, tmax = -1.0f, cx = 0.0f, cy = 0.0f, cz = 0.0f;
+    uint32_t targ = 0u;
+    const unsigned long long have_m = __ballot(have);
+    const int lrow = lane >> 3, lcol = 4 * (lane & 7);
+    // the quad of this lane in the tile owned by lane `l` (wave-uniform l)
+    auto locate = [&](int l, FpsQuad &q) {
+        if (RANGE) {
+            const uint32_t org = (uint32_t)__builtin_amdgcn_readlane((int)my_org, l);
+            const int ncol = (int)((org >> 22) & 31u) + 1, nrow = (int)(org >> 27) + 1;
+            const int nv = lrow < nrow ? min(max(ncol - lcol, 0), 4) : 0;
+            q.nval = nv;
+            q.p0 = nv > 0 ? (int)(org & 0x3FFFFFu) + lrow * g.W + lcol : 0;
+        } else {
+            const int p = __builtin_amdgcn_readlane(my_t, l) * FPS_TILE + 4 * lane;
+            q.nval = min(max(N - p, 0), 4);
+            q.p0 = q.nval > 0 ? p : 0;
+        }
+    };
+    auto store_entry = [&](int l, const FpsTileOut &o, bool with_box) {
+        if (lane == l) {
+            if (with_box) { lo0 = o.lo[0]; lo1 = o.lo[1]; lo2 = o.lo[2]; hi0 = o.hi[0]; hi1 = o.hi[1]; hi2 = o.hi[2]; }
+            tmax = o.wt; targ = o.widx; cx = o.wx; cy = o.wy; cz = o.wz;
+        }
+    };
+    // visits the tiles of the lanes in mask m, two at a time (all loads of a pair are in flight before either is used)
+    auto visit = [&](unsigned long long m, bool with_box) {
+        bool viol = false;
+        while (m) {
+            const int l0 = (int)__ffsll((long long)m) - 1;
+            m &= m - 1ull;
+            const bool two = m != 0ull;
+            const int l1 = two ? (int)__ffsll((long long)m) - 1 : l0;
+            m &= m - 1ull;
+            FpsQuad q0, q1;
+            locate(l0, q0);
+            fps_quad_load<RANGE, VEC>(src, rays, temp, q0);
+            locate(l1, q1);
+            fps_quad_load<RANGE, VEC>(src, rays, temp, q1);   // (a repeated tile for an odd count: loaded, not used)
+            FpsTileOut o;
+            if (fps_tile_update<RANGE, VEC>(q0, org_on, t_org0, c0, c1, c2, temp, with_box, o, viol)) store_entry(l0, o, with_box);
+            if (two && fps_tile_update<RANGE, VEC>(q1, org_on, t_org0, c0, c1, c2, temp, with_box, o, viol)) store_entry(l1, o, with_box);
+        }
+        if (with_box && __ballot(viol) != 0ull && lane == 0) s_viol = 1;
+    };
+    auto update_origin = [&]() {
+        if (org_on) {
+            const float dx = ox - c0, dy = oy - c1, dz = oz - c2;
+            const float d = (dx * dx + dy * dy) + dz * dz;
+            t_org = d < t_org ? d : t_org;
+        }
+    };
+    int par = 0;
+    // arg-max over all tiles and the origin class -> next centre (index and coordinates); one barrier
+    auto select_next = [&]() {
+        const uint32_t key = have ? fps_val_key(tmax) : 0u;
+        uint32_t vmax = dpp_max_u32(key);
+        uint32_t imin = dpp_min_u32(key == vmax ? targ : 0xFFFFFFFFu);
+        {
+            const unsigned long long mm = __ballot(key == vmax && targ == imin);
+            const int wl = mm ? (int)__ffsll((long long)mm) - 1 : 0;
+            const float wx = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(cx), wl));
+            const float wy = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(cy), wl));
+            const float wz = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(cz), wl));
+            if (lane == 0) { slot_k[par][wave] = make_uint2(vmax, vmax >= FPS_KEY_MIN ? imin : 0xFFFFFFFFu); slot_c[par][wave] = make_float4(wx, wy, wz, 0.0f); }
+        }
+        __syncthreads();
+        const uint2 kv = slot_k[par][lane % NW];
+        const float4 cc = slot_c[par][lane % NW];
+        par ^= 1;
+        vmax = dpp_max_u32(kv.x);
+        imin = dpp_min_u32(kv.x == vmax ? kv.y : 0xFFFFFFFFu);
+        const unsigned long long mm = __ballot(kv.x == vmax && kv.y == imin);
+        const int wl = mm ? (int)__ffsll((long long)mm) - 1 : 0;
+        const uint32_t okey = org_on ? fps_val_key(t_org) : 0u;
+        if (okey >= FPS_KEY_MIN && (okey > vmax || (okey == vmax && (uint32_t)org_idx < imin))) {
+            old = org_idx;
+            c0 = ox; c1 = oy; c2 = oz;
+        } else if (vmax < FPS_KEY_MIN || imin == 0xFFFFFFFFu) {  // no candidate anywhere: keep indices defined (the reference would fail)
+            old = 0;
+            fps_load_point<RANGE>(src, rays, 0, c0, c1, c2);
+        } else {
+            old = (int)imin;
+            c0 = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(cc.x), wl));
+            c1 = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(cc.y), wl));
+            c2 = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(cc.z), wl));
+        }
+    };
+
+    DBG_STAMP(8);
+    const bool have_tab = RANGE && tiletab != nullptr && info[RPCC_INFO * b + 3] == 1;
+    if (M > 1 && have_tab) {   // the ground-mask kernel ran the first pass: this lane's entry
+        if (have) {
+            const float4 *t4 = reinterpret_cast<const float4 *>(tiletab + (int64_t)b * FPS_TAB_ROWS * T);
+            const float4 a = t4[my_t], h = t4[T + my_t], c = t4[2 * T + my_t];
+            lo0 = a.x; lo1 = a.y; lo2 = a.z; tmax = a.w; hi0 = h.x; hi1 = h.y; hi2 = h.z; targ = f2u(h.w); cx = c.x; cy = c.y; cz = c.z;
+        }
+        update_origin();  // (idempotent: temp of the empty pixels already holds the first centre's distance)
+    } else if (M > 1) {
+        __syncthreads();   // s_viol = 0 visible
+        visit(have_m, true);
+        __syncthreads();
+        // the origin class must be uniform (it is when temp comes from rpcc_ground_mask); a caller-made temp that
+        // treats the empty pixels individually is handled by a second pass without the class
+        if (org_on && s_viol) {
+            org_on = false; t_org = -1.0f;
+            visit(have_m, true);
+        }
+        update_origin();
+    }
+    if (M > 1) {
+        DBG_STAMP(9);
+        select_next();
+        DBG_STAMP(10);
+        if (tid == 0) { out_idx[1] = old; if (out_cen) { out_cen[3] = c0; out_cen[4] = c1; out_cen[5] = c2; } }
+    }
+    for (int j = 2; j < M; j++) {
+        // this wavefront's tiles against the new centre
+        const float g0 = fmaxf(fmaxf(lo0 - c0, c0 - hi0), 0.0f);
+        const float g1 = fmaxf(fmaxf(lo1 - c1, c1 - hi1), 0.0f);
+        const float g2 = fmaxf(fmaxf(lo2 - c2, c2 - hi2), 0.0f);
+        const float bound = (g0 * g0 + g1 * g1) + g2 * g2;
+        visit(__ballot(have && bound < tmax), false);
+        update_origin();
+        select_next();
+        if (tid == 0) { out_idx[j] = old; if (out_cen) { out_cen[3 * j] = c0; out_cen[3 * j + 1] = c1; out_cen[3 * j + 2] = c2; } }
+    }
+    DBG_STAMP(16);
+    if (RANGE && org_on && (flags & FPS_FLAG_FINALIZE_TEMP)) {
+        __syncthreads();
         for (int p = tid; p < N; p += FPS_TT) {
             const float r = ld_f32(src, (uint32_t)p * 4u), tv = ld_f32(temp, (uint32_t)p * 4u);
             if (r == 0.0f && tv >= 0.0f && tv != t_org) st_f32(temp, (uint32_t)p * 4u, t_org);

@@ -98,6 +98,7 @@ struct PlaneParams {
     int iters;           // 10
     uint32_t seed;
     const int64_t *frame_ids;  // dev i64 [B] or nullptr: the frame's identity for seeding (nullptr: its index in the batch)
+    const double *inject;      // dev f64 [B,K,4] or nullptr: planes that replace the RANSAC result (test hook: pins the glue)
 };
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -366,7 +367,8 @@ struct PlaneWgLds {
     int sbest[32];
 };
 __device__ void plane_label_wg(const float *__restrict__ tm, const uint32_t *__restrict__ order, const float4 *__restrict__ pl_pts,
-                               int n, uint32_t seed, const PlaneParams &pp, PlaneWgLds &S, NpwLds *NW_, float *__restrict__ row) {
+                               int n, uint32_t seed, const PlaneParams &pp, PlaneWgLds &S, NpwLds *NW_, float *__restrict__ row,
+                               const double *__restrict__ inject) {
     const int tid = threadIdx.x;
     bool use_plane = false;
     double plane[4] = {0, 0, 0, 0};
@@ -374,6 +376,7 @@ __device__ void plane_label_wg(const float *__restrict__ tm, const uint32_t *__r
         LabelPoints pts;
         pts.pts = pl_pts; pts.n = n;
         ransac_plane_wg<4, PL_THREADS, PL_MAXH, 4>(pts, pp.iters, (double)pp.thr, seed, plane, S.sred, S.swin, S.sbest);
+        if (inject) { plane[0] = inject[0]; plane[1] = inject[1]; plane[2] = inject[2]; plane[3] = inject[3]; }
         // plane_angle_validation (segment_utils.py:84-93)
         const double a = plane[0], bb = plane[1], c = plane[2];
         const double nrm = sqrt((a * a + bb * bb) + c * c);
@@ -434,7 +437,7 @@ __global__ __launch_bounds__(PL_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8
         if (nn <= big) continue;
         const uint32_t base = hist[((int64_t)b * T) * KP + kk];  // tile 0 offset = start of label kk in the ordered list
         plane_label_wg(tm, order_all + (int64_t)b * P + base, pts_all + (int64_t)b * P + base, nn, mix32(pp.seed, fid, (uint32_t)kk),
-                       pp, S, npw, model + ((int64_t)b * K + kk) * 4);
+                       pp, S, npw, model + ((int64_t)b * K + kk) * 4, pp.inject ? pp.inject + ((int64_t)b * K + kk) * 4 : nullptr);
     }
     const int k = k0 + wave;
     if (k >= K) return;
@@ -457,6 +460,10 @@ __global__ __launch_bounds__(PL_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8
     if (n >= pp.min_points) {
         const uint32_t seed = mix32(pp.seed, fid, (uint32_t)k);
         ransac_plane_wave<4, MAXH>(pts, n, pp.iters, pp.thr, seed, plane);
+        if (pp.inject) {
+            const double *ij = pp.inject + ((int64_t)b * K + k) * 4;
+            plane[0] = ij[0]; plane[1] = ij[1]; plane[2] = ij[2]; plane[3] = ij[3];
+        }
         // plane_angle_validation (segment_utils.py:84-93)
         const double a = plane[0], bb = plane[1], c = plane[2];
         const double nrm = sqrt((a * a + bb * bb) + c * c);

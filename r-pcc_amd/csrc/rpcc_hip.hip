@@ -1201,6 +1201,20 @@ template <bool RANGE>
 static int launch_fps_tiled(const float *src, const float *rays, float *temp, const int32_t *info, int B, const FpsTiling &g,
                             int M, int kflags, int32_t *idx, float *cen, const float *tiletab, bool vec, hipStream_t st) {
     const size_t sh = fps_tiled_lds_bytes(g.T);
+    // register-table form: every tile owned by one lane (at most 64 tiles per wavefront)
+#define FPS_RT_LAUNCH(VEC_, TT_) fps_regtab_kernel<RANGE, VEC_, TT_><<<B, TT_, 0, st>>>(src, rays, temp, info, g, M, kflags, idx, cen, tiletab)
+#ifndef FPS_NO_REGTAB
+    {
+        const int tt = B <= 128 ? FPS_TT_SMALL : FPS_TT_BATCH;
+        if (g.T <= tt) {
+            if (B <= 128) { if (vec) FPS_RT_LAUNCH(true, FPS_TT_SMALL); else FPS_RT_LAUNCH(false, FPS_TT_SMALL); }
+            else          { if (vec) FPS_RT_LAUNCH(true, FPS_TT_BATCH); else FPS_RT_LAUNCH(false, FPS_TT_BATCH); }
+            LAUNCH_CHECK();
+            return RPCC_OK;
+        }
+    }
+#endif
+#undef FPS_RT_LAUNCH
 #define FPS_LAUNCH(VEC_, TT_)                                                                                        \
     do {                                                                                                             \
         HIP_TRY(ensure_dyn_lds(reinterpret_cast<const void *>(&fps_tiled_kernel<RANGE, VEC_, TT_>), (int)sh));       \
@@ -2005,14 +2019,14 @@ static int launch_label_scan(const uint8_t *seg, int B, int P, int M, int32_t *c
 // plane rows from a segmentation whose tile offsets (launch_label_scan) are in ws; extra = order | pts4 scratch
 static int launch_plane_rows(const float *ri, const float *tm, const uint8_t *seg, const double *ground, int B, int P, int M,
                              double cos_cut, uint32_t seed, const int64_t *frame_ids, float *model, const int32_t *counts,
-                             void *ws, void *extra, hipStream_t st) {
+                             void *ws, void *extra, hipStream_t st, const double *inject = nullptr) {
     const int KP = kpad(M), T = ntiles(P), K = M + 2;
     WsLayout L = ws_layout(ws, B, P, M);
     uint32_t *order = reinterpret_cast<uint32_t *>(extra);
     float4 *pts4 = reinterpret_cast<float4 *>(reinterpret_cast<char *>(order) + (((size_t)B * P * 4 + 255) & ~(size_t)255));
     label_order_kernel<<<dim3(T, B), 256, (size_t)16 * (KP + 1) * 4 + (size_t)KP * 4, st>>>(seg, L.hist, P, M, KP, T, order, ri, tm, pts4);
     PlaneParams pp;
-    pp.cos_cut = cos_cut; pp.thr = 0.1f; pp.min_points = 30; pp.iters = 10; pp.seed = seed; pp.frame_ids = frame_ids;
+    pp.cos_cut = cos_cut; pp.thr = 0.1f; pp.min_points = 30; pp.iters = 10; pp.seed = seed; pp.frame_ids = frame_ids; pp.inject = inject;
     plane_model_kernel<10><<<dim3((K + PL_THREADS / 64 - 1) / (PL_THREADS / 64), B), PL_THREADS, 0, st>>>(tm, order, pts4, L.hist, counts, ground, P, M,
                                                                                                      KP, T, pp, PL_BIG, model);
     LAUNCH_CHECK();
@@ -2020,14 +2034,14 @@ static int launch_plane_rows(const float *ri, const float *tm, const uint8_t *se
 }
 
 extern "C" int rpcc_plane_model(const float *ri, const float *tm, const uint8_t *seg, const double *ground, int B, int P,
-                                int M, double cos_cut, uint32_t seed, const int64_t *frame_ids, float *model,
-                                int32_t *counts, void *ws, void *stream) {
+                                int M, double cos_cut, uint32_t seed, const int64_t *frame_ids, const double *inject_planes,
+                                float *model, int32_t *counts, void *ws, void *stream) {
     ARG_TRY(B > 0 && B <= RPCC_MAX_BATCH && P > 0 && M > 0 && M <= RPCC_MAX_CLUSTERS && ri && tm && seg && model && counts && ws);
     hipStream_t st = (hipStream_t)stream;
     int rc;
     if ((rc = launch_label_scan(seg, B, P, M, counts, nullptr, ws, st, false))) return rc;
     return launch_plane_rows(ri, tm, seg, ground, B, P, M, cos_cut, seed, frame_ids, model, counts, ws,
-                             reinterpret_cast<char *>(ws) + ws_layout(nullptr, B, P, M).bytes + 256, st);
+                             reinterpret_cast<char *>(ws) + ws_layout(nullptr, B, P, M).bytes + 256, st, inject_planes);
 }
 
 // ================================================================================================

@@ -393,8 +393,9 @@ def angle_cos_cut(angle_threshold_deg):
     return float(lo)
 
 
-def plane_model(ri, tm, seg, M, angle_threshold=75, seed=0, ground=None, want_counts=False, frame_ids=None):
-    """a9 -> model f32 [B,K,4] (and counts i32 [B,K]).  Label k of frame b draws with hash(seed, frame_ids[b], k)."""
+def plane_model(ri, tm, seg, M, angle_threshold=75, seed=0, ground=None, want_counts=False, frame_ids=None, inject=None):
+    """a9 -> model f32 [B,K,4] (and counts i32 [B,K]).  Label k of frame b draws with hash(seed, frame_ids[b], k).
+    inject f64 [B,K,4] (test hook): planes used instead of the RANSAC results."""
     B = ri.shape[0]
     P = ri[0].numel()
     K = M + 2
@@ -403,7 +404,7 @@ def plane_model(ri, tm, seg, M, angle_threshold=75, seed=0, ground=None, want_co
     counts = torch.empty((B, K), dtype=torch.int32, device=_dev(ri))
     fid = _frame_ids(frame_ids, B, _dev(ri))
     check(_lib.lib().rpcc_plane_model(ptr(ri), ptr(tm), ptr(seg), ptr(ground), B, P, M, angle_cos_cut(angle_threshold),
-                                      int(seed) & 0xFFFFFFFF, ptr(fid), ptr(model), ptr(counts), ptr(ws), stream()))
+                                      int(seed) & 0xFFFFFFFF, ptr(fid), ptr(inject), ptr(model), ptr(counts), ptr(ws), stream()))
     return (model, counts) if want_counts else model
 
 

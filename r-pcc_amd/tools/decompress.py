@@ -22,11 +22,29 @@ from rpcc_amd.tools.compress import make_parser, resolve_cfg  # noqa: E402
 def decode_frame(blob_dict, basic_compressor, transformer, cluster_num, accuracy, level_acc, uniform, want_points=True):
     """decompress_point_cloud + dequantise + predict + back-project (tools/decompress.py:79-112)."""
     H, W = transformer.H, transformer.W
-    import bz2  # noqa: F401  (entropy back-ends live in BasicCompressor)
     d = basic_compressor.decompress_dict(blob_dict)
+    # The .rpcc file stores no configuration (as in the reference): a wrong --lidar / cluster_num / framework shows up as
+    # payload sizes that do not fit.  Check them here instead of letting the kernels index past their buffers.
+    P, K = H * W, cluster_num + 2
+    if len(d["plane_param"]) % 16 != 0:
+        raise ValueError("plane_param payload is not a whole number of float32 [.,4] rows")
     plane_param = np.frombuffer(d["plane_param"], dtype=np.float32).reshape(-1, 4)
+    if plane_param.shape[0] > K:
+        raise ValueError("bitstream holds %d model rows, the configuration allows cluster_num + 2 = %d" % (plane_param.shape[0], K))
+    if len(d["contour_map"]) != (P + 7) // 8:
+        raise ValueError("contour_map holds %d bytes, a %dx%d range image needs %d (wrong --lidar?)"
+                         % (len(d["contour_map"]), H, W, (P + 7) // 8))
+    if len(d["idx_sequence"]) % 2 or len(d["residual_quantized"]) % 2:
+        raise ValueError("idx_sequence / residual_quantized payloads are not 16-bit arrays")
+    s_chk = np.frombuffer(d["idx_sequence"], dtype=np.uint16)
+    n_contour = int(np.unpackbits(np.frombuffer(d["contour_map"], dtype=np.uint8))[:P].sum())
+    if s_chk.size != n_contour:
+        raise ValueError("idx_sequence holds %d labels, the contour map marks %d runs" % (s_chk.size, n_contour))
+    if s_chk.size and int(s_chk.max()) >= plane_param.shape[0]:
+        raise ValueError("idx_sequence names label %d but only %d model rows are stored" % (int(s_chk.max()), plane_param.shape[0]))
+    if not uniform and len(d.get("salience_level", b"")) > K:
+        raise ValueError("salience_level holds more entries than labels")
     dev = transformer.device
-    K = cluster_num + 2
     model = torch.zeros((1, K, 4), dtype=torch.float32, device=dev)
     model[0, : plane_param.shape[0]] = torch.from_numpy(plane_param.copy()).to(dev)
     bits = torch.from_numpy(np.frombuffer(d["contour_map"], dtype=np.uint8).copy()[None]).to(dev)
@@ -36,6 +54,9 @@ def decode_frame(blob_dict, basic_compressor, transformer, cluster_num, accuracy
     seg = ops.contour_decode(bits, seq, H, W, cluster_num)
     q = torch.zeros((1, H * W), dtype=torch.int16, device=dev)
     qq = np.frombuffer(d["residual_quantized"], dtype=np.int16)
+    n_nonempty = int((seg != 1).sum().item())
+    if qq.size != n_nonempty:
+        raise ValueError("residual_quantized holds %d values, the label map has %d non-empty pixels" % (qq.size, n_nonempty))
     q[0, : qq.size] = torch.from_numpy(qq.copy()).to(dev)
     if uniform:
         rec, pc = ops.decode(seg, q, model, transformer.tm_dev, accuracy, want_points=want_points)

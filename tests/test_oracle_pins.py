@@ -1,0 +1,86 @@
+"""The CPU oracle against the round-2 fixture set (tests/golden/pins_*.npz, produced by gen_golden_pins.py from the GENUINE
+reference): cluster_modeling('plane') + plane_angle_validation with injected plane rows (a9 glue), everything downstream
+of it (prediction with plane rows, both quantisers, the .rpcc bytes), and the decoder (f3)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PINS = json.load(open(os.path.join(HERE, "golden", "pins_manifest.json")))
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def load_case(name):
+    c = PINS[name]
+    base = np.load(os.path.join(HERE, "golden", c["base"] + ".npz"))
+    z = np.load(os.path.join(HERE, "golden", "pins_" + name + ".npz"))
+    xyz = base["xyz"]
+    if c["min_range"] > 0:
+        xyz = np.ascontiguousarray(xyz[np.sqrt((xyz.astype(np.float64) ** 2).sum(1)) >= c["min_range"]])
+    assert xyz.shape[0] == c["n_points"]
+    g = orc.LidarGeom(**orc.GEOMS[c["geom"]])
+    return c, z, xyz, base["ground_model"], g, orc.transform_map(g), base
+
+
+@pytest.fixture(scope="module", params=sorted(PINS))
+def case(request):
+    return (request.param,) + load_case(request.param)
+
+
+def test_fixture_covers_the_branches():
+    """The injected rows exercise acceptance, rejection by the angle check, NaN rows, small labels and an empty label."""
+    assert any(c["empty_labels"] > 0 for c in PINS.values())
+    assert all(c["small_labels"] > 0 for c in PINS.values())
+    assert any(c["nan_rows"] > 0 for c in PINS.values())
+    assert all(0 < c["plane_rows_kept"] < c["ransac_calls"] for c in PINS.values())
+
+
+def test_plane_model_glue_matches_reference(case):
+    name, c, z, xyz, gm, g, tm, _ = case
+    ri = orc.project(xyz, g)
+    s = orc.segment(ri, tm, gm)
+    with np.errstate(all="ignore"):
+        cm = orc.cluster_modeling_plane(s["pc"], ri, s["seg_idx"], tm, 75, inject=list(z["plane_rows"]))
+    assert cm.shape == z["cluster_models"].shape
+    assert np.array_equal(cm.view(np.uint64), z["cluster_models"].view(np.uint64))
+    assert sha(cm) == c["sha"]["cluster_models"]
+    mp = np.concatenate((np.asarray(gm, np.float64).reshape(1, 4), cm), 0)
+    for uniform, qk, rk in ((True, "q_uniform_plane", "rpcc_uniform_plane"), (False, "q_nonuniform_plane", "rpcc_nonuniform_plane")):
+        o = orc.compress_frame(xyz, g, tm, gm, uniform=uniform, model_param=mp)
+        if uniform:
+            assert sha(o["pred"]) == c["sha"]["pred_plane"]
+        else:
+            assert np.array_equal(o["salience"].astype(np.uint8), z["salience_plane"])
+        assert np.array_equal(o["q"].astype(np.int16), z[qk])
+        blob = orc.bitstream_bytes(orc.pack_payload(mp, o["seg_idx"], o["salience"], o["q"]), uniform=uniform)
+        assert blob == z[rk].tobytes()
+        assert hashlib.sha256(blob).hexdigest() == c["sha"][rk]
+
+
+@pytest.mark.parametrize("kind", ["uniform_point", "uniform_plane", "nonuniform_plane"])
+def test_decoder_matches_reference(case, kind):
+    name, c, z, xyz, gm, g, tm, base = case
+    if kind == "uniform_point":
+        blob = (z["rpcc_uniform_point"] if "rpcc_uniform_point" in z.files else base["rpcc"]).tobytes()
+    else:
+        blob = z["rpcc_" + kind].tobytes()
+    d = orc.decode_frame(blob, g, tm, 0.02, uniform=kind.startswith("uniform"))
+    assert sha(d["residual"].astype(np.float32)) == c["sha"]["residual_" + kind]
+    assert sha(d["ri_rec"].astype(np.float32)) == c["sha"]["ri_rec_" + kind]
+    assert sha(d["pc_rec"]) == c["sha"]["pc_rec_" + kind]
+    if "ri_rec_" + kind in z.files:
+        assert np.array_equal(d["ri_rec"].astype(np.float32).view(np.uint32), z["ri_rec_" + kind].view(np.uint32))
+    ri = orc.project(xyz, g)
+    err = float(np.abs(d["ri_rec"][..., 0] - ri)[ri != 0].max())
+    exp = c["max_err"][kind]
+    assert (np.isnan(err) and np.isnan(exp)) or abs(err - exp) < 1e-12     # NaN: labels modelled by an injected NaN row
+    if kind == "uniform_point":
+        assert err <= 0.02 + 1e-5                                           # README.md:101-106
