@@ -19,6 +19,7 @@ import numpy as np  # noqa: E402
 
 import rpcc_amd  # noqa: E402,F401
 from rpcc_amd.dataset import build_dataset  # noqa: E402
+from rpcc_amd.loader import StreamingCompressor  # noqa: E402
 from rpcc_amd.pipeline import BatchCompressor  # noqa: E402
 from rpcc_amd.sharding import shard_indices  # noqa: E402
 from rpcc_amd.tools.compress import make_parser, resolve_cfg  # noqa: E402
@@ -34,6 +35,30 @@ def output_path_for(output_dir, file_name):
     return out.replace(out.split(".")[-1], "rpcc")
 
 
+def _prefetch(gen, depth=2):
+    """Runs a generator on a background thread, `depth` items ahead (file reads overlap the device and the entropy coder)."""
+    import queue
+    import threading
+    q = queue.Queue(maxsize=depth)
+    END = object()
+
+    def work():
+        try:
+            for item in gen:
+                q.put(item)
+            q.put(END)
+        except BaseException as e:  # noqa: BLE001
+            q.put(e)
+    threading.Thread(target=work, daemon=True).start()
+    while True:
+        item = q.get()
+        if item is END:
+            return
+        if isinstance(item, BaseException):
+            raise item
+        yield item
+
+
 def compress(args):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -47,13 +72,22 @@ def compress(args):
                          basic_compressor=basic_compressor.method_name, seed=args.seed)
     mine = shard_indices(len(dataset), rank, world)
     t0 = time.time()
-    total_bytes = 0
+    stats = {"bytes": 0}
     with futures.ThreadPoolExecutor(args.workers) as pool:
-        for s in range(0, len(mine), args.batch):
-            idx = mine[s:s + args.batch]
-            names = [dataset.data_list[i] for i in idx]
-            frames = list(pool.map(dataset.load_data, names))
-            blobs = bc.compress(frames, pool=pool, frame_ids=[frame_identity(n) for n in names])   # device part, then the entropy coder on the pool's threads
+        # staged, double-buffered feed (loader.StreamingCompressor): file reads of batch n+1, device work of batch n and
+        # entropy coding + file output of batch n-1 overlap
+        sc = StreamingCompressor(bc, batch=min(args.batch, max(len(mine), 1)), depth=4, workers=args.workers, pool=pool)
+        names_of = {}
+
+        def batches():
+            for k, s in enumerate(range(0, len(mine), sc.B)):
+                names = [dataset.data_list[i] for i in mine[s:s + sc.B]]
+                names_of[k] = names
+                frames = list(pool.map(dataset.load_data, names))
+                yield frames, [frame_identity(n) for n in names]
+
+        def sink(k, blobs):
+            names = names_of.pop(k)
 
             def write(job):
                 name, blob = job
@@ -62,13 +96,14 @@ def compress(args):
                 with open(out, "wb") as f:
                     f.write(blob)
                 return len(blob)
-            total_bytes += sum(pool.map(write, zip(names, blobs)))
+            stats["bytes"] += sum(pool.map(write, zip(names, blobs)))
             if args.output:
-                for name, blob, fr in zip(names, blobs, frames):
-                    print("%s: %d points -> %d bytes" % (name, fr.shape[0], len(blob)))
+                for name, blob in zip(names, blobs):
+                    print("%s -> %d bytes" % (name, len(blob)))
+        sc.run(_prefetch(batches()), sink=sink, entropy=True)
     dt = time.time() - t0
     print("rank %d/%d: %d frames in %.3f s (%.1f frames/s incl. file I/O and entropy coding), %d bytes"
-          % (rank, world, len(mine), dt, len(mine) / max(dt, 1e-9), total_bytes))
+          % (rank, world, len(mine), dt, len(mine) / max(dt, 1e-9), stats["bytes"]))
 
 
 if __name__ == "__main__":

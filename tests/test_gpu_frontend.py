@@ -106,8 +106,8 @@ def test_cli_roundtrip(fe, tmp_path):
     assert os.path.getsize(produced) > 20000
 
 
-@pytest.mark.parametrize("lidar,geom,accuracy", [("Velodyne64E", "Velodyne64E", 0.02), ("Velodyne32E", "Velodyne32E", 0.01),
-                                                 ("VelodyneVLP16", "VelodyneVLP16", 0.05)])
+@pytest.mark.parametrize("accuracy", [0.01, 0.02, 0.05])
+@pytest.mark.parametrize("lidar,geom", [("Velodyne64E", "Velodyne64E"), ("Velodyne32E", "Velodyne32E"), ("VelodyneVLP16", "VelodyneVLP16")])
 def test_nonuniform_plane_batches_mixed_lidars(fe, lidar, geom, accuracy):
     """BASELINE configs[2]/[4]: non-uniform framework + plane model, one batch per lidar geometry, accuracy
     sweep.  The batch path must equal the oracle run stage by stage with the same (fitted) models, and the
@@ -251,3 +251,36 @@ def test_entropy_coding_on_a_thread_pool(fe):
     serial = bc.compress(frames)
     with ThreadPoolExecutor(4) as pool:
         assert bc.compress(frames, pool=pool) == serial
+
+
+def test_streaming_loader_matches_batch_compressor(fe):
+    """f4: loader.StreamingCompressor (pinned staging ring, H2D on a copy stream, submit(n+1) before collect(n), entropy
+    coding on the pool) gives the .rpcc bytes of BatchCompressor.compress -- full batches, a short last batch, a frame
+    without points, .bin-style [N,4] input rows, both frameworks."""
+    from oracle import oracle as orc
+    from rpcc_amd import synth
+    from rpcc_amd.loader import StreamingCompressor
+    gd = orc.GEOMS["VelodyneVLP16"]
+    ds = fe.ds.build_dataset(lidar_type="VelodyneVLP16")
+    frames = [synth.make_frame(700 + i, gd["H"], gd["W"], vmax_deg=gd["vmax_deg"], vmin_deg=gd["vmin_deg"]).numpy() for i in range(11)]
+    frames[4] = np.zeros((0, 3), np.float32)
+    frames4 = [np.concatenate([f, np.ones((f.shape[0], 1), np.float32)], 1) for f in frames]      # x, y, z, intensity
+    ids = [9000 + 7 * i for i in range(len(frames))]
+    for kw in (dict(), dict(uniform=False, model_method="plane")):
+        bc = fe.pl.BatchCompressor(ds.PCTransformer, accuracy=0.02, seed=5, **kw)
+        want = []
+        for s in range(0, len(frames), 4):
+            want += bc.compress(frames[s:s + 4] + [np.zeros((0, 3), np.float32)] * (4 - len(frames[s:s + 4])),
+                                frame_ids=(ids[s:s + 4] + [0] * 4)[:4])[:len(frames[s:s + 4])]
+        sc = StreamingCompressor(bc, batch=4, depth=3, workers=4)
+        got = {}
+        n = sc.run(((frames4[s:s + 4], ids[s:s + 4]) for s in range(0, len(frames), 4)), sink=lambda k, r: got.__setitem__(k, r))
+        assert n == len(frames)
+        flat = [b for k in sorted(got) for b in got[k]]
+        assert flat == want, kw
+        raw = {}
+        sc.run(((frames[s:s + 4], ids[s:s + 4]) for s in range(0, len(frames), 4)), entropy=False,
+               sink=lambda k, r: raw.__setitem__(k, [{kk: np.array(v) for kk, v in r.frame(b).items()} for b in range(len(r))]))
+        assert sum(len(v) for v in raw.values()) == len(frames)
+        bz = fe.cu.BasicCompressor(method_name="bzip2")
+        assert [fe.cu.pack_bitstream(bz.compress_dict(od), uniform=bc.uniform) for k in sorted(raw) for od in raw[k]] == want

@@ -261,3 +261,60 @@ def test_rccl_single_rank_exchange(env):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def _trimmed_least_squares(pts, plane0, thr=0.1, iters=30):
+    """Dense reference fit: least squares (SVD) on the points within `thr` of the current plane, iterated to a fixed
+    point from `plane0` -- what RANSAC + refit approximates with 100 random hypotheses."""
+    n, d = np.asarray(plane0[:3], np.float64), float(plane0[3])
+    nn = np.linalg.norm(n)
+    n, d = n / nn, d / nn
+    p = pts.astype(np.float64)
+    last = None
+    for _ in range(iters):
+        inl = np.abs(p @ n + d) < thr
+        if inl.sum() < 3 or (last is not None and np.array_equal(inl, last)):
+            break
+        last = inl
+        c = p[inl].mean(0)
+        _, _, vt = np.linalg.svd(p[inl] - c, full_matrices=False)
+        n = vt[-1]
+        d = -float(n @ c)
+    return n, d
+
+
+def test_ground_ransac_statistics(env):
+    """a4: the reference's ground fit is Open3D's random RANSAC, so bit parity is undefined; what must hold is
+    the QUALITY of the fit.  Over 256 synthetic sweeps and the reference's example.bin: against a trimmed least-squares fit
+    iterated to convergence on the same candidate set, the seeded RANSAC's plane keeps >= 98 % of the inliers and its
+    normal lies within 0.2 degrees."""
+    torch, ops, synth, orc = env["torch"], env["ops"], env["synth"], env["orc"]
+    g, tm = env["g"], env["tm"]
+    B = 256
+    xyz, offs = synth.make_batch(range(21000, 21000 + B), g.H, g.W, device=env["dev"])
+    ri = ops.project(xyz, offs, env["geom"])
+    planes, inl = ops.ground_ransac(ri, env["d_tm"], seed=11)
+    ri_h, planes_h, inl_h = ri.cpu().numpy(), planes.cpu().numpy(), inl.cpu().numpy()
+    cases = [(ri_h[b], tm, planes_h[b], int(inl_h[b])) for b in range(B)]
+    here = os.path.dirname(os.path.abspath(__file__))
+    z = np.load(os.path.join(here, "golden", "example_64E.npz"))
+    g2 = orc.LidarGeom(**orc.GEOMS["Velodyne64E"])
+    tm2 = orc.transform_map(g2)
+    geom2 = ops.make_geom(g2.H, g2.W, g2.horizontal_FOV, g2.vertical_max, g2.vertical_min)
+    ri2 = ops.project(torch.from_numpy(z["xyz"]).to(env["dev"]), torch.tensor([0, z["xyz"].shape[0]], dtype=torch.int64, device=env["dev"]), geom2)
+    p2, i2 = ops.ground_ransac(ri2, torch.from_numpy(tm2).to(env["dev"]), seed=11)
+    cases.append((ri2[0].cpu().numpy(), tm2, p2[0].cpu().numpy(), int(i2[0])))
+    worst_ratio, worst_angle = 1.0, 0.0
+    for k, (r, t, pl, n_inl) in enumerate(cases):
+        cand = orc.ground_candidates(r, t)
+        assert cand.shape[0] >= 800, k
+        mine = int((np.abs(cand.astype(np.float64) @ pl[:3] + pl[3]) < 0.1).sum())
+        n, d = _trimmed_least_squares(cand, pl)
+        ref = int((np.abs(cand.astype(np.float64) @ n + d) < 0.1).sum())
+        ang = np.degrees(np.arccos(min(1.0, abs(float(n @ pl[:3])) / np.linalg.norm(pl[:3]))))
+        worst_ratio, worst_angle = min(worst_ratio, mine / max(ref, 1)), max(worst_angle, ang)
+        assert mine >= 0.98 * ref, (k, mine, ref)
+        assert ang <= 0.2, (k, ang)
+        assert abs(np.linalg.norm(pl[:3]) - 1.0) < 1e-9 and mine >= 0.5 * cand.shape[0], k       # a unit normal, a real ground plane
+    print("ground RANSAC vs trimmed least squares over %d frames: worst inlier ratio %.4f, worst normal angle %.4f deg"
+          % (len(cases), worst_ratio, worst_angle))
