@@ -238,7 +238,9 @@ __global__ __launch_bounds__(256) void project_finalize_kernel(uint32_t *__restr
 // from L2 / Infinity Cache.  Frames that contain a depth-0 point are left to the exact input-order
 // passes above.
 #define BAND_PX 32768  // 128 KiB of LDS
+#ifndef BAND_THREADS
 #define BAND_THREADS 1024
+#endif
 
 // ---- screened fast path of the pixel computation -----------------------------------------------------------
 // project_point() costs ~330 VALU instructions per wavefront, almost all of it the two fdlibm atan2f
@@ -634,7 +636,9 @@ extern "C" int rpcc_project(const float *xyz, const int64_t *offsets, int64_t to
 //   score       inlier count (|n.p+d| < thr), ties -> lower hypothesis id
 //   refit       the same closed form on the winner's inliers; fp64 sums in a fixed order (256 strided
 //               partials, then a binary tree)
+#ifndef RS_THREADS
 #define RS_THREADS 1024
+#endif
 #define RS_NT 256
 #define RS_MAX_LIST 5120
 #define RS_MAX_HYP 128
