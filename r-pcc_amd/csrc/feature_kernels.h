@@ -48,7 +48,8 @@ typedef unsigned long long feat_key;  // curvature bits << 32 | compacted positi
 template <int Q>                      // keys per lane: chunk <= 64 * Q
 __global__ __launch_bounds__(FEAT_THREADS) void features_kernel(const float *__restrict__ ri, const uint8_t *__restrict__ seg,
                                                                 int H, int W, FeatParams fp, float *__restrict__ feat,
-                                                                uint8_t *__restrict__ kp) {
+                                                                uint8_t *__restrict__ kp, int32_t *__restrict__ kpn = nullptr,
+                                                                int K = 0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
     __shared__ int wcnt[FEAT_THREADS / 64];
     float *row = reinterpret_cast<float *>(fsm);
@@ -235,8 +236,11 @@ __global__ __launch_bounds__(FEAT_THREADS) void features_kernel(const float *__r
     for (int c = tid; c < W; c += FEAT_THREADS) {
         if (feat) feat[base + c] = v[c];
         kp[base + c] = kprow[c];
+        // key points per label for the salience levels (sparse: a few dozen per row); kpn is zeroed by the caller
+        if (kpn && kprow[c] > 0) atomicAdd(&kpn[(int64_t)b * K + seg[base + c]], 1);
     }
 }
+
 
 // a13 (salience): per label p_num (pixels, label 1 excluded by the caller's quantiser anyway) and kp_num
 // (key points > 0); level: label 0 -> ground_level, label 1 -> L-1, p_num < 30 -> L-1, else the first
@@ -293,6 +297,25 @@ __global__ __launch_bounds__(SAL_THREADS) void salience_kernel(const uint8_t *__
         salience[(int64_t)b * K + k] = (uint8_t)lv;
         label_acc[(int64_t)b * K + k] = sp.level_acc[lv];
     }
+}
+
+// a13 (salience) from per-label totals: pixels per label (the model scan's counts) and key points per label (counted by
+// features_kernel): the same rule as salience_kernel below without another pass over the frame.
+__global__ __launch_bounds__(256) void salience_levels_kernel(const int32_t *__restrict__ counts, const int32_t *__restrict__ kpn,
+                                                              int M, SalienceParams sp, uint8_t *__restrict__ salience,
+                                                              float *__restrict__ label_acc) {
+    const int b = blockIdx.x, K = M + 2, k = threadIdx.x;
+    if (k >= K) return;
+    const int pn = counts[(int64_t)b * K + k], kn = kpn[(int64_t)b * K + k];
+    int lv = 0;
+    if (k == 0) lv = sp.ground_level;
+    else if (k == 1) lv = sp.levels - 1;
+    else if (pn < 30) lv = sp.levels - 1;
+    else
+        for (int l = 0; l < sp.levels; l++)
+            if (kn >= sp.level_kp_num[l]) { lv = l; break; }
+    salience[(int64_t)b * K + k] = (uint8_t)lv;
+    label_acc[(int64_t)b * K + k] = sp.level_acc[lv];
 }
 
 // a10 as its own entry: intra_predict (cpp_modules.cpp:248-285)

@@ -637,7 +637,7 @@ extern "C" int rpcc_project(const float *xyz, const int64_t *offsets, int64_t to
 //   refit       the same closed form on the winner's inliers; fp64 sums in a fixed order (256 strided
 //               partials, then a binary tree)
 #ifndef RS_THREADS
-#define RS_THREADS 1024
+#define RS_THREADS 512   // 1024 is no faster alone and co-schedules worse with the other batches' kernels
 #endif
 #define RS_NT 256
 #define RS_MAX_LIST 5120
@@ -1516,8 +1516,8 @@ static WsLayout ws_layout(void *ws, int B, int P, int M) {
     return L;
 }
 // Workspace of one batch: [ model part | projection scratch | FPS temp | planar rays | FPS tile table ]
-static size_t plane_extra_bytes(int B, int P, int M) {   // label-ordered pixel list u32 [B,P] | points float4 [B,P] | label steps f32 [B,K]
-    return (((size_t)B * P * 4 + 255) & ~(size_t)255) + (size_t)B * P * 16 + (((size_t)B * (M + 2) * 4 + 255) & ~(size_t)255) + 256;
+static size_t plane_extra_bytes(int B, int P, int M) {   // label-ordered pixel list u32 [B,P] | points float4 [B,P] | key points per label i32 [B,K] | label steps f32 [B,K]
+    return (((size_t)B * P * 4 + 255) & ~(size_t)255) + (size_t)B * P * 16 + 2 * (((size_t)B * (M + 2) * 4 + 255) & ~(size_t)255) + 256;
 }
 static size_t slice_workspace_bytes(int B, int P, int M, int64_t total_points) {
     const size_t model_ws = ws_layout(nullptr, B, P, M).bytes;
@@ -1945,7 +1945,7 @@ extern "C" int rpcc_backproject(const float *ri, const float *tm, int B, int P, 
 // feat may be NULL (the fused entry only needs the key-point map)
 static int launch_features(const float *ri, const uint8_t *seg, int B, int H, int W, int feature_region, int segments,
                            int sharp_num, int less_sharp_num, int flat_num, float *feat, uint8_t *key_point_map,
-                           hipStream_t st) {
+                           hipStream_t st, int32_t *kpn = nullptr, int K = 0) {
     ARG_TRY(feature_region >= 1 && feature_region <= 16 && segments >= 1 && W < 65536);
     const size_t sh = (size_t)3 * W * 4 + (size_t)W * 2 + (size_t)W * 2 + 16;
     ARG_TRY(sh <= 160 * 1024);
@@ -1955,7 +1955,7 @@ static int launch_features(const float *ri, const uint8_t *seg, int B, int H, in
 #define FEAT_LAUNCH(Q_)                                                                                          \
     do {                                                                                                         \
         HIP_TRY(ensure_dyn_lds(reinterpret_cast<const void *>(&features_kernel<Q_>), (int)sh));                       \
-        features_kernel<Q_><<<dim3(H, B), FEAT_THREADS, sh, st>>>(ri, seg, H, W, fp, feat, key_point_map);                 \
+        features_kernel<Q_><<<dim3(H, B), FEAT_THREADS, sh, st>>>(ri, seg, H, W, fp, feat, key_point_map, kpn, K);         \
     } while (0)
     if (need <= 2) FEAT_LAUNCH(2);
     else if (need <= 4) FEAT_LAUNCH(4);
@@ -2102,15 +2102,19 @@ static int run_batch(const rpcc_batch_io *io, int Bs, int64_t npts, rpcc_geom g,
     float *label_acc = nullptr;
     if (io->nonuniform) {   // key points -> salience level and quantisation step per label
         const rpcc_nonuniform_cfg *nu = io->nonuniform;
-        label_acc = reinterpret_cast<float *>(extra + plane_extra_bytes(Bs, P, M) - 256 - (((size_t)Bs * (M + 2) * 4 + 255) & ~(size_t)255));
+        const size_t ksz = (((size_t)Bs * (M + 2) * 4 + 255) & ~(size_t)255);
+        label_acc = reinterpret_cast<float *>(extra + plane_extra_bytes(Bs, P, M) - 256 - ksz);
+        int32_t *kpn = reinterpret_cast<int32_t *>(extra + plane_extra_bytes(Bs, P, M) - 256 - 2 * ksz);
+        HIP_TRY(hipMemsetAsync(kpn, 0, (size_t)Bs * (M + 2) * 4, st));
         if ((rc = launch_features(ri, io->seg, Bs, g.H, g.W, nu->feature_region, nu->segments, nu->sharp_num, nu->less_sharp_num,
-                                  nu->flat_num, nullptr, io->key_point_map, st)))
+                                  nu->flat_num, nullptr, io->key_point_map, st, kpn, M + 2)))
             return rc;
         SalienceParams sp;
         for (int i = 0; i < 8; i++) { sp.level_kp_num[i] = i < nu->levels ? nu->level_kp_num[i] : 0; sp.level_acc[i] = i < nu->levels ? nu->level_acc[i] : 0.f; }
         sp.levels = nu->levels;
         sp.ground_level = nu->ground_level;
-        salience_kernel<<<Bs, SAL_THREADS, 0, st>>>(io->seg, io->key_point_map, P, M, sp, io->salience, label_acc);
+        // levels from the per-label totals (pixels: the scan's counts; key points: counted by the key-point kernel)
+        salience_levels_kernel<<<Bs, 256, 0, st>>>(io->counts, kpn, M, sp, io->salience, label_acc);
         LAUNCH_CHECK();
     }
     return launch_predict_quantize(ri, io->tm, io->seg, io->model, acc, label_acc, nullptr, Bs, P, M, io->q16,
