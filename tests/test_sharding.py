@@ -89,6 +89,13 @@ def _exchange_worker(rank, world, port, frames, q):
             for r in range(world):
                 for f in range(frames):
                     ok.append(np.array_equal(ex.frame_stream(r, f).numpy(), np.roll(_stream_of(r, f), step)))
+    # lengths-only exchange (bench.py's default): the payload stays with its rank, rank 0 learns every frame's length
+    ex2 = PackedExchange(frames, 0, dev, payloads=False)
+    nnz = torch.tensor([len(r) for r in runs], dtype=torch.int32)
+    ex2.step(None, nnz)
+    assert ex2.pay_all is None and ex2.bytes_per_step() == frames * 4 * world
+    for r in range(world):
+        ok.append(ex2.nnz_all[r].tolist() == [len(_stream_of(r, f)) for f in range(frames)])
     if rank == 0:
         q.put(ok)
     dist.barrier()
@@ -107,4 +114,18 @@ def test_two_rank_gloo_packed_exchange():
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    assert len(res) == 3 * 2 * 6 and all(res)
+    assert len(res) == 3 * 2 * 6 + 2 and all(res)
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """`python bench.py --gpus N` spawns its own N ranks (one per GPU) before touching the GPU; when fewer GPUs are visible it
+    must fail loudly instead of measuring fewer."""
+    import subprocess
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "GPU" in r.stderr and not r.stdout.strip().startswith("{")
+    env2 = dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env2, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr

@@ -54,4 +54,19 @@ for s in range(N):
         ops.compress_batch(xyz, offs, tm, gms[s % depth], bufs[s % depth], ground_seed=0)
 torch.cuda.synchronize()
 t_pipe = (time.perf_counter() - t0) / N * 1e6
-print("VARIANT %-40s fps+mask %7.1f us  (mask %6.1f, fps ~%6.1f)  step serial %7.1f us  pipelined %7.1f us" % (tag, t_both, t_mask, t_both - t_mask, t_serial, t_pipe), flush=True)
+# configs[2]: non-uniform + plane, three in flight
+gb = [ops.BatchBuffers(B, geom, M, dev, general=True) for _ in range(depth)]
+nu = ops.nonuniform_cfg(0.04)
+def c2(k):
+    ops.compress_batch(xyz, offs, tm, gms[k], gb[k], ground_seed=0, model_method="plane", nonuniform=nu)
+for k in range(depth):
+    with torch.cuda.stream(streams[k]):
+        c2(k)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for s in range(30):
+    with torch.cuda.stream(streams[s % depth]):
+        c2(s % depth)
+torch.cuda.synchronize()
+t_c2 = (time.perf_counter() - t0) / 30 * 1e6
+print("VARIANT %-40s fps+mask %7.1f us  (mask %6.1f, fps ~%6.1f)  step serial %7.1f us  pipelined %7.1f us  config2 pipelined %7.1f us" % (tag, t_both, t_mask, t_both - t_mask, t_serial, t_pipe, t_c2), flush=True)
