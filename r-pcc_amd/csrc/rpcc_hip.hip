@@ -241,6 +241,9 @@ __global__ __launch_bounds__(256) void project_finalize_kernel(uint32_t *__restr
 #ifndef BAND_THREADS
 #define BAND_THREADS 1024
 #endif
+#ifndef BAND_INFLIGHT
+#define BAND_INFLIGHT 4   // 16-byte record pairs per thread in flight
+#endif
 
 // ---- screened fast path of the pixel computation -----------------------------------------------------------
 // project_point() costs ~330 VALU instructions per wavefront, almost all of it the two fdlibm atan2f
@@ -450,7 +453,7 @@ __global__ __launch_bounds__(BAND_THREADS) void project_band_kernel(const uint2 
                                                                     const int32_t *__restrict__ flags,
                                                                     const float *__restrict__ tz, float zthr, int rs_chunk,
                                                                     int32_t *__restrict__ zcnt) {
-    extern __shared__ uint32_t band[];  // [BAND_PX]
+    extern __shared__ __attribute__((aligned(16))) uint32_t band[];  // [BAND_PX]
     // XCD-aware mapping: consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2).  The nbands
     // workgroups of a frame all stream the same record list, so they are placed on ONE XCD (ids x, x+8, x+16, ...):
     // XCD x serves the frames b = x (mod 8), and the list is fetched into that L2 once instead of nbands times.
@@ -458,24 +461,38 @@ __global__ __launch_bounds__(BAND_THREADS) void project_band_kernel(const uint2 
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int b = xcd + 8 * (slot / nbands), kband = slot % nbands;
     if (b >= B) return;
-    if (flags[b]) return;
+    // the three dependent scalars of this workgroup first: their latency passes while the LDS band is cleared
+    const int flagged = flags[b];
+    const int64_t n0 = offs[b] - base;  // record indices of this frame
+    const int64_t n1 = offs[b + 1] - base;
     const uint32_t band0 = (uint32_t)kband * BAND_PX;
     const uint32_t npx = min((uint32_t)BAND_PX, (uint32_t)P - band0);
-    for (uint32_t p = threadIdx.x; p < npx; p += BAND_THREADS) band[p] = RI_EMPTY;
+    if ((npx & 3) == 0) {
+        uint4 *b4 = reinterpret_cast<uint4 *>(band);
+        for (uint32_t q = threadIdx.x; q < (npx >> 2); q += BAND_THREADS) b4[q] = make_uint4(RI_EMPTY, RI_EMPTY, RI_EMPTY, RI_EMPTY);
+    } else {
+        for (uint32_t p = threadIdx.x; p < npx; p += BAND_THREADS) band[p] = RI_EMPTY;
+    }
+    if (flagged) return;   // (workgroup-uniform) a frame with a depth-0 point: project_fixup_kernel
     __syncthreads();
-    const int64_t n0 = offs[b] - base, n1 = offs[b + 1] - base;  // record indices of this frame
-    for (int64_t i = n0 + threadIdx.x; i < n1; i += BAND_THREADS * 8) {  // 8 records in flight per thread
-        uint2 v[8];
+    // two records (16 bytes) per lane and load: 8-byte loads reach about half the per-CU L2 read rate of 16-byte ones.  The
+    // list is walked from the even index at or below n0; the record before n0 (another frame's) is masked.
+    const uint4 *__restrict__ pd4 = reinterpret_cast<const uint4 *>(pd);
+    const int64_t h0 = n0 >> 1, h1 = (n1 + 1) >> 1;   // pairs [h0, h1)
+    for (int64_t i = h0 + threadIdx.x; i < h1; i += BAND_THREADS * BAND_INFLIGHT) {  // BAND_INFLIGHT pairs in flight per thread
+        uint4 v[BAND_INFLIGHT];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {  // unconditional (clamped) loads; out-of-range slots are masked below
+        for (int u = 0; u < BAND_INFLIGHT; u++) {  // unconditional (clamped) loads; out-of-range slots are masked below
             const int64_t ii = i + (int64_t)u * BAND_THREADS;
-            v[u] = pd[ii < n1 ? ii : n1 - 1];
-            if (ii >= n1) v[u].x = 0xFFFFFFFFu;
+            v[u] = pd4[ii < h1 ? ii : h1 - 1];
+            if (ii >= h1 || 2 * ii < n0) v[u].x = 0xFFFFFFFFu;
+            if (ii >= h1 || 2 * ii + 1 >= n1) v[u].z = 0xFFFFFFFFu;
         }
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const uint32_t rel = v[u].x - band0;  // skipped records (0xFFFFFFFF) fall outside every band
-            if (rel < npx) atomicMin(&band[rel], v[u].y);
+        for (int u = 0; u < BAND_INFLIGHT; u++) {
+            const uint32_t r0 = v[u].x - band0, r1 = v[u].z - band0;  // skipped records (0xFFFFFFFF) fall outside every band
+            if (r0 < npx) atomicMin(&band[r0], v[u].y);
+            if (r1 < npx) atomicMin(&band[r1], v[u].w);
         }
     }
     __syncthreads();
@@ -485,6 +502,52 @@ __global__ __launch_bounds__(BAND_THREADS) void project_band_kernel(const uint2 
             const uint32_t v = band[p];
             out[p] = (v == RI_EMPTY) ? 0u : v;
         }
+        return;
+    }
+    if ((P & 3) == 0) {
+        // write-out, 16 bytes per lane: four consecutive pixels from LDS (ds_read_b128), their ray z (one 16-byte load), one
+        // 16-byte store.  A chunk boundary (multiple of 64 pixels) never splits a lane's four pixels; a wavefront's 256
+        // pixels lie in one chunk except at a boundary, where the lanes count for themselves.
+        __shared__ int zc[RS_CHUNKS];
+        if (threadIdx.x < RS_CHUNKS) zc[threadIdx.x] = 0;
+        __syncthreads();
+        const uint4 *band4 = reinterpret_cast<const uint4 *>(band);
+        const float4 *tz4 = reinterpret_cast<const float4 *>(tz + band0);
+        uint4 *out4 = reinterpret_cast<uint4 *>(out);
+        const uint32_t nq = npx >> 2;
+        // (whole wavefronts stay in the loop: the DPP sum below needs every lane)
+        for (uint32_t q0 = threadIdx.x; q0 - (threadIdx.x & 63u) < nq; q0 += BAND_THREADS * 4) {  // 4 quads per lane in flight
+            uint4 rv[4];
+            float4 zr[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t q = min(q0 + u * BAND_THREADS, nq - 1);  // unconditional (clamped) loads
+                zr[u] = tz4[q];
+                uint4 v = band4[q];
+                v.x = v.x == RI_EMPTY ? 0u : v.x; v.y = v.y == RI_EMPTY ? 0u : v.y;
+                v.z = v.z == RI_EMPTY ? 0u : v.z; v.w = v.w == RI_EMPTY ? 0u : v.w;
+                rv[u] = v;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t q = q0 + u * BAND_THREADS;
+                const bool in = q < nq;
+                if (in) out4[q] = rv[u];
+                const int c = in ? (int)(u2f(rv[u].x) * zr[u].x < zthr) + (int)(u2f(rv[u].y) * zr[u].y < zthr) +
+                                   (int)(u2f(rv[u].z) * zr[u].z < zthr) + (int)(u2f(rv[u].w) * zr[u].w < zthr) : 0;
+                const uint32_t ch = (band0 + 4u * min(q, nq - 1)) / (uint32_t)rs_chunk;
+                const uint32_t ch0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ch);
+                if (__ballot(ch != ch0) == 0ull) {
+                    const int tot = (int)dpp_sum_u32((uint32_t)c);
+                    if (tot && (threadIdx.x & 63) == 0) atomicAdd(&zc[ch0], tot);
+                } else if (c) {
+                    atomicAdd(&zc[ch], c);
+                }
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < RS_CHUNKS && zc[threadIdx.x]) atomicAdd(&zcnt[b * (RS_CHUNKS + 1) + threadIdx.x], zc[threadIdx.x]);
+        if (kband == 0 && threadIdx.x == 0) zcnt[b * (RS_CHUNKS + 1) + RS_CHUNKS] = 1;
         return;
     }
     // a wavefront covers 64 consecutive pixels per step; rs_chunk is a multiple of 64, so the chunk is wave-uniform
@@ -555,7 +618,7 @@ __global__ __launch_bounds__(FIXUP_THREADS) void project_fixup_kernel(const floa
 }
 
 static size_t project_scratch_bytes(int64_t total, int B, int P) {
-    return ((size_t)B * ((size_t)P + 8)) * 4 + 256 + (size_t)(total > 0 ? total : 0) * 8;
+    return ((size_t)B * ((size_t)P + 8)) * 4 + 256 + (size_t)(total > 0 ? total : 0) * 8 + 16;   // + 16: the band kernel reads records in 16-byte pairs
 }
 extern "C" size_t rpcc_project_scratch_bytes(int64_t total, int B, int P) { return project_scratch_bytes(total, B, P); }
 
