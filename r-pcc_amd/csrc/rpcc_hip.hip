@@ -457,10 +457,14 @@ __global__ __launch_bounds__(BAND_THREADS) void project_band_kernel(const uint2 
     // XCD-aware mapping: consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2).  The nbands
     // workgroups of a frame all stream the same record list, so they are placed on ONE XCD (ids x, x+8, x+16, ...):
     // XCD x serves the frames b = x (mod 8), and the list is fetched into that L2 once instead of nbands times.
+    // The workgroups are persistent: workgroup (xcd, slot) takes the items slot, slot + slots, ... of its XCD (same band, the
+    // next frames), so a 1024-thread / 128 KB workgroup is launched once per CU instead of once per item.
     const int nbands = (P + BAND_PX - 1) / BAND_PX;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int xcd = blockIdx.x & 7, slots = gridDim.x >> 3;
+    for (int slot = blockIdx.x >> 3;; slot += slots) {
     const int b = xcd + 8 * (slot / nbands), kband = slot % nbands;
-    if (b >= B) return;
+    if (b >= B) break;
+    __syncthreads();   // the previous item's LDS band and counters are no longer read
     // the three dependent scalars of this workgroup first: their latency passes while the LDS band is cleared
     const int flagged = flags[b];
     const int64_t n0 = offs[b] - base;  // record indices of this frame
@@ -473,7 +477,7 @@ __global__ __launch_bounds__(BAND_THREADS) void project_band_kernel(const uint2 
     } else {
         for (uint32_t p = threadIdx.x; p < npx; p += BAND_THREADS) band[p] = RI_EMPTY;
     }
-    if (flagged) return;   // (workgroup-uniform) a frame with a depth-0 point: project_fixup_kernel
+    if (flagged) continue;   // (workgroup-uniform) a frame with a depth-0 point: project_fixup_kernel
     __syncthreads();
     // two records (16 bytes) per lane and load: 8-byte loads reach about half the per-CU L2 read rate of 16-byte ones.  The
     // list is walked from the even index at or below n0; the record before n0 (another frame's) is masked.
@@ -502,7 +506,7 @@ __global__ __launch_bounds__(BAND_THREADS) void project_band_kernel(const uint2 
             const uint32_t v = band[p];
             out[p] = (v == RI_EMPTY) ? 0u : v;
         }
-        return;
+        continue;
     }
     if ((P & 3) == 0) {
         // write-out, 16 bytes per lane: four consecutive pixels from LDS (ds_read_b128), their ray z (one 16-byte load), one
@@ -548,7 +552,7 @@ __global__ __launch_bounds__(BAND_THREADS) void project_band_kernel(const uint2 
         __syncthreads();
         if (threadIdx.x < RS_CHUNKS && zc[threadIdx.x]) atomicAdd(&zcnt[b * (RS_CHUNKS + 1) + threadIdx.x], zc[threadIdx.x]);
         if (kband == 0 && threadIdx.x == 0) zcnt[b * (RS_CHUNKS + 1) + RS_CHUNKS] = 1;
-        return;
+        continue;
     }
     // a wavefront covers 64 consecutive pixels per step; rs_chunk is a multiple of 64, so the chunk is wave-uniform
     uint32_t g0 = band0 + (threadIdx.x & ~63u);
@@ -579,6 +583,7 @@ __global__ __launch_bounds__(BAND_THREADS) void project_band_kernel(const uint2 
     }
     if (acc && (threadIdx.x & 63) == 0) atomicAdd(&zcnt[b * (RS_CHUNKS + 1) + ch], acc);
     if (kband == 0 && threadIdx.x == 0) zcnt[b * (RS_CHUNKS + 1) + RS_CHUNKS] = 1;
+    }
 }
 
 // Exact input-order projection of the frames that hold a depth-0 point (flags), as ONE launch: a 256-thread workgroup
@@ -652,7 +657,8 @@ static int launch_project(const float *xyz, const int64_t *offsets, int64_t tota
                 xyz, offsets, total, base, B, g, pix_fast_cfg(g), pd, flags);
         HIP_TRY(ensure_dyn_lds(reinterpret_cast<const void *>(&project_band_kernel), BAND_PX * 4));
         if (zcnt && !cleared) HIP_TRY(hipMemsetAsync(zcnt, 0, (size_t)B * (RS_CHUNKS + 1) * 4, st));
-        project_band_kernel<<<8 * ((B + 7) / 8) * ((P + BAND_PX - 1) / BAND_PX), BAND_THREADS, BAND_PX * 4, st>>>(
+        // persistent: at most one workgroup per CU (8 XCDs x 32), each walking over its XCD's (frame, band) items
+        project_band_kernel<<<8 * std::min(((B + 7) / 8) * ((P + BAND_PX - 1) / BAND_PX), std::max(32 / ((P + BAND_PX - 1) / BAND_PX), 1) * ((P + BAND_PX - 1) / BAND_PX)), BAND_THREADS, BAND_PX * 4, st>>>(
             pd, offsets, base, B, P, rb, flags, tz_plane, -1.5f, rs_chunk_px(P), tz_plane ? zcnt : nullptr);
         LAUNCH_CHECK();
         if (total > 0) {  // exact input-order semantics for frames with depth-0 points: a no-op otherwise

@@ -50,7 +50,7 @@ L = [f"# {tag} PMC passes: HBM-side traffic and VALU instructions per kernel lau
      "stream.  Calibration on kernels with known byte counts: `project_pix_kernel` reads 12 B x 29.0 M points = 348 MB,",
      "`assign_kernel` reads the 134 MB range image; both report about half, so read = 2 x FETCH_SIZE also for 4 B/lane loads.",
      "WRITE_SIZE needs no correction (`project_pix_kernel` writes 232 MB of records, `assign_kernel` 33.5 MB of labels).",
-     "SQ_INSTS_VALU counts wave-level VALU instructions (the chip issues at most 1024 SIMDs x 1 per 2 cycles = 1.23e12 per second at 2.4 GHz).", "",
+     "SQ_INSTS_VALU counts wave-level VALU instructions; a non-packed wave64 instruction occupies a SIMD for 4 cycles (the 157 TFLOP/s fp32 peak = 1024 SIMDs x 16 lanes x fma x packed x 2.4 GHz), so the chip issues at most 1024 x 2.4e9 / 4 = 6.1e11 per second.", "",
      "| kernel | launches | FETCH_SIZE raw MB | read MB (x2) | WRITE_SIZE MB | HBM-side traffic MB/launch | VALU M wave-instr./launch | avg us (profiled) | traffic TB/s | VALU issue % |", "|---|---|---|---|---|---|---|---|---|---|"]
 js = {}
 for n in names:
@@ -58,14 +58,14 @@ for n in names:
     fr = sum(v for v, _ in fv) / len(fv) / 1024; wr = sum(v for v, _ in wv) / len(wv) / 1024; us = sum(t for _, t in fv) / len(fv)
     va = sum(v for v, _ in vv) / len(vv)
     tb = (2 * fr + wr) * 1048576 / (us * 1e-6) / 1e12 if us else 0
-    vp = va / (us * 1e-6) / (1024 * 2.4e9 / 2) * 100 if us else 0
+    vp = va / (us * 1e-6) / (1024 * 2.4e9 / 4) * 100 if us else 0
     L.append("| `%s` | %d | %.1f | %.1f | %.1f | %.1f | %.1f | %.1f | %.2f | %.0f |" % (n[:48], len(fv), fr, 2 * fr, wr, 2 * fr + wr, va / 1e6, us, tb, vp))
     js[n] = {"fetch_raw_MB": round(fr, 2), "read_MB": round(2 * fr, 2), "write_MB": round(wr, 2), "traffic_bytes_per_launch": int((2 * fr + wr) * 1048576),
              "valu_wave_insts_per_launch": int(va), "avg_us": round(us, 1)}
 tot = sum(v["traffic_bytes_per_launch"] for v in js.values()); totv = sum(v["valu_wave_insts_per_launch"] for v in js.values())
 B = bench["prof_bench_final"]["config"]["frames_per_gpu_per_step"]
 L += ["", "Whole step: %.2f GB of HBM-side traffic per %d-frame batch = %.1f MB per frame, %d launches, %.0f M wave-level VALU instructions" % (tot / 1e9, B, tot / B / 1e6, len(js), totv / 1e6),
-      "(= %.2f ms of VALU issue time on the whole chip at 2.4 GHz)." % (totv / (1024 * 2.4e9 / 2) * 1e3)]
+      "(= %.2f ms of VALU issue time on the whole chip at 2.4 GHz)." % (totv / (1024 * 2.4e9 / 4) * 1e3)]
 open(f"{P}/{tag}_pmc.md", 'w').write("\n".join(L) + "\n")
 if "--no-current" not in sys.argv:
     geom = wl.split("(")[-1].split(")")[0] if "x" in wl else "64x2048"
