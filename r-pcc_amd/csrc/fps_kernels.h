@@ -576,7 +576,9 @@ __global__ __launch_bounds__(FPS_TT) void fps_regtab_kernel(const float *__restr
             tmax = o.wt; targ = o.widx; cx = o.wx; cy = o.wy; cz = o.wz;
         }
     };
-    // visits the tiles of the lanes in mask m, two at a time (all loads of a pair are in flight before either is used)
+    // visits the tiles of the lanes in mask m, two at a time (all loads of a pair are in flight before either is used).
+    // (Software-pipelining the visits -- the next tile's loads in flight during the current update -- makes the kernel 7 %
+    // faster alone but needs 127 instead of 96 VGPRs, and the step with batches in flight gets 3 % slower: not kept.)
     auto visit = [&](unsigned long long m, bool with_box) {
         bool viol = false;
         while (m) {
@@ -589,7 +591,7 @@ __global__ __launch_bounds__(FPS_TT) void fps_regtab_kernel(const float *__restr
             locate(l0, q0);
             fps_quad_load<RANGE, VEC>(src, rays, temp, q0);
             locate(l1, q1);
-            fps_quad_load<RANGE, VEC>(src, rays, temp, q1);   // (a repeated tile for an odd count: loaded, not used)
+            fps_quad_load<RANGE, VEC>(src, rays, temp, q1);
             FpsTileOut o;
             if (fps_tile_update<RANGE, VEC>(q0, org_on, t_org0, c0, c1, c2, temp, with_box, o, viol)) store_entry(l0, o, with_box);
             if (two && fps_tile_update<RANGE, VEC>(q1, org_on, t_org0, c0, c1, c2, temp, with_box, o, viol)) store_entry(l1, o, with_box);
