@@ -31,7 +31,7 @@
 #define FPS_TAB_ROWS 12  // three float4 per tile: (lo.xyz, tmax) (hi.xyz, targ) (cx.xyz, tile origin)
 #define FPS_TILE 256
 #define FPS_TROWS 8
-#define RPCC_INFO 8      // int32 per frame in `info`: n_left, first candidate, nnz, table valid, first empty candidate, 3 spare
+// RPCC_INFO (int32 per frame in `info`) is defined in rpcc_hip.hip
 
 struct FpsTiling {
     int N;      // points per frame (P for a range image)

@@ -132,6 +132,7 @@ struct FpsTimer {
 // a2  spherical projection  (cpp_modules.cpp:427-467)
 // ================================================================================================
 #define RI_EMPTY 0xFFFFFFFFu
+#define RPCC_INFO 8      // int32 per frame in `info`: n_left, first candidate, nnz, table valid, first empty candidate, 3 spare
 
 struct RowCol {
     float depth;
@@ -329,9 +330,25 @@ __device__ __forceinline__ bool project_point_fast(float x, float y, float z, co
 // wave slots).  Uncertain points collect in an LDS queue that is drained by the exact sequence 256 at a time, i.e.
 // with full wavefronts.
 #define PIX_THREADS 256
+// What the first kernel of a fused batch (project_pix_kernel) sets up besides its own work, so that a batch needs no
+// separate initialisation launch: the planar copy of the ray table (its z plane is read by the band kernel), the info
+// counters of the ground mask, cleared RANSAC candidate counts and label sums (all consumed by LATER launches only).
+// The per-frame "holds a depth-0 point" flags are read and written by the projection kernels themselves, so they are
+// not cleared but compared with a mark that changes from call to call: a flag is set when it holds *epoch + 1, and the
+// last kernel of the batch increments *epoch (a word of the caller's workspace).  Stale or never-initialised flag words
+// can at worst equal the mark by chance, which sends a frame through the exact fix-up path: slower, same result.
+struct ZeroRange { uint32_t *p; int n; };
+struct BatchInit {
+    const float *tm; float *soa; int P;
+    int32_t *info; int B;
+    ZeroRange z0, z1;
+    int on;
+};
+__device__ __forceinline__ int flag_mark(const int32_t *epoch) { return epoch ? *epoch + 1 : 1; }
+
 __device__ __forceinline__ void project_exact_record(const float *__restrict__ xyz, const int64_t *__restrict__ offs, int64_t base,
                                                      int B, const rpcc_geom g, int64_t il, uint2 *__restrict__ pd,
-                                                     int32_t *__restrict__ flags) {
+                                                     int32_t *__restrict__ flags, int mark) {
     const int64_t i = base + il;
     const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
     const RowCol rc = project_point(x, y, z, g);
@@ -339,7 +356,7 @@ __device__ __forceinline__ void project_exact_record(const float *__restrict__ x
     if (fabsf(rc.depth) <= 3.402823466e+38f) {
         if (rc.depth == 0.0f) {
             int b = find_frame(offs, B, i);
-            flags[b] = 1; flags[B] = 1;
+            flags[b] = mark; flags[B] = mark;
         } else {
             o = make_uint2((uint32_t)rc.pix, f2u(rc.depth));
         }
@@ -350,10 +367,24 @@ __device__ __forceinline__ void project_exact_record(const float *__restrict__ x
 #define PIX_PPT 8  // points per thread and iteration: loads in flight, and one pair of barriers per PIX_PPT * 256 points
 __global__ __launch_bounds__(PIX_THREADS) void project_pix_kernel(const float *__restrict__ xyz, const int64_t *__restrict__ offs,
                                                                   int64_t total, int64_t base, int B, rpcc_geom g, PixFastCfg cfg,
-                                                                  uint2 *__restrict__ pd, int32_t *__restrict__ flags) {
+                                                                  uint2 *__restrict__ pd, int32_t *__restrict__ flags,
+                                                                  const int32_t *__restrict__ epoch, BatchInit init) {
     __shared__ int64_t queue[(PIX_PPT + 1) * PIX_THREADS];
     __shared__ uint32_t qn;
     if (threadIdx.x == 0) qn = 0u;
+    const int mark = flag_mark(epoch);
+    if (init.on) {   // the batch's small initialisations (grid-stride; nothing of it is read by this launch)
+        const int nthr = gridDim.x * PIX_THREADS;
+        for (int p = blockIdx.x * PIX_THREADS + threadIdx.x; p < init.P; p += nthr) {
+            init.soa[p] = init.tm[3 * p]; init.soa[init.P + p] = init.tm[3 * p + 1]; init.soa[2 * (int64_t)init.P + p] = init.tm[3 * p + 2];
+        }
+        for (int p = blockIdx.x * PIX_THREADS + threadIdx.x; p < init.B; p += nthr) {
+            init.info[RPCC_INFO * p] = 0; init.info[RPCC_INFO * p + 1] = init.P; init.info[RPCC_INFO * p + 2] = 0; init.info[RPCC_INFO * p + 3] = 0;
+            init.info[RPCC_INFO * p + 4] = init.P; init.info[RPCC_INFO * p + 5] = 0; init.info[RPCC_INFO * p + 6] = 0; init.info[RPCC_INFO * p + 7] = 0;
+        }
+        for (int p = blockIdx.x * PIX_THREADS + threadIdx.x; p < init.z0.n; p += nthr) init.z0.p[p] = 0u;
+        for (int p = blockIdx.x * PIX_THREADS + threadIdx.x; p < init.z1.n; p += nthr) init.z1.p[p] = 0u;
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -391,7 +422,7 @@ __global__ __launch_bounds__(PIX_THREADS) void project_pix_kernel(const float *_
         __syncthreads();
         if (n >= PIX_THREADS) {  // full workgroups of uncertain points: the exact sequence
             while (n >= PIX_THREADS) {
-                project_exact_record(xyz, offs, base, B, g, queue[n - PIX_THREADS + threadIdx.x], pd, flags);
+                project_exact_record(xyz, offs, base, B, g, queue[n - PIX_THREADS + threadIdx.x], pd, flags, mark);
                 n -= PIX_THREADS;
             }
             __syncthreads();
@@ -400,7 +431,7 @@ __global__ __launch_bounds__(PIX_THREADS) void project_pix_kernel(const float *_
         }
     }
     const uint32_t n = qn;
-    if (threadIdx.x < n) project_exact_record(xyz, offs, base, B, g, queue[threadIdx.x], pd, flags);
+    if (threadIdx.x < n) project_exact_record(xyz, offs, base, B, g, queue[threadIdx.x], pd, flags, mark);
 }
 
 // test hook: counts[0] = points the fast path is certain about, counts[1] = of those, points whose pixel differs
@@ -447,26 +478,40 @@ __global__ __launch_bounds__(256) void project_fastcheck_kernel(const float *__r
 // (frames with a depth-0 point are re-projected afterwards and count for themselves).
 #define RS_CHUNKS 16
 static inline int rs_chunk_px(int P) { return (((P + RS_CHUNKS - 1) / RS_CHUNKS) + 63) & ~63; }
+__device__ void project_fixup_frame(const float *__restrict__ xyz, const int64_t *__restrict__ offs, int b, rpcc_geom g,
+                                    uint32_t *__restrict__ ri, int32_t *__restrict__ lastz);
+
+// band_wgs: the workgroups below that id are band workgroups; the B workgroups from there on (present when the launch has
+// points) run the exact input-order projection of the frames that hold a depth-0 point (project_fixup_frame) -- a no-op
+// for every other frame, and the band workgroups skip those frames -- so the fix-up costs no launch of its own.
 __global__ __launch_bounds__(BAND_THREADS) void project_band_kernel(const uint2 *__restrict__ pd,
                                                                     const int64_t *__restrict__ offs, int64_t base,
                                                                     int B, int P, uint32_t *__restrict__ ri,
                                                                     const int32_t *__restrict__ flags,
                                                                     const float *__restrict__ tz, float zthr, int rs_chunk,
-                                                                    int32_t *__restrict__ zcnt) {
+                                                                    int32_t *__restrict__ zcnt, const int32_t *__restrict__ epoch,
+                                                                    int band_wgs, const float *__restrict__ xyz, rpcc_geom g,
+                                                                    int32_t *__restrict__ lastz) {
     extern __shared__ __attribute__((aligned(16))) uint32_t band[];  // [BAND_PX]
+    const int mark = flag_mark(epoch);
+    if ((int)blockIdx.x >= band_wgs) {
+        const int fb = (int)blockIdx.x - band_wgs;
+        if (flags[fb] == mark) project_fixup_frame(xyz, offs, fb, g, ri, lastz);
+        return;
+    }
     // XCD-aware mapping: consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2).  The nbands
     // workgroups of a frame all stream the same record list, so they are placed on ONE XCD (ids x, x+8, x+16, ...):
     // XCD x serves the frames b = x (mod 8), and the list is fetched into that L2 once instead of nbands times.
     // The workgroups are persistent: workgroup (xcd, slot) takes the items slot, slot + slots, ... of its XCD (same band, the
     // next frames), so a 1024-thread / 128 KB workgroup is launched once per CU instead of once per item.
     const int nbands = (P + BAND_PX - 1) / BAND_PX;
-    const int xcd = blockIdx.x & 7, slots = gridDim.x >> 3;
+    const int xcd = blockIdx.x & 7, slots = band_wgs >> 3;
     for (int slot = blockIdx.x >> 3;; slot += slots) {
     const int b = xcd + 8 * (slot / nbands), kband = slot % nbands;
     if (b >= B) break;
     __syncthreads();   // the previous item's LDS band and counters are no longer read
     // the three dependent scalars of this workgroup first: their latency passes while the LDS band is cleared
-    const int flagged = flags[b];
+    const int flagged = flags[b] == mark;
     const int64_t n0 = offs[b] - base;  // record indices of this frame
     const int64_t n1 = offs[b + 1] - base;
     const uint32_t band0 = (uint32_t)kband * BAND_PX;
@@ -586,17 +631,13 @@ __global__ __launch_bounds__(BAND_THREADS) void project_band_kernel(const uint2 
     }
 }
 
-// Exact input-order projection of the frames that hold a depth-0 point (flags), as ONE launch: a 256-thread workgroup
-// per frame does what project_fill<true> / project_kernel<1> / project_kernel<2> / project_finalize<true> do grid-wide
+// Exact input-order projection of a frame that holds a depth-0 point (flags): one workgroup (the extra workgroups of
+// project_band_kernel) does what project_fill<true> / project_kernel<1> / project_kernel<2> / project_finalize<true> do grid-wide
 // (all dependencies are inside a frame).  Frames without a flag -- the normal case -- leave at once, so the fast path
 // pays one empty launch instead of four.  Loads that follow this kernel's own atomics bypass the CU's L1 (agent scope).
-#define FIXUP_THREADS 256
-__global__ __launch_bounds__(FIXUP_THREADS) void project_fixup_kernel(const float *__restrict__ xyz, const int64_t *__restrict__ offs,
-                                                                      int B, rpcc_geom g, uint32_t *__restrict__ ri,
-                                                                      int32_t *__restrict__ lastz,
-                                                                      const int32_t *__restrict__ flags) {
-    const int b = blockIdx.x;
-    if (flags[b] == 0) return;
+__device__ void project_fixup_frame(const float *__restrict__ xyz, const int64_t *__restrict__ offs, int b, rpcc_geom g,
+                                    uint32_t *__restrict__ ri, int32_t *__restrict__ lastz) {
+    const int FIXUP_THREADS = blockDim.x;
     const int P = g.H * g.W;
     uint32_t *img = ri + (int64_t)b * P;
     int32_t *lz = lastz + (int64_t)b * P;
@@ -640,7 +681,8 @@ extern "C" int rpcc_project_fastpath_check(const float *xyz, int64_t total, rpcc
 // atomic path, which only needs B*(P+8)*4 bytes.
 static int launch_project(const float *xyz, const int64_t *offsets, int64_t total, int64_t base, int B, rpcc_geom g,
                           float *ri, void *scratch, size_t scratch_bytes, hipStream_t st, const float *tz_plane = nullptr,
-                          int32_t *zcnt = nullptr, bool cleared = false) {
+                          int32_t *zcnt = nullptr, const BatchInit *init = nullptr, const int32_t *epoch = nullptr) {
+    const bool cleared = init != nullptr;   // fused batch: the pixel kernel initialises, flags are marked by epoch
     const int P = g.H * g.W;
     uint32_t *rb = reinterpret_cast<uint32_t *>(ri);
     int32_t *lastz = reinterpret_cast<int32_t *>(scratch);
@@ -652,19 +694,21 @@ static int launch_project(const float *xyz, const int64_t *offsets, int64_t tota
     if (fast) {
         uint2 *pd = reinterpret_cast<uint2 *>(reinterpret_cast<char *>(scratch) + ((size_t)B * ((size_t)P + 8)) * 4 + 256);
         if (!cleared) HIP_TRY(hipMemsetAsync(flags, 0, (size_t)(B + 1) * 4, st));
-        if (total > 0)
-            project_pix_kernel<<<(unsigned)std::min<int64_t>((total + PIX_PPT * PIX_THREADS - 1) / (PIX_PPT * PIX_THREADS), 256 * 16), PIX_THREADS, 0, st>>>(
-                xyz, offsets, total, base, B, g, pix_fast_cfg(g), pd, flags);
+        BatchInit bi;
+        memset(&bi, 0, sizeof(bi));
+        if (init) bi = *init;
+        if (total > 0 || bi.on)
+            project_pix_kernel<<<(unsigned)std::max<int64_t>(std::min<int64_t>((total + PIX_PPT * PIX_THREADS - 1) / (PIX_PPT * PIX_THREADS), 256 * 16), 1), PIX_THREADS, 0, st>>>(
+                xyz, offsets, total, base, B, g, pix_fast_cfg(g), pd, flags, epoch, bi);
         HIP_TRY(ensure_dyn_lds(reinterpret_cast<const void *>(&project_band_kernel), BAND_PX * 4));
         if (zcnt && !cleared) HIP_TRY(hipMemsetAsync(zcnt, 0, (size_t)B * (RS_CHUNKS + 1) * 4, st));
         // persistent: at most one workgroup per CU (8 XCDs x 32), each walking over its XCD's (frame, band) items
-        project_band_kernel<<<8 * std::min(((B + 7) / 8) * ((P + BAND_PX - 1) / BAND_PX), std::max(32 / ((P + BAND_PX - 1) / BAND_PX), 1) * ((P + BAND_PX - 1) / BAND_PX)), BAND_THREADS, BAND_PX * 4, st>>>(
-            pd, offsets, base, B, P, rb, flags, tz_plane, -1.5f, rs_chunk_px(P), tz_plane ? zcnt : nullptr);
+        const int nbands = (P + BAND_PX - 1) / BAND_PX;
+        const int band_wgs = 8 * std::min(((B + 7) / 8) * nbands, std::max(32 / nbands, 1) * nbands);
+        // + B workgroups for the exact input-order semantics of frames with depth-0 points (a no-op otherwise)
+        project_band_kernel<<<band_wgs + (total > 0 ? B : 0), BAND_THREADS, BAND_PX * 4, st>>>(
+            pd, offsets, base, B, P, rb, flags, tz_plane, -1.5f, rs_chunk_px(P), tz_plane ? zcnt : nullptr, epoch, band_wgs, xyz, g, lastz);
         LAUNCH_CHECK();
-        if (total > 0) {  // exact input-order semantics for frames with depth-0 points: a no-op otherwise
-            project_fixup_kernel<<<B, FIXUP_THREADS, 0, st>>>(xyz, offsets, B, g, rb, lastz, flags);
-            LAUNCH_CHECK();
-        }
         return RPCC_OK;
     }
     if (zcnt && !cleared) HIP_TRY(hipMemsetAsync(zcnt, 0, (size_t)B * (RS_CHUNKS + 1) * 4, st));
@@ -1250,26 +1294,6 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_range_kernel(const float *__r
     }
 }
 
-// AoS transform_map [P,3] -> three planes (frame-invariant; 12 B/pixel once per call)
-// The fused entry uses it as the first kernel of a batch and lets it also do the batch's small initialisations (instead
-// of four more launches): info = the per-frame counters of the ground mask; z0 / z1 / z2 = dword ranges to clear
-// (projection flags, RANSAC candidate counts, label sums of the point model).
-struct ZeroRange { uint32_t *p; int n; };
-__global__ __launch_bounds__(256) void rays_soa_kernel(const float *__restrict__ tm, int P, float *__restrict__ soa,
-                                                       int32_t *__restrict__ info = nullptr, int B = 0,
-                                                       ZeroRange z0 = {nullptr, 0}, ZeroRange z1 = {nullptr, 0},
-                                                       ZeroRange z2 = {nullptr, 0}) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < P) { soa[p] = tm[3 * p]; soa[P + p] = tm[3 * p + 1]; soa[2 * (int64_t)P + p] = tm[3 * p + 2]; }
-    if (info != nullptr && p < B) {
-        info[RPCC_INFO * p] = 0; info[RPCC_INFO * p + 1] = P; info[RPCC_INFO * p + 2] = 0; info[RPCC_INFO * p + 3] = 0;
-        info[RPCC_INFO * p + 4] = P; info[RPCC_INFO * p + 5] = 0; info[RPCC_INFO * p + 6] = 0; info[RPCC_INFO * p + 7] = 0;
-    }
-    if (p < z0.n) z0.p[p] = 0u;
-    if (p < z1.n) z1.p[p] = 0u;
-    if (p < z2.n) z2.p[p] = 0u;
-}
-
 template <bool RANGE>
 static int launch_fps_tiled(const float *src, const float *rays, float *temp, const int32_t *info, int B, const FpsTiling &g,
                             int M, int kflags, int32_t *idx, float *cen, const float *tiletab, bool vec, hipStream_t st) {
@@ -1809,8 +1833,11 @@ __global__ __launch_bounds__(256) void predict_quantize_kernel(const float *__re
                                                                const float *__restrict__ label_acc,
                                                                const float *__restrict__ residual_in, int P, int M,
                                                                int KP, int T, int16_t *__restrict__ q16,
-                                                               int32_t *__restrict__ q32, float *__restrict__ pred_out) {
+                                                               int32_t *__restrict__ q32, float *__restrict__ pred_out,
+                                                               int32_t *__restrict__ epoch_inc) {
     extern __shared__ unsigned char smem_raw[];
+    // last kernel of a fused batch: the next call's projection flags get a new mark (BatchInit)
+    if (epoch_inc && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *epoch_inc += 1;
     float *smodel = reinterpret_cast<float *>(smem_raw);                 // [KP*4]
     uint32_t *segcnt = reinterpret_cast<uint32_t *>(smodel + 4 * KP);    // [16][KP+1]
     const int SEGP = KP + 1;
@@ -1898,16 +1925,16 @@ __global__ __launch_bounds__(256) void predict_quantize_kernel(const float *__re
 
 static int launch_predict_quantize(const float *ri, const float *tm, const uint8_t *seg, const float *model, float acc,
                                    const float *label_acc, const float *residual_in, int B, int P, int M, int16_t *q16,
-                                   int32_t *q32, float *pred, void *ws, hipStream_t st) {
+                                   int32_t *q32, float *pred, void *ws, hipStream_t st, int32_t *epoch_inc = nullptr) {
     const int KP = kpad(M), T = ntiles(P);
     WsLayout L = ws_layout(ws, B, P, M);
     const size_t sh = (size_t)KP * 4 * 4 + (size_t)16 * (KP + 1) * 4 + (size_t)KP * 4;
     if (residual_in && !pred)
         predict_quantize_kernel<true><<<dim3(T, B), 256, sh, st>>>(ri, tm, seg, model, L.hist, acc, label_acc, residual_in, P,
-                                                                   M, KP, T, q16, q32, pred);
+                                                                   M, KP, T, q16, q32, pred, epoch_inc);
     else
         predict_quantize_kernel<false><<<dim3(T, B), 256, sh, st>>>(ri, tm, seg, model, L.hist, acc, label_acc, residual_in,
-                                                                    P, M, KP, T, q16, q32, pred);
+                                                                    P, M, KP, T, q16, q32, pred, epoch_inc);
     LAUNCH_CHECK();
     return RPCC_OK;
 }
@@ -2135,16 +2162,16 @@ static int run_batch(const rpcc_batch_io *io, int Bs, int64_t npts, rpcc_geom g,
     int32_t *info = io->info;
     int rc;
     int32_t *zcnt = fit_ground ? reinterpret_cast<int32_t *>(tiletab) : nullptr;  // the tile table is written later
-    // first kernel of the batch: planar ray table (band kernel's z), the info counters of the ground mask, and the
-    // cleared projection flags / RANSAC candidate counts / label sums
-    const ZeroRange zflags = {reinterpret_cast<uint32_t *>(proj_scratch) + (size_t)Bs * P, Bs + 1};
-    const ZeroRange zzcnt = {reinterpret_cast<uint32_t *>(zcnt), zcnt ? Bs * (RS_CHUNKS + 1) : 0};
-    const ZeroRange zsums = {reinterpret_cast<uint32_t *>(L.sums), (int)(((char *)L.hist - (char *)L.sums) / 4)};
-    const int init_n = std::max(std::max(P, Bs * (RS_CHUNKS + 1)), zsums.n);
-    rays_soa_kernel<<<(init_n + 255) / 256, 256, 0, st>>>(io->tm, P, rays_soa, info, Bs, zflags, zzcnt, zsums);
-    LAUNCH_CHECK();
+    // The first kernel of the batch (the pixel kernel) also writes the planar ray table (band kernel's z), initialises the info
+    // counters of the ground mask and clears the RANSAC candidate counts and the label sums; the projection's per-frame
+    // flags are marked with an epoch kept in the workspace (BatchInit), so the batch has no initialisation launch.
+    int32_t *epoch = reinterpret_cast<int32_t *>(ws + L.bytes);   // the 256 bytes between the model part and the projection scratch
+    BatchInit bi;
+    bi.tm = io->tm; bi.soa = rays_soa; bi.P = P; bi.info = info; bi.B = Bs; bi.on = 1;
+    bi.z0 = {reinterpret_cast<uint32_t *>(zcnt), zcnt ? Bs * (RS_CHUNKS + 1) : 0};
+    bi.z1 = {reinterpret_cast<uint32_t *>(L.sums), (int)(((char *)L.hist - (char *)L.sums) / 4)};
     if ((rc = launch_project(io->xyz, io->offsets, npts, 0, Bs, g, ri, proj_scratch, proj_bytes, st,
-                             rays_soa + 2 * (int64_t)P, zcnt, true)))
+                             rays_soa + 2 * (int64_t)P, zcnt, &bi, epoch)))
         return rc;
     if (fit_ground &&
         (rc = launch_ground_ransac(ri, io->tm, Bs, P, (uint32_t)io->ground_seed, false, ground, nullptr, st, zcnt, io->frame_ids)))
@@ -2187,7 +2214,7 @@ static int run_batch(const rpcc_batch_io *io, int Bs, int64_t npts, rpcc_geom g,
         LAUNCH_CHECK();
     }
     return launch_predict_quantize(ri, io->tm, io->seg, io->model, acc, label_acc, nullptr, Bs, P, M, io->q16,
-                                   nullptr, nullptr, ws, st);
+                                   nullptr, nullptr, ws, st, epoch);
 }
 
 extern "C" int rpcc_compress_batch(const rpcc_batch_io *io, int B, rpcc_geom g, int M, double ground_threshold,
