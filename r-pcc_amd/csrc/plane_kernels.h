@@ -136,7 +136,12 @@ __device__ int ransac_plane_wave(const float4 *__restrict__ pts, int n, int iter
     // (1) fits: hypothesis h on lane h
     double pl[4] = {0, 0, 0, 0};
     bool ok = false;
+#ifdef RSX_NOFIT
+    if (lane < iters) { pl[2] = 1.0; pl[3] = -(double)lane; ok = true; }
+    if (false) {
+#else
     if (lane < iters) {
+#endif
         const int h = lane;
         int idx[RN];
 #pragma unroll
@@ -172,6 +177,9 @@ __device__ int ransac_plane_wave(const float4 *__restrict__ pts, int n, int iter
     const unsigned long long okmask = __ballot(ok);
     // (2) scoring: every hypothesis in one pass over the points
     const float pfl[4] = {(float)pl[0], (float)pl[1], (float)pl[2], (float)pl[3]};
+    // the planes are wave-uniform (scalar registers); the inlier counts are too: a compare writes a lane mask, s_bcnt1 counts
+    // it -- one vector instruction per test, no per-lane counters and no reduction afterwards.  Lanes past the end of the
+    // list test the point (inf, 0, 0): inf or NaN on every plane, never an inlier.
     float pf[MAXH][4];
     int cnt[MAXH];
 #pragma unroll
@@ -184,35 +192,39 @@ __device__ int ransac_plane_wave(const float4 *__restrict__ pts, int n, int iter
         pf[q][3] = v ? d : __builtin_inff();  // invalid -> never an inlier
         cnt[q] = 0;
     }
+#ifdef RSX_NOSCORE
+    if (n < 0)
+#endif
     for (int i0 = 0; i0 < n; i0 += 256) {
         float4 p[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) p[u] = pts[min(i0 + 64 * u + lane, n - 1)];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const bool in = i0 + 64 * u + lane < n;
-            const rs_v2f xx = {p[u].x, p[u].x}, yy = {p[u].y, p[u].y}, zz = {p[u].z, p[u].z};
+            const float x = i0 + 64 * u + lane < n ? p[u].x : __builtin_inff();
+            const rs_v2f xx = {x, x}, yy = {p[u].y, p[u].y}, zz = {p[u].z, p[u].z};
 #pragma unroll
             for (int q = 0; q + 1 < MAXH; q += 2) {
                 const rs_v2f a = {pf[q][0], pf[q + 1][0]}, b2 = {pf[q][1], pf[q + 1][1]}, c2 = {pf[q][2], pf[q + 1][2]},
                              d2 = {pf[q][3], pf[q + 1][3]};
                 const rs_v2f dd = ((a * xx + b2 * yy) + c2 * zz) + d2;
-                cnt[q] += in && fabsf(dd.x) < thr_f;
-                cnt[q + 1] += in && fabsf(dd.y) < thr_f;
+                cnt[q] += (int)__popcll(__ballot(fabsf(dd.x) < thr_f));
+                cnt[q + 1] += (int)__popcll(__ballot(fabsf(dd.y) < thr_f));
             }
-            if (MAXH & 1) cnt[MAXH - 1] += in && plane_inlier(pf[MAXH - 1], p[u].x, p[u].y, p[u].z, thr_f);
+            if (MAXH & 1) cnt[MAXH - 1] += (int)__popcll(__ballot(plane_inlier(pf[MAXH - 1], x, p[u].y, p[u].z, thr_f)));
         }
     }
     int wcnt = -1, wh = 0;
 #pragma unroll
-    for (int q = 0; q < MAXH; q++) {
-        const int c = (int)dpp_sum_u32((uint32_t)cnt[q]);
-        if (q < iters && ((okmask >> q) & 1ull) && c > wcnt) { wcnt = c; wh = q; }  // most inliers, lowest h among equals
-    }
+    for (int q = 0; q < MAXH; q++)
+        if (q < iters && ((okmask >> q) & 1ull) && cnt[q] > wcnt) { wcnt = cnt[q]; wh = q; }  // most inliers, lowest h among equals
     if (wcnt < 0) return 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) plane[j] = wave_bcast_f64(pl[j], wh);
     if (wcnt < 3) return wcnt;
+#ifdef RSX_NOREFIT
+    return wcnt;
+#endif
     const float wf[4] = {(float)plane[0], (float)plane[1], (float)plane[2], (float)plane[3]};
     // (3) refit on the winner's inliers: ordered fp64 sums, centroid, then moments
     double a3[4][3];
@@ -355,13 +367,35 @@ __device__ float np_mean_wg(const float4 *__restrict__ pts, int n, NpwLds *W, fl
     return total / (float)n;
 }
 
+// plane_angle_validation (segment_utils.py:84-93) for one pixel: v = |n.t| / |n| * |t| in the reference's operation order;
+// "nan" when arccos(v) is NaN (alpha.max() is NaN then and NaN > threshold is False), "bad" when the angle is above the
+// threshold (v <= cos_cut).  The fp64 division is only done for the pixels the multiplication by 1/|n| cannot decide: its
+// result is within a few ulp of v, so it decides every pixel that is not within 1e-12 of cos_cut or of 1.
+__device__ __forceinline__ void plane_angle_test(float tx, float ty, float tz, double a, double bb, double c, double nrm, double inv_nrm,
+                                                 double cos_cut, bool in, bool &nan, bool &bad) {
+    const double dot = fabs(((double)tx * a + (double)ty * bb) + (double)tz * c);
+    const float tn = sqrtf((tx * tx + ty * ty) + tz * tz);
+    const double w = dot * inv_nrm * (double)tn;
+    const bool decided = w > cos_cut + 1e-12 && w < 1.0 - 1e-12;  // neither bad nor nan
+    if (in && !decided) {
+        const double v = dot / nrm * (double)tn;
+        nan |= (v != v) || v > 1.0;
+        bad |= v <= cos_cut;
+    }
+}
+
+#ifndef PL_THREADS
 #define PL_THREADS 256
-#define PL_MAXH 16
-// Workgroup form for one label (all 256 threads call it): ransac_plane_wg with thread t owning the strided partial t of the
-// ordered fp64 sums, four wavefronts sharing the point loops.  Used for the large labels, where one wavefront alone would be
-// the tail of the launch.
+#endif
+#ifndef PL_RU
+#define PL_RU 8
+#endif
+#define PL_MAXH 10
+// Workgroup form for one label (all PL_THREADS threads call it): ransac_plane_wg with thread t < 256 owning the strided
+// partial t of the ordered fp64 sums and the wavefronts sharing the points of the scoring, validation and mean passes.  Used
+// for the large labels, where one wavefront alone would be the tail of the launch.
 struct PlaneWgLds {
-    float part[8];
+    float part[PL_THREADS / 64];
     double sred[6 * RS_NT];
     double swin[64 + PL_MAXH * 4];
     int sbest[32];
@@ -369,34 +403,36 @@ struct PlaneWgLds {
 __device__ void plane_label_wg(const float *__restrict__ tm, const uint32_t *__restrict__ order, const float4 *__restrict__ pl_pts,
                                int n, uint32_t seed, const PlaneParams &pp, PlaneWgLds &S, NpwLds *NW_, float *__restrict__ row,
                                const double *__restrict__ inject) {
+    constexpr int NTH = PL_THREADS;
     const int tid = threadIdx.x;
     bool use_plane = false;
     double plane[4] = {0, 0, 0, 0};
     if (n >= pp.min_points) {
         LabelPoints pts;
         pts.pts = pl_pts; pts.n = n;
-        ransac_plane_wg<4, PL_THREADS, PL_MAXH, 4>(pts, pp.iters, (double)pp.thr, seed, plane, S.sred, S.swin, S.sbest);
+#ifndef PL_SKIP_RANSAC
+        ransac_plane_wg<4, NTH, PL_MAXH, 4, LabelPoints, true, PL_RU>(pts, pp.iters, (double)pp.thr, seed, plane, S.sred, S.swin, S.sbest);
+#else
+        plane[2] = 1.0;
+#endif
         if (inject) { plane[0] = inject[0]; plane[1] = inject[1]; plane[2] = inject[2]; plane[3] = inject[3]; }
-        // plane_angle_validation (segment_utils.py:84-93)
         const double a = plane[0], bb = plane[1], c = plane[2];
-        const double nrm = sqrt((a * a + bb * bb) + c * c);
+        const double nrm = sqrt((a * a + bb * bb) + c * c), inv_nrm = 1.0 / nrm;
         bool bad = false, nan = false;
-        for (int i0 = tid; i0 < n; i0 += PL_THREADS * 4) {  // 4 pixels per thread in flight (index, then ray gather)
-            uint32_t p[4];
+        uint32_t p[4], pn[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) pn[u] = order[min(tid + NTH * u, n - 1)];
+#ifdef PL_SKIP_VALID
+        if (n < 0)
+#endif
+        for (int i0 = tid; i0 < n; i0 += NTH * 4) {  // 4 pixels per thread in flight; the next indices load under the ray gather
             float tx[4], ty[4], tz[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) p[u] = order[min(i0 + PL_THREADS * u, n - 1)];
+            for (int u = 0; u < 4; u++) { p[u] = pn[u]; tx[u] = tm[3 * p[u]]; ty[u] = tm[3 * p[u] + 1]; tz[u] = tm[3 * p[u] + 2]; }
 #pragma unroll
-            for (int u = 0; u < 4; u++) { tx[u] = tm[3 * p[u]]; ty[u] = tm[3 * p[u] + 1]; tz[u] = tm[3 * p[u] + 2]; }
+            for (int u = 0; u < 4; u++) pn[u] = order[min(i0 + NTH * (4 + u), n - 1)];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const double dot = fabs(((double)tx[u] * a + (double)ty[u] * bb) + (double)tz[u] * c);
-                const float tn = sqrtf((tx[u] * tx[u] + ty[u] * ty[u]) + tz[u] * tz[u]);
-                const double v = dot / nrm * (double)tn;
-                const bool in = i0 + PL_THREADS * u < n;
-                nan |= in && ((v != v) || v > 1.0);   // arccos gives NaN, alpha.max() is NaN, NaN > threshold is False
-                bad |= in && v <= pp.cos_cut;
-            }
+            for (int u = 0; u < 4; u++) plane_angle_test(tx[u], ty[u], tz[u], a, bb, c, nrm, inv_nrm, pp.cos_cut, i0 + NTH * u < n, nan, bad);
         }
         const int any_nan = __syncthreads_or(nan ? 1 : 0), any_bad = __syncthreads_or(bad ? 1 : 0);
         use_plane = any_nan || !any_bad;
@@ -404,42 +440,52 @@ __device__ void plane_label_wg(const float *__restrict__ tm, const uint32_t *__r
     if (use_plane) {
         if (tid < 4) row[tid] = (float)plane[tid];
     } else {
+#ifndef PL_SKIP_MEAN
         const float mean = np_mean_wg(pl_pts, n, NW_, S.part);
+#else
+        const float mean = 0.f;
+#endif
         if (tid < 4) row[tid] = tid == 3 ? mean : 0.0f;
     }
-    __syncthreads();  // the next label of the workgroup reuses S
 }
 
-// One 256-thread workgroup per four consecutive labels of a frame.  Labels with more than `big` points are taken one after
-// the other by the whole workgroup (first: they are the tail), the others by one wavefront each, all four at once.
-// Measured on 256 frames of 64x2048 (26 k labels: 48 % below 30 points, median 35, 90 % below 900, largest 43 k), whole
-// rpcc_plane_model call: workgroup per label with the recursive mean 1.41 ms; this kernel 0.72 ms for big = 512 .. 8192
-// (0.74 at 256, 0.98 with every label on one wavefront: the 43 k label is the tail then); register budget for 6 waves per
-// SIMD 0.67 ms (default 4 waves: 0.72, 8 waves: 0.73).
-#define PL_BIG 2048
+// One launch, two kinds of workgroups:
+//   blockIdx <  B*(K-2): one (frame, label >= 2) each; returns at once unless the label has more than `big` points, which
+//                        the whole workgroup then fits.  These start first: the long labels are the critical path.
+//   the others:          PL_THREADS/64 consecutive labels of a frame, one wavefront each (labels above `big` skipped).
+// Measured on 256 frames of 64x2048 (26 k labels: 48 % below 30 points, median 35, 90 % below 900; per frame five to nine
+// labels above 2048 points holding 25 k .. 60 k of its pixels, the largest 15 k): DESIGN.md section 6.
+#ifndef PL_BIG
+#define PL_BIG 4096
+#endif
 template <int MAXH>
-__global__ __launch_bounds__(PL_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8))) void plane_model_kernel(const float *__restrict__ tm,
+#ifndef PL_WAVES
+#define PL_WAVES 4
+#endif
+__global__ __launch_bounds__(PL_THREADS) __attribute__((amdgpu_waves_per_eu(PL_WAVES, 8))) void plane_model_kernel(const float *__restrict__ tm,
                                                                  const uint32_t *__restrict__ order_all,
                                                                  const float4 *__restrict__ pts_all,
                                                                  const uint32_t *__restrict__ hist,
                                                                  const int32_t *__restrict__ counts,
-                                                                 const double *__restrict__ ground, int P, int M, int KP, int T,
+                                                                 const double *__restrict__ ground, int B, int P, int M, int KP, int T,
                                                                  PlaneParams pp, int big, float *__restrict__ model) {
     __shared__ PlaneWgLds S;
     __shared__ NpwLds npw[PL_THREADS / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int b = blockIdx.y, K = M + 2, k0 = blockIdx.x * (PL_THREADS / 64);
-    const uint32_t fid = pp.frame_ids ? (uint32_t)pp.frame_ids[b] : (uint32_t)b;
-    for (int w = 0; w < PL_THREADS / 64; w++) {   // workgroup-uniform
-        const int kk = k0 + w;
-        if (kk < 2 || kk >= K) continue;
+    const int K = M + 2, nbig = B * (K - 2);
+    if ((int)blockIdx.x < nbig) {  // workgroup-uniform
+        const int b = blockIdx.x / (K - 2), kk = 2 + blockIdx.x % (K - 2);
         const int nn = counts[(int64_t)b * K + kk];
-        if (nn <= big) continue;
+        if (nn <= big) return;
+        const uint32_t fid = pp.frame_ids ? (uint32_t)pp.frame_ids[b] : (uint32_t)b;
         const uint32_t base = hist[((int64_t)b * T) * KP + kk];  // tile 0 offset = start of label kk in the ordered list
         plane_label_wg(tm, order_all + (int64_t)b * P + base, pts_all + (int64_t)b * P + base, nn, mix32(pp.seed, fid, (uint32_t)kk),
                        pp, S, npw, model + ((int64_t)b * K + kk) * 4, pp.inject ? pp.inject + ((int64_t)b * K + kk) * 4 : nullptr);
+        return;
     }
-    const int k = k0 + wave;
+    const int groups = (K + PL_THREADS / 64 - 1) / (PL_THREADS / 64), g = blockIdx.x - nbig;
+    const int b = g / groups, k = (g % groups) * (PL_THREADS / 64) + wave;
+    const uint32_t fid = pp.frame_ids ? (uint32_t)pp.frame_ids[b] : (uint32_t)b;
     if (k >= K) return;
     float *row = model + ((int64_t)b * K + k) * 4;
     if (k == 0) {
@@ -459,38 +505,44 @@ __global__ __launch_bounds__(PL_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8
     double plane[4] = {0, 0, 0, 0};
     if (n >= pp.min_points) {
         const uint32_t seed = mix32(pp.seed, fid, (uint32_t)k);
+#ifndef PL_SKIP_RANSAC
         ransac_plane_wave<4, MAXH>(pts, n, pp.iters, pp.thr, seed, plane);
+#else
+        plane[2] = 1.0;
+#endif
         if (pp.inject) {
             const double *ij = pp.inject + ((int64_t)b * K + k) * 4;
             plane[0] = ij[0]; plane[1] = ij[1]; plane[2] = ij[2]; plane[3] = ij[3];
         }
-        // plane_angle_validation (segment_utils.py:84-93)
         const double a = plane[0], bb = plane[1], c = plane[2];
-        const double nrm = sqrt((a * a + bb * bb) + c * c);
+        const double nrm = sqrt((a * a + bb * bb) + c * c), inv_nrm = 1.0 / nrm;
         bool bad = false, nan = false;
-        for (int i0 = 0; i0 < n; i0 += 256) {
-            uint32_t p[4];
+#ifdef PL_SKIP_VALID
+        if (n < 0)
+#endif
+        uint32_t p[4], pn[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) pn[u] = order[min(64 * u + lane, n - 1)];
+        for (int i0 = 0; i0 < n; i0 += 256) {  // the next indices load under the ray gather
             float tx[4], ty[4], tz[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) p[u] = order[min(i0 + 64 * u + lane, n - 1)];
+            for (int u = 0; u < 4; u++) { p[u] = pn[u]; tx[u] = tm[3 * p[u]]; ty[u] = tm[3 * p[u] + 1]; tz[u] = tm[3 * p[u] + 2]; }
 #pragma unroll
-            for (int u = 0; u < 4; u++) { tx[u] = tm[3 * p[u]]; ty[u] = tm[3 * p[u] + 1]; tz[u] = tm[3 * p[u] + 2]; }
+            for (int u = 0; u < 4; u++) pn[u] = order[min(i0 + 256 + 64 * u + lane, n - 1)];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const double dot = fabs(((double)tx[u] * a + (double)ty[u] * bb) + (double)tz[u] * c);
-                const float tn = sqrtf((tx[u] * tx[u] + ty[u] * ty[u]) + tz[u] * tz[u]);
-                const double v = dot / nrm * (double)tn;
-                const bool in = i0 + 64 * u + lane < n;
-                nan |= in && ((v != v) || v > 1.0);   // arccos gives NaN, alpha.max() is NaN, NaN > threshold is False
-                bad |= in && v <= pp.cos_cut;
-            }
+            for (int u = 0; u < 4; u++)
+                plane_angle_test(tx[u], ty[u], tz[u], a, bb, c, nrm, inv_nrm, pp.cos_cut, i0 + 64 * u + lane < n, nan, bad);
         }
         use_plane = __ballot(nan) != 0ull || __ballot(bad) == 0ull;
     }
     if (use_plane) {
         if (lane < 4) row[lane] = (float)plane[lane];
     } else {
+#ifndef PL_SKIP_MEAN
         const float mean = np_mean_wave(pts, n, npw[wave]);
+#else
+        const float mean = 0.f;
+#endif
         if (lane < 4) row[lane] = lane == 3 ? mean : 0.0f;
     }
 }

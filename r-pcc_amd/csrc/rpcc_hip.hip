@@ -798,6 +798,7 @@ struct RsPoints {
 };
 
 typedef float rs_v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float rfl_f32(float v) { return u2f((uint32_t)__builtin_amdgcn_readfirstlane((int)f2u(v))); }
 // inlier test of the specification: fp32, un-fused, plane narrowed to fp32
 __device__ __forceinline__ bool plane_inlier(const float pl[4], float x, float y, float z, float thr) {
     return fabsf(((pl[0] * x + pl[1] * y) + pl[2] * z) + pl[3]) < thr;
@@ -829,7 +830,10 @@ __device__ __forceinline__ void rs_treesum(double (&v)[NV], double *sred) {
 // hypotheses); every thread calls it.  Returns the
 // winner's inlier count.  sred [6*RS_NT] doubles, swin [16*4] doubles, sbest [16*2] ints.
 // RS_PU: points per lane in flight in the scoring / refit loops (1 for points in LDS, more for points in global memory)
-template <int RN, int NTH, int MAXH, int RS_PU, class PTS>
+// BYPTS: the wavefronts share the POINTS instead of the hypotheses (every wavefront scores all MAXH <= 32 planes on its
+// part): for a long list in global memory and few hypotheses, where a pass over the list costs more than the tests.
+// RS_RU: points per thread in flight in the two ordered refit passes (only 256 threads walk those).
+template <int RN, int NTH, int MAXH, int RS_PU, class PTS, bool BYPTS = false, int RS_RU = RS_PU>
 __device__ int ransac_plane_wg(const PTS &pts, int iters, double thr, uint32_t seed, double plane[4], double *sred,
                                double *swin, int *sbest) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -840,7 +844,13 @@ __device__ int ransac_plane_wg(const PTS &pts, int iters, double thr, uint32_t s
     // (1) fits: one hypothesis per lane (iters <= RS_MAX_HYP), results narrowed to fp32 in LDS
     float *hyp = reinterpret_cast<float *>(sred);  // [iters][4] fp32 planes + validity, reused before the sums
     double *hypd = swin + 64;                      // [iters][4] fp64 planes (winner is read back from here)
+#ifdef RSX_NOFIT
+    if (tid < iters) { hyp[5 * tid] = 0; hyp[5 * tid + 1] = 0; hyp[5 * tid + 2] = 1; hyp[5 * tid + 3] = -(float)tid; hyp[5 * tid + 4] = 1.0f;
+                       hypd[4 * tid] = 0; hypd[4 * tid + 1] = 0; hypd[4 * tid + 2] = 1; hypd[4 * tid + 3] = -(double)tid; }
+    if (false) {
+#else
     if (tid < iters) {
+#endif
         const int h = tid;
         int idx[RN];
 #pragma unroll
@@ -873,77 +883,128 @@ __device__ int ransac_plane_wg(const PTS &pts, int iters, double thr, uint32_t s
         hyp[5 * h + 4] = ok ? 1.0f : 0.0f;
         hypd[4 * h] = pl[0]; hypd[4 * h + 1] = pl[1]; hypd[4 * h + 2] = pl[2]; hypd[4 * h + 3] = pl[3];
     }
+    if (BYPTS && tid < 32) sbest[tid] = 0;
     __syncthreads();
     DBG_STAMP(7);
-    // (2) scoring: wavefront w counts the inliers of hypotheses w, w+16, ... -- all of them in one pass
-    // over the points (a point is read from LDS once and tested against up to RS_HPW planes)
-    constexpr int RS_HPW = (MAXH + NTH / 64 - 1) / (NTH / 64);
-    float pf[RS_HPW][4];
-    int cnt[RS_HPW];
+    int wcnt = -1;
+    if constexpr (BYPTS) {
+        static_assert(!BYPTS || MAXH <= 32, "sbest holds one count per hypothesis");
+        float pf[MAXH][4];
+        int cnt[MAXH];
 #pragma unroll
-    for (int q = 0; q < RS_HPW; q++) {
-        const int h = wave + q * (NTH / 64);
-        const bool ok = h < iters && hyp[5 * (h < iters ? h : 0) + 4] != 0.0f;
-        const int hh = h < iters ? h : 0;
-        pf[q][0] = hyp[5 * hh]; pf[q][1] = hyp[5 * hh + 1]; pf[q][2] = hyp[5 * hh + 2];
-        pf[q][3] = ok ? hyp[5 * hh + 3] : __builtin_inff();  // invalid -> never an inlier
-        cnt[q] = 0;
-    }
-    for (int i0 = lane; i0 < n; i0 += 64 * RS_PU) {  // RS_PU points per lane in flight (unconditional, clamped loads)
-        float x[RS_PU], y[RS_PU], z[RS_PU];
-#pragma unroll
-        for (int u = 0; u < RS_PU; u++) pts.getf(min(i0 + 64 * u, n - 1), x[u], y[u], z[u]);
-#pragma unroll
-        for (int u = 0; u < RS_PU; u++) {
-            const bool in = i0 + 64 * u < n;
-            // two hypotheses per packed-fp32 instruction (v_pk_mul_f32 / v_pk_add_f32: each half rounds like the scalar
-            // operation, so this is plane_inlier() twice)
-            const rs_v2f xx = {x[u], x[u]}, yy = {y[u], y[u]}, zz = {z[u], z[u]};
-#pragma unroll
-            for (int q = 0; q + 1 < RS_HPW; q += 2) {
-                const rs_v2f a = {pf[q][0], pf[q + 1][0]}, b2 = {pf[q][1], pf[q + 1][1]}, c2 = {pf[q][2], pf[q + 1][2]},
-                             d2 = {pf[q][3], pf[q + 1][3]};
-                const rs_v2f dd = ((a * xx + b2 * yy) + c2 * zz) + d2;
-                cnt[q] += in && fabsf(dd.x) < thr_f;
-                cnt[q + 1] += in && fabsf(dd.y) < thr_f;
-            }
-            if (RS_HPW & 1) cnt[RS_HPW - 1] += in && plane_inlier(pf[RS_HPW - 1], x[u], y[u], z[u], thr_f);
+        for (int q = 0; q < MAXH; q++) {
+            const int hh = q < iters ? q : 0;
+            const bool ok = q < iters && hyp[5 * hh + 4] != 0.0f;
+            pf[q][0] = rfl_f32(hyp[5 * hh]); pf[q][1] = rfl_f32(hyp[5 * hh + 1]); pf[q][2] = rfl_f32(hyp[5 * hh + 2]);
+            pf[q][3] = rfl_f32(ok ? hyp[5 * hh + 3] : __builtin_inff());  // workgroup-uniform: scalar registers
+            cnt[q] = 0;
         }
-    }
-    int best_cnt = -1, best_h = 0x7fffffff;
+#ifdef RSX_NOSCORE
+        if (n < 0)
+#endif
+        for (int i0 = tid; i0 < n; i0 += NTH * RS_PU) {
+            float x[RS_PU], y[RS_PU], z[RS_PU];
 #pragma unroll
-    for (int q = 0; q < RS_HPW; q++) {
-        const int h = wave + q * (NTH / 64);
-        const int c = (int)dpp_sum_u32((uint32_t)cnt[q]);
-        if (h < iters && hyp[5 * h + 4] != 0.0f && c > best_cnt) { best_cnt = c; best_h = h; }
-    }
-    double best[4] = {0, 0, 1, 0};
-    if (best_cnt >= 0) { best[0] = hypd[4 * best_h]; best[1] = hypd[4 * best_h + 1]; best[2] = hypd[4 * best_h + 2]; best[3] = hypd[4 * best_h + 3]; }
-    __syncthreads();
-    DBG_STAMP(3);
-    if (lane == 0) {
-        sbest[2 * wave] = best_cnt; sbest[2 * wave + 1] = best_h;
-        swin[4 * wave] = best[0]; swin[4 * wave + 1] = best[1]; swin[4 * wave + 2] = best[2]; swin[4 * wave + 3] = best[3];
-    }
-    __syncthreads();
-    int wbest = -1, wcnt = -1, wh = 0x7fffffff;
-    for (int w = 0; w < NTH / 64; w++) {
-        const int c = sbest[2 * w], hh = sbest[2 * w + 1];
-        if (c > wcnt || (c == wcnt && c >= 0 && hh < wh)) { wcnt = c; wh = hh; wbest = w; }
+            for (int u = 0; u < RS_PU; u++) pts.getf(min(i0 + NTH * u, n - 1), x[u], y[u], z[u]);
+#pragma unroll
+            for (int u = 0; u < RS_PU; u++) {
+                // past the end: the point (inf, y, z) -- inf or NaN on every plane, never an inlier.  The counts are
+                // wave-uniform: a compare writes a lane mask, s_bcnt1 counts it.
+                const float xu = i0 + NTH * u < n ? x[u] : __builtin_inff();
+                const rs_v2f xx = {xu, xu}, yy = {y[u], y[u]}, zz = {z[u], z[u]};
+#pragma unroll
+                for (int q = 0; q + 1 < MAXH; q += 2) {
+                    const rs_v2f a = {pf[q][0], pf[q + 1][0]}, b2 = {pf[q][1], pf[q + 1][1]}, c2 = {pf[q][2], pf[q + 1][2]},
+                                 d2 = {pf[q][3], pf[q + 1][3]};
+                    const rs_v2f dd = ((a * xx + b2 * yy) + c2 * zz) + d2;
+                    cnt[q] += (int)__popcll(__ballot(fabsf(dd.x) < thr_f));
+                    cnt[q + 1] += (int)__popcll(__ballot(fabsf(dd.y) < thr_f));
+                }
+                if (MAXH & 1) cnt[MAXH - 1] += (int)__popcll(__ballot(plane_inlier(pf[MAXH - 1], xu, y[u], z[u], thr_f)));
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < MAXH; q++)
+            if (lane == 0 && cnt[q]) atomicAdd(&sbest[q], cnt[q]);
+        __syncthreads();
+        int wh = 0;
+        for (int q = 0; q < MAXH; q++)  // most inliers, lowest hypothesis among equals
+            if (q < iters && hyp[5 * q + 4] != 0.0f && sbest[q] > wcnt) { wcnt = sbest[q]; wh = q; }
+        if (wcnt >= 0) { plane[0] = hypd[4 * wh]; plane[1] = hypd[4 * wh + 1]; plane[2] = hypd[4 * wh + 2]; plane[3] = hypd[4 * wh + 3]; }
+    } else {
+        // (2) scoring: wavefront w counts the inliers of hypotheses w, w+16, ... -- all of them in one pass
+        // over the points (a point is read from LDS once and tested against up to RS_HPW planes)
+        constexpr int RS_HPW = (MAXH + NTH / 64 - 1) / (NTH / 64);
+        float pf[RS_HPW][4];
+        int cnt[RS_HPW];
+#pragma unroll
+        for (int q = 0; q < RS_HPW; q++) {
+            const int h = wave + q * (NTH / 64);
+            const bool ok = h < iters && hyp[5 * (h < iters ? h : 0) + 4] != 0.0f;
+            const int hh = h < iters ? h : 0;
+            pf[q][0] = hyp[5 * hh]; pf[q][1] = hyp[5 * hh + 1]; pf[q][2] = hyp[5 * hh + 2];
+            pf[q][3] = ok ? hyp[5 * hh + 3] : __builtin_inff();  // invalid -> never an inlier
+            cnt[q] = 0;
+        }
+        for (int i0 = lane; i0 < n; i0 += 64 * RS_PU) {  // RS_PU points per lane in flight (unconditional, clamped loads)
+            float x[RS_PU], y[RS_PU], z[RS_PU];
+#pragma unroll
+            for (int u = 0; u < RS_PU; u++) pts.getf(min(i0 + 64 * u, n - 1), x[u], y[u], z[u]);
+#pragma unroll
+            for (int u = 0; u < RS_PU; u++) {
+                const bool in = i0 + 64 * u < n;
+                // two hypotheses per packed-fp32 instruction (v_pk_mul_f32 / v_pk_add_f32: each half rounds like the scalar
+                // operation, so this is plane_inlier() twice)
+                const rs_v2f xx = {x[u], x[u]}, yy = {y[u], y[u]}, zz = {z[u], z[u]};
+#pragma unroll
+                for (int q = 0; q + 1 < RS_HPW; q += 2) {
+                    const rs_v2f a = {pf[q][0], pf[q + 1][0]}, b2 = {pf[q][1], pf[q + 1][1]}, c2 = {pf[q][2], pf[q + 1][2]},
+                                 d2 = {pf[q][3], pf[q + 1][3]};
+                    const rs_v2f dd = ((a * xx + b2 * yy) + c2 * zz) + d2;
+                    cnt[q] += in && fabsf(dd.x) < thr_f;
+                    cnt[q + 1] += in && fabsf(dd.y) < thr_f;
+                }
+                if (RS_HPW & 1) cnt[RS_HPW - 1] += in && plane_inlier(pf[RS_HPW - 1], x[u], y[u], z[u], thr_f);
+            }
+        }
+        int best_cnt = -1, best_h = 0x7fffffff;
+#pragma unroll
+        for (int q = 0; q < RS_HPW; q++) {
+            const int h = wave + q * (NTH / 64);
+            const int c = (int)dpp_sum_u32((uint32_t)cnt[q]);
+            if (h < iters && hyp[5 * h + 4] != 0.0f && c > best_cnt) { best_cnt = c; best_h = h; }
+        }
+        double best[4] = {0, 0, 1, 0};
+        if (best_cnt >= 0) { best[0] = hypd[4 * best_h]; best[1] = hypd[4 * best_h + 1]; best[2] = hypd[4 * best_h + 2]; best[3] = hypd[4 * best_h + 3]; }
+        __syncthreads();
+        DBG_STAMP(3);
+        if (lane == 0) {
+            sbest[2 * wave] = best_cnt; sbest[2 * wave + 1] = best_h;
+            swin[4 * wave] = best[0]; swin[4 * wave + 1] = best[1]; swin[4 * wave + 2] = best[2]; swin[4 * wave + 3] = best[3];
+        }
+        __syncthreads();
+        int wbest = -1, wh = 0x7fffffff;
+        for (int w = 0; w < NTH / 64; w++) {
+            const int c = sbest[2 * w], hh = sbest[2 * w + 1];
+            if (c > wcnt || (c == wcnt && c >= 0 && hh < wh)) { wcnt = c; wh = hh; wbest = w; }
+        }
+        if (wcnt >= 0) { plane[0] = swin[4 * wbest]; plane[1] = swin[4 * wbest + 1]; plane[2] = swin[4 * wbest + 2]; plane[3] = swin[4 * wbest + 3]; }
     }
     if (wcnt < 0) return 0;
-    plane[0] = swin[4 * wbest]; plane[1] = swin[4 * wbest + 1]; plane[2] = swin[4 * wbest + 2]; plane[3] = swin[4 * wbest + 3];
     if (wcnt < 3) return wcnt;
+#ifdef RSX_NOREFIT
+    return wcnt;
+#endif
     const float wf[4] = {(float)plane[0], (float)plane[1], (float)plane[2], (float)plane[3]};
     // refit on the winner's inliers (fp64 moments, ordered sums)
     double c[3] = {0, 0, 0};
     if (tid < RS_NT)
-        for (int i0 = tid; i0 < n; i0 += RS_NT * RS_PU) {  // partial tid accumulates its points in index order
-            float x[RS_PU], y[RS_PU], z[RS_PU];
+        for (int i0 = tid; i0 < n; i0 += RS_NT * RS_RU) {  // partial tid accumulates its points in index order
+            float x[RS_RU], y[RS_RU], z[RS_RU];
 #pragma unroll
-            for (int u = 0; u < RS_PU; u++) pts.getf(min(i0 + RS_NT * u, n - 1), x[u], y[u], z[u]);
+            for (int u = 0; u < RS_RU; u++) pts.getf(min(i0 + RS_NT * u, n - 1), x[u], y[u], z[u]);
 #pragma unroll
-            for (int u = 0; u < RS_PU; u++)
+            for (int u = 0; u < RS_RU; u++)
                 if (i0 + RS_NT * u < n && plane_inlier(wf, x[u], y[u], z[u], thr_f)) { c[0] += (double)x[u]; c[1] += (double)y[u]; c[2] += (double)z[u]; }
         }
     DBG_STAMP(4);
@@ -952,12 +1013,12 @@ __device__ int ransac_plane_wg(const PTS &pts, int iters, double thr, uint32_t s
     c[0] /= (double)wcnt; c[1] /= (double)wcnt; c[2] /= (double)wcnt;
     double m[6] = {0, 0, 0, 0, 0, 0};
     if (tid < RS_NT)
-        for (int i0 = tid; i0 < n; i0 += RS_NT * RS_PU) {
-            float x[RS_PU], y[RS_PU], z[RS_PU];
+        for (int i0 = tid; i0 < n; i0 += RS_NT * RS_RU) {
+            float x[RS_RU], y[RS_RU], z[RS_RU];
 #pragma unroll
-            for (int u = 0; u < RS_PU; u++) pts.getf(min(i0 + RS_NT * u, n - 1), x[u], y[u], z[u]);
+            for (int u = 0; u < RS_RU; u++) pts.getf(min(i0 + RS_NT * u, n - 1), x[u], y[u], z[u]);
 #pragma unroll
-            for (int u = 0; u < RS_PU; u++)
+            for (int u = 0; u < RS_RU; u++)
                 if (i0 + RS_NT * u < n && plane_inlier(wf, x[u], y[u], z[u], thr_f)) {
                     const double rx = (double)x[u] - c[0], ry = (double)y[u] - c[1], rz = (double)z[u] - c[2];
                     m[0] += rx * rx; m[1] += rx * ry; m[2] += rx * rz; m[3] += ry * ry; m[4] += ry * rz; m[5] += rz * rz;
@@ -2048,10 +2109,15 @@ static int launch_features(const float *ri, const uint8_t *seg, int B, int H, in
     ARG_TRY(W <= 64 * FEAT_GPW * (FEAT_THREADS / 64));                        // and so does a wavefront's part of the row
     FeatParams fp = {feature_region, segments, sharp_num, less_sharp_num, flat_num};
     const int need = ((W - 2 * feature_region) / segments + 63) / 64;  // keys per lane
-#define FEAT_LAUNCH(Q_)                                                                                          \
-    do {                                                                                                         \
-        HIP_TRY(ensure_dyn_lds(reinterpret_cast<const void *>(&features_kernel<Q_>), (int)sh));                       \
-        features_kernel<Q_><<<dim3(H, B), FEAT_THREADS, sh, st>>>(ri, seg, H, W, fp, feat, key_point_map, kpn, K);         \
+#define FEAT_LAUNCH_G(Q_, G_)                                                                                          \
+    do {                                                                                                               \
+        HIP_TRY(ensure_dyn_lds(reinterpret_cast<const void *>(&features_kernel<Q_, G_>), (int)sh));                    \
+        features_kernel<Q_, G_><<<dim3(H, B), FEAT_THREADS, sh, st>>>(ri, seg, H, W, fp, feat, key_point_map, kpn, K); \
+    } while (0)
+#define FEAT_LAUNCH(Q_)                                           \
+    do {                                                          \
+        if (W <= 64 * 8 * (FEAT_THREADS / 64)) FEAT_LAUNCH_G(Q_, 8); \
+        else FEAT_LAUNCH_G(Q_, FEAT_GPW);                         \
     } while (0)
     if (need <= 2) FEAT_LAUNCH(2);
     else if (need <= 4) FEAT_LAUNCH(4);
@@ -2059,6 +2125,7 @@ static int launch_features(const float *ri, const uint8_t *seg, int B, int H, in
     else if (need <= 8) FEAT_LAUNCH(8);
     else FEAT_LAUNCH(0);  // long chunks: keys stay in LDS
 #undef FEAT_LAUNCH
+#undef FEAT_LAUNCH_G
     LAUNCH_CHECK();
     return RPCC_OK;
 }
@@ -2127,8 +2194,11 @@ static int launch_plane_rows(const float *ri, const float *tm, const uint8_t *se
     label_order_kernel<<<dim3(T, B), 256, (size_t)16 * (KP + 1) * 4 + (size_t)KP * 4, st>>>(seg, L.hist, P, M, KP, T, order, ri, tm, pts4);
     PlaneParams pp;
     pp.cos_cut = cos_cut; pp.thr = 0.1f; pp.min_points = 30; pp.iters = 10; pp.seed = seed; pp.frame_ids = frame_ids; pp.inject = inject;
-    plane_model_kernel<10><<<dim3((K + PL_THREADS / 64 - 1) / (PL_THREADS / 64), B), PL_THREADS, 0, st>>>(tm, order, pts4, L.hist, counts, ground, P, M,
-                                                                                                     KP, T, pp, PL_BIG, model);
+    // B x (K-2) workgroups that exist for the labels above PL_BIG points (they start first: the long ones are the tail of
+    // the launch), then one wavefront per label for the rest
+    const int wpg = PL_THREADS / 64, groups = (K + wpg - 1) / wpg;
+    plane_model_kernel<10><<<B * (K - 2) + B * groups, PL_THREADS, 0, st>>>(tm, order, pts4, L.hist, counts, ground, B, P, M, KP, T, pp,
+                                                                            PL_BIG, model);
     LAUNCH_CHECK();
     return RPCC_OK;
 }

@@ -1,5 +1,12 @@
 #!/bin/bash
+# usage: tools_dev/r2_band.sh "<flags>" ... : rebuild with the flags, serial kernel stats (grep pattern in $PAT)
 cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp
-for f in "-DBAND_EXP_NOATOMIC" "-DBAND_EXP_NOATOMIC -DBAND_INFLIGHT=8" "-DBAND_THREADS=512 -DBAND_INFLIGHT=8"; do
-  echo "== $f"; RPCC_EXTRA_FLAGS="$f" bash tools_dev/kstats.sh --steps 6 --warmup 2 --no-verify 2>&1 | grep -E "band|sum of"
+for f in "$@"; do
+  echo "== $f"
+  RPCC_EXTRA_FLAGS="$f" python3 -c "
+import sys; sys.path.insert(0,'.')
+import rpcc_amd
+from rpcc_amd import build as b
+b.build(force=True)"
+  bash tools_dev/kstats.sh --steps 6 --warmup 2 --no-verify $KARGS 2>&1 | grep -E "${PAT:-assign|sum of}"
 done
