@@ -13,8 +13,9 @@
 // differs from the double accumulation of the point model.
 #pragma once
 
-// label-ordered pixel list: order[b][pos] = pixel index, labels ascending (label 1 skipped), row-major
-// inside a label -- the same positions the quantiser's ordered scatter uses.
+// label-ordered pixel list: order[b][pos] = pixel index, labels ascending, row-major inside a label -- the same positions
+// the quantiser's ordered scatter uses.  Labels 0 (ground: its model is the ground plane) and 1 (empty) have no plane fit:
+// their positions are left unwritten (about half of a frame's pixels).
 // pts4 (optional): the same list as points (x, y, z, r) so that the plane model streams a label's points instead of
 // gathering them through the pixel index.
 __global__ __launch_bounds__(256) void label_order_kernel(const uint8_t *__restrict__ seg, const uint32_t *__restrict__ hist,
@@ -47,7 +48,7 @@ __global__ __launch_bounds__(256) void label_order_kernel(const uint8_t *__restr
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int p = t * TILE + j * 256 + threadIdx.x;
-        lab[j] = (p < P && lraw[j] != 1) ? lraw[j] : -1;
+        lab[j] = (p < P && lraw[j] > 1) ? lraw[j] : -1;
         rank[j] = 0;
         int todo = lab[j];
         while (true) {
@@ -136,12 +137,7 @@ __device__ int ransac_plane_wave(const float4 *__restrict__ pts, int n, int iter
     // (1) fits: hypothesis h on lane h
     double pl[4] = {0, 0, 0, 0};
     bool ok = false;
-#ifdef RSX_NOFIT
-    if (lane < iters) { pl[2] = 1.0; pl[3] = -(double)lane; ok = true; }
-    if (false) {
-#else
     if (lane < iters) {
-#endif
         const int h = lane;
         int idx[RN];
 #pragma unroll
@@ -192,9 +188,6 @@ __device__ int ransac_plane_wave(const float4 *__restrict__ pts, int n, int iter
         pf[q][3] = v ? d : __builtin_inff();  // invalid -> never an inlier
         cnt[q] = 0;
     }
-#ifdef RSX_NOSCORE
-    if (n < 0)
-#endif
     for (int i0 = 0; i0 < n; i0 += 256) {
         float4 p[4];
 #pragma unroll
@@ -222,9 +215,6 @@ __device__ int ransac_plane_wave(const float4 *__restrict__ pts, int n, int iter
 #pragma unroll
     for (int j = 0; j < 4; j++) plane[j] = wave_bcast_f64(pl[j], wh);
     if (wcnt < 3) return wcnt;
-#ifdef RSX_NOREFIT
-    return wcnt;
-#endif
     const float wf[4] = {(float)plane[0], (float)plane[1], (float)plane[2], (float)plane[3]};
     // (3) refit on the winner's inliers: ordered fp64 sums, centroid, then moments
     double a3[4][3];
@@ -410,11 +400,7 @@ __device__ void plane_label_wg(const float *__restrict__ tm, const uint32_t *__r
     if (n >= pp.min_points) {
         LabelPoints pts;
         pts.pts = pl_pts; pts.n = n;
-#ifndef PL_SKIP_RANSAC
         ransac_plane_wg<4, NTH, PL_MAXH, 4, LabelPoints, true, PL_RU>(pts, pp.iters, (double)pp.thr, seed, plane, S.sred, S.swin, S.sbest);
-#else
-        plane[2] = 1.0;
-#endif
         if (inject) { plane[0] = inject[0]; plane[1] = inject[1]; plane[2] = inject[2]; plane[3] = inject[3]; }
         const double a = plane[0], bb = plane[1], c = plane[2];
         const double nrm = sqrt((a * a + bb * bb) + c * c), inv_nrm = 1.0 / nrm;
@@ -422,9 +408,6 @@ __device__ void plane_label_wg(const float *__restrict__ tm, const uint32_t *__r
         uint32_t p[4], pn[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) pn[u] = order[min(tid + NTH * u, n - 1)];
-#ifdef PL_SKIP_VALID
-        if (n < 0)
-#endif
         for (int i0 = tid; i0 < n; i0 += NTH * 4) {  // 4 pixels per thread in flight; the next indices load under the ray gather
             float tx[4], ty[4], tz[4];
 #pragma unroll
@@ -440,11 +423,7 @@ __device__ void plane_label_wg(const float *__restrict__ tm, const uint32_t *__r
     if (use_plane) {
         if (tid < 4) row[tid] = (float)plane[tid];
     } else {
-#ifndef PL_SKIP_MEAN
         const float mean = np_mean_wg(pl_pts, n, NW_, S.part);
-#else
-        const float mean = 0.f;
-#endif
         if (tid < 4) row[tid] = tid == 3 ? mean : 0.0f;
     }
 }
@@ -505,11 +484,7 @@ __global__ __launch_bounds__(PL_THREADS) __attribute__((amdgpu_waves_per_eu(PL_W
     double plane[4] = {0, 0, 0, 0};
     if (n >= pp.min_points) {
         const uint32_t seed = mix32(pp.seed, fid, (uint32_t)k);
-#ifndef PL_SKIP_RANSAC
         ransac_plane_wave<4, MAXH>(pts, n, pp.iters, pp.thr, seed, plane);
-#else
-        plane[2] = 1.0;
-#endif
         if (pp.inject) {
             const double *ij = pp.inject + ((int64_t)b * K + k) * 4;
             plane[0] = ij[0]; plane[1] = ij[1]; plane[2] = ij[2]; plane[3] = ij[3];
@@ -517,9 +492,6 @@ __global__ __launch_bounds__(PL_THREADS) __attribute__((amdgpu_waves_per_eu(PL_W
         const double a = plane[0], bb = plane[1], c = plane[2];
         const double nrm = sqrt((a * a + bb * bb) + c * c), inv_nrm = 1.0 / nrm;
         bool bad = false, nan = false;
-#ifdef PL_SKIP_VALID
-        if (n < 0)
-#endif
         uint32_t p[4], pn[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) pn[u] = order[min(64 * u + lane, n - 1)];
@@ -538,11 +510,7 @@ __global__ __launch_bounds__(PL_THREADS) __attribute__((amdgpu_waves_per_eu(PL_W
     if (use_plane) {
         if (lane < 4) row[lane] = (float)plane[lane];
     } else {
-#ifndef PL_SKIP_MEAN
         const float mean = np_mean_wave(pts, n, npw[wave]);
-#else
-        const float mean = 0.f;
-#endif
         if (lane < 4) row[lane] = lane == 3 ? mean : 0.0f;
     }
 }

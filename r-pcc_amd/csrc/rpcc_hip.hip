@@ -844,13 +844,7 @@ __device__ int ransac_plane_wg(const PTS &pts, int iters, double thr, uint32_t s
     // (1) fits: one hypothesis per lane (iters <= RS_MAX_HYP), results narrowed to fp32 in LDS
     float *hyp = reinterpret_cast<float *>(sred);  // [iters][4] fp32 planes + validity, reused before the sums
     double *hypd = swin + 64;                      // [iters][4] fp64 planes (winner is read back from here)
-#ifdef RSX_NOFIT
-    if (tid < iters) { hyp[5 * tid] = 0; hyp[5 * tid + 1] = 0; hyp[5 * tid + 2] = 1; hyp[5 * tid + 3] = -(float)tid; hyp[5 * tid + 4] = 1.0f;
-                       hypd[4 * tid] = 0; hypd[4 * tid + 1] = 0; hypd[4 * tid + 2] = 1; hypd[4 * tid + 3] = -(double)tid; }
-    if (false) {
-#else
     if (tid < iters) {
-#endif
         const int h = tid;
         int idx[RN];
 #pragma unroll
@@ -899,9 +893,6 @@ __device__ int ransac_plane_wg(const PTS &pts, int iters, double thr, uint32_t s
             pf[q][3] = rfl_f32(ok ? hyp[5 * hh + 3] : __builtin_inff());  // workgroup-uniform: scalar registers
             cnt[q] = 0;
         }
-#ifdef RSX_NOSCORE
-        if (n < 0)
-#endif
         for (int i0 = tid; i0 < n; i0 += NTH * RS_PU) {
             float x[RS_PU], y[RS_PU], z[RS_PU];
 #pragma unroll
@@ -992,9 +983,6 @@ __device__ int ransac_plane_wg(const PTS &pts, int iters, double thr, uint32_t s
     }
     if (wcnt < 0) return 0;
     if (wcnt < 3) return wcnt;
-#ifdef RSX_NOREFIT
-    return wcnt;
-#endif
     const float wf[4] = {(float)plane[0], (float)plane[1], (float)plane[2], (float)plane[3]};
     // refit on the winner's inliers (fp64 moments, ordered sums)
     double c[3] = {0, 0, 0};
