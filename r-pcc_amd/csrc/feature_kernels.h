@@ -45,6 +45,50 @@ __device__ __forceinline__ void feat_wave_min(uint32_t hi, uint32_t lo, uint32_t
 #define FEAT_THREADS 256     // one workgroup (4 wavefronts) per image row
 #define FEAT_GPW 16          // 64-column groups per wavefront: W <= 4096
 typedef unsigned long long feat_key;  // curvature bits << 32 | compacted position + 1; 0 = no key
+
+// ---- row mode: one chunk per 16-lane DPP row, four chunks per wavefront ----------------------------------------------------
+// all-reduce inside the 16-lane rows by rotation (row_ror 8, 4, 2, 1): every lane ends with its row's maximum / minimum
+__device__ __forceinline__ uint32_t row_allmax_u32(uint32_t v) {
+#define STEP_(ctrl_) v = max(v, (uint32_t)RPCC_DPP(0, v, ctrl_, 0xf))
+    STEP_(0x128); STEP_(0x124); STEP_(0x122); STEP_(0x121);
+#undef STEP_
+    return v;
+}
+__device__ __forceinline__ uint32_t row_allmin_u32(uint32_t v) {
+#define STEP_(ctrl_) v = min(v, (uint32_t)RPCC_DPP(-1, v, ctrl_, 0xf))
+    STEP_(0x128); STEP_(0x124); STEP_(0x122); STEP_(0x121);
+#undef STEP_
+    return v;
+}
+__device__ __forceinline__ feat_key row_allmax_key(feat_key k) {
+    const uint32_t hi = (uint32_t)(k >> 32), lo = (uint32_t)k;
+    const uint32_t mh = row_allmax_u32(hi), ml = row_allmax_u32(hi == mh ? lo : 0u);
+    return ((feat_key)mh << 32) | ml;
+}
+__device__ __forceinline__ feat_key row_allmin_key(feat_key k) {
+    const uint32_t hi = (uint32_t)(k >> 32), lo = (uint32_t)k;
+    const uint32_t mh = row_allmin_u32(hi), ml = row_allmin_u32(hi == mh ? lo : 0xFFFFFFFFu);
+    return ((feat_key)mh << 32) | ml;
+}
+// the three largest (smallest) of a lane's keys, kept sorted: x is inserted
+__device__ __forceinline__ void top3_insert(feat_key x, feat_key &c1, feat_key &c2, feat_key &c3) {
+    bool g = x > c1;
+    feat_key t = g ? c1 : x; c1 = g ? x : c1; x = t;
+    g = x > c2;
+    t = g ? c2 : x; c2 = g ? x : c2; x = t;
+    c3 = x > c3 ? x : c3;
+}
+__device__ __forceinline__ void bot3_insert(feat_key x, feat_key &c1, feat_key &c2, feat_key &c3) {
+    bool g = x < c1;
+    feat_key t = g ? c1 : x; c1 = g ? x : c1; x = t;
+    g = x < c2;
+    t = g ? c2 : x; c2 = g ? x : c2; x = t;
+    c3 = x < c3 ? x : c3;
+}
+#define FEAT_ROWMODE (-1)  // template value of Q: chunk <= 256 entries, 16 keys per lane
+#define FEAT_RQ 16
+#define FEAT_ROW_SEGS 32  // row mode: most segments ...
+#define FEAT_ROW_FLAT 8   // ... and most flat key points per segment (flat_num - 1)
 template <int Q, int GP = FEAT_GPW>  // keys per lane: chunk <= 64 * Q; 64-column groups per wavefront: W <= 256 * GP
 __global__ __launch_bounds__(FEAT_THREADS) void features_kernel(const float *__restrict__ ri, const uint8_t *__restrict__ seg,
                                                                 int H, int W, FeatParams fp, float *__restrict__ feat,
@@ -53,6 +97,7 @@ __global__ __launch_bounds__(FEAT_THREADS) void features_kernel(const float *__r
     extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
     __shared__ int wcnt[FEAT_THREADS / 64];
     __shared__ int kcnt[256];  // key points per label of this row
+    __shared__ feat_key sel_thr[Q == FEAT_ROWMODE ? FEAT_ROW_SEGS : 1], sel_small[Q == FEAT_ROWMODE ? FEAT_ROW_SEGS * FEAT_ROW_FLAT : 1];
     float *row = reinterpret_cast<float *>(fsm);
     float *v = row + W;
     float *cbuf = v + W;
@@ -129,6 +174,92 @@ __global__ __launch_bounds__(FEAT_THREADS) void features_kernel(const float *__r
         // the less_sharp_num largest, then the flat_num smallest accepted keys of every chunk, FEAT_CP chunks interleaved
         // (independent dependency chains hide the latency of the DPP reductions)
         const int stop_n = max(1, max(fp.sharp_num, fp.less_sharp_num));  // the first loop breaks at this accepted entry
+        if constexpr (Q == FEAT_ROWMODE) {
+            // Every round of the two selections costs two reductions and a pass over the lane's keys in the register form
+            // below; here a chunk lives in one 16-lane row (entry i on lane i % 16: neighbours, which tend to be large
+            // together, on different lanes), four chunks per wavefront, the reductions are four DPP rotations each, and a lane
+            // keeps its three best remaining keys sorted, so that a round is: reduce, the winner shifts its cache.  A lane
+            // that wins a fourth time rebuilds the cache from its keys (once per few wavefronts).
+            // The two selections run side by side on different wavefronts (0, 1: the largest; 2, 3: the smallest): the
+            // smallest are taken among ALL accepted non-zero keys and filtered by the threshold afterwards -- they come out
+            // in ascending order, so the ones below the threshold are exactly the first ones of the reference's second loop.
+            const int r = lane & 15, row4 = lane >> 4, half = wave & 1;
+            const bool smallest = wave >= 2;
+            const feat_key none = ~0ull;
+            for (int j0 = half * 4; j0 < fp.segments; j0 += 8) {
+                const int j = j0 + row4;
+                const bool rowok = j < fp.segments;
+                const int sp = chunk * j;
+                feat_key key[FEAT_RQ];
+#pragma unroll
+                for (int q = 0; q < FEAT_RQ; q++) {
+                    const int i = r + 16 * q;
+                    const bool have = rowok && i < chunk;
+                    const int ii = have ? sp + i : 0;
+                    key[q] = (have && accf[ii] != 0) ? ((feat_key)f2u(cbuf[ii]) << 32) | (feat_key)(uint32_t)(ii + fr + 1) : 0ull;
+                }
+                if (!smallest) {
+                    // the stop_n - 1 largest get 3 / 2, the stop_n-th is the threshold of the visited entries
+                    feat_key c1 = 0ull, c2 = 0ull, c3 = 0ull, thr = 0ull;
+#pragma unroll
+                    for (int q = 0; q < FEAT_RQ; q++) top3_insert(key[q], c1, c2, c3);
+                    int left = 3;
+                    for (int n = 1; n <= stop_n; n++) {
+                        const feat_key m = row_allmax_key(c1);
+                        if (__ballot(m != 0ull) == 0ull) break;  // every row of the wavefront is exhausted
+                        if (n == stop_n) { thr = m; break; }      // 0 in an exhausted row: all visited
+                        const bool win = m != 0ull && c1 == m;
+                        if (win) {
+                            kprow[vidx[(uint32_t)m - 1u]] = n < fp.sharp_num ? 3 : 2;
+                            c1 = c2; c2 = c3; c3 = 0ull;
+                            left--;
+                        }
+                        if (__ballot(win && left == 0) != 0ull) {  // rare: rebuild from the keys below the winner
+                            if (win && left == 0) {
+                                c1 = 0ull; c2 = 0ull; c3 = 0ull;
+#pragma unroll
+                                for (int q = 0; q < FEAT_RQ; q++) top3_insert(key[q] < m ? key[q] : 0ull, c1, c2, c3);
+                                left = 3;
+                            }
+                        }
+                    }
+                    if (rowok && r == 0) sel_thr[j] = thr;
+                } else {
+                    // the flat_num - 1 smallest accepted entries with a non-zero curvature, in ascending order
+                    feat_key d1 = none, d2 = none, d3 = none;
+#pragma unroll
+                    for (int q = 0; q < FEAT_RQ; q++) {
+                        key[q] = u2f((uint32_t)(key[q] >> 32)) != 0.0f ? key[q] : none;
+                        bot3_insert(key[q], d1, d2, d3);
+                    }
+                    if (rowok && r < FEAT_ROW_FLAT) sel_small[j * FEAT_ROW_FLAT + r] = none;
+                    int left = 3;
+                    for (int n = 1; n < fp.flat_num; n++) {
+                        const feat_key m = row_allmin_key(d1);
+                        if (__ballot(m != none) == 0ull) break;
+                        if (rowok && r == 0) sel_small[j * FEAT_ROW_FLAT + n - 1] = m;
+                        const bool win = m != none && d1 == m;
+                        if (win) {
+                            d1 = d2; d2 = d3; d3 = none;
+                            left--;
+                        }
+                        if (__ballot(win && left == 0) != 0ull) {
+                            if (win && left == 0) {
+                                d1 = none; d2 = none; d3 = none;
+#pragma unroll
+                                for (int q = 0; q < FEAT_RQ; q++) bot3_insert(key[q] > m ? key[q] : none, d1, d2, d3);
+                                left = 3;
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();  // workgroup-uniform: `active` and the template value are
+            for (int i = tid; i < fp.segments * FEAT_ROW_FLAT; i += FEAT_THREADS) {
+                const feat_key t = sel_thr[i / FEAT_ROW_FLAT], w = sel_small[i];
+                if (i % FEAT_ROW_FLAT < fp.flat_num - 1 && w != none && w < t) kprow[vidx[(uint32_t)w - 1u]] = 1;  // t == 0: all visited
+            }
+        } else
         if constexpr (Q == 0) {
             // chunks of more than 64 * FEAT_MAX_PER_LANE entries (few segments on a wide image): the same selection with the
             // keys rebuilt from LDS in every round instead of held in registers, one chunk per wavefront at a time
@@ -172,7 +303,7 @@ __global__ __launch_bounds__(FEAT_THREADS) void features_kernel(const float *__r
             }
         } else
         for (int j0 = wave * FEAT_CP; j0 < fp.segments; j0 += FEAT_CP * (FEAT_THREADS / 64)) {
-            feat_key key[FEAT_CP][Q ? Q : 1], prev[FEAT_CP], thr[FEAT_CP];
+            feat_key key[FEAT_CP][Q > 0 ? Q : 1], prev[FEAT_CP], thr[FEAT_CP];
             bool alive[FEAT_CP];
 #pragma unroll
             for (int cI = 0; cI < FEAT_CP; cI++) {
@@ -206,7 +337,7 @@ __global__ __launch_bounds__(FEAT_THREADS) void features_kernel(const float *__r
                     prev[cI] = m;
                 }
             }
-            feat_key ek[FEAT_CP][Q ? Q : 1];
+            feat_key ek[FEAT_CP][Q > 0 ? Q : 1];
 #pragma unroll
             for (int cI = 0; cI < FEAT_CP; cI++) {
                 alive[cI] = thr[cI] != 0ull;

@@ -2107,6 +2107,11 @@ static int launch_features(const float *ri, const uint8_t *seg, int B, int H, in
         if (W <= 64 * 8 * (FEAT_THREADS / 64)) FEAT_LAUNCH_G(Q_, 8); \
         else FEAT_LAUNCH_G(Q_, FEAT_GPW);                         \
     } while (0)
+#ifndef FEAT_NO_ROWMODE
+    if ((W - 2 * feature_region) / segments <= 16 * FEAT_RQ && segments <= FEAT_ROW_SEGS && flat_num - 1 <= FEAT_ROW_FLAT)
+        FEAT_LAUNCH(FEAT_ROWMODE);  // a chunk fits a 16-lane row
+    else
+#endif
     if (need <= 2) FEAT_LAUNCH(2);
     else if (need <= 4) FEAT_LAUNCH(4);
     else if (need <= 6) FEAT_LAUNCH(6);
