@@ -89,7 +89,10 @@ __device__ __forceinline__ void bot3_insert(feat_key x, feat_key &c1, feat_key &
 #define FEAT_RQ 16
 #define FEAT_ROW_SEGS 32  // row mode: most segments ...
 #define FEAT_ROW_FLAT 8   // ... and most flat key points per segment (flat_num - 1)
-template <int Q, int GP = FEAT_GPW>  // keys per lane: chunk <= 64 * Q; 64-column groups per wavefront: W <= 256 * GP
+// Q: keys per lane (chunk <= 64 * Q) or FEAT_ROWMODE; GP: 64-column groups per wavefront (W <= 256 * GP);
+// FEATOUT = false (row mode only, ranges >= 0): no curvature image is produced, the curvatures take the place of the row in
+// LDS with the "accepted" flag in their sign bit -- 11 bytes of LDS per column instead of 16: 7 workgroups per CU, not 5.
+template <int Q, int GP = FEAT_GPW, bool FEATOUT = true>
 __global__ __launch_bounds__(FEAT_THREADS) void features_kernel(const float *__restrict__ ri, const uint8_t *__restrict__ seg,
                                                                 int H, int W, FeatParams fp, float *__restrict__ feat,
                                                                 uint8_t *__restrict__ kp, int32_t *__restrict__ kpn = nullptr,
@@ -98,12 +101,13 @@ __global__ __launch_bounds__(FEAT_THREADS) void features_kernel(const float *__r
     __shared__ int wcnt[FEAT_THREADS / 64];
     __shared__ int kcnt[256];  // key points per label of this row
     __shared__ feat_key sel_thr[Q == FEAT_ROWMODE ? FEAT_ROW_SEGS : 1], sel_small[Q == FEAT_ROWMODE ? FEAT_ROW_SEGS * FEAT_ROW_FLAT : 1];
+    static_assert(FEATOUT || Q == FEAT_ROWMODE, "the compact LDS layout is built for the row mode");
     float *row = reinterpret_cast<float *>(fsm);
     float *v = row + W;
-    float *cbuf = v + W;
-    uint16_t *vidx = reinterpret_cast<uint16_t *>(cbuf + W);
-    uint8_t *accf = reinterpret_cast<uint8_t *>(vidx + W);
-    uint8_t *kprow = accf + W;
+    float *cbuf = FEATOUT ? v + W : row;
+    uint16_t *vidx = reinterpret_cast<uint16_t *>((FEATOUT ? cbuf : v) + W);
+    uint8_t *accf = reinterpret_cast<uint8_t *>(vidx + W);  // FEATOUT only
+    uint8_t *kprow = FEATOUT ? accf + W : accf;
     const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t base = ((int64_t)b * H + h) * W;
     const int fr = fp.feature_region;
@@ -146,29 +150,56 @@ __global__ __launch_bounds__(FEAT_THREADS) void features_kernel(const float *__r
     __syncthreads();
     const bool active = vl >= fp.segments + fr * 2 + 1;  // cpp_modules.cpp:59
     const int L = vl - 2 * fr;
-    if (active) {
-        for (int s = fr + tid; s < vl - fr; s += FEAT_THREADS) {  // cpp_modules.cpp:64-72, fp32 in that operation order
-            float f = 0.0f;
-            const float vs = v[s];
-            for (int k = -fr; k <= fr; k++) f += v[s + k] - vs;
-            f = f * f;
-            f /= (float)(2 * fr);
-            f /= vs;
-            cbuf[s - fr] = f;
-            // mark_as_picked's return value (cpp_modules.cpp:10-25); fr <= s <= col <= W-1-fr, so col +- fr is inside the row
-            const int col = vidx[s];
-            const float r = row[col];
-            bool ok = true;
-            for (int k = -fr; k <= fr; k++) ok = ok && !(r - row[col + k] > 0.3f);
-            accf[s - fr] = ok ? 1 : 0;
+    // curvature (cpp_modules.cpp:64-72, fp32 in that operation order) and mark_as_picked's return value (:10-25;
+    // fr <= s <= col <= W-1-fr, so col +- fr is inside the row) of the compacted position s
+    auto curvature = [&](int s, float &f, bool &ok) {
+        f = 0.0f;
+        const float vs = v[s];
+        for (int k = -fr; k <= fr; k++) f += v[s + k] - vs;
+        f = f * f;
+        f /= (float)(2 * fr);
+        f /= vs;
+        const int col = vidx[s];
+        ok = true;
+        for (int k = -fr; k <= fr; k++) ok = ok && !(vs - row[col + k] > 0.3f);  // row[col] is v[s]
+    };
+    if constexpr (FEATOUT) {
+        if (active) {
+            for (int s = fr + tid; s < vl - fr; s += FEAT_THREADS) {
+                float f;
+                bool ok;
+                curvature(s, f, ok);
+                cbuf[s - fr] = f;
+                accf[s - fr] = ok ? 1 : 0;
+            }
         }
+        __syncthreads();
+        // feat row (aliases v, which is dead now): zero, then the curvatures at their columns
+        for (int c = tid; c < W; c += FEAT_THREADS) v[c] = 0.0f;
+        __syncthreads();
+        if (active)
+            for (int i = tid; i < L; i += FEAT_THREADS) v[vidx[i + fr]] = cbuf[i];
+    } else {
+        uint32_t cb[GP];
+#pragma unroll
+        for (int u = 0; u < GP; u++) {
+            const int s = fr + tid + FEAT_THREADS * u;
+            cb[u] = 0u;
+            if (active && s < vl - fr) {
+                float f;
+                bool ok;
+                curvature(s, f, ok);
+                cb[u] = (f2u(f) & 0x7FFFFFFFu) | (ok ? 0x80000000u : 0u);
+            }
+        }
+        __syncthreads();  // the row is dead: the curvatures take its place
+#pragma unroll
+        for (int u = 0; u < GP; u++) {
+            const int s = fr + tid + FEAT_THREADS * u;
+            if (active && s < vl - fr) reinterpret_cast<uint32_t *>(cbuf)[s - fr] = cb[u];
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    // feat row (aliases v, which is dead now): zero, then the curvatures at their columns
-    for (int c = tid; c < W; c += FEAT_THREADS) v[c] = 0.0f;
-    __syncthreads();
-    if (active)
-        for (int i = tid; i < L; i += FEAT_THREADS) v[vidx[i + fr]] = cbuf[i];
     if (active) {
         const int chunk = L / fp.segments;
         // the less_sharp_num largest, then the flat_num smallest accepted keys of every chunk, FEAT_CP chunks interleaved
@@ -196,7 +227,12 @@ __global__ __launch_bounds__(FEAT_THREADS) void features_kernel(const float *__r
                     const int i = r + 16 * q;
                     const bool have = rowok && i < chunk;
                     const int ii = have ? sp + i : 0;
-                    key[q] = (have && accf[ii] != 0) ? ((feat_key)f2u(cbuf[ii]) << 32) | (feat_key)(uint32_t)(ii + fr + 1) : 0ull;
+                    if constexpr (FEATOUT) {
+                        key[q] = (have && accf[ii] != 0) ? ((feat_key)f2u(cbuf[ii]) << 32) | (feat_key)(uint32_t)(ii + fr + 1) : 0ull;
+                    } else {
+                        const uint32_t cbits = reinterpret_cast<const uint32_t *>(cbuf)[ii];
+                        key[q] = (have && (cbits >> 31)) ? ((feat_key)(cbits & 0x7FFFFFFFu) << 32) | (feat_key)(uint32_t)(ii + fr + 1) : 0ull;
+                    }
                 }
                 if (!smallest) {
                     // the stop_n - 1 largest get 3 / 2, the stop_n-th is the threshold of the visited entries
@@ -367,7 +403,7 @@ __global__ __launch_bounds__(FEAT_THREADS) void features_kernel(const float *__r
     }
     __syncthreads();
     for (int c = tid; c < W; c += FEAT_THREADS) {
-        if (feat) feat[base + c] = v[c];
+        if (FEATOUT && feat) feat[base + c] = v[c];
         kp[base + c] = kprow[c];
         // key points per label for the salience levels (sparse: a few dozen per row), tallied in LDS first: one device
         // atomic per label present in the row instead of one per key point (1.6 M atomics per batch cost 0.2 ms)

@@ -2092,31 +2092,30 @@ static int launch_features(const float *ri, const uint8_t *seg, int B, int H, in
                            int sharp_num, int less_sharp_num, int flat_num, float *feat, uint8_t *key_point_map,
                            hipStream_t st, int32_t *kpn = nullptr, int K = 0) {
     ARG_TRY(feature_region >= 1 && feature_region <= 16 && segments >= 1 && W < 65536);
-    const size_t sh = (size_t)3 * W * 4 + (size_t)W * 2 + (size_t)W * 2 + 16;
+    const bool rowmode = (W - 2 * feature_region) / segments <= 16 * FEAT_RQ && segments <= FEAT_ROW_SEGS && flat_num - 1 <= FEAT_ROW_FLAT;
+    const bool compact = rowmode && !feat;  // no curvature image: the fused entry, whose ranges come from the projection (>= 0)
+    const size_t sh = compact ? (size_t)2 * W * 4 + (size_t)W * 2 + (size_t)W + 16 : (size_t)3 * W * 4 + (size_t)W * 2 + (size_t)W * 2 + 16;
     ARG_TRY(sh <= 160 * 1024);
     ARG_TRY(W <= 64 * FEAT_GPW * (FEAT_THREADS / 64));                        // and so does a wavefront's part of the row
     FeatParams fp = {feature_region, segments, sharp_num, less_sharp_num, flat_num};
     const int need = ((W - 2 * feature_region) / segments + 63) / 64;  // keys per lane
-#define FEAT_LAUNCH_G(Q_, G_)                                                                                          \
-    do {                                                                                                               \
-        HIP_TRY(ensure_dyn_lds(reinterpret_cast<const void *>(&features_kernel<Q_, G_>), (int)sh));                    \
-        features_kernel<Q_, G_><<<dim3(H, B), FEAT_THREADS, sh, st>>>(ri, seg, H, W, fp, feat, key_point_map, kpn, K); \
+#define FEAT_LAUNCH_G(Q_, G_, F_)                                                                                         \
+    do {                                                                                                                  \
+        HIP_TRY(ensure_dyn_lds(reinterpret_cast<const void *>(&features_kernel<Q_, G_, F_>), (int)sh));                   \
+        features_kernel<Q_, G_, F_><<<dim3(H, B), FEAT_THREADS, sh, st>>>(ri, seg, H, W, fp, feat, key_point_map, kpn, K); \
     } while (0)
-#define FEAT_LAUNCH(Q_)                                           \
-    do {                                                          \
-        if (W <= 64 * 8 * (FEAT_THREADS / 64)) FEAT_LAUNCH_G(Q_, 8); \
-        else FEAT_LAUNCH_G(Q_, FEAT_GPW);                         \
+#define FEAT_LAUNCH(Q_, F_)                                                \
+    do {                                                                   \
+        if (W <= 64 * 8 * (FEAT_THREADS / 64)) FEAT_LAUNCH_G(Q_, 8, F_);   \
+        else FEAT_LAUNCH_G(Q_, FEAT_GPW, F_);                              \
     } while (0)
-#ifndef FEAT_NO_ROWMODE
-    if ((W - 2 * feature_region) / segments <= 16 * FEAT_RQ && segments <= FEAT_ROW_SEGS && flat_num - 1 <= FEAT_ROW_FLAT)
-        FEAT_LAUNCH(FEAT_ROWMODE);  // a chunk fits a 16-lane row
-    else
-#endif
-    if (need <= 2) FEAT_LAUNCH(2);
-    else if (need <= 4) FEAT_LAUNCH(4);
-    else if (need <= 6) FEAT_LAUNCH(6);
-    else if (need <= 8) FEAT_LAUNCH(8);
-    else FEAT_LAUNCH(0);  // long chunks: keys stay in LDS
+    if (compact) FEAT_LAUNCH(FEAT_ROWMODE, false);
+    else if (rowmode) FEAT_LAUNCH(FEAT_ROWMODE, true);  // a chunk fits a 16-lane row
+    else if (need <= 2) FEAT_LAUNCH(2, true);
+    else if (need <= 4) FEAT_LAUNCH(4, true);
+    else if (need <= 6) FEAT_LAUNCH(6, true);
+    else if (need <= 8) FEAT_LAUNCH(8, true);
+    else FEAT_LAUNCH(0, true);  // long chunks: keys stay in LDS
 #undef FEAT_LAUNCH
 #undef FEAT_LAUNCH_G
     LAUNCH_CHECK();
