@@ -1891,6 +1891,7 @@ __global__ __launch_bounds__(256) void predict_quantize_kernel(const float *__re
     uint32_t *segcnt = reinterpret_cast<uint32_t *>(smodel + 4 * KP);    // [16][KP+1]
     const int SEGP = KP + 1;
     uint32_t *soff = segcnt + 16 * SEGP;                                 // [KP] this tile's output offsets per label
+    float *sacc = reinterpret_cast<float *>(soff + KP);                  // [KP] quantisation step per label (non-uniform)
     const int b = blockIdx.y, t = blockIdx.x, K = M + 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // per-frame bases (wave-uniform): scalar base + 32-bit lane offset instead of 64-bit address arithmetic per access
@@ -1922,6 +1923,8 @@ __global__ __launch_bounds__(256) void predict_quantize_kernel(const float *__re
     for (int i = threadIdx.x; i < 4 * K; i += 256) smodel[i] = RESIDUAL_ONLY ? 0.0f : model[(int64_t)b * K * 4 + i];
     // staged with the first loads: read inside segment_prefix they cost a dependent global round trip per 16 labels
     for (int i = threadIdx.x; i < K; i += 256) soff[i] = hist[((int64_t)b * T + t) * KP + i];
+    if (label_acc)  // staged like the model rows: read per pixel it is a dependent trip to memory behind the barrier
+        for (int i = threadIdx.x; i < K; i += 256) sacc[i] = label_acc[i];
     for (int i = threadIdx.x; i < 16 * SEGP; i += 256) segcnt[i] = 0u;
     __syncthreads();
     int qv[4], rank[4];
@@ -1940,7 +1943,7 @@ __global__ __launch_bounds__(256) void predict_quantize_kernel(const float *__re
             else pr = -p3 / (p0 * t0[j] + p1 * t1[j] + p2 * t2[j]);                    // :275-277
             if (!RESIDUAL_ONLY && pred_out) st_at(pred_out, (uint32_t)gp * 4u, pr);
             const float res = (RESIDUAL_ONLY || residual_in) ? rin[j] : rv[j] - pr;                      // compress.py:106
-            const float step = label_acc ? label_acc[l] : acc;       // cpp_modules.cpp:404,419
+            const float step = label_acc ? sacc[l] : acc;            // cpp_modules.cpp:404,419
             qv[j] = (int)roundf(res / step);                                          // cpp_modules.cpp:315
             lab[j] = (l == 1) ? -1 : l;                                               // label 1 is skipped (:314)
         }
@@ -1977,7 +1980,7 @@ static int launch_predict_quantize(const float *ri, const float *tm, const uint8
                                    int32_t *q32, float *pred, void *ws, hipStream_t st, int32_t *epoch_inc = nullptr) {
     const int KP = kpad(M), T = ntiles(P);
     WsLayout L = ws_layout(ws, B, P, M);
-    const size_t sh = (size_t)KP * 4 * 4 + (size_t)16 * (KP + 1) * 4 + (size_t)KP * 4;
+    const size_t sh = (size_t)KP * 4 * 4 + (size_t)16 * (KP + 1) * 4 + (size_t)KP * 4 + (size_t)KP * 4;
     if (residual_in && !pred)
         predict_quantize_kernel<true><<<dim3(T, B), 256, sh, st>>>(ri, tm, seg, model, L.hist, acc, label_acc, residual_in, P,
                                                                    M, KP, T, q16, q32, pred, epoch_inc);
