@@ -341,7 +341,7 @@ struct ZeroRange { uint32_t *p; int n; };
 struct BatchInit {
     const float *tm; float *soa; int P;
     int32_t *info; int B;
-    ZeroRange z0, z1;
+    ZeroRange z0, z1, z2;
     int on;
 };
 __device__ __forceinline__ int flag_mark(const int32_t *epoch) { return epoch ? *epoch + 1 : 1; }
@@ -384,6 +384,7 @@ __global__ __launch_bounds__(PIX_THREADS) void project_pix_kernel(const float *_
         }
         for (int p = blockIdx.x * PIX_THREADS + threadIdx.x; p < init.z0.n; p += nthr) init.z0.p[p] = 0u;
         for (int p = blockIdx.x * PIX_THREADS + threadIdx.x; p < init.z1.n; p += nthr) init.z1.p[p] = 0u;
+        for (int p = blockIdx.x * PIX_THREADS + threadIdx.x; p < init.z2.n; p += nthr) init.z2.p[p] = 0u;
     }
     __syncthreads();
     const int lane = threadIdx.x & 63;
@@ -2235,6 +2236,12 @@ static int run_batch(const rpcc_batch_io *io, int Bs, int64_t npts, rpcc_geom g,
     bi.tm = io->tm; bi.soa = rays_soa; bi.P = P; bi.info = info; bi.B = Bs; bi.on = 1;
     bi.z0 = {reinterpret_cast<uint32_t *>(zcnt), zcnt ? Bs * (RS_CHUNKS + 1) : 0};
     bi.z1 = {reinterpret_cast<uint32_t *>(L.sums), (int)(((char *)L.hist - (char *)L.sums) / 4)};
+    // model rows + the tile offsets of the ordered scatter (built once, used by the plane list and by the quantiser)
+    char *extra = reinterpret_cast<char *>(tiletab) + (((size_t)Bs * FPS_TAB_ROWS * ((P + 31) / 32 + 4096) * 4 + 255) & ~(size_t)255) + 256;
+    const size_t ksz = (((size_t)Bs * (M + 2) * 4 + 255) & ~(size_t)255);
+    float *label_acc = io->nonuniform ? reinterpret_cast<float *>(extra + plane_extra_bytes(Bs, P, M) - 256 - ksz) : nullptr;
+    int32_t *kpn = io->nonuniform ? reinterpret_cast<int32_t *>(extra + plane_extra_bytes(Bs, P, M) - 256 - 2 * ksz) : nullptr;
+    bi.z2 = {reinterpret_cast<uint32_t *>(kpn), kpn ? Bs * (M + 2) : 0};  // key points per label
     if ((rc = launch_project(io->xyz, io->offsets, npts, 0, Bs, g, ri, proj_scratch, proj_bytes, st,
                              rays_soa + 2 * (int64_t)P, zcnt, &bi, epoch)))
         return rc;
@@ -2250,8 +2257,6 @@ static int run_batch(const rpcc_batch_io *io, int Bs, int64_t npts, rpcc_geom g,
                                tiled ? tiletab : nullptr, io->timer, st)))
         return rc;
     if ((rc = launch_assign(ri, io->tm, ground, io->centers, Bs, g.H, g.W, M, io->seg, st))) return rc;
-    // model rows + the tile offsets of the ordered scatter (built once, used by the plane list and by the quantiser)
-    char *extra = reinterpret_cast<char *>(tiletab) + (((size_t)Bs * FPS_TAB_ROWS * ((P + 31) / 32 + 4096) * 4 + 255) & ~(size_t)255) + 256;
     if (io->model_method == 0) {
         if ((rc = launch_point_model(ri, io->seg, ground, Bs, P, M, io->model, io->counts, io->nnz, ws, st, true))) return rc;
     } else {
@@ -2260,13 +2265,8 @@ static int run_batch(const rpcc_batch_io *io, int Bs, int64_t npts, rpcc_geom g,
                                     io->frame_ids, io->model, io->counts, ws, extra, st)))
             return rc;
     }
-    float *label_acc = nullptr;
     if (io->nonuniform) {   // key points -> salience level and quantisation step per label
         const rpcc_nonuniform_cfg *nu = io->nonuniform;
-        const size_t ksz = (((size_t)Bs * (M + 2) * 4 + 255) & ~(size_t)255);
-        label_acc = reinterpret_cast<float *>(extra + plane_extra_bytes(Bs, P, M) - 256 - ksz);
-        int32_t *kpn = reinterpret_cast<int32_t *>(extra + plane_extra_bytes(Bs, P, M) - 256 - 2 * ksz);
-        HIP_TRY(hipMemsetAsync(kpn, 0, (size_t)Bs * (M + 2) * 4, st));
         if ((rc = launch_features(ri, io->seg, Bs, g.H, g.W, nu->feature_region, nu->segments, nu->sharp_num, nu->less_sharp_num,
                                   nu->flat_num, nullptr, io->key_point_map, st, kpn, M + 2)))
             return rc;
