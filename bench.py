@@ -355,10 +355,12 @@ def main():
         # HBM-side bytes and wave-level VALU instructions per FPS launch from the committed PMC passes (rocprofv3 cannot
         # run inside this process); only reported when those passes were taken on this very configuration
         traffic = traffic_src = valu = step_traffic = None
+        fps_kernel = "fps_range_kernel (brute force)" if a.fps_bruteforce else "fps_regtab_kernel"
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_current.json")))
             if pm["config"] == {"batch": B, "geom": geom_s, "clusters": M, "config": a.config, "input": bool(a.input)} and not a.fps_bruteforce:
-                key = [k for k in pm["kernels"] if k.startswith("fps_tiled_kernel<true")][0]   # template arguments vary
+                key = [k for k in pm["kernels"] if k.startswith(("fps_regtab_kernel<true", "fps_tiled_kernel<true"))][0]   # template arguments vary
+                fps_kernel = key
                 traffic = pm["kernels"][key]["traffic_bytes_per_launch"]
                 valu = pm["kernels"][key].get("valu_wave_insts_per_launch")
                 step_traffic = pm.get("step_traffic_bytes")
@@ -385,7 +387,7 @@ def main():
                        + ("; " + exchange_note if exchange_note else ""),
                        "exchange_bytes_per_step": exchange_bytes if exchange else 0,
                        "verified_frames_per_slot": (S if verified is not None else 0)},
-            "roofline": {"bound": "hbm", "kernel": "fps_range_kernel (brute force)" if a.fps_bruteforce else "fps_tiled_kernel",
+            "roofline": {"bound": "hbm", "kernel": fps_kernel,
                          "model": "stream-once (SURVEY 8d): 20*(M-1)*n_left bytes per frame, the bytes the reference algorithm streams",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "traffic_source": traffic_src,

@@ -129,3 +129,17 @@ def test_bench_refuses_more_gpus_than_visible():
     env2 = dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env2, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
+
+
+def test_bench_finds_its_pmc_numbers():
+    """bench.py fills roofline.traffic / valu_wave_insts from profiles/pmc_current.json: the committed file must describe
+    the default configuration and name the FPS kernel the way bench.py looks it up (a rename once left the fields null)."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pm = json.load(open(os.path.join(root, "profiles", "pmc_current.json")))
+    assert pm["config"] == {"batch": 256, "geom": "64x2048", "clusters": 100, "config": 1, "input": False}
+    keys = [k for k in pm["kernels"] if k.startswith(("fps_regtab_kernel<true", "fps_tiled_kernel<true"))]
+    assert len(keys) == 1, list(pm["kernels"])
+    assert pm["kernels"][keys[0]]["traffic_bytes_per_launch"] > 0 and pm["kernels"][keys[0]]["valu_wave_insts_per_launch"] > 0
+    src = open(os.path.join(root, "bench.py")).read()
+    assert 'startswith(("fps_regtab_kernel<true", "fps_tiled_kernel<true"))' in src
