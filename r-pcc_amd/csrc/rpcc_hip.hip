@@ -1726,19 +1726,20 @@ __global__ __launch_bounds__(256) void model_hist_kernel(const float *__restrict
                 const bool mine = todo == cur;
                 const unsigned long long same = __ballot(mine);
                 uint32_t lo = 0u, hi = 0u;
-                if (cur >= 2) {
+                const bool sum = cur >= 2 && ri != nullptr;  // counts only (label scan): no sums
+                if (sum) {
                     lo = dpp_sum_u32(mine ? (uint32_t)(v & 0x3FFFFull) : 0u);
                     hi = dpp_sum_u32(mine ? (uint32_t)(v >> 18) : 0u);
                 }
                 if (lane == leader) {
                     atomicAdd(&scnt[cur], (uint32_t)__popcll(same));
-                    if (cur >= 2) atomicAdd(&ssum[cur], (unsigned long long)lo + ((unsigned long long)hi << 18));
+                    if (sum) atomicAdd(&ssum[cur], (unsigned long long)lo + ((unsigned long long)hi << 18));
                 }
                 if (mine) todo = -1;
             }
             if (todo >= 0) {
                 atomicAdd(&scnt[todo], 1u);
-                if (todo >= 2) atomicAdd(&ssum[todo], v);
+                if (todo >= 2 && ri != nullptr) atomicAdd(&ssum[todo], v);
             }
         }
     }
