@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void decode_kernel(const uint8_t *__restrict__
                                                      const uint32_t *__restrict__ hist, const uint8_t *__restrict__ salience,
                                                      DecodeSteps steps, int P, int M, int KP, int T,
                                                      float *__restrict__ ri_rec, float *__restrict__ pc_rec) {
-    extern __shared__ unsigned char smem_raw[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float *smodel = reinterpret_cast<float *>(smem_raw);                 // [KP*4]
     uint32_t *segcnt = reinterpret_cast<uint32_t *>(smodel + 4 * KP);    // [16][KP+1]
     const int SEGP = KP + 1;

@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void label_order_kernel(const uint8_t *__restr
                                                           int P, int M, int KP, int T, uint32_t *__restrict__ order,
                                                           const float *__restrict__ ri, const float *__restrict__ tm,
                                                           float4 *__restrict__ pts4) {
-    extern __shared__ unsigned char smem_raw[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint32_t *segcnt = reinterpret_cast<uint32_t *>(smem_raw);  // [16][KP+1]
     const int SEGP = KP + 1;
     uint32_t *soff = segcnt + 16 * SEGP;                        // [KP] this tile's offsets per label

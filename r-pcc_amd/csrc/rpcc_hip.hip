@@ -1681,7 +1681,7 @@ extern "C" size_t rpcc_workspace_bytes_general(int B, int P, int M, int64_t tota
 __global__ __launch_bounds__(256) void model_hist_kernel(const float *__restrict__ ri, const uint8_t *__restrict__ seg,
                                                          int P, int KP, int T, int64_t *__restrict__ sums,
                                                          int32_t *__restrict__ flags, uint32_t *__restrict__ hist) {
-    extern __shared__ unsigned char smem_raw[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned long long *ssum = reinterpret_cast<unsigned long long *>(smem_raw);  // [KP]
     uint32_t *scnt = reinterpret_cast<uint32_t *>(ssum + KP);                      // [KP]
     const int b = blockIdx.y, t = blockIdx.x, lane = threadIdx.x & 63;
@@ -1886,7 +1886,7 @@ __global__ __launch_bounds__(256) void predict_quantize_kernel(const float *__re
                                                                int KP, int T, int16_t *__restrict__ q16,
                                                                int32_t *__restrict__ q32, float *__restrict__ pred_out,
                                                                int32_t *__restrict__ epoch_inc) {
-    extern __shared__ unsigned char smem_raw[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     // last kernel of a fused batch: the next call's projection flags get a new mark (BatchInit)
     if (epoch_inc && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *epoch_inc += 1;
     float *smodel = reinterpret_cast<float *>(smem_raw);                 // [KP*4]
