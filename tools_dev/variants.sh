@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_dev/r2_band.sh "<flags>" ... : rebuild with the flags, serial kernel stats (grep pattern in $PAT)
+# usage: tools_dev/variants.sh "<flags>" ... : rebuild with the flags, serial kernel stats (grep pattern in $PAT)
 cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp
 for f in "$@"; do
   echo "== $f"
