@@ -606,6 +606,12 @@ __global__ __launch_bounds__(FPS_TT) void fps_regtab_kernel(const float *__restr
         }
     };
     int par = 0;
+#ifdef FPS_PROF3   // developer trace: cycles per phase of the iteration chain, summed over the iterations, per wavefront of block 0
+    long long p3_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, p3_last = (long long)__builtin_readcyclecounter();
+#define FPS_P3(i_) do { const long long t_ = (long long)__builtin_readcyclecounter(); p3_acc[i_] += t_ - p3_last; p3_last = t_; } while (0)
+#else
+#define FPS_P3(i_) do { } while (0)
+#endif
     // arg-max over all tiles and the origin class -> next centre (index and coordinates); one barrier
     auto select_next = [&]() {
         const uint32_t key = have ? fps_val_key(tmax) : 0u;
@@ -619,7 +625,9 @@ __global__ __launch_bounds__(FPS_TT) void fps_regtab_kernel(const float *__restr
             const float wz = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(cz), wl));
             if (lane == 0) { slot_k[par][wave] = make_uint2(vmax, vmax >= FPS_KEY_MIN ? imin : 0xFFFFFFFFu); slot_c[par][wave] = make_float4(wx, wy, wz, 0.0f); }
         }
+        FPS_P3(3);
         __syncthreads();
+        FPS_P3(4);
         const uint2 kv = slot_k[par][lane % NW];
         const float4 cc = slot_c[par][lane % NW];
         par ^= 1;
@@ -669,17 +677,30 @@ __global__ __launch_bounds__(FPS_TT) void fps_regtab_kernel(const float *__restr
         DBG_STAMP(10);
         if (tid == 0) { out_idx[1] = old; if (out_cen) { out_cen[3] = c0; out_cen[4] = c1; out_cen[5] = c2; } }
     }
+    FPS_P3(0);
     for (int j = 2; j < M; j++) {
         // this wavefront's tiles against the new centre
         const float g0 = fmaxf(fmaxf(lo0 - c0, c0 - hi0), 0.0f);
         const float g1 = fmaxf(fmaxf(lo1 - c1, c1 - hi1), 0.0f);
         const float g2 = fmaxf(fmaxf(lo2 - c2, c2 - hi2), 0.0f);
         const float bound = (g0 * g0 + g1 * g1) + g2 * g2;
-        visit(__ballot(have && bound < tmax), false);
+        const unsigned long long vm = __ballot(have && bound < tmax);
+#ifdef FPS_PROF3
+        p3_acc[6] += __popcll(vm);
+        p3_acc[7] += vm != 0ull;
+#endif
+        FPS_P3(1);
+        visit(vm, false);
+        FPS_P3(2);
         update_origin();
         select_next();
         if (tid == 0) { out_idx[j] = old; if (out_cen) { out_cen[3 * j] = c0; out_cen[3 * j + 1] = c1; out_cen[3 * j + 2] = c2; } }
+        FPS_P3(5);
     }
+#ifdef FPS_PROF3
+    if (g_dbg_stamps != nullptr && blockIdx.x == 0 && lane == 0)
+        for (int i = 0; i < 8; i++) g_dbg_stamps[64 + wave * 8 + i] = p3_acc[i];
+#endif
     DBG_STAMP(16);
     if (RANGE && org_on && (flags & FPS_FLAG_FINALIZE_TEMP)) {
         __syncthreads();
