@@ -616,9 +616,17 @@ __global__ __launch_bounds__(FPS_TT) void fps_regtab_kernel(const float *__restr
     auto select_next = [&]() {
         const uint32_t key = have ? fps_val_key(tmax) : 0u;
         uint32_t vmax = dpp_max_u32(key);
-        uint32_t imin = dpp_min_u32(key == vmax ? targ : 0xFFFFFFFFu);
+        // lowest index among the lanes that hold the maximum: almost always one lane, whose index is read directly (the second
+        // reduction is 7 dependent DPP steps)
+        unsigned long long mm = __ballot(key == vmax);
+        uint32_t imin;
+        if (__popcll(mm) == 1) {
+            imin = (uint32_t)__builtin_amdgcn_readlane((int)targ, (int)__ffsll((long long)mm) - 1);
+        } else {
+            imin = dpp_min_u32(key == vmax ? targ : 0xFFFFFFFFu);
+            mm = __ballot(key == vmax && targ == imin);
+        }
         {
-            const unsigned long long mm = __ballot(key == vmax && targ == imin);
             const int wl = mm ? (int)__ffsll((long long)mm) - 1 : 0;
             const float wx = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(cx), wl));
             const float wy = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(cy), wl));
@@ -632,8 +640,13 @@ __global__ __launch_bounds__(FPS_TT) void fps_regtab_kernel(const float *__restr
         const float4 cc = slot_c[par][lane % NW];
         par ^= 1;
         vmax = dpp_max_u32(kv.x);
-        imin = dpp_min_u32(kv.x == vmax ? kv.y : 0xFFFFFFFFu);
-        const unsigned long long mm = __ballot(kv.x == vmax && kv.y == imin);
+        mm = __ballot(kv.x == vmax) & ((1ull << NW) - 1ull);   // the NW candidates repeat along the lanes: look at the first NW
+        if (__popcll(mm) == 1) {
+            imin = (uint32_t)__builtin_amdgcn_readlane((int)kv.y, (int)__ffsll((long long)mm) - 1);
+        } else {
+            imin = dpp_min_u32(kv.x == vmax ? kv.y : 0xFFFFFFFFu);
+            mm = __ballot(kv.x == vmax && kv.y == imin);
+        }
         const int wl = mm ? (int)__ffsll((long long)mm) - 1 : 0;
         const uint32_t okey = org_on ? fps_val_key(t_org) : 0u;
         if (okey >= FPS_KEY_MIN && (okey > vmax || (okey == vmax && (uint32_t)org_idx < imin))) {
