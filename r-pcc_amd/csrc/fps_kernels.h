@@ -639,7 +639,7 @@ __global__ __launch_bounds__(FPS_TT) void fps_regtab_kernel(const float *__restr
         const uint2 kv = slot_k[par][lane % NW];
         const float4 cc = slot_c[par][lane % NW];
         par ^= 1;
-        vmax = dpp_max_u32(kv.x);
+        vmax = NW == 8 ? dpp_max8_u32(kv.x) : dpp_max_u32(kv.x);
         mm = __ballot(kv.x == vmax) & ((1ull << NW) - 1ull);   // the NW candidates repeat along the lanes: look at the first NW
         if (__popcll(mm) == 1) {
             imin = (uint32_t)__builtin_amdgcn_readlane((int)kv.y, (int)__ffsll((long long)mm) - 1);
@@ -707,6 +707,8 @@ __global__ __launch_bounds__(FPS_TT) void fps_regtab_kernel(const float *__restr
         FPS_P3(2);
         update_origin();
         select_next();
+        // (collecting the centres in 4 KB of LDS and writing them once at the end takes 2 us off the kernel alone and 5 % off
+        // the step with batches in flight: this kernel's LDS footprint decides what it shares a CU with)
         if (tid == 0) { out_idx[j] = old; if (out_cen) { out_cen[3 * j] = c0; out_cen[3 * j + 1] = c1; out_cen[3 * j + 2] = c2; } }
         FPS_P3(5);
     }

@@ -156,6 +156,14 @@ __device__ __forceinline__ uint32_t dpp_max_u32(uint32_t v) {
 #undef STEP_
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
+// maximum of a value that repeats with period 8 along the lanes (8 candidates): three xor steps inside every group of 8
+// (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror) instead of six row steps
+__device__ __forceinline__ uint32_t dpp_max8_u32(uint32_t v) {
+    v = max(v, (uint32_t)RPCC_DPP(0, v, 0xB1, 0xf));   // quad_perm [1,0,3,2]
+    v = max(v, (uint32_t)RPCC_DPP(0, v, 0x4E, 0xf));   // quad_perm [2,3,0,1]
+    v = max(v, (uint32_t)RPCC_DPP(0, v, 0x141, 0xf));  // row_half_mirror
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
 // float min / max as ONE v_max_u32_dpp per step: floats are mapped to order-preserving unsigned keys
 // (sign bit flipped for non-negative values, all bits flipped for negative ones).  -0 orders below +0;
 // NaNs are not expected here (the callers feed coordinates and +-inf identities).
