@@ -357,7 +357,8 @@ def main():
         traffic = traffic_src = valu = step_traffic = None
         fps_kernel = "fps_range_kernel (brute force)" if a.fps_bruteforce else "fps_regtab_kernel"
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_current.json")))
+            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_current.json" if a.config == 1 and not a.input else
+                                             "pmc_current_c%d%s.json" % (a.config, "_real" if a.input else ""))))
             if pm["config"] == {"batch": B, "geom": geom_s, "clusters": M, "config": a.config, "input": bool(a.input)} and not a.fps_bruteforce:
                 key = [k for k in pm["kernels"] if k.startswith(("fps_regtab_kernel<true", "fps_tiled_kernel<true"))][0]   # template arguments vary
                 fps_kernel = key

@@ -2,7 +2,8 @@
 """Build a committed profiles/ set from the raw rocprofv3 CSVs that tools_dev/round_profiles.sh left in gpurun_out/ (scratch).
 usage: tools_profiles.py <tag> [--config N] [--input] [--no-current]      e.g. r02_v3
 Writes profiles/<tag>_{kernel_stats_serial,kernel_stats_pipelined}.md (+ _raw.csv), <tag>_pmc.md, the three bench lines,
-and (unless --no-current) profiles/pmc_current.json, which bench.py reads for roofline.traffic / valu_wave_insts."""
+and (unless --no-current) profiles/pmc_current.json (pmc_current_c2.json for --config 2, ..._real.json for --input), which
+bench.py reads for roofline.traffic / valu_wave_insts when it runs that configuration."""
 import collections, csv, json, os, sys
 tag = sys.argv[1]
 cfg = int(sys.argv[sys.argv.index("--config") + 1]) if "--config" in sys.argv else 1
@@ -74,7 +75,7 @@ if "--no-current" not in sys.argv:
     json.dump({"tag": tag, "config": {"batch": B, "geom": m.group(1) if m else "64x2048", "clusters": 100, "config": cfg, "input": real},
                "step_traffic_bytes": tot, "step_valu_wave_insts": totv, "kernels": js,
                "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU, separate passes, serial steps; read = 2 x FETCH_SIZE (gfx950, calibrated)"},
-              open(f"{P}/pmc_current.json", 'w'), indent=1)
+              open(f"{P}/pmc_current.json" if cfg == 1 and not real else f"{P}/pmc_current_c{cfg}{'_real' if real else ''}.json", 'w'), indent=1)
 print(open(f"{P}/{tag}_kernel_stats_serial.md").read())
 print(open(f"{P}/{tag}_pmc.md").read().split("| kernel |")[1][:4000])
 print("bench (no profiler):", bench["prof_bench_final"]["value"], "frames/s", bench["prof_bench_final"]["ms_per_step"], "ms/step; serial:", bench["prof_serial_bench"]["ms_per_step"])
