@@ -291,9 +291,10 @@ def main():
     from oracle import oracle as orc
     g_o = orc.LidarGeom(H=H, W=W, hfov_deg=360, vmax_deg=2.0, vmin_deg=-24.9)
     cfg_o = dict(orc.DEFAULT_CFG, accuracy=a.accuracy, cluster_num=M)
-    threads = os.cpu_count() or 1
+    from rpcc_amd.utils import available_cpus
+    threads = available_cpus()   # affinity mask capped by the cgroup quota: the CPUs the host leg really gets
     want_cpu = a.cpu_sample > 0 and world == 1 and rank == 0
-    S = min(B, max(a.cpu_sample, 2 * threads)) if want_cpu else min(B, 8)
+    S = min(B, max(a.cpu_sample, 16 * threads)) if want_cpu else min(B, 8)   # ~10 s of CPU work for the baseline leg
     frames_h = [xyz[offs_host[i]:offs_host[i + 1]].cpu().numpy() for i in range(S)]
     oracle_out = [None] * S
 

@@ -76,6 +76,26 @@ _SIGS = {
 }
 
 
+HOST_LIB_PATH = os.path.join(_HERE, "lib", "librpcc_host.so")
+_host = None
+
+
+def host_lib():
+    """librpcc_host.so (include/rpcc_host.h): the host-side container packer.  Raises RpccError when it is not built."""
+    global _host
+    if _host is None:
+        if not os.path.exists(HOST_LIB_PATH):
+            raise RpccError("librpcc_host.so is not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'`"
+                            % HOST_LIB_PATH)
+        h = C.CDLL(HOST_LIB_PATH)
+        h.rpcc_host_version.restype = C.c_int
+        h.rpcc_host_version.argtypes = []
+        h.rpcc_host_pack_bz2.restype = C.c_int
+        h.rpcc_host_pack_bz2.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        _host = h
+    return _host
+
+
 def exported_symbols():
     return sorted(_SIGS)
 

@@ -7,6 +7,8 @@ SRC = os.path.join(_HERE, "csrc", "rpcc_hip.hip")
 DEPS = [os.path.join(_HERE, "csrc", f) for f in sorted(os.listdir(os.path.join(_HERE, "csrc")))] + \
        [os.path.join(os.path.dirname(_HERE), "include", "rpcc_hip.h")]
 LIB = os.path.join(_HERE, "lib", "librpcc_hip.so")
+HOST_SRC = os.path.join(_HERE, "csrc", "rpcc_host.c")
+HOST_LIB = os.path.join(_HERE, "lib", "librpcc_host.so")
 
 # -ffp-contract=off: the reference's C++ (projection, models, prediction, quantisation) is un-fused x86 SSE arithmetic and a
 # contracted FMA changes results.  (The reference's CUDA FPS kernel is a different matter: nvcc contracts its distance into
@@ -15,7 +17,23 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
                "-shared", "-Wno-unused-value"]
 
 
+def build_host(force=False, verbose=False):
+    """librpcc_host.so: the plain-C container packer (bzip2 through the libbz2 the interpreter's bz2 module links)."""
+    os.makedirs(os.path.dirname(HOST_LIB), exist_ok=True)
+    if not force and os.path.exists(HOST_LIB) and os.path.getmtime(HOST_LIB) >= os.path.getmtime(HOST_SRC):
+        return HOST_LIB
+    cmd = [os.environ.get("CC", "gcc"), "-O2", "-shared", "-fPIC", "-Wall", HOST_SRC, "-o", HOST_LIB, "-l:libbz2.so.1.0"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return HOST_LIB
+
+
 def build(force=False, verbose=False):
+    try:
+        build_host(force, verbose)
+    except (subprocess.CalledProcessError, OSError) as e:   # no libbz2.so.1.0 / no gcc: compress_utils.pack_frames then
+        print("librpcc_host.so not built (%s): containers are packed by the interpreter's bz2 module" % e)  # takes the Python path
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in DEPS):
         return LIB

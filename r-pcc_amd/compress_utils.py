@@ -4,6 +4,7 @@ packing, the .rpcc container and the entropy back-ends (stdlib calls, excluded f
 import bz2
 import copy
 import gzip
+import os
 import struct
 
 import numpy as np
@@ -115,6 +116,28 @@ def pack_bitstream(compressed_data, uniform=True):
     """The .rpcc container (utils/compress_utils.py:167-179): [int32 length | bytes] per array."""
     keys = (() if uniform else ("salience_level",)) + _ORDER
     return b"".join(struct.pack("i", len(compressed_data[k])) + bytes(compressed_data[k]) for k in keys)
+
+
+def pack_frames(basic_compressor, frames, uniform=True):
+    """The .rpcc byte strings of several frames: compress_dict + pack_bitstream per frame, with the bzip2 back-end done by
+    ONE call into librpcc_host.so for the whole list (include/rpcc_host.h) -- a pool thread then enters the interpreter once
+    per chunk of frames instead of once per array.  Same bytes as the per-frame path (tests/test_host_pack.py)."""
+    from . import _lib
+    if basic_compressor.method_name != "bzip2" or not frames or not os.path.exists(_lib.HOST_LIB_PATH):
+        return [pack_bitstream(basic_compressor.compress_dict(od), uniform=uniform) for od in frames]
+    keys = (() if uniform else ("salience_level",)) + _ORDER
+    arrs = [np.ascontiguousarray(od[k]) for od in frames for k in keys]
+    n, na = len(frames), len(keys)
+    ptrs = np.fromiter((a.ctypes.data for a in arrs), dtype=np.uint64, count=n * na)
+    lens = np.fromiter((a.nbytes for a in arrs), dtype=np.uint32, count=n * na)
+    # bzip2 never expands by more than 1 % + 600 bytes
+    stride = int((lens.reshape(n, na).astype(np.int64) * 101 // 100 + 604).sum(1).max())
+    out = np.empty((n, stride), np.uint8)
+    out_len = np.zeros(n, np.uint32)
+    rc = _lib.host_lib().rpcc_host_pack_bz2(n, na, ptrs.ctypes.data, lens.ctypes.data, out.ctypes.data, stride, out_len.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("rpcc_host_pack_bz2 failed on frame %d of the chunk" % (-rc - 1))
+    return [out[i, :int(out_len[i])].tobytes() for i in range(n)]
 
 
 def unpack_bitstream(blob, uniform=True):

@@ -22,7 +22,8 @@ import numpy as np
 import torch
 
 from . import ops
-from .compress_utils import pack_bitstream
+from .compress_utils import pack_bitstream, pack_frames  # noqa: F401
+from .utils import available_cpus
 
 
 class _Slot:
@@ -94,7 +95,7 @@ class StreamingCompressor:
         self.device = bc.device
         P = bc.T.H * bc.T.W
         self.cap = int(points_per_frame if points_per_frame is not None else P) * self.B   # a pixel holds >= 1 point: nnz <= points
-        self.pool = pool or ThreadPoolExecutor(workers or min(32, os.cpu_count() or 8))
+        self.pool = pool or ThreadPoolExecutor(workers or min(32, available_cpus()))
         self.copy_stream = torch.cuda.Stream(device=self.device)
         self.compute_stream = torch.cuda.Stream(device=self.device)
         # On this ROCm build a non_blocking copy_ of several hundred MB from pinned memory still holds the calling host thread
@@ -180,7 +181,7 @@ class StreamingCompressor:
 
     def _encode_chunk(self, payload, lo, hi):
         bc = self.bc
-        return [pack_bitstream(bc.bc.compress_dict(payload.frame(b)), uniform=bc.uniform) for b in range(lo, hi)]
+        return pack_frames(bc.bc, [payload.frame(b) for b in range(lo, hi)], uniform=bc.uniform)
 
     def run(self, batches, sink=None, entropy=True):
         """batches: iterable of (frames, frame_ids) -- frames a list of [N,>=3] float32 arrays (at most `batch` of them),

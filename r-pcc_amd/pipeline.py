@@ -6,7 +6,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .compress_utils import BasicCompressor, pack_bitstream
+from .compress_utils import BasicCompressor, pack_bitstream, pack_frames  # noqa: F401
 
 
 class BatchCompressor:
@@ -87,10 +87,13 @@ class BatchCompressor:
             od["contour_map"] = bits_h[b]
             od["idx_sequence"] = seq_h[so[b]: so[b + 1]]
             od["plane_param"] = model[b, :nrow]
-            return pack_bitstream(self.bc.compress_dict(od), uniform=self.uniform)
-        if pool is not None:
-            return list(pool.map(assemble, range(ctx["n"])))
-        return [assemble(b) for b in range(ctx["n"])]
+            return od
+        # a few frames per task: one call into the host library per chunk (compress_utils.pack_frames)
+        n = ctx["n"]
+        step = max(1, n // 64) if pool is not None else max(n, 1)
+        chunk = lambda lo: pack_frames(self.bc, [assemble(b) for b in range(lo, min(lo + step, n))], uniform=self.uniform)
+        parts = list(pool.map(chunk, range(0, n, step))) if pool is not None else [chunk(lo) for lo in range(0, n, step)]
+        return [blob for part in parts for blob in part]
 
     def compress(self, frames, ground=None, pool=None, frame_ids=None):
         """frames: list of [N,3] arrays.  -> list of .rpcc byte strings (one per frame)."""

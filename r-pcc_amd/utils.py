@@ -33,3 +33,29 @@ def frame_identity(path):
     batch size, the position in the batch, the number of ranks or the tool (compress.py / compress_datalist.py) that
     processes it.  (The reference's Open3D RANSAC is unseeded: its output is not reproducible at all.)"""
     return zlib.crc32(os.path.basename(str(path).strip()).encode()) & 0x7FFFFFFF
+
+
+def available_cpus():
+    """CPUs this process may actually use: the scheduler affinity mask, capped by the cgroup CPU quota (cpu.max) -- a
+    container that shows 256 logical CPUs may be limited to 16 of them, and 256 threads then only time-slice."""
+    import math
+    import os
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            quota, period = open(path).read().split()[:2]
+            if quota != "max":
+                n = min(n, max(1, math.ceil(int(quota) / int(period))))
+        except (OSError, ValueError):
+            pass
+    try:   # cgroup v1
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0 and p > 0:
+            n = min(n, max(1, math.ceil(q / p)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)

@@ -1,0 +1,74 @@
+"""librpcc_host.so: the native container packer produces the bytes of the per-frame Python path (bz2.compress per array +
+[int32 length | bytes] records, utils/compress_utils.py:167-179,199-214).  CPU only."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def cu():
+    import __graft_entry__ as ge
+    ge.build()
+    import rpcc_amd  # noqa: F401
+    from rpcc_amd import compress_utils
+    return compress_utils
+
+
+def _frames(rng, n, uniform):
+    out = []
+    for i in range(n):
+        nnz = int(rng.integers(0, 120000)) if i else 0      # frame 0: empty residual stream
+        K = int(rng.integers(2, 102))
+        od = {"residual_quantized": rng.normal(0, 3, nnz).astype(np.int16),
+              "contour_map": rng.integers(0, 256, 16384, dtype=np.uint8),
+              "idx_sequence": rng.integers(0, 102, int(rng.integers(0, 4000))).astype(np.uint16),
+              "plane_param": rng.normal(0, 1, (K, 4)).astype(np.float32)}
+        if not uniform:
+            od["salience_level"] = rng.integers(0, 4, K).astype(np.uint8)
+        out.append(od)
+    return out
+
+
+@pytest.mark.parametrize("uniform", [True, False])
+def test_native_container_equals_python_path(cu, uniform):
+    rng = np.random.default_rng(11 + uniform)
+    bc = cu.BasicCompressor(method_name="bzip2")
+    frames = _frames(rng, 6, uniform)
+    want = [cu.pack_bitstream(bc.compress_dict(od), uniform=uniform) for od in frames]
+    got = cu.pack_frames(bc, frames, uniform=uniform)
+    assert got == want
+    # views into a larger buffer (what the loader hands over) and a single frame
+    big = np.concatenate([f["residual_quantized"] for f in frames])
+    o = np.cumsum([0] + [len(f["residual_quantized"]) for f in frames])
+    views = [dict(f, residual_quantized=big[o[i]:o[i + 1]]) for i, f in enumerate(frames)]
+    assert cu.pack_frames(bc, views[2:3], uniform=uniform) == want[2:3]
+    assert cu.pack_frames(bc, [], uniform=uniform) == []
+    # round trip through the container reader
+    back = cu.unpack_bitstream(got[3], uniform=uniform)
+    assert np.array_equal(np.frombuffer(bc.decompress(back["residual_quantized"]), np.int16), frames[3]["residual_quantized"])
+
+
+def test_other_back_ends_take_the_python_path(cu):
+    rng = np.random.default_rng(3)
+    bc = cu.BasicCompressor(method_name="gzip")
+    frames = _frames(rng, 2, True)
+    got = cu.pack_frames(bc, frames, uniform=True)
+    for blob, od in zip(got, frames):
+        back = cu.unpack_bitstream(blob, uniform=True)
+        assert np.array_equal(np.frombuffer(bc.decompress(back["contour_map"]), np.uint8), od["contour_map"])
+
+
+def test_host_header_symbols_exported(cu):
+    from rpcc_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "rpcc_host.h")).read()
+    declared = sorted(set(re.findall(r"\b(rpcc_host_[a-z0-9_]+)\s*\(", hdr)))
+    assert declared == ["rpcc_host_pack_bz2", "rpcc_host_version"]
+    lib = ctypes.CDLL(_lib.HOST_LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert _lib.host_lib().rpcc_host_version() >= 100

@@ -1,3 +1,4 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp
-timeout 600 python3 tools_dev/loader_bench.py 16 32 2>&1 | grep -v "^$" | tail -12
+echo "nproc $(nproc); cpu.max $(cat /sys/fs/cgroup/cpu.max 2>/dev/null); cfs quota $(cat /sys/fs/cgroup/cpu/cpu.cfs_quota_us 2>/dev/null) / $(cat /sys/fs/cgroup/cpu/cpu.cfs_period_us 2>/dev/null)"
+timeout 500 python3 tools_dev/loader_entropy.py 10 16 32 2>&1 | grep workers
