@@ -227,6 +227,46 @@ def test_fused_general_entry_equals_staged_path_and_oracle(env, uniform, method)
             assert np.array_equal(sal[i, :o["model"].shape[0]], o["sal"].astype(np.uint8)), i
 
 
+@pytest.mark.parametrize("kp", [dict(segments=16, flat_num=9, sharp_num=2, less_sharp_num=5, feature_region=2),
+                                dict(segments=32, flat_num=3, sharp_num=0, less_sharp_num=1),
+                                dict(segments=40, flat_num=6, sharp_num=4, less_sharp_num=8),
+                                dict(segments=4, flat_num=10, sharp_num=3, less_sharp_num=12, feature_region=5),
+                                dict(segments=8, flat_num=1, sharp_num=0, less_sharp_num=0),
+                                dict(segments=11, flat_num=7, sharp_num=9, less_sharp_num=2, feature_region=1)])
+def test_fused_key_point_settings_equal_staged_path(env, kp):
+    """The fused entry picks its key-point kernel by the settings (a chunk per 16-lane row with the compact LDS layout when a
+    chunk has <= 256 entries, <= 32 segments and <= 8 flat points; the register / LDS forms otherwise): every choice gives the
+    key-point map, salience levels and integers of the stage entries (which tests/test_gpu_parity.py holds to the oracle)."""
+    torch, ops, synth = env["torch"], env["ops"], env["synth"]
+    B = 5
+    ids = list(range(23000, 23000 + B))
+    xyz, offs = synth.make_batch(ids, env["g"].H, env["g"].W, device=env["dev"])
+    buf = ops.BatchBuffers(B, env["geom"], 100, env["dev"], general=True)
+    gms = torch.zeros((B, 4), dtype=torch.float64, device=env["dev"])
+    ops.compress_batch(xyz, offs, env["d_tm"], gms, buf, ground_seed=4, frame_ids=ids, model_method="point",
+                       nonuniform=ops.nonuniform_cfg(0.04, kp))
+    torch.cuda.synchronize()
+
+    class CC:
+        pass
+    cc = CC()
+    cc.seed, cc.ground_threshold, cc.model_method, cc.uniform, cc.acc, cc.cfg = 4, 0.1, "point", False, 0.04, kp
+    buf2 = ops.BatchBuffers(B, env["geom"], 100, env["dev"], general=True)
+    gms2 = torch.zeros((B, 4), dtype=torch.float64, device=env["dev"])
+    sal2 = ops.compress_batch_general(xyz, offs, env["d_tm"], gms2, buf2, cc, True, frame_ids=ids)
+    torch.cuda.synchronize()
+    assert torch.equal(buf.seg, buf2.seg)
+    _, kp2 = ops.extract_features(buf2.ri, buf2.seg, kp.get("feature_region", 3), kp["segments"], kp["sharp_num"], kp["less_sharp_num"],
+                                  kp["flat_num"])
+    assert torch.equal(buf.key_point_map, kp2), kp
+    assert int((buf.key_point_map > 0).sum()) > 0 or (kp["flat_num"] <= 1 and max(kp["sharp_num"], kp["less_sharp_num"]) <= 1)
+    assert torch.equal(buf.salience, sal2), kp
+    nz = buf.nnz.cpu().numpy()
+    assert np.array_equal(nz, buf2.nnz.cpu().numpy())
+    for i in range(B):
+        assert torch.equal(buf.q16[i, :nz[i]], buf2.q16[i, :nz[i]]), (kp, i)
+
+
 def test_rccl_single_rank_exchange(env):
     """The N > 1 exchange of bench.py / the datalist driver (sharding.PackedExchange over torch.distributed 'nccl' = RCCL)
     as a single-rank group on this GPU: lengths and packed residual streams come back as they were sent."""
