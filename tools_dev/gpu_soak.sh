@@ -1,7 +1,5 @@
 #!/bin/bash
+# soak on the GPU box: usage gpu_soak.sh [frames fused] [frames general]
 cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp; mkdir -p gpurun_out
-timeout 300 python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
-for gname in Velodyne64E Velodyne32E VelodyneVLP16; do
-  timeout 600 python3 tools_dev/soak_fullsize.py 1024 900000 $gname 2>&1 | tail -1
-done
-timeout 900 python3 tools_dev/soak_general.py 2048 950000 2>&1 | tail -1
+timeout 900 python3 tools_dev/soak_fullsize.py ${1:-16384} 1200000 2>&1 | tail -1 | tee gpurun_out/soak_fullsize.log
+timeout 1200 python3 tools_dev/soak_general.py ${2:-8192} 1300000 2>&1 | tail -1 | tee gpurun_out/soak_general.log
