@@ -14,13 +14,17 @@
 extern "C" {
 #endif
 
-int rpcc_host_version(void);
+int rpcc_host_version(void);   /* 101 */
+
+#define RPCC_HOST_ERR_ARG (-1)
 
 /* src, src_bytes: [nframes * narrays] arrays in container order (salience_level first for the non-uniform framework, then
- * contour_map, idx_sequence, plane_param, residual_quantized); dst: nframes regions of dst_stride bytes each; dst_bytes:
- * [nframes] container lengths.  Returns 0, or -(1 + frame) when a frame does not fit its region or libbz2 reports an error. */
+ * contour_map, idx_sequence, plane_param, residual_quantized); frame f's container is written at dst + dst_off[f] and may use
+ * dst_off[f + 1] - dst_off[f] bytes (dst_off: [nframes + 1]); dst_bytes: [nframes] container lengths.
+ * Returns 0; RPCC_HOST_ERR_ARG for a bad argument; -(16 + frame) when that frame does not fit its region or libbz2 reports an
+ * error. */
 int rpcc_host_pack_bz2(int nframes, int narrays, const void *const *src, const uint32_t *src_bytes, uint8_t *dst,
-                       size_t dst_stride, uint32_t *dst_bytes);
+                       const uint64_t *dst_off, uint32_t *dst_bytes);
 
 #ifdef __cplusplus
 }

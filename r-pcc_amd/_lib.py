@@ -80,18 +80,31 @@ HOST_LIB_PATH = os.path.join(_HERE, "lib", "librpcc_host.so")
 _host = None
 
 
+HOST_ABI = 101      # rpcc_host_version() this binding was written against (a stale .so after an interface change is refused)
+_host_failed = None
+
+
 def host_lib():
-    """librpcc_host.so (include/rpcc_host.h): the host-side container packer.  Raises RpccError when it is not built."""
-    global _host
+    """librpcc_host.so (include/rpcc_host.h): the host-side container packer.  Raises RpccError when it is not built, cannot
+    be loaded (e.g. libbz2.so.1.0 missing at run time) or is a stale build; the failure is remembered, so the callers'
+    fallback (compress_utils.pack_frames -> the interpreter's bz2 module, same bytes) is taken at once afterwards."""
+    global _host, _host_failed
+    if _host_failed is not None:
+        raise RpccError(_host_failed)
     if _host is None:
-        if not os.path.exists(HOST_LIB_PATH):
-            raise RpccError("librpcc_host.so is not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'`"
-                            % HOST_LIB_PATH)
-        h = C.CDLL(HOST_LIB_PATH)
-        h.rpcc_host_version.restype = C.c_int
-        h.rpcc_host_version.argtypes = []
-        h.rpcc_host_pack_bz2.restype = C.c_int
-        h.rpcc_host_pack_bz2.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        try:
+            if not os.path.exists(HOST_LIB_PATH):
+                raise OSError("not built; run `python -c 'import __graft_entry__ as g; g.build()'`")
+            h = C.CDLL(HOST_LIB_PATH)
+            h.rpcc_host_version.restype = C.c_int
+            h.rpcc_host_version.argtypes = []
+            if h.rpcc_host_version() != HOST_ABI:
+                raise OSError("reports interface version %d, this binding needs %d (stale build)" % (h.rpcc_host_version(), HOST_ABI))
+            h.rpcc_host_pack_bz2.restype = C.c_int
+            h.rpcc_host_pack_bz2.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        except (OSError, AttributeError) as e:
+            _host_failed = "librpcc_host.so (%s): %s" % (HOST_LIB_PATH, e)
+            raise RpccError(_host_failed)
         _host = h
     return _host
 

@@ -123,21 +123,31 @@ def pack_frames(basic_compressor, frames, uniform=True):
     ONE call into librpcc_host.so for the whole list (include/rpcc_host.h) -- a pool thread then enters the interpreter once
     per chunk of frames instead of once per array.  Same bytes as the per-frame path (tests/test_host_pack.py)."""
     from . import _lib
-    if basic_compressor.method_name != "bzip2" or not frames or not os.path.exists(_lib.HOST_LIB_PATH):
+    host = None
+    if basic_compressor.method_name == "bzip2" and frames:
+        try:
+            host = _lib.host_lib()     # not built / not loadable / stale: remembered by _lib, the Python path below gives the same bytes
+        except _lib.RpccError:
+            host = None
+    if host is None:
         return [pack_bitstream(basic_compressor.compress_dict(od), uniform=uniform) for od in frames]
     keys = (() if uniform else ("salience_level",)) + _ORDER
     arrs = [np.ascontiguousarray(od[k]) for od in frames for k in keys]
     n, na = len(frames), len(keys)
     ptrs = np.fromiter((a.ctypes.data for a in arrs), dtype=np.uint64, count=n * na)
     lens = np.fromiter((a.nbytes for a in arrs), dtype=np.uint32, count=n * na)
-    # bzip2 never expands by more than 1 % + 600 bytes
-    stride = int((lens.reshape(n, na).astype(np.int64) * 101 // 100 + 604).sum(1).max())
-    out = np.empty((n, stride), np.uint8)
+    # bzip2 never expands by more than 1 % + 600 bytes; every frame gets the room its own arrays need
+    room = (lens.reshape(n, na).astype(np.int64) * 101 // 100 + 604).sum(1)
+    offs = np.zeros(n + 1, np.uint64)
+    offs[1:] = np.cumsum(room)
+    out = np.empty(int(offs[-1]), np.uint8)
     out_len = np.zeros(n, np.uint32)
-    rc = _lib.host_lib().rpcc_host_pack_bz2(n, na, ptrs.ctypes.data, lens.ctypes.data, out.ctypes.data, stride, out_len.ctypes.data)
+    rc = host.rpcc_host_pack_bz2(n, na, ptrs.ctypes.data, lens.ctypes.data, out.ctypes.data, offs.ctypes.data, out_len.ctypes.data)
+    if rc == -1:
+        raise RuntimeError("rpcc_host_pack_bz2: bad argument")
     if rc != 0:
-        raise RuntimeError("rpcc_host_pack_bz2 failed on frame %d of the chunk" % (-rc - 1))
-    return [out[i, :int(out_len[i])].tobytes() for i in range(n)]
+        raise RuntimeError("rpcc_host_pack_bz2 failed on frame %d of the chunk" % (-rc - 16))
+    return [out[int(offs[i]): int(offs[i]) + int(out_len[i])].tobytes() for i in range(n)]
 
 
 def unpack_bitstream(blob, uniform=True):

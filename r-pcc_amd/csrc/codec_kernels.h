@@ -236,7 +236,8 @@ __global__ __launch_bounds__(256) void decode_kernel(const uint8_t *__restrict__
         else pr = -p3 / (p0 * ray[j].x + p1 * ray[j].y + p2 * ray[j].z);
         float res = 0.0f;  // label 1 keeps the zero of np.zeros_like (compress_utils.py:115)
         if (lab[j] >= 0) {
-            const double st = steps.levels ? steps.acc[salience[(int64_t)b * K + l]] : steps.acc[0];
+            // (a level beyond the configured ones -- a corrupt stream; tools/decompress.py rejects it -- is clamped, never read past acc[])
+            const double st = steps.levels ? steps.acc[min((int)salience[(int64_t)b * K + l], steps.levels - 1)] : steps.acc[0];
             res = (float)((double)qv[j] * st);  // int16 * python float -> float64 -> stored into a float32 array
         }
         const float rec = pr + res;          // tools/decompress.py:104

@@ -56,6 +56,16 @@ class _Slot:
         self.done = torch.cuda.Event()
         self.n = 0
 
+    def grow(self, cap_points, device):
+        """More points than the slot was sized for (dense sweeps, dual returns: a frame may hold more than one point per
+        pixel): the point-count-sized buffers are replaced.  Only called while the slot is idle (nothing of it in flight);
+        the projection workspace inside BatchBuffers follows by itself (ops.compress_batch)."""
+        self.cap = int(cap_points)
+        self.xyz_pin = torch.empty((self.cap, 3), dtype=torch.float32).pin_memory()
+        self.xyz_dev = torch.empty((self.cap, 3), dtype=torch.float32, device=device)
+        self.qp = torch.empty((self.cap,), dtype=torch.int16, device=device)
+        self.qp_pin = torch.empty((self.cap,), dtype=torch.int16).pin_memory()
+
 
 class BatchPayload:
     """What the container of every frame of a batch is assembled from: views into a slot's pinned output buffers.
@@ -94,7 +104,10 @@ class StreamingCompressor:
         self.bc, self.B, self.depth = bc, int(batch), int(depth)
         self.device = bc.device
         P = bc.T.H * bc.T.W
-        self.cap = int(points_per_frame if points_per_frame is not None else P) * self.B   # a pixel holds >= 1 point: nnz <= points
+        # initial capacity of a slot in points (default: one per pixel and frame -- a sweep rarely holds more); a batch with
+        # more points makes its slot grow (_Slot.grow), so this is a sizing hint, not a limit
+        self.cap = int(points_per_frame if points_per_frame is not None else P) * self.B
+        self.grown = 0
         self.pool = pool or ThreadPoolExecutor(workers or min(32, available_cpus()))
         self.copy_stream = torch.cuda.Stream(device=self.device)
         self.compute_stream = torch.cuda.Stream(device=self.device)
@@ -116,8 +129,9 @@ class StreamingCompressor:
         offs = np.zeros(self.B + 1, np.int64)
         offs[1:n + 1] = np.cumsum(sizes)
         offs[n + 1:] = offs[n]                       # a short last batch: the missing frames are empty
-        if offs[n] > slot.cap:
-            raise ValueError("batch holds %d points, the staging slot %d (raise points_per_frame)" % (offs[n], slot.cap))
+        if offs[n] > slot.cap:      # the slot is idle here (run() drained it): replace its point-sized buffers, with headroom
+            slot.grow(int(offs[n]) + int(offs[n]) // 4, self.device)
+            self.grown += 1
         dst = slot.xyz_pin.numpy()
 
         def copy(lo, hi):

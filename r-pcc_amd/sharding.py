@@ -61,6 +61,54 @@ def gather_payloads(local_payloads, device, group=None, dst=0):
     return out
 
 
+class RoundGather:
+    """The north-star exchange of the datalist driver (tools/compress_datalist.py --gather): every rank entropy-codes its
+    round-robin shard; the finished .rpcc byte strings travel to rank `dst` in rounds of `round_items` frames per rank
+    (gather_payloads: all_gather of the sizes + one padded gather of the bytes) and come out there in DATALIST order with
+    their datalist index.  Every rank calls the same number of rounds -- ceil(ceil(n / world) / round_items), fixed by the
+    datalist length alone -- a rank whose shard is shorter sends what it has."""
+
+    def __init__(self, n_items, rank, world, device, round_items=4096, group=None, dst=0):
+        self.n, self.rank, self.world, self.device, self.group, self.dst = int(n_items), rank, world, device, group, dst
+        self.R = max(1, int(round_items))
+        self.mine = len(shard_indices(self.n, rank, world))
+        longest = len(shard_indices(self.n, 0, world))
+        self.rounds = (longest + self.R - 1) // self.R
+        self.done_rounds = 0
+        self.pending = []          # this rank's blobs of the current and later rounds, in shard order
+        self.taken = 0             # blobs of this rank already sent
+
+    def _round(self):
+        j = self.done_rounds
+        want = max(0, min(self.R, self.mine - j * self.R))       # this rank's share of round j
+        assert len(self.pending) >= want
+        send, self.pending = self.pending[:want], self.pending[want:]
+        out = gather_payloads(send, self.device, group=self.group, dst=self.dst)
+        self.done_rounds += 1
+        self.taken += want
+        if out is None:
+            return []
+        base = j * self.R * self.world       # first datalist index of the round: local item k of rank r is entry r + k * world
+        return [(base + i, blob) for i, blob in enumerate(out)]
+
+    def add(self, blobs):
+        """blobs: the next finished payloads of this rank, in shard order.  Runs every round that is complete on this rank;
+        returns [(datalist index, bytes)] on dst (datalist order inside a round), [] elsewhere."""
+        self.pending.extend(blobs)
+        out = []
+        while self.done_rounds < self.rounds and (len(self.pending) >= self.R or self.taken + len(self.pending) >= self.mine):
+            out.extend(self._round())
+        return out
+
+    def finish(self):
+        """Call once after the last add(): runs the rounds that are still open (ranks without items left send nothing)."""
+        out = []
+        while self.done_rounds < self.rounds:
+            out.extend(self._round())
+        assert not self.pending, "more payloads handed in than the shard holds"
+        return out
+
+
 class PackedExchange:
     """The per-step exchange of bench.py / the batch drivers.  Every step the ranks all_gather the per-frame
     payload lengths nnz (what rank `dst` needs to index the job; B * 4 bytes per rank).  With payloads=True every rank also

@@ -6,7 +6,9 @@ Output path rule of the reference (tools/compress_datalist.py:136-142): output_d
 the extension replaced by `rpcc`.
 
 Multi-GPU: launch one process per GPU (torchrun); rank r takes datalist entries r, r+R, ... (frames are
-independent; no collective on the data path)."""
+independent; no collective on the data path).  By default every rank writes the files of its shard.  --gather is the
+north star's "RCCL only for the final gather of compressed bitstreams": every rank entropy-codes its shard, the .rpcc byte
+strings (~61 KB per frame) go to rank 0 in rounds (sharding.RoundGather) and rank 0 writes all files in datalist order."""
 import os
 import sys
 import time
@@ -21,7 +23,7 @@ import rpcc_amd  # noqa: E402,F401
 from rpcc_amd.dataset import build_dataset  # noqa: E402
 from rpcc_amd.loader import StreamingCompressor  # noqa: E402
 from rpcc_amd.pipeline import BatchCompressor  # noqa: E402
-from rpcc_amd.sharding import shard_indices  # noqa: E402
+from rpcc_amd.sharding import RoundGather, shard_indices  # noqa: E402
 from rpcc_amd.tools.compress import make_parser, resolve_cfg  # noqa: E402
 from rpcc_amd.utils import frame_identity  # noqa: E402
 
@@ -59,6 +61,28 @@ def _prefetch(gen, depth=2):
         yield item
 
 
+def write_blob(output_dir, name, blob):
+    out = output_path_for(output_dir, name)
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    with open(out, "wb") as f:
+        f.write(blob)
+    return len(blob)
+
+
+def init_gather_group(rank, world, local):
+    """Process group of the --gather exchange: RCCL (backend "nccl") between the ranks' GPUs; RPCC_DIST_BACKEND overrides."""
+    import torch
+    import torch.distributed as dist
+    if dist.is_initialized():
+        return dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29544")
+    backend = os.environ.get("RPCC_DIST_BACKEND", "nccl")
+    kw = dict(device_id=torch.device("cuda", local)) if backend == "nccl" else {}
+    dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return dist
+
+
 def compress(args):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -71,12 +95,18 @@ def compress(args):
                          model_method=model_cfg["model_method"], compressor_cfg=dict(cfg),
                          basic_compressor=basic_compressor.method_name, seed=args.seed)
     mine = shard_indices(len(dataset), rank, world)
+    gather = None
+    if getattr(args, "gather", False):
+        import torch
+        init_gather_group(rank, world, local)
+        gather = RoundGather(len(dataset), rank, world, torch.device(device), round_items=args.gather_round)
     t0 = time.time()
-    stats = {"bytes": 0}
+    stats = {"bytes": 0, "files": 0}
     with futures.ThreadPoolExecutor(args.workers) as pool:
         # staged, double-buffered feed (loader.StreamingCompressor): file reads of batch n+1, device work of batch n and
         # entropy coding + file output of batch n-1 overlap
-        sc = StreamingCompressor(bc, batch=min(args.batch, max(len(mine), 1)), depth=4, workers=args.workers, pool=pool)
+        sc = StreamingCompressor(bc, batch=min(args.batch, max(len(mine), 1)), depth=4, workers=args.workers, pool=pool,
+                                 points_per_frame=getattr(args, "points_per_frame", None))
         names_of = {}
 
         def batches():
@@ -86,24 +116,30 @@ def compress(args):
                 frames = list(pool.map(dataset.load_data, names))
                 yield frames, [frame_identity(n) for n in names]
 
+        def write_all(jobs):      # jobs: [(file name, bytes)]
+            stats["bytes"] += sum(pool.map(lambda j: write_blob(args.output_dir, j[0], j[1]), jobs))
+            stats["files"] += len(jobs)
+            if args.output:
+                for name, blob in jobs:
+                    print("%s -> %d bytes" % (name, len(blob)))
+
         def sink(k, blobs):
             names = names_of.pop(k)
-
-            def write(job):
-                name, blob = job
-                out = output_path_for(args.output_dir, name)
-                os.makedirs(os.path.dirname(out), exist_ok=True)
-                with open(out, "wb") as f:
-                    f.write(blob)
-                return len(blob)
-            stats["bytes"] += sum(pool.map(write, zip(names, blobs)))
-            if args.output:
-                for name, blob in zip(names, blobs):
-                    print("%s -> %d bytes" % (name, len(blob)))
+            if gather is None:
+                write_all(list(zip(names, blobs)))
+            else:     # the bytes go to rank 0, which writes them under their datalist names
+                write_all([(dataset.data_list[i], blob) for i, blob in gather.add(blobs)])
         sc.run(_prefetch(batches()), sink=sink, entropy=True)
+        if gather is not None:
+            write_all([(dataset.data_list[i], blob) for i, blob in gather.finish()])
     dt = time.time() - t0
-    print("rank %d/%d: %d frames in %.3f s (%.1f frames/s incl. file I/O and entropy coding), %d bytes"
-          % (rank, world, len(mine), dt, len(mine) / max(dt, 1e-9), stats["bytes"]))
+    print("rank %d/%d: %d frames in %.3f s (%.1f frames/s incl. file I/O and entropy coding), %d files / %d bytes written%s"
+          % (rank, world, len(mine), dt, len(mine) / max(dt, 1e-9), stats["files"], stats["bytes"],
+             " (gathered to rank 0 over the process group)" if gather is not None else ""))
+    if gather is not None:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -42,8 +42,17 @@ def decode_frame(blob_dict, basic_compressor, transformer, cluster_num, accuracy
         raise ValueError("idx_sequence holds %d labels, the contour map marks %d runs" % (s_chk.size, n_contour))
     if s_chk.size and int(s_chk.max()) >= plane_param.shape[0]:
         raise ValueError("idx_sequence names label %d but only %d model rows are stored" % (int(s_chk.max()), plane_param.shape[0]))
-    if not uniform and len(d.get("salience_level", b"")) > K:
-        raise ValueError("salience_level holds more entries than labels")
+    if not uniform:
+        if "salience_level" not in d:
+            raise ValueError("non-uniform framework: the bitstream holds no salience_level payload (written with the uniform framework?)")
+        sl_chk = np.frombuffer(d["salience_level"], dtype=np.uint8)
+        if sl_chk.size > K:
+            raise ValueError("salience_level holds more entries than labels")
+        if sl_chk.size < plane_param.shape[0]:
+            raise ValueError("salience_level holds %d entries for %d model rows" % (sl_chk.size, plane_param.shape[0]))
+        if sl_chk.size and int(sl_chk.max()) >= len(level_acc):
+            raise ValueError("salience level %d in the bitstream, the configuration defines %d levels (other level_key_point_num?)"
+                             % (int(sl_chk.max()), len(level_acc)))
     dev = transformer.device
     model = torch.zeros((1, K, 4), dtype=torch.float32, device=dev)
     model[0, : plane_param.shape[0]] = torch.from_numpy(plane_param.copy()).to(dev)

@@ -59,3 +59,33 @@ def available_cpus():
     except (OSError, ValueError):
         pass
     return max(1, n)
+
+
+def visible_gpus():
+    """Number of GPUs this process would see, WITHOUT initialising HIP / HSA here (bench.py's parent counts before it
+    spawns its rank processes and must stay a process that never touched the GPU): the KFD topology in sysfs (nodes with
+    simd_count > 0 are GPUs), narrowed by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES when one of them
+    is a plain index list.  None when sysfs tells nothing (not a ROCm host)."""
+    import glob
+    import re
+    n = None
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if nodes:
+        n = 0
+        for p in nodes:
+            try:
+                m = re.search(r"^simd_count\s+(\d+)", open(p).read(), re.M)
+            except OSError:
+                continue
+            if m and int(m.group(1)) > 0:
+                n += 1
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is None:
+            continue
+        items = [s for s in v.split(",") if s.strip() != ""]
+        if all(re.fullmatch(r"\s*\d+\s*", s) for s in items):
+            n = len(items) if n is None else min(n, len(items))
+        elif v.strip() == "":
+            n = 0
+    return n

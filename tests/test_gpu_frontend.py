@@ -106,6 +106,57 @@ def test_cli_roundtrip(fe, tmp_path):
     assert os.path.getsize(produced) > 20000
 
 
+def test_datalist_gather_writes_the_same_files(fe, tmp_path):
+    """tools/compress_datalist.py --gather (the north star's "RCCL only for the final gather of compressed bitstreams"): the
+    .rpcc bytes go through sharding.RoundGather over a single-rank RCCL group and rank 0 writes them -- the files equal the
+    default mode's (every rank writes its own), with rounds shorter than the datalist."""
+    from rpcc_amd import synth
+    from rpcc_amd.tools import compress_datalist as tdl
+    from oracle import oracle as orc
+    gd = orc.GEOMS["VelodyneVLP16"]
+    names = []
+    for i in range(5):
+        f = synth.make_frame(40 + i, gd["H"], gd["W"], vmax_deg=gd["vmax_deg"], vmin_deg=gd["vmin_deg"]).numpy()
+        src = tmp_path / ("sweep_%03d.bin" % i)
+        np.concatenate((f, np.zeros((f.shape[0], 1), np.float32)), 1).astype(np.float32).tofile(src)
+        names.append(str(src))
+    lst = tmp_path / "list.txt"
+    lst.write_text("\n".join(names) + "\n")
+    base = ["--datalist", str(lst), "--lidar", "VelodyneVLP16", "--batch", "2"]
+    tdl.compress(fe.tc.make_parser(datalist=True).parse_args(base + ["--output_dir", str(tmp_path / "a")]))
+    old = {k: os.environ.get(k) for k in ("MASTER_PORT",)}
+    os.environ["MASTER_PORT"] = "29571"
+    try:
+        tdl.compress(fe.tc.make_parser(datalist=True).parse_args(base + ["--output_dir", str(tmp_path / "b"), "--gather", "--gather-round", "2"]))
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    for n in names:
+        a, b = tdl.output_path_for(str(tmp_path / "a"), n), tdl.output_path_for(str(tmp_path / "b"), n)
+        assert os.path.getsize(a) > 1000 and open(a, "rb").read() == open(b, "rb").read(), n
+
+
+def test_streaming_loader_grows_its_slots(fe):
+    """A batch with more points than one per pixel and frame (dense / dual-return sweeps): the staging slot grows instead of
+    raising, and the bytes equal BatchCompressor.compress (which sizes its buffers from the data)."""
+    from oracle import oracle as orc
+    from rpcc_amd import synth
+    from rpcc_amd.loader import StreamingCompressor
+    gd = orc.GEOMS["VelodyneVLP16"]
+    ds = fe.ds.build_dataset(lidar_type="VelodyneVLP16")
+    base = [synth.make_frame(820 + i, gd["H"], gd["W"], vmax_deg=gd["vmax_deg"], vmin_deg=gd["vmin_deg"]).numpy() for i in range(4)]
+    rng = np.random.default_rng(3)
+    dense = [np.concatenate([f, f * np.float32(1.01), f[rng.permutation(f.shape[0])] * np.float32(0.99)]) for f in base]   # ~2.4 points per pixel
+    assert all(f.shape[0] > gd["H"] * gd["W"] for f in dense)
+    bc = fe.pl.BatchCompressor(ds.PCTransformer, accuracy=0.02, seed=2)
+    want = bc.compress(dense[:2], frame_ids=[5, 6]) + bc.compress(dense[2:], frame_ids=[7, 8])
+    sc = StreamingCompressor(bc, batch=2, depth=2, workers=2)
+    got = {}
+    n = sc.run(((dense[s:s + 2], [5 + s, 6 + s]) for s in (0, 2)), sink=lambda k, r: got.__setitem__(k, r))
+    assert n == 4 and sc.grown >= 1
+    assert [b for k in sorted(got) for b in got[k]] == want
+
+
 @pytest.mark.parametrize("accuracy", [0.01, 0.02, 0.05])
 @pytest.mark.parametrize("lidar,geom", [("Velodyne64E", "Velodyne64E"), ("Velodyne32E", "Velodyne32E"), ("VelodyneVLP16", "VelodyneVLP16")])
 def test_nonuniform_plane_batches_mixed_lidars(fe, lidar, geom, accuracy):

@@ -131,3 +131,15 @@ def test_decoder_rejects_inconsistent_streams(env):
     short = dict(raw, residual_quantized=raw["residual_quantized"][:-8])
     with pytest.raises(ValueError):
         env["dec"].decode_frame(bc.compress_dict({k: np.frombuffer(v, np.uint8) for k, v in short.items()}), bc, T16, 100, 0.04, None, True)
+    # non-uniform framework: the salience levels come straight from the file and index the step table
+    nrow = np.frombuffer(raw["plane_param"], np.float32).size // 4
+    lv = [0.04, 0.06, 0.08, 0.10]
+    as_u8 = lambda dct: bc.compress_dict({k: np.frombuffer(v, np.uint8) for k, v in dct.items()})
+    ok = dict(raw, salience_level=np.full(nrow, 3, np.uint8).tobytes())
+    env["dec"].decode_frame(as_u8(ok), bc, T16, 100, 0.04, lv, False)                # a consistent stream decodes
+    with pytest.raises(ValueError):                                                  # a level the configuration does not define
+        env["dec"].decode_frame(as_u8(dict(raw, salience_level=np.full(nrow, 4, np.uint8).tobytes())), bc, T16, 100, 0.04, lv, False)
+    with pytest.raises(ValueError):                                                  # fewer levels than model rows
+        env["dec"].decode_frame(as_u8(dict(raw, salience_level=np.zeros(nrow - 1, np.uint8).tobytes())), bc, T16, 100, 0.04, lv, False)
+    with pytest.raises(ValueError):                                                  # a uniform stream read as non-uniform
+        env["dec"].decode_frame(as_u8(raw), bc, T16, 100, 0.04, lv, False)

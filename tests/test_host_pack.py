@@ -71,4 +71,38 @@ def test_host_header_symbols_exported(cu):
     lib = ctypes.CDLL(_lib.HOST_LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert _lib.host_lib().rpcc_host_version() >= 100
+    assert _lib.host_lib().rpcc_host_version() == _lib.HOST_ABI
+
+
+def test_unusable_host_library_falls_back_to_python(cu, monkeypatch):
+    """A library that is present but cannot be used (libbz2 missing at run time, a stale build): pack_frames takes the per-frame
+    Python path -- same bytes -- and the failure is remembered instead of being raised inside pool threads again and again."""
+    from rpcc_amd import _lib
+    rng = np.random.default_rng(5)
+    bc = cu.BasicCompressor(method_name="bzip2")
+    frames = _frames(rng, 3, True)
+    want = [cu.pack_bitstream(bc.compress_dict(od), uniform=True) for od in frames]
+    monkeypatch.setattr(_lib, "_host", None)
+    monkeypatch.setattr(_lib, "_host_failed", None)
+    monkeypatch.setattr(_lib, "HOST_ABI", 9999)            # "stale .so after an interface change"
+    assert cu.pack_frames(bc, frames, uniform=True) == want
+    assert _lib._host_failed and "stale" in _lib._host_failed
+    assert cu.pack_frames(bc, frames, uniform=True) == want
+    monkeypatch.setattr(_lib, "_host_failed", None)
+    monkeypatch.setattr(_lib, "HOST_LIB_PATH", "/nonexistent/librpcc_host.so")
+    assert cu.pack_frames(bc, frames, uniform=True) == want
+
+
+def test_host_pack_return_codes(cu):
+    """Distinct codes: RPCC_HOST_ERR_ARG for a bad argument, -(16 + frame) for the frame that does not fit its region."""
+    from rpcc_amd import _lib
+    h = _lib.host_lib()
+    a = np.arange(1000, dtype=np.uint8)
+    ptrs = np.array([a.ctypes.data, a.ctypes.data], np.uint64)
+    lens = np.array([a.nbytes, a.nbytes], np.uint32)
+    out = np.empty(8192, np.uint8)
+    out_len = np.zeros(2, np.uint32)
+    offs = np.array([0, 4096, 4100], np.uint64)             # frame 1 gets 4 bytes
+    assert h.rpcc_host_pack_bz2(2, 1, ptrs.ctypes.data, lens.ctypes.data, out.ctypes.data, offs.ctypes.data, out_len.ctypes.data) == -17
+    assert h.rpcc_host_pack_bz2(2, 0, ptrs.ctypes.data, lens.ctypes.data, out.ctypes.data, offs.ctypes.data, out_len.ctypes.data) == -1
+    assert h.rpcc_host_pack_bz2(2, 1, ptrs.ctypes.data, lens.ctypes.data, out.ctypes.data, None, out_len.ctypes.data) == -1

@@ -47,6 +47,57 @@ def test_two_rank_gloo_gather(n_items):
     assert len(res) == n_items and all(res)
 
 
+def _round_worker(rank, world, port, n_items, round_items, outdir, q):
+    """tools/compress_datalist.py --gather with the device part replaced by a stand-in: every rank "compresses" its shard in
+    batches of 3, hands the blobs to RoundGather as they finish, rank 0 writes the files it receives."""
+    sys.path.insert(0, ROOT)
+    import rpcc_amd  # noqa: F401
+    from rpcc_amd.sharding import RoundGather, shard_indices
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = shard_indices(n_items, rank, world)
+    rg = RoundGather(n_items, rank, world, torch.device("cpu"), round_items=round_items)
+    got = []
+    for s in range(0, len(mine), 3):
+        got += rg.add([_payload(i) for i in mine[s:s + 3]])
+    got += rg.finish()
+    for i, blob in got:
+        with open(os.path.join(outdir, "%04d.rpcc" % i), "wb") as f:
+            f.write(blob)
+    if rank == 0:
+        q.put(([i for i, _ in got], rg.rounds))
+    else:
+        assert got == []
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_items,round_items", [(11, 2), (8, 4), (5, 100), (1, 1), (12, 3)])
+def test_two_rank_round_gather_writes_single_rank_files(tmp_path, n_items, round_items):
+    """The product's collective (sharding.RoundGather, used by tools/compress_datalist.py --gather): two gloo ranks, the files
+    rank 0 writes equal those of a single-rank run, the indices arrive in datalist order, and every rank ran the same number of
+    rounds."""
+    ctx = mp.get_context("spawn")
+    outs = {}
+    for world in (1, 2):
+        d = tmp_path / ("w%d" % world)
+        d.mkdir()
+        q = ctx.Queue()
+        port = 29700 + 10 * n_items + world
+        procs = [ctx.Process(target=_round_worker, args=(r, world, port, n_items, round_items, str(d), q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        idx, rounds = q.get(timeout=120)
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+        assert idx == list(range(n_items))
+        outs[world] = {f: open(os.path.join(d, f), "rb").read() for f in sorted(os.listdir(d))}
+    assert len(outs[1]) == n_items and outs[1] == outs[2]
+    assert all(outs[2]["%04d.rpcc" % i] == _payload(i) for i in range(n_items))
+
+
 def test_shard_indices_partition():
     sys.path.insert(0, ROOT)
     import rpcc_amd  # noqa: F401
@@ -131,6 +182,75 @@ def test_bench_refuses_more_gpus_than_visible():
     assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
 
 
+def _bench_env(**kw):
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "RPCC_RDZV_FILE"):
+        env.pop(k, None)
+    env.update(kw)
+    return env
+
+
+def test_bench_spawn_dry_run_two_ranks():
+    """The launch path of `python bench.py --gpus 2` without a GPU (RPCC_BENCH_DRYRUN: gloo ranks): the parent counts no GPU
+    through HIP, starts two fresh rank processes, they meet through the parent's file store, and rank 0's single JSON line
+    -- carrying ranks_joined -- is relayed as the last line."""
+    import json
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=_bench_env(RPCC_BENCH_DRYRUN="gloo"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rec["n_gpus"] == 2 and rec["ranks_joined"] == 2 and len(rec["per_rank_s"]) == 2
+
+
+def test_bench_spawn_stops_the_group_when_a_rank_dies():
+    """Rank 1 dies before the rendezvous: rank 0 would sit in init_process_group until the collective timeout.  The parent
+    polls every child, kills the group and exits non-zero within seconds."""
+    import subprocess
+    import time
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"],
+                       env=_bench_env(RPCC_BENCH_DRYRUN="gloo", RPCC_BENCH_DIE_RANK="1", RPCC_BENCH_PG_TIMEOUT_S="600"),
+                       capture_output=True, text=True, timeout=300)
+    took = time.monotonic() - t0
+    assert r.returncode != 0 and "rank 1 exited with code 7" in r.stderr, (r.returncode, r.stderr[-2000:])
+    assert took < 60, took                      # import torch dominates; the rendezvous timeout is 600 s
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_spawn_wall_budget():
+    """A rank that never finishes: the parent's wall budget ends the run."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"],
+                       env=_bench_env(RPCC_BENCH_DRYRUN="gloo", RPCC_BENCH_HANG_RANK="0", RPCC_BENCH_WALL_S="8"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "wall budget" in r.stderr, (r.returncode, r.stderr[-2000:])
+
+
+def test_bench_parent_never_imports_torch_before_spawning():
+    """The parent of `--gpus N` must stay a process that never touched HIP: the GPU count comes from sysfs / the
+    *_VISIBLE_DEVICES masks (utils.visible_gpus), and spawn_ranks itself imports neither torch nor the HIP library."""
+    import ast
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "spawn_ranks"][0]
+    names = {a.name for n in ast.walk(fn) if isinstance(n, ast.Import) for a in n.names} | \
+            {n.module for n in ast.walk(fn) if isinstance(n, ast.ImportFrom)}
+    assert "torch" not in names and not any(str(m).startswith("torch") for m in names), names
+    sys.path.insert(0, ROOT)
+    import rpcc_amd  # noqa: F401
+    from rpcc_amd import utils
+    old = dict(os.environ)
+    try:
+        os.environ["HIP_VISIBLE_DEVICES"] = "0,1,2"
+        n = utils.visible_gpus()
+        assert n is not None and n <= 3
+        os.environ["HIP_VISIBLE_DEVICES"] = ""
+        assert utils.visible_gpus() == 0
+    finally:
+        os.environ.clear()
+        os.environ.update(old)
+
+
 def test_bench_finds_its_pmc_numbers():
     """bench.py fills roofline.traffic / valu_wave_insts from profiles/pmc_current.json: the committed file must describe
     the default configuration and name the FPS kernel the way bench.py looks it up (a rename once left the fields null)."""
@@ -141,5 +261,6 @@ def test_bench_finds_its_pmc_numbers():
     keys = [k for k in pm["kernels"] if k.startswith(("fps_regtab_kernel<true", "fps_tiled_kernel<true"))]
     assert len(keys) == 1, list(pm["kernels"])
     assert pm["kernels"][keys[0]]["traffic_bytes_per_launch"] > 0 and pm["kernels"][keys[0]]["valu_wave_insts_per_launch"] > 0
+    assert pm["step_traffic_bytes"] > 0 and pm["step_valu_wave_insts"] > 0     # roofline.frac (VALU issue) / step_traffic_frac
     src = open(os.path.join(root, "bench.py")).read()
     assert 'startswith(("fps_regtab_kernel<true", "fps_tiled_kernel<true"))' in src
