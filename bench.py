@@ -596,7 +596,8 @@ def main():
     import rpcc_amd  # noqa: F401
     ctx = dict(rank=rank, world=world, dev=dev, dist=dist)
     out = run_workload(a, ctx)
-    if out is not None and world == 1 and not a.no_secondary and not a.force_gather:
+    headline = a.config == 1 and not a.input and a.geom is None and not (a.fps_bruteforce or a.h2d or a.force_gather)
+    if out is not None and world == 1 and headline and not a.no_secondary:     # beside the headline only
         out["secondary"] = run_secondary(a, ctx)
     if dist is not None:
         dist.barrier()

@@ -370,13 +370,15 @@ __global__ __launch_bounds__(FPS_TT) void fps_tiled_kernel(const float *__restri
         DBG_STAMP(10);
         if (tid == 0) { out_idx[1] = old; if (out_cen) { out_cen[3] = c0; out_cen[4] = c1; out_cen[5] = c2; } }
     }
+#ifdef RPCC_DEVTRACE   // developer trace (per-iteration cycle stamps of workgroup 0); absent from the shipped build
     long long acc_a = 0, acc_b = 0, acc_c = 0, acc_n = 0, tq = 0;
-#ifdef FPS_PROF2
-    long long acc_p1 = 0, acc_p2 = 0, acc_p3 = 0;
-#endif
     const bool prof = g_dbg_stamps != nullptr && blockIdx.x == 0 && tid == 0;
+#define FPS_TR(code_) do { if (prof) { code_; } } while (0)
+#else
+#define FPS_TR(code_) do { } while (0)
+#endif
     for (int j = 2; j < M; j++) {
-        if (prof) tq = (long long)__builtin_readcyclecounter();
+        FPS_TR(tq = (long long)__builtin_readcyclecounter());
         // tile test against the new centre; active tiles go to the work list
         for (int t = tid; t < T; t += FPS_TT) {
             const float4 lo = L.lo4[t], hi = L.hi4[t];
@@ -396,10 +398,8 @@ __global__ __launch_bounds__(FPS_TT) void fps_tiled_kernel(const float *__restri
         update_origin();
         __syncthreads();
         const int n = wcount;
-        if (prof) { const long long t1 = (long long)__builtin_readcyclecounter(); acc_a += t1 - tq; tq = t1; acc_n += n; }
-#ifdef FPS_PROF2
-        if (prof) { g_dbg_stamps[64 + 8 * j] = n; g_dbg_stamps[64 + 8 * j + 1] = acc_a; }
-#endif
+        FPS_TR(const long long t1 = (long long)__builtin_readcyclecounter(); acc_a += t1 - tq; tq = t1; acc_n += n;
+               g_dbg_stamps[64 + 8 * j] = n; g_dbg_stamps[64 + 8 * j + 1] = acc_a);
         for (int e = wave; e < n; e += NW * GROUP) {
             FpsQuad q[GROUP];
             int tt[GROUP];
@@ -410,35 +410,27 @@ __global__ __launch_bounds__(FPS_TT) void fps_tiled_kernel(const float *__restri
                 locate(tt[gi], q[gi]);
                 fps_quad_load<RANGE, VEC>(src, rays, temp, q[gi]);   // unconditional (a repeated tile for the tail is harmless and unused)
             }
-#ifdef FPS_PROF2
+#ifdef RPCC_DEVTRACE
             if (prof && e == wave) g_dbg_stamps[64 + 8 * j + 2] = (long long)__builtin_readcyclecounter() - tq;   // loads issued
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (prof && e == wave) g_dbg_stamps[64 + 8 * j + 3] = (long long)__builtin_readcyclecounter() - tq;   // data arrived
 #endif
 #pragma unroll
             for (int gi = 0; gi < GROUP; gi++) if (e + gi * NW < n) compute_tile(tt[gi], q[gi], false);
-#ifdef FPS_PROF2
-            if (prof && e == wave) g_dbg_stamps[64 + 8 * j + 4] = (long long)__builtin_readcyclecounter() - tq;   // round 1 computed
-#endif
+            FPS_TR(if (e == wave) g_dbg_stamps[64 + 8 * j + 4] = (long long)__builtin_readcyclecounter() - tq);   // round 1 computed
         }
         __syncthreads();
-#ifdef FPS_PROF2
-        if (prof) g_dbg_stamps[64 + 8 * j + 5] = (long long)__builtin_readcyclecounter() - tq;   // barrier 2 passed
-#endif
-        if (prof) { const long long t1 = (long long)__builtin_readcyclecounter(); acc_b += t1 - tq; tq = t1; }
+        FPS_TR(g_dbg_stamps[64 + 8 * j + 5] = (long long)__builtin_readcyclecounter() - tq;   // barrier 2 passed
+               const long long t1 = (long long)__builtin_readcyclecounter(); acc_b += t1 - tq; tq = t1);
         if (tid == 0) wcount = 0;
         select_next();
-#ifdef FPS_PROF2
-        if (prof) g_dbg_stamps[64 + 8 * j + 6] = (long long)__builtin_readcyclecounter() - tq;   // select done
-#endif
-        if (prof) { const long long t1 = (long long)__builtin_readcyclecounter(); acc_c += t1 - tq; tq = t1; }
+        FPS_TR(g_dbg_stamps[64 + 8 * j + 6] = (long long)__builtin_readcyclecounter() - tq;   // select done
+               const long long t1 = (long long)__builtin_readcyclecounter(); acc_c += t1 - tq; tq = t1);
         if (tid == 0) { out_idx[j] = old; if (out_cen) { out_cen[3 * j] = c0; out_cen[3 * j + 1] = c1; out_cen[3 * j + 2] = c2; } }
     }
     DBG_STAMP(16);
-    if (prof) { g_dbg_stamps[24] = acc_a; g_dbg_stamps[25] = acc_b; g_dbg_stamps[26] = acc_c; g_dbg_stamps[27] = acc_n; }
-#ifdef FPS_PROF2
-    if (prof) { g_dbg_stamps[28] = acc_p1; g_dbg_stamps[29] = acc_p2; g_dbg_stamps[30] = acc_p3; }
-#endif
+    FPS_TR(g_dbg_stamps[24] = acc_a; g_dbg_stamps[25] = acc_b; g_dbg_stamps[26] = acc_c; g_dbg_stamps[27] = acc_n);
+#undef FPS_TR
     if (RANGE && org_on && (flags & FPS_FLAG_FINALIZE_TEMP)) {
         // the empty pixels' temp entries were not touched while the class was carried as a scalar
         for (int p = tid; p < N; p += FPS_TT) {
@@ -606,7 +598,7 @@ __global__ __launch_bounds__(FPS_TT) void fps_regtab_kernel(const float *__restr
         }
     };
     int par = 0;
-#ifdef FPS_PROF3   // developer trace: cycles per phase of the iteration chain, summed over the iterations, per wavefront of block 0
+#ifdef RPCC_DEVTRACE   // developer trace: cycles per phase of the iteration chain, summed over the iterations, per wavefront of block 0
     long long p3_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, p3_last = (long long)__builtin_readcyclecounter();
 #define FPS_P3(i_) do { const long long t_ = (long long)__builtin_readcyclecounter(); p3_acc[i_] += t_ - p3_last; p3_last = t_; } while (0)
 #else
@@ -698,7 +690,7 @@ __global__ __launch_bounds__(FPS_TT) void fps_regtab_kernel(const float *__restr
         const float g2 = fmaxf(fmaxf(lo2 - c2, c2 - hi2), 0.0f);
         const float bound = (g0 * g0 + g1 * g1) + g2 * g2;
         const unsigned long long vm = __ballot(have && bound < tmax);
-#ifdef FPS_PROF3
+#ifdef RPCC_DEVTRACE
         p3_acc[6] += __popcll(vm);
         p3_acc[7] += vm != 0ull;
 #endif
@@ -712,7 +704,7 @@ __global__ __launch_bounds__(FPS_TT) void fps_regtab_kernel(const float *__restr
         if (tid == 0) { out_idx[j] = old; if (out_cen) { out_cen[3 * j] = c0; out_cen[3 * j + 1] = c1; out_cen[3 * j + 2] = c2; } }
         FPS_P3(5);
     }
-#ifdef FPS_PROF3
+#ifdef RPCC_DEVTRACE
     if (g_dbg_stamps != nullptr && blockIdx.x == 0 && lane == 0)
         for (int i = 0; i < 8; i++) g_dbg_stamps[64 + wave * 8 + i] = p3_acc[i];
 #endif

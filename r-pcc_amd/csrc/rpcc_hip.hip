@@ -41,8 +41,11 @@ static int set_err(int code, const char *fmt, const char *a = "", const char *b 
 extern "C" int rpcc_version(void) { return 100; }
 extern "C" const char *rpcc_last_error(void) { return g_err; }
 
-// Developer phase timing: when a buffer is registered, block 0 / thread 0 of instrumented kernels stores
-// s_memtime at phase boundaries (tools_dev/phase_times.py).  NULL (default) = one scalar load per stamp.
+// Developer phase timing.  The shipped library carries NO trace code: only a build with -DRPCC_DEVTRACE (RPCC_EXTRA_FLAGS, see
+// r-pcc_amd/build.py; tools_dev/phase_times.py, tools_dev/fps_phases.sh) compiles the stamps -- block 0 / thread 0 of the
+// instrumented kernels then stores the shader clock at phase boundaries into the registered buffer -- and the per-phase cycle
+// counters of the FPS kernels.  Without it rpcc_debug_stamps() reports that the build has no trace support.
+#ifdef RPCC_DEVTRACE
 __device__ long long *g_dbg_stamps = nullptr;
 extern "C" int rpcc_debug_stamps(void *dev_i64_buffer) {
     long long *p = reinterpret_cast<long long *>(dev_i64_buffer);
@@ -54,6 +57,13 @@ extern "C" int rpcc_debug_stamps(void *dev_i64_buffer) {
         if (g_dbg_stamps != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) \
             g_dbg_stamps[slot_] = (long long)__builtin_readcyclecounter();                   \
     } while (0)
+#else
+extern "C" int rpcc_debug_stamps(void *dev_i64_buffer) {
+    if (dev_i64_buffer == nullptr) return RPCC_OK;
+    return set_err(RPCC_ERR_ARG, "rpcc_debug_stamps: this library was built without -DRPCC_DEVTRACE%s%s");
+}
+#define DBG_STAMP(slot_) do { } while (0)
+#endif
 
 // Kernel attributes (dynamic LDS size) are set once per (device, kernel), not per launch.
 static std::mutex g_attr_mu;

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Developer tool (library built with -DFPS_PROF3): cycles per phase of the FPS iteration chain, summed over the 98 iterations,
+"""Developer tool (library built with -DRPCC_DEVTRACE): cycles per phase of the FPS iteration chain, summed over the 98 iterations,
 for every wavefront of block 0.  usage: fps_phases.py [B]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,6 +1,6 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp
-RPCC_EXTRA_FLAGS="-DFPS_PROF3" python3 -c "
+RPCC_EXTRA_FLAGS="-DRPCC_DEVTRACE" python3 -c "
 import sys; sys.path.insert(0,'.')
 import rpcc_amd
 from rpcc_amd import build as b

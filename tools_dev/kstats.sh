@@ -3,7 +3,7 @@
 # usage: tools_dev/kstats.sh [bench.py args]
 cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp
 rm -rf /tmp/kst && mkdir -p /tmp/kst
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kst -o k -- python3 bench.py --cpu-sample 0 --pipeline 1 "$@" > /tmp/kst/bench.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kst -o k -- python3 bench.py --no-secondary --cpu-sample 0 --pipeline 1 "$@" > /tmp/kst/bench.log 2>&1
 f=$(find /tmp/kst -name "*kernel_stats.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv, sys

@@ -3,7 +3,7 @@
 # usage: tools_dev/pmc.sh "CTR1 CTR2 ..."
 cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp
 rm -rf /tmp/pmc && mkdir -p /tmp/pmc
-rocprofv3 --pmc $1 --kernel-trace --output-format csv -d /tmp/pmc -o p -- python3 bench.py --cpu-sample 0 --pipeline 1 --steps 2 --warmup 1 > /tmp/pmc/bench.log 2>&1
+rocprofv3 --pmc $1 --kernel-trace --output-format csv -d /tmp/pmc -o p -- python3 bench.py --no-secondary --cpu-sample 0 --pipeline 1 --steps 2 --warmup 1 > /tmp/pmc/bench.log 2>&1
 f=$(find /tmp/pmc -name "*counter_collection.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv, sys, collections
