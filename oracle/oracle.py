@@ -137,6 +137,26 @@ def fps(xyz, m):
     return idx
 
 
+def fps_modes(xyz, m, fma=0, cuda_tie=False):
+    """a6 with the CUDA binary's two unpinned degrees of freedom as switches (orc_fps_modes): fma = 0 un-fused,
+    1 fma(dz,dz,fma(dx,dx,dy*dy)), 2 fma(dz,dz,fma(dy,dy,dx*dx)) -- nvcc's --fmad=true contractions of sampling_gpu.cu:64;
+    cuda_tie: the survivor of the kernel's own reduction among exactly equal values (sampling_gpu.cu:16-21,55-69,74-134)
+    instead of the lowest index.  fps_modes(xyz, m) == fps(xyz, m)."""
+    xyz = _f32(xyz)
+    idx = np.zeros(m, np.int32)
+    lib().orc_fps_modes(_p(xyz), int(xyz.shape[0]), int(m), int(fma), int(bool(cuda_tie)), _p(idx))
+    return idx
+
+
+def fps_cuda_emulated(xyz, m, fma=0):
+    """The CUDA kernel thread by thread (strided per-thread scan + shared-memory tree): small inputs only (test of the
+    closed-form tie rule of fps_modes(cuda_tie=True))."""
+    xyz = _f32(xyz)
+    idx = np.zeros(m, np.int32)
+    lib().orc_fps_cuda_emulated(_p(xyz), int(xyz.shape[0]), int(m), int(fma), _p(idx))
+    return idx
+
+
 def assign(ri, pc, tm, plane, centers):
     """a7: ground/cluster arg-nearest + relabel (utils/segment_utils.py:127-131,168-169) -> int32 [H,W]."""
     ri2 = _f32(ri).reshape(pc.shape[0], pc.shape[1])
@@ -317,7 +337,10 @@ def segment(ri, tm, ground_model, cfg=DEFAULT_CFG):
     dd = vertical_residual(pc, ground_model)
     mask = dd > cfg["ground_threshold"]
     pc_left = pc[np.where(mask)]
-    idx = fps(pc_left, cfg["cluster_num"])
+    if cfg.get("fps_fma", 0) or cfg.get("fps_cuda_tie", False):
+        idx = fps_modes(pc_left, cfg["cluster_num"], cfg.get("fps_fma", 0), cfg.get("fps_cuda_tie", False))
+    else:
+        idx = fps(pc_left, cfg["cluster_num"])
     centers = pc_left[idx]
     pix = np.flatnonzero(mask.reshape(-1))[idx].astype(np.int32)
     seg = assign(ri, pc, tm, ground_model, centers).astype(np.int64)

@@ -210,6 +210,109 @@ void orc_fps(const float *xyz, int n, int m, int *idx) {
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* a6 with the two things of the CUDA binary that the specification above leaves out, as switches (the  */
+/* reference has no golden vector for either; this restates what the SOURCE defines):                    */
+/*   fma  0  un-fused ((dx*dx)+(dy*dy))+(dz*dz)         (orc_fps; what -fmad=false would give)            */
+/*        1  fma(dz,dz, fma(dx,dx, dy*dy))              nvcc's default --fmad=true contracts :64; the     */
+/*        2  fma(dz,dz, fma(dy,dy, dx*dx))              two plausible contractions of (A + B) + C         */
+/*   cuda_tie 0  lowest index among equal values (the sequential strict-'>' scan)                          */
+/*            1  the winner the kernel's own reduction picks among EXACTLY equal values                    */
+/*               (sampling_gpu.cu:9-13,16-21,55-69,74-134): thread tid scans k = tid, tid+bs, ... with a     */
+/*               strict '>' (lowest k of its own), the shared-memory tree folds slot t+s into slot t with    */
+/*               `v2 > v1 ? i2 : i1` for s = bs/2 .. 1 (ties keep the lower slot), so the survivor is the    */
+/*               candidate with the smallest bit-reversed (k mod bs), then the smallest k;                   */
+/*               bs = max(min(1 << (int)(log(n)/log(2)), 1024), 1) as opt_n_threads computes it in double.   */
+/* ------------------------------------------------------------------------------------------ */
+static inline float fps_dist(float dx, float dy, float dz, int fma_mode) {
+    if (fma_mode == 1) return fmaf(dz, dz, fmaf(dx, dx, dy * dy));
+    if (fma_mode == 2) return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+    return (dx * dx + dy * dy) + dz * dz;
+}
+int orc_fps_block_size(int n) {
+    const int pow_2 = (int)(log((double)n) / log(2.0));   /* sampling_gpu.cu:9-13 */
+    int b = 1 << pow_2;
+    if (b > 1024) b = 1024;
+    if (b < 1) b = 1;
+    return b;
+}
+static inline uint32_t bitrev_bits(uint32_t v, int bits) {
+    uint32_t r = 0;
+    for (int i = 0; i < bits; i++) r |= ((v >> i) & 1u) << (bits - 1 - i);
+    return r;
+}
+void orc_fps_modes(const float *xyz, int n, int m, int fma_mode, int cuda_tie, int *idx) {
+    if (m <= 0 || n <= 0) return;
+    float *temp = (float *)malloc(sizeof(float) * (size_t)n);
+    for (int k = 0; k < n; k++) temp[k] = 1e10f;
+    const int bs = orc_fps_block_size(n);
+    int bits = 0;
+    while ((1 << bits) < bs) bits++;
+    int old = 0;
+    idx[0] = 0;
+    for (int j = 1; j < m; j++) {
+        int besti = 0;
+        float best = -1;
+        uint64_t bestkey = 0;
+        const float x1 = xyz[3 * old], y1 = xyz[3 * old + 1], z1 = xyz[3 * old + 2];
+        for (int k = 0; k < n; k++) {
+            const float dx = xyz[3 * k] - x1, dy = xyz[3 * k + 1] - y1, dz = xyz[3 * k + 2] - z1;
+            const float d = fps_dist(dx, dy, dz, fma_mode);
+            const float d2 = d < temp[k] ? d : temp[k];   /* min(d, temp[k]) */
+            temp[k] = d2;
+            if (!cuda_tie) {
+                if (d2 > best) { best = d2; besti = k; }
+            } else {
+                /* the CUDA kernel's survivor among equal values: smallest (bitrev(k mod bs), k) */
+                const uint64_t key = ((uint64_t)bitrev_bits((uint32_t)(k % bs), bits) << 32) | (uint32_t)k;
+                if (d2 > best || (d2 == best && key < bestkey)) { best = d2; besti = k; bestkey = key; }
+            }
+        }
+        old = besti;
+        idx[j] = old;
+    }
+    free(temp);
+}
+/* The kernel itself, thread by thread (per-thread strided scan + the shared-memory tree), for small n: the check that  */
+/* the closed form of cuda_tie = 1 above is what the source's reduction computes.                                        */
+void orc_fps_cuda_emulated(const float *xyz, int n, int m, int fma_mode, int *idx) {
+    if (m <= 0 || n <= 0) return;
+    float *temp = (float *)malloc(sizeof(float) * (size_t)n);
+    for (int k = 0; k < n; k++) temp[k] = 1e10f;
+    const int bs = orc_fps_block_size(n);
+    float *dists = (float *)malloc(sizeof(float) * (size_t)bs);
+    int *dists_i = (int *)malloc(sizeof(int) * (size_t)bs);
+    int old = 0;
+    idx[0] = 0;
+    for (int j = 1; j < m; j++) {
+        const float x1 = xyz[3 * old], y1 = xyz[3 * old + 1], z1 = xyz[3 * old + 2];
+        for (int tid = 0; tid < bs; tid++) {
+            int besti = 0;
+            float best = -1;
+            for (int k = tid; k < n; k += bs) {
+                const float dx = xyz[3 * k] - x1, dy = xyz[3 * k + 1] - y1, dz = xyz[3 * k + 2] - z1;
+                const float d = fps_dist(dx, dy, dz, fma_mode);
+                const float d2 = d < temp[k] ? d : temp[k];
+                temp[k] = d2;
+                besti = d2 > best ? k : besti;
+                best = d2 > best ? d2 : best;
+            }
+            dists[tid] = best;
+            dists_i[tid] = besti;
+        }
+        for (int s = bs / 2; s >= 1; s >>= 1)
+            for (int tid = 0; tid < s; tid++) {   /* __update(dists, dists_i, tid, tid + s) */
+                const float v1 = dists[tid], v2 = dists[tid + s];
+                const int i1 = dists_i[tid], i2 = dists_i[tid + s];
+                dists[tid] = v1 > v2 ? v1 : v2;
+                dists_i[tid] = v2 > v1 ? i2 : i1;
+            }
+        old = dists_i[0];
+        idx[j] = old;
+    }
+    free(temp); free(dists); free(dists_i);
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* a7: assignment, utils/segment_utils.py:127-131 + :168-169.                                   */
 /*   ground term (calc_plane_residual_depth :64-67): g = ri - (-d / ((a*tx + b*ty) + c*tz)), fp64 */
 /*   cluster term (calc_cluster_residual_radius :21-23): sqrtf(((dx*dx)+(dy*dy))+(dz*dz)), fp32   */

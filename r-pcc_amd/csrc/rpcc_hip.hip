@@ -288,22 +288,20 @@ static PixFastCfg pix_fast_cfg(const rpcc_geom g) {
     return c;
 }
 
-// atan(mn / mx) for 0 <= mn <= mx, mx > 0 (result in [0, pi/4]), absolute error < 5e-7
+// atan(mn / mx) for 0 <= mn <= mx, mx > 0 (result in [0, pi/4]), absolute error < 5e-7 (polynomial 2e-8; rcp and the reduction the rest)
 __device__ __forceinline__ float fast_atan_pos(float mn, float mx) {
     const float t = mn * __builtin_amdgcn_rcpf(mx);
     const bool red = t > 0.41421356f;  // tan(pi/8): atan(t) = pi/4 + atan((t-1)/(t+1))
     const float u = red ? (t - 1.0f) * __builtin_amdgcn_rcpf(t + 1.0f) : t;
     const float z = u * u;
-    float p = 1.6285819933e-02f;
-    p = __builtin_fmaf(p, z, -3.6531571299e-02f);
-    p = __builtin_fmaf(p, z, 4.9768779427e-02f);
-    p = __builtin_fmaf(p, z, -5.8335702866e-02f);
-    p = __builtin_fmaf(p, z, 6.6610731184e-02f);
-    p = __builtin_fmaf(p, z, -7.6918758452e-02f);
-    p = __builtin_fmaf(p, z, 9.0908870101e-02f);
-    p = __builtin_fmaf(p, z, -1.1111110449e-01f);
-    p = __builtin_fmaf(p, z, 1.4285714924e-01f);
-    p = __builtin_fmaf(p, z, -2.0000000298e-01f);
+    // (1 - atan(u) / u) / z on z <= tan(pi/8)^2 = 0.1716 as a degree-5 polynomial (Chebyshev fit, coefficients rounded to fp32):
+    // evaluated in fp32 the result is within 1.8e-8 of atan(u) -- the rounding of the result itself (half an ulp at 0.39 is
+    // 1.5e-8); fdlibm's eleven coefficients, used here until round 3, give the same 1.8e-8 with five more fmas.
+    float p = -5.0542026758e-02f;
+    p = __builtin_fmaf(p, z, 8.6272865534e-02f);
+    p = __builtin_fmaf(p, z, -1.1071758717e-01f);
+    p = __builtin_fmaf(p, z, 1.4284175634e-01f);
+    p = __builtin_fmaf(p, z, -1.9999977946e-01f);
     p = __builtin_fmaf(p, z, 3.3333334327e-01f);
     const float r = __builtin_fmaf(-u, z * p, u);
     return red ? 0.78539816f + r : r;
@@ -954,26 +952,27 @@ __device__ int ransac_plane_wg(const PTS &pts, int iters, double thr, uint32_t s
             for (int u = 0; u < RS_PU; u++) pts.getf(min(i0 + 64 * u, n - 1), x[u], y[u], z[u]);
 #pragma unroll
             for (int u = 0; u < RS_PU; u++) {
-                const bool in = i0 + 64 * u < n;
+                // past the end: the point (inf, y, z) -- inf or NaN on every plane, never an inlier (no per-lane `in` mask)
+                const float xq = i0 + 64 * u < n ? x[u] : __builtin_inff();
                 // two hypotheses per packed-fp32 instruction (v_pk_mul_f32 / v_pk_add_f32: each half rounds like the scalar
                 // operation, so this is plane_inlier() twice)
-                const rs_v2f xx = {x[u], x[u]}, yy = {y[u], y[u]}, zz = {z[u], z[u]};
+                const rs_v2f xx = {xq, xq}, yy = {y[u], y[u]}, zz = {z[u], z[u]};
 #pragma unroll
                 for (int q = 0; q + 1 < RS_HPW; q += 2) {
                     const rs_v2f a = {pf[q][0], pf[q + 1][0]}, b2 = {pf[q][1], pf[q + 1][1]}, c2 = {pf[q][2], pf[q + 1][2]},
                                  d2 = {pf[q][3], pf[q + 1][3]};
                     const rs_v2f dd = ((a * xx + b2 * yy) + c2 * zz) + d2;
-                    cnt[q] += in && fabsf(dd.x) < thr_f;
-                    cnt[q + 1] += in && fabsf(dd.y) < thr_f;
+                    cnt[q] += (int)__popcll(__ballot(fabsf(dd.x) < thr_f));       // wave-uniform: v_cmp writes a lane mask, s_bcnt1 counts it
+                    cnt[q + 1] += (int)__popcll(__ballot(fabsf(dd.y) < thr_f));
                 }
-                if (RS_HPW & 1) cnt[RS_HPW - 1] += in && plane_inlier(pf[RS_HPW - 1], x[u], y[u], z[u], thr_f);
+                if (RS_HPW & 1) cnt[RS_HPW - 1] += (int)__popcll(__ballot(plane_inlier(pf[RS_HPW - 1], xq, y[u], z[u], thr_f)));
             }
         }
         int best_cnt = -1, best_h = 0x7fffffff;
 #pragma unroll
         for (int q = 0; q < RS_HPW; q++) {
             const int h = wave + q * (NTH / 64);
-            const int c = (int)dpp_sum_u32((uint32_t)cnt[q]);
+            const int c = cnt[q];
             if (h < iters && hyp[5 * h + 4] != 0.0f && c > best_cnt) { best_cnt = c; best_h = h; }
         }
         double best[4] = {0, 0, 1, 0};
@@ -1029,6 +1028,28 @@ __device__ int ransac_plane_wg(const PTS &pts, int iters, double thr, uint32_t s
     return wcnt;
 }
 
+// a / d for 32-bit unsigned a and a divisor d >= 2 that is the same for a whole frame: multiply-high by a 33-bit reciprocal
+// prepared once (the "branch-free" form of invariant division: q = mulhi(a, magic); ((a - q) >> 1) + q) >> shift; exact for
+// every a < 2^32) -- five VALU instructions instead of the ~20 of a hardware-assisted 32-bit division per use.
+struct UDiv32 { uint32_t magic, shift; };
+__device__ __forceinline__ UDiv32 udiv32_make(uint32_t d) {
+    UDiv32 u;
+    const uint32_t L = 31u - (uint32_t)__builtin_clz(d);
+    if ((d & (d - 1u)) == 0u) { u.magic = 0u; u.shift = L - 1u; return u; }
+    const unsigned long long num = (1ull << L) << 32;
+    uint32_t m = (uint32_t)(num / d);
+    const uint32_t rem = (uint32_t)(num - (unsigned long long)m * d);
+    m += m;
+    const uint32_t tw = rem + rem;
+    if (tw >= d || tw < rem) m += 1u;
+    u.magic = 1u + m; u.shift = L;
+    return u;
+}
+__device__ __forceinline__ uint32_t udiv32(uint32_t a, const UDiv32 u) {
+    const uint32_t q = __umulhi(a, u.magic);
+    return (((a - q) >> 1) + q) >> u.shift;
+}
+
 #define RS_CU 16  // pixels per lane in flight during the compaction pass
 __global__ __launch_bounds__(RS_THREADS) void ground_ransac_kernel(const float *__restrict__ ri_all,
                                                                    const float *__restrict__ tm, int P, float zthr,
@@ -1075,6 +1096,12 @@ __global__ __launch_bounds__(RS_THREADS) void ground_ransac_kernel(const float *
     RsPoints pts;
     pts.ri = ri; pts.tm = tm; pts.lds = nullptr; pts.n = P; pts.raw = raw;
     const bool small_prod = (unsigned long long)nc * (unsigned long long)max_pts < (1ull << 32);
+    UDiv32 by_nc = {0u, 0u};
+    if (nc > max_pts && small_prod) {   // (workgroup-uniform; one 64-bit division per frame, kept in scalar registers)
+        by_nc = udiv32_make((uint32_t)__builtin_amdgcn_readfirstlane(nc));
+        by_nc.magic = (uint32_t)__builtin_amdgcn_readfirstlane((int)by_nc.magic);
+        by_nc.shift = (uint32_t)__builtin_amdgcn_readfirstlane((int)by_nc.shift);
+    }
     if (nc >= min_pts) {
         int run = base;
         for (int p00 = w0; p00 < w1; p00 += 64 * RS_CU) {  // all loads of RS_CU steps are issued before any is used
@@ -1097,11 +1124,11 @@ __global__ __launch_bounds__(RS_THREADS) void ground_ransac_kernel(const float *
                     bool keep = true;
                     long long slot = i;
                     if (nc > max_pts) {
-                        if (small_prod) {  // i * max_pts < nc * max_pts < 2^32: 32-bit divisions (a 64-bit one costs ~10x)
+                        if (small_prod) {  // i * max_pts < nc * max_pts < 2^32: 32-bit quotients by the frame's invariant divisor
                             const uint32_t a = (uint32_t)i * (uint32_t)max_pts;
-                            const uint32_t sl = a / (uint32_t)nc;
+                            const uint32_t sl = udiv32(a, by_nc);
                             slot = sl;
-                            keep = (a + (uint32_t)max_pts) / (uint32_t)nc > sl;
+                            keep = udiv32(a + (uint32_t)max_pts, by_nc) > sl;
                         } else {
                             slot = (i * max_pts) / nc;
                             keep = ((i + 1) * max_pts) / nc > slot;
@@ -1956,6 +1983,8 @@ __global__ __launch_bounds__(256) void predict_quantize_kernel(const float *__re
             if (!RESIDUAL_ONLY && pred_out) st_at(pred_out, (uint32_t)gp * 4u, pr);
             const float res = (RESIDUAL_ONLY || residual_in) ? rin[j] : rv[j] - pr;                      // compress.py:106
             const float step = label_acc ? sacc[l] : acc;            // cpp_modules.cpp:404,419
+            // (a reciprocal-multiply + rndne screen in front of this quotient was measured in round 3: 61.0 M against 60.8 M
+            // wave instructions per batch -- the IEEE division is not where this kernel's instructions go)
             qv[j] = (int)roundf(res / step);                                          // cpp_modules.cpp:315
             lab[j] = (l == 1) ? -1 : l;                                               // label 1 is skipped (:314)
         }
