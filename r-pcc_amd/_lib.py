@@ -6,7 +6,8 @@ import os
 import torch  # imported first so the library binds to the HIP runtime torch already loaded
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "librpcc_hip.so")
+# RPCC_HIP_LIB: developer knob -- another build of the same ABI (an A/B of kernel variants inside one GPU session, tools_dev/ab.sh)
+LIB_PATH = os.environ.get("RPCC_HIP_LIB") or os.path.join(_HERE, "lib", "librpcc_hip.so")
 
 
 class Geom(C.Structure):

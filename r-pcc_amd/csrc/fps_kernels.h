@@ -483,17 +483,27 @@ __device__ __forceinline__ bool fps_tile_update(const FpsQuad &q, bool org_on, f
     }
     if (VEC && ch) st_at(reinterpret_cast<float4 *>(temp), (uint32_t)q.p0 * 4u, make_float4(nt[0], nt[1], nt[2], nt[3]));
     if (!with_box && __ballot(ch) == 0ull) return false;
+    // (Leaving the arg-max out when the point that holds the tile's maximum did not change -- the entry is then provably what it
+    // was -- was measured in round 3: the holder has the largest temp of the tile, so it is the FIRST point a centre in reach
+    // lowers; the test fired rarely, cost four compares per visit, and the kernel got 2 % slower.)
     if (with_box) fps_tile_box(x, y, z, cand, o.lo, o.hi);
     fps_tile_argmax(x, y, z, key, q.p0, o.wt, o.wx, o.wy, o.wz, o.widx);
     return true;
 }
 
+#ifndef FPS_VGPR_ATTR
+#define FPS_VGPR_ATTR
+#endif
 template <bool RANGE, bool VEC, int FPS_TT>
-__global__ __launch_bounds__(FPS_TT) void fps_regtab_kernel(const float *__restrict__ src, const float *__restrict__ rays,
+__global__ __launch_bounds__(FPS_TT) FPS_VGPR_ATTR void fps_regtab_kernel(const float *__restrict__ src, const float *__restrict__ rays,
                                                             float *__restrict__ temp, const int32_t *__restrict__ info,
                                                             FpsTiling g, int M, int flags, int32_t *__restrict__ out_idx,
                                                             float *__restrict__ out_cen, const float *__restrict__ tiletab) {
     constexpr int NW = FPS_TT / 64;
+    RPCC_SET_LAT_PRIO();
+#ifdef RPCC_DEVTRACE   // developer trace: wall clock (100 MHz) at the start and the end of every workgroup -> stamps[2048 + 2 b ..]
+    if (g_dbg_stamps != nullptr && threadIdx.x == 0) g_dbg_stamps[2048 + 2 * blockIdx.x] = (long long)wall_clock64();
+#endif
     __shared__ uint2 slot_k[2][NW];    // candidate of a wavefront: (value key, point index)
     __shared__ float4 slot_c[2][NW];   //                          its coordinates
     __shared__ int s_viol;
@@ -709,6 +719,9 @@ __global__ __launch_bounds__(FPS_TT) void fps_regtab_kernel(const float *__restr
         for (int i = 0; i < 8; i++) g_dbg_stamps[64 + wave * 8 + i] = p3_acc[i];
 #endif
     DBG_STAMP(16);
+#ifdef RPCC_DEVTRACE
+    if (g_dbg_stamps != nullptr && threadIdx.x == 0) g_dbg_stamps[2048 + 2 * blockIdx.x + 1] = (long long)wall_clock64();
+#endif
     if (RANGE && org_on && (flags & FPS_FLAG_FINALIZE_TEMP)) {
         __syncthreads();
         for (int p = tid; p < N; p += FPS_TT) {

@@ -248,7 +248,12 @@ __global__ __launch_bounds__(256) void project_finalize_kernel(uint32_t *__restr
 // BAND_PX pixels) takes the minimum of its band in LDS (ds_min_u32) while streaming the frame's records
 // from L2 / Infinity Cache.  Frames that contain a depth-0 point are left to the exact input-order
 // passes above.
+#ifndef BAND_PX
 #define BAND_PX 32768  // 128 KiB of LDS
+#endif
+#ifndef BAND_WG_PER_XCD
+#define BAND_WG_PER_XCD 32   // persistent workgroups per XCD (32 CUs): one per CU with 128 KiB bands
+#endif
 #ifndef BAND_THREADS
 #define BAND_THREADS 1024
 #endif
@@ -493,7 +498,10 @@ __device__ void project_fixup_frame(const float *__restrict__ xyz, const int64_t
 // band_wgs: the workgroups below that id are band workgroups; the B workgroups from there on (present when the launch has
 // points) run the exact input-order projection of the frames that hold a depth-0 point (project_fixup_frame) -- a no-op
 // for every other frame, and the band workgroups skip those frames -- so the fix-up costs no launch of its own.
-__global__ __launch_bounds__(BAND_THREADS) void project_band_kernel(const uint2 *__restrict__ pd,
+#ifndef BAND_VGPR_ATTR
+#define BAND_VGPR_ATTR
+#endif
+__global__ __launch_bounds__(BAND_THREADS) BAND_VGPR_ATTR void project_band_kernel(const uint2 *__restrict__ pd,
                                                                     const int64_t *__restrict__ offs, int64_t base,
                                                                     int B, int P, uint32_t *__restrict__ ri,
                                                                     const int32_t *__restrict__ flags,
@@ -502,6 +510,7 @@ __global__ __launch_bounds__(BAND_THREADS) void project_band_kernel(const uint2 
                                                                     int band_wgs, const float *__restrict__ xyz, rpcc_geom g,
                                                                     int32_t *__restrict__ lastz) {
     extern __shared__ __attribute__((aligned(16))) uint32_t band[];  // [BAND_PX]
+    RPCC_SET_LAT_PRIO();
     const int mark = flag_mark(epoch);
     if ((int)blockIdx.x >= band_wgs) {
         const int fb = (int)blockIdx.x - band_wgs;
@@ -713,7 +722,7 @@ static int launch_project(const float *xyz, const int64_t *offsets, int64_t tota
         if (zcnt && !cleared) HIP_TRY(hipMemsetAsync(zcnt, 0, (size_t)B * (RS_CHUNKS + 1) * 4, st));
         // persistent: at most one workgroup per CU (8 XCDs x 32), each walking over its XCD's (frame, band) items
         const int nbands = (P + BAND_PX - 1) / BAND_PX;
-        const int band_wgs = 8 * std::min(((B + 7) / 8) * nbands, std::max(32 / nbands, 1) * nbands);
+        const int band_wgs = 8 * std::min(((B + 7) / 8) * nbands, std::max(BAND_WG_PER_XCD / nbands, 1) * nbands);
         // + B workgroups for the exact input-order semantics of frames with depth-0 points (a no-op otherwise)
         project_band_kernel<<<band_wgs + (total > 0 ? B : 0), BAND_THREADS, BAND_PX * 4, st>>>(
             pd, offsets, base, B, P, rb, flags, tz_plane, -1.5f, rs_chunk_px(P), tz_plane ? zcnt : nullptr, epoch, band_wgs, xyz, g, lastz);
@@ -1060,6 +1069,7 @@ __global__ __launch_bounds__(RS_THREADS) void ground_ransac_kernel(const float *
                                                                    const int32_t *__restrict__ zcnt,
                                                                    const int64_t *__restrict__ frame_ids) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rs_smem[];
+    RPCC_SET_LAT_PRIO();
     double *sred = reinterpret_cast<double *>(rs_smem);          // [6*256]
     double *swin = sred + 6 * RS_NT;                             // [64] + [RS_MAX_HYP*4] fp64 hypotheses
     int *sbest = reinterpret_cast<int *>(swin + 64 + RS_MAX_HYP * 4);  // [32]
@@ -1715,6 +1725,13 @@ extern "C" size_t rpcc_workspace_bytes_general(int B, int P, int M, int64_t tota
     return slice_workspace_bytes(B, P, M, total_points) + 4096 + plane_extra_bytes(B, P, M);
 }
 
+// A lane owns FOUR CONSECUTIVE pixels of the tile (VEC: one 4-byte load of labels, one 16-byte load of ranges), a wavefront
+// 256 consecutive pixels.  Labels are spatially coherent, so the pixels that carry the label of the wavefront's first pixel
+// -- usually most of the 256 -- are aggregated once per wavefront (four compare masks counted in scalar registers, two DPP
+// sums for the range total), the others add themselves to LDS directly: integer sums, any order.  The fixed-point value of a
+// range r in [2^-5, 2^8) is read off its bit pattern: r * 2^28 = mantissa << (exponent + 5), an integer below 2^36, kept as
+// an 18-bit low part and a high part whose sums over a wavefront stay below 2^32.
+template <bool VEC>
 __global__ __launch_bounds__(256) void model_hist_kernel(const float *__restrict__ ri, const uint8_t *__restrict__ seg,
                                                          int P, int KP, int T, int64_t *__restrict__ sums,
                                                          int32_t *__restrict__ flags, uint32_t *__restrict__ hist) {
@@ -1722,62 +1739,85 @@ __global__ __launch_bounds__(256) void model_hist_kernel(const float *__restrict
     unsigned long long *ssum = reinterpret_cast<unsigned long long *>(smem_raw);  // [KP]
     uint32_t *scnt = reinterpret_cast<uint32_t *>(ssum + KP);                      // [KP]
     const int b = blockIdx.y, t = blockIdx.x, lane = threadIdx.x & 63;
-    bool inexact = false;
     const uint8_t *seg_b = seg + (int64_t)b * P;
     const float *ri_b = ri != nullptr ? ri + (int64_t)b * P : nullptr;
-    int lab_in[TILE / 256];
-    float r_in[TILE / 256];
+    const bool want_sum = ri != nullptr;
+    const int p0 = t * TILE + 4 * (int)threadIdx.x;
+    const int nval = min(max(P - p0, 0), 4);
+    int lab[4];
+    uint32_t rb[4];
+    // all loads first (unconditional, clamped)
+    if (VEC) {
+        const uint32_t q = (uint32_t)(nval > 0 ? p0 : 0);
+        const uint32_t l4 = ld_at(reinterpret_cast<const uint32_t *>(seg_b), q);
+        lab[0] = (int)(l4 & 255u); lab[1] = (int)((l4 >> 8) & 255u); lab[2] = (int)((l4 >> 16) & 255u); lab[3] = (int)(l4 >> 24);
+        if (want_sum) {
+            const uint4 r4 = ld_at(reinterpret_cast<const uint4 *>(ri_b), q * 4u);
+            rb[0] = r4.x; rb[1] = r4.y; rb[2] = r4.z; rb[3] = r4.w;
+        } else {
+            rb[0] = rb[1] = rb[2] = rb[3] = 0x3F800000u;
+        }
+    } else {
 #pragma unroll
-    for (int j = 0; j < TILE / 256; j++) {  // all loads of the tile first (unconditional, clamped): one latency, not four
-        const uint32_t gp = (uint32_t)min(t * TILE + j * 256 + (int)threadIdx.x, P - 1);  // offsets from the frame's bases
-        lab_in[j] = ld_at(seg_b, gp);
-        r_in[j] = ri != nullptr ? ld_at(ri_b, gp * 4u) : 1.0f;
+        for (int e = 0; e < 4; e++) {
+            const uint32_t gp = (uint32_t)min(p0 + e, P - 1);
+            lab[e] = ld_at(seg_b, gp);
+            rb[e] = want_sum ? f2u(ld_at(ri_b, gp * 4u)) : 0x3F800000u;
+        }
     }
     for (int k = threadIdx.x; k < KP; k += blockDim.x) { ssum[k] = 0ull; scnt[k] = 0u; }  // while the loads are in flight
     __syncthreads();
+    bool inexact = false;
+    int todo[4];
+    uint32_t lo[4], hi[4];
 #pragma unroll
-    for (int j = 0; j < TILE / 256; j++) {
-        const int p = t * TILE + j * 256 + threadIdx.x;
-        int todo = -1;
-        unsigned long long v = 0ull;
-        {
-            const int l = lab_in[j];
-            const float r = r_in[j];
-            if (p < P) {
-                todo = l;
-                if (todo >= 2 && ri != nullptr) {
-                    if (!(r >= 0.03125f && r < 256.0f)) inexact = true;
-                    else v = (unsigned long long)(long long)(r * 268435456.0f);  // exact: r * 2^28 < 2^36
-                }
+    for (int e = 0; e < 4; e++) {
+        todo[e] = e < nval ? lab[e] : -1;
+        lo[e] = hi[e] = 0u;
+        if (want_sum && todo[e] >= 2) {
+            const float r = u2f(rb[e]);
+            if (!(r >= 0.03125f && r < 256.0f)) {
+                inexact = true;
+            } else {   // r * 2^28, exact (see above): biased exponent 122 .. 134
+                const uint32_t sh = (rb[e] >> 23) - 122u, m = (rb[e] & 0x7FFFFFu) | 0x800000u;
+                lo[e] = (m << sh) & 0x3FFFFu;
+                hi[e] = m >> (18u - sh);
             }
         }
-        // labels are spatially coherent: aggregate per distinct label of the wavefront (ballot + DPP sums),
-        // one LDS atomic pair per (wavefront, label) instead of one per pixel
-        // (the label of the first pending lane -- usually the majority of the 64 pixels -- that way; the lanes of the
-        // other labels, few, add themselves to LDS directly: integer sums, any order)
-        {
-            const unsigned long long pending = __ballot(todo >= 0);
-            if (pending) {
-                const int leader = (int)__ffsll((long long)pending) - 1;
-                const int cur = __builtin_amdgcn_readlane(todo, leader);
-                const bool mine = todo == cur;
-                const unsigned long long same = __ballot(mine);
-                uint32_t lo = 0u, hi = 0u;
-                const bool sum = cur >= 2 && ri != nullptr;  // counts only (label scan): no sums
-                if (sum) {
-                    lo = dpp_sum_u32(mine ? (uint32_t)(v & 0x3FFFFull) : 0u);
-                    hi = dpp_sum_u32(mine ? (uint32_t)(v >> 18) : 0u);
-                }
-                if (lane == leader) {
-                    atomicAdd(&scnt[cur], (uint32_t)__popcll(same));
-                    if (sum) atomicAdd(&ssum[cur], (unsigned long long)lo + ((unsigned long long)hi << 18));
-                }
-                if (mine) todo = -1;
-            }
-            if (todo >= 0) {
-                atomicAdd(&scnt[todo], 1u);
-                if (todo >= 2 && ri != nullptr) atomicAdd(&ssum[todo], v);
-            }
+    }
+    // up to HIST_ROUNDS labels of the wavefront are aggregated (the label of the first pixel still pending: 256 consecutive
+    // pixels usually hold two to four labels); what is left adds itself to LDS pixel by pixel
+#define HIST_ROUNDS 3
+#pragma unroll 1
+    for (int round = 0; round < HIST_ROUNDS; round++) {
+        int first = todo[0] >= 0 ? 0 : todo[1] >= 0 ? 1 : todo[2] >= 0 ? 2 : todo[3] >= 0 ? 3 : -1;   // this lane's first pending element
+        const unsigned long long pending = __ballot(first >= 0);
+        if (!pending) break;
+        const int leader = (int)__ffsll((long long)pending) - 1;
+        const int mylab = first == 0 ? todo[0] : first == 1 ? todo[1] : first == 2 ? todo[2] : todo[3];
+        const int cur = __builtin_amdgcn_readlane(mylab, leader);
+        int ctot = 0;
+        uint32_t slo = 0u, shi = 0u;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const bool mine = todo[e] == cur;
+            ctot += (int)__popcll(__ballot(mine));
+            slo += mine ? lo[e] : 0u;
+            shi += mine ? hi[e] : 0u;
+            todo[e] = mine ? -1 : todo[e];
+        }
+        const bool sum = want_sum && cur >= 2;
+        if (sum) { slo = dpp_sum_u32(slo); shi = dpp_sum_u32(shi); }
+        if (lane == leader) {
+            atomicAdd(&scnt[cur], (uint32_t)ctot);
+            if (sum) atomicAdd(&ssum[cur], (unsigned long long)slo + ((unsigned long long)shi << 18));
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        if (todo[e] >= 0) {
+            atomicAdd(&scnt[todo[e]], 1u);
+            if (want_sum && todo[e] >= 2) atomicAdd(&ssum[todo[e]], (unsigned long long)lo[e] + ((unsigned long long)hi[e] << 18));
         }
     }
     if (__any(inexact) && lane == 0) flags[4 * b] = 1;
@@ -1786,6 +1826,12 @@ __global__ __launch_bounds__(256) void model_hist_kernel(const float *__restrict
         hist[((int64_t)b * T + t) * KP + k] = scnt[k];
         if (ssum[k]) atomicAdd(reinterpret_cast<unsigned long long *>(&sums[(int64_t)b * KP + k]), ssum[k]);
     }
+}
+static void launch_model_hist(const float *ri, const uint8_t *seg, int B, int P, int KP, int T, int64_t *sums, int32_t *flags,
+                              uint32_t *hist, hipStream_t st) {
+    const bool vec = (P & 3) == 0 && ((uintptr_t)seg & 3u) == 0 && (ri == nullptr || ((uintptr_t)ri & 15u) == 0);
+    if (vec) model_hist_kernel<true><<<dim3(T, B), 256, (size_t)KP * 12, st>>>(ri, seg, P, KP, T, sums, flags, hist);
+    else     model_hist_kernel<false><<<dim3(T, B), 256, (size_t)KP * 12, st>>>(ri, seg, P, KP, T, sums, flags, hist);
 }
 
 // One workgroup per frame: label totals, tile offsets, label bases, means, model rows.
@@ -1796,6 +1842,7 @@ __global__ __launch_bounds__(256) void model_scan_kernel(const float *__restrict
                                                          float *__restrict__ model, int32_t *__restrict__ counts,
                                                          int32_t *__restrict__ nnz) {
     extern __shared__ __attribute__((aligned(16))) uint32_t sh[];  // [T*KP] when it fits in LDS (use_lds), else unused
+    RPCC_SET_LAT_PRIO();
     __shared__ uint32_t tot[256];
     __shared__ uint32_t base[256];
     const int b = blockIdx.x, k = threadIdx.x, K = M + 2;
@@ -1872,7 +1919,7 @@ static int launch_point_model(const float *ri, const uint8_t *seg, const double 
     const int KP = kpad(M), T = ntiles(P);
     WsLayout L = ws_layout(ws, B, P, M);
     if (!cleared) HIP_TRY(hipMemsetAsync(L.sums, 0, (size_t)((char *)L.hist - (char *)L.sums), st));
-    model_hist_kernel<<<dim3(T, B), 256, (size_t)KP * 12, st>>>(ri, seg, P, KP, T, L.sums, L.flags, L.hist);
+    launch_model_hist(ri, seg, B, P, KP, T, L.sums, L.flags, L.hist, st);
     LAUNCH_CHECK();
     HIP_TRY(ensure_dyn_lds(reinterpret_cast<const void *>(&model_scan_kernel), 96 * 1024));
     model_scan_kernel<<<B, 256, scan_lds_bytes(P, M), st>>>(ri, seg, ground, P, M, KP, T, L.sums, L.flags, L.hist, model, counts, nnz);
@@ -2044,7 +2091,7 @@ extern "C" int rpcc_predict_quantize(const float *ri, const float *tm, const uin
     const int KP = kpad(M), T = ntiles(P);
     WsLayout L = ws_layout(ws, B, P, M);
     HIP_TRY(hipMemsetAsync(L.sums, 0, (size_t)((char *)L.hist - (char *)L.sums), st));
-    model_hist_kernel<<<dim3(T, B), 256, (size_t)KP * 12, st>>>(ri, seg, P, KP, T, L.sums, L.flags, L.hist);
+    launch_model_hist(ri, seg, B, P, KP, T, L.sums, L.flags, L.hist, st);
     LAUNCH_CHECK();
     HIP_TRY(ensure_dyn_lds(reinterpret_cast<const void *>(&model_scan_kernel), 96 * 1024));
     model_scan_kernel<<<B, 256, scan_lds_bytes(P, M), st>>>(ri, seg, nullptr, P, M, KP, T, L.sums, L.flags, L.hist, nullptr, nullptr, nnz);
@@ -2097,7 +2144,7 @@ extern "C" int rpcc_decode(const uint8_t *seg, const int16_t *q16, const float *
     const int KP = kpad(M), T = ntiles(P);
     WsLayout L = ws_layout(ws, B, P, M);
     HIP_TRY(hipMemsetAsync(L.sums, 0, (size_t)((char *)L.hist - (char *)L.sums), st));
-    model_hist_kernel<<<dim3(T, B), 256, (size_t)KP * 12, st>>>(nullptr, seg, P, KP, T, L.sums, L.flags, L.hist);
+    launch_model_hist(nullptr, seg, B, P, KP, T, L.sums, L.flags, L.hist, st);
     HIP_TRY(ensure_dyn_lds(reinterpret_cast<const void *>(&model_scan_kernel), 96 * 1024));
     model_scan_kernel<<<B, 256, scan_lds_bytes(P, M), st>>>(nullptr, seg, nullptr, P, M, KP, T, L.sums, L.flags, L.hist,
                                                             nullptr, nullptr, nullptr);
@@ -2212,7 +2259,7 @@ static int launch_label_scan(const uint8_t *seg, int B, int P, int M, int32_t *c
     const int KP = kpad(M), T = ntiles(P);
     WsLayout L = ws_layout(ws, B, P, M);
     if (!cleared) HIP_TRY(hipMemsetAsync(L.sums, 0, (size_t)((char *)L.hist - (char *)L.sums), st));
-    model_hist_kernel<<<dim3(T, B), 256, (size_t)KP * 12, st>>>(nullptr, seg, P, KP, T, L.sums, L.flags, L.hist);
+    launch_model_hist(nullptr, seg, B, P, KP, T, L.sums, L.flags, L.hist, st);
     HIP_TRY(ensure_dyn_lds(reinterpret_cast<const void *>(&model_scan_kernel), 96 * 1024));
     model_scan_kernel<<<B, 256, scan_lds_bytes(P, M), st>>>(nullptr, seg, nullptr, P, M, KP, T, L.sums, L.flags, L.hist,
                                                             nullptr, counts, nnz);

@@ -53,10 +53,15 @@ def one(job):
         cen = left[idx]
         if base is None:
             base = cen
-        same = np.array_equal(cen.view(np.uint32), base.view(np.uint32))
-        first = int(np.argmax((cen.view(np.uint32) != base.view(np.uint32)).any(1))) if not same else -1
-        nchg = int((cen.view(np.uint32) != base.view(np.uint32)).any(1).sum())
-        out["%d%s" % (f, "c" if t else "l")] = (same, first, nchg)
+        # a centre "changes" when its coordinates differ as VALUES; the empty pixels all back-project to (+-0, +-0, +-0) -- the sign
+        # of each zero follows the pixel's ray -- so two members of that class are the same point with different zero signs:
+        # every distance computed from them is identical (x - (+0) == x - (-0), the squares are +0), only the stored bits differ
+        dif = (cen != base).any(1)
+        same = not dif.any()
+        first = int(np.argmax(dif)) if not same else -1
+        nchg = int(dif.sum())
+        zsign = int(((cen.view(np.uint32) != base.view(np.uint32)).any(1) & ~dif).sum())    # same value, other zero signs
+        out["%d%s" % (f, "c" if t else "l")] = (same, first, nchg, zsign)
     return kind if kind == "example" else arg[0], out, int(left.shape[0])
 
 
@@ -76,10 +81,11 @@ def main():
         res = list(ex.map(one, jobs, chunksize=4))
     groups = {}
     for name, out, n_left in res:
-        g = groups.setdefault(name, dict(frames=0, n_left=0, modes={k: [0, 0, []] for k in out}))
+        g = groups.setdefault(name, dict(frames=0, n_left=0, modes={k: [0, 0, [], 0] for k in out}))
         g["frames"] += 1
         g["n_left"] += n_left
-        for k, (same, first, nchg) in out.items():
+        for k, (same, first, nchg, zsign) in out.items():
+            g["modes"][k][3] += 1 if zsign else 0
             if not same:
                 g["modes"][k][0] += 1
                 g["modes"][k][1] += nchg
@@ -92,7 +98,9 @@ def main():
     L = ["# FPS: sensitivity of the selected centres to the CUDA binary's unobservable degrees of freedom", "",
          "`python tools_dev/fps_sensitivity.py` (CPU, oracle/orc_fps_modes).  Per frame set and mode: frames in which at least one of the",
          "100 centre COORDINATES differs from the default mode's (un-fused distance, lowest index among equal values), the number of",
-         "centres that differ in those frames, and the earliest iteration at which a frame diverges.  The tie rule can only act on exactly",
+         "centres that differ in those frames, and the earliest iteration at which a frame diverges (coordinates compared as values; the",
+         "last column counts frames in which a centre of the origin class -- the empty pixels, all at (+-0, +-0, +-0) -- was taken from",
+         "another member: same point, other zero signs, no effect on any later stage).  The tie rule can only act on exactly",
          "equal distances between DISTINCT points (equal coordinates give equal centres whichever index wins); a contraction changes",
          "roundings, so two nearly equidistant candidates can swap, after which the two runs select different (equally valid) centre sets.", ""]
     for name in ("bench", "example", "Velodyne64E", "Velodyne32E", "VelodyneVLP16"):
@@ -100,16 +108,16 @@ def main():
             continue
         g = groups[name]
         L += ["## %s -- %d frame(s), %.0f candidates per frame" % (names[name], g["frames"], g["n_left"] / g["frames"]), "",
-              "| mode | frames with >= 1 changed centre | changed centres in those frames | earliest diverging iteration |", "|---|---|---|---|"]
+              "| mode | frames with >= 1 changed centre | changed centres in those frames | earliest diverging iteration | frames where only the zero signs of an origin centre differ |", "|---|---|---|---|---|"]
         for k in ("0l", "0c", "1l", "1c", "2l", "2c"):
-            c, n, firsts = g["modes"][k]
-            L.append("| %s | %d of %d | %d | %s |" % (label[k], c, g["frames"], n, min(firsts) if firsts else "-"))
+            c, n, firsts, zs = g["modes"][k]
+            L.append("| %s | %d of %d | %d | %s | %d |" % (label[k], c, g["frames"], n, min(firsts) if firsts else "-", zs))
         L.append("")
     text = "\n".join(L)
     print(text)
     if a.md:
         open(a.md, "w").write(text)
-        json.dump({k: {m: v[:2] for m, v in g["modes"].items()} | {"frames": g["frames"]} for k, g in groups.items()},
+        json.dump({k: {m: [v[0], v[1], v[3]] for m, v in g["modes"].items()} | {"frames": g["frames"]} for k, g in groups.items()},
                   open(a.md.replace(".md", ".json"), "w"), indent=1)
 
 

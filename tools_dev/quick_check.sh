@@ -4,7 +4,7 @@
 cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp; mkdir -p gpurun_out
 if [ "$1" != "notest" ]; then
   if [ -n "$1" ]; then timeout 1200 python3 -m pytest tests -m gpu -x -q -k "$1" 2>&1 | tail -4
-  else timeout 1200 python3 -m pytest tests -m gpu -x -q -n 4 2>&1 | tail -4; fi
+  else timeout 1200 python3 -m pytest tests -m gpu -x -q 2>&1 | tail -4; fi
 fi
 for i in 1 2; do timeout 300 python3 bench.py --no-secondary --cpu-sample 0 --steps 50 2>/dev/null | tail -1 | python3 -c "
 import sys, json
