@@ -28,6 +28,14 @@ extern "C" {
 #define RPCC_MAX_BATCH 65535   /* frames per call: the frame index is a grid dimension */
 #define RPCC_INFO_INTS 8       /* int32 per frame in the `info` arrays below */
 #define RPCC_FPS_BRUTEFORCE 1  /* flag: farthest point sampling by the one-pass-per-centre kernel (test reference) */
+/* The two things of the reference's CUDA binary that its source leaves to the compiler / the reduction tree (no golden vector
+ * exists for either; measured effect on the selected centres: profiles/r03_fps_mode_sensitivity.md -- none in 305 frames).
+ * Default (no flag): un-fused distance, lowest index among exactly equal values.  A mode flag runs the reference's own
+ * algorithm (one pass per centre), about 16x the time of the pruned kernel. */
+#define RPCC_FPS_FMA1 2        /* distance of sampling_gpu.cu:64 contracted as nvcc --fmad=true may: fma(dz,dz,fma(dx,dx,dy*dy)) */
+#define RPCC_FPS_FMA2 4        /* ... or fma(dz,dz,fma(dy,dy,dx*dx)) */
+#define RPCC_FPS_TIE_CUDA 8    /* winner among exactly equal values = the survivor of the kernel's shared-memory tree
+                                  (sampling_gpu.cu:16-21,55-69,74-134): smallest bit-reversed (k mod block), then smallest k */
 
 /* Re-entrancy: the library keeps no per-call state of its own (a cache of kernel attributes already set, behind a
  * mutex, is all it holds); every call works on the caller's buffers and stream, so host threads may call concurrently
@@ -115,13 +123,18 @@ int rpcc_fps_xyz(int B, int N, int M, const float *points, float *temp, int32_t 
  *   info     dev i32 [B,8]       from rpcc_ground_mask (first candidate = start point; first empty candidate)
  *   cen_pix  dev i32 [B,M]  out  pixel index of each centre
  *   centers  dev f32 [B,M,3] out cluster_centers
- *   flags    0, or RPCC_FPS_BRUTEFORCE for the one-pass-per-centre kernel (identical results)         */
+ *   flags    0, or RPCC_FPS_BRUTEFORCE for the one-pass-per-centre kernel (identical results), or the CUDA-binary modes
+ *            RPCC_FPS_FMA1 / RPCC_FPS_FMA2 / RPCC_FPS_TIE_CUDA (fps_table must be NULL then; k of the tie rule = rank of
+ *            the pixel among the candidates, block = opt_n_threads(n_left))                              */
 int rpcc_fps_range(const float *ri, const float *tm, float *temp, const int32_t *info, int B, int H, int W, int M,
                    int32_t *cen_pix, float *centers, int flags,
                    const void *fps_table /* from rpcc_ground_mask, or NULL */, void *stream);
 
 /* The brute-force form of rpcc_fps_xyz (one full pass per centre): the test reference of the tile-pruned kernels. */
 int rpcc_fps_xyz_bruteforce(int B, int N, int M, const float *points, float *temp, int32_t *idx, void *stream);
+/* rpcc_fps_xyz with flags: RPCC_FPS_BRUTEFORCE, RPCC_FPS_FMA1 / RPCC_FPS_FMA2, RPCC_FPS_TIE_CUDA (k = the point's index,
+ * block = opt_n_threads(N) as sampling_gpu.cu:9-13 computes it). */
+int rpcc_fps_xyz_mode(int B, int N, int M, const float *points, float *temp, int32_t *idx, int flags, void *stream);
 
 /* ---- a7: ground / cluster assignment + relabel ---------------------------------------------- *
  * replaces calc_plane_residual_depth, calc_cluster_residual_radius, concatenate + argmax and the
@@ -271,7 +284,7 @@ typedef struct rpcc_batch_io {
     int16_t *q16;            /* dev i16 [B,P] out */
     int32_t *nnz;            /* dev i32 [B] out */
     int32_t *info;           /* dev i32 [B,8] out */
-    int32_t flags;           /* 0 or RPCC_FPS_BRUTEFORCE */
+    int32_t flags;           /* 0, RPCC_FPS_BRUTEFORCE, or the CUDA-binary FPS modes RPCC_FPS_FMA1 / _FMA2 / _TIE_CUDA */
     void *timer;             /* rpcc_timer_create() handle or NULL: times this call's FPS launch (bench.py) */
     /* framework / model selection (tools/compress.py:109-124, cfgs/compressor.yaml: compress_framework, modeling_method) */
     int32_t model_method;    /* 0: point model (a8);  1: plane model (a9: rpcc_plane_model with plane_cos_cut, plane_seed,

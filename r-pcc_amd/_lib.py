@@ -32,6 +32,18 @@ class NonuniformCfg(C.Structure):
 
 INFO_INTS = 8          # RPCC_INFO_INTS
 FPS_BRUTEFORCE = 1     # RPCC_FPS_BRUTEFORCE
+FPS_FMA1, FPS_FMA2, FPS_TIE_CUDA = 2, 4, 8   # RPCC_FPS_FMA1 / RPCC_FPS_FMA2 / RPCC_FPS_TIE_CUDA
+
+
+def fps_mode_flags(fma=0, cuda_tie=False):
+    """The CUDA-binary FPS modes as flag bits: fma 0 / 1 / 2 (sampling_gpu.cu:64 un-fused / either nvcc contraction),
+    cuda_tie (the reduction tree's winner among equal values).  None -> the environment (RPCC_FPS_FMA, RPCC_FPS_TIE_CUDA)."""
+    if fma is None:
+        fma = int(os.environ.get("RPCC_FPS_FMA", "0"))
+    if cuda_tie is None:
+        cuda_tie = os.environ.get("RPCC_FPS_TIE_CUDA", "0") not in ("", "0")
+    assert fma in (0, 1, 2)
+    return (FPS_FMA1 if fma == 1 else FPS_FMA2 if fma == 2 else 0) | (FPS_TIE_CUDA if cuda_tie else 0)
 
 
 class RpccError(RuntimeError):
@@ -52,6 +64,7 @@ _SIGS = {
     "rpcc_fps_table_bytes": (C.c_size_t, [_I, _I, _I]),
     "rpcc_fps_xyz": (C.c_int, [_I, _I, _I, _VP, _VP, _VP, _VP]),
     "rpcc_fps_xyz_bruteforce": (C.c_int, [_I, _I, _I, _VP, _VP, _VP, _VP]),
+    "rpcc_fps_xyz_mode": (C.c_int, [_I, _I, _I, _VP, _VP, _VP, _I, _VP]),
     "rpcc_fps_range": (C.c_int, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP, _I, _VP, _VP]),
     "rpcc_assign": (C.c_int, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP]),
     "rpcc_point_model": (C.c_int, [_VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP]),

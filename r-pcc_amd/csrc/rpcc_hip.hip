@@ -5,6 +5,7 @@
 // and the roofline of every kernel: DESIGN.md.  Reference citations are relative to the reference
 // repository root.
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -1391,6 +1392,135 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_range_kernel(const float *__r
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The CUDA binary's two unobservable degrees of freedom as a selectable mode (measured sensitivity:
+// profiles/r03_fps_mode_sensitivity.md).  One 1024-thread workgroup per frame, one full pass per centre:
+//   fma      0 un-fused (the specification), 1 fma(dz,dz,fma(dx,dx,dy*dy)), 2 fma(dz,dz,fma(dy,dy,dx*dx)):
+//            nvcc's --fmad=true contractions of sampling_gpu.cu:64
+//   ctie     winner among EXACTLY equal values as the kernel's own reduction picks it (sampling_gpu.cu:16-21,55-69,74-134):
+//            the candidate with the smallest bit-reversed (k mod bs), then the smallest k, where k is the position in the
+//            COMPACTED candidate list the reference hands to the kernel (range image: rank among the pixels with temp >= 0;
+//            point list: the index) and bs = opt_n_threads(number of candidates) (:9-13; pow2_down: see fps_cuda_block)
+// A pass tracks per thread the best value, its lowest index and how many of the thread's points reach it; only when the
+// maximum is reached by more than one point does the tie pass run (ranks by a workgroup-wide prefix count in index order).
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fps_dist_mode(float dx, float dy, float dz, int fma) {
+    if (fma == 1) return __builtin_fmaf(dz, dz, __builtin_fmaf(dx, dx, dy * dy));
+    if (fma == 2) return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+    return (dx * dx + dy * dy) + dz * dz;
+}
+// opt_n_threads (sampling_gpu.cu:9-13): max(min(1 << (int)(log(n) / log(2)), 1024), 1), evaluated in double on the HOST by the
+// reference.  For n that is no power of two the truncation is floor(log2 n); for n = 2^p (p <= 10 is all that matters below
+// the cap) the quotient of the two logarithms may fall just below p -- pow2_down has bit p set when the host's libm does that.
+static uint32_t fps_pow2_down_mask() {
+    uint32_t m = 0;
+    for (int p = 1; p <= 10; p++)
+        if ((int)(log((double)(1 << p)) / log(2.0)) < p) m |= 1u << p;
+    return m;
+}
+__device__ __forceinline__ int fps_cuda_block(int n, uint32_t pow2_down) {
+    if (n < 1) return 1;
+    int p = 31 - __builtin_clz((unsigned)n);
+    if (n == (1 << p) && p <= 10 && ((pow2_down >> p) & 1u)) p -= 1;
+    const int b = 1 << p;
+    return b > 1024 ? 1024 : (b < 1 ? 1 : b);
+}
+template <bool RANGE>
+__global__ __launch_bounds__(FPS_THREADS) void fps_modes_kernel(const float *__restrict__ src, const float *__restrict__ rays,
+                                                                float *__restrict__ temp, const int32_t *__restrict__ info, int N,
+                                                                int M, int fma, int ctie, uint32_t pow2_down,
+                                                                int32_t *__restrict__ out_idx, float *__restrict__ out_cen) {
+    __shared__ unsigned long long sm[16];
+    __shared__ int scnt[16];
+    __shared__ int swin;
+    if (M <= 0) return;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    src += (int64_t)b * N * (RANGE ? 1 : 3);
+    temp += (int64_t)b * N;
+    out_idx += (int64_t)b * M;
+    if (out_cen) out_cen += (int64_t)b * M * 3;
+    int old = 0, ncand = N;
+    if (RANGE) { old = info[RPCC_INFO * b + 1]; if (old >= N) old = 0; ncand = info[RPCC_INFO * b + 0]; }
+    const int bs = fps_cuda_block(ncand, pow2_down);
+    int bits = 0;
+    while ((1 << bits) < bs) bits++;
+    for (int j = 0; j < M; j++) {
+        float x1, y1, z1;
+        fps_load_point<RANGE>(src, rays, old, x1, y1, z1);
+        if (tid == 0) {
+            out_idx[j] = old;
+            if (out_cen) { out_cen[3 * j] = x1; out_cen[3 * j + 1] = y1; out_cen[3 * j + 2] = z1; }
+        }
+        if (j == M - 1) break;
+        float best = -1.0f;
+        int besti = 0, cnt_eq = 0;
+        for (int k = tid; k < N; k += FPS_THREADS) {   // (a reference mode: scalar loads, one point per thread and step)
+            const float t = temp[k];
+            float x, y, z;
+            fps_load_point<RANGE>(src, rays, k, x, y, z);
+            const float d = fps_dist_mode(x - x1, y - y1, z - z1, fma);
+            const float d2 = fminf(d, t);      // t < 0 (not a candidate) stays negative: never above best = -1
+            if (d2 != t) temp[k] = d2;
+            if (d2 > best) { best = d2; besti = k; cnt_eq = 1; }
+            else if (d2 == best && t >= 0.0f) cnt_eq++;
+        }
+        // maximum, lowest index among the points that reach it, and how many reach it
+        const unsigned long long key = fps_key(best, (uint32_t)besti);
+        unsigned long long kmax = wave_max_u64(key);
+        __syncthreads();   // previous readers of sm / scnt are done; every temp store of this pass is visible afterwards
+        if (lane == 0) sm[wave] = kmax;
+        __syncthreads();
+        kmax = wave_max_u64(sm[lane & 15]);
+        const uint32_t vmax_hi = (uint32_t)(kmax >> 32);
+        int winner = (int)fps_key_index(kmax);
+        if (ctie && vmax_hi != 0u) {
+            const float vmax = u2f(vmax_hi - 1u);
+            int tot = wave_sum_i32(best == vmax ? cnt_eq : 0);
+            if (lane == 0) scnt[wave] = tot;
+            __syncthreads();
+            tot = wave_sum_i32(lane < 16 ? scnt[lane] : 0);
+            if (tot > 1) {   // (workgroup-uniform) exact ties at the maximum: the CUDA tree's survivor
+                unsigned long long bkey = ~0ull;
+                int bp = 0, running = 0;
+                for (int base = 0; base < N; base += FPS_THREADS) {
+                    const int p = base + tid;
+                    const float t = p < N ? temp[p] : -1.0f;
+                    const bool cand = RANGE ? t >= 0.0f : p < N;
+                    const unsigned long long m = __ballot(cand);
+                    const int below = __popcll(m & ((1ull << lane) - 1ull));
+                    __syncthreads();
+                    if (lane == 0) scnt[wave] = __popcll(m);
+                    __syncthreads();
+                    int wbase = 0, total = 0;
+                    for (int w = 0; w < 16; w++) { const int c = scnt[w]; if (w < wave) wbase += c; total += c; }
+                    const int rank = running + wbase + below;
+                    if (cand && t == vmax) {
+                        const uint32_t r = (uint32_t)rank % (uint32_t)bs;
+                        const uint32_t br = bits ? (__brev(r) >> (32 - bits)) : 0u;
+                        const unsigned long long k2 = ((unsigned long long)br << 32) | (uint32_t)rank;
+                        if (k2 < bkey) { bkey = k2; bp = p; }
+                    }
+                    running += total;
+                }
+                // minimum key of the workgroup and the pixel that holds it
+                unsigned long long kk = bkey;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) { const unsigned long long t2 = __shfl_xor(kk, o, RPCC_WAVE); kk = t2 < kk ? t2 : kk; }
+                __syncthreads();
+                if (lane == 0) sm[wave] = kk;
+                __syncthreads();
+                unsigned long long kmin = sm[lane & 15];
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) { const unsigned long long t2 = __shfl_xor(kmin, o, RPCC_WAVE); kmin = t2 < kmin ? t2 : kmin; }
+                if (bkey == kmin && bkey != ~0ull) swin = bp;   // ranks are distinct: exactly one thread
+                __syncthreads();
+                winner = swin;
+            }
+        }
+        old = winner;
+    }
+}
+
 template <bool RANGE>
 static int launch_fps_tiled(const float *src, const float *rays, float *temp, const int32_t *info, int B, const FpsTiling &g,
                             int M, int kflags, int32_t *idx, float *cen, const float *tiletab, bool vec, hipStream_t st) {
@@ -1421,9 +1551,19 @@ static int launch_fps_tiled(const float *src, const float *rays, float *temp, co
     return RPCC_OK;
 }
 
-static int fps_xyz_impl(int B, int N, int M, const float *points, float *temp, int32_t *idx, bool brute, hipStream_t st) {
+#define RPCC_FPS_MODE_BITS (RPCC_FPS_FMA1 | RPCC_FPS_FMA2 | RPCC_FPS_TIE_CUDA)
+static inline int fps_fma_of(int flags) { return (flags & RPCC_FPS_FMA1) ? 1 : (flags & RPCC_FPS_FMA2) ? 2 : 0; }
+
+static int fps_xyz_impl(int B, int N, int M, const float *points, float *temp, int32_t *idx, bool brute, hipStream_t st, int flags = 0) {
     ARG_TRY(B > 0 && B <= RPCC_MAX_BATCH && N > 0 && M >= 0 && points && temp && idx);
+    ARG_TRY(!((flags & RPCC_FPS_FMA1) && (flags & RPCC_FPS_FMA2)));
     if (M == 0) return RPCC_OK;
+    if (flags & RPCC_FPS_MODE_BITS) {   // CUDA-binary modes: the reference kernel, one pass per centre
+        fps_modes_kernel<false><<<B, FPS_THREADS, 0, st>>>(points, nullptr, temp, nullptr, N, M, fps_fma_of(flags),
+                                                           (flags & RPCC_FPS_TIE_CUDA) ? 1 : 0, fps_pow2_down_mask(), idx, nullptr);
+        LAUNCH_CHECK();
+        return RPCC_OK;
+    }
     const FpsTiling g = fps_tiling_list(N);
     if (!brute && g.T <= FPS_TILED_MAX_TILES && N < (1 << 30) / 3) {
         const bool vec = (N % 4 == 0) && aligned16(points) && aligned16(temp);
@@ -1439,6 +1579,9 @@ extern "C" int rpcc_fps_xyz(int B, int N, int M, const float *points, float *tem
 extern "C" int rpcc_fps_xyz_bruteforce(int B, int N, int M, const float *points, float *temp, int32_t *idx, void *stream) {
     return fps_xyz_impl(B, N, M, points, temp, idx, true, (hipStream_t)stream);
 }
+extern "C" int rpcc_fps_xyz_mode(int B, int N, int M, const float *points, float *temp, int32_t *idx, int flags, void *stream) {
+    return fps_xyz_impl(B, N, M, points, temp, idx, (flags & RPCC_FPS_BRUTEFORCE) != 0, (hipStream_t)stream, flags);
+}
 
 // flags: RPCC_FPS_BRUTEFORCE -> the one-pass-per-centre kernel; finalize_temp: temp is read by the caller afterwards
 static int launch_fps_range(const float *ri, const float *tm, float *temp, const int32_t *info, int B, int H, int W, int M,
@@ -1447,6 +1590,15 @@ static int launch_fps_range(const float *ri, const float *tm, float *temp, const
     const int P = H * W;
     const FpsTiling g = fps_tiling_range(H, W);
     const bool brute = (flags & RPCC_FPS_BRUTEFORCE) != 0;
+    if (flags & RPCC_FPS_MODE_BITS) {   // CUDA-binary modes (contraction / tree tie rule): the reference kernel, one pass per centre
+        if ((flags & RPCC_FPS_FMA1) && (flags & RPCC_FPS_FMA2)) return set_err(RPCC_ERR_ARG, "fps: RPCC_FPS_FMA1 and RPCC_FPS_FMA2 exclude each other%s%s");
+        if (tiletab != nullptr) return set_err(RPCC_ERR_ARG, "fps: the FPS table of rpcc_ground_mask holds un-fused first-pass distances; pass NULL with a mode flag%s%s");
+        FpsTimer tmr(st, timer);
+        fps_modes_kernel<true><<<B, FPS_THREADS, 0, st>>>(ri, tm, temp, info, P, M, fps_fma_of(flags), (flags & RPCC_FPS_TIE_CUDA) ? 1 : 0,
+                                                          fps_pow2_down_mask(), cen_pix, centers);
+        LAUNCH_CHECK();
+        return RPCC_OK;
+    }
     if (!brute && g.T <= FPS_TILED_MAX_TILES && P < (1 << 22)) {
         const bool vec = (W % 4 == 0) && aligned16(ri) && aligned16(temp) && aligned16(tm);
         FpsTimer tmr(st, timer);
@@ -2335,7 +2487,7 @@ static int run_batch(const rpcc_batch_io *io, int Bs, int64_t npts, rpcc_geom g,
     if (fit_ground &&
         (rc = launch_ground_ransac(ri, io->tm, Bs, P, (uint32_t)io->ground_seed, false, ground, nullptr, st, zcnt, io->frame_ids)))
         return rc;
-    const bool brute = (io->flags & RPCC_FPS_BRUTEFORCE) != 0;
+    const bool brute = (io->flags & (RPCC_FPS_BRUTEFORCE | RPCC_FPS_MODE_BITS)) != 0;   // a mode flag selects the reference kernel too
     const bool tiled = !brute && fps_tiling_range(g.H, g.W).T <= FPS_TILED_MAX_TILES;
     if ((rc = launch_ground_mask(ri, io->tm, ground, ground_threshold, Bs, g.H, g.W, temp, info,
                                  tiled ? tiletab : nullptr, st, false, true)))
@@ -2376,7 +2528,7 @@ extern "C" int rpcc_compress_batch(const rpcc_batch_io *io, int B, rpcc_geom g, 
             io->counts && io->q16 && io->nnz && io->info);
     const int P = g.H * g.W;
     // only the brute-force FPS kernel (16-byte loads at frame bases) needs P % 4 == 0; the tile-pruned one does not
-    ARG_TRY(P % 4 == 0 || (!(io->flags & RPCC_FPS_BRUTEFORCE) && fps_tiling_range(g.H, g.W).T <= FPS_TILED_MAX_TILES));
+    ARG_TRY(P % 4 == 0 || (io->flags & RPCC_FPS_MODE_BITS) || (!(io->flags & RPCC_FPS_BRUTEFORCE) && fps_tiling_range(g.H, g.W).T <= FPS_TILED_MAX_TILES));
     ARG_TRY(io->model_method == 0 || io->model_method == 1);
     if (io->nonuniform) {
         const rpcc_nonuniform_cfg *nu = io->nonuniform;

@@ -109,25 +109,33 @@ def ground_mask(ri, tm, ground, threshold, fps_table=False):
     return (temp, info, tab) if fps_table else (temp, info)
 
 
-def fps_xyz(points, npoint, temp=None, bruteforce=False):
+def fps_xyz(points, npoint, temp=None, bruteforce=False, fma=0, cuda_tie=False):
     """a6 on an explicit point list: furthest_point_sampling_wrapper(b,n,m,points,temp,idx)
     (ops/fps/src/sampling.cpp:24-37).  points f32 [B,N,3] -> idx i32 [B,npoint].  bruteforce=True: the
-    one-pass-per-centre kernel (test reference of the tile-pruned one; identical results)."""
+    one-pass-per-centre kernel (test reference of the tile-pruned one; identical results).  fma / cuda_tie: the CUDA
+    binary's contraction of sampling_gpu.cu:64 and its reduction tree's tie rule (_lib.fps_mode_flags; None = environment)."""
     B, N, _ = points.shape
     if temp is None:
         temp = torch.full((B, N), 1e10, dtype=torch.float32, device=_dev(points))
     idx = torch.empty((B, npoint), dtype=torch.int32, device=_dev(points))
+    mode = _lib.fps_mode_flags(fma, cuda_tie)
+    if mode:
+        check(_lib.lib().rpcc_fps_xyz_mode(B, N, npoint, ptr(points), ptr(temp), ptr(idx), mode, stream()))
+        return idx
     fn = _lib.lib().rpcc_fps_xyz_bruteforce if bruteforce else _lib.lib().rpcc_fps_xyz
     check(fn(B, N, npoint, ptr(points), ptr(temp), ptr(idx), stream()))
     return idx
 
 
-def fps_range(ri, tm, temp, info, M, fps_table=None, cen_pix=None, centers=None, bruteforce=False):
+def fps_range(ri, tm, temp, info, M, fps_table=None, cen_pix=None, centers=None, bruteforce=False, fma=0, cuda_tie=False):
+    """a6 on the range image.  fma / cuda_tie: the CUDA-binary modes (_lib.fps_mode_flags); they need temp / info from
+    ground_mask(..., fps_table=False)."""
     B, H, W = ri.shape
     cen_pix = torch.empty((B, M), dtype=torch.int32, device=_dev(ri)) if cen_pix is None else cen_pix
     centers = torch.empty((B, M, 3), dtype=torch.float32, device=_dev(ri)) if centers is None else centers
+    flags = (_lib.FPS_BRUTEFORCE if bruteforce else 0) | _lib.fps_mode_flags(fma, cuda_tie)
     check(_lib.lib().rpcc_fps_range(ptr(ri), ptr(tm), ptr(temp), ptr(info), B, H, W, M, ptr(cen_pix), ptr(centers),
-                                    _lib.FPS_BRUTEFORCE if bruteforce else 0, ptr(fps_table), stream()))
+                                    flags, ptr(fps_table), stream()))
     return cen_pix, centers
 
 
@@ -345,13 +353,16 @@ def nonuniform_cfg(acc, cfg=None):
 
 
 def compress_batch(xyz, offsets, tm, ground, buf, ground_threshold=0.1, acc=0.04, ground_seed=-1, frame_ids=None,
-                   fps_bruteforce=False, timer=None, model_method="point", angle_threshold=75, plane_seed=0, nonuniform=None):
+                   fps_bruteforce=False, timer=None, model_method="point", angle_threshold=75, plane_seed=0, nonuniform=None,
+                   fps_fma=None, fps_cuda_tie=None):
     """Fused a2..a13 for a batch, one call: FPS segmentation, point or plane model, uniform or non-uniform framework
     (tools/compress.py:93-125).  ground f64 [B,4]: injected models when ground_seed < 0, otherwise output of the seeded
     ground RANSAC run inside the call (frame b draws with ground_seed + frame_ids[b]; frame_ids: stable identities,
     e.g. utils.frame_identity(path); default the batch position).  model_method "plane": rpcc_plane_model's seeded fits
     (plane_seed, frame_ids) with the reference's angle validation.  nonuniform: a nonuniform_cfg() struct -> key points,
-    salience levels (buf.salience) and per-label steps; None = uniform framework with step `acc`."""
+    salience levels (buf.salience) and per-label steps; None = uniform framework with step `acc`.
+    fps_fma / fps_cuda_tie: the CUDA-binary FPS modes (_lib.fps_mode_flags); None = the environment variables RPCC_FPS_FMA
+    (0 / 1 / 2) and RPCC_FPS_TIE_CUDA, so every front-end (tools, pipeline, loader) honours them."""
     general = model_method != "point" or nonuniform is not None
     assert not general or buf.general, "BatchBuffers(..., general=True) is needed for the plane model / non-uniform framework"
     if xyz.shape[0] > buf.max_points:
@@ -364,7 +375,8 @@ def compress_batch(xyz, offsets, tm, ground, buf, ground_threshold=0.1, acc=0.04
                  int(ground_seed), ptr(fid).value if fid is not None else None, ptr(buf.ri).value, ptr(buf.seg).value,
                  ptr(buf.cen_pix).value, ptr(buf.centers).value, ptr(buf.model).value, ptr(buf.counts).value,
                  ptr(buf.q16).value, ptr(buf.nnz).value, ptr(buf.info).value,
-                 _lib.FPS_BRUTEFORCE if fps_bruteforce else 0, timer.h if timer is not None else None,
+                 (_lib.FPS_BRUTEFORCE if fps_bruteforce else 0) | _lib.fps_mode_flags(fps_fma, fps_cuda_tie),
+                 timer.h if timer is not None else None,
                  0 if model_method == "point" else 1, angle_cos_cut(angle_threshold) if model_method != "point" else 0.0,
                  int(plane_seed), C.addressof(nonuniform) if nonuniform is not None else None,
                  ptr(buf.salience).value if nonuniform is not None else None,
@@ -417,9 +429,14 @@ def compress_batch_general(xyz, offsets, tm, ground, buf, cc, fit_ground, frame_
     if fit_ground:
         g, _ = ground_ransac(buf.ri, tm, seed=cc.seed, frame_ids=frame_ids)
         ground.copy_(g)
-    temp, info, tab = ground_mask(buf.ri, tm, ground, cc.ground_threshold, fps_table=True)
-    buf.info.copy_(info)
-    _, centers = fps_range(buf.ri, tm, temp, info, M, fps_table=tab, cen_pix=buf.cen_pix, centers=buf.centers)
+    if _lib.fps_mode_flags(None, None):   # RPCC_FPS_FMA / RPCC_FPS_TIE_CUDA in the environment
+        temp, info = ground_mask(buf.ri, tm, ground, cc.ground_threshold, fps_table=False)
+        buf.info.copy_(info)
+        _, centers = fps_range(buf.ri, tm, temp, info, M, cen_pix=buf.cen_pix, centers=buf.centers, fma=None, cuda_tie=None)
+    else:
+        temp, info, tab = ground_mask(buf.ri, tm, ground, cc.ground_threshold, fps_table=True)
+        buf.info.copy_(info)
+        _, centers = fps_range(buf.ri, tm, temp, info, M, fps_table=tab, cen_pix=buf.cen_pix, centers=buf.centers)
     assign(buf.ri, tm, ground, centers, out=buf.seg)
     if cc.model_method == "point":
         model, counts = point_model(buf.ri, buf.seg, ground, M, ws=buf.ws)

@@ -60,8 +60,14 @@ class PointCloudSegment:
             ground = torch.from_numpy(np.asarray(gm, np.float64).reshape(1, 4)).to(self.device)
         else:
             ground, _ = ops.ground_ransac(ri, self._tm, seed=self.seed, frame_ids=[self.frame_id])
-        temp, info, tab = ops.ground_mask(ri, self._tm, ground, thr, fps_table=True)
-        cen_pix, centers = ops.fps_range(ri, self._tm, temp, info, M, fps_table=tab)
+        # RPCC_FPS_FMA / RPCC_FPS_TIE_CUDA (environment): the CUDA binary's contraction / tree tie rule (ops.fps_range)
+        from ._lib import fps_mode_flags
+        if fps_mode_flags(None, None):
+            temp, info = ops.ground_mask(ri, self._tm, ground, thr, fps_table=False)
+            cen_pix, centers = ops.fps_range(ri, self._tm, temp, info, M, fma=None, cuda_tie=None)
+        else:
+            temp, info, tab = ops.ground_mask(ri, self._tm, ground, thr, fps_table=True)
+            cen_pix, centers = ops.fps_range(ri, self._tm, temp, info, M, fps_table=tab)
         seg = ops.assign(ri, self._tm, ground, centers)
         self._cache = dict(ri=ri, ground=ground, seg=seg, M=M)
         return seg[0].cpu().numpy().astype(np.int64), ground[0].cpu().numpy()

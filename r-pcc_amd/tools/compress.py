@@ -52,7 +52,22 @@ def make_parser(datalist=False):
     p.add_argument("--eval", action="store_true", help="evaluate the reconstruction quality.")
     p.add_argument("--cpu", action="store_true", help="accepted for compatibility; the HIP path has no CPU mode.")
     p.add_argument("--seed", type=int, default=0, help="seed of the ground / plane RANSAC (this build).")
+    p.add_argument("--fps_fma", type=int, default=None, choices=(0, 1, 2),
+                   help="FPS distance as the reference's CUDA binary may contract it (0 un-fused = default, 1 fma(dz,dz,fma(dx,dx,dy*dy)), "
+                        "2 fma(dz,dz,fma(dy,dy,dx*dx))); sets RPCC_FPS_FMA.")
+    p.add_argument("--fps_tie_cuda", action="store_true",
+                   help="FPS ties between exactly equal distances resolved like the CUDA kernel's reduction tree (default: lowest "
+                        "index); sets RPCC_FPS_TIE_CUDA.")
     return p
+
+
+def apply_fps_mode(args):
+    """--fps_fma / --fps_tie_cuda -> the environment variables every FPS call of this build reads (ops.compress_batch,
+    segment_utils.PointCloudSegment.segment)."""
+    if getattr(args, "fps_fma", None) is not None:
+        os.environ["RPCC_FPS_FMA"] = str(args.fps_fma)
+    if getattr(args, "fps_tie_cuda", False):
+        os.environ["RPCC_FPS_TIE_CUDA"] = "1"
 
 
 def resolve_cfg(args):
@@ -86,6 +101,7 @@ def make_quantizer(cfg, accuracy, uniform):
 
 
 def compress(args):
+    apply_fps_mode(args)
     cfg, accuracy, segment_cfg, model_cfg, basic_compressor, uniform = resolve_cfg(args)
     dataset = build_dataset(lidar_type=args.lidar)
     model_num = segment_cfg["cluster_num"] + 1

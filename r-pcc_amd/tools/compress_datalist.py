@@ -24,7 +24,7 @@ from rpcc_amd.dataset import build_dataset  # noqa: E402
 from rpcc_amd.loader import StreamingCompressor  # noqa: E402
 from rpcc_amd.pipeline import BatchCompressor  # noqa: E402
 from rpcc_amd.sharding import RoundGather, shard_indices  # noqa: E402
-from rpcc_amd.tools.compress import make_parser, resolve_cfg  # noqa: E402
+from rpcc_amd.tools.compress import apply_fps_mode, make_parser, resolve_cfg  # noqa: E402
 from rpcc_amd.utils import frame_identity  # noqa: E402
 
 
@@ -88,6 +88,7 @@ def compress(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     device = "cuda:%d" % local
+    apply_fps_mode(args)
     cfg, accuracy, segment_cfg, model_cfg, basic_compressor, uniform = resolve_cfg(args)
     dataset = build_dataset(datalist=args.datalist, lidar_type=args.lidar, device=device)
     bc = BatchCompressor(dataset.PCTransformer, cluster_num=segment_cfg["cluster_num"], accuracy=accuracy / 2,

@@ -369,6 +369,68 @@ def test_assign_ground_screen_band(env):
     assert n_band > 100, "test inputs must contain pixels inside the screen's error band"
 
 
+@pytest.mark.parametrize("fma,cuda_tie", [(0, True), (1, False), (1, True), (2, False), (2, True)])
+def test_fps_cuda_binary_modes_equal_the_oracle(env, fma, cuda_tie):
+    """a6: the CUDA binary's contraction of sampling_gpu.cu:64 and its reduction tree's winner among equal values as selectable
+    modes (RPCC_FPS_FMA1 / _FMA2 / _TIE_CUDA): the kernel equals oracle.fps_modes (itself checked against a thread-by-thread
+    restatement of the CUDA kernel) -- on point lists made of ties, ragged sizes incl. powers of two, on a range image whose
+    constant range makes whole rings of pixels equidistant, on a synthetic sweep through the stage entries and through the fused
+    entry, and via the environment variables the front-ends read."""
+    torch, ops, orc, synth = env["torch"], env["ops"], env["orc"], env["synth"]
+    rng = np.random.default_rng(100 + 10 * fma + int(cuda_tie))
+    # (1) operator seam: lattices (ties everywhere), sizes around the block-size rule of opt_n_threads
+    for n, m in ((7, 5), (64, 20), (1000, 40), (1024, 33), (1025, 33), (2048, 64), (3000, 100), (20000, 60)):
+        pts = rng.integers(-4, 5, (2, n, 3)).astype(np.float32)
+        got = ops.fps_xyz(_to(env, pts), m, fma=fma, cuda_tie=cuda_tie).cpu().numpy()
+        for b in range(2):
+            assert np.array_equal(got[b], orc.fps_modes(pts[b], m, fma, cuda_tie)), (n, m, b)
+    pts = rng.normal(0, 20, (1, 30000, 3)).astype(np.float32)
+    assert np.array_equal(ops.fps_xyz(_to(env, pts), 100, fma=fma, cuda_tie=cuda_tie).cpu().numpy()[0], orc.fps_modes(pts[0], 100, fma, cuda_tie))
+    # (2) range images: constant range (rings of exactly equidistant pixels, empty pixels = one class of equal points) and a sweep
+    g, geom, tm = _geom(env, "VelodyneVLP16")
+    gd = orc.GEOMS["VelodyneVLP16"]
+    ri_c = np.full((g.H, g.W), 12.0, np.float32)
+    ri_c[rng.random(ri_c.shape) < 0.15] = 0
+    xyz = synth.make_frame(4242, g.H, g.W, vmax_deg=gd["vmax_deg"], vmin_deg=gd["vmin_deg"]).numpy()
+    ri_s = orc.project(xyz, g)
+    plane = np.array([0.01, -0.02, -0.9997, -1.72])
+    M = 40
+    for ri in (ri_c, ri_s):
+        cfg = dict(orc.DEFAULT_CFG, cluster_num=M, fps_fma=fma, fps_cuda_tie=cuda_tie)
+        want = orc.segment(ri, tm, plane, cfg)
+        d_ri, d_tm, d_pl = _to(env, ri[None]), _to(env, tm), _to(env, plane[None])
+        temp, info = ops.ground_mask(d_ri, d_tm, d_pl, 0.1, fps_table=False)
+        pix, cen = ops.fps_range(d_ri, d_tm, temp, info, M, fma=fma, cuda_tie=cuda_tie)
+        assert np.array_equal(pix[0].cpu().numpy(), want["fps_pix"])
+        assert _beq(cen[0].cpu().numpy(), want["centers"])
+        if cuda_tie:   # the tie rule is exercised: the default rule picks other pixels on the constant-range image
+            base = orc.segment(ri, tm, plane, dict(cfg, fps_cuda_tie=False))
+            if ri is ri_c:
+                assert not np.array_equal(base["fps_pix"], want["fps_pix"])
+    # (3) fused entry with the flags, and the environment variables of the front-ends
+    frames = [xyz, synth.make_frame(4243, g.H, g.W, vmax_deg=gd["vmax_deg"], vmin_deg=gd["vmin_deg"]).numpy()]
+    offs = np.zeros(3, np.int64)
+    offs[1:] = np.cumsum([f.shape[0] for f in frames])
+    ground = np.stack([plane, np.array([-0.01, 0.005, -0.9999, -1.75])])
+    buf = ops.BatchBuffers(2, geom, 100, env["dev"])
+    old = {k: os.environ.get(k) for k in ("RPCC_FPS_FMA", "RPCC_FPS_TIE_CUDA")}
+    try:
+        for via_env in (False, True):
+            if via_env:
+                os.environ["RPCC_FPS_FMA"], os.environ["RPCC_FPS_TIE_CUDA"] = str(fma), "1" if cuda_tie else "0"
+            ops.compress_batch(_to(env, np.concatenate(frames)), _to(env, offs), _to(env, tm), _to(env, ground), buf,
+                               fps_fma=None if via_env else fma, fps_cuda_tie=None if via_env else cuda_tie)
+            for i, f in enumerate(frames):
+                o = orc.compress_frame(f, g, tm, ground[i], dict(orc.DEFAULT_CFG, fps_fma=fma, fps_cuda_tie=cuda_tie))
+                assert np.array_equal(buf.cen_pix[i].cpu().numpy(), o["fps_pix"]), (via_env, i)
+                assert np.array_equal(buf.seg[i].cpu().numpy(), o["seg_idx"].astype(np.uint8))
+                n = int(buf.nnz[i])
+                assert n == o["q"].shape[0] and np.array_equal(buf.q16[i, :n].cpu().numpy(), o["q"].astype(np.int16))
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+
+
 def test_fps_tiled_equals_bruteforce(env):
     """The tile-pruned FPS kernels are exact: same indices, same centres AND the same final temp array
     (bit for bit) as the brute-force kernels, on range images and on explicit point lists."""

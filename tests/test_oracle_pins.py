@@ -84,3 +84,28 @@ def test_decoder_matches_reference(case, kind):
     assert (np.isnan(err) and np.isnan(exp)) or abs(err - exp) < 1e-12     # NaN: labels modelled by an injected NaN row
     if kind == "uniform_point":
         assert err <= 0.02 + 1e-5                                           # README.md:101-106
+
+
+def test_fps_modes_closed_form_equals_the_cuda_kernel_thread_by_thread():
+    """a6, the CUDA binary's unpinned degrees of freedom (oracle.fps_modes): the closed form of the reduction tree's tie rule
+    -- smallest bit-reversed (k mod block), then smallest k -- against the kernel restated thread by thread (strided scan per
+    thread with a strict '>', the shared-memory tree of `__update`, sampling_gpu.cu:16-21,55-69,74-134), on inputs made of
+    ties (integer lattices, duplicates), for the un-fused distance and both contractions; mode (0, lowest index) is orc.fps."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(7)
+    differs = 0
+    for trial in range(30):
+        n, m = int(rng.integers(3, 2500)), int(rng.integers(1, 40))
+        pts = rng.integers(-3, 4, (n, 3)).astype(np.float32)
+        for f in (0, 1, 2):
+            a = orc.fps_modes(pts, m, f, True)
+            assert np.array_equal(a, orc.fps_cuda_emulated(pts, m, f)), (trial, f)
+            differs += int(not np.array_equal(a, orc.fps_modes(pts, m, f, False)))
+        assert np.array_equal(orc.fps_modes(pts, m, 0, False), orc.fps(pts, m))
+    assert differs > 30          # the tie rule matters on these inputs
+    # opt_n_threads (sampling_gpu.cu:9-13)
+    assert [orc.lib().orc_fps_block_size(n) for n in (1, 2, 3, 7, 9, 1023, 1025, 5000, 100000)] == [1, 2, 2, 4, 8, 512, 1024, 1024, 1024]
+    # a contraction changes roundings: on generic points the three distance forms must at least run and agree on the first centres
+    pts = rng.normal(0, 10, (4000, 3)).astype(np.float32)
+    i0, i1, i2 = (orc.fps_modes(pts, 50, f, False) for f in (0, 1, 2))
+    assert i0[0] == i1[0] == i2[0] == 0 and i0[1] == i1[1] == i2[1]
