@@ -148,9 +148,9 @@ __device__ __forceinline__ void fps_tile_box(const float (&x)[4], const float (&
     hi[0] = hi[1] = hi[2] = -inf;
 #pragma unroll
     for (int e = 0; e < 4; e++) {
-        lo[0] = fminf(lo[0], cand[e] ? x[e] : inf); hi[0] = fmaxf(hi[0], cand[e] ? x[e] : -inf);
-        lo[1] = fminf(lo[1], cand[e] ? y[e] : inf); hi[1] = fmaxf(hi[1], cand[e] ? y[e] : -inf);
-        lo[2] = fminf(lo[2], cand[e] ? z[e] : inf); hi[2] = fmaxf(hi[2], cand[e] ? z[e] : -inf);
+        lo[0] = fmin_raw(lo[0], cand[e] ? x[e] : inf); hi[0] = fmax_raw(hi[0], cand[e] ? x[e] : -inf);
+        lo[1] = fmin_raw(lo[1], cand[e] ? y[e] : inf); hi[1] = fmax_raw(hi[1], cand[e] ? y[e] : -inf);
+        lo[2] = fmin_raw(lo[2], cand[e] ? z[e] : inf); hi[2] = fmax_raw(hi[2], cand[e] ? z[e] : -inf);
     }
     dpp_box6(lo[0], lo[1], lo[2], hi[0], hi[1], hi[2]);
 }
@@ -578,25 +578,35 @@ __global__ __launch_bounds__(FPS_TT) FPS_VGPR_ATTR void fps_regtab_kernel(const 
             tmax = o.wt; targ = o.widx; cx = o.wx; cy = o.wy; cz = o.wz;
         }
     };
-    // visits the tiles of the lanes in mask m, two at a time (all loads of a pair are in flight before either is used).
-    // (Software-pipelining the visits -- the next tile's loads in flight during the current update -- makes the kernel 7 %
-    // faster alone but needs 127 instead of 96 VGPRs, and the step with batches in flight gets 3 % slower: not kept.)
+    // visits the tiles of the lanes in mask m, FPS_VISIT = 2 at a time (all loads of a pair are in flight before either is used).
+    // Larger groups -- three or four tiles' loads in flight, so that the wavefront that owns most of the changed tiles pays one
+    // memory latency instead of two -- were measured in round 3 (with and without loads for absent tiles): 292 / 298 us alone
+    // against 273 us (139 instead of 96 VGPRs), and 7-11 % fewer frames/s with batches in flight.  (Round 2 had measured
+    // software-pipelined visits: 7 % faster alone, 3 % slower with batches in flight.)
+#ifndef FPS_VISIT
+#define FPS_VISIT 2
+#endif
     auto visit = [&](unsigned long long m, bool with_box) {
         bool viol = false;
         while (m) {
-            const int l0 = (int)__ffsll((long long)m) - 1;
-            m &= m - 1ull;
-            const bool two = m != 0ull;
-            const int l1 = two ? (int)__ffsll((long long)m) - 1 : l0;
-            m &= m - 1ull;
-            FpsQuad q0, q1;
-            locate(l0, q0);
-            fps_quad_load<RANGE, VEC>(src, rays, temp, q0);
-            locate(l1, q1);
-            fps_quad_load<RANGE, VEC>(src, rays, temp, q1);
-            FpsTileOut o;
-            if (fps_tile_update<RANGE, VEC>(q0, org_on, t_org0, c0, c1, c2, temp, with_box, o, viol)) store_entry(l0, o, with_box);
-            if (two && fps_tile_update<RANGE, VEC>(q1, org_on, t_org0, c0, c1, c2, temp, with_box, o, viol)) store_entry(l1, o, with_box);
+            int l[FPS_VISIT];
+            bool on[FPS_VISIT];
+            FpsQuad q[FPS_VISIT];
+#pragma unroll
+            for (int u = 0; u < FPS_VISIT; u++) {
+                on[u] = m != 0ull;
+                l[u] = on[u] ? (int)__ffsll((long long)m) - 1 : l[0];
+                m &= m - 1ull;     // (0 & anything stays 0)
+                if (u < 2 || on[u]) {   // (wave-uniform) the first pair unconditionally, the rest only when there is a tile
+                    locate(l[u], q[u]);
+                    fps_quad_load<RANGE, VEC>(src, rays, temp, q[u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < FPS_VISIT; u++) {
+                FpsTileOut o;
+                if (on[u] && fps_tile_update<RANGE, VEC>(q[u], org_on, t_org0, c0, c1, c2, temp, with_box, o, viol)) store_entry(l[u], o, with_box);
+            }
         }
         if (with_box && __ballot(viol) != 0ull && lane == 0) s_viol = 1;
     };

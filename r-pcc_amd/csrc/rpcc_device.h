@@ -107,6 +107,12 @@ __device__ __forceinline__ float atan2f_fdlibm(float y, float x) {
     }
 }
 
+// v_min_f32 / v_max_f32 as single instructions.  fminf / fmaxf on a value the compiler cannot prove to be no signalling
+// NaN (a select, a loop-carried value) are lowered to a canonicalising v_max_f32 x, x, x in front of the v_min / v_max; the
+// callers here feed coordinates and +-inf only (never NaN), for which the bare instruction gives the same result.
+__device__ __forceinline__ float fmin_raw(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float fmax_raw(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
 // ---------------------------------------------------------------------------------------------
 // Loads / stores at "wave-uniform base + 32-bit byte offset".  Written with an explicit unsigned byte offset so that the
 // compiler can use the scalar-base addressing mode (global_load v, v_offset, s[base]) instead of building a 64-bit

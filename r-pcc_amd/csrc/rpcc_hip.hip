@@ -1747,9 +1747,9 @@ __global__ __launch_bounds__(256) void assign_kernel(const float *__restrict__ r
         float lo0 = inf, lo1 = inf, lo2 = inf, hi0 = -inf, hi1 = -inf, hi2 = -inf;
 #pragma unroll
         for (int e = 0; e < ASSIGN_PX; e++) {
-            lo0 = fminf(lo0, live[e] ? x[e] : inf); hi0 = fmaxf(hi0, live[e] ? x[e] : -inf);
-            lo1 = fminf(lo1, live[e] ? y[e] : inf); hi1 = fmaxf(hi1, live[e] ? y[e] : -inf);
-            lo2 = fminf(lo2, live[e] ? z[e] : inf); hi2 = fmaxf(hi2, live[e] ? z[e] : -inf);
+            lo0 = fmin_raw(lo0, live[e] ? x[e] : inf); hi0 = fmax_raw(hi0, live[e] ? x[e] : -inf);
+            lo1 = fmin_raw(lo1, live[e] ? y[e] : inf); hi1 = fmax_raw(hi1, live[e] ? y[e] : -inf);
+            lo2 = fmin_raw(lo2, live[e] ? z[e] : inf); hi2 = fmax_raw(hi2, live[e] ? z[e] : -inf);
         }
         dpp_box6(lo0, lo1, lo2, hi0, hi1, hi2);
         // screen the centres: lane handles centres lane, lane+64, ...
@@ -1795,10 +1795,11 @@ __global__ __launch_bounds__(256) void assign_kernel(const float *__restrict__ r
                     for (int e1 = 0; e1 < 2; e1++) {
                         const int e = 2 * e2 + e1;
                         const float d2 = e1 ? dd.y : dd.x;
+                        // two smallest squared distances: m1 <= m2 always, so the new runner-up is the median of (m1, m2, d2)
                         const bool lt = d2 < m1[e];
-                        m2[e] = lt ? m1[e] : fminf(m2[e], d2);
+                        m2[e] = __builtin_amdgcn_fmed3f(m1[e], m2[e], d2);
                         k1[e] = lt ? k : k1[e];
-                        m1[e] = lt ? d2 : m1[e];
+                        m1[e] = lt ? d2 : m1[e];   // (the compare's mask again: fminf would add a canonicalising v_max)
                     }
                 }
             }
@@ -2112,7 +2113,14 @@ __device__ __forceinline__ void segment_prefix(uint32_t *segcnt, int SEGP, const
 
 // RESIDUAL_ONLY: the quantiser's own seam (uniform_quantize(seg_idx, residual, acc)): no prediction, so ri, tm and
 // model are not read at all (they may be NULL).
-template <bool RESIDUAL_ONLY>
+//
+// Round 3 layout: a lane owns FOUR CONSECUTIVE pixels of the tile (VEC: one 4-byte load of labels, 16-byte loads of range,
+// rays and residual), a wavefront 256 consecutive pixels, the workgroup's four wavefronts the four quarters of the tile in
+// order.  Output position of a pixel = tile offset of its label (model_scan_kernel) + pixels of that label in the wavefronts
+// before + in the lanes before (four compare masks per label of the wavefront, counted with mbcnt) + in the lane's own
+// earlier pixels.  The cross-wavefront prefix is four counters per label, one thread per label.  (Until round 3 the tile
+// was 16 segments of 64 pixels, one pixel per lane and pass: a 16 x K counter matrix, cleared and prefix-scanned per tile.)
+template <bool RESIDUAL_ONLY, bool VEC>
 __global__ __launch_bounds__(256) void predict_quantize_kernel(const float *__restrict__ ri, const float *__restrict__ tm,
                                                                const uint8_t *__restrict__ seg,
                                                                const float *__restrict__ model,
@@ -2125,10 +2133,9 @@ __global__ __launch_bounds__(256) void predict_quantize_kernel(const float *__re
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     // last kernel of a fused batch: the next call's projection flags get a new mark (BatchInit)
     if (epoch_inc && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *epoch_inc += 1;
-    float *smodel = reinterpret_cast<float *>(smem_raw);                 // [KP*4]
-    uint32_t *segcnt = reinterpret_cast<uint32_t *>(smodel + 4 * KP);    // [16][KP+1]
-    const int SEGP = KP + 1;
-    uint32_t *soff = segcnt + 16 * SEGP;                                 // [KP] this tile's output offsets per label
+    float4 *smodel = reinterpret_cast<float4 *>(smem_raw);               // [KP] model rows
+    uint32_t *wcnt = reinterpret_cast<uint32_t *>(smodel + KP);          // [4][KP]: pixels of label k in wavefront w -> its first output slot
+    uint32_t *soff = wcnt + 4 * KP;                                      // [KP] this tile's output offsets per label
     float *sacc = reinterpret_cast<float *>(soff + KP);                  // [KP] quantisation step per label (non-uniform)
     const int b = blockIdx.y, t = blockIdx.x, K = M + 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -2140,77 +2147,111 @@ __global__ __launch_bounds__(256) void predict_quantize_kernel(const float *__re
     if (q16) q16 += (int64_t)b * P;
     if (q32) q32 += (int64_t)b * P;
     if (label_acc) label_acc += (int64_t)b * K;
+    if (!RESIDUAL_ONLY) model += (int64_t)b * K * 4;
+    hist += ((int64_t)b * T + t) * KP;
+    const int p0 = t * TILE + 4 * (int)threadIdx.x;
+    const int nval = min(max(P - p0, 0), 4);
     // all global loads first, unconditional on clamped indices (a guarded load is waited for on the spot)
     int lab[4];
-    float rv[4], t0[4], t1[4], t2[4], rin[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int p = min(t * TILE + j * 256 + (int)threadIdx.x, P - 1);
-        const uint32_t up = (uint32_t)p;  // byte offsets from wave-uniform bases (scalar-base addressing, P * 12 < 2^32)
-        lab[j] = ld_at(seg, up);
+    float rv[4], ray[12], rin[4];
+    if (VEC) {
+        const uint32_t q = (uint32_t)(nval > 0 ? p0 : 0);
+        const uint32_t l4 = ld_at(reinterpret_cast<const uint32_t *>(seg), q);
+        lab[0] = (int)(l4 & 255u); lab[1] = (int)((l4 >> 8) & 255u); lab[2] = (int)((l4 >> 16) & 255u); lab[3] = (int)(l4 >> 24);
         if (RESIDUAL_ONLY) {
-            rv[j] = t0[j] = t1[j] = t2[j] = 0.0f;
-            rin[j] = ld_at(residual_in, up * 4u);
+#pragma unroll
+            for (int e = 0; e < 4; e++) rv[e] = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 12; i++) ray[i] = 0.0f;
         } else {
-            rv[j] = ld_at(ri, up * 4u);
-            const f32x3 ray = ld_at(reinterpret_cast<const f32x3 *>(tm), up * 12u);
-            t0[j] = ray.x; t1[j] = ray.y; t2[j] = ray.z;
-            rin[j] = residual_in ? ld_at(residual_in, up * 4u) : 0.0f;
+            const float4 r4 = ld_at(reinterpret_cast<const float4 *>(ri), q * 4u);
+            rv[0] = r4.x; rv[1] = r4.y; rv[2] = r4.z; rv[3] = r4.w;
+            const float4 a = ld_at(reinterpret_cast<const float4 *>(tm), q * 12u), bq = ld_at(reinterpret_cast<const float4 *>(tm), q * 12u + 16u),
+                         c = ld_at(reinterpret_cast<const float4 *>(tm), q * 12u + 32u);
+            ray[0] = a.x; ray[1] = a.y; ray[2] = a.z; ray[3] = a.w; ray[4] = bq.x; ray[5] = bq.y; ray[6] = bq.z; ray[7] = bq.w;
+            ray[8] = c.x; ray[9] = c.y; ray[10] = c.z; ray[11] = c.w;
+        }
+        if (residual_in) {
+            const float4 x4 = ld_at(reinterpret_cast<const float4 *>(residual_in), q * 4u);
+            rin[0] = x4.x; rin[1] = x4.y; rin[2] = x4.z; rin[3] = x4.w;
+        } else {
+            rin[0] = rin[1] = rin[2] = rin[3] = 0.0f;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const uint32_t up = (uint32_t)min(p0 + e, P - 1);
+            lab[e] = ld_at(seg, up);
+            rv[e] = RESIDUAL_ONLY ? 0.0f : ld_at(ri, up * 4u);
+            if (RESIDUAL_ONLY) { ray[3 * e] = ray[3 * e + 1] = ray[3 * e + 2] = 0.0f; }
+            else { ray[3 * e] = ld_f32(tm, up * 12u); ray[3 * e + 1] = ld_f32(tm, up * 12u + 4u); ray[3 * e + 2] = ld_f32(tm, up * 12u + 8u); }
+            rin[e] = residual_in ? ld_at(residual_in, up * 4u) : 0.0f;
         }
     }
-    for (int i = threadIdx.x; i < 4 * K; i += 256) smodel[i] = RESIDUAL_ONLY ? 0.0f : model[(int64_t)b * K * 4 + i];
-    // staged with the first loads: read inside segment_prefix they cost a dependent global round trip per 16 labels
-    for (int i = threadIdx.x; i < K; i += 256) soff[i] = hist[((int64_t)b * T + t) * KP + i];
-    if (label_acc)  // staged like the model rows: read per pixel it is a dependent trip to memory behind the barrier
-        for (int i = threadIdx.x; i < K; i += 256) sacc[i] = label_acc[i];
-    for (int i = threadIdx.x; i < 16 * SEGP; i += 256) segcnt[i] = 0u;
+    // staging (K <= 256: one step each); model rows as 16-byte copies
+    if ((int)threadIdx.x < K) {
+        const uint32_t i = threadIdx.x;
+        smodel[i] = RESIDUAL_ONLY ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(model[4 * i], model[4 * i + 1], model[4 * i + 2], model[4 * i + 3]);
+        soff[i] = hist[i];
+        if (label_acc) sacc[i] = label_acc[i];
+        wcnt[i] = 0u; wcnt[KP + i] = 0u; wcnt[2 * KP + i] = 0u; wcnt[3 * KP + i] = 0u;
+    }
     __syncthreads();
-    int qv[4], rank[4];
+    int qv[4], rank[4], todo[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int p = t * TILE + j * 256 + threadIdx.x;
-        const int l = lab[j];
-        qv[j] = 0;
-        rank[j] = 0;
-        lab[j] = -1;
-        if (p < P) {
-            const int gp = p;
-            const float p0 = smodel[4 * l], p1 = smodel[4 * l + 1], p2 = smodel[4 * l + 2], p3 = smodel[4 * l + 3];
+    for (int e = 0; e < 4; e++) {
+        const int l = lab[e];
+        qv[e] = 0;
+        rank[e] = 0;
+        todo[e] = -1;
+        if (e < nval) {
+            const float4 pm = smodel[l];
             float pr;
-            if (p0 + p1 + p2 == 0.0f) pr = p3;                                        // cpp_modules.cpp:271-272
-            else pr = -p3 / (p0 * t0[j] + p1 * t1[j] + p2 * t2[j]);                    // :275-277
-            if (!RESIDUAL_ONLY && pred_out) st_at(pred_out, (uint32_t)gp * 4u, pr);
-            const float res = (RESIDUAL_ONLY || residual_in) ? rin[j] : rv[j] - pr;                      // compress.py:106
-            const float step = label_acc ? sacc[l] : acc;            // cpp_modules.cpp:404,419
-            // (a reciprocal-multiply + rndne screen in front of this quotient was measured in round 3: 61.0 M against 60.8 M
-            // wave instructions per batch -- the IEEE division is not where this kernel's instructions go)
-            qv[j] = (int)roundf(res / step);                                          // cpp_modules.cpp:315
-            lab[j] = (l == 1) ? -1 : l;                                               // label 1 is skipped (:314)
+            if (pm.x + pm.y + pm.z == 0.0f) pr = pm.w;                                          // cpp_modules.cpp:271-272
+            else pr = -pm.w / (pm.x * ray[3 * e] + pm.y * ray[3 * e + 1] + pm.z * ray[3 * e + 2]);  // :275-277
+            if (!RESIDUAL_ONLY && pred_out) st_at(pred_out, (uint32_t)(p0 + e) * 4u, pr);
+            const float res = (RESIDUAL_ONLY || residual_in) ? rin[e] : rv[e] - pr;            // compress.py:106
+            const float step = label_acc ? sacc[l] : acc;                                      // cpp_modules.cpp:404,419
+            qv[e] = (int)roundf(res / step);                                                    // cpp_modules.cpp:315
+            todo[e] = (l == 1) ? -1 : l;                                                        // label 1 is skipped (:314)
         }
-        // rank among equal labels inside this 64-pixel segment
-        int todo = lab[j];
-        while (true) {
-            const unsigned long long pending = __ballot(todo >= 0);
-            if (!pending) break;
-            const int leader = (int)__ffsll((long long)pending) - 1;
-            const int cur = __builtin_amdgcn_readlane(todo, leader);
-            const unsigned long long same = __ballot(todo == cur);
-            if (todo == cur) {
-                rank[j] = __popcll(same & ((1ull << lane) - 1ull));
-                if (lane == leader) segcnt[(j * 4 + wave) * SEGP + cur] = (uint32_t)__popcll(same);
-                todo = -1;
-            }
+        lab[e] = todo[e];
+    }
+    // rank among equal labels inside the wavefront's 256 pixels, one label of the wavefront per round
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    while (true) {
+        const int first = todo[0] >= 0 ? todo[0] : todo[1] >= 0 ? todo[1] : todo[2] >= 0 ? todo[2] : todo[3];   // -1: nothing pending
+        const unsigned long long pending = __ballot(first >= 0);
+        if (!pending) break;
+        const int leader = (int)__ffsll((long long)pending) - 1;
+        const int cur = __builtin_amdgcn_readlane(first, leader);
+        int below = 0, total = 0, own = 0;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const bool mine = todo[e] == cur;
+            const unsigned long long m = __ballot(mine);
+            below += (int)__popcll(m & lt);
+            total += (int)__popcll(m);
+            if (mine) { rank[e] = own; todo[e] = -1; }   // (lanes before are added below)
+            own += mine ? 1 : 0;
         }
+#pragma unroll
+        for (int e = 0; e < 4; e++) rank[e] += (lab[e] == cur) ? below : 0;
+        if (lane == leader) wcnt[wave * KP + cur] = (uint32_t)total;
     }
     __syncthreads();
-    segment_prefix(segcnt, SEGP, soff, K);
+    if ((int)threadIdx.x < K) {   // exclusive prefix over the four wavefronts, seeded with the tile's offset
+        const uint32_t i = threadIdx.x;
+        const uint32_t c0 = wcnt[i], c1 = wcnt[KP + i], c2 = wcnt[2 * KP + i], base = soff[i];
+        wcnt[i] = base; wcnt[KP + i] = base + c0; wcnt[2 * KP + i] = base + c0 + c1; wcnt[3 * KP + i] = base + c0 + c1 + c2;
+    }
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        if (lab[j] >= 0) {
-            const uint32_t o = segcnt[(j * 4 + wave) * SEGP + lab[j]] + rank[j];
-            if (q16) st_at(q16, o * 2u, (int16_t)qv[j]);  // astype(np.int16): two's-complement truncation
-            if (q32) st_at(q32, o * 4u, (int32_t)qv[j]);
+    for (int e = 0; e < 4; e++) {
+        if (lab[e] >= 0) {
+            const uint32_t o = wcnt[wave * KP + lab[e]] + (uint32_t)rank[e];
+            if (q16) st_at(q16, o * 2u, (int16_t)qv[e]);  // astype(np.int16): two's-complement truncation
+            if (q32) st_at(q32, o * 4u, (int32_t)qv[e]);
         }
     }
 }
@@ -2220,13 +2261,14 @@ static int launch_predict_quantize(const float *ri, const float *tm, const uint8
                                    int32_t *q32, float *pred, void *ws, hipStream_t st, int32_t *epoch_inc = nullptr) {
     const int KP = kpad(M), T = ntiles(P);
     WsLayout L = ws_layout(ws, B, P, M);
-    const size_t sh = (size_t)KP * 4 * 4 + (size_t)16 * (KP + 1) * 4 + (size_t)KP * 4 + (size_t)KP * 4;
-    if (residual_in && !pred)
-        predict_quantize_kernel<true><<<dim3(T, B), 256, sh, st>>>(ri, tm, seg, model, L.hist, acc, label_acc, residual_in, P,
-                                                                   M, KP, T, q16, q32, pred, epoch_inc);
-    else
-        predict_quantize_kernel<false><<<dim3(T, B), 256, sh, st>>>(ri, tm, seg, model, L.hist, acc, label_acc, residual_in,
-                                                                    P, M, KP, T, q16, q32, pred, epoch_inc);
+    const size_t sh = (size_t)KP * 16 + (size_t)4 * KP * 4 + (size_t)KP * 4 + (size_t)KP * 4;
+    const bool resid = residual_in && !pred;
+    const bool vec = (P & 3) == 0 && ((uintptr_t)seg & 3u) == 0 && (resid || (aligned16(ri) && aligned16(tm))) &&
+                     (!residual_in || aligned16(residual_in));
+#define PQ_LAUNCH(R_, V_) predict_quantize_kernel<R_, V_><<<dim3(T, B), 256, sh, st>>>(ri, tm, seg, model, L.hist, acc, label_acc, residual_in, P, M, KP, T, q16, q32, pred, epoch_inc)
+    if (resid) { if (vec) PQ_LAUNCH(true, true); else PQ_LAUNCH(true, false); }
+    else       { if (vec) PQ_LAUNCH(false, true); else PQ_LAUNCH(false, false); }
+#undef PQ_LAUNCH
     LAUNCH_CHECK();
     return RPCC_OK;
 }
