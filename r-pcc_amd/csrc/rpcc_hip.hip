@@ -1939,36 +1939,42 @@ __global__ __launch_bounds__(256) void model_hist_kernel(const float *__restrict
         }
     }
     // up to HIST_ROUNDS labels of the wavefront are aggregated (the label of the first pixel still pending: 256 consecutive
-    // pixels usually hold two to four labels); what is left adds itself to LDS pixel by pixel
+    // pixels hold four labels on average); what is left adds itself to LDS pixel by pixel.  The pending pixels are four lane
+    // masks in scalar registers (one per pixel slot), as in the quantiser.
+#ifndef HIST_ROUNDS
 #define HIST_ROUNDS 3
+#endif
+    unsigned long long pend[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) pend[e] = __ballot(todo[e] >= 0);
 #pragma unroll 1
-    for (int round = 0; round < HIST_ROUNDS; round++) {
-        int first = todo[0] >= 0 ? 0 : todo[1] >= 0 ? 1 : todo[2] >= 0 ? 2 : todo[3] >= 0 ? 3 : -1;   // this lane's first pending element
-        const unsigned long long pending = __ballot(first >= 0);
-        if (!pending) break;
-        const int leader = (int)__ffsll((long long)pending) - 1;
-        const int mylab = first == 0 ? todo[0] : first == 1 ? todo[1] : first == 2 ? todo[2] : todo[3];
-        const int cur = __builtin_amdgcn_readlane(mylab, leader);
+    for (int round = 0; round < HIST_ROUNDS && (pend[0] | pend[1] | pend[2] | pend[3]) != 0ull; round++) {
+        int cur;
+        if (pend[0])      cur = __builtin_amdgcn_readlane(todo[0], (int)__ffsll((long long)pend[0]) - 1);
+        else if (pend[1]) cur = __builtin_amdgcn_readlane(todo[1], (int)__ffsll((long long)pend[1]) - 1);
+        else if (pend[2]) cur = __builtin_amdgcn_readlane(todo[2], (int)__ffsll((long long)pend[2]) - 1);
+        else              cur = __builtin_amdgcn_readlane(todo[3], (int)__ffsll((long long)pend[3]) - 1);
         int ctot = 0;
         uint32_t slo = 0u, shi = 0u;
 #pragma unroll
         for (int e = 0; e < 4; e++) {
             const bool mine = todo[e] == cur;
-            ctot += (int)__popcll(__ballot(mine));
+            const unsigned long long m = __ballot(mine);
+            ctot += (int)__popcll(m);
+            pend[e] &= ~m;
             slo += mine ? lo[e] : 0u;
             shi += mine ? hi[e] : 0u;
-            todo[e] = mine ? -1 : todo[e];
         }
         const bool sum = want_sum && cur >= 2;
         if (sum) { slo = dpp_sum_u32(slo); shi = dpp_sum_u32(shi); }
-        if (lane == leader) {
+        if (lane == 0) {
             atomicAdd(&scnt[cur], (uint32_t)ctot);
             if (sum) atomicAdd(&ssum[cur], (unsigned long long)slo + ((unsigned long long)shi << 18));
         }
     }
 #pragma unroll
     for (int e = 0; e < 4; e++) {
-        if (todo[e] >= 0) {
+        if (pend[e] != 0ull && ((pend[e] >> lane) & 1ull)) {   // (first test wave-uniform: usually nothing is left)
             atomicAdd(&scnt[todo[e]], 1u);
             if (want_sum && todo[e] >= 2) atomicAdd(&ssum[todo[e]], (unsigned long long)lo[e] + ((unsigned long long)hi[e] << 18));
         }
@@ -2197,13 +2203,13 @@ __global__ __launch_bounds__(256) void predict_quantize_kernel(const float *__re
         wcnt[i] = 0u; wcnt[KP + i] = 0u; wcnt[2 * KP + i] = 0u; wcnt[3 * KP + i] = 0u;
     }
     __syncthreads();
-    int qv[4], rank[4], todo[4];
+    int qv[4], rank[4];
 #pragma unroll
     for (int e = 0; e < 4; e++) {
         const int l = lab[e];
+        int keep = -1;
         qv[e] = 0;
         rank[e] = 0;
-        todo[e] = -1;
         if (e < nval) {
             const float4 pm = smodel[l];
             float pr;
@@ -2213,31 +2219,41 @@ __global__ __launch_bounds__(256) void predict_quantize_kernel(const float *__re
             const float res = (RESIDUAL_ONLY || residual_in) ? rin[e] : rv[e] - pr;            // compress.py:106
             const float step = label_acc ? sacc[l] : acc;                                      // cpp_modules.cpp:404,419
             qv[e] = (int)roundf(res / step);                                                    // cpp_modules.cpp:315
-            todo[e] = (l == 1) ? -1 : l;                                                        // label 1 is skipped (:314)
+            keep = (l == 1) ? -1 : l;                                                           // label 1 is skipped (:314)
         }
-        lab[e] = todo[e];
+        lab[e] = keep;
     }
-    // rank among equal labels inside the wavefront's 256 pixels, one label of the wavefront per round
+    // rank among equal labels inside the wavefront's 256 pixels, one label of the wavefront per round.  Which pixels are still
+    // unranked is kept as four lane masks in SCALAR registers (one per pixel slot): a round takes the label of the first
+    // pending pixel of the lowest pending slot, and every pixel that carries it is ranked in that round, so a label compare
+    // alone finds the round's pixels -- no per-lane bookkeeping in vector registers.
     const unsigned long long lt = (1ull << lane) - 1ull;
-    while (true) {
-        const int first = todo[0] >= 0 ? todo[0] : todo[1] >= 0 ? todo[1] : todo[2] >= 0 ? todo[2] : todo[3];   // -1: nothing pending
-        const unsigned long long pending = __ballot(first >= 0);
-        if (!pending) break;
-        const int leader = (int)__ffsll((long long)pending) - 1;
-        const int cur = __builtin_amdgcn_readlane(first, leader);
-        int below = 0, total = 0, own = 0;
+    unsigned long long pend[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) pend[e] = __ballot(lab[e] >= 0);
+    while ((pend[0] | pend[1] | pend[2] | pend[3]) != 0ull) {
+        int cur;
+        if (pend[0])      cur = __builtin_amdgcn_readlane(lab[0], (int)__ffsll((long long)pend[0]) - 1);
+        else if (pend[1]) cur = __builtin_amdgcn_readlane(lab[1], (int)__ffsll((long long)pend[1]) - 1);
+        else if (pend[2]) cur = __builtin_amdgcn_readlane(lab[2], (int)__ffsll((long long)pend[2]) - 1);
+        else              cur = __builtin_amdgcn_readlane(lab[3], (int)__ffsll((long long)pend[3]) - 1);
+        unsigned long long m[4];
+        int below = 0, total = 0;
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-            const bool mine = todo[e] == cur;
-            const unsigned long long m = __ballot(mine);
-            below += (int)__popcll(m & lt);
-            total += (int)__popcll(m);
-            if (mine) { rank[e] = own; todo[e] = -1; }   // (lanes before are added below)
+            m[e] = __ballot(lab[e] == cur);
+            below += (int)__popcll(m[e] & lt);     // matching pixels in the lanes before (mbcnt)
+            total += (int)__popcll(m[e]);          // (scalar)
+            pend[e] &= ~m[e];
+        }
+        int own = below;                            // + matching pixels of this lane before slot e
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const bool mine = lab[e] == cur;
+            rank[e] = mine ? own : rank[e];
             own += mine ? 1 : 0;
         }
-#pragma unroll
-        for (int e = 0; e < 4; e++) rank[e] += (lab[e] == cur) ? below : 0;
-        if (lane == leader) wcnt[wave * KP + cur] = (uint32_t)total;
+        if (lane == 0) wcnt[wave * KP + cur] = (uint32_t)total;
     }
     __syncthreads();
     if ((int)threadIdx.x < K) {   // exclusive prefix over the four wavefronts, seeded with the tile's offset
