@@ -110,6 +110,9 @@ __device__ __forceinline__ float atan2f_fdlibm(float y, float x) {
 // v_min_f32 / v_max_f32 as single instructions.  fminf / fmaxf on a value the compiler cannot prove to be no signalling
 // NaN (a select, a loop-carried value) are lowered to a canonicalising v_max_f32 x, x, x in front of the v_min / v_max; the
 // callers here feed coordinates and +-inf only (never NaN), for which the bare instruction gives the same result.
+// CAUTION: the compiler's hazard recogniser does not look into inline assembly -- an operand produced by a transcendental
+// instruction (v_sqrt / v_rcp / ...) just before needs a wait state the compiler will not insert (found the hard way in the
+// pixel kernel, round 3).  Only use these on values that come from plain VALU arithmetic, selects or loads.
 __device__ __forceinline__ float fmin_raw(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float fmax_raw(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 

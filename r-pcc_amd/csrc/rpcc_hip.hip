@@ -313,13 +313,29 @@ __device__ __forceinline__ float fast_atan_pos(float mn, float mx) {
     return red ? 0.78539816f + r : r;
 }
 
+// Correctly rounded sqrtf for 2^-96 <= s < 2^127 (finite, normal result): the compiler's own expansion of sqrtf -- v_sqrt_f32 (1 ulp)
+// followed by the two residual tests s - (r -+ 1 ulp) r that pick the neighbour when it is the better rounding -- without the
+// rescaling of tiny arguments and the zero / inf selection in front and behind it (seven of its sixteen instructions), which
+// the caller's range test makes unnecessary.
+__device__ __forceinline__ float sqrt_rn_normal(float s) {
+    const float r = __builtin_amdgcn_sqrtf(s);
+    const float rd = u2f(f2u(r) - 1u), ru = u2f(f2u(r) + 1u);
+    const float ed = __builtin_fmaf(-rd, r, s), eu = __builtin_fmaf(-ru, r, s);
+    float q = ed <= 0.0f ? rd : r;
+    q = eu > 0.0f ? ru : q;
+    return q;
+}
+
 // -> true when pix is certainly the reference's pixel
 __device__ __forceinline__ bool project_point_fast(float x, float y, float z, const rpcc_geom g, const PixFastCfg c, int &pix,
                                                    float *colf_out = nullptr, float *rowf_out = nullptr) {
     const float ax = fabsf(x), ay = fabsf(y), az = fabsf(z);
-    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
-    // 2^-60 .. 2^60; false for NaN / inf / the origin (fmaxf drops a NaN operand, so every coordinate is tested itself)
-    bool ok = mx >= 8.7e-19f && ax <= 1.15e18f && ay <= 1.15e18f && az <= 1.15e18f;
+    // max / min of non-negative floats as unsigned integers (one instruction each; fmaxf / fminf on the loaded values would be
+    // preceded by a canonicalising v_max x, x).  A NaN orders above everything: mx is then NaN and `ok` false.
+    const float mx = u2f(max(f2u(ax), f2u(ay))), mn = u2f(min(f2u(ax), f2u(ay)));
+    // 2^-46 .. 2^60; false for NaN / inf / the origin (every coordinate is tested itself as well).  The
+    // lower bound also keeps x*x + y*y + z*z >= 2^-92 for sqrt_rn_normal() (the depth of a point that passes)
+    bool ok = mx >= 1.5e-14f && ax <= 1.15e18f && ay <= 1.15e18f && az <= 1.15e18f;
     float a = fast_atan_pos(mn, mx);
     a = ay > ax ? 1.57079633f - a : a;
     a = x < 0.0f ? 3.14159265f - a : a;
@@ -328,7 +344,7 @@ __device__ __forceinline__ bool project_point_fast(float x, float y, float z, co
     const float c0 = rintf(colf);
     ok = ok && fabsf(colf - c0) < c.ccol && c0 >= 1.0f && c0 <= (float)(g.W - 1);  // columns 0 / W (wrap) go the exact way
     const float rho = __builtin_amdgcn_sqrtf(__builtin_fmaf(x, x, y * y));
-    float e = fast_atan_pos(fminf(az, rho), fmaxf(az, rho));
+    float e = fast_atan_pos(u2f(min(f2u(az), f2u(rho))), u2f(max(f2u(az), f2u(rho))));   // (both >= 0 -- or NaN, then not `ok`)
     e = az > rho ? 1.57079633f - e : e;
     e = z < 0.0f ? -e : e;
     const float rowf = fminf(fmaxf((e - c.vmin) * c.krow, 0.0f), (float)(g.H - 1));  // the clamp of :455-458 first
@@ -406,11 +422,16 @@ __global__ __launch_bounds__(PIX_THREADS) void project_pix_kernel(const float *_
     const int64_t nchunks = (total + PIX_PPT * PIX_THREADS - 1) / (PIX_PPT * PIX_THREADS);
     for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
         float x[PIX_PPT], y[PIX_PPT], z[PIX_PPT];
+        // unconditional loads, all in flight: wave-uniform chunk base + 32-bit lane offsets; only the last chunk clamps its indices
+        const int64_t il0 = c * (PIX_PPT * PIX_THREADS);
+        const f32x3 *cb = reinterpret_cast<const f32x3 *>(xyz + 3 * (base + il0));
+        const uint32_t room = (uint32_t)min((int64_t)(PIX_PPT * PIX_THREADS), total - il0);   // points of this chunk (>= 1)
 #pragma unroll
-        for (int u = 0; u < PIX_PPT; u++) {  // unconditional (clamped) loads, all in flight
-            const int64_t il = (c * PIX_PPT + u) * PIX_THREADS + threadIdx.x;  // record index; point index = base + il
-            const int64_t i = base + (il < total ? il : total - 1);
-            x[u] = xyz[3 * i]; y[u] = xyz[3 * i + 1]; z[u] = xyz[3 * i + 2];
+        for (int u = 0; u < PIX_PPT; u++) {
+            uint32_t k = (uint32_t)(u * PIX_THREADS) + threadIdx.x;
+            if (room < (uint32_t)(PIX_PPT * PIX_THREADS)) k = min(k, room - 1u);   // (wave-uniform test)
+            const f32x3 p3 = ld_at(cb, k * 12u);
+            x[u] = p3.x; y[u] = p3.y; z[u] = p3.z;
         }
 #pragma unroll
         for (int u = 0; u < PIX_PPT; u++) {
@@ -418,8 +439,8 @@ __global__ __launch_bounds__(PIX_THREADS) void project_pix_kernel(const float *_
             bool slow = false;
             if (il < total) {
                 int pix;
-                if (cfg.on && project_point_fast(x[u], y[u], z[u], g, cfg, pix))
-                    pd[il] = make_uint2((uint32_t)pix, f2u(sqrtf(x[u] * x[u] + y[u] * y[u] + z[u] * z[u])));  // depth: :446
+                if (cfg.on && project_point_fast(x[u], y[u], z[u], g, cfg, pix))   // (2^-92 <= the sum < 2^122: sqrt_rn_normal == sqrtf)
+                    pd[il] = make_uint2((uint32_t)pix, f2u(sqrt_rn_normal(x[u] * x[u] + y[u] * y[u] + z[u] * z[u])));  // depth: :446
                 else
                     slow = true;
             }
