@@ -857,9 +857,10 @@ __global__ __launch_bounds__(256) void ground_mask_tab_kernel(float *__restrict_
             const unsigned long long mc = __ballot(cand), mz = __ballot(nz), mo = __ballot(cand && !nz);
             cnt += __popcll(mc);
             nzc += __popcll(mz);
-            // candidates of one element slot are not in index order across lanes of different rows: take the minimum
-            if (mc) first = min(first, cand ? q[k].p0 + e : P);
-            if (mo) forg = min(forg, (cand && !nz) ? q[k].p0 + e : P);
+            // inside a tile the lanes are in pixel order (lane = 8 * row + quad of the row), so the first set lane of a slot's
+            // mask holds the slot's lowest pixel: wave-uniform minima in scalar registers, no reduction at the end
+            if (mc) first = min(first, __builtin_amdgcn_readlane(q[k].p0, (int)__ffsll((long long)mc) - 1) + e);
+            if (mo) forg = min(forg, __builtin_amdgcn_readlane(q[k].p0, (int)__ffsll((long long)mo) - 1) + e);
         }
         if (VEC && q[k].nval > 0) {
             if (RAW) st_at(reinterpret_cast<float4 *>(ri_b), (uint32_t)q[k].p0 * 4u, make_float4(rr[0], rr[1], rr[2], rr[3]));
@@ -878,8 +879,6 @@ __global__ __launch_bounds__(256) void ground_mask_tab_kernel(float *__restrict_
             }
         }
     }
-    first = wave_min_i32(first);
-    forg = wave_min_i32(forg);
     if (lane == 0) { s_cnt[wave] = cnt; s_nz[wave] = nzc; s_first[wave] = first; s_forg[wave] = forg; }
     __syncthreads();
     if (threadIdx.x == 0) {

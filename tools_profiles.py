@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Build a committed profiles/ set from the raw rocprofv3 CSVs that tools_dev/round_profiles.sh left in gpurun_out/ (scratch).
-usage: tools_profiles.py <tag> [--config N] [--input] [--no-current]      e.g. r02_v3
+usage: tools_profiles.py <tag> [--config N] [--input] [--no-current] [--src DIR]      e.g. r03_v1 --src gpurun_out/c1
 Writes profiles/<tag>_{kernel_stats_serial,kernel_stats_pipelined}.md (+ _raw.csv), <tag>_pmc.md, the three bench lines,
 and (unless --no-current) profiles/pmc_current.json (pmc_current_c2.json for --config 2, ..._real.json for --input), which
 bench.py reads for roofline.traffic / valu_wave_insts when it runs that configuration."""
@@ -8,7 +8,8 @@ import collections, csv, json, os, sys
 tag = sys.argv[1]
 cfg = int(sys.argv[sys.argv.index("--config") + 1]) if "--config" in sys.argv else 1
 real = "--input" in sys.argv
-G, P = "gpurun_out", "profiles"
+G = sys.argv[sys.argv.index("--src") + 1] if "--src" in sys.argv else "gpurun_out"
+P = "profiles"
 SKIP = ('at::native', 'rocblas', 'rocclr', 'rocprim', 'hipcub', 'anonymous')
 short = lambda n: n.split('(')[0].replace('void ', '')
 
