@@ -436,14 +436,14 @@ __global__ __launch_bounds__(PIX_THREADS) void project_pix_kernel(const float *_
 #pragma unroll
         for (int u = 0; u < PIX_PPT; u++) {
             const int64_t il = (c * PIX_PPT + u) * PIX_THREADS + threadIdx.x;
-            bool slow = false;
-            if (il < total) {
-                int pix;
-                if (cfg.on && project_point_fast(x[u], y[u], z[u], g, cfg, pix))   // (2^-92 <= the sum < 2^122: sqrt_rn_normal == sqrtf)
-                    pd[il] = make_uint2((uint32_t)pix, f2u(sqrt_rn_normal(x[u] * x[u] + y[u] * y[u] + z[u] * z[u])));  // depth: :446
-                else
-                    slow = true;
-            }
+            // straight-line: the lane masks of `fast` / `slow` stay in scalar registers (a boolean set inside divergent branches is
+            // materialised in a VGPR and compared again for the ballot)
+            int pix;
+            const bool in = il < total;
+            const bool fast = project_point_fast(x[u], y[u], z[u], g, cfg, pix) && cfg.on && in;
+            const float depth = sqrt_rn_normal(x[u] * x[u] + y[u] * y[u] + z[u] * z[u]);   // :446 (2^-92 <= the sum < 2^122 when `fast`: == sqrtf)
+            if (fast) pd[il] = make_uint2((uint32_t)pix, f2u(depth));
+            const bool slow = in && !fast;
             const unsigned long long sm = __ballot(slow);
             if (sm) {
                 const int leader = (int)__ffsll((long long)sm) - 1;
