@@ -542,6 +542,58 @@ def run_feed(a, ctx, frames_total=8192):
             "bound": "host copy into pinned memory + PCIe H2D (12 B per point), not the kernels"}
 
 
+def run_mixed(a, ctx, per=85, reps=20):
+    """Secondary: configs[4]'s content on one GPU -- 64E / 32E / VLP16 sweeps (variable H x W) in one mixed batch, non-uniform
+    framework + plane model: the three geometry groups as batches on three streams (what pipeline.MixedBatchCompressor queues),
+    device part only.  Verified: labels, salience levels and quantised integers of the first frames of every group against the
+    oracle."""
+    import numpy as np
+    import torch
+    from oracle import oracle as orc
+    from rpcc_amd import dataset, synth
+    from rpcc_amd.pipeline import BatchCompressor
+    dev = ctx["dev"]
+    groups = []
+    for n in ("Velodyne64E", "Velodyne32E", "VelodyneVLP16"):
+        gd = orc.GEOMS[n]
+        T = dataset.build_dataset(lidar_type=n, device=str(dev)).PCTransformer
+        ids = list(range(3000, 3000 + per))
+        xyz, offs = synth.make_batch(ids, gd["H"], gd["W"], device=dev, vmax_deg=gd["vmax_deg"], vmin_deg=gd["vmin_deg"])
+        bc = BatchCompressor(T, accuracy=a.accuracy, uniform=False, model_method="plane", seed=1)
+        groups.append((n, gd, bc, xyz, offs, torch.as_tensor(np.asarray(ids, np.int64), device=dev), torch.cuda.Stream(device=dev)))
+    outs = {}
+    for n, gd, bc, xyz, offs, fid, st in groups:      # warm-up (per-stream allocator pools, first-use attributes)
+        with torch.cuda.stream(st):
+            outs[n] = bc.compress_device(xyz, offs, frame_ids=fid)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        for n, gd, bc, xyz, offs, fid, st in groups:
+            with torch.cuda.stream(st):
+                outs[n] = bc.compress_device(xyz, offs, frame_ids=fid)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    ok = True
+    for n, gd, bc, xyz, offs, fid, st in groups:
+        buf, g_fit, bits, seq, nseq, sal = outs[n]
+        g = orc.LidarGeom(**gd)
+        tm = orc.transform_map(g)
+        o_h = offs.cpu().numpy()
+        for i in range(2):
+            f = xyz[o_h[i]:o_h[i + 1]].cpu().numpy()
+            gm = orc.ground_model(orc.project(f, g), tm, seed=1 + 3000 + i)
+            o = orc.compress_frame(f, g, tm, gm, dict(orc.DEFAULT_CFG, accuracy=a.accuracy), uniform=False,
+                                   plane=dict(angle_deg=75, seed=1, frame=3000 + i))
+            nz = int(buf.nnz[i])
+            ok = ok and (np.array_equal(buf.seg[i].cpu().numpy(), o["seg_idx"].astype(np.uint8)) and nz == o["q"].shape[0] and
+                         np.array_equal(buf.q16[i, :nz].cpu().numpy(), o["q"].astype(np.int16)) and
+                         np.array_equal(sal[i, :o["salience"].shape[0]].cpu().numpy(), o["salience"].astype(np.uint8)))
+    n_frames = 3 * per
+    return {"what": "configs[4] on one GPU: %d + %d + %d sweeps of 64x2000 / 32x2250 / 16x1800 in one mixed batch, non-uniform + "
+                    "plane-model, the three geometry groups overlapped on three streams; device part" % (per, per, per),
+            "value": round(n_frames / dt, 1), "unit": "frames/s", "ms_per_mixed_batch": round(dt * 1e3, 3), "verified": bool(ok)}
+
+
 def run_secondary(a, ctx):
     """Driver-witnessed numbers beside the headline (outside its timed region, rank 0 at N=1): configs[2] as one fused
     call per batch on the KITTI-64E shape, the reference's example sweep replicated, and the datalist feed."""
@@ -551,10 +603,11 @@ def run_secondary(a, ctx):
     def brief(rec):
         return {k: rec[k] for k in ("value", "unit", "ms_per_step", "steps", "verified")} | {"workload": rec["config"]["workload"],
                                                                                              "verified_frames_per_slot": rec["config"]["verified_frames_per_slot"]}
-    try:
-        sec["feed"] = run_feed(a, ctx)
-    except Exception as e:  # noqa: BLE001
-        sec["feed"] = {"error": str(e).splitlines()[0][:300] if str(e) else repr(e)}
+    for name, fn in (("feed", run_feed), ("mixed_lidars", run_mixed)):
+        try:
+            sec[name] = fn(a, ctx)
+        except Exception as e:  # noqa: BLE001
+            sec[name] = {"error": str(e).splitlines()[0][:300] if str(e) else repr(e)}
     for name, kw in (("configs2_fused", dict(config=2, geom="64x2000", input=None)),
                      ("real_sweep", dict(config=1, geom=None, input=os.path.join(ROOT, "tests", "golden", "example_64E.npz")))):
         b = copy.copy(a)
