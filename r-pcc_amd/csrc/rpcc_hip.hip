@@ -2015,32 +2015,31 @@ static void launch_model_hist(const float *ri, const uint8_t *seg, int B, int P,
 }
 
 // One workgroup per frame: label totals, tile offsets, label bases, means, model rows.
+// Round 3: thread k walks label k's column of the tile x label table straight from global memory (the loads of consecutive
+// threads are consecutive words; SCAN_U tiles' loads in flight per thread) in two passes -- totals, then offsets with the label's
+// base added -- instead of staging the table in LDS (64 KB per workgroup for 64x2048: its footprint kept everything else off
+// the CU, and the 128 dependent LDS round trips of the in-LDS scan were most of the kernel's time).
+#define SCAN_U 16
 __global__ __launch_bounds__(256) void model_scan_kernel(const float *__restrict__ ri, const uint8_t *__restrict__ seg,
                                                          const double *__restrict__ ground, int P, int M, int KP, int T,
                                                          const int64_t *__restrict__ sums,
                                                          const int32_t *__restrict__ flags, uint32_t *__restrict__ hist,
                                                          float *__restrict__ model, int32_t *__restrict__ counts,
                                                          int32_t *__restrict__ nnz) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t sh[];  // [T*KP] when it fits in LDS (use_lds), else unused
     RPCC_SET_LAT_PRIO();
     __shared__ uint32_t tot[256];
     __shared__ uint32_t base[256];
     const int b = blockIdx.x, k = threadIdx.x, K = M + 2;
     uint32_t *gh = hist + (int64_t)b * T * KP;
-    const bool use_lds = (size_t)T * KP * 4 <= 96 * 1024;
-    uint32_t *h = use_lds ? sh : gh;
-    if (use_lds) {  // coalesced 16-byte copy in (KP is a multiple of 64); the per-label walks below then run at LDS latency
-        const uint4 *g4 = reinterpret_cast<const uint4 *>(gh);
-        uint4 *s4 = reinterpret_cast<uint4 *>(sh);
-        for (int i = threadIdx.x; i < T * KP / 4; i += blockDim.x) s4[i] = g4[i];
-        __syncthreads();
-    }
+    const uint32_t kp4 = (uint32_t)KP * 4u, k4 = (uint32_t)k * 4u;
     uint32_t total = 0;
     if (k < K) {
-        for (int t = 0; t < T; t++) {
-            const uint32_t c = h[(int64_t)t * KP + k];
-            h[(int64_t)t * KP + k] = total;  // exclusive prefix over tiles (label base added below)
-            total += c;
+        for (int t0 = 0; t0 < T; t0 += SCAN_U) {
+            uint32_t c[SCAN_U];
+#pragma unroll
+            for (int j = 0; j < SCAN_U; j++) c[j] = ld_at(gh, (uint32_t)min(t0 + j, T - 1) * kp4 + k4);   // unconditional (clamped) loads
+#pragma unroll
+            for (int j = 0; j < SCAN_U; j++) total += t0 + j < T ? c[j] : 0u;
         }
     }
     tot[k] = (k < K && k != 1) ? total : 0u;
@@ -2052,15 +2051,17 @@ __global__ __launch_bounds__(256) void model_scan_kernel(const float *__restrict
     }
     __syncthreads();
     if (k < K) {
-        const uint32_t bs = base[k];
-        for (int t = 0; t < T; t++) h[(int64_t)t * KP + k] += bs;
+        uint32_t run = base[k];   // exclusive prefix over tiles, seeded with the label's base
+        for (int t0 = 0; t0 < T; t0 += SCAN_U) {
+            uint32_t c[SCAN_U];
+#pragma unroll
+            for (int j = 0; j < SCAN_U; j++) c[j] = ld_at(gh, (uint32_t)min(t0 + j, T - 1) * kp4 + k4);
+#pragma unroll
+            for (int j = 0; j < SCAN_U; j++) {
+                if (t0 + j < T) { st_at(gh, (uint32_t)(t0 + j) * kp4 + k4, run); run += c[j]; }
+            }
+        }
         if (counts) counts[(int64_t)b * K + k] = (int32_t)total;
-    }
-    if (use_lds) {
-        __syncthreads();
-        uint4 *g4 = reinterpret_cast<uint4 *>(gh);
-        const uint4 *s4 = reinterpret_cast<const uint4 *>(sh);
-        for (int i = threadIdx.x; i < T * KP / 4; i += blockDim.x) g4[i] = s4[i];
     }
     if (k < K && model != nullptr) {
         float *row = model + ((int64_t)b * K + k) * 4;
@@ -2089,10 +2090,7 @@ __global__ __launch_bounds__(256) void model_scan_kernel(const float *__restrict
     }
 }
 
-static size_t scan_lds_bytes(int P, int M) {
-    const size_t n = (size_t)ntiles(P) * kpad(M) * 4;
-    return n <= 96 * 1024 ? n : 0;
-}
+static size_t scan_lds_bytes(int, int) { return 0; }   // (the scan walks the table in global memory since round 3)
 
 static int launch_point_model(const float *ri, const uint8_t *seg, const double *ground, int B, int P, int M,
                               float *model, int32_t *counts, int32_t *nnz, void *ws, hipStream_t st, bool cleared = false) {
@@ -2101,7 +2099,6 @@ static int launch_point_model(const float *ri, const uint8_t *seg, const double 
     if (!cleared) HIP_TRY(hipMemsetAsync(L.sums, 0, (size_t)((char *)L.hist - (char *)L.sums), st));
     launch_model_hist(ri, seg, B, P, KP, T, L.sums, L.flags, L.hist, st);
     LAUNCH_CHECK();
-    HIP_TRY(ensure_dyn_lds(reinterpret_cast<const void *>(&model_scan_kernel), 96 * 1024));
     model_scan_kernel<<<B, 256, scan_lds_bytes(P, M), st>>>(ri, seg, ground, P, M, KP, T, L.sums, L.flags, L.hist, model, counts, nnz);
     LAUNCH_CHECK();
     return RPCC_OK;
@@ -2324,7 +2321,6 @@ extern "C" int rpcc_predict_quantize(const float *ri, const float *tm, const uin
     HIP_TRY(hipMemsetAsync(L.sums, 0, (size_t)((char *)L.hist - (char *)L.sums), st));
     launch_model_hist(ri, seg, B, P, KP, T, L.sums, L.flags, L.hist, st);
     LAUNCH_CHECK();
-    HIP_TRY(ensure_dyn_lds(reinterpret_cast<const void *>(&model_scan_kernel), 96 * 1024));
     model_scan_kernel<<<B, 256, scan_lds_bytes(P, M), st>>>(ri, seg, nullptr, P, M, KP, T, L.sums, L.flags, L.hist, nullptr, nullptr, nnz);
     LAUNCH_CHECK();
     return launch_predict_quantize(ri, tm, seg, model, acc, label_acc, residual_in, B, P, M, q16, q32, pred, ws, st);
@@ -2376,7 +2372,6 @@ extern "C" int rpcc_decode(const uint8_t *seg, const int16_t *q16, const float *
     WsLayout L = ws_layout(ws, B, P, M);
     HIP_TRY(hipMemsetAsync(L.sums, 0, (size_t)((char *)L.hist - (char *)L.sums), st));
     launch_model_hist(nullptr, seg, B, P, KP, T, L.sums, L.flags, L.hist, st);
-    HIP_TRY(ensure_dyn_lds(reinterpret_cast<const void *>(&model_scan_kernel), 96 * 1024));
     model_scan_kernel<<<B, 256, scan_lds_bytes(P, M), st>>>(nullptr, seg, nullptr, P, M, KP, T, L.sums, L.flags, L.hist,
                                                             nullptr, nullptr, nullptr);
     DecodeSteps steps;
@@ -2491,7 +2486,6 @@ static int launch_label_scan(const uint8_t *seg, int B, int P, int M, int32_t *c
     WsLayout L = ws_layout(ws, B, P, M);
     if (!cleared) HIP_TRY(hipMemsetAsync(L.sums, 0, (size_t)((char *)L.hist - (char *)L.sums), st));
     launch_model_hist(nullptr, seg, B, P, KP, T, L.sums, L.flags, L.hist, st);
-    HIP_TRY(ensure_dyn_lds(reinterpret_cast<const void *>(&model_scan_kernel), 96 * 1024));
     model_scan_kernel<<<B, 256, scan_lds_bytes(P, M), st>>>(nullptr, seg, nullptr, P, M, KP, T, L.sums, L.flags, L.hist,
                                                             nullptr, counts, nnz);
     LAUNCH_CHECK();
