@@ -2019,7 +2019,9 @@ static void launch_model_hist(const float *ri, const uint8_t *seg, int B, int P,
 // threads are consecutive words; SCAN_U tiles' loads in flight per thread) in two passes -- totals, then offsets with the label's
 // base added -- instead of staging the table in LDS (64 KB per workgroup for 64x2048: its footprint kept everything else off
 // the CU, and the 128 dependent LDS round trips of the in-LDS scan were most of the kernel's time).
-#define SCAN_U 16
+#ifndef SCAN_U
+#define SCAN_U 32
+#endif
 __global__ __launch_bounds__(256) void model_scan_kernel(const float *__restrict__ ri, const uint8_t *__restrict__ seg,
                                                          const double *__restrict__ ground, int P, int M, int KP, int T,
                                                          const int64_t *__restrict__ sums,
