@@ -206,6 +206,14 @@ __device__ __forceinline__ uint32_t dpp_sum_u32(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+// inclusive prefix sum over the 64 lanes (six v_add_u32_dpp); all lanes must be active
+__device__ __forceinline__ uint32_t dpp_scan_incl_u32(uint32_t v) {
+#define STEP_(ctrl_, rm_) v = v + (uint32_t)RPCC_DPP(0, v, ctrl_, rm_)
+    STEP_(0x111, 0xf); STEP_(0x112, 0xf); STEP_(0x114, 0xf); STEP_(0x118, 0xf); STEP_(0x142, 0xa); STEP_(0x143, 0xc);
+#undef STEP_
+    return v;
+}
+
 // Bounding box of a wavefront in ONE block of native float DPP instructions: three minima and three maxima reduced
 // together, the six chains interleaved step by step (five independent instructions between two dependent ones cover
 // the DPP read-after-write wait states, so no s_nop and no order-key conversion: 36 + 6 instructions instead of 6 x 13).

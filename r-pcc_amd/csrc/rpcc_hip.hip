@@ -376,32 +376,98 @@ struct BatchInit {
 };
 __device__ __forceinline__ int flag_mark(const int32_t *epoch) { return epoch ? *epoch + 1 : 1; }
 
-__device__ __forceinline__ void project_exact_record(const float *__restrict__ xyz, const int64_t *__restrict__ offs, int64_t base,
-                                                     int B, const rpcc_geom g, int64_t il, uint2 *__restrict__ pd,
-                                                     int32_t *__restrict__ flags, int mark) {
-    const int64_t i = base + il;
-    const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
-    const RowCol rc = project_point(x, y, z, g);
-    uint2 o = make_uint2(0xFFFFFFFFu, 0u);
-    if (fabsf(rc.depth) <= 3.402823466e+38f) {
-        if (rc.depth == 0.0f) {
-            int b = find_frame(offs, B, i);
-            flags[b] = mark; flags[B] = mark;
-        } else {
-            o = make_uint2((uint32_t)rc.pix, f2u(rc.depth));
-        }
-    }
-    pd[il] = o;
+// Records binned by (frame, band).  project_pix_kernel walks the points in chunks of 2048 that never cross a frame end (chunk ids:
+// frame f owns the ids from (offs[f] - base) / 2048 + f on, one more than it can need) and writes every point's (pixel, depth bits)
+// record straight into the share of its wavefront and chunk (a wavefront handles 512 points of a chunk): 512 slots per image band
+// (BAND_PX pixels), filled from slot 0 in the order the LDS counter of the band hands out -- no reservation in global memory, no
+// device atomics and no register copy of the records.  counts[chunk][wavefront][band] says how
+// many there are.  A band workgroup then streams only its own records instead of testing the frame's whole list (three of four
+// records were another band's).  The few points of the exact path (queued, projected later by whichever lanes drain the queue)
+// go to a second set of lists, one per frame and band pair with room for all the frame's points, reserved through cursors.
+// The order inside a list is whatever it is -- the band kernel takes minima, which do not care.
+#define PIX_PPT 8  // points per thread and chunk: loads in flight, and one pair of barriers per PIX_PPT * 256 points
+#define PIX_CH_SHIFT 11
+#define PIX_WAVES (PIX_THREADS / 64)
+#define SUB_CAP (PIX_PPT * PIX_THREADS)   // slots per chunk and band
+#define PIX_MAX_BANDS 8   // bands per frame the binned path handles (a power of two)
+#define BAND_ROUND 256     // shares (chunks) a band workgroup queues at a time
+#define BAND_SHIFT 15
+static_assert((1 << BAND_SHIFT) == BAND_PX, "BAND_PX is a power of two");
+static_assert((1 << PIX_CH_SHIFT) == PIX_PPT * PIX_THREADS, "chunk size");
+struct BandBins {
+    uint32_t *counts;    // [chunk ids][nbe]
+    uint2 *lists;        // [chunk ids][nbe][SUB_CAP]
+    uint32_t *ocursor;   // [B][nbe]   records of the exact path (cleared per launch)
+    uint2 *olists;       // frame f: nbe / 2 regions of cap_f = n_f rounded up to even slots from slot (nbe / 2) * (offs[f] - base + f)
+    int nbe;             // bands per frame, rounded up to even
+};
+__device__ __forceinline__ int64_t chunk_first(const int64_t *__restrict__ offs, int64_t base, int f) {
+    return ((offs[f] - base) >> PIX_CH_SHIFT) + f;
 }
 
-#define PIX_PPT 8  // points per thread and iteration: loads in flight, and one pair of barriers per PIX_PPT * 256 points
-__global__ __launch_bounds__(PIX_THREADS) void project_pix_kernel(const float *__restrict__ xyz, const int64_t *__restrict__ offs,
+// one record per lane, any mix of bins in the wavefront (the exact path's records): the lanes of one bin elect a leader, which
+// reserves the bin's slots with ONE atomic; all leaders' atomics are in flight together.  Every lane of the wavefront calls.
+// ostart / cap: the lane's pair region in olists; odd bands fill it from the top.
+__device__ __forceinline__ void bin_append_any(bool valid, uint32_t bin, int64_t ostart, uint32_t cap, uint32_t pix, uint32_t dep, const BandBins bb) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long pend = __ballot(valid);
+    uint32_t r = 0u, cnt = 0u;
+    int ldr = 0;
+    while (pend) {
+        const int l = (int)__ffsll((long long)pend) - 1;
+        const uint32_t kb = (uint32_t)__builtin_amdgcn_readlane((int)bin, l);
+        const bool mine = valid && bin == kb;
+        const unsigned long long m = __ballot(mine);
+        if (mine) { r = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); cnt = (uint32_t)__popcll(m); ldr = l; }
+        pend &= ~m;
+    }
+    uint32_t b0 = 0u;
+    if (valid && lane == ldr) b0 = atomicAdd(&bb.ocursor[bin], cnt);
+    b0 = (uint32_t)__shfl((int)b0, ldr, 64);
+    const uint32_t x = b0 + r;
+    if (valid) bb.olists[ostart + ((bin & 1u) ? cap - 1u - x : x)] = make_uint2(pix, dep);   // (nbe is even: bin & 1 == band & 1)
+}
+
+// the exact sequence for one point (every lane of the wavefront calls; `active` = the lane holds a queued point)
+__device__ __forceinline__ void project_exact_record(const float *__restrict__ xyz, const int64_t *__restrict__ offs, int64_t base,
+                                                     int B, const rpcc_geom g, bool active, int64_t il, const BandBins bb,
+                                                     int32_t *__restrict__ flags, int mark) {
+    bool valid = false;
+    uint32_t bin = 0u, cap = 0u, pix = 0u, dep = 0u;
+    int64_t ostart = 0;
+    if (active) {
+        const int64_t i = base + il;
+        const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+        const RowCol rc = project_point(x, y, z, g);
+        if (fabsf(rc.depth) <= 3.402823466e+38f) {
+            const int b = find_frame(offs, B, i);
+            if (rc.depth == 0.0f) {
+                flags[b] = mark; flags[B] = mark;
+            } else {
+                const int band = rc.pix >> BAND_SHIFT;
+                const int64_t o0 = offs[b] - base, o1 = offs[b + 1] - base;
+                valid = true; pix = (uint32_t)rc.pix; dep = f2u(rc.depth);
+                bin = (uint32_t)(b * bb.nbe + band);
+                cap = (uint32_t)((o1 - o0 + 1) & ~(int64_t)1);
+                ostart = (int64_t)(bb.nbe >> 1) * (o0 + b) + (int64_t)(band >> 1) * cap;
+            }
+        }
+    }
+    bin_append_any(valid, bin, ostart, cap, pix, dep, bb);
+}
+
+#ifndef PIX_VGPR_ATTR
+#define PIX_VGPR_ATTR
+#endif
+__global__ __launch_bounds__(PIX_THREADS) PIX_VGPR_ATTR void project_pix_kernel(const float *__restrict__ xyz, const int64_t *__restrict__ offs,
                                                                   int64_t total, int64_t base, int B, rpcc_geom g, PixFastCfg cfg,
-                                                                  uint2 *__restrict__ pd, int32_t *__restrict__ flags,
+                                                                  BandBins bb, int32_t *__restrict__ flags,
                                                                   const int32_t *__restrict__ epoch, BatchInit init) {
     __shared__ int64_t queue[(PIX_PPT + 1) * PIX_THREADS];
     __shared__ uint32_t qn;
+    __shared__ uint32_t bcnt[PIX_MAX_BANDS];   // records per band of the chunk so far
     if (threadIdx.x == 0) qn = 0u;
+    if (threadIdx.x < PIX_MAX_BANDS) bcnt[threadIdx.x] = 0u;
     const int mark = flag_mark(epoch);
     if (init.on) {   // the batch's small initialisations (grid-stride; nothing of it is read by this launch)
         const int nthr = gridDim.x * PIX_THREADS;
@@ -419,30 +485,59 @@ __global__ __launch_bounds__(PIX_THREADS) void project_pix_kernel(const float *_
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    const int64_t nchunks = (total + PIX_PPT * PIX_THREADS - 1) / (PIX_PPT * PIX_THREADS);
-    for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    const int wave = threadIdx.x >> 6;
+    const int64_t nck = (total >> PIX_CH_SHIFT) + B;   // chunk ids
+    // chunk id -> frame, first point (launch-relative), points; the ids of a workgroup ascend, so the search starts at the last frame
+    auto locate = [&](int64_t k, int &f, int64_t &first, int64_t &room) {
+        int lo = f, hi = B;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (chunk_first(offs, base, mid) <= k) lo = mid; else hi = mid;
+        }
+        f = lo;
+        const int64_t o0 = offs[f] - base, o1 = offs[f + 1] - base;
+        first = o0 + ((k - ((o0 >> PIX_CH_SHIFT) + f)) << PIX_CH_SHIFT);
+        room = min((int64_t)(PIX_PPT * PIX_THREADS), o1 - first);
+    };
+    int fnext = 0;
+    int64_t il_next = 0, room_next = 0;
+    if ((int64_t)blockIdx.x < nck) locate(blockIdx.x, fnext, il_next, room_next);
+    for (int64_t k = blockIdx.x; k < nck; k += gridDim.x) {
+        const int64_t il0 = il_next, room64 = room_next;
+        uint32_t *cnt_out = bb.counts + k * bb.nbe;
+        if (room64 <= 0) {   // (workgroup-uniform) an id the frame does not need
+            if ((int)threadIdx.x < bb.nbe) cnt_out[threadIdx.x] = 0u;
+            if (k + gridDim.x < nck) locate(k + gridDim.x, fnext, il_next, room_next);
+            continue;
+        }
         float x[PIX_PPT], y[PIX_PPT], z[PIX_PPT];
-        // unconditional loads, all in flight: wave-uniform chunk base + 32-bit lane offsets; only the last chunk clamps its indices
-        const int64_t il0 = c * (PIX_PPT * PIX_THREADS);
+        // unconditional loads, all in flight: wave-uniform chunk base + 32-bit lane offsets; only a frame's last chunk clamps its indices
         const f32x3 *cb = reinterpret_cast<const f32x3 *>(xyz + 3 * (base + il0));
-        const uint32_t room = (uint32_t)min((int64_t)(PIX_PPT * PIX_THREADS), total - il0);   // points of this chunk (>= 1)
+        const uint32_t room = (uint32_t)room64;   // points of this chunk (>= 1)
 #pragma unroll
         for (int u = 0; u < PIX_PPT; u++) {
-            uint32_t k = (uint32_t)(u * PIX_THREADS) + threadIdx.x;
-            if (room < (uint32_t)(PIX_PPT * PIX_THREADS)) k = min(k, room - 1u);   // (wave-uniform test)
-            const f32x3 p3 = ld_at(cb, k * 12u);
+            uint32_t i = (uint32_t)(u * PIX_THREADS) + threadIdx.x;
+            if (room < (uint32_t)(PIX_PPT * PIX_THREADS)) i = min(i, room - 1u);   // (wave-uniform test)
+            const f32x3 p3 = ld_at(cb, i * 12u);
             x[u] = p3.x; y[u] = p3.y; z[u] = p3.z;
         }
+        if (k + gridDim.x < nck) locate(k + gridDim.x, fnext, il_next, room_next);   // (scalar loads: their latency passes under the point loads)
+        uint2 *reg = bb.lists + k * (int64_t)(bb.nbe * SUB_CAP);   // the chunk's share of the lists
 #pragma unroll
         for (int u = 0; u < PIX_PPT; u++) {
-            const int64_t il = (c * PIX_PPT + u) * PIX_THREADS + threadIdx.x;
+            const uint32_t ci = (uint32_t)(u * PIX_THREADS) + threadIdx.x;
             // straight-line: the lane masks of `fast` / `slow` stay in scalar registers (a boolean set inside divergent branches is
             // materialised in a VGPR and compared again for the ballot)
             int pix;
-            const bool in = il < total;
+            const bool in = ci < room;
             const bool fast = project_point_fast(x[u], y[u], z[u], g, cfg, pix) && cfg.on && in;
             const float depth = sqrt_rn_normal(x[u] * x[u] + y[u] * y[u] + z[u] * z[u]);   // :446 (2^-92 <= the sum < 2^122 when `fast`: == sqrtf)
-            if (fast) pd[il] = make_uint2((uint32_t)pix, f2u(depth));
+            // the record's slot in its band's run: the workgroup's LDS counter of the band (ds_add_rtn: the LDS pipe ranks, not the VALU)
+            const uint32_t band = (uint32_t)pix >> BAND_SHIFT;
+            if (fast) {
+                const uint32_t xr = atomicAdd(&bcnt[band & (PIX_MAX_BANDS - 1)], 1u);
+                reg[band * SUB_CAP + xr] = make_uint2((uint32_t)pix, f2u(depth));
+            }
             const bool slow = in && !fast;
             const unsigned long long sm = __ballot(slow);
             if (sm) {
@@ -450,15 +545,16 @@ __global__ __launch_bounds__(PIX_THREADS) void project_pix_kernel(const float *_
                 uint32_t q0 = 0u;
                 if (lane == leader) q0 = atomicAdd(&qn, (uint32_t)__popcll(sm));
                 q0 = (uint32_t)__builtin_amdgcn_readlane((int)q0, leader);
-                if (slow) queue[q0 + __popcll(sm & lt)] = il;
+                if (slow) queue[q0 + __popcll(sm & lt)] = il0 + ci;
             }
         }
         __syncthreads();
         uint32_t n = qn;
+        if ((int)threadIdx.x < bb.nbe) { cnt_out[threadIdx.x] = bcnt[threadIdx.x]; bcnt[threadIdx.x] = 0u; }
         __syncthreads();
         if (n >= PIX_THREADS) {  // full workgroups of uncertain points: the exact sequence
             while (n >= PIX_THREADS) {
-                project_exact_record(xyz, offs, base, B, g, queue[n - PIX_THREADS + threadIdx.x], pd, flags, mark);
+                project_exact_record(xyz, offs, base, B, g, true, queue[n - PIX_THREADS + threadIdx.x], bb, flags, mark);
                 n -= PIX_THREADS;
             }
             __syncthreads();
@@ -467,7 +563,7 @@ __global__ __launch_bounds__(PIX_THREADS) void project_pix_kernel(const float *_
         }
     }
     const uint32_t n = qn;
-    if (threadIdx.x < n) project_exact_record(xyz, offs, base, B, g, queue[threadIdx.x], pd, flags, mark);
+    if ((threadIdx.x & ~63u) < n) project_exact_record(xyz, offs, base, B, g, threadIdx.x < n, queue[min(threadIdx.x, n - 1u)], bb, flags, mark);
 }
 
 // test hook: counts[0] = points the fast path is certain about, counts[1] = of those, points whose pixel differs
@@ -523,7 +619,7 @@ __device__ void project_fixup_frame(const float *__restrict__ xyz, const int64_t
 #ifndef BAND_VGPR_ATTR
 #define BAND_VGPR_ATTR
 #endif
-__global__ __launch_bounds__(BAND_THREADS) BAND_VGPR_ATTR void project_band_kernel(const uint2 *__restrict__ pd,
+__global__ __launch_bounds__(BAND_THREADS) BAND_VGPR_ATTR void project_band_kernel(const BandBins bb,
                                                                     const int64_t *__restrict__ offs, int64_t base,
                                                                     int B, int P, uint32_t *__restrict__ ri,
                                                                     const int32_t *__restrict__ flags,
@@ -532,6 +628,9 @@ __global__ __launch_bounds__(BAND_THREADS) BAND_VGPR_ATTR void project_band_kern
                                                                     int band_wgs, const float *__restrict__ xyz, rpcc_geom g,
                                                                     int32_t *__restrict__ lastz) {
     extern __shared__ __attribute__((aligned(16))) uint32_t band[];  // [BAND_PX]
+    __shared__ uint16_t ldq[BAND_ROUND * 16];   // queued loads: share of the round << 2 | 64-pair step
+    __shared__ uint16_t cntl[BAND_ROUND];          // records per share
+    __shared__ uint32_t nslots;
     RPCC_SET_LAT_PRIO();
     const int mark = flag_mark(epoch);
     if ((int)blockIdx.x >= band_wgs) {
@@ -552,10 +651,18 @@ __global__ __launch_bounds__(BAND_THREADS) BAND_VGPR_ATTR void project_band_kern
     __syncthreads();   // the previous item's LDS band and counters are no longer read
     // the three dependent scalars of this workgroup first: their latency passes while the LDS band is cleared
     const int flagged = flags[b] == mark;
-    const int64_t n0 = offs[b] - base;  // record indices of this frame
-    const int64_t n1 = offs[b + 1] - base;
+    const int64_t o0 = offs[b] - base, o1 = offs[b + 1] - base;
+    const uint32_t ocnt = bb.ocursor[b * bb.nbe + kband];        // records of the exact path
+    const int64_t c0 = (o0 >> PIX_CH_SHIFT) + b;                   // the frame's chunk ids: c0 .. (o1 >> 11) + b
+    const int S = (int)(((o1 >> PIX_CH_SHIFT) + b + 1) - c0);   // shares (one per chunk of the pixel kernel)
+    const int pairb = kband >> 1;
+    const uint32_t odd = (uint32_t)kband & 1u;
     const uint32_t band0 = (uint32_t)kband * BAND_PX;
     const uint32_t npx = min((uint32_t)BAND_PX, (uint32_t)P - band0);
+    // (issued before the band is cleared: the latency passes under the LDS stores)
+    uint32_t mycnt = 0u;
+    if ((int)threadIdx.x < min(S, BAND_ROUND) && !flagged) mycnt = min(bb.counts[(c0 + threadIdx.x) * bb.nbe + kband], (uint32_t)SUB_CAP);
+    if (threadIdx.x == 0) nslots = 0u;
     if ((npx & 3) == 0) {
         uint4 *b4 = reinterpret_cast<uint4 *>(band);
         for (uint32_t q = threadIdx.x; q < (npx >> 2); q += BAND_THREADS) b4[q] = make_uint4(RI_EMPTY, RI_EMPTY, RI_EMPTY, RI_EMPTY);
@@ -563,25 +670,56 @@ __global__ __launch_bounds__(BAND_THREADS) BAND_VGPR_ATTR void project_band_kern
         for (uint32_t p = threadIdx.x; p < npx; p += BAND_THREADS) band[p] = RI_EMPTY;
     }
     if (flagged) continue;   // (workgroup-uniform) a frame with a depth-0 point: project_fixup_kernel
-    __syncthreads();
-    // two records (16 bytes) per lane and load: 8-byte loads reach about half the per-CU L2 read rate of 16-byte ones.  The
-    // list is walked from the even index at or below n0; the record before n0 (another frame's) is masked.
-    const uint4 *__restrict__ pd4 = reinterpret_cast<const uint4 *>(pd);
-    const int64_t h0 = n0 >> 1, h1 = (n1 + 1) >> 1;   // pairs [h0, h1)
-    for (int64_t i = h0 + threadIdx.x; i < h1; i += BAND_THREADS * BAND_INFLIGHT) {  // BAND_INFLIGHT pairs in flight per thread
-        uint4 v[BAND_INFLIGHT];
-#pragma unroll
-        for (int u = 0; u < BAND_INFLIGHT; u++) {  // unconditional (clamped) loads; out-of-range slots are masked below
-            const int64_t ii = i + (int64_t)u * BAND_THREADS;
-            v[u] = pd4[ii < h1 ? ii : h1 - 1];
-            if (ii >= h1 || 2 * ii < n0) v[u].x = 0xFFFFFFFFu;
-            if (ii >= h1 || 2 * ii + 1 >= n1) v[u].z = 0xFFFFFFFFu;
+    // The band's records of a share are a run of 0 .. 512 slots.  They are read as 16-byte pairs (8-byte loads reach about half
+    // the per-CU L2 read rate), 64 pairs per wavefront and load; every share first queues the loads it needs (`ldq`), then the
+    // wavefronts take BAND_INFLIGHT of them at a time.
+    for (int g0 = 0; g0 < S; g0 += BAND_ROUND) {   // (one round unless the frame has more than half a million points)
+        if (g0) {
+            __syncthreads();   // the previous round's queue is consumed
+            if (threadIdx.x == 0) nslots = 0u;
+            mycnt = (int)threadIdx.x < min(S - g0, BAND_ROUND) ? min(bb.counts[(c0 + g0 + threadIdx.x) * bb.nbe + kband], (uint32_t)SUB_CAP) : 0u;
         }
+        __syncthreads();   // the band is cleared, the queue is empty
+        if ((int)threadIdx.x < min(S - g0, BAND_ROUND)) {
+            cntl[threadIdx.x] = (uint16_t)mycnt;
+            const uint32_t nq = (mycnt + 127u) >> 7;   // <= 16
+            uint32_t pos = nq ? atomicAdd(&nslots, nq) : 0u;
+            for (uint32_t q = 0; q < nq; q++) ldq[pos + q] = (uint16_t)((threadIdx.x << 4) | q);
+        }
+        __syncthreads();
+        const uint32_t ns = nslots;
+        const uint2 *gl = bb.lists + ((c0 + g0) * bb.nbe + kband) * (int64_t)SUB_CAP;   // share 0 of the round
+        const uint32_t share_stride = (uint32_t)bb.nbe * SUB_CAP * 8u;   // bytes
+        for (uint32_t i = (threadIdx.x >> 6) * BAND_INFLIGHT; i < ns; i += (BAND_THREADS >> 6) * BAND_INFLIGHT) {
+            uint4 v[BAND_INFLIGHT];
 #pragma unroll
-        for (int u = 0; u < BAND_INFLIGHT; u++) {
-            const uint32_t r0 = v[u].x - band0, r1 = v[u].z - band0;  // skipped records (0xFFFFFFFF) fall outside every band
-            if (r0 < npx) atomicMin(&band[r0], v[u].y);
-            if (r1 < npx) atomicMin(&band[r1], v[u].w);
+            for (int u = 0; u < BAND_INFLIGHT; u++) {  // unconditional (clamped) loads; slots beyond the run are masked
+                const uint32_t e = ldq[min(i + u, ns - 1u)];
+                const uint32_t sl = e >> 4;
+                const uint32_t cnt = cntl[sl];
+                const uint32_t p = ((e & 15u) << 6) + (threadIdx.x & 63u);   // pair
+                v[u] = ld_at(reinterpret_cast<const uint4 *>(gl), sl * share_stride + min(p, (cnt - 1u) >> 1) * 16u);
+                const bool live = i + u < ns;
+                if (!live || 2u * p >= cnt) v[u].x = 0xFFFFFFFFu;
+                if (!live || 2u * p + 1u >= cnt) v[u].z = 0xFFFFFFFFu;
+            }
+#pragma unroll
+            for (int u = 0; u < BAND_INFLIGHT; u++) {
+                const uint32_t r0 = v[u].x - band0, r1 = v[u].z - band0;  // masked slots (0xFFFFFFFF) fall outside every band
+                if (r0 < npx) atomicMin(&band[r0], v[u].y);
+                if (r1 < npx) atomicMin(&band[r1], v[u].w);
+            }
+        }
+    }
+    if (ocnt) {   // the exact path's records of this band
+        const uint32_t cap = (uint32_t)((o1 - o0 + 1) & ~(int64_t)1);
+        const uint2 *ol = bb.olists + (int64_t)(bb.nbe >> 1) * (o0 + b) + (int64_t)pairb * cap + (odd ? cap - min(ocnt, cap) : 0u);
+        const uint32_t on = min(ocnt, cap);
+        for (uint32_t i = threadIdx.x; i < on; i += BAND_THREADS * 2) {
+            const uint2 ra = ol[i], rb2 = ol[min(i + BAND_THREADS, on - 1u)];
+            const uint32_t r0 = ra.x - band0, r1 = rb2.x - band0;
+            if (r0 < npx) atomicMin(&band[r0], ra.y);
+            if (i + BAND_THREADS < on && r1 < npx) atomicMin(&band[r1], rb2.y);
         }
     }
     __syncthreads();
@@ -703,8 +841,16 @@ __device__ void project_fixup_frame(const float *__restrict__ xyz, const int64_t
         if (__hip_atomic_load(&img[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == RI_EMPTY) img[p] = 0u;
 }
 
-static size_t project_scratch_bytes(int64_t total, int B, int P) {
-    return ((size_t)B * ((size_t)P + 8)) * 4 + 256 + (size_t)(total > 0 ? total : 0) * 8 + 16;   // + 16: the band kernel reads records in 16-byte pairs
+static inline int band_bins_even(int P) { return (((P + BAND_PX - 1) / BAND_PX) + 1) & ~1; }   // bands per frame, rounded up to even
+static inline int64_t pix_chunk_ids(int64_t total, int B) { return ((total > 0 ? total : 0) >> PIX_CH_SHIFT) + B; }
+static inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
+static inline size_t project_small_bytes(int B, int P) { return align16(((size_t)B * ((size_t)P + 8)) * 4 + 256); }   // lastz + flags
+static inline size_t project_cursor_bytes(int B, int P) { return align16((size_t)B * band_bins_even(P) * 4); }
+static inline size_t project_counts_bytes(int64_t total, int B, int P) { return align16((size_t)pix_chunk_ids(total, B) * band_bins_even(P) * 4); }
+static inline size_t project_lists_bytes(int64_t total, int B, int P) { return (size_t)pix_chunk_ids(total, B) * band_bins_even(P) * SUB_CAP * 8; }
+static size_t project_scratch_bytes(int64_t total, int B, int P) {   // lastz, flags | cursors | counts | shares | exact path's lists
+    return project_small_bytes(B, P) + project_cursor_bytes(B, P) + project_counts_bytes(total, B, P) + project_lists_bytes(total, B, P) +
+           (size_t)(band_bins_even(P) / 2) * (size_t)((total > 0 ? total : 0) + B) * 8 + 16;
 }
 extern "C" size_t rpcc_project_scratch_bytes(int64_t total, int B, int P) { return project_scratch_bytes(total, B, P); }
 
@@ -730,16 +876,24 @@ static int launch_project(const float *xyz, const int64_t *offsets, int64_t tota
     const dim3 fg((P + 1023) / 1024 < 64 ? (P + 1023) / 1024 : 64, B);
     const unsigned nb = (unsigned)((total + 255) / 256);
     const unsigned nb_small = nb < 2048 ? (nb ? nb : 1) : 2048;
-    const bool fast = scratch_bytes >= project_scratch_bytes(total, B, P);
+    BandBins bb;
+    bb.nbe = band_bins_even(P);
+    // the binned path: room for the lists, a counter per band and wavefront in the pixel kernel's LDS
+    const bool fast = scratch_bytes >= project_scratch_bytes(total, B, P) && bb.nbe <= PIX_MAX_BANDS;
     if (fast) {
-        uint2 *pd = reinterpret_cast<uint2 *>(reinterpret_cast<char *>(scratch) + ((size_t)B * ((size_t)P + 8)) * 4 + 256);
+        char *q = reinterpret_cast<char *>(scratch) + project_small_bytes(B, P);
+        bb.ocursor = reinterpret_cast<uint32_t *>(q); q += project_cursor_bytes(B, P);
+        bb.counts = reinterpret_cast<uint32_t *>(q); q += project_counts_bytes(total, B, P);
+        bb.lists = reinterpret_cast<uint2 *>(q); q += project_lists_bytes(total, B, P);
+        bb.olists = reinterpret_cast<uint2 *>(q);
+        HIP_TRY(hipMemsetAsync(bb.ocursor, 0, (size_t)B * bb.nbe * 4, st));
         if (!cleared) HIP_TRY(hipMemsetAsync(flags, 0, (size_t)(B + 1) * 4, st));
         BatchInit bi;
         memset(&bi, 0, sizeof(bi));
         if (init) bi = *init;
         if (total > 0 || bi.on)
-            project_pix_kernel<<<(unsigned)std::max<int64_t>(std::min<int64_t>((total + PIX_PPT * PIX_THREADS - 1) / (PIX_PPT * PIX_THREADS), 256 * 16), 1), PIX_THREADS, 0, st>>>(
-                xyz, offsets, total, base, B, g, pix_fast_cfg(g), pd, flags, epoch, bi);
+            project_pix_kernel<<<(unsigned)std::max<int64_t>(std::min<int64_t>(pix_chunk_ids(total, B), 256 * 16), 1), PIX_THREADS, 0, st>>>(
+                xyz, offsets, total, base, B, g, pix_fast_cfg(g), bb, flags, epoch, bi);
         HIP_TRY(ensure_dyn_lds(reinterpret_cast<const void *>(&project_band_kernel), BAND_PX * 4));
         if (zcnt && !cleared) HIP_TRY(hipMemsetAsync(zcnt, 0, (size_t)B * (RS_CHUNKS + 1) * 4, st));
         // persistent: at most one workgroup per CU (8 XCDs x 32), each walking over its XCD's (frame, band) items
@@ -747,7 +901,7 @@ static int launch_project(const float *xyz, const int64_t *offsets, int64_t tota
         const int band_wgs = 8 * std::min(((B + 7) / 8) * nbands, std::max(BAND_WG_PER_XCD / nbands, 1) * nbands);
         // + B workgroups for the exact input-order semantics of frames with depth-0 points (a no-op otherwise)
         project_band_kernel<<<band_wgs + (total > 0 ? B : 0), BAND_THREADS, BAND_PX * 4, st>>>(
-            pd, offsets, base, B, P, rb, flags, tz_plane, -1.5f, rs_chunk_px(P), tz_plane ? zcnt : nullptr, epoch, band_wgs, xyz, g, lastz);
+            bb, offsets, base, B, P, rb, flags, tz_plane, -1.5f, rs_chunk_px(P), tz_plane ? zcnt : nullptr, epoch, band_wgs, xyz, g, lastz);
         LAUNCH_CHECK();
         return RPCC_OK;
     }
