@@ -152,6 +152,57 @@ def test_projection_edge_cases(env):
         assert _beq(r[0], orc.project(z["xyz"], g32))
 
 
+def test_projection_record_bins(env):
+    """The pixel kernel bins its records by (frame, image band) in chunks that never cross a frame end: ragged batches of tiny and
+    empty frames, a frame larger than one round of the band kernel's queue, scan-ordered points (one band per chunk), images of
+    eight bands and of more bands than the binned path handles (device-atomic path), every point on the exact path."""
+    torch, ops, orc, synth = env["torch"], env["ops"], env["orc"], env["synth"]
+    rng = np.random.default_rng(77)
+
+    def check(frames, g, geom, tag):
+        offs = np.zeros(len(frames) + 1, np.int64)
+        offs[1:] = np.cumsum([f.shape[0] for f in frames])
+        xyz = np.concatenate(frames) if offs[-1] else np.zeros((0, 3), np.float32)
+        ri = ops.project(_to(env, xyz) if offs[-1] else torch.zeros((0, 3), dtype=torch.float32, device=env["dev"]), _to(env, offs), geom).cpu().numpy()
+        for i, f in enumerate(frames):
+            assert _beq(ri[i], orc.project(f, g)), (tag, i)
+
+    def cloud(n, spread=20.0):
+        a = rng.normal(0, spread, (n, 3)).astype(np.float32)
+        a[:, 2] = rng.normal(-1, 1.5, n)
+        return a
+
+    g, geom, _ = _geom(env, "Velodyne64E")
+    # 1. sizes around the chunk size (2048) and its multiples, empty frames first, in the middle and last
+    sizes = [0, 0, 1, 2047, 2048, 2049, 0, 4095, 4096, 4097, 63, 64, 65, 1, 0, 6000, 3, 0]
+    check([cloud(n) for n in sizes], g, geom, "ragged")
+    # 2. many tiny frames (several per chunk of points)
+    check([cloud(int(n)) for n in rng.integers(0, 300, 200)], g, geom, "tiny")
+    # 3. a frame of more than 256 chunks (two rounds of the band kernel's queue) next to a small one
+    check([cloud(2048 * 300 + 77), cloud(500)], g, geom, "large")
+    # 4. scan order: consecutive points share an image row (all of a chunk's records fall into one band)
+    gb = orc.LidarGeom(H=64, W=2048, hfov_deg=360, vmax_deg=2.0, vmin_deg=-24.9)
+    geomb = ops.make_geom(gb.H, gb.W, gb.horizontal_FOV, gb.vertical_max, gb.vertical_min)
+    f = synth.make_frame(3, 64, 2048).numpy()
+    row = np.round((f[:, 2] / np.linalg.norm(f, axis=1)) * 200).astype(np.int64)      # (coarse elevation bins, then azimuth)
+    order = np.lexsort((np.arctan2(f[:, 1], f[:, 0]), -row))
+    check([f[order], f, f[order][::-1].copy()], gb, geomb, "scan order")
+    # 5. eight bands (128 x 2048) and sixteen (128 x 4096: beyond the binned path)
+    for W in (2048, 4096):
+        g8 = orc.LidarGeom(H=128, W=W, hfov_deg=360, vmax_deg=15.0, vmin_deg=-25.0)
+        geom8 = ops.make_geom(g8.H, g8.W, g8.horizontal_FOV, g8.vertical_max, g8.vertical_min)
+        fr = [synth.make_frame(40 + i, 128, W, vmax_deg=15.0, vmin_deg=-25.0).numpy()[: 150000 + 1000 * i] for i in range(3)]
+        check(fr + [cloud(5000, 8.0)], g8, geom8, "bands %d" % W)
+    # 6. every point uncertain for the fast pixel test (on pixel boundaries of a coarse image): all records take the exact path
+    gc = orc.LidarGeom(H=16, W=1800, hfov_deg=360, vmax_deg=15.0, vmin_deg=-15.0)
+    geomc = ops.make_geom(gc.H, gc.W, gc.horizontal_FOV, gc.vertical_max, gc.vertical_min)
+    az = (np.arange(20000) % 1800 + 0.5) * (2 * np.pi / 1800)          # exactly between two columns
+    el = np.deg2rad(rng.uniform(-15, 15, 20000))
+    r = rng.uniform(2, 60, 20000)
+    pts = np.stack([r * np.cos(el) * np.cos(az), r * np.cos(el) * np.sin(az), r * np.sin(el)], 1).astype(np.float32)
+    check([pts, pts[:100], pts[::-1].copy()], gc, geomc, "exact path")
+
+
 def test_fps_xyz_operator(env):
     """The reference FPS operator signature (B,N,3)->(B,M): ragged N, duplicates (exact ties), N<M."""
     torch, ops, orc = env["torch"], env["ops"], env["orc"]
