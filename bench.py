@@ -53,7 +53,8 @@ def parse():
                     help="BASELINE.json configs[]: 1 = uniform + point model (headline), 2 = non-uniform + plane model")
     ap.add_argument("--input", default=None,
                     help="real sweep (.npz with 'xyz', .bin or .npy): the batch is this frame replicated with a per-copy yaw "
-                         "rotation and point shuffle instead of the synthetic scene (64x2000 unless --geom)")
+                         "rotation instead of the synthetic scene, points in the file's order (64x2000 unless --geom)")
+    ap.add_argument("--input-shuffle", action="store_true", help="with --input: shuffle each copy's points (the synthetic frames are shuffled)")
     ap.add_argument("--cpu-sample", type=int, default=24, help="frames timed on the host for cpu_baseline (0 = skip)")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the outputs after the timed region")
     ap.add_argument("--gather-payloads", action="store_true", help="N>1: also gather the packed residual streams to rank 0 every step")
@@ -188,8 +189,9 @@ def dry_run_rank(a, rank, world):
                           "per_rank_s": [round(float(t.item()), 4) for t in allt]}), flush=True)
 
 
-def load_real_batch(path, ids, H, W, dev):
-    """The real sweep replicated: copy i = the frame rotated about z by i * 2pi/|ids| (+ a little) and shuffled."""
+def load_real_batch(path, ids, H, W, dev, shuffle=False):
+    """The real sweep replicated: copy i = the frame rotated about z by a per-copy angle; the points keep the file's order (the
+    scanner's: ring by ring) unless `shuffle`."""
     import numpy as np
     import torch
     if path.endswith(".npz"):
@@ -204,7 +206,7 @@ def load_real_batch(path, ids, H, W, dev):
         rng = np.random.Generator(np.random.PCG64(77_000 + int(i)))
         a = 2 * np.pi * ((int(i) * 0.61803398875) % 1.0)
         c, s = np.float32(np.cos(a)), np.float32(np.sin(a))
-        f = xyz[rng.permutation(xyz.shape[0])]
+        f = xyz[rng.permutation(xyz.shape[0])] if shuffle else xyz
         frames.append(np.stack([c * f[:, 0] - s * f[:, 1], s * f[:, 0] + c * f[:, 1], f[:, 2]], 1).astype(np.float32))
     offs = np.zeros(len(frames) + 1, np.int64)
     offs[1:] = np.cumsum([f.shape[0] for f in frames])
@@ -249,7 +251,7 @@ def run_workload(a, ctx):
     # this rank's batch: frame ids are disjoint across ranks (frame-sharded datalist)
     ids = list(range(rank * B, rank * B + B))
     if a.input:
-        xyz, offs = load_real_batch(a.input, ids, H, W, dev)
+        xyz, offs = load_real_batch(a.input, ids, H, W, dev, shuffle=a.input_shuffle)
     else:
         xyz, offs = synth.make_batch(ids, H, W, device=dev)
     offs_host = offs.cpu().numpy()
@@ -434,7 +436,7 @@ def run_workload(a, ctx):
         step_valu_frac = pm["step_valu"] / step_s / VALU_PEAK_WAVE_INSTS_PER_S if pm and pm.get("step_valu") else None
         step_traffic_frac = pm["step_traffic"] / step_s / 1e9 / HBM_PEAK_GBS if pm and pm.get("step_traffic") else None
         workload = ("configs[%d]: batch=%d %s Velodyne-64E frames (%dx%d) per GPU, %s, accuracy=%g, cluster_num=%d, ground plane by "
-                    "seeded RANSAC inside the step" % (a.config, B, "real (%s, rotated + shuffled copies)" % os.path.basename(a.input) if a.input else "synthetic",
+                    "seeded RANSAC inside the step" % (a.config, B, "real (%s, rotated copies, %s)" % (os.path.basename(a.input), "shuffled" if a.input_shuffle else "points in stored order") if a.input else "synthetic",
                                                        H, W, "non-uniform + FPS + plane-model" if general else "uniform + FPS + point-model", a.accuracy, M))
         exch_s = ("no exchange" if not exchange else
                   "RCCL all_gather of the per-frame payload lengths" + (" + gather of the packed pre-entropy residual streams to rank 0" if a.gather_payloads
