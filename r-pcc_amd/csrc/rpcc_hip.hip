@@ -645,11 +645,14 @@ __global__ __launch_bounds__(BAND_THREADS) BAND_VGPR_ATTR void project_band_kern
     // next frames), so a 1024-thread / 128 KB workgroup is launched once per CU instead of once per item.
     const int nbands = (P + BAND_PX - 1) / BAND_PX;
     const int xcd = blockIdx.x & 7, slots = band_wgs >> 3;
+    // the LDS band is cleared once; every item's write-out leaves it cleared for the next
+    {
+        uint4 *b4 = reinterpret_cast<uint4 *>(band);
+        for (uint32_t q = threadIdx.x; q < BAND_PX / 4; q += BAND_THREADS) b4[q] = make_uint4(RI_EMPTY, RI_EMPTY, RI_EMPTY, RI_EMPTY);
+    }
     for (int slot = blockIdx.x >> 3;; slot += slots) {
     const int b = xcd + 8 * (slot / nbands), kband = slot % nbands;
     if (b >= B) break;
-    __syncthreads();   // the previous item's LDS band and counters are no longer read
-    // the three dependent scalars of this workgroup first: their latency passes while the LDS band is cleared
     const int flagged = flags[b] == mark;
     const int64_t o0 = offs[b] - base, o1 = offs[b + 1] - base;
     const uint32_t ocnt = bb.ocursor[b * bb.nbe + kband];        // records of the exact path
@@ -662,13 +665,7 @@ __global__ __launch_bounds__(BAND_THREADS) BAND_VGPR_ATTR void project_band_kern
     // (issued before the band is cleared: the latency passes under the LDS stores)
     uint32_t mycnt = 0u;
     if ((int)threadIdx.x < min(S, BAND_ROUND) && !flagged) mycnt = min(bb.counts[(c0 + threadIdx.x) * bb.nbe + kband], (uint32_t)SUB_CAP);
-    if (threadIdx.x == 0) nslots = 0u;
-    if ((npx & 3) == 0) {
-        uint4 *b4 = reinterpret_cast<uint4 *>(band);
-        for (uint32_t q = threadIdx.x; q < (npx >> 2); q += BAND_THREADS) b4[q] = make_uint4(RI_EMPTY, RI_EMPTY, RI_EMPTY, RI_EMPTY);
-    } else {
-        for (uint32_t p = threadIdx.x; p < npx; p += BAND_THREADS) band[p] = RI_EMPTY;
-    }
+    if (threadIdx.x == 0) nslots = 0u;   // (every thread has read the previous item's value: a barrier lies between)
     if (flagged) continue;   // (workgroup-uniform) a frame with a depth-0 point: project_fixup_kernel
     // The band's records of a share are a run of 0 .. 512 slots.  They are read as 16-byte pairs (8-byte loads reach about half
     // the per-CU L2 read rate), 64 pairs per wavefront and load; every share first queues the loads it needs (`ldq`), then the
@@ -679,7 +676,7 @@ __global__ __launch_bounds__(BAND_THREADS) BAND_VGPR_ATTR void project_band_kern
             if (threadIdx.x == 0) nslots = 0u;
             mycnt = (int)threadIdx.x < min(S - g0, BAND_ROUND) ? min(bb.counts[(c0 + g0 + threadIdx.x) * bb.nbe + kband], (uint32_t)SUB_CAP) : 0u;
         }
-        __syncthreads();   // the band is cleared, the queue is empty
+        __syncthreads();   // the band is cleared (the previous item's write-out is complete), the queue is empty
         if ((int)threadIdx.x < min(S - g0, BAND_ROUND)) {
             cntl[threadIdx.x] = (uint16_t)mycnt;
             const uint32_t nq = (mycnt + 127u) >> 7;   // <= 16
@@ -727,6 +724,7 @@ __global__ __launch_bounds__(BAND_THREADS) BAND_VGPR_ATTR void project_band_kern
     if (zcnt == nullptr) {
         for (uint32_t p = threadIdx.x; p < npx; p += BAND_THREADS) {
             const uint32_t v = band[p];
+            band[p] = RI_EMPTY;
             out[p] = (v == RI_EMPTY) ? 0u : v;
         }
         continue;
@@ -739,6 +737,7 @@ __global__ __launch_bounds__(BAND_THREADS) BAND_VGPR_ATTR void project_band_kern
         if (threadIdx.x < RS_CHUNKS) zc[threadIdx.x] = 0;
         __syncthreads();
         const uint4 *band4 = reinterpret_cast<const uint4 *>(band);
+        uint4 *band4w = reinterpret_cast<uint4 *>(band);
         const float4 *tz4 = reinterpret_cast<const float4 *>(tz + band0);
         uint4 *out4 = reinterpret_cast<uint4 *>(out);
         const uint32_t nq = npx >> 2;
@@ -751,6 +750,7 @@ __global__ __launch_bounds__(BAND_THREADS) BAND_VGPR_ATTR void project_band_kern
                 const uint32_t q = min(q0 + u * BAND_THREADS, nq - 1);  // unconditional (clamped) loads
                 zr[u] = tz4[q];
                 uint4 v = band4[q];
+                if (q0 + u * BAND_THREADS < nq) band4w[q] = make_uint4(RI_EMPTY, RI_EMPTY, RI_EMPTY, RI_EMPTY);
                 v.x = v.x == RI_EMPTY ? 0u : v.x; v.y = v.y == RI_EMPTY ? 0u : v.y;
                 v.z = v.z == RI_EMPTY ? 0u : v.z; v.w = v.w == RI_EMPTY ? 0u : v.w;
                 rv[u] = v;
@@ -789,6 +789,7 @@ __global__ __launch_bounds__(BAND_THREADS) BAND_VGPR_ATTR void project_band_kern
             const uint32_t p = min(p0 + u * BAND_THREADS, npx - 1);  // unconditional (clamped) loads
             zr[u] = tz[band0 + p];
             const uint32_t v = band[p];
+            if (p0 + u * BAND_THREADS < npx) band[p] = RI_EMPTY;
             rv[u] = (v == RI_EMPTY) ? 0u : v;
         }
 #pragma unroll
