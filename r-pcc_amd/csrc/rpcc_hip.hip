@@ -389,6 +389,10 @@ __device__ __forceinline__ int flag_mark(const int32_t *epoch) { return epoch ? 
 #define PIX_CH_SHIFT 11
 #define PIX_WAVES (PIX_THREADS / 64)
 #define SUB_CAP (PIX_PPT * PIX_THREADS)   // slots per chunk and band
+#ifndef REC6
+#define REC6 1   // 1: 6-byte records (depth u32 array + pixel-in-band u16 array per share); 0: 8-byte (pixel, depth) records
+#endif
+#define SHARE_BYTES (SUB_CAP * (REC6 ? 6 : 8))
 #define PIX_MAX_BANDS 8   // bands per frame the binned path handles (a power of two)
 #define BAND_ROUND 256     // shares (chunks) a band workgroup queues at a time
 #define BAND_SHIFT 15
@@ -396,7 +400,7 @@ static_assert((1 << BAND_SHIFT) == BAND_PX, "BAND_PX is a power of two");
 static_assert((1 << PIX_CH_SHIFT) == PIX_PPT * PIX_THREADS, "chunk size");
 struct BandBins {
     uint32_t *counts;    // [chunk ids][nbe]
-    uint2 *lists;        // [chunk ids][nbe][SUB_CAP]
+    char *lists;         // [chunk ids][nbe] shares of SHARE_BYTES: depth bits u32 [SUB_CAP] | pixel inside the band u16 [SUB_CAP]
     uint32_t *ocursor;   // [B][nbe]   records of the exact path (cleared per launch)
     uint2 *olists;       // frame f: nbe / 2 regions of cap_f = n_f rounded up to even slots from slot (nbe / 2) * (offs[f] - base + f)
     int nbe;             // bands per frame, rounded up to even
@@ -522,7 +526,7 @@ __global__ __launch_bounds__(PIX_THREADS) PIX_VGPR_ATTR void project_pix_kernel(
             x[u] = p3.x; y[u] = p3.y; z[u] = p3.z;
         }
         if (k + gridDim.x < nck) locate(k + gridDim.x, fnext, il_next, room_next);   // (scalar loads: their latency passes under the point loads)
-        uint2 *reg = bb.lists + k * (int64_t)(bb.nbe * SUB_CAP);   // the chunk's share of the lists
+        char *reg = bb.lists + k * (int64_t)(bb.nbe * SHARE_BYTES);   // the chunk's shares of the lists
 #pragma unroll
         for (int u = 0; u < PIX_PPT; u++) {
             const uint32_t ci = (uint32_t)(u * PIX_THREADS) + threadIdx.x;
@@ -536,7 +540,13 @@ __global__ __launch_bounds__(PIX_THREADS) PIX_VGPR_ATTR void project_pix_kernel(
             const uint32_t band = (uint32_t)pix >> BAND_SHIFT;
             if (fast) {
                 const uint32_t xr = atomicAdd(&bcnt[band & (PIX_MAX_BANDS - 1)], 1u);
-                reg[band * SUB_CAP + xr] = make_uint2((uint32_t)pix, f2u(depth));
+                char *sh = reg + band * (uint32_t)SHARE_BYTES;   // 6 bytes per record: the depth bits and the pixel's offset in its band
+#if REC6
+                st_at(reinterpret_cast<uint32_t *>(sh), xr * 4u, f2u(depth));
+                st_at(reinterpret_cast<uint16_t *>(sh + SUB_CAP * 4), xr * 2u, (uint16_t)((uint32_t)pix & (BAND_PX - 1)));
+#else
+                st_at(reinterpret_cast<uint2 *>(sh), xr * 8u, make_uint2((uint32_t)pix & (BAND_PX - 1), f2u(depth)));
+#endif
             }
             const bool slow = in && !fast;
             const unsigned long long sm = __ballot(slow);
@@ -667,8 +677,8 @@ __global__ __launch_bounds__(BAND_THREADS) BAND_VGPR_ATTR void project_band_kern
     if ((int)threadIdx.x < min(S, BAND_ROUND) && !flagged) mycnt = min(bb.counts[(c0 + threadIdx.x) * bb.nbe + kband], (uint32_t)SUB_CAP);
     if (threadIdx.x == 0) nslots = 0u;   // (every thread has read the previous item's value: a barrier lies between)
     if (flagged) continue;   // (workgroup-uniform) a frame with a depth-0 point: project_fixup_kernel
-    // The band's records of a share are a run of 0 .. 512 slots.  They are read as 16-byte pairs (8-byte loads reach about half
-    // the per-CU L2 read rate), 64 pairs per wavefront and load; every share first queues the loads it needs (`ldq`), then the
+    // The band's records of a share are a run of 0 .. 2048 slots, read four at a time (16 bytes of depths + 8 bytes of pixels per lane),
+    // 256 records per wavefront and step; every share first queues the loads it needs (`ldq`), then the
     // wavefronts take BAND_INFLIGHT of them at a time.
     for (int g0 = 0; g0 < S; g0 += BAND_ROUND) {   // (one round unless the frame has more than half a million points)
         if (g0) {
@@ -679,32 +689,42 @@ __global__ __launch_bounds__(BAND_THREADS) BAND_VGPR_ATTR void project_band_kern
         __syncthreads();   // the band is cleared (the previous item's write-out is complete), the queue is empty
         if ((int)threadIdx.x < min(S - g0, BAND_ROUND)) {
             cntl[threadIdx.x] = (uint16_t)mycnt;
-            const uint32_t nq = (mycnt + 127u) >> 7;   // <= 16
+            const uint32_t nq = (mycnt + 255u) >> 8;   // <= 8
             uint32_t pos = nq ? atomicAdd(&nslots, nq) : 0u;
             for (uint32_t q = 0; q < nq; q++) ldq[pos + q] = (uint16_t)((threadIdx.x << 4) | q);
         }
         __syncthreads();
         const uint32_t ns = nslots;
-        const uint2 *gl = bb.lists + ((c0 + g0) * bb.nbe + kband) * (int64_t)SUB_CAP;   // share 0 of the round
-        const uint32_t share_stride = (uint32_t)bb.nbe * SUB_CAP * 8u;   // bytes
+        const char *gl = bb.lists + ((c0 + g0) * bb.nbe + kband) * (int64_t)SHARE_BYTES;   // share 0 of the round
+        const uint32_t share_stride = (uint32_t)bb.nbe * SHARE_BYTES;
         for (uint32_t i = (threadIdx.x >> 6) * BAND_INFLIGHT; i < ns; i += (BAND_THREADS >> 6) * BAND_INFLIGHT) {
-            uint4 v[BAND_INFLIGHT];
+            uint4 dv[BAND_INFLIGHT];
+            uint2 pv[BAND_INFLIGHT];
+            uint32_t left[BAND_INFLIGHT];   // records of the run from this lane's first on (0: none)
 #pragma unroll
-            for (int u = 0; u < BAND_INFLIGHT; u++) {  // unconditional (clamped) loads; slots beyond the run are masked
+            for (int u = 0; u < BAND_INFLIGHT; u++) {  // unconditional (clamped) loads; records beyond the run are masked
                 const uint32_t e = ldq[min(i + u, ns - 1u)];
                 const uint32_t sl = e >> 4;
                 const uint32_t cnt = cntl[sl];
-                const uint32_t p = ((e & 15u) << 6) + (threadIdx.x & 63u);   // pair
-                v[u] = ld_at(reinterpret_cast<const uint4 *>(gl), sl * share_stride + min(p, (cnt - 1u) >> 1) * 16u);
-                const bool live = i + u < ns;
-                if (!live || 2u * p >= cnt) v[u].x = 0xFFFFFFFFu;
-                if (!live || 2u * p + 1u >= cnt) v[u].z = 0xFFFFFFFFu;
+                const uint32_t p = ((e & 15u) << 6) + (threadIdx.x & 63u);   // group of four records
+                const uint32_t pc = min(p, (cnt - 1u) >> 2);
+#if REC6
+                dv[u] = ld_at(reinterpret_cast<const uint4 *>(gl), sl * share_stride + pc * 16u);
+                pv[u] = ld_at(reinterpret_cast<const uint2 *>(gl), sl * share_stride + (uint32_t)(SUB_CAP * 4) + pc * 8u);
+#else
+                const uint4 r01 = ld_at(reinterpret_cast<const uint4 *>(gl), sl * share_stride + pc * 32u);
+                const uint4 r23 = ld_at(reinterpret_cast<const uint4 *>(gl), sl * share_stride + pc * 32u + 16u);
+                dv[u] = make_uint4(r01.y, r01.w, r23.y, r23.w);
+                pv[u] = make_uint2(r01.x | r01.z << 16, r23.x | r23.z << 16);
+#endif
+                left[u] = (i + u < ns && 4u * p < cnt) ? cnt - 4u * p : 0u;
             }
 #pragma unroll
             for (int u = 0; u < BAND_INFLIGHT; u++) {
-                const uint32_t r0 = v[u].x - band0, r1 = v[u].z - band0;  // masked slots (0xFFFFFFFF) fall outside every band
-                if (r0 < npx) atomicMin(&band[r0], v[u].y);
-                if (r1 < npx) atomicMin(&band[r1], v[u].w);
+                if (left[u] > 0u) atomicMin(&band[pv[u].x & 0xFFFFu], dv[u].x);
+                if (left[u] > 1u) atomicMin(&band[pv[u].x >> 16], dv[u].y);
+                if (left[u] > 2u) atomicMin(&band[pv[u].y & 0xFFFFu], dv[u].z);
+                if (left[u] > 3u) atomicMin(&band[pv[u].y >> 16], dv[u].w);
             }
         }
     }
@@ -848,7 +868,7 @@ static inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 static inline size_t project_small_bytes(int B, int P) { return align16(((size_t)B * ((size_t)P + 8)) * 4 + 256); }   // lastz + flags
 static inline size_t project_cursor_bytes(int B, int P) { return align16((size_t)B * band_bins_even(P) * 4); }
 static inline size_t project_counts_bytes(int64_t total, int B, int P) { return align16((size_t)pix_chunk_ids(total, B) * band_bins_even(P) * 4); }
-static inline size_t project_lists_bytes(int64_t total, int B, int P) { return (size_t)pix_chunk_ids(total, B) * band_bins_even(P) * SUB_CAP * 8; }
+static inline size_t project_lists_bytes(int64_t total, int B, int P) { return (size_t)pix_chunk_ids(total, B) * band_bins_even(P) * SHARE_BYTES; }
 static size_t project_scratch_bytes(int64_t total, int B, int P) {   // lastz, flags | cursors | counts | shares | exact path's lists
     return project_small_bytes(B, P) + project_cursor_bytes(B, P) + project_counts_bytes(total, B, P) + project_lists_bytes(total, B, P) +
            (size_t)(band_bins_even(P) / 2) * (size_t)((total > 0 ? total : 0) + B) * 8 + 16;
@@ -885,7 +905,7 @@ static int launch_project(const float *xyz, const int64_t *offsets, int64_t tota
         char *q = reinterpret_cast<char *>(scratch) + project_small_bytes(B, P);
         bb.ocursor = reinterpret_cast<uint32_t *>(q); q += project_cursor_bytes(B, P);
         bb.counts = reinterpret_cast<uint32_t *>(q); q += project_counts_bytes(total, B, P);
-        bb.lists = reinterpret_cast<uint2 *>(q); q += project_lists_bytes(total, B, P);
+        bb.lists = q; q += project_lists_bytes(total, B, P);
         bb.olists = reinterpret_cast<uint2 *>(q);
         HIP_TRY(hipMemsetAsync(bb.ocursor, 0, (size_t)B * bb.nbe * 4, st));
         if (!cleared) HIP_TRY(hipMemsetAsync(flags, 0, (size_t)(B + 1) * 4, st));

@@ -16,7 +16,7 @@ tm = torch.from_numpy(ops.transform_map(H, W, hfov, vmax, vmin)).to(dev)
 xyz, offs = synth.make_batch(range(B), H, W, device=dev)
 ri = ops.project(xyz, offs, geom)
 g, inl = ops.ground_ransac(ri, tm, 0)
-stamps = torch.zeros(64 + 8 * 128, dtype=torch.int64, device=dev)
+stamps = torch.zeros(4096 + 16 * 128 * 8, dtype=torch.int64, device=dev)
 for rep in range(2):
     temp, info, tab = ops.ground_mask(ri, tm, g, 0.1, fps_table=True)
     stamps.zero_()
@@ -32,5 +32,10 @@ print("launch %.1f us; per wavefront of block 0, cycles summed over 98 iteration
 print("wave |   test |  visit | to-barrier | barrier wait | after barrier+store | tiles visited | iterations with a visit")
 for w in range(8):
     print("  %d  | %6d | %6d | %6d | %6d | %6d | %4d | %3d" % (w, s[w, 1], s[w, 2], s[w, 3], s[w, 4], s[w, 5], s[w, 6], s[w, 7]))
+vv = stamps.cpu().numpy()[3000:3032].reshape(8, 4)
+print("visit rounds per wavefront: cycles issuing loads / waiting for the data / updating, per round:")
+for w in range(8):
+    r = max(int(vv[w, 3]), 1)
+    print("  %d  | rounds %3d | issue %5d | wait %5d | update %5d" % (w, vv[w, 3], vv[w, 0] / r, vv[w, 1] / r, vv[w, 2] / r))
 tot = s[:, 1:6].sum(1)
 print("sum per wave:", tot, " -> per iteration", (tot / 98).round(0))
