@@ -393,9 +393,13 @@ __device__ __forceinline__ int flag_mark(const int32_t *epoch) { return epoch ? 
 #define REC6 1   // 1: 6-byte records (depth u32 array + pixel-in-band u16 array per share); 0: 8-byte (pixel, depth) records
 #endif
 #define SHARE_BYTES (SUB_CAP * (REC6 ? 6 : 8))
+#ifndef PIX_MAX_BANDS
 #define PIX_MAX_BANDS 8   // bands per frame the binned path handles (a power of two)
+#endif
 #define BAND_ROUND 256     // shares (chunks) a band workgroup queues at a time
+#ifndef BAND_SHIFT
 #define BAND_SHIFT 15
+#endif
 static_assert((1 << BAND_SHIFT) == BAND_PX, "BAND_PX is a power of two");
 static_assert((1 << PIX_CH_SHIFT) == PIX_PPT * PIX_THREADS, "chunk size");
 struct BandBins {
