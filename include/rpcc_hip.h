@@ -302,8 +302,10 @@ size_t rpcc_workspace_bytes_general(int B, int P, int M, int64_t total_points); 
 int rpcc_compress_batch(const rpcc_batch_io *io, int B, rpcc_geom g, int M, double ground_threshold, float acc,
                         void *ws, void *stream);
 
-/* Developer hook: register a device int64[64] buffer; instrumented kernels store the shader clock at
- * phase boundaries (block 0 only).  NULL disables it (default). */
+/* Developer hook (libraries built with -DRPCC_DEVTRACE only; the shipped one returns RPCC_ERR_ARG for a non-NULL buffer):
+ * register a device int64 buffer of at least RPCC_DEBUG_STAMPS_WORDS words; instrumented kernels store the shader clock at
+ * phase boundaries, the FPS kernel its per-phase cycle sums and per-iteration tile counts.  NULL disables it (default). */
+#define RPCC_DEBUG_STAMPS_WORDS (4096 + 16 * 128 * 8)
 int rpcc_debug_stamps(void *dev_i64_buffer);
 
 /* Timer objects for bench.py: a handle given in rpcc_batch_io.timer makes the call record hipEvents around its FPS

@@ -586,27 +586,45 @@ __global__ __launch_bounds__(FPS_TT) FPS_VGPR_ATTR void fps_regtab_kernel(const 
 #ifndef FPS_VISIT
 #define FPS_VISIT 2
 #endif
+#ifndef FPS_VISIT_UNCOND
+#define FPS_VISIT_UNCOND 2   // (1: the second tile's loads only when there is one -- 3 % faster alone, 2 % slower with batches in flight)
+#endif
+#ifdef RPCC_DEVTRACE
+    long long vacc[4] = {0, 0, 0, 0};   // visit rounds: cycles issuing the loads / waiting for the data / updating, rounds
+#endif
     auto visit = [&](unsigned long long m, bool with_box) {
         bool viol = false;
         while (m) {
             int l[FPS_VISIT];
             bool on[FPS_VISIT];
             FpsQuad q[FPS_VISIT];
+#ifdef RPCC_DEVTRACE
+            const long long v0 = (long long)__builtin_readcyclecounter();
+#endif
 #pragma unroll
             for (int u = 0; u < FPS_VISIT; u++) {
                 on[u] = m != 0ull;
                 l[u] = on[u] ? (int)__ffsll((long long)m) - 1 : l[0];
                 m &= m - 1ull;     // (0 & anything stays 0)
-                if (u < 2 || on[u]) {   // (wave-uniform) the first pair unconditionally, the rest only when there is a tile
+                if (u < FPS_VISIT_UNCOND || on[u]) {   // (wave-uniform) the first pair unconditionally, the rest only when there is a tile
                     locate(l[u], q[u]);
                     fps_quad_load<RANGE, VEC>(src, rays, temp, q[u]);
                 }
             }
+#ifdef RPCC_DEVTRACE
+            const long long v1 = (long long)__builtin_readcyclecounter();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const long long v2 = (long long)__builtin_readcyclecounter();
+#endif
 #pragma unroll
             for (int u = 0; u < FPS_VISIT; u++) {
                 FpsTileOut o;
                 if (on[u] && fps_tile_update<RANGE, VEC>(q[u], org_on, t_org0, c0, c1, c2, temp, with_box, o, viol)) store_entry(l[u], o, with_box);
             }
+#ifdef RPCC_DEVTRACE
+            const long long v3 = (long long)__builtin_readcyclecounter();
+            vacc[0] += v1 - v0; vacc[1] += v2 - v1; vacc[2] += v3 - v2; vacc[3] += 1;
+#endif
         }
         if (with_box && __ballot(viol) != 0ull && lane == 0) s_viol = 1;
     };
@@ -713,6 +731,8 @@ __global__ __launch_bounds__(FPS_TT) FPS_VGPR_ATTR void fps_regtab_kernel(const 
 #ifdef RPCC_DEVTRACE
         p3_acc[6] += __popcll(vm);
         p3_acc[7] += vm != 0ull;
+        // tiles to visit per iteration and wavefront, blocks 0..15 -> stamps[4096 + ((block * 128 + j) * 8 + wave)]
+        if (g_dbg_stamps != nullptr && blockIdx.x < 16 && lane == 0 && j < 128 && wave < 8) g_dbg_stamps[4096 + ((blockIdx.x * 128 + j) * 8 + wave)] = __popcll(vm);
 #endif
         FPS_P3(1);
         visit(vm, false);
@@ -727,6 +747,8 @@ __global__ __launch_bounds__(FPS_TT) FPS_VGPR_ATTR void fps_regtab_kernel(const 
 #ifdef RPCC_DEVTRACE
     if (g_dbg_stamps != nullptr && blockIdx.x == 0 && lane == 0)
         for (int i = 0; i < 8; i++) g_dbg_stamps[64 + wave * 8 + i] = p3_acc[i];
+    if (g_dbg_stamps != nullptr && blockIdx.x == 0 && lane == 0)
+        for (int i = 0; i < 4; i++) g_dbg_stamps[3000 + wave * 4 + i] = vacc[i];
 #endif
     DBG_STAMP(16);
 #ifdef RPCC_DEVTRACE

@@ -14,7 +14,7 @@ geom = ops.make_geom(H, W, hfov, vmax, vmin)
 tm = torch.from_numpy(ops.transform_map(H, W, hfov, vmax, vmin)).to(dev)
 xyz, offs = synth.make_batch(range(B), H, W, device=dev)
 ri = ops.project(xyz, offs, geom)
-stamps = torch.zeros(64 + 8 * 128, dtype=torch.int64, device=dev)
+stamps = torch.zeros(4096 + 16 * 128 * 8, dtype=torch.int64, device=dev)
 for which in ("ransac", "fps"):
     stamps.zero_()
     _lib.check(_lib.lib().rpcc_debug_stamps(_lib.ptr(stamps)))

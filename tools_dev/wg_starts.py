@@ -18,7 +18,7 @@ ground, _ = ops.ground_ransac(ri, tm, 0)
 temp0, info, tab = ops.ground_mask(ri, tm, ground, 0.1, fps_table=True)
 cen_pix, centers = ops.fps_range(ri, tm, temp0.clone(), info, M, fps_table=tab)
 ri2, seg2 = ri.clone(), torch.empty((B, H, W), dtype=torch.uint8, device=dev)
-stamps = torch.zeros(2048 + 2 * B + 64, dtype=torch.int64, device=dev)
+stamps = torch.zeros(max(2048 + 2 * B + 64, 4096 + 16 * 128 * 8), dtype=torch.int64, device=dev)
 side = torch.cuda.Stream(device=dev)
 nb = {"none": None, "assign": lambda: ops.assign(ri2, tm, ground, centers, out=seg2),
       "ground mask": lambda: ops.ground_mask(ri2, tm, ground, 0.1, fps_table=True)}
