@@ -397,10 +397,11 @@ __device__ __forceinline__ int flag_mark(const int32_t *epoch) { return epoch ? 
 #define PIX_MAX_BANDS 8   // bands per frame the binned path handles (a power of two)
 #endif
 #define BAND_ROUND 256     // shares (chunks) a band workgroup queues at a time
-#ifndef BAND_SHIFT
-#define BAND_SHIFT 15
-#endif
-static_assert((1 << BAND_SHIFT) == BAND_PX, "BAND_PX is a power of two");
+// the records are binned by image bands of BIN_PX pixels; a band workgroup handles BAND_PX <= BIN_PX of them (its LDS band) and
+// filters its bin's records when the two differ
+#define BIN_SHIFT 15
+#define BIN_PX (1 << BIN_SHIFT)
+static_assert(BAND_PX <= BIN_PX && BIN_PX % BAND_PX == 0, "a band workgroup's pixels lie in one bin");
 static_assert((1 << PIX_CH_SHIFT) == PIX_PPT * PIX_THREADS, "chunk size");
 struct BandBins {
     uint32_t *counts;    // [chunk ids][nbe]
@@ -452,7 +453,7 @@ __device__ __forceinline__ void project_exact_record(const float *__restrict__ x
             if (rc.depth == 0.0f) {
                 flags[b] = mark; flags[B] = mark;
             } else {
-                const int band = rc.pix >> BAND_SHIFT;
+                const int band = rc.pix >> BIN_SHIFT;
                 const int64_t o0 = offs[b] - base, o1 = offs[b + 1] - base;
                 valid = true; pix = (uint32_t)rc.pix; dep = f2u(rc.depth);
                 bin = (uint32_t)(b * bb.nbe + band);
@@ -541,15 +542,15 @@ __global__ __launch_bounds__(PIX_THREADS) PIX_VGPR_ATTR void project_pix_kernel(
             const bool fast = project_point_fast(x[u], y[u], z[u], g, cfg, pix) && cfg.on && in;
             const float depth = sqrt_rn_normal(x[u] * x[u] + y[u] * y[u] + z[u] * z[u]);   // :446 (2^-92 <= the sum < 2^122 when `fast`: == sqrtf)
             // the record's slot in its band's run: the workgroup's LDS counter of the band (ds_add_rtn: the LDS pipe ranks, not the VALU)
-            const uint32_t band = (uint32_t)pix >> BAND_SHIFT;
+            const uint32_t band = (uint32_t)pix >> BIN_SHIFT;
             if (fast) {
                 const uint32_t xr = atomicAdd(&bcnt[band & (PIX_MAX_BANDS - 1)], 1u);
                 char *sh = reg + band * (uint32_t)SHARE_BYTES;   // 6 bytes per record: the depth bits and the pixel's offset in its band
 #if REC6
                 st_at(reinterpret_cast<uint32_t *>(sh), xr * 4u, f2u(depth));
-                st_at(reinterpret_cast<uint16_t *>(sh + SUB_CAP * 4), xr * 2u, (uint16_t)((uint32_t)pix & (BAND_PX - 1)));
+                st_at(reinterpret_cast<uint16_t *>(sh + SUB_CAP * 4), xr * 2u, (uint16_t)((uint32_t)pix & (BIN_PX - 1)));
 #else
-                st_at(reinterpret_cast<uint2 *>(sh), xr * 8u, make_uint2((uint32_t)pix & (BAND_PX - 1), f2u(depth)));
+                st_at(reinterpret_cast<uint2 *>(sh), xr * 8u, make_uint2((uint32_t)pix & (BIN_PX - 1), f2u(depth)));
 #endif
             }
             const bool slow = in && !fast;
@@ -669,16 +670,18 @@ __global__ __launch_bounds__(BAND_THREADS) BAND_VGPR_ATTR void project_band_kern
     if (b >= B) break;
     const int flagged = flags[b] == mark;
     const int64_t o0 = offs[b] - base, o1 = offs[b + 1] - base;
-    const uint32_t ocnt = bb.ocursor[b * bb.nbe + kband];        // records of the exact path
+    const int bin = (int)(((uint32_t)kband * BAND_PX) >> BIN_SHIFT);   // the record bin this band lies in
+    const uint32_t sub0 = ((uint32_t)kband * BAND_PX) & (BIN_PX - 1);  // the band's first pixel inside the bin
+    const uint32_t ocnt = bb.ocursor[b * bb.nbe + bin];          // records of the exact path
     const int64_t c0 = (o0 >> PIX_CH_SHIFT) + b;                   // the frame's chunk ids: c0 .. (o1 >> 11) + b
     const int S = (int)(((o1 >> PIX_CH_SHIFT) + b + 1) - c0);   // shares (one per chunk of the pixel kernel)
-    const int pairb = kband >> 1;
-    const uint32_t odd = (uint32_t)kband & 1u;
+    const int pairb = bin >> 1;
+    const uint32_t odd = (uint32_t)bin & 1u;
     const uint32_t band0 = (uint32_t)kband * BAND_PX;
     const uint32_t npx = min((uint32_t)BAND_PX, (uint32_t)P - band0);
     // (issued before the band is cleared: the latency passes under the LDS stores)
     uint32_t mycnt = 0u;
-    if ((int)threadIdx.x < min(S, BAND_ROUND) && !flagged) mycnt = min(bb.counts[(c0 + threadIdx.x) * bb.nbe + kband], (uint32_t)SUB_CAP);
+    if ((int)threadIdx.x < min(S, BAND_ROUND) && !flagged) mycnt = min(bb.counts[(c0 + threadIdx.x) * bb.nbe + bin], (uint32_t)SUB_CAP);
     if (threadIdx.x == 0) nslots = 0u;   // (every thread has read the previous item's value: a barrier lies between)
     if (flagged) continue;   // (workgroup-uniform) a frame with a depth-0 point: project_fixup_kernel
     // The band's records of a share are a run of 0 .. 2048 slots, read four at a time (16 bytes of depths + 8 bytes of pixels per lane),
@@ -688,7 +691,7 @@ __global__ __launch_bounds__(BAND_THREADS) BAND_VGPR_ATTR void project_band_kern
         if (g0) {
             __syncthreads();   // the previous round's queue is consumed
             if (threadIdx.x == 0) nslots = 0u;
-            mycnt = (int)threadIdx.x < min(S - g0, BAND_ROUND) ? min(bb.counts[(c0 + g0 + threadIdx.x) * bb.nbe + kband], (uint32_t)SUB_CAP) : 0u;
+            mycnt = (int)threadIdx.x < min(S - g0, BAND_ROUND) ? min(bb.counts[(c0 + g0 + threadIdx.x) * bb.nbe + bin], (uint32_t)SUB_CAP) : 0u;
         }
         __syncthreads();   // the band is cleared (the previous item's write-out is complete), the queue is empty
         if ((int)threadIdx.x < min(S - g0, BAND_ROUND)) {
@@ -699,7 +702,7 @@ __global__ __launch_bounds__(BAND_THREADS) BAND_VGPR_ATTR void project_band_kern
         }
         __syncthreads();
         const uint32_t ns = nslots;
-        const char *gl = bb.lists + ((c0 + g0) * bb.nbe + kband) * (int64_t)SHARE_BYTES;   // share 0 of the round
+        const char *gl = bb.lists + ((c0 + g0) * bb.nbe + bin) * (int64_t)SHARE_BYTES;   // share 0 of the round
         const uint32_t share_stride = (uint32_t)bb.nbe * SHARE_BYTES;
         for (uint32_t i = (threadIdx.x >> 6) * BAND_INFLIGHT; i < ns; i += (BAND_THREADS >> 6) * BAND_INFLIGHT) {
             uint4 dv[BAND_INFLIGHT];
@@ -725,10 +728,18 @@ __global__ __launch_bounds__(BAND_THREADS) BAND_VGPR_ATTR void project_band_kern
             }
 #pragma unroll
             for (int u = 0; u < BAND_INFLIGHT; u++) {
-                if (left[u] > 0u) atomicMin(&band[pv[u].x & 0xFFFFu], dv[u].x);
-                if (left[u] > 1u) atomicMin(&band[pv[u].x >> 16], dv[u].y);
-                if (left[u] > 2u) atomicMin(&band[pv[u].y & 0xFFFFu], dv[u].z);
-                if (left[u] > 3u) atomicMin(&band[pv[u].y >> 16], dv[u].w);
+                if (BAND_PX == BIN_PX) {
+                    if (left[u] > 0u) atomicMin(&band[pv[u].x & 0xFFFFu], dv[u].x);
+                    if (left[u] > 1u) atomicMin(&band[pv[u].x >> 16], dv[u].y);
+                    if (left[u] > 2u) atomicMin(&band[pv[u].y & 0xFFFFu], dv[u].z);
+                    if (left[u] > 3u) atomicMin(&band[pv[u].y >> 16], dv[u].w);
+                } else {   // the bin's records of the other bands fall outside [0, npx)
+                    const uint32_t r0 = (pv[u].x & 0xFFFFu) - sub0, r1 = (pv[u].x >> 16) - sub0, r2 = (pv[u].y & 0xFFFFu) - sub0, r3 = (pv[u].y >> 16) - sub0;
+                    if (left[u] > 0u && r0 < npx) atomicMin(&band[r0], dv[u].x);
+                    if (left[u] > 1u && r1 < npx) atomicMin(&band[r1], dv[u].y);
+                    if (left[u] > 2u && r2 < npx) atomicMin(&band[r2], dv[u].z);
+                    if (left[u] > 3u && r3 < npx) atomicMin(&band[r3], dv[u].w);
+                }
             }
         }
     }
@@ -866,7 +877,7 @@ __device__ void project_fixup_frame(const float *__restrict__ xyz, const int64_t
         if (__hip_atomic_load(&img[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == RI_EMPTY) img[p] = 0u;
 }
 
-static inline int band_bins_even(int P) { return (((P + BAND_PX - 1) / BAND_PX) + 1) & ~1; }   // bands per frame, rounded up to even
+static inline int band_bins_even(int P) { return (((P + BIN_PX - 1) / BIN_PX) + 1) & ~1; }   // record bins per frame, rounded up to even
 static inline int64_t pix_chunk_ids(int64_t total, int B) { return ((total > 0 ? total : 0) >> PIX_CH_SHIFT) + B; }
 static inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 static inline size_t project_small_bytes(int B, int P) { return align16(((size_t)B * ((size_t)P + 8)) * 4 + 256); }   // lastz + flags
