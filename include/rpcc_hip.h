@@ -60,8 +60,10 @@ typedef struct rpcc_geom {
  *   total    host                offsets[B]
  *   ri       dev f32 [B,P]  out  min positive depth per pixel, 0 where empty
  *   scratch  dev, scratch_bytes  work buffer (contents undefined on return).  With
- *            rpcc_project_scratch_bytes(total,B,P) bytes the LDS-band path runs; with at least
- *            B*(P+8)*4 bytes the device-atomic path runs (same result).
+ *            rpcc_project_scratch_bytes(total,B,P) bytes the LDS-band path runs (about 40 bytes of address
+ *            space per point for images of up to four 32768-pixel bands -- the records are binned by
+ *            chunk of 2048 points and band in fixed shares, 6 bytes per point are touched); with at least
+ *            B*(P+8)*4 bytes, or an image of more than eight bands, the device-atomic path runs (same result).
  * Exact reference semantics incl. a depth-0 point resetting its pixel in input order.  Points
  * whose depth is not finite are skipped (reference: undefined behaviour).
  * The pixel of a point is first computed by a screened fast path and recomputed with the exact
