@@ -189,6 +189,9 @@ def dry_run_rank(a, rank, world):
                           "per_rank_s": [round(float(t.item()), 4) for t in allt]}), flush=True)
 
 
+SETUP_ROUNDS = 8   # untimed runs of every pipeline slot before the warm-up steps (run_workload)
+
+
 def load_real_batch(path, ids, H, W, dev, shuffle=False):
     """The real sweep replicated: copy i = the frame rotated about z by a per-copy angle; the points keep the file's order (the
     scanner's: ring by ring) unless `shuffle`."""
@@ -265,6 +268,7 @@ def run_workload(a, ctx):
     gms_l = [torch.zeros((B, 4), dtype=torch.float64, device=dev) for _ in range(depth)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(depth)] if depth > 1 else [torch.cuda.current_stream()]
     timer = ops.FpsTimer()
+    timer.reserve(max(a.steps, a.warmup) + 8)   # hipEventCreate stays out of the timed region
     nu = ops.nonuniform_cfg(acc) if general else None    # compressor.yaml defaults (levels 30/10/3/0, +0/.02/.04/.06 m)
 
     if a.h2d:
@@ -313,11 +317,14 @@ def run_workload(a, ctx):
             dist.barrier()
         torch.cuda.synchronize()
 
-    # set-up (untimed, like the allocations above): touch every pipeline slot once so that stream creation, first-use
-    # kernel attribute calls and page faults of its buffers are not billed to a timed step
-    for k in range(depth):
-        with torch.cuda.stream(streams[k]):
-            run(k, xyz, timed=False)
+    # set-up (untimed, like the allocations above): every pipeline slot is run SETUP_ROUNDS times so that stream creation,
+    # first-use kernel attribute calls and page faults of its buffers are not billed to a timed step, and so that the GPU has
+    # left its idle power state before the W warm-up steps: with W = 5 alone a 20-step region measures 3-4 % below the
+    # steady state (0.825 against 0.795 ms per step; --warmup 30 shows the same).  Reported as config.setup_batches.
+    for _ in range(SETUP_ROUNDS):
+        for k in range(depth):
+            with torch.cuda.stream(streams[k]):
+                run(k, xyz, timed=False)
     torch.cuda.synchronize()
     if exchange:
         # one untimed trial of the exchange with a content check on rank 0 (its own frames must come back as they were
@@ -489,7 +496,8 @@ def run_workload(a, ctx):
                        + ("; " + exchange_note if exchange_note else ""),
                        "exchange": ("none" if not exchange else ("lengths+payloads" if a.gather_payloads else "lengths")),
                        "exchange_bytes_per_step": exchange_bytes if exchange else 0,
-                       "verified_frames_per_slot": (S if verified is not None else 0)},
+                       "verified_frames_per_slot": (S if verified is not None else 0),
+                       "setup_batches": SETUP_ROUNDS * depth},   # untimed, before the W warm-up steps (see run_workload)
             "roofline": roof,
         }
         if want_cpu:

@@ -312,9 +312,12 @@ int rpcc_debug_stamps(void *dev_i64_buffer);
 
 /* Timer objects for bench.py: a handle given in rpcc_batch_io.timer makes the call record hipEvents around its FPS
  * launch on the call's stream; rpcc_timer_read returns the accumulated milliseconds and the launch count since the
- * last read (synchronises the events).  One handle per measuring thread; the library keeps no global timing state. */
+ * last read (synchronises the events).  One handle per measuring thread; the library keeps no global timing state.
+ * rpcc_timer_reserve creates the events of the next `launches` timed launches ahead of time (event creation is not
+ * cheap and would otherwise fall into the caller's timed region). */
 void *rpcc_timer_create(void);
 void rpcc_timer_destroy(void *timer);
+int rpcc_timer_reserve(void *timer, int launches);
 int rpcc_timer_read(void *timer, double *ms, int *launches);
 
 #ifdef __cplusplus

@@ -86,6 +86,7 @@ _SIGS = {
     "rpcc_debug_stamps": (C.c_int, [_VP]),
     "rpcc_timer_create": (_VP, []),
     "rpcc_timer_destroy": (None, [_VP]),
+    "rpcc_timer_reserve": (C.c_int, [_VP, C.c_int]),
     "rpcc_timer_read": (C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
 }
 

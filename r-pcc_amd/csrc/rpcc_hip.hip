@@ -99,6 +99,21 @@ extern "C" void rpcc_timer_destroy(void *t) {
     for (size_t i = 0; i < tm->ev0.size(); i++) { (void)hipEventDestroy(tm->ev0[i]); (void)hipEventDestroy(tm->ev1[i]); }
     delete tm;
 }
+// creates the events of the next `launches` timed launches now (hipEventCreate is not cheap: without this the first use of
+// every slot pays for it inside the caller's timed region)
+extern "C" int rpcc_timer_reserve(void *t, int launches) {
+    rpcc_timer *tm = reinterpret_cast<rpcc_timer *>(t);
+    ARG_TRY(tm != nullptr && launches >= 0 && launches <= (1 << 20));
+    std::lock_guard<std::mutex> lk(tm->mu);
+    while (tm->ev0.size() < (size_t)launches) {
+        hipEvent_t a, b;
+        HIP_TRY(hipEventCreate(&a));
+        HIP_TRY(hipEventCreate(&b));
+        tm->ev0.push_back(a);
+        tm->ev1.push_back(b);
+    }
+    return RPCC_OK;
+}
 extern "C" int rpcc_timer_read(void *t, double *ms, int *launches) {
     rpcc_timer *tm = reinterpret_cast<rpcc_timer *>(t);
     ARG_TRY(tm != nullptr);

@@ -320,6 +320,10 @@ class FpsTimer:
         self.h = C.c_void_p(_lib.lib().rpcc_timer_create())
         assert self.h.value, "rpcc_timer_create failed"
 
+    def reserve(self, launches):
+        """Create the events of the next `launches` timed launches now (outside the caller's timed region)."""
+        check(_lib.lib().rpcc_timer_reserve(self.h, int(launches)))
+
     def read(self):
         """-> (accumulated ms, launches) since the last read; synchronises the recorded events."""
         ms, n = C.c_double(0), C.c_int(0)
