@@ -480,6 +480,22 @@ __device__ __forceinline__ void project_exact_record(const float *__restrict__ x
     bin_append_any(valid, bin, ostart, cap, pix, dep, bb);
 }
 
+// the batch's small initialisations, grid-stride over nthr threads (this thread: t)
+__device__ __forceinline__ void batch_init(const BatchInit &init, int nthr, int t) {
+    for (int p = t; p < init.P; p += nthr) {
+        init.soa[p] = init.tm[3 * p]; init.soa[init.P + p] = init.tm[3 * p + 1]; init.soa[2 * (int64_t)init.P + p] = init.tm[3 * p + 2];
+    }
+    for (int p = t; p < init.B; p += nthr) {
+        init.info[RPCC_INFO * p] = 0; init.info[RPCC_INFO * p + 1] = init.P; init.info[RPCC_INFO * p + 2] = 0; init.info[RPCC_INFO * p + 3] = 0;
+        init.info[RPCC_INFO * p + 4] = init.P; init.info[RPCC_INFO * p + 5] = 0; init.info[RPCC_INFO * p + 6] = 0; init.info[RPCC_INFO * p + 7] = 0;
+    }
+    for (int p = t; p < init.z0.n; p += nthr) init.z0.p[p] = 0u;
+    for (int p = t; p < init.z1.n; p += nthr) init.z1.p[p] = 0u;
+    for (int p = t; p < init.z2.n; p += nthr) init.z2.p[p] = 0u;
+}
+// (the device-atomic projection path has no pixel kernel to carry the initialisations)
+__global__ __launch_bounds__(256) void batch_init_kernel(BatchInit init) { batch_init(init, gridDim.x * 256, blockIdx.x * 256 + threadIdx.x); }
+
 #ifndef PIX_VGPR_ATTR
 #define PIX_VGPR_ATTR
 #endif
@@ -493,19 +509,7 @@ __global__ __launch_bounds__(PIX_THREADS) PIX_VGPR_ATTR void project_pix_kernel(
     if (threadIdx.x == 0) qn = 0u;
     if (threadIdx.x < PIX_MAX_BANDS) bcnt[threadIdx.x] = 0u;
     const int mark = flag_mark(epoch);
-    if (init.on) {   // the batch's small initialisations (grid-stride; nothing of it is read by this launch)
-        const int nthr = gridDim.x * PIX_THREADS;
-        for (int p = blockIdx.x * PIX_THREADS + threadIdx.x; p < init.P; p += nthr) {
-            init.soa[p] = init.tm[3 * p]; init.soa[init.P + p] = init.tm[3 * p + 1]; init.soa[2 * (int64_t)init.P + p] = init.tm[3 * p + 2];
-        }
-        for (int p = blockIdx.x * PIX_THREADS + threadIdx.x; p < init.B; p += nthr) {
-            init.info[RPCC_INFO * p] = 0; init.info[RPCC_INFO * p + 1] = init.P; init.info[RPCC_INFO * p + 2] = 0; init.info[RPCC_INFO * p + 3] = 0;
-            init.info[RPCC_INFO * p + 4] = init.P; init.info[RPCC_INFO * p + 5] = 0; init.info[RPCC_INFO * p + 6] = 0; init.info[RPCC_INFO * p + 7] = 0;
-        }
-        for (int p = blockIdx.x * PIX_THREADS + threadIdx.x; p < init.z0.n; p += nthr) init.z0.p[p] = 0u;
-        for (int p = blockIdx.x * PIX_THREADS + threadIdx.x; p < init.z1.n; p += nthr) init.z1.p[p] = 0u;
-        for (int p = blockIdx.x * PIX_THREADS + threadIdx.x; p < init.z2.n; p += nthr) init.z2.p[p] = 0u;
-    }
+    if (init.on) batch_init(init, gridDim.x * PIX_THREADS, blockIdx.x * PIX_THREADS + threadIdx.x);   // (nothing of it is read by this launch)
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -930,7 +934,11 @@ static int launch_project(const float *xyz, const int64_t *offsets, int64_t tota
     BandBins bb;
     bb.nbe = band_bins_even(P);
     // the binned path: room for the lists, a counter per band and wavefront in the pixel kernel's LDS
+#ifdef PROJECT_FORCE_ATOMIC   // (experiment: the device-atomic path inside the fused batch)
+    const bool fast = false;
+#else
     const bool fast = scratch_bytes >= project_scratch_bytes(total, B, P) && bb.nbe <= PIX_MAX_BANDS;
+#endif
     if (fast) {
         char *q = reinterpret_cast<char *>(scratch) + project_small_bytes(B, P);
         bb.ocursor = reinterpret_cast<uint32_t *>(q); q += project_cursor_bytes(B, P);
@@ -957,6 +965,7 @@ static int launch_project(const float *xyz, const int64_t *offsets, int64_t tota
         return RPCC_OK;
     }
     if (zcnt && !cleared) HIP_TRY(hipMemsetAsync(zcnt, 0, (size_t)B * (RS_CHUNKS + 1) * 4, st));
+    if (init && init->on) batch_init_kernel<<<256, 256, 0, st>>>(*init);   // (clears zcnt: the RANSAC kernel counts for itself)
     project_fill_kernel<false><<<fg, 256, 0, st>>>(rb, lastz, flags, P);
     LAUNCH_CHECK();
     if (total > 0) {

@@ -876,11 +876,12 @@ def test_projection_fast_path_never_disagrees(env, gname):
     assert tot_sure > 0
 
 
-@pytest.mark.parametrize("H,W,M", [(5, 300, 7), (8, 512, 20), (33, 1000, 100), (16, 4000, 50)])
+@pytest.mark.parametrize("H,W,M", [(5, 300, 7), (8, 512, 20), (33, 1000, 100), (16, 4000, 50), (128, 2048, 30), (128, 4096, 30)])
 def test_odd_geometries_fused(env, H, W, M):
     """Fused entry (ground fit inside) on image shapes that are no multiple of any tile size the kernels use
     (4x32 FPS / assign tiles, 1024-pixel scatter tiles, 32768-pixel projection bands, RANSAC chunks), with
-    cluster counts from 7 to 100: every output equals the oracle's."""
+    cluster counts from 7 to 100, and on images of 8 record bins (the binned projection's limit) and of 16 (the fused entry
+    then projects with device atomics and a separate initialisation launch): every output equals the oracle's."""
     torch, ops, orc, synth = env["torch"], env["ops"], env["orc"], env["synth"]
     g = orc.LidarGeom(H, W, 360.0, 3.0, -25.0)
     tm = ops.transform_map(g.H, g.W, g.horizontal_FOV, g.vertical_max, g.vertical_min)
