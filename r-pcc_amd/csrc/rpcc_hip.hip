@@ -950,8 +950,8 @@ static int launch_project(const float *xyz, const int64_t *offsets, int64_t tota
         BatchInit bi;
         memset(&bi, 0, sizeof(bi));
         if (init) bi = *init;
-        if (total > 0 || bi.on)
-            project_pix_kernel<<<(unsigned)std::max<int64_t>(std::min<int64_t>(pix_chunk_ids(total, B), 256 * 16), 1), PIX_THREADS, 0, st>>>(
+        // (also for a batch without points: every chunk id's share counts are written by this kernel, the band kernel reads them)
+        project_pix_kernel<<<(unsigned)std::max<int64_t>(std::min<int64_t>(pix_chunk_ids(total, B), 256 * 16), 1), PIX_THREADS, 0, st>>>(
                 xyz, offsets, total, base, B, g, pix_fast_cfg(g), bb, flags, epoch, bi);
         HIP_TRY(ensure_dyn_lds(reinterpret_cast<const void *>(&project_band_kernel), BAND_PX * 4));
         if (zcnt && !cleared) HIP_TRY(hipMemsetAsync(zcnt, 0, (size_t)B * (RS_CHUNKS + 1) * 4, st));

@@ -176,6 +176,8 @@ def test_projection_record_bins(env):
     # 1. sizes around the chunk size (2048) and its multiples, empty frames first, in the middle and last
     sizes = [0, 0, 1, 2047, 2048, 2049, 0, 4095, 4096, 4097, 63, 64, 65, 1, 0, 6000, 3, 0]
     check([cloud(n) for n in sizes], g, geom, "ragged")
+    # 1b. a batch without any point
+    check([np.zeros((0, 3), np.float32)] * 5, g, geom, "no points")
     # 2. many tiny frames (several per chunk of points)
     check([cloud(int(n)) for n in rng.integers(0, 300, 200)], g, geom, "tiny")
     # 3. a frame of more than 256 chunks (two rounds of the band kernel's queue) next to a small one
