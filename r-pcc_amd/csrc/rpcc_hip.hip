@@ -496,6 +496,9 @@ __device__ __forceinline__ void batch_init(const BatchInit &init, int nthr, int 
 // (the device-atomic projection path has no pixel kernel to carry the initialisations)
 __global__ __launch_bounds__(256) void batch_init_kernel(BatchInit init) { batch_init(init, gridDim.x * 256, blockIdx.x * 256 + threadIdx.x); }
 
+#ifndef PIX_WG_PER_CU
+#define PIX_WG_PER_CU 16   // grid = 256 x this many persistent workgroups (6 / 8 / 32 measured: kernel alone 126 / 126 / 117 against 120 us, no change in flight)
+#endif
 #ifndef PIX_VGPR_ATTR
 #define PIX_VGPR_ATTR
 #endif
@@ -951,7 +954,7 @@ static int launch_project(const float *xyz, const int64_t *offsets, int64_t tota
         memset(&bi, 0, sizeof(bi));
         if (init) bi = *init;
         // (also for a batch without points: every chunk id's share counts are written by this kernel, the band kernel reads them)
-        project_pix_kernel<<<(unsigned)std::max<int64_t>(std::min<int64_t>(pix_chunk_ids(total, B), 256 * 16), 1), PIX_THREADS, 0, st>>>(
+        project_pix_kernel<<<(unsigned)std::max<int64_t>(std::min<int64_t>(pix_chunk_ids(total, B), 256 * PIX_WG_PER_CU), 1), PIX_THREADS, 0, st>>>(
                 xyz, offsets, total, base, B, g, pix_fast_cfg(g), bb, flags, epoch, bi);
         HIP_TRY(ensure_dyn_lds(reinterpret_cast<const void *>(&project_band_kernel), BAND_PX * 4));
         if (zcnt && !cleared) HIP_TRY(hipMemsetAsync(zcnt, 0, (size_t)B * (RS_CHUNKS + 1) * 4, st));
