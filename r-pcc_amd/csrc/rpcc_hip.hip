@@ -1150,7 +1150,8 @@ __device__ int ransac_plane_wg(const PTS &pts, int iters, double thr, uint32_t s
             pf[q][3] = rfl_f32(ok ? hyp[5 * hh + 3] : __builtin_inff());  // workgroup-uniform: scalar registers
             cnt[q] = 0;
         }
-        for (int i0 = tid; i0 < n; i0 += NTH * RS_PU) {
+        for (int ib = 0; ib < n; ib += NTH * RS_PU) {   // (workgroup-uniform trip count)
+            const int i0 = ib + tid;
             float x[RS_PU], y[RS_PU], z[RS_PU];
 #pragma unroll
             for (int u = 0; u < RS_PU; u++) pts.getf(min(i0 + NTH * u, n - 1), x[u], y[u], z[u]);
@@ -1194,7 +1195,9 @@ __device__ int ransac_plane_wg(const PTS &pts, int iters, double thr, uint32_t s
             pf[q][3] = ok ? hyp[5 * hh + 3] : __builtin_inff();  // invalid -> never an inlier
             cnt[q] = 0;
         }
-        for (int i0 = lane; i0 < n; i0 += 64 * RS_PU) {  // RS_PU points per lane in flight (unconditional, clamped loads)
+        // (wave-uniform trip count: with a per-lane bound the loop is divergent and the scalar counters are copied to VGPRs at every exit test)
+        for (int ib = 0; ib < n; ib += 64 * RS_PU) {  // RS_PU points per lane in flight (unconditional, clamped loads)
+            const int i0 = ib + lane;
             float x[RS_PU], y[RS_PU], z[RS_PU];
 #pragma unroll
             for (int u = 0; u < RS_PU; u++) pts.getf(min(i0 + 64 * u, n - 1), x[u], y[u], z[u]);
@@ -1299,6 +1302,9 @@ __device__ __forceinline__ uint32_t udiv32(uint32_t a, const UDiv32 u) {
 }
 
 #define RS_CU 16  // pixels per lane in flight during the compaction pass
+#ifndef RS_GROUND_PU
+#define RS_GROUND_PU 4   // candidates per lane in flight in the scoring loop (LDS reads; 1 / 2 / 4: 108.5 / 106.9 / 105.3 us)
+#endif
 __global__ __launch_bounds__(RS_THREADS) void ground_ransac_kernel(const float *__restrict__ ri_all,
                                                                    const float *__restrict__ tm, int P, float zthr,
                                                                    int max_pts, int min_pts, int ransac_n, int iters,
@@ -1397,7 +1403,7 @@ __global__ __launch_bounds__(RS_THREADS) void ground_ransac_kernel(const float *
     (void)ransac_n;  // the ground fit samples 10 points (utils/segment_utils.py:75)
     // the frame's seed follows its identity (datalist index), not its position in the batch
     const uint32_t fid = frame_ids ? (uint32_t)frame_ids[b] : (uint32_t)b;
-    const int inl = ransac_plane_wg<10, RS_THREADS, RS_MAX_HYP, 1>(pts, iters, thr, seed0 + fid, plane, sred, swin, sbest);
+    const int inl = ransac_plane_wg<10, RS_THREADS, RS_MAX_HYP, RS_GROUND_PU, RsPoints, false, 1>(pts, iters, thr, seed0 + fid, plane, sred, swin, sbest);
     DBG_STAMP(6);
     if (tid == 0) {
         ground[4 * b] = plane[0]; ground[4 * b + 1] = plane[1]; ground[4 * b + 2] = plane[2]; ground[4 * b + 3] = plane[3];

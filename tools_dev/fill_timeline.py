@@ -27,8 +27,13 @@ gms = [torch.zeros((B, 4), dtype=torch.float64, device=dev) for _ in range(depth
 streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
 
 
+timer = ops.FpsTimer() if os.environ.get("FILL_TIMER") else None   # (FILL_TIMER=1: with the bench's HIP events around every FPS launch)
+if timer is not None:
+    timer.reserve(4096)
+
+
 def run(k):
-    ops.compress_batch(xyz, offs, tm, gms[k], bufs[k], ground_threshold=0.1, acc=0.02, ground_seed=0, frame_ids=fid)
+    ops.compress_batch(xyz, offs, tm, gms[k], bufs[k], ground_threshold=0.1, acc=0.02, ground_seed=0, frame_ids=fid, timer=timer)
 
 
 for k in range(depth):
@@ -47,6 +52,8 @@ def region(stagger_ms, steps):
             with torch.cuda.stream(streams[k]):
                 run(k)
     torch.cuda.synchronize()
+    if timer is not None:
+        timer.read()
     start = torch.cuda.Event(enable_timing=True)
     ev = []
     w0 = time.perf_counter()
@@ -68,7 +75,7 @@ def region(stagger_ms, steps):
     return wall, done
 
 
-for stagger in (0.0, 0.15, 0.27, 0.40):
+for stagger in ((0.0,) if os.environ.get("FILL_ONLY0") else (0.0, 0.15, 0.27, 0.40)):
     walls = []
     for rep in range(3):
         wall, done = region(stagger, K)
