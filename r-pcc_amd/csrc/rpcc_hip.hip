@@ -500,7 +500,7 @@ __global__ __launch_bounds__(256) void batch_init_kernel(BatchInit init) { batch
 #define PIX_WG_PER_CU 16   // grid = 256 x this many persistent workgroups (6 / 8 / 32 measured: kernel alone 126 / 126 / 117 against 120 us, no change in flight)
 #endif
 #ifndef PIX_VGPR_ATTR
-#define PIX_VGPR_ATTR
+#define PIX_VGPR_ATTR __attribute__((amdgpu_waves_per_eu(6, 8)))   // 80 VGPRs (81 without: one wavefront per SIMD less)
 #endif
 __global__ __launch_bounds__(PIX_THREADS) PIX_VGPR_ATTR void project_pix_kernel(const float *__restrict__ xyz, const int64_t *__restrict__ offs,
                                                                   int64_t total, int64_t base, int B, rpcc_geom g, PixFastCfg cfg,
@@ -567,12 +567,12 @@ __global__ __launch_bounds__(PIX_THREADS) PIX_VGPR_ATTR void project_pix_kernel(
             const uint32_t band = (uint32_t)pix >> BIN_SHIFT;
             if (fast) {
                 const uint32_t xr = atomicAdd(&bcnt[band & (PIX_MAX_BANDS - 1)], 1u);
-                char *sh = reg + band * (uint32_t)SHARE_BYTES;   // 6 bytes per record: the depth bits and the pixel's offset in its band
-#if REC6
-                st_at(reinterpret_cast<uint32_t *>(sh), xr * 4u, f2u(depth));
-                st_at(reinterpret_cast<uint16_t *>(sh + SUB_CAP * 4), xr * 2u, (uint16_t)((uint32_t)pix & (BIN_PX - 1)));
+                const uint32_t so = band * (uint32_t)SHARE_BYTES;   // (32-bit offsets from the chunk's wave-uniform base: scalar-base stores)
+#if REC6   // 6 bytes per record: the depth bits and the pixel's offset in its band
+                st_at(reinterpret_cast<uint32_t *>(reg), so + xr * 4u, f2u(depth));
+                st_at(reinterpret_cast<uint16_t *>(reg), so + (uint32_t)(SUB_CAP * 4) + xr * 2u, (uint16_t)((uint32_t)pix & (BIN_PX - 1)));
 #else
-                st_at(reinterpret_cast<uint2 *>(sh), xr * 8u, make_uint2((uint32_t)pix & (BIN_PX - 1), f2u(depth)));
+                st_at(reinterpret_cast<uint2 *>(reg), so + xr * 8u, make_uint2((uint32_t)pix & (BIN_PX - 1), f2u(depth)));
 #endif
             }
             const bool slow = in && !fast;
