@@ -83,11 +83,23 @@ __device__ __forceinline__ void fps_quad_xyz(const FpsQuad &q, bool range, float
 }
 
 // loads of one lane's quad: src = range image (RANGE) or xyz list; rays = [P,3] table (RANGE)
-template <bool RANGE, bool VEC>
+// SOA (RANGE, VEC): rays = the planar copy [3][n_plane] of the table -- the three 16-byte loads share the offset of the range /
+// temp loads (no multiplication by 12) and return the four pixels' x, y, z as register pairs (no re-packing for packed fp32)
+template <bool RANGE, bool VEC, bool SOA = false>
 __device__ __forceinline__ void fps_quad_load(const float *__restrict__ src, const float *__restrict__ rays,
-                                              const float *__restrict__ temp, FpsQuad &q) {
+                                              const float *__restrict__ temp, FpsQuad &q, int n_plane = 0) {
     const uint32_t p0 = (uint32_t)q.p0;
-    if (VEC) {  // 16-byte loads at wave-uniform base + 32-bit byte offset
+    if (VEC && RANGE && SOA) {
+        const float4 tp = ld_at(reinterpret_cast<const float4 *>(temp), p0 * 4u);
+        q.tp[0] = tp.x; q.tp[1] = tp.y; q.tp[2] = tp.z; q.tp[3] = tp.w;
+        const float4 a = ld_at(reinterpret_cast<const float4 *>(rays), p0 * 4u);
+        const float4 b = ld_at(reinterpret_cast<const float4 *>(rays + n_plane), p0 * 4u);
+        const float4 c = ld_at(reinterpret_cast<const float4 *>(rays + 2 * (size_t)n_plane), p0 * 4u);
+        q.t[0] = a.x; q.t[3] = a.y; q.t[6] = a.z; q.t[9] = a.w; q.t[1] = b.x; q.t[4] = b.y; q.t[7] = b.z; q.t[10] = b.w;
+        q.t[2] = c.x; q.t[5] = c.y; q.t[8] = c.z; q.t[11] = c.w;
+        const float4 r = ld_at(reinterpret_cast<const float4 *>(src), p0 * 4u);
+        q.r[0] = r.x; q.r[1] = r.y; q.r[2] = r.z; q.r[3] = r.w;
+    } else if (VEC) {  // 16-byte loads at wave-uniform base + 32-bit byte offset
         const float4 tp = ld_at(reinterpret_cast<const float4 *>(temp), p0 * 4u);
         q.tp[0] = tp.x; q.tp[1] = tp.y; q.tp[2] = tp.z; q.tp[3] = tp.w;
         const float *tb = RANGE ? rays : src;
@@ -492,13 +504,14 @@ __device__ __forceinline__ bool fps_tile_update(const FpsQuad &q, bool org_on, f
 }
 
 #ifndef FPS_VGPR_ATTR
-#define FPS_VGPR_ATTR
+#define FPS_VGPR_ATTR __attribute__((amdgpu_waves_per_eu(5, 8)))   // at most 96 VGPRs: with 98 the kernel is 2 % faster alone and the step 2 % slower
 #endif
-template <bool RANGE, bool VEC, int FPS_TT>
+template <bool RANGE, bool VEC, int FPS_TT, bool SOA = false>
 __global__ __launch_bounds__(FPS_TT) FPS_VGPR_ATTR void fps_regtab_kernel(const float *__restrict__ src, const float *__restrict__ rays,
                                                             float *__restrict__ temp, const int32_t *__restrict__ info,
                                                             FpsTiling g, int M, int flags, int32_t *__restrict__ out_idx,
-                                                            float *__restrict__ out_cen, const float *__restrict__ tiletab) {
+                                                            float *__restrict__ out_cen, const float *__restrict__ tiletab,
+                                                            const float *__restrict__ rays_soa = nullptr) {
     constexpr int NW = FPS_TT / 64;
     RPCC_SET_LAT_PRIO();
 #ifdef RPCC_DEVTRACE   // developer trace: wall clock (100 MHz) at the start and the end of every workgroup -> stamps[2048 + 2 b ..]
@@ -579,6 +592,9 @@ __global__ __launch_bounds__(FPS_TT) FPS_VGPR_ATTR void fps_regtab_kernel(const 
         }
     };
     // visits the tiles of the lanes in mask m, FPS_VISIT = 2 at a time (all loads of a pair are in flight before either is used).
+    // REGISTERS: the kernel must stay at or below 96 VGPRs (FPS_VGPR_ATTR).  Round 3 found that every variant that was "faster
+    // alone, slower with batches in flight" (the second tile loaded only when present, the planar ray table, round 2's
+    // software-pipelined visits) had crossed that line by two registers; capped, they are faster in flight too.
     // Larger groups -- three or four tiles' loads in flight, so that the wavefront that owns most of the changed tiles pays one
     // memory latency instead of two -- were measured in round 3 (with and without loads for absent tiles): 292 / 298 us alone
     // against 273 us (139 instead of 96 VGPRs), and 7-11 % fewer frames/s with batches in flight.  (Round 2 had measured
@@ -587,7 +603,7 @@ __global__ __launch_bounds__(FPS_TT) FPS_VGPR_ATTR void fps_regtab_kernel(const 
 #define FPS_VISIT 2
 #endif
 #ifndef FPS_VISIT_UNCOND
-#define FPS_VISIT_UNCOND 2   // (1: the second tile's loads only when there is one -- 3 % faster alone, 2 % slower with batches in flight)
+#define FPS_VISIT_UNCOND 1   // tiles of a round loaded unconditionally; the second tile's loads are issued only when there is one
 #endif
 #ifdef RPCC_DEVTRACE
     long long vacc[4] = {0, 0, 0, 0};   // visit rounds: cycles issuing the loads / waiting for the data / updating, rounds
@@ -608,7 +624,7 @@ __global__ __launch_bounds__(FPS_TT) FPS_VGPR_ATTR void fps_regtab_kernel(const 
                 m &= m - 1ull;     // (0 & anything stays 0)
                 if (u < FPS_VISIT_UNCOND || on[u]) {   // (wave-uniform) the first pair unconditionally, the rest only when there is a tile
                     locate(l[u], q[u]);
-                    fps_quad_load<RANGE, VEC>(src, rays, temp, q[u]);
+                    fps_quad_load<RANGE, VEC, SOA>(src, SOA ? rays_soa : rays, temp, q[u], N);
                 }
             }
 #ifdef RPCC_DEVTRACE

@@ -1767,13 +1767,20 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_modes_kernel(const float *__r
 
 template <bool RANGE>
 static int launch_fps_tiled(const float *src, const float *rays, float *temp, const int32_t *info, int B, const FpsTiling &g,
-                            int M, int kflags, int32_t *idx, float *cen, const float *tiletab, bool vec, hipStream_t st) {
+                            int M, int kflags, int32_t *idx, float *cen, const float *tiletab, bool vec, hipStream_t st,
+                            const float *rays_soa = nullptr) {
     const size_t sh = fps_tiled_lds_bytes(g.T);
     // register-table form: every tile owned by one lane (at most 64 tiles per wavefront)
 #define FPS_RT_LAUNCH(VEC_, TT_) fps_regtab_kernel<RANGE, VEC_, TT_><<<B, TT_, 0, st>>>(src, rays, temp, info, g, M, kflags, idx, cen, tiletab)
 #ifndef FPS_NO_REGTAB
     {
         const int tt = B <= 128 ? FPS_TT_SMALL : FPS_TT_BATCH;
+        if constexpr (RANGE) if (g.T <= tt && vec && rays_soa != nullptr) {   // planar copy of the ray table (the fused batch has one)
+            if (B <= 128) fps_regtab_kernel<RANGE, true, FPS_TT_SMALL, true><<<B, FPS_TT_SMALL, 0, st>>>(src, rays, temp, info, g, M, kflags, idx, cen, tiletab, rays_soa);
+            else          fps_regtab_kernel<RANGE, true, FPS_TT_BATCH, true><<<B, FPS_TT_BATCH, 0, st>>>(src, rays, temp, info, g, M, kflags, idx, cen, tiletab, rays_soa);
+            LAUNCH_CHECK();
+            return RPCC_OK;
+        }
         if (g.T <= tt) {
             if (B <= 128) { if (vec) FPS_RT_LAUNCH(true, FPS_TT_SMALL); else FPS_RT_LAUNCH(false, FPS_TT_SMALL); }
             else          { if (vec) FPS_RT_LAUNCH(true, FPS_TT_BATCH); else FPS_RT_LAUNCH(false, FPS_TT_BATCH); }
@@ -1795,6 +1802,9 @@ static int launch_fps_tiled(const float *src, const float *rays, float *temp, co
     return RPCC_OK;
 }
 
+#ifndef FPS_SOA
+#define FPS_SOA 1   // the fused batch hands the planar copy of the ray table to the FPS kernel
+#endif
 #define RPCC_FPS_MODE_BITS (RPCC_FPS_FMA1 | RPCC_FPS_FMA2 | RPCC_FPS_TIE_CUDA)
 static inline int fps_fma_of(int flags) { return (flags & RPCC_FPS_FMA1) ? 1 : (flags & RPCC_FPS_FMA2) ? 2 : 0; }
 
@@ -1830,7 +1840,7 @@ extern "C" int rpcc_fps_xyz_mode(int B, int N, int M, const float *points, float
 // flags: RPCC_FPS_BRUTEFORCE -> the one-pass-per-centre kernel; finalize_temp: temp is read by the caller afterwards
 static int launch_fps_range(const float *ri, const float *tm, float *temp, const int32_t *info, int B, int H, int W, int M,
                             int32_t *cen_pix, float *centers, int flags, bool finalize_temp, const float *tiletab,
-                            void *timer, hipStream_t st) {
+                            void *timer, hipStream_t st, const float *rays_soa = nullptr) {
     const int P = H * W;
     const FpsTiling g = fps_tiling_range(H, W);
     const bool brute = (flags & RPCC_FPS_BRUTEFORCE) != 0;
@@ -1847,7 +1857,7 @@ static int launch_fps_range(const float *ri, const float *tm, float *temp, const
         const bool vec = (W % 4 == 0) && aligned16(ri) && aligned16(temp) && aligned16(tm);
         FpsTimer tmr(st, timer);
         return launch_fps_tiled<true>(ri, tm, temp, info, B, g, M, finalize_temp ? FPS_FLAG_FINALIZE_TEMP : 0, cen_pix, centers,
-                                      tiletab, vec, st);
+                                      tiletab, vec, st, rays_soa);
     }
     if (tiletab != nullptr && !brute)
         return set_err(RPCC_ERR_ARG, "fps_range: an FPS table was produced but the tiled kernel cannot run (image too large)%s%s");
@@ -2793,7 +2803,7 @@ static int run_batch(const rpcc_batch_io *io, int Bs, int64_t npts, rpcc_geom g,
                                  tiled ? tiletab : nullptr, st, false, true)))
         return rc;
     if ((rc = launch_fps_range(ri, io->tm, temp, info, Bs, g.H, g.W, M, io->cen_pix, io->centers, io->flags, false,
-                               tiled ? tiletab : nullptr, io->timer, st)))
+                               tiled ? tiletab : nullptr, io->timer, st, FPS_SOA ? rays_soa : nullptr)))
         return rc;
     if ((rc = launch_assign(ri, io->tm, ground, io->centers, Bs, g.H, g.W, M, io->seg, st))) return rc;
     if (io->model_method == 0) {
