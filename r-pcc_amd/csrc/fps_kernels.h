@@ -790,8 +790,11 @@ __global__ __launch_bounds__(FPS_TT) FPS_VGPR_ATTR void fps_regtab_kernel(const 
 // info[b][4] = first empty pixel that is a candidate (the representative of the FPS kernel's origin class).
 // ------------------------------------------------------------------------------------------------
 #define TAB_TPW 2
+#ifndef MASK_VGPR_ATTR
+#define MASK_VGPR_ATTR
+#endif
 template <bool RAW, bool VEC>
-__global__ __launch_bounds__(256) void ground_mask_tab_kernel(float *__restrict__ ri, const float *__restrict__ tm,
+__global__ __launch_bounds__(256) MASK_VGPR_ATTR void ground_mask_tab_kernel(float *__restrict__ ri, const float *__restrict__ tm,
                                                               const double *__restrict__ ground, double thr, FpsTiling g,
                                                               float *__restrict__ temp, int32_t *__restrict__ info,
                                                               float *__restrict__ tiletab) {
