@@ -1302,6 +1302,9 @@ __device__ __forceinline__ uint32_t udiv32(uint32_t a, const UDiv32 u) {
 }
 
 #define RS_CU 16  // pixels per lane in flight during the compaction pass
+// hypotheses the ground fit's scoring is compiled for: 100 iterations over 8 wavefronts = 13 slots per wavefront (with RS_MAX_HYP = 128
+// every wavefront evaluated 16, three of them always invalid)
+#define RS_GROUND_MAXH 104
 #ifndef RS_GROUND_PU
 #define RS_GROUND_PU 4   // candidates per lane in flight in the scoring loop (LDS reads; 1 / 2 / 4: 108.5 / 106.9 / 105.3 us)
 #endif
@@ -1406,7 +1409,7 @@ __global__ __launch_bounds__(RS_THREADS) RS_VGPR_ATTR void ground_ransac_kernel(
     (void)ransac_n;  // the ground fit samples 10 points (utils/segment_utils.py:75)
     // the frame's seed follows its identity (datalist index), not its position in the batch
     const uint32_t fid = frame_ids ? (uint32_t)frame_ids[b] : (uint32_t)b;
-    const int inl = ransac_plane_wg<10, RS_THREADS, RS_MAX_HYP, RS_GROUND_PU, RsPoints, false, 1>(pts, iters, thr, seed0 + fid, plane, sred, swin, sbest);
+    const int inl = ransac_plane_wg<10, RS_THREADS, RS_GROUND_MAXH, RS_GROUND_PU, RsPoints, false, 1>(pts, iters, thr, seed0 + fid, plane, sred, swin, sbest);
     DBG_STAMP(6);
     if (tid == 0) {
         ground[4 * b] = plane[0]; ground[4 * b + 1] = plane[1]; ground[4 * b + 2] = plane[2]; ground[4 * b + 3] = plane[3];
