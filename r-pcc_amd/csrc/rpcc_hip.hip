@@ -1301,7 +1301,9 @@ __device__ __forceinline__ uint32_t udiv32(uint32_t a, const UDiv32 u) {
     return (((a - q) >> 1) + q) >> u.shift;
 }
 
+#ifndef RS_CU
 #define RS_CU 16  // pixels per lane in flight during the compaction pass
+#endif
 // hypotheses the ground fit's scoring is compiled for: 100 iterations over 8 wavefronts = 13 slots per wavefront (with RS_MAX_HYP = 128
 // every wavefront evaluated 16, three of them always invalid)
 #define RS_GROUND_MAXH 104
