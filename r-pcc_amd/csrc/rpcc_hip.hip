@@ -506,7 +506,7 @@ __global__ __launch_bounds__(PIX_THREADS) PIX_VGPR_ATTR void project_pix_kernel(
                                                                   int64_t total, int64_t base, int B, rpcc_geom g, PixFastCfg cfg,
                                                                   BandBins bb, int32_t *__restrict__ flags,
                                                                   const int32_t *__restrict__ epoch, BatchInit init) {
-    __shared__ int64_t queue[(PIX_PPT + 1) * PIX_THREADS];
+    __shared__ uint32_t queue[(PIX_PPT + 1) * PIX_THREADS];   // launch-relative point indices (launch_project: total < 2^32)
     __shared__ uint32_t qn;
     __shared__ uint32_t bcnt[PIX_MAX_BANDS];   // records per band of the chunk so far
     if (threadIdx.x == 0) qn = 0u;
@@ -582,7 +582,7 @@ __global__ __launch_bounds__(PIX_THREADS) PIX_VGPR_ATTR void project_pix_kernel(
                 uint32_t q0 = 0u;
                 if (lane == leader) q0 = atomicAdd(&qn, (uint32_t)__popcll(sm));
                 q0 = (uint32_t)__builtin_amdgcn_readlane((int)q0, leader);
-                if (slow) queue[q0 + __popcll(sm & lt)] = il0 + ci;
+                if (slow) queue[q0 + __popcll(sm & lt)] = (uint32_t)(il0 + ci);
             }
         }
         __syncthreads();
@@ -591,7 +591,7 @@ __global__ __launch_bounds__(PIX_THREADS) PIX_VGPR_ATTR void project_pix_kernel(
         __syncthreads();
         if (n >= PIX_THREADS) {  // full workgroups of uncertain points: the exact sequence
             while (n >= PIX_THREADS) {
-                project_exact_record(xyz, offs, base, B, g, true, queue[n - PIX_THREADS + threadIdx.x], bb, flags, mark);
+                project_exact_record(xyz, offs, base, B, g, true, (int64_t)queue[n - PIX_THREADS + threadIdx.x], bb, flags, mark);
                 n -= PIX_THREADS;
             }
             __syncthreads();
@@ -600,7 +600,7 @@ __global__ __launch_bounds__(PIX_THREADS) PIX_VGPR_ATTR void project_pix_kernel(
         }
     }
     const uint32_t n = qn;
-    if ((threadIdx.x & ~63u) < n) project_exact_record(xyz, offs, base, B, g, threadIdx.x < n, queue[min(threadIdx.x, n - 1u)], bb, flags, mark);
+    if ((threadIdx.x & ~63u) < n) project_exact_record(xyz, offs, base, B, g, threadIdx.x < n, (int64_t)queue[min(threadIdx.x, n - 1u)], bb, flags, mark);
 }
 
 // test hook: counts[0] = points the fast path is certain about, counts[1] = of those, points whose pixel differs
@@ -940,7 +940,7 @@ static int launch_project(const float *xyz, const int64_t *offsets, int64_t tota
 #ifdef PROJECT_FORCE_ATOMIC   // (experiment: the device-atomic path inside the fused batch)
     const bool fast = false;
 #else
-    const bool fast = scratch_bytes >= project_scratch_bytes(total, B, P) && bb.nbe <= PIX_MAX_BANDS;
+    const bool fast = scratch_bytes >= project_scratch_bytes(total, B, P) && bb.nbe <= PIX_MAX_BANDS && total < ((int64_t)1 << 32);
 #endif
     if (fast) {
         char *q = reinterpret_cast<char *>(scratch) + project_small_bytes(B, P);
