@@ -205,6 +205,43 @@ def test_projection_record_bins(env):
     check([pts, pts[:100], pts[::-1].copy()], gc, geomc, "exact path")
 
 
+def test_projection_paths_agree_on_random_batches(env):
+    """The binned LDS-band path against the device-atomic path (both held to the oracle elsewhere) on random batches: 1 .. 48 frames
+    of 0 .. 9000 points (clusters of tiny and empty frames included), four image shapes from 1 to 8 record bins, points in random
+    or sorted order, duplicated points, depth-0 points sprinkled in."""
+    torch, ops, orc = env["torch"], env["ops"], env["orc"]
+    rng = np.random.default_rng(2024)
+    shapes = [(16, 1800, 15.0, -15.0), (64, 2000, 2.0, -24.9), (64, 2048, 2.0, -24.9), (128, 2048, 15.0, -25.0), (7, 333, 10.0, -20.0)]
+    for draw in range(60):
+        H, W, vmax, vmin = shapes[draw % len(shapes)]
+        g = orc.LidarGeom(H=H, W=W, hfov_deg=360, vmax_deg=vmax, vmin_deg=vmin)
+        geom = ops.make_geom(g.H, g.W, g.horizontal_FOV, g.vertical_max, g.vertical_min)
+        B = int(rng.integers(1, 49))
+        frames = []
+        for _ in range(B):
+            kind = rng.integers(0, 5)
+            n = 0 if kind == 0 else int(rng.integers(1, 40)) if kind == 1 else int(rng.integers(40, 9000))
+            a = rng.normal(0, 15, (n, 3)).astype(np.float32)
+            a[:, 2] = rng.normal(-1, 2.0, n)
+            if n > 10 and rng.random() < 0.5:
+                a[: n // 3] = a[n // 3: 2 * (n // 3)]                      # duplicates: pixel collisions with equal depths
+            if n > 10 and rng.random() < 0.3:
+                a[rng.integers(0, n, 3)] = 0                              # depth-0 points: the exact input-order path
+            if n > 10 and rng.random() < 0.5:
+                a = a[np.lexsort((np.arctan2(a[:, 1], a[:, 0]), -np.round(a[:, 2] * 4)))]
+            frames.append(a)
+        offs = np.zeros(B + 1, np.int64)
+        offs[1:] = np.cumsum([f.shape[0] for f in frames])
+        xyz = np.concatenate(frames) if offs[-1] else np.zeros((0, 3), np.float32)
+        xt = _to(env, xyz) if offs[-1] else torch.zeros((0, 3), dtype=torch.float32, device=env["dev"])
+        a_fast = ops.project(xt, _to(env, offs), geom)
+        a_atom = ops.project(xt, _to(env, offs), geom, atomic_path=True)
+        assert torch.equal(a_fast.view(torch.int32), a_atom.view(torch.int32)), (draw, H, W, B)
+        if draw % 10 == 0:   # and the oracle now and then
+            i = int(rng.integers(0, B))
+            assert _beq(a_fast[i].cpu().numpy(), orc.project(frames[i], g)), (draw, i)
+
+
 def test_fps_xyz_operator(env):
     """The reference FPS operator signature (B,N,3)->(B,M): ragged N, duplicates (exact ties), N<M."""
     torch, ops, orc = env["torch"], env["ops"], env["orc"]
