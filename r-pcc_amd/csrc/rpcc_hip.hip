@@ -516,7 +516,6 @@ __global__ __launch_bounds__(PIX_THREADS) PIX_VGPR_ATTR void project_pix_kernel(
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    const int wave = threadIdx.x >> 6;
     const int64_t nck = (total >> PIX_CH_SHIFT) + B;   // chunk ids
     // chunk id -> frame, first point (launch-relative), points; the ids of a workgroup ascend, so the search starts at the last frame
     auto locate = [&](int64_t k, int &f, int64_t &first, int64_t &room) {
