@@ -790,6 +790,9 @@ __global__ __launch_bounds__(FPS_TT) FPS_VGPR_ATTR void fps_regtab_kernel(const 
 // info[b][4] = first empty pixel that is a candidate (the representative of the FPS kernel's origin class).
 // ------------------------------------------------------------------------------------------------
 #define TAB_TPW 2
+#ifndef MASK_F32_SCREEN
+#define MASK_F32_SCREEN 1
+#endif
 #ifndef MASK_VGPR_ATTR
 #define MASK_VGPR_ATTR
 #endif
@@ -811,12 +814,28 @@ __global__ __launch_bounds__(256) MASK_VGPR_ATTR void ground_mask_tab_kernel(flo
     const bool screen = thr >= 1e-200 && thr_div >= 1e-200 && thr_div <= 1e200;
     const double t_hi = thr_div * (1.0 + 1e-15), t_lo = thr_div * (1.0 - 1e-15);
     // classify one pixel from its loaded range and ray: back-projection, "is a candidate"
-    // (An fp32 estimate with an error bound in front of the fp64 dot product -- the pattern of assign_kernel's ground term -- was
-    // measured in round 3: the fp64 sequence is 11 instructions per pixel, the fp32 screen 8 plus the wave-level branch; the
-    // kernel's instruction count did not move (56.2 M against 55.4 M wave instructions per batch), so it is not here.)
+    // (The fp32 estimate in front of the fp64 dot product -- the pattern of assign_kernel's ground term -- does not lower the
+    // instruction COUNT (52.4 M against 50.5 M wave instructions per batch: 14 fp32 instructions per pixel against 11 fp64 ones),
+    // but fp64 instructions take two issue passes: 95.6 -> 93.8 us alone, 0.765 -> 0.762 ms per step.)
+#if MASK_F32_SCREEN
+    // fp32 estimate of the numerator with its error bound in front of the fp64 sequence (fp64 instructions take two issue passes):
+    // n32 = fl(fl(fl(x af + y bf) + z cf) + df) differs from the exact x a + y b + z c + d by at most 5 * 2^-24 * (|x a| + |y b| +
+    // |z c| + |d|) (narrowing of the plane, three products, three sums); twice that is used.  Pixels the estimate cannot decide
+    // (and NaN / infinite values, which fail both compares) take the fp64 sequence.
+    const float af = (float)a, bf = (float)bb, cf = (float)c, df = (float)d;
+    const float thi32 = (float)t_hi * 1.0000002f, tlo32 = (float)t_lo * 0.9999998f;
+#endif
     auto classify = [&](float &r, float tx, float ty, float tz, float &x, float &y, float &z) -> bool {
         if (RAW && f2u(r) == RI_EMPTY) r = 0.0f;
         x = r * tx; y = r * ty; z = r * tz;
+#if MASK_F32_SCREEN
+        if (screen) {
+            const float n32 = fabsf(((x * af + y * bf) + z * cf) + df);
+            const float e32 = 6.0e-7f * (((fabsf(x) * fabsf(af) + fabsf(y) * fabsf(bf)) + fabsf(z) * fabsf(cf)) + fabsf(df)) + 1.0e-30f;
+            if (n32 - e32 > thi32) return true;
+            if (n32 + e32 < tlo32) return false;
+        }
+#endif
         const double s = ((double)x * a + (double)y * bb) + (double)z * c;
         const double num = fabs(s + d);
         if (screen && num > t_hi) return true;
