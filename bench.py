@@ -134,19 +134,19 @@ def spawn_ranks(n, argv=None, wall_s=None):
         reader.join(timeout=10)
     finally:
         shutil.rmtree(rdzv, ignore_errors=True)
-    text = (out0[0] if out0 else b"").decode(errors="replace")
-    lines = [ln for ln in text.splitlines() if ln.startswith("{")]
-    if not lines:
+    all_lines = (out0[0] if out0 else b"").decode(errors="replace").splitlines()
+    js = [i for i, ln in enumerate(all_lines) if ln.startswith("{")]
+    if not js:
         print("bench.py: rank 0 printed no JSON line", file=sys.stderr)
         return 1
-    rec = json.loads(lines[-1])
+    rec = json.loads(all_lines[js[-1]])
     if rec.get("n_gpus") != n or rec.get("ranks_joined", n) != n:
         print("bench.py: asked for %d GPUs, %s ranks joined" % (n, rec.get("ranks_joined", rec.get("n_gpus"))), file=sys.stderr)
         return 1
-    for ln in text.splitlines():           # the JSON line stays the last line on stdout
-        if ln is not lines[-1]:
+    for i, ln in enumerate(all_lines):     # ONE JSON line, and it is the last line on stdout
+        if i != js[-1]:
             print(ln)
-    print(lines[-1], flush=True)
+    print(all_lines[js[-1]], flush=True)
     return 0
 
 

@@ -199,8 +199,10 @@ def test_bench_spawn_dry_run_two_ranks():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=_bench_env(RPCC_BENCH_DRYRUN="gloo"),
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
-    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    out = r.stdout.strip().splitlines()
+    rec = json.loads(out[-1])
     assert rec["n_gpus"] == 2 and rec["ranks_joined"] == 2 and len(rec["per_rank_s"]) == 2
+    assert sum(1 for ln in out if ln.startswith("{")) == 1, "exactly ONE JSON line on stdout"
 
 
 def test_bench_spawn_stops_the_group_when_a_rank_dies():
