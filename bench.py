@@ -70,7 +70,7 @@ def parse():
     ap.add_argument("--pipeline", type=int, default=3, help="batches in flight (streams); 1 = strictly serial steps")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary measurements (configs[2] fused, the real sweep, the datalist feed) that follow the headline at N=1")
-    ap.add_argument("--verify-frames", type=int, default=8, help="frames per pipeline slot checked against the oracle when no cpu_baseline leg runs")
+    ap.add_argument("--verify-frames", type=int, default=64, help="frames per pipeline slot checked against the oracle when no cpu_baseline leg runs")
     return ap.parse_args()
 
 
@@ -82,6 +82,19 @@ def parse():
 # -- or the wall budget running out -- ends the whole group at once instead of leaving the others in init_process_group /
 # a collective until the RCCL timeout.
 # ----------------------------------------------------------------------------------------------------------------------
+class _Stopped(Exception):
+    """Raised inside spawn_ranks by its SIGTERM / SIGINT / SIGHUP handler."""
+
+
+def _die_with_parent():
+    """preexec_fn of a rank process (Linux): SIGKILL this child when the parent that forked it dies, however it dies (a
+    SIGKILL of the parent runs no handler and no finally block)."""
+    try:
+        C.CDLL(None, use_errno=True).prctl(1, 9, 0, 0, 0)   # PR_SET_PDEATHSIG, SIGKILL
+    except Exception:
+        pass
+
+
 def spawn_ranks(n, argv=None, wall_s=None):
     import shutil
     import signal
@@ -90,26 +103,66 @@ def spawn_ranks(n, argv=None, wall_s=None):
     import rpcc_amd  # noqa: F401
     from rpcc_amd.utils import visible_gpus
     dry = os.environ.get("RPCC_BENCH_DRYRUN")          # CPU dry run of the launch path (gloo ranks, tests/test_sharding.py)
-    have = visible_gpus() or 0                         # no KFD topology in sysfs: not a ROCm host, no GPU
-    if not dry and have < n:
-        print("bench.py: --gpus %d but only %d GPU(s) are visible" % (n, have), file=sys.stderr)
-        return 2
+    have = visible_gpus()
+    if not dry:
+        if have is None and os.path.exists("/dev/kfd"):
+            # a container with the device nodes passed through but no KFD topology in sysfs: the count is unknown, not zero --
+            # the supervised ranks fail fast if a device is missing
+            print("bench.py: cannot count the GPUs without touching HIP (no KFD topology in sysfs); starting %d ranks anyway" % n, file=sys.stderr)
+        elif (have or 0) < n:                          # (no /dev/kfd at all: not a ROCm host, no GPU)
+            print("bench.py: --gpus %d but only %d GPU(s) are visible" % (n, have or 0), file=sys.stderr)
+            return 2
     wall_s = float(os.environ.get("RPCC_BENCH_WALL_S", "1500")) if wall_s is None else wall_s
     rdzv = tempfile.mkdtemp(prefix="rpcc_rdzv_")
     procs, out0 = [], []
+
+    def stop_all():                                   # the ranks' own process groups: nothing of theirs survives
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)
+                except (ProcessLookupError, PermissionError):
+                    p.kill()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                pass
+
+    def on_signal(signum, frame):
+        raise _Stopped(signum)
+    # The ranks run in sessions of their own (a group kill of one rank must not take the parent along), so a signal sent to the
+    # parent -- the driver's `timeout`, Ctrl-C, a closed terminal -- reaches none of them: the parent hands it on.
+    old_handlers = {}
+    if threading.current_thread() is threading.main_thread():
+        for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+            old_handlers[sg] = signal.signal(sg, on_signal)
+    reader = None
+    rc_out = None
     try:
         for r in range(n):
             env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), RPCC_RDZV_FILE=os.path.join(rdzv, "store"),
                        HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
             procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + (sys.argv[1:] if argv is None else argv), env=env,
-                                          stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, start_new_session=True))
+                                          stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, start_new_session=True,
+                                          preexec_fn=_die_with_parent))
         reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
         reader.start()
         t0, failed = time.monotonic(), None
         while failed is None:
             rcs = [p.poll() for p in procs]
             bad = [(r, rc) for r, rc in enumerate(rcs) if rc not in (None, 0)]
-            if bad:
+            if bad == [(0, 3)]:
+                # rank 0 printed its line with "verified": false and exited 3 (after the group was torn down): the other ranks are
+                # finishing; the line is relayed and the exit code kept
+                t1 = time.monotonic()
+                while any(p.poll() is None for p in procs) and time.monotonic() - t1 < 30:
+                    time.sleep(0.05)
+                if all(p.poll() == 0 for p in procs[1:]):
+                    rc_out = 3
+                    break
+                failed = "rank 0 reported a verification failure and another rank did not finish"
+            elif bad:
                 failed = "rank %d exited with code %d" % bad[0]
             elif all(rc == 0 for rc in rcs):
                 break
@@ -118,21 +171,23 @@ def spawn_ranks(n, argv=None, wall_s=None):
             else:
                 time.sleep(0.05)
         if failed is not None:
-            for p in procs:                       # the ranks' own process groups: nothing of theirs survives
-                if p.poll() is None:
-                    try:
-                        os.killpg(p.pid, signal.SIGKILL)
-                    except (ProcessLookupError, PermissionError):
-                        p.kill()
-            for p in procs:
-                try:
-                    p.wait(timeout=10)
-                except subprocess.TimeoutExpired:
-                    pass
+            stop_all()
+            reader.join(timeout=10)
             print("bench.py: %s; all ranks stopped (exit codes %s)" % (failed, [p.poll() for p in procs]), file=sys.stderr)
+            if out0 and out0[0]:                    # what rank 0 had printed so far: diagnostics, on stderr (stdout carries only a valid line)
+                print("bench.py: rank 0's output before the stop:\n" + out0[0].decode(errors="replace")[-4000:], file=sys.stderr)
             return 1
         reader.join(timeout=10)
+    except _Stopped as e:
+        stop_all()
+        print("bench.py: signal %d; all ranks stopped" % e.args[0], file=sys.stderr)
+        return 128 + int(e.args[0])
+    except BaseException:
+        stop_all()
+        raise
     finally:
+        for sg, h in old_handlers.items():
+            signal.signal(sg, h)
         shutil.rmtree(rdzv, ignore_errors=True)
     all_lines = (out0[0] if out0 else b"").decode(errors="replace").splitlines()
     js = [i for i, ln in enumerate(all_lines) if ln.startswith("{")]
@@ -147,7 +202,7 @@ def spawn_ranks(n, argv=None, wall_s=None):
         if i != js[-1]:
             print(ln)
     print(all_lines[js[-1]], flush=True)
-    return 0
+    return rc_out or 0
 
 
 def init_group(backend, rank, world, device_id=None):
@@ -185,8 +240,11 @@ def dry_run_rank(a, rank, world):
     dist.barrier()
     dist.destroy_process_group()
     if rank == 0:
+        bad = os.environ.get("RPCC_BENCH_DRY_VERIFY_FAIL") == "1"     # what a failed oracle check looks like from outside: the line, then exit 3
         print(json.dumps({"metric": "dry run (no GPU work)", "value": 0.0, "n_gpus": world, "ranks_joined": len(allt),
-                          "per_rank_s": [round(float(t.item()), 4) for t in allt]}), flush=True)
+                          "per_rank_s": [round(float(t.item()), 4) for t in allt], "verified": not bad}), flush=True)
+        if bad:
+            sys.exit(3)
 
 
 SETUP_ROUNDS = 8   # untimed runs of every pipeline slot before the warm-up steps (run_workload)
@@ -275,17 +333,19 @@ def run_workload(a, ctx):
         xyz_host = xyz.cpu().pin_memory()
         xyz_l = [torch.empty_like(xyz) for _ in range(depth)]
     exchange = (world > 1 or a.force_gather) and not a.no_gather
-    exch = None
+    exch = exch_alt = None
     exchange_bytes = 0
+    mode = [0]          # 0: the exchange the flags select (the headline), 1: the other one (timed after it, `exchange_modes`)
     if exchange:
         # the exchange step.  Default: what rank 0 needs to index the job -- the per-frame payload lengths
         # (the payload bytes stay with the rank that made them and writes its own .rpcc files, as
         # tools/compress_datalist.py does).  --gather-payloads: every rank also packs its frames' residual runs back to
         # back (rpcc_pack_payload: sum(nnz) <= its point count, so `cap` entries always fit) and rank 0 receives them.
         from rpcc_amd.sharding import PackedExchange
-        cap = PackedExchange.agree_capacity(int(offs_host[-1] - offs_host[0]), dev) if a.gather_payloads else 0
+        cap = PackedExchange.agree_capacity(int(offs_host[-1] - offs_host[0]), dev)
         packed_l = [torch.zeros((max(cap, 1),), dtype=torch.int16, device=dev) for _ in range(depth)]
-        exch = PackedExchange(B, cap, dev, payloads=a.gather_payloads)
+        exch = PackedExchange(B, cap if a.gather_payloads else 0, dev, payloads=a.gather_payloads)
+        exch_alt = PackedExchange(B, 0 if a.gather_payloads else cap, dev, payloads=not a.gather_payloads)
         exchange_bytes = exch.bytes_per_step()
 
     step_no = [0]
@@ -307,9 +367,10 @@ def run_workload(a, ctx):
                 src = xyz_l[k]
             run(k, src)
             if exchange:
-                if a.gather_payloads:
+                ex = exch_alt if mode[0] else exch
+                if ex.payloads:
                     ops.pack_payload(bufs[k].q16, bufs[k].nnz, packed=packed_l[k], capacity=cap, total=pack_tot)
-                exch.step(packed_l[k], bufs[k].nnz)
+                ex.step(packed_l[k], bufs[k].nnz)
 
     def barrier():
         torch.cuda.synchronize()
@@ -331,35 +392,78 @@ def run_workload(a, ctx):
         # packed).  An error that every rank sees alike (an unsupported dtype, a missing backend feature) switches the
         # exchange off instead of killing the run -- and says so in the JSON line.
         try:
-            if a.gather_payloads:
-                ops.pack_payload(bufs[0].q16, bufs[0].nnz, packed=packed_l[0], capacity=cap, total=pack_tot)
-            exch.step(packed_l[0], bufs[0].nnz)
-            torch.cuda.synchronize()
-            if rank == 0:
-                assert torch.equal(exch.nnz_all[0], bufs[0].nnz), "exchange returned other lengths than sent"
-                if a.gather_payloads:
-                    for f in (0, B // 2, B - 1):
-                        n = int(bufs[0].nnz[f])
-                        assert torch.equal(exch.frame_stream(0, f), bufs[0].q16[f, :n]), "exchange returned other data than packed"
+            for ex in (exch, exch_alt):
+                if ex.payloads:
+                    ops.pack_payload(bufs[0].q16, bufs[0].nnz, packed=packed_l[0], capacity=cap, total=pack_tot)
+                ex.step(packed_l[0], bufs[0].nnz)
+                torch.cuda.synchronize()
+                if rank == 0:
+                    assert torch.equal(ex.nnz_all[0], bufs[0].nnz), "exchange returned other lengths than sent"
+                    if ex.payloads:
+                        for f in (0, B // 2, B - 1):
+                            n = int(bufs[0].nnz[f])
+                            assert torch.equal(ex.frame_stream(0, f), bufs[0].q16[f, :n]), "exchange returned other data than packed"
         except Exception as e:  # noqa: BLE001
             exchange = False
             exchange_note = "exchange disabled after its trial failed: %s" % (str(e).splitlines()[0][:200],)
+    # Length of the timed region.  N = 1: exactly --steps.  N > 1: at least RPCC_BENCH_MIN_REGION_MS (200 ms) -- a 15 ms region
+    # (20 steps) would let one late rank or one slow collective decide the "scaling efficiency"; the number of steps is agreed
+    # on by all ranks (they run a collective per step) from the warm-up's own timing and REPORTED as `steps`.
+    torch.cuda.synchronize()
+    tw = time.perf_counter()
     for _ in range(a.warmup):
         step()
-    barrier()
-    timer.read()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    tw = (time.perf_counter() - tw) / max(a.warmup, 1)
+    steps = a.steps
+    if world > 1:
+        min_ms = float(os.environ.get("RPCC_BENCH_MIN_REGION_MS", "200"))
+        want = int(np.ceil(min_ms * 1e-3 / max(tw, 1e-5))) if a.warmup > 0 else a.steps
+        t = torch.tensor([max(a.steps, min(want, 100000))], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        steps = int(t.item())
+        timer.reserve(steps + 8)
+
+    def timed_region(k_steps):
+        """K steps between two barriers; returns (this rank's time, [every rank's time]).  A rank's time runs from the opening
+        barrier to ITS OWN torch.cuda.synchronize() after its K-th step -- the closing barrier (synchronize + RCCL barrier +
+        synchronize) is outside it; the job's time is the slowest rank's."""
+        barrier()
+        timer.read()
+        t0 = time.perf_counter()
+        for _ in range(k_steps):
+            step()
+        torch.cuda.synchronize()
+        dt_local = time.perf_counter() - t0
+        barrier()
+        rank_dt = [dt_local]
+        if world > 1:
+            allt = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+            dist.all_gather(allt, torch.tensor([dt_local], dtype=torch.float64, device=dev))
+            rank_dt = [float(t.item()) for t in allt]
+        return max(rank_dt), rank_dt
+
+    dt, rank_dt = timed_region(steps)
     fps_ms, fps_n = timer.read()
-    rank_dt = [dt]
-    if world > 1:       # every rank's own time for the K steps; the job's time is the slowest rank's
-        allt = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
-        dist.all_gather(allt, torch.tensor([dt], dtype=torch.float64, device=dev))
-        rank_dt = [float(t.item()) for t in allt]
-        dt = max(rank_dt)
+    # N > 1: the OTHER exchange mode, timed right after the headline's with the same number of steps (SURVEY 8e names the gather
+    # of the bitstreams; the default exchanges the lengths only): both are reported under `exchange_modes`
+    exchange_modes = None
+    if exchange and exch_alt is not None:
+        head_mode = "lengths+payloads" if a.gather_payloads else "lengths"
+        exchange_modes = {head_mode: {"value": round(world * B * steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 4),
+                                      "exchange_bytes_per_step": exchange_bytes}}
+        try:
+            mode[0] = 1
+            for _ in range(min(5, steps)):
+                step()
+            dt2, _ = timed_region(steps)
+            exchange_modes["lengths" if a.gather_payloads else "lengths+payloads"] = {
+                "value": round(world * B * steps / dt2, 2), "ms_per_step": round(dt2 / steps * 1e3, 4), "exchange_bytes_per_step": exch_alt.bytes_per_step()}
+        except Exception as e:  # noqa: BLE001
+            exchange_modes["error"] = str(e).splitlines()[0][:200]
+        finally:
+            mode[0] = 0
+        timer.read()
 
     buf = bufs[0]
     info = buf.info.cpu().numpy()
@@ -433,13 +537,13 @@ def run_workload(a, ctx):
 
     out = None
     if rank == 0:
-        frames_per_s = world * B * a.steps / dt
+        frames_per_s = world * B * steps / dt
         fps_launch_ms = fps_ms / max(fps_n, 1)
         lt = fps_launch_ms * 1e-3
         stream_once = fps_bytes / lt / 1e9 if fps_n else 0.0
         pm = pmc_numbers(a, B, geom_s, M)
         fps_kernel = "fps_range_kernel (brute force)" if a.fps_bruteforce else (pm["kernel"] if pm else "fps_regtab_kernel")
-        step_s = dt / a.steps
+        step_s = dt / steps
         step_valu_frac = pm["step_valu"] / step_s / VALU_PEAK_WAVE_INSTS_PER_S if pm and pm.get("step_valu") else None
         step_traffic_frac = pm["step_traffic"] / step_s / 1e9 / HBM_PEAK_GBS if pm and pm.get("step_traffic") else None
         workload = ("configs[%d]: batch=%d %s Velodyne-64E frames (%dx%d) per GPU, %s, accuracy=%g, cluster_num=%d, ground plane by "
@@ -481,14 +585,14 @@ def run_workload(a, ctx):
                                     "frac": round(stream_once / HBM_PEAK_GBS, 4),
                                     "note": "bounds nothing for the pruned kernel (frac > 1): the pruning is exact, results equal the "
                                             "brute-force kernel's bit for bit; --fps-bruteforce runs the kernel this model describes"}},
-                "whole_path_stream_once_GBs": round(b_alg * a.steps / dt / 1e9, 2)}
+                "whole_path_stream_once_GBs": round(b_alg * steps / dt / 1e9, 2)}
         out = {
             "metric": "frames/s (64E, 64x2048 range img), projection->segmentation->model->quantise",
-            "value": round(frames_per_s, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "value": round(frames_per_s, 2), "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "real sweep replicated" if a.input else "synthetic",
             "verified": verified, "ranks_joined": len(rank_dt),
-            "per_rank_frames_per_s": {"min": round(B * a.steps / max(rank_dt), 2), "max": round(B * a.steps / min(rank_dt), 2)},
+            "per_rank_frames_per_s": {"min": round(B * steps / max(rank_dt), 2), "max": round(B * steps / min(rank_dt), 2)},
             "config": {"workload": workload, "frames_per_gpu_per_step": B, "batches_in_flight": depth,
                        "inputs": ("copied from pinned host memory inside every step (PCIe-inclusive run, not the headline)" if a.h2d
                                   else "resident in HBM before the timed region"),
@@ -497,9 +601,16 @@ def run_workload(a, ctx):
                        "exchange": ("none" if not exchange else ("lengths+payloads" if a.gather_payloads else "lengths")),
                        "exchange_bytes_per_step": exchange_bytes if exchange else 0,
                        "verified_frames_per_slot": (S if verified is not None else 0),
-                       "setup_batches": SETUP_ROUNDS * depth},   # untimed, before the W warm-up steps (see run_workload)
+                       "setup_batches": SETUP_ROUNDS * depth,    # untimed, before the W warm-up steps (see run_workload)
+                       "timing": "per rank: opening barrier -> its own synchronize after the K-th step (the closing RCCL barrier is "
+                                 "outside); job time = slowest rank"},
             "roofline": roof,
         }
+        if steps != a.steps:
+            out["steps_requested"] = a.steps
+            out["config"]["min_timed_region_ms"] = float(os.environ.get("RPCC_BENCH_MIN_REGION_MS", "200"))
+        if exchange_modes is not None:
+            out["exchange_modes"] = exchange_modes
         if want_cpu:
             out["cpu_baseline"] = {"value": round(cpu_rate, 3), "unit": "frames/s", "cores": threads, "kind": "port",
                                    "sample": "%d of the same frames, C port of the reference cpu=True path "
@@ -662,6 +773,7 @@ def main():
     headline = a.config == 1 and not a.input and a.geom is None and not (a.fps_bruteforce or a.h2d or a.force_gather)
     if out is not None and world == 1 and headline and not a.no_secondary:     # beside the headline only
         out["secondary"] = run_secondary(a, ctx)
+        out["secondary_verified"] = not any(isinstance(v, dict) and v.get("verified") is False for v in out["secondary"].values())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -670,7 +782,10 @@ def main():
         # version banner to stdout under NCCL_DEBUG=VERSION, and a pipe delays it until the buffer is flushed)
         _flush_c_stdio()
         print(json.dumps(out), flush=True)
-    if out is not None and out.get("verified") is False:
+    sec_bad = out is not None and [k for k, v in out.get("secondary", {}).items() if isinstance(v, dict) and v.get("verified") is False]
+    if sec_bad:
+        print("bench.py: VERIFICATION FAILED in secondary measurement(s): %s" % ", ".join(sec_bad), file=sys.stderr)
+    if out is not None and (out.get("verified") is False or sec_bad):
         sys.exit(3)
 
 

@@ -305,8 +305,10 @@ class BatchBuffers:
         self.q16 = torch.empty((B, P), dtype=torch.int16, device=device)
         self.nnz = torch.empty((B,), dtype=i32, device=device)
         self.info = torch.empty((B, _lib.INFO_INTS), dtype=i32, device=device)
-        # max_points: capacity (sum of N over the batch) for the projection's record list; default 2 per pixel
-        self.max_points = int(max_points) if max_points is not None else 2 * B * P
+        # max_points: initial capacity (sum of N over the batch) of the projection's record space -- about 40 B of workspace per point
+        # and 48 KB per frame (INTEGRATION.md "Memory").  Default one point per pixel: compress_batch re-allocates the workspace
+        # when a batch holds more (dense or dual-return sweeps), so the default no longer reserves twice that up front.
+        self.max_points = int(max_points) if max_points is not None else B * P
         self.general = bool(general)
         self.ws = workspace(B, P, M, device, self.max_points, general=self.general)
         self.salience = torch.zeros((B, K), dtype=torch.uint8, device=device) if general else None

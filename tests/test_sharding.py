@@ -229,6 +229,56 @@ def test_bench_spawn_wall_budget():
     assert r.returncode != 0 and "wall budget" in r.stderr, (r.returncode, r.stderr[-2000:])
 
 
+def test_bench_spawn_dry_run_four_ranks():
+    """Four gloo ranks through the same launch path (the round-end scaling run uses 2, 4 and 8)."""
+    import json
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=_bench_env(RPCC_BENCH_DRYRUN="gloo"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rec["n_gpus"] == 4 and rec["ranks_joined"] == 4 and len(rec["per_rank_s"]) == 4
+
+
+def test_bench_spawn_relays_a_failed_verification():
+    """Rank 0 prints its line with "verified": false and exits 3: the parent relays the line and keeps the exit code (it used to
+    discard both and return 1)."""
+    import json
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"],
+                       env=_bench_env(RPCC_BENCH_DRYRUN="gloo", RPCC_BENCH_DRY_VERIFY_FAIL="1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 3, (r.returncode, r.stderr[-2000:])
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rec["verified"] is False and rec["ranks_joined"] == 2
+
+
+def test_bench_spawn_signal_to_the_parent_stops_every_rank():
+    """The ranks live in sessions of their own, so a SIGTERM to the parent (the driver's `timeout`, Ctrl-C) reaches none of them
+    by itself: the parent's handler must stop them.  A hung rank is left running; the parent is signalled; no child survives."""
+    import signal
+    import subprocess
+    import time
+    import psutil
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"],
+                         env=_bench_env(RPCC_BENCH_DRYRUN="gloo", RPCC_BENCH_HANG_RANK="1", RPCC_BENCH_WALL_S="600"),
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    kids = []
+    t0 = time.monotonic()
+    while time.monotonic() - t0 < 120 and len(kids) < 2:
+        time.sleep(0.2)
+        try:
+            kids = psutil.Process(p.pid).children(recursive=True)
+        except psutil.NoSuchProcess:
+            break
+    assert len(kids) == 2, "the parent did not start its two ranks"
+    time.sleep(1.0)
+    p.send_signal(signal.SIGTERM)
+    out, err = p.communicate(timeout=60)
+    assert p.returncode == 128 + signal.SIGTERM and "all ranks stopped" in err, (p.returncode, err[-2000:])
+    gone, alive = psutil.wait_procs(kids, timeout=20)
+    assert not alive, "rank processes survived the parent: %s" % alive
+
+
 def test_bench_parent_never_imports_torch_before_spawning():
     """The parent of `--gpus N` must stay a process that never touched HIP: the GPU count comes from sysfs / the
     *_VISIBLE_DEVICES masks (utils.visible_gpus), and spawn_ranks itself imports neither torch nor the HIP library."""
