@@ -76,6 +76,12 @@ size_t rpcc_project_scratch_bytes(int64_t total, int B, int P);
 int rpcc_project_fastpath_check(const float *xyz, int64_t total, rpcc_geom g, uint64_t *counts, void *stream);
 int rpcc_project(const float *xyz, const int64_t *offsets, int64_t total, int B, rpcc_geom g, float *ri,
                  void *scratch, size_t scratch_bytes, void *stream);
+/* The same on the points AS STORED: the reference reads a sweep as np.fromfile(path, float32).reshape(-1, 4) -- rows
+ * (x, y, z, intensity) -- and slices [:, :3] on the host (dataset/dataset.py:48-50,62).  With point_stride_bytes = 16 the
+ * rows go to the device as they are (file -> pinned buffer -> DMA, no host pass over the points) and the kernel reads one
+ * 16-byte row per point (points 16-byte aligned); 12 (or 0) = packed xyz = rpcc_project.  offsets / total count POINTS. */
+int rpcc_project_strided(const float *points, int point_stride_bytes, const int64_t *offsets, int64_t total, int B,
+                         rpcc_geom g, float *ri, void *scratch, size_t scratch_bytes, void *stream);
 
 /* ---- a4: ground plane ----------------------------------------------------------------------- *
  * replaces the ground branch of PointCloudSegment.segment: candidate selection + RANSAC
@@ -270,7 +276,7 @@ typedef struct rpcc_nonuniform_cfg {
 } rpcc_nonuniform_cfg;
 
 typedef struct rpcc_batch_io {
-    const float *xyz;        /* dev f32 [total,3] */
+    const float *xyz;        /* dev f32 [total,3] (or [total,4] rows with point_stride_bytes = 16) */
     const int64_t *offsets;  /* dev i64 [B+1] */
     int64_t total;
     const float *tm;         /* dev f32 [P,3] */
@@ -297,6 +303,8 @@ typedef struct rpcc_batch_io {
                                 levels + per-label steps (a12, a13), ws of rpcc_workspace_bytes_general() bytes */
     uint8_t *salience;       /* dev u8 [B,K] out (non-uniform) */
     uint8_t *key_point_map;  /* dev u8 [B,P] out (non-uniform) */
+    int32_t point_stride_bytes; /* bytes per point of `xyz`: 0 or 12 = packed xyz; 16 = (x, y, z, intensity) rows as stored in a
+                                KITTI .bin (see rpcc_project_strided) */
 } rpcc_batch_io;
 
 size_t rpcc_workspace_bytes(int B, int P, int M, int64_t total_points);

@@ -21,7 +21,8 @@ class BatchIO(C.Structure):
                 ("seg", C.c_void_p), ("cen_pix", C.c_void_p), ("centers", C.c_void_p), ("model", C.c_void_p),
                 ("counts", C.c_void_p), ("q16", C.c_void_p), ("nnz", C.c_void_p), ("info", C.c_void_p),
                 ("flags", C.c_int32), ("timer", C.c_void_p), ("model_method", C.c_int32), ("plane_cos_cut", C.c_double),
-                ("plane_seed", C.c_int64), ("nonuniform", C.c_void_p), ("salience", C.c_void_p), ("key_point_map", C.c_void_p)]
+                ("plane_seed", C.c_int64), ("nonuniform", C.c_void_p), ("salience", C.c_void_p), ("key_point_map", C.c_void_p),
+                ("point_stride_bytes", C.c_int32)]
 
 
 class NonuniformCfg(C.Structure):
@@ -59,6 +60,7 @@ _SIGS = {
     "rpcc_project_scratch_bytes": (C.c_size_t, [_I64, _I, _I]),
     "rpcc_project_fastpath_check": (C.c_int, [_VP, _I64, Geom, _VP, _VP]),
     "rpcc_project": (C.c_int, [_VP, _VP, _I64, _I, Geom, _VP, _VP, C.c_size_t, _VP]),
+    "rpcc_project_strided": (C.c_int, [_VP, _I, _VP, _I64, _I, Geom, _VP, _VP, C.c_size_t, _VP]),
     "rpcc_ground_ransac": (C.c_int, [_VP, _VP, _I, _I, C.c_uint32, _VP, _VP, _VP, _VP]),
     "rpcc_ground_mask": (C.c_int, [_VP, _VP, _VP, _D, _I, _I, _I, _VP, _VP, _VP, _VP]),
     "rpcc_fps_table_bytes": (C.c_size_t, [_I, _I, _I]),

@@ -202,7 +202,8 @@ template <int MODE>
 __global__ __launch_bounds__(256) void project_kernel(const float *__restrict__ xyz, const int64_t *__restrict__ offs,
                                                       int64_t total, int64_t base, int B, rpcc_geom g,
                                                       uint32_t *__restrict__ ri, int32_t *__restrict__ lastz,
-                                                      int32_t *__restrict__ flags) {
+                                                      int32_t *__restrict__ flags, int ps) {
+    // ps: floats per point (3: packed xyz; 4: the .bin rows x, y, z, intensity as stored -- dataset/dataset.py:48-50,62)
     // offs[] holds absolute point indices; this launch covers points base .. base+total (frames offs[0..B])
     if (MODE != 0 && flags[B] == 0) return;  // no frame of this batch holds a depth-0 point
     const int64_t P = (int64_t)g.H * g.W;
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(256) void project_kernel(const float *__restrict__ 
         int b = __builtin_amdgcn_readfirstlane(find_frame(offs, B, __shfl(i, __ffsll((long long)__ballot(1)) - 1, 64)));
         if (i >= offs[b + 1]) b = find_frame(offs, B, i);
         if (MODE != 0 && flags[b] == 0) continue;
-        const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+        const float x = xyz[ps * i], y = xyz[ps * i + 1], z = xyz[ps * i + 2];
         const RowCol rc = project_point(x, y, z, g);
         if (!(fabsf(rc.depth) <= 3.402823466e+38f)) continue;  // NaN / inf depth: skipped (reference: UB)
         const int32_t pos = (int32_t)(i - offs[b]) + 1;
@@ -455,13 +456,13 @@ __device__ __forceinline__ void bin_append_any(bool valid, uint32_t bin, int64_t
 // the exact sequence for one point (every lane of the wavefront calls; `active` = the lane holds a queued point)
 __device__ __forceinline__ void project_exact_record(const float *__restrict__ xyz, const int64_t *__restrict__ offs, int64_t base,
                                                      int B, const rpcc_geom g, bool active, int64_t il, const BandBins bb,
-                                                     int32_t *__restrict__ flags, int mark) {
+                                                     int32_t *__restrict__ flags, int mark, int ps) {
     bool valid = false;
     uint32_t bin = 0u, cap = 0u, pix = 0u, dep = 0u;
     int64_t ostart = 0;
     if (active) {
         const int64_t i = base + il;
-        const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+        const float x = xyz[ps * i], y = xyz[ps * i + 1], z = xyz[ps * i + 2];
         const RowCol rc = project_point(x, y, z, g);
         if (fabsf(rc.depth) <= 3.402823466e+38f) {
             const int b = find_frame(offs, B, i);
@@ -502,6 +503,7 @@ __global__ __launch_bounds__(256) void batch_init_kernel(BatchInit init) { batch
 #ifndef PIX_VGPR_ATTR
 #define PIX_VGPR_ATTR __attribute__((amdgpu_waves_per_eu(6, 8)))   // 80 VGPRs (81 without: one wavefront per SIMD less)
 #endif
+template <int PS>   // floats per point: 3 (packed xyz) or 4 (x, y, z, intensity rows as stored in a KITTI .bin: one 16-byte load per point)
 __global__ __launch_bounds__(PIX_THREADS) PIX_VGPR_ATTR void project_pix_kernel(const float *__restrict__ xyz, const int64_t *__restrict__ offs,
                                                                   int64_t total, int64_t base, int B, rpcc_geom g, PixFastCfg cfg,
                                                                   BandBins bb, int32_t *__restrict__ flags,
@@ -542,14 +544,14 @@ __global__ __launch_bounds__(PIX_THREADS) PIX_VGPR_ATTR void project_pix_kernel(
         }
         float x[PIX_PPT], y[PIX_PPT], z[PIX_PPT];
         // unconditional loads, all in flight: wave-uniform chunk base + 32-bit lane offsets; only a frame's last chunk clamps its indices
-        const f32x3 *cb = reinterpret_cast<const f32x3 *>(xyz + 3 * (base + il0));
+        const float *cb = xyz + PS * (base + il0);
         const uint32_t room = (uint32_t)room64;   // points of this chunk (>= 1)
 #pragma unroll
         for (int u = 0; u < PIX_PPT; u++) {
             uint32_t i = (uint32_t)(u * PIX_THREADS) + threadIdx.x;
             if (room < (uint32_t)(PIX_PPT * PIX_THREADS)) i = min(i, room - 1u);   // (wave-uniform test)
-            const f32x3 p3 = ld_at(cb, i * 12u);
-            x[u] = p3.x; y[u] = p3.y; z[u] = p3.z;
+            if (PS == 4) { const float4 p4 = ld_at(reinterpret_cast<const float4 *>(cb), i * 16u); x[u] = p4.x; y[u] = p4.y; z[u] = p4.z; }
+            else { const f32x3 p3 = ld_at(reinterpret_cast<const f32x3 *>(cb), i * 12u); x[u] = p3.x; y[u] = p3.y; z[u] = p3.z; }
         }
         if (k + gridDim.x < nck) locate(k + gridDim.x, fnext, il_next, room_next);   // (scalar loads: their latency passes under the point loads)
         char *reg = bb.lists + k * (int64_t)(bb.nbe * SHARE_BYTES);   // the chunk's shares of the lists
@@ -590,7 +592,7 @@ __global__ __launch_bounds__(PIX_THREADS) PIX_VGPR_ATTR void project_pix_kernel(
         __syncthreads();
         if (n >= PIX_THREADS) {  // full workgroups of uncertain points: the exact sequence
             while (n >= PIX_THREADS) {
-                project_exact_record(xyz, offs, base, B, g, true, (int64_t)queue[n - PIX_THREADS + threadIdx.x], bb, flags, mark);
+                project_exact_record(xyz, offs, base, B, g, true, (int64_t)queue[n - PIX_THREADS + threadIdx.x], bb, flags, mark, PS);
                 n -= PIX_THREADS;
             }
             __syncthreads();
@@ -599,7 +601,7 @@ __global__ __launch_bounds__(PIX_THREADS) PIX_VGPR_ATTR void project_pix_kernel(
         }
     }
     const uint32_t n = qn;
-    if ((threadIdx.x & ~63u) < n) project_exact_record(xyz, offs, base, B, g, threadIdx.x < n, (int64_t)queue[min(threadIdx.x, n - 1u)], bb, flags, mark);
+    if ((threadIdx.x & ~63u) < n) project_exact_record(xyz, offs, base, B, g, threadIdx.x < n, (int64_t)queue[min(threadIdx.x, n - 1u)], bb, flags, mark, PS);
 }
 
 // test hook: counts[0] = points the fast path is certain about, counts[1] = of those, points whose pixel differs
@@ -647,7 +649,7 @@ __global__ __launch_bounds__(256) void project_fastcheck_kernel(const float *__r
 #define RS_CHUNKS 16
 static inline int rs_chunk_px(int P) { return (((P + RS_CHUNKS - 1) / RS_CHUNKS) + 63) & ~63; }
 __device__ void project_fixup_frame(const float *__restrict__ xyz, const int64_t *__restrict__ offs, int b, rpcc_geom g,
-                                    uint32_t *__restrict__ ri, int32_t *__restrict__ lastz);
+                                    uint32_t *__restrict__ ri, int32_t *__restrict__ lastz, int ps);
 
 // band_wgs: the workgroups below that id are band workgroups; the B workgroups from there on (present when the launch has
 // points) run the exact input-order projection of the frames that hold a depth-0 point (project_fixup_frame) -- a no-op
@@ -662,7 +664,7 @@ __global__ __launch_bounds__(BAND_THREADS) BAND_VGPR_ATTR void project_band_kern
                                                                     const float *__restrict__ tz, float zthr, int rs_chunk,
                                                                     int32_t *__restrict__ zcnt, const int32_t *__restrict__ epoch,
                                                                     int band_wgs, const float *__restrict__ xyz, rpcc_geom g,
-                                                                    int32_t *__restrict__ lastz) {
+                                                                    int32_t *__restrict__ lastz, int ps) {
     extern __shared__ __attribute__((aligned(16))) uint32_t band[];  // [BAND_PX]
     __shared__ uint16_t ldq[BAND_ROUND * 16];   // queued loads: share of the round << 2 | 64-pair step
     __shared__ uint16_t cntl[BAND_ROUND];          // records per share
@@ -671,7 +673,7 @@ __global__ __launch_bounds__(BAND_THREADS) BAND_VGPR_ATTR void project_band_kern
     const int mark = flag_mark(epoch);
     if ((int)blockIdx.x >= band_wgs) {
         const int fb = (int)blockIdx.x - band_wgs;
-        if (flags[fb] == mark) project_fixup_frame(xyz, offs, fb, g, ri, lastz);
+        if (flags[fb] == mark) project_fixup_frame(xyz, offs, fb, g, ri, lastz, ps);
         return;
     }
     // XCD-aware mapping: consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2).  The nbands
@@ -871,7 +873,7 @@ __global__ __launch_bounds__(BAND_THREADS) BAND_VGPR_ATTR void project_band_kern
 // (all dependencies are inside a frame).  Frames without a flag -- the normal case -- leave at once, so the fast path
 // pays one empty launch instead of four.  Loads that follow this kernel's own atomics bypass the CU's L1 (agent scope).
 __device__ void project_fixup_frame(const float *__restrict__ xyz, const int64_t *__restrict__ offs, int b, rpcc_geom g,
-                                    uint32_t *__restrict__ ri, int32_t *__restrict__ lastz) {
+                                    uint32_t *__restrict__ ri, int32_t *__restrict__ lastz, int ps) {
     const int FIXUP_THREADS = blockDim.x;
     const int P = g.H * g.W;
     uint32_t *img = ri + (int64_t)b * P;
@@ -881,13 +883,13 @@ __device__ void project_fixup_frame(const float *__restrict__ xyz, const int64_t
     __syncthreads();
     const int64_t i0 = offs[b], i1 = offs[b + 1];
     for (int64_t i = i0 + threadIdx.x; i < i1; i += FIXUP_THREADS) {  // last input position of a depth-0 point per pixel
-        const RowCol rc = project_point(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], g);
+        const RowCol rc = project_point(xyz[ps * i], xyz[ps * i + 1], xyz[ps * i + 2], g);
         if (fabsf(rc.depth) <= 3.402823466e+38f && rc.depth == 0.0f) atomicMax(&lz[rc.pix], (int32_t)(i - i0) + 1);
     }
     __threadfence();
     __syncthreads();
     for (int64_t i = i0 + threadIdx.x; i < i1; i += FIXUP_THREADS) {  // minimum over the points after that position
-        const RowCol rc = project_point(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], g);
+        const RowCol rc = project_point(xyz[ps * i], xyz[ps * i + 1], xyz[ps * i + 2], g);
         if (!(fabsf(rc.depth) <= 3.402823466e+38f) || rc.depth == 0.0f) continue;
         const int32_t last = __hip_atomic_load(&lz[rc.pix], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((int32_t)(i - i0) + 1 > last) atomicMin(&img[rc.pix], f2u(rc.depth));
@@ -924,7 +926,7 @@ extern "C" int rpcc_project_fastpath_check(const float *xyz, int64_t total, rpcc
 // atomic path, which only needs B*(P+8)*4 bytes.
 static int launch_project(const float *xyz, const int64_t *offsets, int64_t total, int64_t base, int B, rpcc_geom g,
                           float *ri, void *scratch, size_t scratch_bytes, hipStream_t st, const float *tz_plane = nullptr,
-                          int32_t *zcnt = nullptr, const BatchInit *init = nullptr, const int32_t *epoch = nullptr) {
+                          int32_t *zcnt = nullptr, const BatchInit *init = nullptr, const int32_t *epoch = nullptr, int ps = 3) {
     const bool cleared = init != nullptr;   // fused batch: the pixel kernel initialises, flags are marked by epoch
     const int P = g.H * g.W;
     uint32_t *rb = reinterpret_cast<uint32_t *>(ri);
@@ -953,8 +955,9 @@ static int launch_project(const float *xyz, const int64_t *offsets, int64_t tota
         memset(&bi, 0, sizeof(bi));
         if (init) bi = *init;
         // (also for a batch without points: every chunk id's share counts are written by this kernel, the band kernel reads them)
-        project_pix_kernel<<<(unsigned)std::max<int64_t>(std::min<int64_t>(pix_chunk_ids(total, B), 256 * PIX_WG_PER_CU), 1), PIX_THREADS, 0, st>>>(
-                xyz, offsets, total, base, B, g, pix_fast_cfg(g), bb, flags, epoch, bi);
+        const unsigned pix_wgs = (unsigned)std::max<int64_t>(std::min<int64_t>(pix_chunk_ids(total, B), 256 * PIX_WG_PER_CU), 1);
+        if (ps == 4) project_pix_kernel<4><<<pix_wgs, PIX_THREADS, 0, st>>>(xyz, offsets, total, base, B, g, pix_fast_cfg(g), bb, flags, epoch, bi);
+        else project_pix_kernel<3><<<pix_wgs, PIX_THREADS, 0, st>>>(xyz, offsets, total, base, B, g, pix_fast_cfg(g), bb, flags, epoch, bi);
         HIP_TRY(ensure_dyn_lds(reinterpret_cast<const void *>(&project_band_kernel), BAND_PX * 4));
         if (zcnt && !cleared) HIP_TRY(hipMemsetAsync(zcnt, 0, (size_t)B * (RS_CHUNKS + 1) * 4, st));
         // persistent: at most one workgroup per CU (8 XCDs x 32), each walking over its XCD's (frame, band) items
@@ -962,7 +965,7 @@ static int launch_project(const float *xyz, const int64_t *offsets, int64_t tota
         const int band_wgs = 8 * std::min(((B + 7) / 8) * nbands, std::max(BAND_WG_PER_XCD / nbands, 1) * nbands);
         // + B workgroups for the exact input-order semantics of frames with depth-0 points (a no-op otherwise)
         project_band_kernel<<<band_wgs + (total > 0 ? B : 0), BAND_THREADS, BAND_PX * 4, st>>>(
-            bb, offsets, base, B, P, rb, flags, tz_plane, -1.5f, rs_chunk_px(P), tz_plane ? zcnt : nullptr, epoch, band_wgs, xyz, g, lastz);
+            bb, offsets, base, B, P, rb, flags, tz_plane, -1.5f, rs_chunk_px(P), tz_plane ? zcnt : nullptr, epoch, band_wgs, xyz, g, lastz, ps);
         LAUNCH_CHECK();
         return RPCC_OK;
     }
@@ -971,10 +974,10 @@ static int launch_project(const float *xyz, const int64_t *offsets, int64_t tota
     project_fill_kernel<false><<<fg, 256, 0, st>>>(rb, lastz, flags, P);
     LAUNCH_CHECK();
     if (total > 0) {
-        project_kernel<0><<<nb, 256, 0, st>>>(xyz, offsets, total, base, B, g, rb, lastz, flags);
+        project_kernel<0><<<nb, 256, 0, st>>>(xyz, offsets, total, base, B, g, rb, lastz, flags, ps);
         project_fill_kernel<true><<<fg, 256, 0, st>>>(rb, lastz, flags, P);
-        project_kernel<1><<<nb_small, 256, 0, st>>>(xyz, offsets, total, base, B, g, rb, lastz, flags);
-        project_kernel<2><<<nb_small, 256, 0, st>>>(xyz, offsets, total, base, B, g, rb, lastz, flags);
+        project_kernel<1><<<nb_small, 256, 0, st>>>(xyz, offsets, total, base, B, g, rb, lastz, flags, ps);
+        project_kernel<2><<<nb_small, 256, 0, st>>>(xyz, offsets, total, base, B, g, rb, lastz, flags, ps);
         LAUNCH_CHECK();
     }
     project_finalize_kernel<false><<<fg, 256, 0, st>>>(rb, P, flags);
@@ -982,13 +985,23 @@ static int launch_project(const float *xyz, const int64_t *offsets, int64_t tota
     return RPCC_OK;
 }
 
-extern "C" int rpcc_project(const float *xyz, const int64_t *offsets, int64_t total, int B, rpcc_geom g, float *ri,
-                            void *scratch, size_t scratch_bytes, void *stream) {
+// point_stride_bytes -> floats per point (0 = 12); only packed xyz (12) and the stored (x, y, z, intensity) rows (16) exist
+static inline int point_floats(int point_stride_bytes) { return point_stride_bytes == 0 || point_stride_bytes == 12 ? 3 : point_stride_bytes == 16 ? 4 : -1; }
+
+extern "C" int rpcc_project_strided(const float *points, int point_stride_bytes, const int64_t *offsets, int64_t total, int B,
+                                    rpcc_geom g, float *ri, void *scratch, size_t scratch_bytes, void *stream) {
     ARG_TRY(B > 0 && B <= RPCC_MAX_BATCH && g.H > 1 && g.W > 0 && total >= 0);
     ARG_TRY(ri != nullptr && scratch != nullptr && offsets != nullptr);
-    ARG_TRY(total == 0 || xyz != nullptr);
+    ARG_TRY(total == 0 || points != nullptr);
+    ARG_TRY(point_floats(point_stride_bytes) > 0);
+    ARG_TRY(point_stride_bytes != 16 || (reinterpret_cast<uintptr_t>(points) & 15u) == 0);   // rows are read with 16-byte loads
     ARG_TRY(scratch_bytes >= ((size_t)B * ((size_t)g.H * g.W + 8)) * 4);
-    return launch_project(xyz, offsets, total, 0, B, g, ri, scratch, scratch_bytes, (hipStream_t)stream);
+    return launch_project(points, offsets, total, 0, B, g, ri, scratch, scratch_bytes, (hipStream_t)stream, nullptr, nullptr, nullptr, nullptr,
+                          point_floats(point_stride_bytes));
+}
+extern "C" int rpcc_project(const float *xyz, const int64_t *offsets, int64_t total, int B, rpcc_geom g, float *ri,
+                            void *scratch, size_t scratch_bytes, void *stream) {
+    return rpcc_project_strided(xyz, 12, offsets, total, B, g, ri, scratch, scratch_bytes, stream);
 }
 
 // ================================================================================================
@@ -2840,7 +2853,7 @@ static int run_batch(const rpcc_batch_io *io, int Bs, int64_t npts, rpcc_geom g,
     int32_t *kpn = io->nonuniform ? reinterpret_cast<int32_t *>(extra + plane_extra_bytes(Bs, P, M) - 256 - 2 * ksz) : nullptr;
     bi.z2 = {reinterpret_cast<uint32_t *>(kpn), kpn ? Bs * (M + 2) : 0};  // key points per label
     if ((rc = launch_project(io->xyz, io->offsets, npts, 0, Bs, g, ri, proj_scratch, proj_bytes, st,
-                             rays_soa + 2 * (int64_t)P, zcnt, &bi, epoch)))
+                             rays_soa + 2 * (int64_t)P, zcnt, &bi, epoch, point_floats(io->point_stride_bytes))))
         return rc;
     if (fit_ground &&
         (rc = launch_ground_ransac(ri, io->tm, Bs, P, (uint32_t)io->ground_seed, false, ground, nullptr, st, zcnt, io->frame_ids)))
@@ -2888,6 +2901,7 @@ extern "C" int rpcc_compress_batch(const rpcc_batch_io *io, int B, rpcc_geom g, 
     // only the brute-force FPS kernel (16-byte loads at frame bases) needs P % 4 == 0; the tile-pruned one does not
     ARG_TRY(P % 4 == 0 || (io->flags & RPCC_FPS_MODE_BITS) || (!(io->flags & RPCC_FPS_BRUTEFORCE) && fps_tiling_range(g.H, g.W).T <= FPS_TILED_MAX_TILES));
     ARG_TRY(io->model_method == 0 || io->model_method == 1);
+    ARG_TRY(point_floats(io->point_stride_bytes) > 0 && (io->point_stride_bytes != 16 || (reinterpret_cast<uintptr_t>(io->xyz) & 15u) == 0));
     if (io->nonuniform) {
         const rpcc_nonuniform_cfg *nu = io->nonuniform;
         ARG_TRY(io->salience && io->key_point_map && nu->levels >= 1 && nu->levels <= 8 && nu->ground_level >= 0 && nu->ground_level < nu->levels);

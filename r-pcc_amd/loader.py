@@ -27,13 +27,13 @@ from .utils import available_cpus
 
 
 class _Slot:
-    def __init__(self, bc, B, cap_points, device):
+    def __init__(self, bc, B, cap_points, device, cols=3):
         P, K = bc.T.H * bc.T.W, bc.M + 2
-        self.B, self.cap = B, int(cap_points)
-        self.xyz_pin = torch.empty((self.cap, 3), dtype=torch.float32).pin_memory()
+        self.B, self.cap, self.cols = B, int(cap_points), int(cols)    # cols: floats per point in the staging / device input (3 or 4)
+        self.xyz_pin = torch.empty((self.cap, self.cols), dtype=torch.float32).pin_memory()
         self.offs_pin = torch.zeros((B + 1,), dtype=torch.int64).pin_memory()
         self.fid_pin = torch.zeros((B,), dtype=torch.int64).pin_memory()
-        self.xyz_dev = torch.empty((self.cap, 3), dtype=torch.float32, device=device)
+        self.xyz_dev = torch.empty((self.cap, self.cols), dtype=torch.float32, device=device)
         self.offs_dev = torch.zeros((B + 1,), dtype=torch.int64, device=device)
         self.fid_dev = torch.zeros((B,), dtype=torch.int64, device=device)
         self.ground = torch.zeros((B, 4), dtype=torch.float64, device=device)
@@ -61,8 +61,8 @@ class _Slot:
         pixel): the point-count-sized buffers are replaced.  Only called while the slot is idle (nothing of it in flight);
         the projection workspace inside BatchBuffers follows by itself (ops.compress_batch)."""
         self.cap = int(cap_points)
-        self.xyz_pin = torch.empty((self.cap, 3), dtype=torch.float32).pin_memory()
-        self.xyz_dev = torch.empty((self.cap, 3), dtype=torch.float32, device=device)
+        self.xyz_pin = torch.empty((self.cap, self.cols), dtype=torch.float32).pin_memory()
+        self.xyz_dev = torch.empty((self.cap, self.cols), dtype=torch.float32, device=device)
         self.qp = torch.empty((self.cap,), dtype=torch.int16, device=device)
         self.qp_pin = torch.empty((self.cap,), dtype=torch.int16).pin_memory()
 
@@ -100,7 +100,16 @@ class StreamingCompressor:
     """bc: pipeline.BatchCompressor (settings: lidar geometry, cluster count, framework, model, entropy back-end).
     batch: frames per device batch; depth: slots in flight; workers: host threads (staging copies, entropy coding)."""
 
-    def __init__(self, bc, batch=256, depth=4, workers=None, points_per_frame=None, pool=None):
+    def __init__(self, bc, batch=256, depth=4, workers=None, points_per_frame=None, pool=None, ingest="xyz"):
+        """ingest: "xyz"  -- frames are [N,>=3] arrays; their first three columns are copied into the pinned slot (12 bytes per
+                             point staged and sent over the link; a strided host pass when the arrays are .bin rows);
+                   "rows" -- the sweeps AS STORED (dataset/dataset.py:48-50: float32 rows x, y, z, intensity): frames are
+                             [N,4] arrays (one contiguous copy each) or .bin PATHS, which are read straight into the pinned
+                             slot (file -> pinned buffer -> DMA, no pass over the points on the host); the kernels read
+                             the rows with a 16-byte stride (rpcc_batch_io.point_stride_bytes = 16).  16 bytes per point
+                             cross the link instead of 12."""
+        assert ingest in ("xyz", "rows")
+        self.ingest = ingest
         self.bc, self.B, self.depth = bc, int(batch), int(depth)
         self.device = bc.device
         P = bc.T.H * bc.T.W
@@ -117,7 +126,7 @@ class StreamingCompressor:
         self.enq_pool = ThreadPoolExecutor(1)
         self.side_stream = torch.cuda.Stream(device=self.device)     # late copies that must not queue behind the next batch
         self.seq_eager = max(1024, self.B * P // 16)                # index-sequence entries fetched with the batch (typical: P/20 per frame)
-        self.slots = [_Slot(bc, self.B, self.cap, self.device) for _ in range(self.depth)]
+        self.slots = [_Slot(bc, self.B, self.cap, self.device, cols=4 if ingest == "rows" else 3) for _ in range(self.depth)]
         self.prof = {"stage": 0.0, "enqueue": 0.0, "collect": 0.0, "drain": 0.0}   # host seconds per phase (diagnostics)
         self.stage_chunks = max(1, min(self.B, 16))      # staging tasks per batch: a few MB each (more, smaller tasks are slower)
 
@@ -125,7 +134,11 @@ class StreamingCompressor:
     def _stage(self, slot, frames, frame_ids):
         n = len(frames)
         assert 0 < n <= self.B
-        sizes = np.fromiter((f.shape[0] for f in frames), dtype=np.int64, count=n)
+        rows = self.ingest == "rows"
+        if rows:
+            sizes = np.fromiter((os.path.getsize(f) // 16 if isinstance(f, (str, os.PathLike)) else f.shape[0] for f in frames), dtype=np.int64, count=n)
+        else:
+            sizes = np.fromiter((f.shape[0] for f in frames), dtype=np.int64, count=n)
         offs = np.zeros(self.B + 1, np.int64)
         offs[1:n + 1] = np.cumsum(sizes)
         offs[n + 1:] = offs[n]                       # a short last batch: the missing frames are empty
@@ -137,7 +150,23 @@ class StreamingCompressor:
         def copy(lo, hi):
             for i in range(lo, hi):
                 f = frames[i]
-                dst[offs[i]:offs[i + 1]] = f[:, :3]   # .bin rows are (x, y, z, intensity): the strided copy drops the 4th column
+                if not rows:
+                    dst[offs[i]:offs[i + 1]] = f[:, :3]   # .bin rows are (x, y, z, intensity): the strided copy drops the 4th column
+                elif isinstance(f, (str, os.PathLike)):       # the file's bytes land in the pinned slot: no pass over the points at all
+                    if offs[i + 1] == offs[i]:
+                        continue
+                    with open(f, "rb", buffering=0) as fh:
+                        view = memoryview(dst[offs[i]:offs[i + 1]].reshape(-1).view(np.uint8))
+                        got = fh.readinto(view)
+                        while 0 < got < len(view):            # (short reads: network file systems)
+                            m = fh.readinto(view[got:])
+                            if not m:
+                                break
+                            got += m
+                        assert got == len(view), "%s changed size while it was read" % f
+                else:
+                    assert f.ndim == 2 and f.shape[1] == 4 and f.dtype == np.float32, 'ingest="rows" takes [N,4] float32 rows or .bin paths'
+                    dst[offs[i]:offs[i + 1]] = f           # contiguous rows: one memcpy
             return hi - lo
         step = (n + self.stage_chunks - 1) // self.stage_chunks
         list(self.pool.map(lambda lo: copy(lo, min(lo + step, n)), range(0, n, step)))

@@ -41,8 +41,16 @@ def _dev(t):
     return t.device
 
 
+def _point_stride(xyz):
+    """Bytes per point of a point tensor: [N,3] packed xyz -> 12; [N,4] rows (x, y, z, intensity) as a KITTI .bin stores them
+    (dataset/dataset.py:48-50) -> 16, read by the kernel as they are."""
+    assert xyz.dim() == 2 and xyz.shape[1] in (3, 4) and xyz.dtype == torch.float32, "points: f32 [N,3] or [N,4]"
+    return 4 * int(xyz.shape[1])
+
+
 def project(xyz, offsets, geom, ri=None, scratch=None, atomic_path=False):
-    """a2 batched.  xyz f32 [total,3], offsets i64 [B+1] (device) -> ri f32 [B,H,W].
+    """a2 batched.  xyz f32 [total,3] -- or the stored rows f32 [total,4] (x, y, z, intensity), read with a 16-byte stride --,
+    offsets i64 [B+1] (device) -> ri f32 [B,H,W].
     atomic_path=True gives the library only the small scratch, which selects the device-atomic kernels
     (same result as the default LDS-band kernels)."""
     B = offsets.numel() - 1
@@ -53,8 +61,8 @@ def project(xyz, offsets, geom, ri=None, scratch=None, atomic_path=False):
     if scratch is None:
         n = B * (P + 8) * 4 if atomic_path else _lib.lib().rpcc_project_scratch_bytes(xyz.shape[0], B, P)
         scratch = torch.empty(n, dtype=torch.uint8, device=_dev(offsets))
-    check(_lib.lib().rpcc_project(ptr(xyz) if xyz.numel() else None, ptr(offsets), xyz.shape[0], B, geom, ptr(ri),
-                                  ptr(scratch), scratch.numel() * scratch.element_size(), stream()))
+    check(_lib.lib().rpcc_project_strided(ptr(xyz) if xyz.numel() else None, _point_stride(xyz), ptr(offsets), xyz.shape[0], B, geom,
+                                          ptr(ri), ptr(scratch), scratch.numel() * scratch.element_size(), stream()))
     return ri
 
 
@@ -362,7 +370,8 @@ def compress_batch(xyz, offsets, tm, ground, buf, ground_threshold=0.1, acc=0.04
                    fps_bruteforce=False, timer=None, model_method="point", angle_threshold=75, plane_seed=0, nonuniform=None,
                    fps_fma=None, fps_cuda_tie=None):
     """Fused a2..a13 for a batch, one call: FPS segmentation, point or plane model, uniform or non-uniform framework
-    (tools/compress.py:93-125).  ground f64 [B,4]: injected models when ground_seed < 0, otherwise output of the seeded
+    (tools/compress.py:93-125).  xyz: f32 [total,3], or the stored (x, y, z, intensity) rows f32 [total,4] (16-byte stride,
+    no host-side slice).  ground f64 [B,4]: injected models when ground_seed < 0, otherwise output of the seeded
     ground RANSAC run inside the call (frame b draws with ground_seed + frame_ids[b]; frame_ids: stable identities,
     e.g. utils.frame_identity(path); default the batch position).  model_method "plane": rpcc_plane_model's seeded fits
     (plane_seed, frame_ids) with the reference's angle validation.  nonuniform: a nonuniform_cfg() struct -> key points,
@@ -386,7 +395,8 @@ def compress_batch(xyz, offsets, tm, ground, buf, ground_threshold=0.1, acc=0.04
                  0 if model_method == "point" else 1, angle_cos_cut(angle_threshold) if model_method != "point" else 0.0,
                  int(plane_seed), C.addressof(nonuniform) if nonuniform is not None else None,
                  ptr(buf.salience).value if nonuniform is not None else None,
-                 ptr(buf.key_point_map).value if nonuniform is not None else None)
+                 ptr(buf.key_point_map).value if nonuniform is not None else None,
+                 _point_stride(xyz))
     check(_lib.lib().rpcc_compress_batch(C.byref(io), buf.B, buf.geom, buf.M, float(ground_threshold), float(acc),
                                          ptr(buf.ws), stream()))
     return buf

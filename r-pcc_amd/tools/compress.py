@@ -32,6 +32,9 @@ def make_parser(datalist=False):
         p.add_argument("--batch", type=int, default=64, help="frames per device batch.")
         p.add_argument("--points-per-frame", dest="points_per_frame", type=int, default=None,
                        help="initial staging capacity in points per frame (default H x W; the staging slots grow on demand).")
+        p.add_argument("--ingest", choices=("auto", "rows", "xyz"), default="auto",
+                       help="rows: .bin sweeps go to the device as stored (x, y, z, intensity rows, 16-byte stride, no host pass); "
+                            "xyz: loaded and sliced on the host (12 bytes per point over the link); auto: rows when every file is a .bin.")
         p.add_argument("--gather", action="store_true",
                        help="multi-GPU: every rank entropy-codes its shard, the .rpcc bytes are gathered to rank 0 (RCCL) in "
                             "datalist order and rank 0 writes all files (default: every rank writes its own files).")

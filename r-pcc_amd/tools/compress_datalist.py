@@ -106,15 +106,21 @@ def compress(args):
     with futures.ThreadPoolExecutor(args.workers) as pool:
         # staged, double-buffered feed (loader.StreamingCompressor): file reads of batch n+1, device work of batch n and
         # entropy coding + file output of batch n-1 overlap
+        # .bin sweeps (float32 rows x, y, z, intensity: dataset/dataset.py:48-50) are read straight into the pinned staging slot
+        # and go to the device as stored -- no np.fromfile + [:, :3] pass on the host; other formats are loaded and sliced
+        want = getattr(args, "ingest", "auto")
+        all_bin = len(mine) > 0 and all(str(dataset.data_list[i]).endswith(".bin") for i in mine)
+        ingest = "rows" if (want == "rows" or (want == "auto" and all_bin)) else "xyz"
+        assert ingest == "xyz" or all_bin, "--ingest rows needs a datalist of .bin files"
         sc = StreamingCompressor(bc, batch=min(args.batch, max(len(mine), 1)), depth=4, workers=args.workers, pool=pool,
-                                 points_per_frame=getattr(args, "points_per_frame", None))
+                                 points_per_frame=getattr(args, "points_per_frame", None), ingest=ingest)
         names_of = {}
 
         def batches():
             for k, s in enumerate(range(0, len(mine), sc.B)):
                 names = [dataset.data_list[i] for i in mine[s:s + sc.B]]
                 names_of[k] = names
-                frames = list(pool.map(dataset.load_data, names))
+                frames = names if ingest == "rows" else list(pool.map(dataset.load_data, names))
                 yield frames, [frame_identity(n) for n in names]
 
         def write_all(jobs):      # jobs: [(file name, bytes)]

@@ -136,6 +136,48 @@ def test_datalist_gather_writes_the_same_files(fe, tmp_path):
         assert os.path.getsize(a) > 1000 and open(a, "rb").read() == open(b, "rb").read(), n
 
 
+def test_streaming_loader_rows_ingest(fe, tmp_path):
+    """ingest="rows": the sweeps as stored (float32 rows x, y, z, intensity; dataset/dataset.py:48-50) -- [N,4] arrays copied whole,
+    or .bin PATHS read straight into the pinned slot -- go to the device unsliced (rpcc_batch_io.point_stride_bytes = 16).  The
+    .rpcc bytes equal those of the default ingest (host-side [:, :3] slice); a slot that is too small grows; the datalist tool
+    picks the mode by itself for a datalist of .bin files."""
+    from oracle import oracle as orc
+    from rpcc_amd import synth
+    from rpcc_amd.loader import StreamingCompressor
+    gd = orc.GEOMS["VelodyneVLP16"]
+    ds = fe.ds.build_dataset(lidar_type="VelodyneVLP16")
+    frames = [synth.make_frame(1700 + i, gd["H"], gd["W"], vmax_deg=gd["vmax_deg"], vmin_deg=gd["vmin_deg"]).numpy() for i in range(7)]
+    frames[2] = np.zeros((0, 3), np.float32)
+    rng = np.random.default_rng(4)
+    rows = [np.concatenate([f, rng.random((f.shape[0], 1), dtype=np.float32)], 1) for f in frames]
+    paths = []
+    for i, r in enumerate(rows):
+        paths.append(str(tmp_path / ("%06d.bin" % i)))
+        r.tofile(paths[-1])
+    ids = [40 + 3 * i for i in range(len(frames))]
+    bc = fe.pl.BatchCompressor(ds.PCTransformer, accuracy=0.02, seed=9)
+    want = {}
+    StreamingCompressor(bc, batch=3, depth=2, workers=2).run(((frames[s:s + 3], ids[s:s + 3]) for s in range(0, 7, 3)),
+                                                             sink=lambda k, r: want.__setitem__(k, r))
+    for src in (rows, paths):
+        sc = StreamingCompressor(bc, batch=3, depth=2, workers=2, ingest="rows", points_per_frame=64)   # (undersized on purpose)
+        got = {}
+        n = sc.run(((src[s:s + 3], ids[s:s + 3]) for s in range(0, 7, 3)), sink=lambda k, r: got.__setitem__(k, r))
+        assert n == 7 and sc.grown >= 1 and sc.slots[0].xyz_dev.shape[1] == 4
+        assert got == want
+    # the datalist tool: .bin datalist -> rows by itself; the files equal those of --ingest xyz
+    dl = tmp_path / "list.txt"
+    dl.write_text("\n".join(paths) + "\n")
+    from rpcc_amd.tools import compress_datalist as tdl
+    outs = {}
+    for mode in ("auto", "xyz"):
+        od = tmp_path / ("out_" + mode)
+        tdl.compress(fe.tc.make_parser(datalist=True).parse_args(["--datalist", str(dl), "--output_dir", str(od), "--lidar", "VelodyneVLP16",
+                                                                  "--batch", "4", "--ingest", mode]))
+        outs[mode] = {os.path.basename(f): open(os.path.join(d, f), "rb").read() for d, _, fs in os.walk(od) for f in fs}
+    assert len(outs["auto"]) == 7 and outs["auto"] == outs["xyz"]
+
+
 def test_streaming_loader_grows_its_slots(fe):
     """A batch with more points than one per pixel and frame (dense / dual-return sweeps): the staging slot grows instead of
     raising, and the bytes equal BatchCompressor.compress (which sizes its buffers from the data)."""

@@ -152,6 +152,60 @@ def test_projection_edge_cases(env):
         assert _beq(r[0], orc.project(z["xyz"], g32))
 
 
+def test_projection_rows_as_stored(env):
+    """point_stride_bytes = 16: the sweep as a KITTI .bin stores it -- float32 rows (x, y, z, intensity), which the reference reads with
+    np.fromfile(...).reshape(-1, 4) and slices [:, :3] on the host (dataset/dataset.py:48-50,62) -- goes to the kernels unsliced.  Same
+    range image as the packed xyz, on the binned and on the device-atomic path, with depth-0 points (input-order fix-up), the
+    exact-sequence queue, ragged / empty frames and a garbage 4th column (NaN, inf) that must never be read as a coordinate."""
+    torch, ops, orc = env["torch"], env["ops"], env["orc"]
+    g, geom, tm = _geom(env, "Velodyne64E")
+    rng = np.random.default_rng(2104)
+    a = rng.normal(0, 20, (70001, 3)).astype(np.float32)
+    a[:, 2] = rng.normal(-1, 1.5, a.shape[0])
+    b = a[:5003].copy()
+    for k in (17, 2500, 5002):
+        b[k] = 0                                                   # depth-0 points: the frame takes the fix-up path
+    b[30:40] = [[5, -1e-9, 0.0]] * 10                             # column wrap: exact sequence
+    frames = [a, b, np.zeros((0, 3), np.float32), a[:1].copy(), b[::-1].copy(), a[1000:3049].copy()]
+    offs = np.zeros(len(frames) + 1, np.int64)
+    offs[1:] = np.cumsum([f.shape[0] for f in frames])
+    xyz = np.concatenate(frames)
+    rows = np.empty((xyz.shape[0], 4), np.float32)
+    rows[:, :3] = xyz
+    rows[:, 3] = rng.choice(np.array([0.0, 0.37, np.nan, np.inf, -1e30], np.float32), xyz.shape[0])
+    for atomic in (False, True):
+        ri3 = ops.project(_to(env, xyz), _to(env, offs), geom, atomic_path=atomic).cpu().numpy()
+        ri4 = ops.project(_to(env, rows), _to(env, offs), geom, atomic_path=atomic).cpu().numpy()
+        assert _beq(ri3, ri4), atomic
+        for i, f in enumerate(frames):
+            assert _beq(ri4[i], orc.project(f, g)), (atomic, i)
+    # the fused entry: every output of the batch
+    gms = _to(env, np.tile(np.array([0.01, -0.02, -0.9997, -1.72]), (len(frames), 1)))
+    outs = []
+    for pts in (xyz, rows):
+        buf = ops.BatchBuffers(len(frames), geom, 100, env["dev"])
+        ops.compress_batch(_to(env, pts), _to(env, offs), _to(env, tm), gms.clone(), buf)
+        torch.cuda.synchronize()
+        outs.append([t.cpu().numpy().copy() for t in (buf.ri, buf.seg, buf.cen_pix, buf.nnz, buf.q16, buf.model)])
+    for u, v in zip(*outs):
+        if u.dtype == np.float32:
+            assert _beq(u, v)
+        elif u.dtype == np.int16:
+            n = outs[0][3]
+            assert all(np.array_equal(u[i, :n[i]], v[i, :n[i]]) for i in range(len(frames)))
+        else:
+            assert np.array_equal(u, v)
+    # an unsupported stride and a misaligned row pointer are refused, not mis-read
+    from rpcc_amd import _lib
+    sc = torch.empty(_lib.lib().rpcc_project_scratch_bytes(8, 1, geom.H * geom.W), dtype=torch.uint8, device=env["dev"])
+    ri = torch.empty((1, geom.H, geom.W), dtype=torch.float32, device=env["dev"])
+    r16 = _to(env, rows[:9])
+    o1 = _to(env, np.array([0, 8], np.int64))
+    assert _lib.lib().rpcc_project_strided(ops.ptr(r16), 20, ops.ptr(o1), 8, 1, geom, ops.ptr(ri), ops.ptr(sc), sc.numel(), ops.stream()) == -1
+    mis = r16.view(-1)[1:33]                                       # 4-byte aligned only
+    assert _lib.lib().rpcc_project_strided(ops.ptr(mis), 16, ops.ptr(o1), 8, 1, geom, ops.ptr(ri), ops.ptr(sc), sc.numel(), ops.stream()) == -1
+
+
 def test_projection_record_bins(env):
     """The pixel kernel bins its records by (frame, image band) in chunks that never cross a frame end: ragged batches of tiny and
     empty frames, a frame larger than one round of the band kernel's queue, scan-ordered points (one band per chunk), images of

@@ -76,6 +76,22 @@ def classify(op):
     return "other"
 
 
+# SIMD cycles a wave64 instruction occupies the VALU for (measured: tools_dev/valu_peak.hip, profiles/r04_valu_peak.md).
+FAST2 = {"v_fma_f32", "v_mul_f32", "v_add_f32", "v_sub_f32", "v_subrev_f32", "v_fmac_f32", "v_mac_f32", "v_add_u32", "v_sub_u32", "v_subrev_u32",
+         "v_and_b32", "v_or_b32", "v_xor_b32", "v_not_b32", "v_lshrrev_b32", "v_ashrrev_i32", "v_mov_b32"}
+
+
+def valu_cycles(op):
+    base = re.sub(r"_(e32|e64|sdwa)$", "", op)
+    if "_dpp" in base:
+        return 4
+    if re.match(r"v_(rcp|rsq|sqrt)_f64", base):
+        return 16
+    if re.match(r"v_(rcp|rsq|sqrt|exp|log|sin|cos)_", base):
+        return 8
+    return 2 if base in FAST2 else 4
+
+
 def parse(path):
     kernels, cur, body = {}, None, []
     meta = collections.defaultdict(dict)
@@ -117,6 +133,9 @@ def main():
     for k in names:
         c = collections.Counter(classify(op) for op in kernels[k])
         tot_valu = sum(v for kk, v in c.items() if kk.startswith("valu"))
+        vops = [op for op in kernels[k] if op.startswith("v_")]
+        c["cyc"] = sum(valu_cycles(op) for op in vops) / max(len(vops), 1)
+        c["fast2"] = sum(1 for op in vops if valu_cycles(op) == 2) / max(len(vops), 1)
         rows.append((dm[k], tot_valu, c, meta[k]))
         if dump and dump in dm[k]:
             print("==== " + dm[k])
@@ -124,17 +143,19 @@ def main():
             for op, n in ops.most_common(60):
                 print("  %-28s %d" % (op, n))
     rows.sort(key=lambda r: -r[1])
-    hdr = "| kernel | VALU total | " + " | ".join(c.replace("valu_", "v:") for c in classes) + " | VGPR | AGPR | SGPR | scratch B | LDS B | occupancy |"
-    L = [hdr, "|" + "---|" * (len(classes) + 8)]
+    hdr = "| kernel | VALU total | share of 2-cycle ops | mean cycles per VALU instr. | " + " | ".join(c.replace("valu_", "v:") for c in classes) + " | VGPR | AGPR | SGPR | scratch B | LDS B | occupancy |"
+    L = [hdr, "|" + "---|" * (len(classes) + 10)]
     for n, tv, c, m in rows:
-        L.append("| `%s` | %d | " % (n[:70], tv) + " | ".join(str(c.get(cl, 0)) for cl in classes) +
+        L.append("| `%s` | %d | %.2f | %.2f | " % (n[:70], tv, c["fast2"], c["cyc"]) + " | ".join(str(c.get(cl, 0)) for cl in classes) +
                  " | %s | %s | %s | %s | %s | %s |" % (m.get("NumVgprs"), m.get("NumAgprs"), m.get("NumSgprs"), m.get("ScratchSize"), m.get("LDSByteSize"), m.get("Occupancy")))
     text = "\n".join(L) + "\n"
     if md:
         open(md, "w").write("# Static gfx950 instruction counts per kernel (hipcc --save-temps, product flags%s)\n\n" % ((" + " + " ".join(args)) if args else "") +
                             "`valu` = plain VALU; v:f64 fp64, v:pk packed fp32, v:trans rcp/sqrt/..., v:div the div_scale/fmas/fixup helpers of an IEEE "
                             "division, v:dpp DPP forms, v:lane readlane/readfirstlane, v:cmp compares, v:sel cndmask.  Static counts: loops and branches "
-                            "are counted once.\n\n" + text)
+                            "are counted once.  Share of 2-cycle ops / mean cycles: every VALU instruction weighted with the SIMD cycles its class occupies "
+                            "(2: fma / mul / add / sub f32, add / sub u32, and / or / xor / not, right shifts, mov; 8: fp32 transcendentals; 16: fp64 rcp / sqrt; 4: "
+                            "everything else -- measured, profiles/r04_valu_peak.md).\n\n" + text)
     else:
         print(text)
     print("asm:", asm)
