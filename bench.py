@@ -27,10 +27,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-# 1024 SIMDs x one wave64 VALU instruction per 4 cycles at 2.4 GHz.  (The 157 TFLOP/s fp32 vector peak of the data sheet is
-# 1024 SIMDs x 16 lanes x 2 (fma) x 2 (packed) x 2.4 GHz: a non-packed wave64 instruction occupies a SIMD for 4 cycles; the VALU-bound
-# kernels of this path -- pixel, mask, assign, quantiser -- measure 84-93 % of this rate)
-VALU_PEAK_WAVE_INSTS_PER_S = 1024 * 2.4e9 / 4
+# VALU: 1024 SIMDs x 2.4 GHz cycles per second.  A wave64 instruction occupies its SIMD for 2 cycles (fma / mul / add / sub f32, add / sub
+# u32, and / or / xor, right shifts, mov), 4 cycles (compares, selects, min / max, conversions, 3-operand integer forms, packed fp32,
+# fp64, DPP, lane operations) or 8 (fp32 transcendentals) -- measured per class by tools_dev/valu_peak.hip, profiles/r04_valu_peak.md.
+# The step's VALU work is therefore counted in SIMD cycles: PMC SQ_INSTS_VALU per kernel x the mean cycles of the kernel's static
+# instruction mix (profiles/pmc_current.json: step_valu_simd_cycles), and priced against the cycles the chip has.
+VALU_SIMD_CYCLES_PER_S = 1024 * 2.4e9
 
 
 def _flush_c_stdio():
@@ -284,10 +286,10 @@ def pmc_numbers(a, B, geom_s, M):
             return None
         key = [k for k in pm["kernels"] if k.startswith(("fps_regtab_kernel<true", "fps_tiled_kernel<true"))][0]   # template arguments vary
         return dict(kernel=key, traffic=pm["kernels"][key]["traffic_bytes_per_launch"],
-                    valu=pm["kernels"][key].get("valu_wave_insts_per_launch"), step_traffic=pm.get("step_traffic_bytes"),
-                    step_valu=pm.get("step_valu_wave_insts"),
+                    valu=pm["kernels"][key].get("valu_wave_insts_per_launch"), valu_cyc=pm["kernels"][key].get("valu_mean_cycles_static"),
+                    step_traffic=pm.get("step_traffic_bytes"), step_valu=pm.get("step_valu_wave_insts"), step_cycles=pm.get("step_valu_simd_cycles"),
                     src="profiles/%s_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU, separate passes, serial steps, x2 read "
-                        "correction); constants of the committed profile, not measured in this run" % pm.get("tag", "?"))
+                        "correction) + profiles/isa_mix_current.json (static cycle mix); constants of the committed profile, not measured in this run" % pm.get("tag", "?"))
     except Exception:
         return None
 
@@ -544,7 +546,9 @@ def run_workload(a, ctx):
         pm = pmc_numbers(a, B, geom_s, M)
         fps_kernel = "fps_range_kernel (brute force)" if a.fps_bruteforce else (pm["kernel"] if pm else "fps_regtab_kernel")
         step_s = dt / steps
-        step_valu_frac = pm["step_valu"] / step_s / VALU_PEAK_WAVE_INSTS_PER_S if pm and pm.get("step_valu") else None
+        mean_cyc = (pm["step_cycles"] / pm["step_valu"]) if pm and pm.get("step_valu") and pm.get("step_cycles") else None
+        valu_peak = VALU_SIMD_CYCLES_PER_S / mean_cyc if mean_cyc else None       # wave-instructions per second of THIS instruction mix
+        step_valu_frac = pm["step_cycles"] / step_s / VALU_SIMD_CYCLES_PER_S if mean_cyc else None
         step_traffic_frac = pm["step_traffic"] / step_s / 1e9 / HBM_PEAK_GBS if pm and pm.get("step_traffic") else None
         workload = ("configs[%d]: batch=%d %s Velodyne-64E frames (%dx%d) per GPU, %s, accuracy=%g, cluster_num=%d, ground plane by "
                     "seeded RANSAC inside the step" % (a.config, B, "real (%s, rotated copies, %s)" % (os.path.basename(a.input), "shuffled" if a.input_shuffle else "points in stored order") if a.input else "synthetic",
@@ -554,17 +558,19 @@ def run_workload(a, ctx):
                                                                         else " (payload bytes stay with the rank that writes the files)"))
         if world > 1 or a.force_gather:
             workload += "; exchange per step: " + exch_s
-        # The roofline object.  The step is bound by VALU issue, not by HBM (five of the nine kernels
-        # run at 84-93 % of the chip's VALU issue rate when alone; the whole pipelined step at ~70 %), so `bound`, `achieved`,
+        # The roofline object.  The resource the step uses most is the VALU (profiles/r04_valu_peak.md: the throughput kernels keep the
+        # pipes 48-79 % busy when alone, the pipelined step ~60 %; HBM-side traffic is at ~40 % of the spec), so `bound`, `achieved`,
         # `peak` and `frac` describe THAT resource over the whole step.  The task statement's stream-once HBM figure of the
         # dominant kernel (FPS) is kept under dominant_kernel.stream_once, labelled: the exact tile-pruned kernel does not
         # move those bytes, so it exceeds the peak and bounds nothing.
         roof = {"bound": "valu", "scope": "whole step (all launches of one batch, %d batches in flight)" % depth,
-                "what": "wave-level VALU instructions of the step (PMC SQ_INSTS_VALU, summed over its launches) / measured step time / "
-                        "chip issue rate (1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction)",
-                "achieved": (round(pm["step_valu"] / step_s / 1e9, 2) if pm and pm.get("step_valu") else None),
-                "peak": round(VALU_PEAK_WAVE_INSTS_PER_S / 1e9, 1), "unit": "G wave-instr/s",
+                "what": "VALU pipe time of the step / measured step time: wave-level VALU instructions per kernel (PMC SQ_INSTS_VALU) x the mean SIMD "
+                        "cycles per instruction of the kernel's static instruction mix (2 / 4 / 8 cycles by class, measured: profiles/r04_valu_peak.md), "
+                        "summed over the step's launches, against 1024 SIMDs x 2.4 GHz; achieved / peak in wave-instructions of this mix",
+                "achieved": (round(pm["step_valu"] / step_s / 1e9, 2) if mean_cyc else None),
+                "peak": (round(valu_peak / 1e9, 1) if valu_peak else None), "unit": "G wave-instr/s",
                 "frac": (round(step_valu_frac, 4) if step_valu_frac is not None else None),
+                "mean_valu_cycles_per_instruction": (round(mean_cyc, 3) if mean_cyc else None),
                 "traffic": (pm["step_traffic"] if pm else None),
                 "step_valu_wave_insts": (pm["step_valu"] if pm else None),
                 "step_valu_frac": (round(step_valu_frac, 4) if step_valu_frac is not None else None),
@@ -579,7 +585,7 @@ def run_workload(a, ctx):
                     "traffic": pm["traffic"] if pm else None,
                     "traffic_frac": (round(pm["traffic"] / lt / 1e9 / HBM_PEAK_GBS, 4) if pm and fps_n else None),
                     "valu_wave_insts": pm["valu"] if pm else None,
-                    "valu_frac": (round(pm["valu"] / lt / VALU_PEAK_WAVE_INSTS_PER_S, 4) if pm and pm.get("valu") and fps_n else None),
+                    "valu_frac": (round(pm["valu"] * pm["valu_cyc"] / lt / VALU_SIMD_CYCLES_PER_S, 4) if pm and pm.get("valu") and pm.get("valu_cyc") and fps_n else None),
                     "stream_once": {"model": "SURVEY 8d: 20*(M-1)*n_left bytes per frame, the bytes the reference's brute-force algorithm streams",
                                     "alg_bytes_per_launch": fps_bytes, "achieved": round(stream_once, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                     "frac": round(stream_once / HBM_PEAK_GBS, 4),

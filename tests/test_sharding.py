@@ -314,5 +314,8 @@ def test_bench_finds_its_pmc_numbers():
     assert len(keys) == 1, list(pm["kernels"])
     assert pm["kernels"][keys[0]]["traffic_bytes_per_launch"] > 0 and pm["kernels"][keys[0]]["valu_wave_insts_per_launch"] > 0
     assert pm["step_traffic_bytes"] > 0 and pm["step_valu_wave_insts"] > 0     # roofline.frac (VALU issue) / step_traffic_frac
+    # the VALU roofline is priced in SIMD cycles of the measured 2 / 4 / 8-cycle classes (profiles/r04_valu_peak.md)
+    assert 2.0 * pm["step_valu_wave_insts"] <= pm["step_valu_simd_cycles"] <= 4.5 * pm["step_valu_wave_insts"]
+    assert all(2.0 <= k["valu_mean_cycles_static"] <= 8.0 for k in pm["kernels"].values())
     src = open(os.path.join(root, "bench.py")).read()
     assert 'startswith(("fps_regtab_kernel<true", "fps_tiled_kernel<true"))' in src

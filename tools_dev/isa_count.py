@@ -121,6 +121,9 @@ def main():
     md = dump = None
     if "--md" in args:
         i = args.index("--md"); md = args[i + 1]; del args[i:i + 2]
+    js = None
+    if "--json" in args:
+        i = args.index("--json"); js = args[i + 1]; del args[i:i + 2]
     if "--dump" in args:
         i = args.index("--dump"); dump = args[i + 1]; del args[i:i + 2]
     asm = compile_asm(args)
@@ -149,6 +152,10 @@ def main():
         L.append("| `%s` | %d | %.2f | %.2f | " % (n[:70], tv, c["fast2"], c["cyc"]) + " | ".join(str(c.get(cl, 0)) for cl in classes) +
                  " | %s | %s | %s | %s | %s | %s |" % (m.get("NumVgprs"), m.get("NumAgprs"), m.get("NumSgprs"), m.get("ScratchSize"), m.get("LDSByteSize"), m.get("Occupancy")))
     text = "\n".join(L) + "\n"
+    if js:   # kernel -> static mean VALU cycles per instruction and share of 2-cycle operations (tools_profiles.py, bench.py's roofline)
+        import json
+        json.dump({n: {"valu_mean_cycles": round(c["cyc"], 4), "share_2cycle": round(c["fast2"], 4), "valu_static": tv} for n, tv, c, m in rows},
+                  open(js, "w"), indent=1, sort_keys=True)
     if md:
         open(md, "w").write("# Static gfx950 instruction counts per kernel (hipcc --save-temps, product flags%s)\n\n" % ((" + " + " ".join(args)) if args else "") +
                             "`valu` = plain VALU; v:f64 fp64, v:pk packed fp32, v:trans rcp/sqrt/..., v:div the div_scale/fmas/fixup helpers of an IEEE "
