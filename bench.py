@@ -69,6 +69,8 @@ def parse():
     ap.add_argument("--fps-bruteforce", action="store_true",
                     help="run the brute-force FPS kernel (streams every candidate for every sample: the reference algorithm's "
                          "roofline case) instead of the exact tile-pruned one; same results")
+    ap.add_argument("--scene", default="default", choices=("default", "shell", "noise", "corridor"),
+                    help="synthetic scene: the headline's (default) or an adversarial input of the FPS pruning study (synth.make_frame)")
     ap.add_argument("--pipeline", type=int, default=3, help="batches in flight (streams); 1 = strictly serial steps")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary measurements (configs[2] fused, the real sweep, the datalist feed) that follow the headline at N=1")
@@ -282,7 +284,7 @@ def pmc_numbers(a, B, geom_s, M):
     try:
         name = "pmc_current.json" if a.config == 1 and not a.input else "pmc_current_c%d%s.json" % (a.config, "_real" if a.input else "")
         pm = json.load(open(os.path.join(ROOT, "profiles", name)))
-        if pm["config"] != {"batch": B, "geom": geom_s, "clusters": M, "config": a.config, "input": bool(a.input)} or a.fps_bruteforce:
+        if pm["config"] != {"batch": B, "geom": geom_s, "clusters": M, "config": a.config, "input": bool(a.input)} or a.fps_bruteforce or a.scene != "default":
             return None
         key = [k for k in pm["kernels"] if k.startswith(("fps_regtab_kernel<true", "fps_tiled_kernel<true"))][0]   # template arguments vary
         return dict(kernel=key, traffic=pm["kernels"][key]["traffic_bytes_per_launch"],
@@ -316,7 +318,7 @@ def run_workload(a, ctx):
     if a.input:
         xyz, offs = load_real_batch(a.input, ids, H, W, dev, shuffle=a.input_shuffle)
     else:
-        xyz, offs = synth.make_batch(ids, H, W, device=dev)
+        xyz, offs = synth.make_batch(ids, H, W, device=dev, scene=a.scene)
     offs_host = offs.cpu().numpy()
     fid = torch.as_tensor(np.asarray(ids, np.int64), device=dev)
     tm = torch.from_numpy(tm_np).to(dev)
@@ -551,7 +553,8 @@ def run_workload(a, ctx):
         step_valu_frac = pm["step_cycles"] / step_s / VALU_SIMD_CYCLES_PER_S if mean_cyc else None
         step_traffic_frac = pm["step_traffic"] / step_s / 1e9 / HBM_PEAK_GBS if pm and pm.get("step_traffic") else None
         workload = ("configs[%d]: batch=%d %s Velodyne-64E frames (%dx%d) per GPU, %s, accuracy=%g, cluster_num=%d, ground plane by "
-                    "seeded RANSAC inside the step" % (a.config, B, "real (%s, rotated copies, %s)" % (os.path.basename(a.input), "shuffled" if a.input_shuffle else "points in stored order") if a.input else "synthetic",
+                    "seeded RANSAC inside the step" % (a.config, B, "real (%s, rotated copies, %s)" % (os.path.basename(a.input), "shuffled" if a.input_shuffle else "points in stored order") if a.input
+                                                       else ("synthetic" if a.scene == "default" else "synthetic ADVERSARIAL scene '%s'" % a.scene),
                                                        H, W, "non-uniform + FPS + plane-model" if general else "uniform + FPS + point-model", a.accuracy, M))
         exch_s = ("no exchange" if not exchange else
                   "RCCL all_gather of the per-frame payload lengths" + (" + gather of the packed pre-entropy residual streams to rank 0" if a.gather_payloads
@@ -776,7 +779,7 @@ def main():
     import rpcc_amd  # noqa: F401
     ctx = dict(rank=rank, world=world, dev=dev, dist=dist)
     out = run_workload(a, ctx)
-    headline = a.config == 1 and not a.input and a.geom is None and not (a.fps_bruteforce or a.h2d or a.force_gather)
+    headline = a.config == 1 and not a.input and a.geom is None and a.scene == "default" and not (a.fps_bruteforce or a.h2d or a.force_gather)
     if out is not None and world == 1 and headline and not a.no_secondary:     # beside the headline only
         out["secondary"] = run_secondary(a, ctx)
         out["secondary_verified"] = not any(isinstance(v, dict) and v.get("verified") is False for v in out["secondary"].values())

@@ -38,7 +38,7 @@ def build(force=False, verbose=False):
     if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in DEPS):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    extra = os.environ.get("RPCC_EXTRA_FLAGS", "").split()   # developer knob: -D switches of the tuning experiments (tools_dev/)
+    extra = os.environ.get("RPCC_EXTRA_FLAGS", "").split()   # developer builds only: -DRPCC_DEVTRACE (csrc/rpcc_trace.h)
     cmd = [hipcc] + HIPCC_FLAGS + extra + [SRC, "-o", LIB]
     if verbose:
         print(" ".join(cmd))

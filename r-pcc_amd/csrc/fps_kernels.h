@@ -184,13 +184,9 @@ __device__ __forceinline__ void fps_load_point(const float *__restrict__ src, co
 // Threads of the tile-pruned FPS workgroup (one workgroup per frame): FPS_TT_BATCH for batches that fill the chip
 // (several batches in flight share the CUs), FPS_TT_SMALL for small batches (nothing to co-schedule with).
 // Measurements: DESIGN.md section 5.
-#ifndef FPS_TT_BATCH
 #define FPS_TT_BATCH 512
-#endif
 #define FPS_TT_SMALL 1024
-#ifndef FPS_GROUP
 #define FPS_GROUP 2
-#endif
 #define FPS_FLAG_FINALIZE_TEMP 1  // write the origin class's value back to the empty pixels' temp entries at the end
 
 template <bool RANGE, bool VEC, int FPS_TT>
@@ -344,7 +340,6 @@ __global__ __launch_bounds__(FPS_TT) void fps_tiled_kernel(const float *__restri
     };
 
     constexpr int NW = FPS_TT / 64, GROUP = FPS_GROUP;  // tiles per wavefront in flight
-    DBG_STAMP(8);
     // first centre: every tile is visited once (also builds the boxes) -- unless ground_mask already did
     // that pass and left the tile table (info[b][3] == 1)
     const bool have_tab = RANGE && tiletab != nullptr && info[RPCC_INFO * b + 3] == 1;
@@ -377,20 +372,10 @@ __global__ __launch_bounds__(FPS_TT) void fps_tiled_kernel(const float *__restri
         update_origin();
     }
     if (M > 1) {
-        DBG_STAMP(9);
         select_next();
-        DBG_STAMP(10);
         if (tid == 0) { out_idx[1] = old; if (out_cen) { out_cen[3] = c0; out_cen[4] = c1; out_cen[5] = c2; } }
     }
-#ifdef RPCC_DEVTRACE   // developer trace (per-iteration cycle stamps of workgroup 0); absent from the shipped build
-    long long acc_a = 0, acc_b = 0, acc_c = 0, acc_n = 0, tq = 0;
-    const bool prof = g_dbg_stamps != nullptr && blockIdx.x == 0 && tid == 0;
-#define FPS_TR(code_) do { if (prof) { code_; } } while (0)
-#else
-#define FPS_TR(code_) do { } while (0)
-#endif
     for (int j = 2; j < M; j++) {
-        FPS_TR(tq = (long long)__builtin_readcyclecounter());
         // tile test against the new centre; active tiles go to the work list
         for (int t = tid; t < T; t += FPS_TT) {
             const float4 lo = L.lo4[t], hi = L.hi4[t];
@@ -410,8 +395,6 @@ __global__ __launch_bounds__(FPS_TT) void fps_tiled_kernel(const float *__restri
         update_origin();
         __syncthreads();
         const int n = wcount;
-        FPS_TR(const long long t1 = (long long)__builtin_readcyclecounter(); acc_a += t1 - tq; tq = t1; acc_n += n;
-               g_dbg_stamps[64 + 8 * j] = n; g_dbg_stamps[64 + 8 * j + 1] = acc_a);
         for (int e = wave; e < n; e += NW * GROUP) {
             FpsQuad q[GROUP];
             int tt[GROUP];
@@ -422,27 +405,14 @@ __global__ __launch_bounds__(FPS_TT) void fps_tiled_kernel(const float *__restri
                 locate(tt[gi], q[gi]);
                 fps_quad_load<RANGE, VEC>(src, rays, temp, q[gi]);   // unconditional (a repeated tile for the tail is harmless and unused)
             }
-#ifdef RPCC_DEVTRACE
-            if (prof && e == wave) g_dbg_stamps[64 + 8 * j + 2] = (long long)__builtin_readcyclecounter() - tq;   // loads issued
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (prof && e == wave) g_dbg_stamps[64 + 8 * j + 3] = (long long)__builtin_readcyclecounter() - tq;   // data arrived
-#endif
 #pragma unroll
             for (int gi = 0; gi < GROUP; gi++) if (e + gi * NW < n) compute_tile(tt[gi], q[gi], false);
-            FPS_TR(if (e == wave) g_dbg_stamps[64 + 8 * j + 4] = (long long)__builtin_readcyclecounter() - tq);   // round 1 computed
         }
         __syncthreads();
-        FPS_TR(g_dbg_stamps[64 + 8 * j + 5] = (long long)__builtin_readcyclecounter() - tq;   // barrier 2 passed
-               const long long t1 = (long long)__builtin_readcyclecounter(); acc_b += t1 - tq; tq = t1);
         if (tid == 0) wcount = 0;
         select_next();
-        FPS_TR(g_dbg_stamps[64 + 8 * j + 6] = (long long)__builtin_readcyclecounter() - tq;   // select done
-               const long long t1 = (long long)__builtin_readcyclecounter(); acc_c += t1 - tq; tq = t1);
         if (tid == 0) { out_idx[j] = old; if (out_cen) { out_cen[3 * j] = c0; out_cen[3 * j + 1] = c1; out_cen[3 * j + 2] = c2; } }
     }
-    DBG_STAMP(16);
-    FPS_TR(g_dbg_stamps[24] = acc_a; g_dbg_stamps[25] = acc_b; g_dbg_stamps[26] = acc_c; g_dbg_stamps[27] = acc_n);
-#undef FPS_TR
     if (RANGE && org_on && (flags & FPS_FLAG_FINALIZE_TEMP)) {
         // the empty pixels' temp entries were not touched while the class was carried as a scalar
         for (int p = tid; p < N; p += FPS_TT) {
@@ -503,9 +473,7 @@ __device__ __forceinline__ bool fps_tile_update(const FpsQuad &q, bool org_on, f
     return true;
 }
 
-#ifndef FPS_VGPR_ATTR
 #define FPS_VGPR_ATTR __attribute__((amdgpu_waves_per_eu(5, 8)))   // at most 96 VGPRs: with 98 the kernel is 2 % faster alone and the step 2 % slower
-#endif
 template <bool RANGE, bool VEC, int FPS_TT, bool SOA = false>
 __global__ __launch_bounds__(FPS_TT) FPS_VGPR_ATTR void fps_regtab_kernel(const float *__restrict__ src, const float *__restrict__ rays,
                                                             float *__restrict__ temp, const int32_t *__restrict__ info,
@@ -513,10 +481,8 @@ __global__ __launch_bounds__(FPS_TT) FPS_VGPR_ATTR void fps_regtab_kernel(const 
                                                             float *__restrict__ out_cen, const float *__restrict__ tiletab,
                                                             const float *__restrict__ rays_soa = nullptr) {
     constexpr int NW = FPS_TT / 64;
-    RPCC_SET_LAT_PRIO();
-#ifdef RPCC_DEVTRACE   // developer trace: wall clock (100 MHz) at the start and the end of every workgroup -> stamps[2048 + 2 b ..]
-    if (g_dbg_stamps != nullptr && threadIdx.x == 0) g_dbg_stamps[2048 + 2 * blockIdx.x] = (long long)wall_clock64();
-#endif
+    TRACE_FPS_DECLS();      // (developer trace hooks: empty unless the library is built with -DRPCC_DEVTRACE, rpcc_trace.h)
+    TRACE_FPS_WG(0);
     __shared__ uint2 slot_k[2][NW];    // candidate of a wavefront: (value key, point index)
     __shared__ float4 slot_c[2][NW];   //                          its coordinates
     __shared__ int s_viol;
@@ -599,24 +565,15 @@ __global__ __launch_bounds__(FPS_TT) FPS_VGPR_ATTR void fps_regtab_kernel(const 
     // memory latency instead of two -- were measured in round 3 (with and without loads for absent tiles): 292 / 298 us alone
     // against 273 us (139 instead of 96 VGPRs), and 7-11 % fewer frames/s with batches in flight.  (Round 2 had measured
     // software-pipelined visits: 7 % faster alone, 3 % slower with batches in flight.)
-#ifndef FPS_VISIT
-#define FPS_VISIT 2
-#endif
-#ifndef FPS_VISIT_UNCOND
-#define FPS_VISIT_UNCOND 1   // tiles of a round loaded unconditionally; the second tile's loads are issued only when there is one
-#endif
-#ifdef RPCC_DEVTRACE
-    long long vacc[4] = {0, 0, 0, 0};   // visit rounds: cycles issuing the loads / waiting for the data / updating, rounds
-#endif
+    constexpr int FPS_VISIT = 2;          // tiles per visit round
+    constexpr int FPS_VISIT_UNCOND = 1;   // tiles of a round loaded unconditionally; the second tile's loads are issued only when there is one
     auto visit = [&](unsigned long long m, bool with_box) {
         bool viol = false;
         while (m) {
             int l[FPS_VISIT];
             bool on[FPS_VISIT];
             FpsQuad q[FPS_VISIT];
-#ifdef RPCC_DEVTRACE
-            const long long v0 = (long long)__builtin_readcyclecounter();
-#endif
+            TRACE_FPS_VISIT(0);
 #pragma unroll
             for (int u = 0; u < FPS_VISIT; u++) {
                 on[u] = m != 0ull;
@@ -627,20 +584,13 @@ __global__ __launch_bounds__(FPS_TT) FPS_VGPR_ATTR void fps_regtab_kernel(const 
                     fps_quad_load<RANGE, VEC, SOA>(src, SOA ? rays_soa : rays, temp, q[u], N);
                 }
             }
-#ifdef RPCC_DEVTRACE
-            const long long v1 = (long long)__builtin_readcyclecounter();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const long long v2 = (long long)__builtin_readcyclecounter();
-#endif
+            TRACE_FPS_VISIT(1);
 #pragma unroll
             for (int u = 0; u < FPS_VISIT; u++) {
                 FpsTileOut o;
                 if (on[u] && fps_tile_update<RANGE, VEC>(q[u], org_on, t_org0, c0, c1, c2, temp, with_box, o, viol)) store_entry(l[u], o, with_box);
             }
-#ifdef RPCC_DEVTRACE
-            const long long v3 = (long long)__builtin_readcyclecounter();
-            vacc[0] += v1 - v0; vacc[1] += v2 - v1; vacc[2] += v3 - v2; vacc[3] += 1;
-#endif
+            TRACE_FPS_VISIT(2);
         }
         if (with_box && __ballot(viol) != 0ull && lane == 0) s_viol = 1;
     };
@@ -652,12 +602,6 @@ __global__ __launch_bounds__(FPS_TT) FPS_VGPR_ATTR void fps_regtab_kernel(const 
         }
     };
     int par = 0;
-#ifdef RPCC_DEVTRACE   // developer trace: cycles per phase of the iteration chain, summed over the iterations, per wavefront of block 0
-    long long p3_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, p3_last = (long long)__builtin_readcyclecounter();
-#define FPS_P3(i_) do { const long long t_ = (long long)__builtin_readcyclecounter(); p3_acc[i_] += t_ - p3_last; p3_last = t_; } while (0)
-#else
-#define FPS_P3(i_) do { } while (0)
-#endif
     // arg-max over all tiles and the origin class -> next centre (index and coordinates); one barrier
     auto select_next = [&]() {
         const uint32_t key = have ? fps_val_key(tmax) : 0u;
@@ -679,9 +623,9 @@ __global__ __launch_bounds__(FPS_TT) FPS_VGPR_ATTR void fps_regtab_kernel(const 
             const float wz = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(cz), wl));
             if (lane == 0) { slot_k[par][wave] = make_uint2(vmax, vmax >= FPS_KEY_MIN ? imin : 0xFFFFFFFFu); slot_c[par][wave] = make_float4(wx, wy, wz, 0.0f); }
         }
-        FPS_P3(3);
+        TRACE_FPS_PHASE(3);
         __syncthreads();
-        FPS_P3(4);
+        TRACE_FPS_PHASE(4);
         const uint2 kv = slot_k[par][lane % NW];
         const float4 cc = slot_c[par][lane % NW];
         par ^= 1;
@@ -709,7 +653,6 @@ __global__ __launch_bounds__(FPS_TT) FPS_VGPR_ATTR void fps_regtab_kernel(const 
         }
     };
 
-    DBG_STAMP(8);
     const bool have_tab = RANGE && tiletab != nullptr && info[RPCC_INFO * b + 3] == 1;
     if (M > 1 && have_tab) {   // the ground-mask kernel ran the first pass: this lane's entry
         if (have) {
@@ -731,12 +674,10 @@ __global__ __launch_bounds__(FPS_TT) FPS_VGPR_ATTR void fps_regtab_kernel(const 
         update_origin();
     }
     if (M > 1) {
-        DBG_STAMP(9);
         select_next();
-        DBG_STAMP(10);
         if (tid == 0) { out_idx[1] = old; if (out_cen) { out_cen[3] = c0; out_cen[4] = c1; out_cen[5] = c2; } }
     }
-    FPS_P3(0);
+    TRACE_FPS_PHASE(0);
     for (int j = 2; j < M; j++) {
         // this wavefront's tiles against the new centre
         const float g0 = fmaxf(fmaxf(lo0 - c0, c0 - hi0), 0.0f);
@@ -744,32 +685,18 @@ __global__ __launch_bounds__(FPS_TT) FPS_VGPR_ATTR void fps_regtab_kernel(const 
         const float g2 = fmaxf(fmaxf(lo2 - c2, c2 - hi2), 0.0f);
         const float bound = (g0 * g0 + g1 * g1) + g2 * g2;
         const unsigned long long vm = __ballot(have && bound < tmax);
-#ifdef RPCC_DEVTRACE
-        p3_acc[6] += __popcll(vm);
-        p3_acc[7] += vm != 0ull;
-        // tiles to visit per iteration and wavefront, blocks 0..15 -> stamps[4096 + ((block * 128 + j) * 8 + wave)]
-        if (g_dbg_stamps != nullptr && blockIdx.x < 16 && lane == 0 && j < 128 && wave < 8) g_dbg_stamps[4096 + ((blockIdx.x * 128 + j) * 8 + wave)] = __popcll(vm);
-#endif
-        FPS_P3(1);
+        TRACE_FPS_TILES(vm, j);
+        TRACE_FPS_PHASE(1);
         visit(vm, false);
-        FPS_P3(2);
+        TRACE_FPS_PHASE(2);
         update_origin();
         select_next();
         // (collecting the centres in 4 KB of LDS and writing them once at the end takes 2 us off the kernel alone and 5 % off
         // the step with batches in flight: this kernel's LDS footprint decides what it shares a CU with)
         if (tid == 0) { out_idx[j] = old; if (out_cen) { out_cen[3 * j] = c0; out_cen[3 * j + 1] = c1; out_cen[3 * j + 2] = c2; } }
-        FPS_P3(5);
+        TRACE_FPS_PHASE(5);
     }
-#ifdef RPCC_DEVTRACE
-    if (g_dbg_stamps != nullptr && blockIdx.x == 0 && lane == 0)
-        for (int i = 0; i < 8; i++) g_dbg_stamps[64 + wave * 8 + i] = p3_acc[i];
-    if (g_dbg_stamps != nullptr && blockIdx.x == 0 && lane == 0)
-        for (int i = 0; i < 4; i++) g_dbg_stamps[3000 + wave * 4 + i] = vacc[i];
-#endif
-    DBG_STAMP(16);
-#ifdef RPCC_DEVTRACE
-    if (g_dbg_stamps != nullptr && threadIdx.x == 0) g_dbg_stamps[2048 + 2 * blockIdx.x + 1] = (long long)wall_clock64();
-#endif
+    TRACE_FPS_WG(1);
     if (RANGE && org_on && (flags & FPS_FLAG_FINALIZE_TEMP)) {
         __syncthreads();
         for (int p = tid; p < N; p += FPS_TT) {
@@ -790,12 +717,7 @@ __global__ __launch_bounds__(FPS_TT) FPS_VGPR_ATTR void fps_regtab_kernel(const 
 // info[b][4] = first empty pixel that is a candidate (the representative of the FPS kernel's origin class).
 // ------------------------------------------------------------------------------------------------
 #define TAB_TPW 2
-#ifndef MASK_F32_SCREEN
-#define MASK_F32_SCREEN 1
-#endif
-#ifndef MASK_VGPR_ATTR
 #define MASK_VGPR_ATTR
-#endif
 template <bool RAW, bool VEC>
 __global__ __launch_bounds__(256) MASK_VGPR_ATTR void ground_mask_tab_kernel(float *__restrict__ ri, const float *__restrict__ tm,
                                                               const double *__restrict__ ground, double thr, FpsTiling g,
@@ -817,25 +739,21 @@ __global__ __launch_bounds__(256) MASK_VGPR_ATTR void ground_mask_tab_kernel(flo
     // (The fp32 estimate in front of the fp64 dot product -- the pattern of assign_kernel's ground term -- does not lower the
     // instruction COUNT (52.4 M against 50.5 M wave instructions per batch: 14 fp32 instructions per pixel against 11 fp64 ones),
     // but fp64 instructions take two issue passes: 95.6 -> 93.8 us alone, 0.765 -> 0.762 ms per step.)
-#if MASK_F32_SCREEN
     // fp32 estimate of the numerator with its error bound in front of the fp64 sequence (fp64 instructions take two issue passes):
     // n32 = fl(fl(fl(x af + y bf) + z cf) + df) differs from the exact x a + y b + z c + d by at most 5 * 2^-24 * (|x a| + |y b| +
     // |z c| + |d|) (narrowing of the plane, three products, three sums); twice that is used.  Pixels the estimate cannot decide
     // (and NaN / infinite values, which fail both compares) take the fp64 sequence.
     const float af = (float)a, bf = (float)bb, cf = (float)c, df = (float)d;
     const float thi32 = (float)t_hi * 1.0000002f, tlo32 = (float)t_lo * 0.9999998f;
-#endif
     auto classify = [&](float &r, float tx, float ty, float tz, float &x, float &y, float &z) -> bool {
         if (RAW && f2u(r) == RI_EMPTY) r = 0.0f;
         x = r * tx; y = r * ty; z = r * tz;
-#if MASK_F32_SCREEN
         if (screen) {
             const float n32 = fabsf(((x * af + y * bf) + z * cf) + df);
             const float e32 = 6.0e-7f * (((fabsf(x) * fabsf(af) + fabsf(y) * fabsf(bf)) + fabsf(z) * fabsf(cf)) + fabsf(df)) + 1.0e-30f;
             if (n32 - e32 > thi32) return true;
             if (n32 + e32 < tlo32) return false;
         }
-#endif
         const double s = ((double)x * a + (double)y * bb) + (double)z * c;
         const double num = fabs(s + d);
         if (screen && num > t_hi) return true;

@@ -374,12 +374,8 @@ __device__ __forceinline__ void plane_angle_test(float tx, float ty, float tz, d
     }
 }
 
-#ifndef PL_THREADS
 #define PL_THREADS 256
-#endif
-#ifndef PL_RU
 #define PL_RU 8
-#endif
 #define PL_MAXH 10
 // Workgroup form for one label (all PL_THREADS threads call it): ransac_plane_wg with thread t < 256 owning the strided
 // partial t of the ordered fp64 sums and the wavefronts sharing the points of the scoring, validation and mean passes.  Used
@@ -434,13 +430,9 @@ __device__ void plane_label_wg(const float *__restrict__ tm, const uint32_t *__r
 //   the others:          PL_THREADS/64 consecutive labels of a frame, one wavefront each (labels above `big` skipped).
 // Measured on 256 frames of 64x2048 (26 k labels: 48 % below 30 points, median 35, 90 % below 900; per frame five to nine
 // labels above 2048 points holding 25 k .. 60 k of its pixels, the largest 15 k): DESIGN.md section 6.
-#ifndef PL_BIG
 #define PL_BIG 4096
-#endif
 template <int MAXH>
-#ifndef PL_WAVES
 #define PL_WAVES 4
-#endif
 __global__ __launch_bounds__(PL_THREADS) __attribute__((amdgpu_waves_per_eu(PL_WAVES, 8))) void plane_model_kernel(const float *__restrict__ tm,
                                                                  const uint32_t *__restrict__ order_all,
                                                                  const float4 *__restrict__ pts_all,

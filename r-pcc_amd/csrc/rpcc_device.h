@@ -9,13 +9,6 @@
 
 #define RPCC_WAVE 64
 
-// Wave priority of the latency-bound one-workgroup-per-frame kernels (FPS, ground RANSAC, band projection, scan): their
-// dependency chains compete for VALU issue slots with the throughput kernels of the other batches in flight.
-#ifndef RPCC_LAT_PRIO
-#define RPCC_LAT_PRIO 0
-#endif
-#define RPCC_SET_LAT_PRIO() do { if (RPCC_LAT_PRIO) __builtin_amdgcn_s_setprio(RPCC_LAT_PRIO); } while (0)
-
 namespace rpcc {
 
 __device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }

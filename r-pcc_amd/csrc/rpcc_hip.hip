@@ -42,28 +42,21 @@ static int set_err(int code, const char *fmt, const char *a = "", const char *b 
 extern "C" int rpcc_version(void) { return 100; }
 extern "C" const char *rpcc_last_error(void) { return g_err; }
 
-// Developer phase timing.  The shipped library carries NO trace code: only a build with -DRPCC_DEVTRACE (RPCC_EXTRA_FLAGS, see
-// r-pcc_amd/build.py; tools_dev/phase_times.py, tools_dev/fps_phases.sh) compiles the stamps -- block 0 / thread 0 of the
-// instrumented kernels then stores the shader clock at phase boundaries into the registered buffer -- and the per-phase cycle
-// counters of the FPS kernels.  Without it rpcc_debug_stamps() reports that the build has no trace support.
+// Developer trace: the shipped library carries none.  Only a build with -DRPCC_DEVTRACE includes rpcc_trace.h (cycle stamps at
+// phase boundaries of the instrumented kernels); here its hooks are empty and rpcc_debug_stamps() refuses a buffer.
 #ifdef RPCC_DEVTRACE
-__device__ long long *g_dbg_stamps = nullptr;
-extern "C" int rpcc_debug_stamps(void *dev_i64_buffer) {
-    long long *p = reinterpret_cast<long long *>(dev_i64_buffer);
-    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_stamps), &p, sizeof(p)));
-    return RPCC_OK;
-}
-#define DBG_STAMP(slot_)                                                                     \
-    do {                                                                                     \
-        if (g_dbg_stamps != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) \
-            g_dbg_stamps[slot_] = (long long)__builtin_readcyclecounter();                   \
-    } while (0)
+#include "rpcc_trace.h"
 #else
 extern "C" int rpcc_debug_stamps(void *dev_i64_buffer) {
     if (dev_i64_buffer == nullptr) return RPCC_OK;
     return set_err(RPCC_ERR_ARG, "rpcc_debug_stamps: this library was built without -DRPCC_DEVTRACE%s%s");
 }
 #define DBG_STAMP(slot_) do { } while (0)
+#define TRACE_FPS_DECLS() do { } while (0)
+#define TRACE_FPS_PHASE(i_) do { } while (0)
+#define TRACE_FPS_VISIT(k_) do { } while (0)
+#define TRACE_FPS_TILES(vm_, j_) do { } while (0)
+#define TRACE_FPS_WG(end_) do { } while (0)
 #endif
 
 // Kernel attributes (dynamic LDS size) are set once per (device, kernel), not per launch.
@@ -265,18 +258,10 @@ __global__ __launch_bounds__(256) void project_finalize_kernel(uint32_t *__restr
 // BAND_PX pixels) takes the minimum of its band in LDS (ds_min_u32) while streaming the frame's records
 // from L2 / Infinity Cache.  Frames that contain a depth-0 point are left to the exact input-order
 // passes above.
-#ifndef BAND_PX
 #define BAND_PX 32768  // 128 KiB of LDS
-#endif
-#ifndef BAND_WG_PER_XCD
 #define BAND_WG_PER_XCD 32   // persistent workgroups per XCD (32 CUs): one per CU with 128 KiB bands
-#endif
-#ifndef BAND_THREADS
 #define BAND_THREADS 1024
-#endif
-#ifndef BAND_INFLIGHT
 #define BAND_INFLIGHT 4   // 16-byte record pairs per thread in flight
-#endif
 
 // ---- screened fast path of the pixel computation -----------------------------------------------------------
 // project_point() costs ~330 VALU instructions per wavefront, almost all of it the two fdlibm atan2f
@@ -405,13 +390,8 @@ __device__ __forceinline__ int flag_mark(const int32_t *epoch) { return epoch ? 
 #define PIX_CH_SHIFT 11
 #define PIX_WAVES (PIX_THREADS / 64)
 #define SUB_CAP (PIX_PPT * PIX_THREADS)   // slots per chunk and band
-#ifndef REC6
-#define REC6 1   // 1: 6-byte records (depth u32 array + pixel-in-band u16 array per share); 0: 8-byte (pixel, depth) records
-#endif
-#define SHARE_BYTES (SUB_CAP * (REC6 ? 6 : 8))
-#ifndef PIX_MAX_BANDS
+#define SHARE_BYTES (SUB_CAP * 6)   // 6-byte records: a depth u32 array + a pixel-in-band u16 array per share
 #define PIX_MAX_BANDS 8   // bands per frame the binned path handles (a power of two)
-#endif
 #define BAND_ROUND 256     // shares (chunks) a band workgroup queues at a time
 // the records are binned by image bands of BIN_PX pixels; a band workgroup handles BAND_PX <= BIN_PX of them (its LDS band) and
 // filters its bin's records when the two differ
@@ -497,12 +477,8 @@ __device__ __forceinline__ void batch_init(const BatchInit &init, int nthr, int 
 // (the device-atomic projection path has no pixel kernel to carry the initialisations)
 __global__ __launch_bounds__(256) void batch_init_kernel(BatchInit init) { batch_init(init, gridDim.x * 256, blockIdx.x * 256 + threadIdx.x); }
 
-#ifndef PIX_WG_PER_CU
 #define PIX_WG_PER_CU 16   // grid = 256 x this many persistent workgroups (6 / 8 / 32 measured: kernel alone 126 / 126 / 117 against 120 us, no change in flight)
-#endif
-#ifndef PIX_VGPR_ATTR
 #define PIX_VGPR_ATTR __attribute__((amdgpu_waves_per_eu(6, 8)))   // 80 VGPRs (81 without: one wavefront per SIMD less)
-#endif
 template <int PS>   // floats per point: 3 (packed xyz) or 4 (x, y, z, intensity rows as stored in a KITTI .bin: one 16-byte load per point)
 __global__ __launch_bounds__(PIX_THREADS) PIX_VGPR_ATTR void project_pix_kernel(const float *__restrict__ xyz, const int64_t *__restrict__ offs,
                                                                   int64_t total, int64_t base, int B, rpcc_geom g, PixFastCfg cfg,
@@ -569,12 +545,9 @@ __global__ __launch_bounds__(PIX_THREADS) PIX_VGPR_ATTR void project_pix_kernel(
             if (fast) {
                 const uint32_t xr = atomicAdd(&bcnt[band & (PIX_MAX_BANDS - 1)], 1u);
                 const uint32_t so = band * (uint32_t)SHARE_BYTES;   // (32-bit offsets from the chunk's wave-uniform base: scalar-base stores)
-#if REC6   // 6 bytes per record: the depth bits and the pixel's offset in its band
+                // 6 bytes per record: the depth bits and the pixel's offset in its band
                 st_at(reinterpret_cast<uint32_t *>(reg), so + xr * 4u, f2u(depth));
                 st_at(reinterpret_cast<uint16_t *>(reg), so + (uint32_t)(SUB_CAP * 4) + xr * 2u, (uint16_t)((uint32_t)pix & (BIN_PX - 1)));
-#else
-                st_at(reinterpret_cast<uint2 *>(reg), so + xr * 8u, make_uint2((uint32_t)pix & (BIN_PX - 1), f2u(depth)));
-#endif
             }
             const bool slow = in && !fast;
             const unsigned long long sm = __ballot(slow);
@@ -654,9 +627,7 @@ __device__ void project_fixup_frame(const float *__restrict__ xyz, const int64_t
 // band_wgs: the workgroups below that id are band workgroups; the B workgroups from there on (present when the launch has
 // points) run the exact input-order projection of the frames that hold a depth-0 point (project_fixup_frame) -- a no-op
 // for every other frame, and the band workgroups skip those frames -- so the fix-up costs no launch of its own.
-#ifndef BAND_VGPR_ATTR
 #define BAND_VGPR_ATTR __attribute__((amdgpu_waves_per_eu(6, 8)))   // 80 VGPRs instead of 81 (no spill): +0.5 % with batches in flight
-#endif
 __global__ __launch_bounds__(BAND_THREADS) BAND_VGPR_ATTR void project_band_kernel(const BandBins bb,
                                                                     const int64_t *__restrict__ offs, int64_t base,
                                                                     int B, int P, uint32_t *__restrict__ ri,
@@ -669,7 +640,6 @@ __global__ __launch_bounds__(BAND_THREADS) BAND_VGPR_ATTR void project_band_kern
     __shared__ uint16_t ldq[BAND_ROUND * 16];   // queued loads: share of the round << 2 | 64-pair step
     __shared__ uint16_t cntl[BAND_ROUND];          // records per share
     __shared__ uint32_t nslots;
-    RPCC_SET_LAT_PRIO();
     const int mark = flag_mark(epoch);
     if ((int)blockIdx.x >= band_wgs) {
         const int fb = (int)blockIdx.x - band_wgs;
@@ -738,15 +708,8 @@ __global__ __launch_bounds__(BAND_THREADS) BAND_VGPR_ATTR void project_band_kern
                 const uint32_t cnt = cntl[sl];
                 const uint32_t p = ((e & 15u) << 6) + (threadIdx.x & 63u);   // group of four records
                 const uint32_t pc = min(p, (cnt - 1u) >> 2);
-#if REC6
                 dv[u] = ld_at(reinterpret_cast<const uint4 *>(gl), sl * share_stride + pc * 16u);
                 pv[u] = ld_at(reinterpret_cast<const uint2 *>(gl), sl * share_stride + (uint32_t)(SUB_CAP * 4) + pc * 8u);
-#else
-                const uint4 r01 = ld_at(reinterpret_cast<const uint4 *>(gl), sl * share_stride + pc * 32u);
-                const uint4 r23 = ld_at(reinterpret_cast<const uint4 *>(gl), sl * share_stride + pc * 32u + 16u);
-                dv[u] = make_uint4(r01.y, r01.w, r23.y, r23.w);
-                pv[u] = make_uint2(r01.x | r01.z << 16, r23.x | r23.z << 16);
-#endif
                 left[u] = (i + u < ns && 4u * p < cnt) ? cnt - 4u * p : 0u;
             }
 #pragma unroll
@@ -938,11 +901,7 @@ static int launch_project(const float *xyz, const int64_t *offsets, int64_t tota
     BandBins bb;
     bb.nbe = band_bins_even(P);
     // the binned path: room for the lists, a counter per band and wavefront in the pixel kernel's LDS
-#ifdef PROJECT_FORCE_ATOMIC   // (experiment: the device-atomic path inside the fused batch)
-    const bool fast = false;
-#else
     const bool fast = scratch_bytes >= project_scratch_bytes(total, B, P) && bb.nbe <= PIX_MAX_BANDS && total < ((int64_t)1 << 32);
-#endif
     if (fast) {
         char *q = reinterpret_cast<char *>(scratch) + project_small_bytes(B, P);
         bb.ocursor = reinterpret_cast<uint32_t *>(q); q += project_cursor_bytes(B, P);
@@ -1018,9 +977,7 @@ extern "C" int rpcc_project(const float *xyz, const int64_t *offsets, int64_t to
 //   score       inlier count (|n.p+d| < thr), ties -> lower hypothesis id
 //   refit       the same closed form on the winner's inliers; fp64 sums in a fixed order (256 strided
 //               partials, then a binary tree)
-#ifndef RS_THREADS
 #define RS_THREADS 512   // 1024 is no faster alone and co-schedules worse with the other batches' kernels
-#endif
 #define RS_NT 256
 #define RS_MAX_LIST 5120
 #define RS_MAX_HYP 128
@@ -1313,18 +1270,12 @@ __device__ __forceinline__ uint32_t udiv32(uint32_t a, const UDiv32 u) {
     return (((a - q) >> 1) + q) >> u.shift;
 }
 
-#ifndef RS_CU
 #define RS_CU 16  // pixels per lane in flight during the compaction pass
-#endif
 // hypotheses the ground fit's scoring is compiled for: 100 iterations over 8 wavefronts = 13 slots per wavefront (with RS_MAX_HYP = 128
 // every wavefront evaluated 16, three of them always invalid)
 #define RS_GROUND_MAXH 104
-#ifndef RS_GROUND_PU
 #define RS_GROUND_PU 4   // candidates per lane in flight in the scoring loop (LDS reads; 1 / 2 / 4: 108.5 / 106.9 / 105.3 us)
-#endif
-#ifndef RS_VGPR_ATTR
 #define RS_VGPR_ATTR
-#endif
 __global__ __launch_bounds__(RS_THREADS) RS_VGPR_ATTR void ground_ransac_kernel(const float *__restrict__ ri_all,
                                                                    const float *__restrict__ tm, int P, float zthr,
                                                                    int max_pts, int min_pts, int ransac_n, int iters,
@@ -1334,7 +1285,6 @@ __global__ __launch_bounds__(RS_THREADS) RS_VGPR_ATTR void ground_ransac_kernel(
                                                                    const int32_t *__restrict__ zcnt,
                                                                    const int64_t *__restrict__ frame_ids) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rs_smem[];
-    RPCC_SET_LAT_PRIO();
     double *sred = reinterpret_cast<double *>(rs_smem);          // [6*256]
     double *swin = sred + 6 * RS_NT;                             // [64] + [RS_MAX_HYP*4] fp64 hypotheses
     int *sbest = reinterpret_cast<int *>(swin + 64 + RS_MAX_HYP * 4);  // [32]
@@ -1792,7 +1742,6 @@ static int launch_fps_tiled(const float *src, const float *rays, float *temp, co
     const size_t sh = fps_tiled_lds_bytes(g.T);
     // register-table form: every tile owned by one lane (at most 64 tiles per wavefront)
 #define FPS_RT_LAUNCH(VEC_, TT_) fps_regtab_kernel<RANGE, VEC_, TT_><<<B, TT_, 0, st>>>(src, rays, temp, info, g, M, kflags, idx, cen, tiletab)
-#ifndef FPS_NO_REGTAB
     {
         const int tt = B <= 128 ? FPS_TT_SMALL : FPS_TT_BATCH;
         if constexpr (RANGE) if (g.T <= tt && vec && rays_soa != nullptr) {   // planar copy of the ray table (the fused batch has one)
@@ -1808,7 +1757,6 @@ static int launch_fps_tiled(const float *src, const float *rays, float *temp, co
             return RPCC_OK;
         }
     }
-#endif
 #undef FPS_RT_LAUNCH
 #define FPS_LAUNCH(VEC_, TT_)                                                                                        \
     do {                                                                                                             \
@@ -1822,9 +1770,7 @@ static int launch_fps_tiled(const float *src, const float *rays, float *temp, co
     return RPCC_OK;
 }
 
-#ifndef FPS_SOA
 #define FPS_SOA 1   // the fused batch hands the planar copy of the ray table to the FPS kernel
-#endif
 #define RPCC_FPS_MODE_BITS (RPCC_FPS_FMA1 | RPCC_FPS_FMA2 | RPCC_FPS_TIE_CUDA)
 static inline int fps_fma_of(int flags) { return (flags & RPCC_FPS_FMA1) ? 1 : (flags & RPCC_FPS_FMA2) ? 2 : 0; }
 
@@ -1972,9 +1918,7 @@ __device__ __forceinline__ int assign_label(float r, float tx, float ty, float t
 #define ASSIGN_PX 4     // pixels per lane: a tile is (2 * ASSIGN_PX) rows x 32 columns, lane l pixel e -> row (l >> 4) + 4 * (e >> 1), column 2 * (l & 15) + (e & 1)
 #define ASSIGN_ROWS (2 * ASSIGN_PX)
 #define ASSIGN_TILES_PER_WAVE (4 / ASSIGN_PX)
-#ifndef ASSIGN_VGPR_ATTR
 #define ASSIGN_VGPR_ATTR
-#endif
 __global__ __launch_bounds__(256) ASSIGN_VGPR_ATTR void assign_kernel(const float *__restrict__ ri, const float *__restrict__ tm,
                                                      const double *__restrict__ ground,
                                                      const float *__restrict__ centers, int H, int W, int M,
@@ -2218,9 +2162,7 @@ __global__ __launch_bounds__(256) void model_hist_kernel(const float *__restrict
     // up to HIST_ROUNDS labels of the wavefront are aggregated (the label of the first pixel still pending: 256 consecutive
     // pixels hold four labels on average); what is left adds itself to LDS pixel by pixel.  The pending pixels are four lane
     // masks in scalar registers (one per pixel slot), as in the quantiser.
-#ifndef HIST_ROUNDS
 #define HIST_ROUNDS 3
-#endif
     unsigned long long pend[4];
 #pragma unroll
     for (int e = 0; e < 4; e++) pend[e] = __ballot(todo[e] >= 0);
@@ -2275,9 +2217,7 @@ static void launch_model_hist(const float *ri, const uint8_t *seg, int B, int P,
 // threads are consecutive words; SCAN_U tiles' loads in flight per thread) in two passes -- totals, then offsets with the label's
 // base added -- instead of staging the table in LDS (64 KB per workgroup for 64x2048: its footprint kept everything else off
 // the CU, and the 128 dependent LDS round trips of the in-LDS scan were most of the kernel's time).
-#ifndef SCAN_U
 #define SCAN_U 32
-#endif
 #define SCAN_THREADS 512
 // Thread (g, k): label k of tile group g.  The SCAN_THREADS threads form NG = SCAN_THREADS / KP2 groups (KP2 = K rounded up to a
 // power of two: 4 groups for 102 labels), a group owns T / NG consecutive tiles; with at most SCAN_U tiles per group (128 tiles, 4
@@ -2289,7 +2229,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void model_scan_kernel(const float *_
                                                          const int32_t *__restrict__ flags, uint32_t *__restrict__ hist,
                                                          float *__restrict__ model, int32_t *__restrict__ counts,
                                                          int32_t *__restrict__ nnz) {
-    RPCC_SET_LAT_PRIO();
     __shared__ uint32_t gtot[SCAN_THREADS];   // [group][KP2] counts of a label in a tile group
     __shared__ uint32_t tot[256];
     __shared__ uint32_t base[256];

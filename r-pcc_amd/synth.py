@@ -32,8 +32,18 @@ def _scene(rng):
     return n, d, bc - bs / 2, bc + bs / 2, cyl
 
 
-def make_frame(frame_id, H, W, vmax_deg=2.0, vmin_deg=-24.9, hfov_deg=360.0, device="cpu"):
-    """Return one synthetic sweep as a float32 torch tensor [N,3] on `device` (N ~ 0.8*H*W)."""
+SCENES = ("default", "shell", "noise", "corridor")
+
+
+def make_frame(frame_id, H, W, vmax_deg=2.0, vmin_deg=-24.9, hfov_deg=360.0, device="cpu", scene="default"):
+    """Return one synthetic sweep as a float32 torch tensor [N,3] on `device` (N ~ 0.8*H*W).
+    scene: "default" (above), or one of the adversarial inputs of the FPS pruning study (the tile-pruned
+    FPS is data dependent, the reference kernel is not -- ops/fps/src/sampling_gpu.cu:49-69):
+      "shell"    every ray returns from a sphere of 30 m around the sensor (all candidates equally far: flat boxes, many ties in reach);
+      "noise"    every pixel an independent range, uniform in 2 .. 80 m (every tile's box spans the whole radial extent: no pruning);
+      "corridor" two walls 1.5 m left and right of the sensor over a floor, open ends (ranges from 1.5 m to the 80 m cut-off,
+                 most pixels near the sensor)."""
+    assert scene in SCENES, scene
     rng = np.random.Generator(np.random.PCG64(20_000 + int(frame_id)))
     n, d, bmin, bmax, cyl = _scene(rng)
     P = H * W
@@ -78,6 +88,14 @@ def make_frame(frame_id, H, W, vmax_deg=2.0, vmin_deg=-24.9, hfov_deg=360.0, dev
     tc = torch.where(ok, tc, torch.full_like(tc, float("inf"))).amin(-1)
     t = torch.minimum(t, tc)
 
+    if scene == "shell":
+        t = torch.full((P,), 30.0, dtype=torch.float64, device=dev)
+    elif scene == "noise":
+        t = t64(rng.uniform(2.0, 80.0, P))
+    elif scene == "corridor":
+        tw = 1.5 / torch.abs(dirs[:, 1]).clamp(min=1e-12)                       # walls at y = -1.5 and y = +1.5
+        tfl = torch.where(dirs[:, 2] < 0, -1.73 / dirs[:, 2].clamp(max=-1e-12), inf)    # floor at z = -1.73
+        t = torch.minimum(tw, tfl)
     t = t + t64(noise)
     valid = torch.isfinite(t) & (t < MAX_RANGE) & (t > 0.5) & torch.as_tensor(keep, device=dev)
     xyz = (dirs * t[:, None]).to(torch.float32)
