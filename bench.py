@@ -630,7 +630,7 @@ def run_workload(a, ctx):
     return out
 
 
-def run_feed(a, ctx, frames_total=8192):
+def run_feed(a, ctx, frames_total=8192, ingest="xyz"):
     """Secondary: the datalist feed (loader.StreamingCompressor) without the entropy coder -- frames in host memory ->
     pinned staging -> H2D -> device path + contour codec + payload packing -> D2H of the packed payload.  Verified: the
     residual streams of the first batch against the oracle outputs of the headline run (same frames, same seeds)."""
@@ -646,8 +646,10 @@ def run_feed(a, ctx, frames_total=8192):
                       device=str(ctx["dev"]))
     from rpcc_amd import synth
     base = [f.cpu().numpy() for f in (synth.make_frame(i, H, W, device=ctx["dev"]) for i in range(B))]
+    if ingest == "rows":     # the sweeps as a .bin stores them: float32 rows (x, y, z, intensity), handed over unsliced
+        base = [np.ascontiguousarray(np.concatenate([f, np.full((f.shape[0], 1), 0.5, np.float32)], 1)) for f in base]
     bc = BatchCompressor(T, cluster_num=a.clusters, accuracy=a.accuracy, seed=0)
-    sc = StreamingCompressor(bc, batch=B, depth=4)
+    sc = StreamingCompressor(bc, batch=B, depth=4, ingest=ingest)
     nb = max(1, frames_total // B)
 
     def batches(n):
@@ -659,57 +661,67 @@ def run_feed(a, ctx, frames_total=8192):
         if k == 0 and not got:
             got["q"] = [np.array(payload.frame(b)["residual_quantized"], copy=True) for b in range(min(last["S"], len(payload), 16))]
     sc.run(batches(2), sink=None, entropy=False)      # warm-up: pinned slots touched, streams created
-    t0 = time.perf_counter()
+    for k in sc.prof:
+        sc.prof[k] = 0.0
+    t0, c0 = time.perf_counter(), time.process_time()
     n = sc.run(batches(nb), sink=sink, entropy=False)
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    dt, cpu = time.perf_counter() - t0, time.process_time() - c0
     ok = None
     if last["oracle_out"] and last["oracle_out"][0] is not None:
         ok = all(np.array_equal(q, last["oracle_out"][i]["q"]) for i, q in enumerate(got.get("q", []))) and len(got.get("q", [])) > 0
     return {"what": "datalist feed without the entropy coder: %d frames of %dx%d from host memory through loader.StreamingCompressor "
-                    "(pinned staging, H2D, device path + contour codec + payload packing, D2H), batches of %d" % (n, H, W, B),
+                    "(pinned staging, H2D, device path + contour codec + payload packing, D2H), batches of %d; ingest=%s: %s"
+                    % (n, H, W, B, ingest, "first three columns staged by a host copy (strided for .bin rows), 12 B per point over the link" if ingest == "xyz" else
+                       "the stored [N,4] rows copied whole, 16 B per point over the link, 16-byte row loads in the kernel"),
             "value": round(n / dt, 1), "unit": "frames/s", "verified": ok,
-            "bound": "host copy into pinned memory + PCIe H2D (12 B per point), not the kernels"}
+            "host_cpu_ms_per_frame": round(cpu / max(n, 1) * 1e3, 4), "host_stage_ms_per_batch": round(sc.prof["stage"] / max(nb, 1) * 1e3, 3),
+            "bound": "host copy into pinned memory + PCIe H2D, not the kernels"}
 
 
-def run_mixed(a, ctx, per=85, reps=20):
-    """Secondary: configs[4]'s content on one GPU -- 64E / 32E / VLP16 sweeps (variable H x W) in one mixed batch, non-uniform
-    framework + plane model: the three geometry groups as batches on three streams (what pipeline.MixedBatchCompressor queues),
-    device part only.  Verified: labels, salience levels and quantised integers of the first frames of every group against the
-    oracle."""
+def run_mixed(a, ctx, per=85, reps=24, slots=None):
+    """Secondary: configs[4]'s content on one GPU -- 64E / 32E / VLP16 sweeps (variable H x W) in mixed batches, non-uniform
+    framework + plane model: the three geometry groups of a mixed batch as calls on their own streams, `slots` mixed batches in
+    flight (what pipeline.MixedBatchCompressor queues), device part only.  Verified: labels, salience levels and quantised
+    integers of the first frames of every group against the oracle."""
     import numpy as np
     import torch
     from oracle import oracle as orc
     from rpcc_amd import dataset, synth
-    from rpcc_amd.pipeline import BatchCompressor
+    from rpcc_amd.pipeline import BatchCompressor, MixedBatchCompressor
     dev = ctx["dev"]
+    slots = int(os.environ.get("RPCC_MIXED_SLOTS", MixedBatchCompressor.SLOTS)) if slots is None else slots
     groups = []
     for n in ("Velodyne64E", "Velodyne32E", "VelodyneVLP16"):
         gd = orc.GEOMS[n]
         T = dataset.build_dataset(lidar_type=n, device=str(dev)).PCTransformer
         ids = list(range(3000, 3000 + per))
         xyz, offs = synth.make_batch(ids, gd["H"], gd["W"], device=dev, vmax_deg=gd["vmax_deg"], vmin_deg=gd["vmin_deg"])
-        bc = BatchCompressor(T, accuracy=a.accuracy, uniform=False, model_method="plane", seed=1)
-        groups.append((n, gd, bc, xyz, offs, torch.as_tensor(np.asarray(ids, np.int64), device=dev), torch.cuda.Stream(device=dev)))
+        sl = [(BatchCompressor(T, accuracy=a.accuracy, uniform=False, model_method="plane", seed=1), torch.cuda.Stream(device=dev)) for _ in range(slots)]
+        groups.append((n, gd, sl, xyz, offs, torch.as_tensor(np.asarray(ids, np.int64), device=dev)))
     outs = {}
-    for n, gd, bc, xyz, offs, fid, st in groups:      # warm-up (per-stream allocator pools, first-use attributes)
-        with torch.cuda.stream(st):
-            outs[n] = bc.compress_device(xyz, offs, frame_ids=fid)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        for n, gd, bc, xyz, offs, fid, st in groups:
+
+    def mixed_batch(r):          # one mixed batch: its three geometry groups on the streams of slot r % slots
+        for n, gd, sl, xyz, offs, fid in groups:
+            bc, st = sl[r % slots]
             with torch.cuda.stream(st):
                 outs[n] = bc.compress_device(xyz, offs, frame_ids=fid)
+    for r in range(2 * slots):      # warm-up (per-stream allocator pools, first-use attributes)
+        mixed_batch(r)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for r in range(reps):
+        mixed_batch(r)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     ok = True
-    for n, gd, bc, xyz, offs, fid, st in groups:
+    nver = 4
+    for n, gd, sl, xyz, offs, fid in groups:
         buf, g_fit, bits, seq, nseq, sal = outs[n]
         g = orc.LidarGeom(**gd)
         tm = orc.transform_map(g)
         o_h = offs.cpu().numpy()
-        for i in range(2):
+        for i in range(nver):
             f = xyz[o_h[i]:o_h[i + 1]].cpu().numpy()
             gm = orc.ground_model(orc.project(f, g), tm, seed=1 + 3000 + i)
             o = orc.compress_frame(f, g, tm, gm, dict(orc.DEFAULT_CFG, accuracy=a.accuracy), uniform=False,
@@ -719,9 +731,10 @@ def run_mixed(a, ctx, per=85, reps=20):
                          np.array_equal(buf.q16[i, :nz].cpu().numpy(), o["q"].astype(np.int16)) and
                          np.array_equal(sal[i, :o["salience"].shape[0]].cpu().numpy(), o["salience"].astype(np.uint8)))
     n_frames = 3 * per
-    return {"what": "configs[4] on one GPU: %d + %d + %d sweeps of 64x2000 / 32x2250 / 16x1800 in one mixed batch, non-uniform + "
-                    "plane-model, the three geometry groups overlapped on three streams; device part" % (per, per, per),
-            "value": round(n_frames / dt, 1), "unit": "frames/s", "ms_per_mixed_batch": round(dt * 1e3, 3), "verified": bool(ok)}
+    return {"what": "configs[4] on one GPU: mixed batches of %d + %d + %d sweeps of 64x2000 / 32x2250 / 16x1800, non-uniform + "
+                    "plane-model, the three geometry groups of a batch on their own streams, %d mixed batch(es) in flight; device part" % (per, per, per, slots),
+            "value": round(n_frames / dt, 1), "unit": "frames/s", "ms_per_mixed_batch": round(dt * 1e3, 3), "verified": bool(ok),
+            "verified_frames_per_group": nver}
 
 
 def run_secondary(a, ctx):
@@ -733,7 +746,7 @@ def run_secondary(a, ctx):
     def brief(rec):
         return {k: rec[k] for k in ("value", "unit", "ms_per_step", "steps", "verified")} | {"workload": rec["config"]["workload"],
                                                                                              "verified_frames_per_slot": rec["config"]["verified_frames_per_slot"]}
-    for name, fn in (("feed", run_feed), ("mixed_lidars", run_mixed)):
+    for name, fn in (("feed", run_feed), ("feed_rows", lambda a_, c_: run_feed(a_, c_, ingest="rows")), ("mixed_lidars", run_mixed)):
         try:
             sec[name] = fn(a, ctx)
         except Exception as e:  # noqa: BLE001

@@ -106,6 +106,8 @@ class MixedBatchCompressor:
     workgroup per frame in FPS / RANSAC), so the groups overlap -- and the results come back in input order.
     transformers: {lidar name: PCTransformer}; the other arguments are BatchCompressor's."""
 
+    SLOTS = 1      # mixed batches in flight of the streaming form (submit / collect); bench.py's secondary measures it
+
     def __init__(self, transformers, **kw):
         self.bcs = {name: BatchCompressor(t, **kw) for name, t in transformers.items()}
         dev = next(iter(self.bcs.values())).device

@@ -108,6 +108,29 @@ def test_fps_tiled_equals_bruteforce_at_batch_256(env):
             assert np.array_equal(a, b), (mode, what, np.flatnonzero((a != b).reshape(B, -1).any(1))[:8])
 
 
+@pytest.mark.parametrize("scene", ["shell", "noise", "corridor"])
+def test_fps_tiled_equals_bruteforce_on_adversarial_scenes(env, scene):
+    """The reference kernel costs the same on any input (ops/fps/src/sampling_gpu.cu:49-69); the tile-pruned one is data dependent.
+    Its worst cases (a sphere shell, independent ranges per pixel -- boxes that prune nothing --, a corridor) stay
+    exact: indices, centres and the final temp array of 32 frames equal the brute-force kernel's, with and without the tile table."""
+    torch, ops, synth = env["torch"], env["ops"], env["synth"]
+    B = 32
+    xyz, offs = synth.make_batch(range(9500, 9500 + B), env["g"].H, env["g"].W, device=env["dev"], scene=scene)
+    ri = ops.project(xyz, offs, env["geom"])
+    gms, _ = ops.ground_ransac(ri, env["d_tm"], seed=1)
+    res = {}
+    for mode in ("brute", "tiled", "tiled+table"):
+        if mode == "tiled+table":
+            temp, info, tab = ops.ground_mask(ri, env["d_tm"], gms, 0.1, fps_table=True)
+        else:
+            (temp, info), tab = ops.ground_mask(ri, env["d_tm"], gms, 0.1), None
+        pix, cen = ops.fps_range(ri, env["d_tm"], temp, info, 100, fps_table=tab, bruteforce=(mode == "brute"))
+        res[mode] = (pix.cpu().numpy(), cen.cpu().numpy().view(np.uint32), temp.cpu().numpy().view(np.uint32))
+    for mode in ("tiled", "tiled+table"):
+        for a, b, what in zip(res["brute"], res[mode], ("indices", "centres", "temp")):
+            assert np.array_equal(a, b), (scene, mode, what)
+
+
 def test_concurrent_host_threads(env):
     """Four host threads, each with its own stream and buffers, call rpcc_compress_batch at the same time (the reference's
     ThreadPoolExecutor front-end): results equal the same calls made one after the other."""
