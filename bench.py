@@ -286,7 +286,7 @@ def pmc_numbers(a, B, geom_s, M):
         pm = json.load(open(os.path.join(ROOT, "profiles", name)))
         if pm["config"] != {"batch": B, "geom": geom_s, "clusters": M, "config": a.config, "input": bool(a.input)} or a.fps_bruteforce or a.scene != "default":
             return None
-        key = [k for k in pm["kernels"] if k.startswith(("fps_regtab_kernel<true", "fps_tiled_kernel<true"))][0]   # template arguments vary
+        key = [k for k in pm["kernels"] if k.startswith(("fps_regtab_planar_kernel", "fps_regtab_kernel<true", "fps_tiled_kernel<true"))][0]   # template arguments vary
         return dict(kernel=key, traffic=pm["kernels"][key]["traffic_bytes_per_launch"],
                     valu=pm["kernels"][key].get("valu_wave_insts_per_launch"), valu_cyc=pm["kernels"][key].get("valu_mean_cycles_static"),
                     step_traffic=pm.get("step_traffic_bytes"), step_valu=pm.get("step_valu_wave_insts"), step_cycles=pm.get("step_valu_simd_cycles"),

@@ -7,8 +7,10 @@
 //   point list:   tile t covers indices 256*t ..; lane l, element e -> 256*t + 4*l + e
 // In both layouts (lane, element) in lexicographic order is increasing point index, which is what the
 // lowest-index tie rule of the arg-max needs.  With W % 4 == 0 (N % 4 == 0 for lists) a lane's four points are one
-// 16-byte load of the range image, one of temp and three of the [P,3] ray table (VEC); otherwise the same layout is
-// read with scalar loads.
+// 16-byte load of the range image, one of temp and three of the [P,3] ray table (VEC).  A range image whose width is no multiple
+// of four (Velodyne 32E: 2250 columns) keeps the 16-byte loads at 4-byte alignment (EDGE: global_load_dwordx4 needs dword
+// alignment only); its row ends cut a lane's quad short, and those lanes read and write their valid elements one by one.
+// Point lists that fit neither are read with scalar loads.
 //
 // Per tile the workgroup keeps in LDS (FpsLds, three float4): the bounding box of the tile's candidates, the
 // tile's current maximum of temp with its (lowest) index, and that point's coordinates.  For a new centre
@@ -85,10 +87,22 @@ __device__ __forceinline__ void fps_quad_xyz(const FpsQuad &q, bool range, float
 // loads of one lane's quad: src = range image (RANGE) or xyz list; rays = [P,3] table (RANGE)
 // SOA (RANGE, VEC): rays = the planar copy [3][n_plane] of the table -- the three 16-byte loads share the offset of the range /
 // temp loads (no multiplication by 12) and return the four pixels' x, y, z as register pairs (no re-packing for packed fp32)
-template <bool RANGE, bool VEC, bool SOA = false>
+template <bool RANGE, bool VEC, bool SOA = false, bool EDGE = false>
 __device__ __forceinline__ void fps_quad_load(const float *__restrict__ src, const float *__restrict__ rays,
                                               const float *__restrict__ temp, FpsQuad &q, int n_plane = 0) {
     const uint32_t p0 = (uint32_t)q.p0;
+    using float4 = typename std::conditional<EDGE, f32x4u, ::float4>::type;   // EDGE: the same 16-byte loads, 4-byte aligned
+    if (VEC && EDGE && q.nval != 4) {   // a quad cut short by the row end (or a lane outside the frame): element loads, clamped
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const uint32_t p = p0 + (uint32_t)(e < q.nval ? e : 0);
+            q.tp[e] = ld_f32(temp, p * 4u);
+            if (SOA) { q.t[3 * e] = ld_f32(rays, p * 4u); q.t[3 * e + 1] = ld_f32(rays + n_plane, p * 4u); q.t[3 * e + 2] = ld_f32(rays + 2 * (size_t)n_plane, p * 4u); }
+            else { const float *tb = RANGE ? rays : src; q.t[3 * e] = ld_f32(tb, p * 12u); q.t[3 * e + 1] = ld_f32(tb, p * 12u + 4u); q.t[3 * e + 2] = ld_f32(tb, p * 12u + 8u); }
+            if (RANGE) q.r[e] = ld_f32(src, p * 4u);
+        }
+        return;
+    }
     if (VEC && RANGE && SOA) {
         const float4 tp = ld_at(reinterpret_cast<const float4 *>(temp), p0 * 4u);
         q.tp[0] = tp.x; q.tp[1] = tp.y; q.tp[2] = tp.z; q.tp[3] = tp.w;
@@ -438,19 +452,20 @@ struct FpsTileOut { float lo[3], hi[3], wt, wx, wy, wz; uint32_t widx; };
 
 // update of one tile against centre (c0,c1,c2): returns true (wave-uniform) when its table entry changed (always with
 // with_box); the new entry comes back in `o`.  viol: an empty pixel is not what the origin class assumes (first pass only).
-template <bool RANGE, bool VEC>
+template <bool RANGE, bool VEC, bool EDGE = false>
 __device__ __forceinline__ bool fps_tile_update(const FpsQuad &q, bool org_on, float t_org0, float c0, float c1, float c2,
                                                 float *__restrict__ temp, bool with_box, FpsTileOut &o, bool &viol) {
     float x[4], y[4], z[4], nt[4];
     uint32_t key[4];
     bool cand[4], ch = false;
     fps_quad_xyz(q, RANGE, x, y, z);
-    const bool lane_ok = q.nval > 0;   // VEC: a lane's four elements are inside the frame together
+    const bool lane_ok = q.nval > 0;   // VEC without EDGE: a lane's four elements are inside the frame together
+    constexpr bool QUAD = VEC && !EDGE;
 #pragma unroll
     for (int e = 0; e < 4; e++) {
-        float tp = (VEC ? lane_ok : e < q.nval) ? q.tp[e] : -1.0f;
+        float tp = (QUAD ? lane_ok : e < q.nval) ? q.tp[e] : -1.0f;
         if (RANGE && org_on && q.r[e] == 0.0f) {   // member of the origin class: carried by t_org
-            if (with_box) viol |= (VEC ? lane_ok : e < q.nval) && tp != t_org0;
+            if (with_box) viol |= (QUAD ? lane_ok : e < q.nval) && tp != t_org0;
             tp = -1.0f;
         }
         cand[e] = tp >= 0.0f;
@@ -460,10 +475,11 @@ __device__ __forceinline__ bool fps_tile_update(const FpsQuad &q, bool org_on, f
         key[e] = fps_val_key(nt[e]);
         const bool c = nt[e] != tp;
         ch |= c;
-        if (!VEC && c) st_f32(temp, (uint32_t)(q.p0 + e) * 4u, nt[e]);
+        if ((!VEC || (EDGE && q.nval != 4)) && c) st_f32(temp, (uint32_t)(q.p0 + e) * 4u, nt[e]);   // (c implies a valid element)
         if (!c) nt[e] = q.tp[e];   // value to write back for an unchanged element
     }
-    if (VEC && ch) st_at(reinterpret_cast<float4 *>(temp), (uint32_t)q.p0 * 4u, make_float4(nt[0], nt[1], nt[2], nt[3]));
+    if (QUAD && ch) st_at(reinterpret_cast<float4 *>(temp), (uint32_t)q.p0 * 4u, make_float4(nt[0], nt[1], nt[2], nt[3]));
+    if (VEC && EDGE && ch && q.nval == 4) st_at(reinterpret_cast<f32x4u *>(temp), (uint32_t)q.p0 * 4u, f32x4u{nt[0], nt[1], nt[2], nt[3]});
     if (!with_box && __ballot(ch) == 0ull) return false;
     // (Leaving the arg-max out when the point that holds the tile's maximum did not change -- the entry is then provably what it
     // was -- was measured in round 3: the holder has the largest temp of the tile, so it is the FIRST point a centre in reach
@@ -473,13 +489,12 @@ __device__ __forceinline__ bool fps_tile_update(const FpsQuad &q, bool org_on, f
     return true;
 }
 
-#define FPS_VGPR_ATTR __attribute__((amdgpu_waves_per_eu(5, 8)))   // at most 96 VGPRs: with 98 the kernel is 2 % faster alone and the step 2 % slower
-template <bool RANGE, bool VEC, int FPS_TT, bool SOA = false>
-__global__ __launch_bounds__(FPS_TT) FPS_VGPR_ATTR void fps_regtab_kernel(const float *__restrict__ src, const float *__restrict__ rays,
-                                                            float *__restrict__ temp, const int32_t *__restrict__ info,
-                                                            FpsTiling g, int M, int flags, int32_t *__restrict__ out_idx,
-                                                            float *__restrict__ out_cen, const float *__restrict__ tiletab,
-                                                            const float *__restrict__ rays_soa = nullptr) {
+template <bool RANGE, bool VEC, int FPS_TT, bool SOA, bool EDGE = false>
+__device__ __forceinline__ void fps_regtab_body(const float *__restrict__ src, const float *__restrict__ rays,
+                                                float *__restrict__ temp, const int32_t *__restrict__ info,
+                                                FpsTiling g, int M, int flags, int32_t *__restrict__ out_idx,
+                                                float *__restrict__ out_cen, const float *__restrict__ tiletab,
+                                                const float *__restrict__ rays_soa) {
     constexpr int NW = FPS_TT / 64;
     TRACE_FPS_DECLS();      // (developer trace hooks: empty unless the library is built with -DRPCC_DEVTRACE, rpcc_trace.h)
     TRACE_FPS_WG(0);
@@ -581,14 +596,14 @@ __global__ __launch_bounds__(FPS_TT) FPS_VGPR_ATTR void fps_regtab_kernel(const 
                 m &= m - 1ull;     // (0 & anything stays 0)
                 if (u < FPS_VISIT_UNCOND || on[u]) {   // (wave-uniform) the first pair unconditionally, the rest only when there is a tile
                     locate(l[u], q[u]);
-                    fps_quad_load<RANGE, VEC, SOA>(src, SOA ? rays_soa : rays, temp, q[u], N);
+                    fps_quad_load<RANGE, VEC, SOA, EDGE>(src, SOA ? rays_soa : rays, temp, q[u], N);
                 }
             }
             TRACE_FPS_VISIT(1);
 #pragma unroll
             for (int u = 0; u < FPS_VISIT; u++) {
                 FpsTileOut o;
-                if (on[u] && fps_tile_update<RANGE, VEC>(q[u], org_on, t_org0, c0, c1, c2, temp, with_box, o, viol)) store_entry(l[u], o, with_box);
+                if (on[u] && fps_tile_update<RANGE, VEC, EDGE>(q[u], org_on, t_org0, c0, c1, c2, temp, with_box, o, viol)) store_entry(l[u], o, with_box);
             }
             TRACE_FPS_VISIT(2);
         }
@@ -706,6 +721,23 @@ __global__ __launch_bounds__(FPS_TT) FPS_VGPR_ATTR void fps_regtab_kernel(const 
     }
 }
 
+// The fused batch's variant (planar ray table) is the one that shares the CUs with the other batches in flight: at most 96 VGPRs
+// (with 98 the kernel is 2 % faster alone and the step 2 % slower: one wavefront per SIMD less beside it).  The stage entry's
+// variants (rays as the [P,3] table, point lists) need a few registers more for the re-packing and would spill under that cap;
+// they run alone and take the next occupancy step instead (<= 128 VGPRs, no scratch).
+template <bool RANGE, bool VEC, int FPS_TT, bool EDGE = false>
+__global__ __launch_bounds__(FPS_TT) __attribute__((amdgpu_waves_per_eu(4, 8))) void fps_regtab_kernel(
+    const float *__restrict__ src, const float *__restrict__ rays, float *__restrict__ temp, const int32_t *__restrict__ info, FpsTiling g, int M,
+    int flags, int32_t *__restrict__ out_idx, float *__restrict__ out_cen, const float *__restrict__ tiletab) {
+    fps_regtab_body<RANGE, VEC, FPS_TT, false, EDGE>(src, rays, temp, info, g, M, flags, out_idx, out_cen, tiletab, nullptr);
+}
+template <int FPS_TT, bool EDGE = false>
+__global__ __launch_bounds__(FPS_TT) __attribute__((amdgpu_waves_per_eu(5, 8))) void fps_regtab_planar_kernel(
+    const float *__restrict__ src, const float *__restrict__ rays, float *__restrict__ temp, const int32_t *__restrict__ info, FpsTiling g, int M,
+    int flags, int32_t *__restrict__ out_idx, float *__restrict__ out_cen, const float *__restrict__ tiletab, const float *__restrict__ rays_soa) {
+    fps_regtab_body<true, true, FPS_TT, true, EDGE>(src, rays, temp, info, g, M, flags, out_idx, out_cen, tiletab, rays_soa);
+}
+
 // ------------------------------------------------------------------------------------------------
 // a3 + a5 with the FIRST pass of the farthest point sampling (at full-chip parallelism).
 // FPS starts at the first candidate in row-major order.  Every wavefront re-derives it from the first
@@ -718,7 +750,7 @@ __global__ __launch_bounds__(FPS_TT) FPS_VGPR_ATTR void fps_regtab_kernel(const 
 // ------------------------------------------------------------------------------------------------
 #define TAB_TPW 2
 #define MASK_VGPR_ATTR
-template <bool RAW, bool VEC>
+template <bool RAW, bool VEC, bool EDGE = false>   // EDGE (with VEC): the image width is no multiple of four -- 16-byte accesses at 4-byte alignment, row-end quads by element
 __global__ __launch_bounds__(256) MASK_VGPR_ATTR void ground_mask_tab_kernel(float *__restrict__ ri, const float *__restrict__ tm,
                                                               const double *__restrict__ ground, double thr, FpsTiling g,
                                                               float *__restrict__ temp, int32_t *__restrict__ info,
@@ -789,12 +821,13 @@ __global__ __launch_bounds__(256) MASK_VGPR_ATTR void ground_mask_tab_kernel(flo
         q[k].nval = row < g.H ? min(max(g.W - col, 0), 4) : 0;
         q[k].p0 = q[k].nval > 0 ? row * g.W + col : 0;
         const uint32_t p0 = (uint32_t)q[k].p0;
-        if (VEC) {
-            const float4 r = ld_at(reinterpret_cast<const float4 *>(ri_b), p0 * 4u);
+        using V4 = typename std::conditional<EDGE, f32x4u, float4>::type;
+        if (VEC && (!EDGE || q[k].nval == 4)) {
+            const V4 r = ld_at(reinterpret_cast<const V4 *>(ri_b), p0 * 4u);
             q[k].r[0] = r.x; q[k].r[1] = r.y; q[k].r[2] = r.z; q[k].r[3] = r.w;
-            const float4 ra = ld_at(reinterpret_cast<const float4 *>(tm), p0 * 12u);
-            const float4 rb = ld_at(reinterpret_cast<const float4 *>(tm), p0 * 12u + 16u);
-            const float4 rc = ld_at(reinterpret_cast<const float4 *>(tm), p0 * 12u + 32u);
+            const V4 ra = ld_at(reinterpret_cast<const V4 *>(tm), p0 * 12u);
+            const V4 rb = ld_at(reinterpret_cast<const V4 *>(tm), p0 * 12u + 16u);
+            const V4 rc = ld_at(reinterpret_cast<const V4 *>(tm), p0 * 12u + 32u);
             q[k].t[0] = ra.x; q[k].t[1] = ra.y; q[k].t[2] = ra.z; q[k].t[3] = ra.w; q[k].t[4] = rb.x; q[k].t[5] = rb.y;
             q[k].t[6] = rb.z; q[k].t[7] = rb.w; q[k].t[8] = rc.x; q[k].t[9] = rc.y; q[k].t[10] = rc.z; q[k].t[11] = rc.w;
         } else {
@@ -828,7 +861,7 @@ __global__ __launch_bounds__(256) MASK_VGPR_ATTR void ground_mask_tab_kernel(flo
             }
             boxc[e] = cand && nz;                 // empty pixels belong to the origin class, not to the tile
             key[e] = boxc[e] ? fps_val_key(nt[e]) : 0u;
-            if (!VEC && valid) {
+            if ((!VEC || (EDGE && q[k].nval != 4)) && valid) {
                 if (RAW) st_f32(ri_b, (uint32_t)(q[k].p0 + e) * 4u, r);
                 st_f32(temp_b, (uint32_t)(q[k].p0 + e) * 4u, nt[e]);
             }
@@ -840,9 +873,13 @@ __global__ __launch_bounds__(256) MASK_VGPR_ATTR void ground_mask_tab_kernel(flo
             if (mc) first = min(first, __builtin_amdgcn_readlane(q[k].p0, (int)__ffsll((long long)mc) - 1) + e);
             if (mo) forg = min(forg, __builtin_amdgcn_readlane(q[k].p0, (int)__ffsll((long long)mo) - 1) + e);
         }
-        if (VEC && q[k].nval > 0) {
+        if (VEC && !EDGE && q[k].nval > 0) {
             if (RAW) st_at(reinterpret_cast<float4 *>(ri_b), (uint32_t)q[k].p0 * 4u, make_float4(rr[0], rr[1], rr[2], rr[3]));
             st_at(reinterpret_cast<float4 *>(temp_b), (uint32_t)q[k].p0 * 4u, make_float4(nt[0], nt[1], nt[2], nt[3]));
+        }
+        if (VEC && EDGE && q[k].nval == 4) {
+            if (RAW) st_at(reinterpret_cast<f32x4u *>(ri_b), (uint32_t)q[k].p0 * 4u, f32x4u{rr[0], rr[1], rr[2], rr[3]});
+            st_at(reinterpret_cast<f32x4u *>(temp_b), (uint32_t)q[k].p0 * 4u, f32x4u{nt[0], nt[1], nt[2], nt[3]});
         }
         if (fast) {
             float lo[3], hi[3], wt, wx, wy, wz;

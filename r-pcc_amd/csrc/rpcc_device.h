@@ -121,6 +121,7 @@ __device__ __forceinline__ void st_f32(float *base, uint32_t byte_off, float v) 
     *reinterpret_cast<float *>(reinterpret_cast<char *>(base) + byte_off) = v;
 }
 struct f32x3 { float x, y, z; };  // one ray of the transform map: a single 12-byte load
+struct f32x4u { float x, y, z, w; };  // four floats at a 4-byte aligned address: one global_load_dwordx4 (dword alignment is all the hardware asks)
 template <class T>
 __device__ __forceinline__ T ld_at(const T *base, uint32_t byte_off) {
     return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_off);

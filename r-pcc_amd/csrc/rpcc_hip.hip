@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <mutex>
 #include <new>
+#include <type_traits>
 #include <utility>
 #include <vector>
 #include "../../include/rpcc_hip.h"
@@ -1477,9 +1478,10 @@ static int launch_ground_mask(float *ri, const float *tm, const double *ground, 
         const FpsTiling g = fps_tiling_range(H, W);
         const dim3 grid((g.T + 4 * TAB_TPW - 1) / (4 * TAB_TPW), B);
         const bool vec = (W % 4 == 0) && aligned16(ri) && aligned16(temp) && aligned16(tm);
-#define GM_LAUNCH(RAW_, VEC_) ground_mask_tab_kernel<RAW_, VEC_><<<grid, 256, 0, st>>>(ri, tm, ground, thr, g, temp, info, tiletab)
-        if (raw) { if (vec) GM_LAUNCH(true, true); else GM_LAUNCH(true, false); }
-        else     { if (vec) GM_LAUNCH(false, true); else GM_LAUNCH(false, false); }
+#define GM_LAUNCH(RAW_, EDGE_) ground_mask_tab_kernel<RAW_, true, EDGE_><<<grid, 256, 0, st>>>(ri, tm, ground, thr, g, temp, info, tiletab)
+        // (a width that is no multiple of four, or buffers that are not 16-byte aligned: the same quad layout at 4-byte alignment)
+        if (raw) { if (vec) GM_LAUNCH(true, false); else GM_LAUNCH(true, true); }
+        else     { if (vec) GM_LAUNCH(false, false); else GM_LAUNCH(false, true); }
 #undef GM_LAUNCH
     } else {
         const dim3 grid((P + GM_PIX - 1) / GM_PIX, B);
@@ -1738,15 +1740,27 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_modes_kernel(const float *__r
 template <bool RANGE>
 static int launch_fps_tiled(const float *src, const float *rays, float *temp, const int32_t *info, int B, const FpsTiling &g,
                             int M, int kflags, int32_t *idx, float *cen, const float *tiletab, bool vec, hipStream_t st,
-                            const float *rays_soa = nullptr) {
+                            const float *rays_soa = nullptr, bool edge = false) {
+    // edge (range images only): the width is no multiple of four -- the quad kernels run with 4-byte aligned 16-byte accesses
     const size_t sh = fps_tiled_lds_bytes(g.T);
     // register-table form: every tile owned by one lane (at most 64 tiles per wavefront)
 #define FPS_RT_LAUNCH(VEC_, TT_) fps_regtab_kernel<RANGE, VEC_, TT_><<<B, TT_, 0, st>>>(src, rays, temp, info, g, M, kflags, idx, cen, tiletab)
     {
         const int tt = B <= 128 ? FPS_TT_SMALL : FPS_TT_BATCH;
-        if constexpr (RANGE) if (g.T <= tt && vec && rays_soa != nullptr) {   // planar copy of the ray table (the fused batch has one)
-            if (B <= 128) fps_regtab_kernel<RANGE, true, FPS_TT_SMALL, true><<<B, FPS_TT_SMALL, 0, st>>>(src, rays, temp, info, g, M, kflags, idx, cen, tiletab, rays_soa);
-            else          fps_regtab_kernel<RANGE, true, FPS_TT_BATCH, true><<<B, FPS_TT_BATCH, 0, st>>>(src, rays, temp, info, g, M, kflags, idx, cen, tiletab, rays_soa);
+        if constexpr (RANGE) if (g.T <= tt && (vec || edge) && rays_soa != nullptr) {   // planar copy of the ray table (the fused batch has one)
+            if (edge) {
+                if (B <= 128) fps_regtab_planar_kernel<FPS_TT_SMALL, true><<<B, FPS_TT_SMALL, 0, st>>>(src, rays, temp, info, g, M, kflags, idx, cen, tiletab, rays_soa);
+                else          fps_regtab_planar_kernel<FPS_TT_BATCH, true><<<B, FPS_TT_BATCH, 0, st>>>(src, rays, temp, info, g, M, kflags, idx, cen, tiletab, rays_soa);
+            } else {
+                if (B <= 128) fps_regtab_planar_kernel<FPS_TT_SMALL><<<B, FPS_TT_SMALL, 0, st>>>(src, rays, temp, info, g, M, kflags, idx, cen, tiletab, rays_soa);
+                else          fps_regtab_planar_kernel<FPS_TT_BATCH><<<B, FPS_TT_BATCH, 0, st>>>(src, rays, temp, info, g, M, kflags, idx, cen, tiletab, rays_soa);
+            }
+            LAUNCH_CHECK();
+            return RPCC_OK;
+        }
+        if constexpr (RANGE) if (g.T <= tt && edge) {
+            if (B <= 128) fps_regtab_kernel<true, true, FPS_TT_SMALL, true><<<B, FPS_TT_SMALL, 0, st>>>(src, rays, temp, info, g, M, kflags, idx, cen, tiletab);
+            else          fps_regtab_kernel<true, true, FPS_TT_BATCH, true><<<B, FPS_TT_BATCH, 0, st>>>(src, rays, temp, info, g, M, kflags, idx, cen, tiletab);
             LAUNCH_CHECK();
             return RPCC_OK;
         }
@@ -1823,7 +1837,7 @@ static int launch_fps_range(const float *ri, const float *tm, float *temp, const
         const bool vec = (W % 4 == 0) && aligned16(ri) && aligned16(temp) && aligned16(tm);
         FpsTimer tmr(st, timer);
         return launch_fps_tiled<true>(ri, tm, temp, info, B, g, M, finalize_temp ? FPS_FLAG_FINALIZE_TEMP : 0, cen_pix, centers,
-                                      tiletab, vec, st, rays_soa);
+                                      tiletab, vec, st, rays_soa, !vec);
     }
     if (tiletab != nullptr && !brute)
         return set_err(RPCC_ERR_ARG, "fps_range: an FPS table was produced but the tiled kernel cannot run (image too large)%s%s");

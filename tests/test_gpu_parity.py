@@ -969,7 +969,8 @@ def test_projection_fast_path_never_disagrees(env, gname):
     assert tot_sure > 0
 
 
-@pytest.mark.parametrize("H,W,M", [(5, 300, 7), (8, 512, 20), (33, 1000, 100), (16, 4000, 50), (128, 2048, 30), (128, 4096, 30)])
+@pytest.mark.parametrize("H,W,M", [(5, 300, 7), (8, 512, 20), (33, 1000, 100), (16, 4000, 50), (128, 2048, 30), (128, 4096, 30),
+                                   (7, 301, 9), (12, 1030, 40), (20, 2051, 60)])   # widths that are no multiple of four: quads at 4-byte alignment, row-end quads by element
 def test_odd_geometries_fused(env, H, W, M):
     """Fused entry (ground fit inside) on image shapes that are no multiple of any tile size the kernels use
     (4x32 FPS / assign tiles, 1024-pixel scatter tiles, 32768-pixel projection bands, RANSAC chunks), with

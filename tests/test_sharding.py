@@ -310,7 +310,7 @@ def test_bench_finds_its_pmc_numbers():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     pm = json.load(open(os.path.join(root, "profiles", "pmc_current.json")))
     assert pm["config"] == {"batch": 256, "geom": "64x2048", "clusters": 100, "config": 1, "input": False}
-    keys = [k for k in pm["kernels"] if k.startswith(("fps_regtab_kernel<true", "fps_tiled_kernel<true"))]
+    keys = [k for k in pm["kernels"] if k.startswith(("fps_regtab_planar_kernel", "fps_regtab_kernel<true", "fps_tiled_kernel<true"))]
     assert len(keys) == 1, list(pm["kernels"])
     assert pm["kernels"][keys[0]]["traffic_bytes_per_launch"] > 0 and pm["kernels"][keys[0]]["valu_wave_insts_per_launch"] > 0
     assert pm["step_traffic_bytes"] > 0 and pm["step_valu_wave_insts"] > 0     # roofline.frac (VALU issue) / step_traffic_frac
@@ -318,4 +318,4 @@ def test_bench_finds_its_pmc_numbers():
     assert 2.0 * pm["step_valu_wave_insts"] <= pm["step_valu_simd_cycles"] <= 4.5 * pm["step_valu_wave_insts"]
     assert all(2.0 <= k["valu_mean_cycles_static"] <= 8.0 for k in pm["kernels"].values())
     src = open(os.path.join(root, "bench.py")).read()
-    assert 'startswith(("fps_regtab_kernel<true", "fps_tiled_kernel<true"))' in src
+    assert 'startswith(("fps_regtab_planar_kernel", "fps_regtab_kernel<true", "fps_tiled_kernel<true"))' in src
