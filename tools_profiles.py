@@ -34,6 +34,12 @@ for n in ("prof_default_bench", "prof_serial_bench", "prof_bench_final"):
     open(f"{P}/{tag}_{n[5:]}.json", 'w').write(line + "\n")
     bench[n] = json.loads(line)
 
+# static VALU cycle mix per kernel (tools_dev/isa_count.py --json): mean SIMD cycles per wave64 instruction by the measured classes
+mix = json.load(open(f"{P}/isa_mix_current.json")) if os.path.exists(f"{P}/isa_mix_current.json") else {}
+def mean_cycles(kernel):
+    m = mix.get(kernel) or next((v for k, v in mix.items() if k.split('<')[0] == kernel.split('<')[0]), None)
+    return m["valu_mean_cycles"] if m else 4.0
+
 out = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
     agg = collections.defaultdict(list)
@@ -52,30 +58,34 @@ L = [f"# {tag} PMC passes: HBM-side traffic and VALU instructions per kernel lau
      "stream.  Calibration on kernels with known byte counts: `project_pix_kernel` reads 12 B x 29.0 M points = 348 MB,",
      "`assign_kernel` reads the 134 MB range image; both report about half, so read = 2 x FETCH_SIZE also for 4 B/lane loads.",
      "WRITE_SIZE needs no correction (`project_pix_kernel` writes 232 MB of records, `assign_kernel` 33.5 MB of labels).",
-     "SQ_INSTS_VALU counts wave-level VALU instructions; a non-packed wave64 instruction occupies a SIMD for 4 cycles (the 157 TFLOP/s fp32 peak = 1024 SIMDs x 16 lanes x fma x packed x 2.4 GHz), so the chip issues at most 1024 x 2.4e9 / 4 = 6.1e11 per second.", "",
-     "| kernel | launches | FETCH_SIZE raw MB | read MB (x2) | WRITE_SIZE MB | HBM-side traffic MB/launch | VALU M wave-instr./launch | avg us (profiled) | traffic TB/s | VALU issue % |", "|---|---|---|---|---|---|---|---|---|---|"]
+     "SQ_INSTS_VALU counts wave-level VALU instructions.  A wave64 instruction occupies its SIMD for 2, 4 or 8 cycles depending on its class (measured: profiles/r04_valu_peak.md);",
+     "mean cycles = the kernel's static instruction mix weighted with those classes (profiles/isa_mix_current.json); VALU busy = instructions x mean cycles / (1024 SIMDs x 2.4 GHz x duration).", "",
+     "| kernel | launches | FETCH_SIZE raw MB | read MB (x2) | WRITE_SIZE MB | HBM-side traffic MB/launch | VALU M wave-instr./launch | mean cycles / instr. | avg us (profiled) | traffic TB/s | VALU busy % |", "|---|---|---|---|---|---|---|---|---|---|---|"]
 js = {}
 for n in names:
     fv = out['FETCH_SIZE'][n]; wv = out['WRITE_SIZE'].get(n, [(0, 0)]); vv = out['SQ_INSTS_VALU'].get(n, [(0, 0)])
     fr = sum(v for v, _ in fv) / len(fv) / 1024; wr = sum(v for v, _ in wv) / len(wv) / 1024; us = sum(t for _, t in fv) / len(fv)
     va = sum(v for v, _ in vv) / len(vv)
     tb = (2 * fr + wr) * 1048576 / (us * 1e-6) / 1e12 if us else 0
-    vp = va / (us * 1e-6) / (1024 * 2.4e9 / 4) * 100 if us else 0
-    L.append("| `%s` | %d | %.1f | %.1f | %.1f | %.1f | %.1f | %.1f | %.2f | %.0f |" % (n[:48], len(fv), fr, 2 * fr, wr, 2 * fr + wr, va / 1e6, us, tb, vp))
+    mc = mean_cycles(n)
+    vp = va * mc / (us * 1e-6) / (1024 * 2.4e9) * 100 if us else 0
+    L.append("| `%s` | %d | %.1f | %.1f | %.1f | %.1f | %.1f | %.2f | %.1f | %.2f | %.0f |" % (n[:48], len(fv), fr, 2 * fr, wr, 2 * fr + wr, va / 1e6, mc, us, tb, vp))
     js[n] = {"fetch_raw_MB": round(fr, 2), "read_MB": round(2 * fr, 2), "write_MB": round(wr, 2), "traffic_bytes_per_launch": int((2 * fr + wr) * 1048576),
-             "valu_wave_insts_per_launch": int(va), "avg_us": round(us, 1)}
+             "valu_wave_insts_per_launch": int(va), "valu_mean_cycles_static": mc, "avg_us": round(us, 1)}
 tot = sum(v["traffic_bytes_per_launch"] for v in js.values()); totv = sum(v["valu_wave_insts_per_launch"] for v in js.values())
+totc = sum(v["valu_wave_insts_per_launch"] * v["valu_mean_cycles_static"] for v in js.values())
 B = bench["prof_bench_final"]["config"]["frames_per_gpu_per_step"]
 L += ["", "Whole step: %.2f GB of HBM-side traffic per %d-frame batch = %.1f MB per frame, %d launches, %.0f M wave-level VALU instructions" % (tot / 1e9, B, tot / B / 1e6, len(js), totv / 1e6),
-      "(= %.2f ms of VALU issue time on the whole chip at 2.4 GHz)." % (totv / (1024 * 2.4e9 / 4) * 1e3)]
+      "x %.2f cycles (mix-weighted mean) = %.3f ms of VALU time on the whole chip (1024 SIMDs at 2.4 GHz)." % (totc / max(totv, 1), totc / (1024 * 2.4e9) * 1e3)]
 open(f"{P}/{tag}_pmc.md", 'w').write("\n".join(L) + "\n")
 if "--no-current" not in sys.argv:
     geom = wl.split("(")[-1].split(")")[0] if "x" in wl else "64x2048"
     import re
     m = re.search(r"\((\d+x\d+)\)", wl)
     json.dump({"tag": tag, "config": {"batch": B, "geom": m.group(1) if m else "64x2048", "clusters": 100, "config": cfg, "input": real},
-               "step_traffic_bytes": tot, "step_valu_wave_insts": totv, "kernels": js,
-               "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU, separate passes, serial steps; read = 2 x FETCH_SIZE (gfx950, calibrated)"},
+               "step_traffic_bytes": tot, "step_valu_wave_insts": totv, "step_valu_simd_cycles": int(totc), "kernels": js,
+               "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU, separate passes, serial steps; read = 2 x FETCH_SIZE (gfx950, calibrated); "
+                       "valu_mean_cycles_static: static instruction mix of the kernel's assembly weighted with the measured cycle classes (profiles/r04_valu_peak.md)"},
               open(f"{P}/pmc_current.json" if cfg == 1 and not real else f"{P}/pmc_current_c{cfg}{'_real' if real else ''}.json", 'w'), indent=1)
 print(open(f"{P}/{tag}_kernel_stats_serial.md").read())
 print(open(f"{P}/{tag}_pmc.md").read().split("| kernel |")[1][:4000])
