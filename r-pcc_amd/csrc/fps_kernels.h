@@ -749,13 +749,14 @@ __global__ __launch_bounds__(FPS_TT) __attribute__((amdgpu_waves_per_eu(5, 8))) 
 // info[b][4] = first empty pixel that is a candidate (the representative of the FPS kernel's origin class).
 // ------------------------------------------------------------------------------------------------
 #define TAB_TPW 2
+#define MASK_WAVES 4   // wavefronts per workgroup (independent of each other but for the frame counters at the end)
 #define MASK_VGPR_ATTR
 template <bool RAW, bool VEC, bool EDGE = false>   // EDGE (with VEC): the image width is no multiple of four -- 16-byte accesses at 4-byte alignment, row-end quads by element
-__global__ __launch_bounds__(256) MASK_VGPR_ATTR void ground_mask_tab_kernel(float *__restrict__ ri, const float *__restrict__ tm,
+__global__ __launch_bounds__(64 * MASK_WAVES) MASK_VGPR_ATTR void ground_mask_tab_kernel(float *__restrict__ ri, const float *__restrict__ tm,
                                                               const double *__restrict__ ground, double thr, FpsTiling g,
                                                               float *__restrict__ temp, int32_t *__restrict__ info,
                                                               float *__restrict__ tiletab) {
-    __shared__ int s_cnt[4], s_nz[4], s_first[4], s_forg[4];
+    __shared__ int s_cnt[MASK_WAVES], s_nz[MASK_WAVES], s_first[MASK_WAVES], s_forg[MASK_WAVES];
     const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int P = g.N, T = g.T;
     const double a = ground[4 * b], bb = ground[4 * b + 1], c = ground[4 * b + 2], d = ground[4 * b + 3];
@@ -809,7 +810,7 @@ __global__ __launch_bounds__(256) MASK_VGPR_ATTR void ground_mask_tab_kernel(flo
     }
     float4 *tab4 = reinterpret_cast<float4 *>(tiletab + (int64_t)b * FPS_TAB_ROWS * T);
     int cnt = 0, nzc = 0, first = P, forg = P;
-    const int t0 = (blockIdx.x * 4 + wave) * TAB_TPW;
+    const int t0 = (blockIdx.x * MASK_WAVES + wave) * TAB_TPW;
     const int lrow = lane >> 3, lcol = 4 * (lane & 7);
     // the loads of all TAB_TPW tiles of this wavefront first (unconditional, clamped): one memory latency, not TAB_TPW
     FpsQuad q[TAB_TPW];
@@ -897,10 +898,9 @@ __global__ __launch_bounds__(256) MASK_VGPR_ATTR void ground_mask_tab_kernel(flo
     if (lane == 0) { s_cnt[wave] = cnt; s_nz[wave] = nzc; s_first[wave] = first; s_forg[wave] = forg; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const int tc = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-        const int tz = s_nz[0] + s_nz[1] + s_nz[2] + s_nz[3];
-        const int tf = min(min(s_first[0], s_first[1]), min(s_first[2], s_first[3]));
-        const int to = min(min(s_forg[0], s_forg[1]), min(s_forg[2], s_forg[3]));
+        int tc = 0, tz = 0, tf = P, to = P;
+#pragma unroll
+        for (int w = 0; w < MASK_WAVES; w++) { tc += s_cnt[w]; tz += s_nz[w]; tf = min(tf, s_first[w]); to = min(to, s_forg[w]); }
         if (tc) { atomicAdd(&info[RPCC_INFO * b + 0], tc); atomicMin(&info[RPCC_INFO * b + 1], tf); }
         if (tz) atomicAdd(&info[RPCC_INFO * b + 2], tz);
         if (to < P) atomicMin(&info[RPCC_INFO * b + 4], to);

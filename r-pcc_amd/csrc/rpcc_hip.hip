@@ -1476,9 +1476,9 @@ static int launch_ground_mask(float *ri, const float *tm, const double *ground, 
     if (!info_ready) info_init_kernel<<<(B + 255) / 256, 256, 0, st>>>(info, B, P);
     if (tiletab) {
         const FpsTiling g = fps_tiling_range(H, W);
-        const dim3 grid((g.T + 4 * TAB_TPW - 1) / (4 * TAB_TPW), B);
+        const dim3 grid((g.T + MASK_WAVES * TAB_TPW - 1) / (MASK_WAVES * TAB_TPW), B);
         const bool vec = (W % 4 == 0) && aligned16(ri) && aligned16(temp) && aligned16(tm);
-#define GM_LAUNCH(RAW_, EDGE_) ground_mask_tab_kernel<RAW_, true, EDGE_><<<grid, 256, 0, st>>>(ri, tm, ground, thr, g, temp, info, tiletab)
+#define GM_LAUNCH(RAW_, EDGE_) ground_mask_tab_kernel<RAW_, true, EDGE_><<<grid, 64 * MASK_WAVES, 0, st>>>(ri, tm, ground, thr, g, temp, info, tiletab)
         // (a width that is no multiple of four, or buffers that are not 16-byte aligned: the same quad layout at 4-byte alignment)
         if (raw) { if (vec) GM_LAUNCH(true, false); else GM_LAUNCH(true, true); }
         else     { if (vec) GM_LAUNCH(false, false); else GM_LAUNCH(false, true); }
@@ -1932,8 +1932,9 @@ __device__ __forceinline__ int assign_label(float r, float tx, float ty, float t
 #define ASSIGN_PX 4     // pixels per lane: a tile is (2 * ASSIGN_PX) rows x 32 columns, lane l pixel e -> row (l >> 4) + 4 * (e >> 1), column 2 * (l & 15) + (e & 1)
 #define ASSIGN_ROWS (2 * ASSIGN_PX)
 #define ASSIGN_TILES_PER_WAVE (4 / ASSIGN_PX)
+#define ASSIGN_WAVES 2   // wavefronts per workgroup (they share the centre table in LDS, nothing else)
 #define ASSIGN_VGPR_ATTR
-__global__ __launch_bounds__(256) ASSIGN_VGPR_ATTR void assign_kernel(const float *__restrict__ ri, const float *__restrict__ tm,
+__global__ __launch_bounds__(64 * ASSIGN_WAVES) ASSIGN_VGPR_ATTR void assign_kernel(const float *__restrict__ ri, const float *__restrict__ tm,
                                                      const double *__restrict__ ground,
                                                      const float *__restrict__ centers, int H, int W, int M,
                                                      uint8_t *__restrict__ seg) {
@@ -1950,7 +1951,7 @@ __global__ __launch_bounds__(256) ASSIGN_VGPR_ATTR void assign_kernel(const floa
     G.af = (float)G.a; G.bf = (float)G.b; G.cf = (float)G.c; G.df = (float)G.d;
     G.S = (float)((fabs(G.a) + fabs(G.b) + fabs(G.c)) * 1.001);
     const int tcols = (W + 31) >> 5, ntile = ((H + ASSIGN_ROWS - 1) / ASSIGN_ROWS) * tcols;
-    const int t0 = (blockIdx.x * 4 + wave) * ASSIGN_TILES_PER_WAVE;
+    const int t0 = (blockIdx.x * ASSIGN_WAVES + wave) * ASSIGN_TILES_PER_WAVE;
     const float *ri_b = ri + (int64_t)b * P;
     uint8_t *seg_b = seg + (int64_t)b * P;
     const float inf = __builtin_inff();
@@ -2051,8 +2052,8 @@ __global__ __launch_bounds__(256) ASSIGN_VGPR_ATTR void assign_kernel(const floa
 static int launch_assign(const float *ri, const float *tm, const double *ground, const float *centers, int B, int H,
                          int W, int M, uint8_t *seg, hipStream_t st) {
     const int ntile = ((H + ASSIGN_ROWS - 1) / ASSIGN_ROWS) * ((W + 31) / 32);
-    const dim3 grid((ntile + 4 * ASSIGN_TILES_PER_WAVE - 1) / (4 * ASSIGN_TILES_PER_WAVE), B);
-    assign_kernel<<<grid, 256, (size_t)M * sizeof(float4), st>>>(ri, tm, ground, centers, H, W, M, seg);
+    const dim3 grid((ntile + ASSIGN_WAVES * ASSIGN_TILES_PER_WAVE - 1) / (ASSIGN_WAVES * ASSIGN_TILES_PER_WAVE), B);
+    assign_kernel<<<grid, 64 * ASSIGN_WAVES, (size_t)M * sizeof(float4), st>>>(ri, tm, ground, centers, H, W, M, seg);
     LAUNCH_CHECK();
     return RPCC_OK;
 }
