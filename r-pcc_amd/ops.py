@@ -4,6 +4,7 @@ PyTorch is only the device-memory container and the stream provider here; all co
 librpcc_hip.so.  Every function enqueues on torch's current HIP stream and does not synchronise.
 """
 import ctypes as C
+import functools
 import math
 
 import numpy as np
@@ -402,6 +403,7 @@ def compress_batch(xyz, offsets, tm, ground, buf, ground_threshold=0.1, acc=0.04
     return buf
 
 
+@functools.lru_cache(maxsize=64)
 def angle_cos_cut(angle_threshold_deg):
     """Largest double v with arccos(v) > pi*(angle/180): the reference rejects a plane when
     alpha.max() > threshold (utils/segment_utils.py:89); the kernel compares v <= cos_cut instead of
