@@ -421,11 +421,8 @@ def run_workload(a, ctx):
     tw = (time.perf_counter() - tw) / max(a.warmup, 1)
     steps = a.steps
     if world > 1:
-        min_ms = float(os.environ.get("RPCC_BENCH_MIN_REGION_MS", "200"))
-        want = int(np.ceil(min_ms * 1e-3 / max(tw, 1e-5))) if a.warmup > 0 else a.steps
-        t = torch.tensor([max(a.steps, min(want, 100000))], dtype=torch.int64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        steps = int(t.item())
+        from rpcc_amd.sharding import agree_steps
+        steps = agree_steps(a.steps, tw if a.warmup > 0 else 0.0, float(os.environ.get("RPCC_BENCH_MIN_REGION_MS", "200")) * 1e-3, dev)
         timer.reserve(steps + 8)
 
     def timed_region(k_steps):
@@ -442,9 +439,8 @@ def run_workload(a, ctx):
         barrier()
         rank_dt = [dt_local]
         if world > 1:
-            allt = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
-            dist.all_gather(allt, torch.tensor([dt_local], dtype=torch.float64, device=dev))
-            rank_dt = [float(t.item()) for t in allt]
+            from rpcc_amd.sharding import gather_rank_times
+            rank_dt = gather_rank_times(dt_local, dev)
         return max(rank_dt), rank_dt
 
     dt, rank_dt = timed_region(steps)

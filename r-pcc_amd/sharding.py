@@ -4,6 +4,8 @@ Frames are independent, so the data path has no collective: rank r of R compress
 r, r+R, r+2R, ...  The only exchange is the final gather of the variable-length payloads to rank 0:
 an all_gather of the byte counts, then a gather of the padded byte buffers (RCCL on GPUs, gloo in the
 CPU tests).  Both functions take the process group as an argument and work with any backend."""
+import math
+
 import torch
 import torch.distributed as dist
 
@@ -148,3 +150,22 @@ class PackedExchange:
         nnz = self.nnz_all[rank].to(torch.int64)
         start = int(nnz[:frame].sum().item())
         return self.pay_all[rank].view(torch.int16)[start:start + int(nnz[frame].item())]
+
+
+def agree_steps(requested, warm_step_s, min_region_s, device, group=None, cap=100000):
+    """Length of a multi-rank timed region (bench.py): at least `requested` steps and at least `min_region_s` seconds by the
+    slowest-to-decide rank's own warm-up step time; every rank returns the same number (the ranks run a collective per step)."""
+    want = int(requested)
+    if warm_step_s and warm_step_s > 0:
+        want = max(want, min(int(math.ceil(min_region_s / warm_step_s - 1e-9)), int(cap)))
+    t = torch.tensor([want], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return int(t.item())
+
+
+def gather_rank_times(dt_local, device, group=None):
+    """Every rank's own time of a timed region, in rank order, on every rank (the job's time is the maximum)."""
+    world = dist.get_world_size(group)
+    allt = [torch.zeros(1, dtype=torch.float64, device=device) for _ in range(world)]
+    dist.all_gather(allt, torch.tensor([float(dt_local)], dtype=torch.float64, device=device), group=group)
+    return [float(t.item()) for t in allt]

@@ -98,6 +98,41 @@ def test_two_rank_round_gather_writes_single_rank_files(tmp_path, n_items, round
     assert all(outs[2]["%04d.rpcc" % i] == _payload(i) for i in range(n_items))
 
 
+def _region_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import rpcc_amd  # noqa: F401
+    from rpcc_amd.sharding import agree_steps, gather_rank_times
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cpu")
+    # the ranks measured different warm-up step times: 0.8 ms and 0.5 ms -> 200 ms need 250 / 400 steps; everyone runs 400
+    steps = agree_steps(20, 0.8e-3 if rank == 0 else 0.5e-3, 0.2, dev)
+    same = agree_steps(1000, 1e-3, 0.2, dev)          # the request is already long enough
+    nowarm = agree_steps(20, 0.0, 0.2, dev)           # no warm-up timing: the request stands
+    times = gather_rank_times(0.1 * (rank + 1), dev)
+    q.put((rank, steps, same, nowarm, times))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_timed_region_helpers():
+    """bench.py at N > 1: all ranks agree on the number of timed steps (a collective runs per step) -- the longest any rank's
+    warm-up asks for to fill 200 ms, never fewer than requested -- and every rank's own time arrives in rank order."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_region_worker, args=(r, 2, 29677, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, steps, same, nowarm, times in res:
+        assert steps == 400 and same == 1000 and nowarm == 20
+        assert [round(t, 3) for t in times] == [0.1, 0.2]
+
+
 def test_shard_indices_partition():
     sys.path.insert(0, ROOT)
     import rpcc_amd  # noqa: F401
