@@ -252,6 +252,7 @@ def dry_run_rank(a, rank, world):
 
 
 SETUP_ROUNDS = 8   # untimed runs of every pipeline slot before the warm-up steps (run_workload)
+LEN_EVERY = 8      # N > 1, lengths-only exchange: steps whose per-frame payload lengths travel in one all_gather
 
 
 def load_real_batch(path, ids, H, W, dev, shuffle=False):
@@ -348,9 +349,13 @@ def run_workload(a, ctx):
         from rpcc_amd.sharding import PackedExchange
         cap = PackedExchange.agree_capacity(int(offs_host[-1] - offs_host[0]), dev)
         packed_l = [torch.zeros((max(cap, 1),), dtype=torch.int16, device=dev) for _ in range(depth)]
-        exch = PackedExchange(B, cap if a.gather_payloads else 0, dev, payloads=a.gather_payloads)
-        exch_alt = PackedExchange(B, 0 if a.gather_payloads else cap, dev, payloads=not a.gather_payloads)
-        exchange_bytes = exch.bytes_per_step()
+        # lengths only: the lengths of LEN_EVERY consecutive steps travel in ONE all_gather (fewer, larger collectives: a collective
+        # per 0.75 ms step costs the chain more in cross-stream events than in bytes); with payloads: one gather per step
+        exch_len = PackedExchange(LEN_EVERY * B, 0, dev, payloads=False)
+        exch_pay = PackedExchange(B, cap, dev, payloads=True)
+        exch, exch_alt = (exch_pay, exch_len) if a.gather_payloads else (exch_len, exch_pay)
+        exchange_bytes = exch_pay.bytes_per_step() if a.gather_payloads else exch_len.bytes_per_step() // LEN_EVERY
+        lens_ring = torch.zeros((2, LEN_EVERY, B), dtype=torch.int32, device=dev)
 
     step_no = [0]
     pack_tot = torch.zeros((1,), dtype=torch.int64, device=dev)
@@ -361,6 +366,30 @@ def run_workload(a, ctx):
                            fps_bruteforce=a.fps_bruteforce, timer=timer if timed else None,
                            model_method="plane" if general else "point", angle_threshold=75, plane_seed=0, nonuniform=nu)
 
+    # The exchange of a step runs on a stream of its own behind an event of the step's stream, so the next batch of that pipeline
+    # slot is not held up by the collective (RCCL kernels of a few microseconds each cost the chain ~6 % when they sit on it); a
+    # slot's next step waits for the slot's previous exchange before it overwrites the lengths / the packed stream.
+    exch_stream = torch.cuda.Stream(device=dev) if exchange else None
+    step_done = [torch.cuda.Event() for _ in range(depth)] if exchange else None
+    exch_done = [None] * depth      # payload mode: the slot's previous gather (its packed stream may be overwritten after it)
+    ring_done = [None, None]        # lengths mode: the previous all_gather of each half of the lengths ring
+    len_no = [0]                    # steps whose lengths sit in the ring since the last flush boundary
+
+    def send_lengths(r):
+        """all_gather of ring half r on the exchange stream, behind the last step of every pipeline slot"""
+        with torch.cuda.stream(exch_stream):
+            for ev in step_done:
+                exch_stream.wait_event(ev)
+            exch_len.step(None, lens_ring[r].view(-1))
+            ring_done[r] = torch.cuda.Event()
+            ring_done[r].record(exch_stream)
+
+    def flush_exchange():
+        """end of a timed region: the lengths of the steps since the last full ring half (inside the region)"""
+        if exchange and not (exch_alt if mode[0] else exch).payloads and len_no[0] % LEN_EVERY:
+            send_lengths((len_no[0] // LEN_EVERY) % 2)
+            len_no[0] += LEN_EVERY - len_no[0] % LEN_EVERY
+
     def step():
         k = step_no[0] % depth
         step_no[0] += 1
@@ -369,12 +398,28 @@ def run_workload(a, ctx):
             if a.h2d:
                 xyz_l[k].copy_(xyz_host, non_blocking=True)
                 src = xyz_l[k]
+            ex = (exch_alt if mode[0] else exch) if exchange else None
+            if ex is not None and ex.payloads and exch_done[k] is not None:
+                streams[k].wait_event(exch_done[k])
+            if ex is not None and not ex.payloads:     # the call writes its per-frame lengths straight into their place in the ring
+                r, j = (len_no[0] // LEN_EVERY) % 2, len_no[0] % LEN_EVERY
+                if j < depth and ring_done[r] is not None:
+                    streams[k].wait_event(ring_done[r])     # (first touch of this half by this slot's stream since its last all_gather)
+                bufs[k].nnz = lens_ring[r, j]
             run(k, src)
-            if exchange:
-                ex = exch_alt if mode[0] else exch
-                if ex.payloads:
-                    ops.pack_payload(bufs[k].q16, bufs[k].nnz, packed=packed_l[k], capacity=cap, total=pack_tot)
-                ex.step(packed_l[k], bufs[k].nnz)
+            if ex is not None and ex.payloads:
+                ops.pack_payload(bufs[k].q16, bufs[k].nnz, packed=packed_l[k], capacity=cap, total=pack_tot)
+                step_done[k].record(streams[k])
+                with torch.cuda.stream(exch_stream):
+                    exch_stream.wait_event(step_done[k])
+                    ex.step(packed_l[k], bufs[k].nnz)
+                    exch_done[k] = torch.cuda.Event()
+                    exch_done[k].record(exch_stream)
+            elif ex is not None:
+                step_done[k].record(streams[k])
+                len_no[0] += 1
+                if j == LEN_EVERY - 1:
+                    send_lengths(r)
 
     def barrier():
         torch.cuda.synchronize()
@@ -399,10 +444,13 @@ def run_workload(a, ctx):
             for ex in (exch, exch_alt):
                 if ex.payloads:
                     ops.pack_payload(bufs[0].q16, bufs[0].nnz, packed=packed_l[0], capacity=cap, total=pack_tot)
-                ex.step(packed_l[0], bufs[0].nnz)
+                    ex.step(packed_l[0], bufs[0].nnz)
+                else:
+                    lens_ring[0, 0].copy_(bufs[0].nnz)
+                    ex.step(None, lens_ring[0].view(-1))
                 torch.cuda.synchronize()
                 if rank == 0:
-                    assert torch.equal(ex.nnz_all[0], bufs[0].nnz), "exchange returned other lengths than sent"
+                    assert torch.equal(ex.nnz_all[0][:B], bufs[0].nnz), "exchange returned other lengths than sent"
                     if ex.payloads:
                         for f in (0, B // 2, B - 1):
                             n = int(bufs[0].nnz[f])
@@ -434,6 +482,7 @@ def run_workload(a, ctx):
         t0 = time.perf_counter()
         for _ in range(k_steps):
             step()
+        flush_exchange()
         torch.cuda.synchronize()
         dt_local = time.perf_counter() - t0
         barrier()
@@ -453,12 +502,13 @@ def run_workload(a, ctx):
         exchange_modes = {head_mode: {"value": round(world * B * steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 4),
                                       "exchange_bytes_per_step": exchange_bytes}}
         try:
+            flush_exchange()
             mode[0] = 1
             for _ in range(min(5, steps)):
                 step()
             dt2, _ = timed_region(steps)
             exchange_modes["lengths" if a.gather_payloads else "lengths+payloads"] = {
-                "value": round(world * B * steps / dt2, 2), "ms_per_step": round(dt2 / steps * 1e3, 4), "exchange_bytes_per_step": exch_alt.bytes_per_step()}
+                "value": round(world * B * steps / dt2, 2), "ms_per_step": round(dt2 / steps * 1e3, 4), "exchange_bytes_per_step": exch_alt.bytes_per_step() // (1 if exch_alt.payloads else LEN_EVERY)}
         except Exception as e:  # noqa: BLE001
             exchange_modes["error"] = str(e).splitlines()[0][:200]
         finally:
@@ -553,8 +603,8 @@ def run_workload(a, ctx):
                                                        else ("synthetic" if a.scene == "default" else "synthetic ADVERSARIAL scene '%s'" % a.scene),
                                                        H, W, "non-uniform + FPS + plane-model" if general else "uniform + FPS + point-model", a.accuracy, M))
         exch_s = ("no exchange" if not exchange else
-                  "RCCL all_gather of the per-frame payload lengths" + (" + gather of the packed pre-entropy residual streams to rank 0" if a.gather_payloads
-                                                                        else " (payload bytes stay with the rank that writes the files)"))
+                  ("RCCL all_gather of the per-frame payload lengths + gather of the packed pre-entropy residual streams to rank 0, every step" if a.gather_payloads
+                   else "RCCL all_gather of the per-frame payload lengths, %d steps per collective (payload bytes stay with the rank that writes the files)" % LEN_EVERY))
         if world > 1 or a.force_gather:
             workload += "; exchange per step: " + exch_s
         # The roofline object.  The resource the step uses most is the VALU (profiles/r04_valu_peak.md: the throughput kernels keep the
