@@ -796,17 +796,26 @@ __global__ __launch_bounds__(64 * MASK_WAVES) MASK_VGPR_ATTR void ground_mask_ta
     float *ri_b = ri + (int64_t)b * P, *temp_b = temp + (int64_t)b * P;
     bool fast;
     float c0, c1, c2;
+    int forg0;   // first EMPTY candidate among the frame's first 64 pixels (-1: none there)
     {
         const int p = min(lane, P - 1);
         float r = ri_b[p], x, y, z;
         const bool cd = classify(r, tm[3 * p], tm[3 * p + 1], tm[3 * p + 2], x, y, z) && lane < P;
-        const unsigned long long m = __ballot(cd);
+        const unsigned long long m = __ballot(cd), mo = __ballot(cd && r == 0.0f);
         fast = m != 0ull;
         const int f0 = fast ? (int)__ffsll((long long)m) - 1 : 0;
+        forg0 = mo ? (int)__ffsll((long long)mo) - 1 : -1;
         c0 = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(x), f0));
         c1 = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(y), f0));
         c2 = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(z), f0));
-        if (blockIdx.x == 0 && threadIdx.x == 0) info[RPCC_INFO * b + 3] = fast ? 1 : 0;
+        // Every wavefront of the frame knows these from its own copy of the first 64 pixels: when the frame's first candidate / first
+        // empty candidate lies among them (the usual case) it IS the minimum over the frame, so workgroup 0 stores it and nobody
+        // runs an atomicMin on the frame's words (two of the four atomics of every workgroup).
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            info[RPCC_INFO * b + 3] = fast ? 1 : 0;
+            if (fast) info[RPCC_INFO * b + 1] = f0;
+            if (forg0 >= 0) info[RPCC_INFO * b + 4] = forg0;
+        }
     }
     float4 *tab4 = reinterpret_cast<float4 *>(tiletab + (int64_t)b * FPS_TAB_ROWS * T);
     int cnt = 0, nzc = 0, first = P, forg = P;
@@ -901,8 +910,8 @@ __global__ __launch_bounds__(64 * MASK_WAVES) MASK_VGPR_ATTR void ground_mask_ta
         int tc = 0, tz = 0, tf = P, to = P;
 #pragma unroll
         for (int w = 0; w < MASK_WAVES; w++) { tc += s_cnt[w]; tz += s_nz[w]; tf = min(tf, s_first[w]); to = min(to, s_forg[w]); }
-        if (tc) { atomicAdd(&info[RPCC_INFO * b + 0], tc); atomicMin(&info[RPCC_INFO * b + 1], tf); }
+        if (tc) { atomicAdd(&info[RPCC_INFO * b + 0], tc); if (!fast) atomicMin(&info[RPCC_INFO * b + 1], tf); }
         if (tz) atomicAdd(&info[RPCC_INFO * b + 2], tz);
-        if (to < P) atomicMin(&info[RPCC_INFO * b + 4], to);
+        if (forg0 < 0 && to < P) atomicMin(&info[RPCC_INFO * b + 4], to);
     }
 }
