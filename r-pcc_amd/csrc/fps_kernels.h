@@ -759,6 +759,42 @@ __global__ __launch_bounds__(64 * MASK_WAVES) MASK_VGPR_ATTR void ground_mask_ta
     __shared__ int s_cnt[MASK_WAVES], s_nz[MASK_WAVES], s_first[MASK_WAVES], s_forg[MASK_WAVES];
     const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int P = g.N, T = g.T;
+    // (all loads of the wavefront go out before the plane's fp64 preamble -- square root, thresholds -- is computed)
+    float *ri_b = ri + (int64_t)b * P, *temp_b = temp + (int64_t)b * P;
+    float4 *tab4 = reinterpret_cast<float4 *>(tiletab + (int64_t)b * FPS_TAB_ROWS * T);
+    int cnt = 0, nzc = 0, first = P, forg = P;
+    const int t0 = (blockIdx.x * MASK_WAVES + wave) * TAB_TPW;
+    const int lrow = lane >> 3, lcol = 4 * (lane & 7);
+    const float pr = ri_b[min(lane, P - 1)];                                                   // the frame's first 64 pixels (first centre)
+    const f32x3 pray = ld_at(reinterpret_cast<const f32x3 *>(tm), (uint32_t)min(lane, P - 1) * 12u);
+    // the loads of all TAB_TPW tiles of this wavefront first (unconditional, clamped): one memory latency, not TAB_TPW
+    FpsQuad q[TAB_TPW];
+#pragma unroll
+    for (int k = 0; k < TAB_TPW; k++) {
+        const int t = min(t0 + k, T - 1);
+        const int tr = t / g.tcols, tc = t - tr * g.tcols;
+        const int row = FPS_TROWS * tr + lrow, col = 32 * tc + lcol;
+        q[k].nval = row < g.H ? min(max(g.W - col, 0), 4) : 0;
+        q[k].p0 = q[k].nval > 0 ? row * g.W + col : 0;
+        const uint32_t p0 = (uint32_t)q[k].p0;
+        using V4 = typename std::conditional<EDGE, f32x4u, float4>::type;
+        if (VEC && (!EDGE || q[k].nval == 4)) {
+            const V4 r = ld_at(reinterpret_cast<const V4 *>(ri_b), p0 * 4u);
+            q[k].r[0] = r.x; q[k].r[1] = r.y; q[k].r[2] = r.z; q[k].r[3] = r.w;
+            const V4 ra = ld_at(reinterpret_cast<const V4 *>(tm), p0 * 12u);
+            const V4 rb = ld_at(reinterpret_cast<const V4 *>(tm), p0 * 12u + 16u);
+            const V4 rc = ld_at(reinterpret_cast<const V4 *>(tm), p0 * 12u + 32u);
+            q[k].t[0] = ra.x; q[k].t[1] = ra.y; q[k].t[2] = ra.z; q[k].t[3] = ra.w; q[k].t[4] = rb.x; q[k].t[5] = rb.y;
+            q[k].t[6] = rb.z; q[k].t[7] = rb.w; q[k].t[8] = rc.x; q[k].t[9] = rc.y; q[k].t[10] = rc.z; q[k].t[11] = rc.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const uint32_t p = p0 + (uint32_t)(e < q[k].nval ? e : 0);
+                q[k].r[e] = ld_f32(ri_b, p * 4u);
+                q[k].t[3 * e] = ld_f32(tm, p * 12u); q[k].t[3 * e + 1] = ld_f32(tm, p * 12u + 4u); q[k].t[3 * e + 2] = ld_f32(tm, p * 12u + 8u);
+            }
+        }
+    }
     const double a = ground[4 * b], bb = ground[4 * b + 1], c = ground[4 * b + 2], d = ground[4 * b + 3];
     // np.linalg.norm(plane_param[:, :3]) on a (1,1,4) array: all four components (segment_utils.py:47)
     const double div = sqrt(((a * a + bb * bb) + c * c) + d * d);
@@ -793,14 +829,14 @@ __global__ __launch_bounds__(64 * MASK_WAVES) MASK_VGPR_ATTR void ground_mask_ta
         if (screen && num < t_lo) return false;
         return num / div > thr;
     };
-    float *ri_b = ri + (int64_t)b * P, *temp_b = temp + (int64_t)b * P;
+    // (the first centre -- the frame's first candidate among its first 64 pixels -- is classified AFTER the tiles' loads are issued: its own
+    // load went out before them, so the wavefront pays one trip to memory at its start, not two)
     bool fast;
     float c0, c1, c2;
     int forg0;   // first EMPTY candidate among the frame's first 64 pixels (-1: none there)
     {
-        const int p = min(lane, P - 1);
-        float r = ri_b[p], x, y, z;
-        const bool cd = classify(r, tm[3 * p], tm[3 * p + 1], tm[3 * p + 2], x, y, z) && lane < P;
+        float r = pr, x, y, z;
+        const bool cd = classify(r, pray.x, pray.y, pray.z, x, y, z) && lane < P;
         const unsigned long long m = __ballot(cd), mo = __ballot(cd && r == 0.0f);
         fast = m != 0ull;
         const int f0 = fast ? (int)__ffsll((long long)m) - 1 : 0;
@@ -815,38 +851,6 @@ __global__ __launch_bounds__(64 * MASK_WAVES) MASK_VGPR_ATTR void ground_mask_ta
             info[RPCC_INFO * b + 3] = fast ? 1 : 0;
             if (fast) info[RPCC_INFO * b + 1] = f0;
             if (forg0 >= 0) info[RPCC_INFO * b + 4] = forg0;
-        }
-    }
-    float4 *tab4 = reinterpret_cast<float4 *>(tiletab + (int64_t)b * FPS_TAB_ROWS * T);
-    int cnt = 0, nzc = 0, first = P, forg = P;
-    const int t0 = (blockIdx.x * MASK_WAVES + wave) * TAB_TPW;
-    const int lrow = lane >> 3, lcol = 4 * (lane & 7);
-    // the loads of all TAB_TPW tiles of this wavefront first (unconditional, clamped): one memory latency, not TAB_TPW
-    FpsQuad q[TAB_TPW];
-#pragma unroll
-    for (int k = 0; k < TAB_TPW; k++) {
-        const int t = min(t0 + k, T - 1);
-        const int tr = t / g.tcols, tc = t - tr * g.tcols;
-        const int row = FPS_TROWS * tr + lrow, col = 32 * tc + lcol;
-        q[k].nval = row < g.H ? min(max(g.W - col, 0), 4) : 0;
-        q[k].p0 = q[k].nval > 0 ? row * g.W + col : 0;
-        const uint32_t p0 = (uint32_t)q[k].p0;
-        using V4 = typename std::conditional<EDGE, f32x4u, float4>::type;
-        if (VEC && (!EDGE || q[k].nval == 4)) {
-            const V4 r = ld_at(reinterpret_cast<const V4 *>(ri_b), p0 * 4u);
-            q[k].r[0] = r.x; q[k].r[1] = r.y; q[k].r[2] = r.z; q[k].r[3] = r.w;
-            const V4 ra = ld_at(reinterpret_cast<const V4 *>(tm), p0 * 12u);
-            const V4 rb = ld_at(reinterpret_cast<const V4 *>(tm), p0 * 12u + 16u);
-            const V4 rc = ld_at(reinterpret_cast<const V4 *>(tm), p0 * 12u + 32u);
-            q[k].t[0] = ra.x; q[k].t[1] = ra.y; q[k].t[2] = ra.z; q[k].t[3] = ra.w; q[k].t[4] = rb.x; q[k].t[5] = rb.y;
-            q[k].t[6] = rb.z; q[k].t[7] = rb.w; q[k].t[8] = rc.x; q[k].t[9] = rc.y; q[k].t[10] = rc.z; q[k].t[11] = rc.w;
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const uint32_t p = p0 + (uint32_t)(e < q[k].nval ? e : 0);
-                q[k].r[e] = ld_f32(ri_b, p * 4u);
-                q[k].t[3 * e] = ld_f32(tm, p * 12u); q[k].t[3 * e + 1] = ld_f32(tm, p * 12u + 4u); q[k].t[3 * e + 2] = ld_f32(tm, p * 12u + 8u);
-            }
         }
     }
 #pragma unroll

@@ -1941,6 +1941,28 @@ __global__ __launch_bounds__(64 * ASSIGN_WAVES) ASSIGN_VGPR_ATTR void assign_ker
     extern __shared__ __attribute__((aligned(16))) float4 cen4[];  // [M] (x,y,z,0)
     const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int P = H * W;
+    static_assert(ASSIGN_TILES_PER_WAVE == 1, "one tile per wavefront: its loads are issued before the centre table is filled");
+    const int tcols = (W + 31) >> 5, ntile = ((H + ASSIGN_ROWS - 1) / ASSIGN_ROWS) * tcols;
+    const int t0 = (blockIdx.x * ASSIGN_WAVES + wave) * ASSIGN_TILES_PER_WAVE;
+    const float *ri_b = ri + (int64_t)b * P;
+    uint8_t *seg_b = seg + (int64_t)b * P;
+    // the tile's loads go out first (unconditional, clamped), then the centres: one trip to memory before the barrier, not two
+    bool valid[ASSIGN_PX];
+    int p[ASSIGN_PX];
+    float r[ASSIGN_PX], tx[ASSIGN_PX], ty[ASSIGN_PX], tz[ASSIGN_PX];
+    {
+        const int t = min(t0, ntile - 1);
+        const int row0 = (t / tcols) * ASSIGN_ROWS + (lane >> 4), col0 = (t % tcols) * 32 + 2 * (lane & 15);
+#pragma unroll
+        for (int e = 0; e < ASSIGN_PX; e++) {
+            const int row = row0 + 4 * (e >> 1), col = col0 + (e & 1);
+            valid[e] = row < H && col < W && t0 < ntile;
+            p[e] = valid[e] ? row * W + col : 0;
+            r[e] = ld_at(ri_b, (uint32_t)p[e] * 4u);  // byte offsets from the frame's bases (scalar-base addressing)
+            const f32x3 ray = ld_at(reinterpret_cast<const f32x3 *>(tm), (uint32_t)p[e] * 12u);
+            tx[e] = ray.x; ty[e] = ray.y; tz[e] = ray.z;
+        }
+    }
     for (int i = threadIdx.x; i < M; i += blockDim.x) {
         const float *c = centers + ((int64_t)b * M + i) * 3;
         cen4[i] = make_float4(c[0], c[1], c[2], 0.0f);
@@ -1950,26 +1972,14 @@ __global__ __launch_bounds__(64 * ASSIGN_WAVES) ASSIGN_VGPR_ATTR void assign_ker
     G.a = ground[4 * b]; G.b = ground[4 * b + 1]; G.c = ground[4 * b + 2]; G.d = ground[4 * b + 3];
     G.af = (float)G.a; G.bf = (float)G.b; G.cf = (float)G.c; G.df = (float)G.d;
     G.S = (float)((fabs(G.a) + fabs(G.b) + fabs(G.c)) * 1.001);
-    const int tcols = (W + 31) >> 5, ntile = ((H + ASSIGN_ROWS - 1) / ASSIGN_ROWS) * tcols;
-    const int t0 = (blockIdx.x * ASSIGN_WAVES + wave) * ASSIGN_TILES_PER_WAVE;
-    const float *ri_b = ri + (int64_t)b * P;
-    uint8_t *seg_b = seg + (int64_t)b * P;
     const float inf = __builtin_inff();
     for (int t = t0; t < min(t0 + ASSIGN_TILES_PER_WAVE, ntile); t++) {
-        const int row0 = (t / tcols) * ASSIGN_ROWS + (lane >> 4), col0 = (t % tcols) * 32 + 2 * (lane & 15);
-        bool valid[ASSIGN_PX], live[ASSIGN_PX];
-        int p[ASSIGN_PX];
-        float r[ASSIGN_PX], tx[ASSIGN_PX], ty[ASSIGN_PX], tz[ASSIGN_PX], x[ASSIGN_PX], y[ASSIGN_PX], z[ASSIGN_PX];
+        bool live[ASSIGN_PX];
+        float x[ASSIGN_PX], y[ASSIGN_PX], z[ASSIGN_PX];
         bool any_live = false;
 #pragma unroll
         for (int e = 0; e < ASSIGN_PX; e++) {
-            const int row = row0 + 4 * (e >> 1), col = col0 + (e & 1);
-            valid[e] = row < H && col < W;
-            p[e] = valid[e] ? row * W + col : 0;
-            r[e] = ld_at(ri_b, (uint32_t)p[e] * 4u);  // byte offsets from the frame's bases (scalar-base addressing)
             if (!valid[e]) r[e] = 0.0f;
-            const f32x3 ray = ld_at(reinterpret_cast<const f32x3 *>(tm), (uint32_t)p[e] * 12u);
-            tx[e] = ray.x; ty[e] = ray.y; tz[e] = ray.z;
             x[e] = r[e] * tx[e]; y[e] = r[e] * ty[e]; z[e] = r[e] * tz[e];
             live[e] = valid[e] && r[e] != 0.0f;
             any_live |= live[e];
