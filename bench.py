@@ -725,11 +725,12 @@ def run_feed(a, ctx, frames_total=8192, ingest="xyz"):
             "bound": "host copy into pinned memory + PCIe H2D, not the kernels"}
 
 
-def run_mixed(a, ctx, per=85, reps=24, slots=None):
+def run_mixed(a, ctx, per=85, reps=24, slots=None, by_streams=False):
     """Secondary: configs[4]'s content on one GPU -- 64E / 32E / VLP16 sweeps (variable H x W) in mixed batches, non-uniform
-    framework + plane model: the three geometry groups of a mixed batch as calls on their own streams, `slots` mixed batches in
-    flight (what pipeline.MixedBatchCompressor queues), device part only.  Verified: labels, salience levels and quantised
-    integers of the first frames of every group against the oracle."""
+    framework + plane model: every mixed batch is ONE fused call (rpcc_compress_batch_mixed: the per-frame and per-label kernels run
+    once over the three geometry groups) plus the groups' contour coding, on the stream of its slot; `slots` mixed batches in
+    flight, device part only.  by_streams (A/B, tools_dev): the form used until round 4 -- every group its own chain of launches on
+    its own stream.  Verified: labels, salience levels and quantised integers of the first frames of every group against the oracle."""
     import numpy as np
     import torch
     from oracle import oracle as orc
@@ -737,21 +738,30 @@ def run_mixed(a, ctx, per=85, reps=24, slots=None):
     from rpcc_amd.pipeline import BatchCompressor, MixedBatchCompressor
     dev = ctx["dev"]
     slots = int(os.environ.get("RPCC_MIXED_SLOTS", MixedBatchCompressor.SLOTS)) if slots is None else slots
+    names = ("Velodyne64E", "Velodyne32E", "VelodyneVLP16")
+    kw = dict(accuracy=a.accuracy, uniform=False, model_method="plane", seed=1)
+    T = {n: dataset.build_dataset(lidar_type=n, device=str(dev)).PCTransformer for n in names}
     groups = []
-    for n in ("Velodyne64E", "Velodyne32E", "VelodyneVLP16"):
+    for n in names:
         gd = orc.GEOMS[n]
-        T = dataset.build_dataset(lidar_type=n, device=str(dev)).PCTransformer
         ids = list(range(3000, 3000 + per))
         xyz, offs = synth.make_batch(ids, gd["H"], gd["W"], device=dev, vmax_deg=gd["vmax_deg"], vmin_deg=gd["vmin_deg"])
-        sl = [(BatchCompressor(T, accuracy=a.accuracy, uniform=False, model_method="plane", seed=1), torch.cuda.Stream(device=dev)) for _ in range(slots)]
+        sl = [(BatchCompressor(T[n], **kw), torch.cuda.Stream(device=dev)) for _ in range(slots)] if by_streams else None
         groups.append((n, gd, sl, xyz, offs, torch.as_tensor(np.asarray(ids, np.int64), device=dev)))
+    mixed = [(MixedBatchCompressor(T, **kw), torch.cuda.Stream(device=dev)) for _ in range(slots)]
+    parts = {n: (xyz, offs, None, fid) for n, gd, sl, xyz, offs, fid in groups}
     outs = {}
 
-    def mixed_batch(r):          # one mixed batch: its three geometry groups on the streams of slot r % slots
-        for n, gd, sl, xyz, offs, fid in groups:
-            bc, st = sl[r % slots]
+    def mixed_batch(r):
+        if by_streams:           # its three geometry groups on the streams of slot r % slots
+            for n, gd, sl, xyz, offs, fid in groups:
+                bc, st = sl[r % slots]
+                with torch.cuda.stream(st):
+                    outs[n] = bc.compress_device(xyz, offs, frame_ids=fid)
+        else:                    # one fused call on the stream of slot r % slots
+            mc, st = mixed[r % slots]
             with torch.cuda.stream(st):
-                outs[n] = bc.compress_device(xyz, offs, frame_ids=fid)
+                outs.update(mc.compress_device(parts))
     for r in range(2 * slots):      # warm-up (per-stream allocator pools, first-use attributes)
         mixed_batch(r)
     torch.cuda.synchronize()
@@ -778,7 +788,9 @@ def run_mixed(a, ctx, per=85, reps=24, slots=None):
                          np.array_equal(sal[i, :o["salience"].shape[0]].cpu().numpy(), o["salience"].astype(np.uint8)))
     n_frames = 3 * per
     return {"what": "configs[4] on one GPU: mixed batches of %d + %d + %d sweeps of 64x2000 / 32x2250 / 16x1800, non-uniform + "
-                    "plane-model, the three geometry groups of a batch on their own streams, %d mixed batch(es) in flight; device part" % (per, per, per, slots),
+                    "plane-model, %s, %d mixed batch(es) in flight; device part"
+                    % (per, per, per, "the three geometry groups of a batch on their own streams" if by_streams else
+                       "one fused call per mixed batch (per-frame / per-label kernels once over the three geometry groups)", slots),
             "value": round(n_frames / dt, 1), "unit": "frames/s", "ms_per_mixed_batch": round(dt * 1e3, 3), "verified": bool(ok),
             "verified_frames_per_group": nver}
 

@@ -312,6 +312,18 @@ size_t rpcc_workspace_bytes_general(int B, int P, int M, int64_t total_points); 
 int rpcc_compress_batch(const rpcc_batch_io *io, int B, rpcc_geom g, int M, double ground_threshold, float acc,
                         void *ws, void *stream);
 
+/* The same for a batch that holds sweeps of several lidar geometries (variable H x W inside one call: BASELINE configs[4]; the
+ * reference compresses such a list frame by frame with one dataset / transformer per lidar, tools/compress_datalist.py:160-206,
+ * dataset/lidar_cfg/*.yaml).  The frames are grouped by geometry: group i = ios[i] (its own buffers, laid out for Bs[i] frames of
+ * geoms[i], exactly as for rpcc_compress_batch), workspace wss[i] of rpcc_workspace_bytes[_general](Bs[i], P_i, M, total_i) bytes.
+ * Everything is queued on `stream`; the kernels with one workgroup per frame or per label (ground RANSAC, FPS, plane fits) run
+ * as ONE launch over the frames of all groups, the pixel-parallel kernels group after group.  Results per group are what
+ * rpcc_compress_batch returns for that group alone.  G <= RPCC_MAX_GROUPS; ground_seed / model_method / nonuniform may differ
+ * between the groups. */
+#define RPCC_MAX_GROUPS 4
+int rpcc_compress_batch_mixed(const rpcc_batch_io *ios, const int *Bs, const rpcc_geom *geoms, int G, int M,
+                              double ground_threshold, float acc, void *const *wss, void *stream);
+
 /* Developer hook (libraries built with -DRPCC_DEVTRACE only; the shipped one returns RPCC_ERR_ARG for a non-NULL buffer):
  * register a device int64 buffer of at least RPCC_DEBUG_STAMPS_WORDS words; instrumented kernels store the shader clock at
  * phase boundaries, the FPS kernel its per-phase cycle sums and per-iteration tile counts.  NULL disables it (default). */

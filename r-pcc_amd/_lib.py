@@ -10,6 +10,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RPCC_HIP_LIB") or os.path.join(_HERE, "lib", "librpcc_hip.so")
 
 
+MAX_GROUPS = 4   # RPCC_MAX_GROUPS (include/rpcc_hip.h)
+
+
 class Geom(C.Structure):
     _fields_ = [("H", C.c_int32), ("W", C.c_int32), ("horizontal_fov", C.c_float), ("vertical_max", C.c_float),
                 ("vertical_min", C.c_float)]
@@ -85,6 +88,7 @@ _SIGS = {
     "rpcc_workspace_bytes": (C.c_size_t, [_I, _I, _I, _I64]),
     "rpcc_workspace_bytes_general": (C.c_size_t, [_I, _I, _I, _I64]),
     "rpcc_compress_batch": (C.c_int, [C.POINTER(BatchIO), _I, Geom, _I, _D, _F, _VP, _VP]),
+    "rpcc_compress_batch_mixed": (C.c_int, [C.POINTER(BatchIO), C.POINTER(C.c_int), C.POINTER(Geom), _I, _I, _D, _F, C.POINTER(C.c_void_p), _VP]),
     "rpcc_debug_stamps": (C.c_int, [_VP]),
     "rpcc_timer_create": (_VP, []),
     "rpcc_timer_destroy": (None, [_VP]),

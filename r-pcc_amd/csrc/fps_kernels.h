@@ -494,7 +494,7 @@ __device__ __forceinline__ void fps_regtab_body(const float *__restrict__ src, c
                                                 float *__restrict__ temp, const int32_t *__restrict__ info,
                                                 FpsTiling g, int M, int flags, int32_t *__restrict__ out_idx,
                                                 float *__restrict__ out_cen, const float *__restrict__ tiletab,
-                                                const float *__restrict__ rays_soa) {
+                                                const float *__restrict__ rays_soa, const int b) {   // b: the workgroup's frame
     constexpr int NW = FPS_TT / 64;
     TRACE_FPS_DECLS();      // (developer trace hooks: empty unless the library is built with -DRPCC_DEVTRACE, rpcc_trace.h)
     TRACE_FPS_WG(0);
@@ -502,7 +502,7 @@ __device__ __forceinline__ void fps_regtab_body(const float *__restrict__ src, c
     __shared__ float4 slot_c[2][NW];   //                          its coordinates
     __shared__ int s_viol;
     const int T = g.T, N = g.N;
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     src += (int64_t)b * N * (RANGE ? 1 : 3);
     temp += (int64_t)b * N;
     out_idx += (int64_t)b * M;
@@ -729,13 +729,40 @@ template <bool RANGE, bool VEC, int FPS_TT, bool EDGE = false>
 __global__ __launch_bounds__(FPS_TT) __attribute__((amdgpu_waves_per_eu(4, 8))) void fps_regtab_kernel(
     const float *__restrict__ src, const float *__restrict__ rays, float *__restrict__ temp, const int32_t *__restrict__ info, FpsTiling g, int M,
     int flags, int32_t *__restrict__ out_idx, float *__restrict__ out_cen, const float *__restrict__ tiletab) {
-    fps_regtab_body<RANGE, VEC, FPS_TT, false, EDGE>(src, rays, temp, info, g, M, flags, out_idx, out_cen, tiletab, nullptr);
+    fps_regtab_body<RANGE, VEC, FPS_TT, false, EDGE>(src, rays, temp, info, g, M, flags, out_idx, out_cen, tiletab, nullptr, blockIdx.x);
 }
 template <int FPS_TT, bool EDGE = false>
 __global__ __launch_bounds__(FPS_TT) __attribute__((amdgpu_waves_per_eu(5, 8))) void fps_regtab_planar_kernel(
     const float *__restrict__ src, const float *__restrict__ rays, float *__restrict__ temp, const int32_t *__restrict__ info, FpsTiling g, int M,
     int flags, int32_t *__restrict__ out_idx, float *__restrict__ out_cen, const float *__restrict__ tiletab, const float *__restrict__ rays_soa) {
-    fps_regtab_body<true, true, FPS_TT, true, EDGE>(src, rays, temp, info, g, M, flags, out_idx, out_cen, tiletab, rays_soa);
+    fps_regtab_body<true, true, FPS_TT, true, EDGE>(src, rays, temp, info, g, M, flags, out_idx, out_cen, tiletab, rays_soa, blockIdx.x);
+}
+// The same for the frames of several geometry groups in ONE launch (rpcc_compress_batch_mixed: variable H x W inside one call).  The device runs
+// as many kernels side by side as the process has hardware queues -- three or four -- and this kernel keeps one CU per frame busy for 99
+// dependent iterations whatever the image size, so the groups' launches side by side on streams leave most of the chip idle
+// (tools_dev/launch_rate.hip, profiles/HISTORY.md).  Workgroup -> (group, frame of the group) through the table in the kernel arguments.
+struct FpsGroupArgs {
+    const float *src, *rays;
+    float *temp;
+    const int32_t *info;
+    FpsTiling g;
+    int32_t *out_idx;
+    float *out_cen;
+    const float *tiletab, *rays_soa;
+};
+struct FpsMulti {
+    int n, first[RPCC_MAX_GROUPS + 1];   // group i owns the workgroups first[i] .. first[i + 1] - 1
+    int edge[RPCC_MAX_GROUPS];           // the group's image width is no multiple of four (EDGE accesses)
+    FpsGroupArgs a[RPCC_MAX_GROUPS];
+};
+template <int FPS_TT>
+__global__ __launch_bounds__(FPS_TT) __attribute__((amdgpu_waves_per_eu(5, 8))) void fps_regtab_planar_multi_kernel(const FpsMulti m, int M, int flags) {
+    const int gi = multi_group_of(m.first, m.n, blockIdx.x);
+    const FpsGroupArgs &a = m.a[gi];
+    const int b = (int)blockIdx.x - m.first[gi];
+    // (both access variants in one kernel, chosen per workgroup: the launch lasts as long as its slowest frame, two launches as long as both)
+    if (m.edge[gi]) fps_regtab_body<true, true, FPS_TT, true, true>(a.src, a.rays, a.temp, a.info, a.g, M, flags, a.out_idx, a.out_cen, a.tiletab, a.rays_soa, b);
+    else            fps_regtab_body<true, true, FPS_TT, true, false>(a.src, a.rays, a.temp, a.info, a.g, M, flags, a.out_idx, a.out_cen, a.tiletab, a.rays_soa, b);
 }
 
 // ------------------------------------------------------------------------------------------------

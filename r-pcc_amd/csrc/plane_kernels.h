@@ -431,21 +431,21 @@ __device__ void plane_label_wg(const float *__restrict__ tm, const uint32_t *__r
 // Measured on 256 frames of 64x2048 (26 k labels: 48 % below 30 points, median 35, 90 % below 900; per frame five to nine
 // labels above 2048 points holding 25 k .. 60 k of its pixels, the largest 15 k): DESIGN.md section 6.
 #define PL_BIG 4096
-template <int MAXH>
 #define PL_WAVES 4
-__global__ __launch_bounds__(PL_THREADS) __attribute__((amdgpu_waves_per_eu(PL_WAVES, 8))) void plane_model_kernel(const float *__restrict__ tm,
-                                                                 const uint32_t *__restrict__ order_all,
-                                                                 const float4 *__restrict__ pts_all,
-                                                                 const uint32_t *__restrict__ hist,
-                                                                 const int32_t *__restrict__ counts,
-                                                                 const double *__restrict__ ground, int B, int P, int M, int KP, int T,
-                                                                 PlaneParams pp, int big, float *__restrict__ model) {
+template <int MAXH>
+__device__ __forceinline__ void plane_model_body(const float *__restrict__ tm,
+                                                 const uint32_t *__restrict__ order_all,
+                                                 const float4 *__restrict__ pts_all,
+                                                 const uint32_t *__restrict__ hist,
+                                                 const int32_t *__restrict__ counts,
+                                                 const double *__restrict__ ground, int B, int P, int M, int KP, int T,
+                                                 const PlaneParams &pp, int big, float *__restrict__ model, const int wg) {   // wg: workgroup index of the launch layout above
     __shared__ PlaneWgLds S;
     __shared__ NpwLds npw[PL_THREADS / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int K = M + 2, nbig = B * (K - 2);
-    if ((int)blockIdx.x < nbig) {  // workgroup-uniform
-        const int b = blockIdx.x / (K - 2), kk = 2 + blockIdx.x % (K - 2);
+    if (wg < nbig) {  // workgroup-uniform
+        const int b = wg / (K - 2), kk = 2 + wg % (K - 2);
         const int nn = counts[(int64_t)b * K + kk];
         if (nn <= big) return;
         const uint32_t fid = pp.frame_ids ? (uint32_t)pp.frame_ids[b] : (uint32_t)b;
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(PL_THREADS) __attribute__((amdgpu_waves_per_eu(PL_W
                        pp, S, npw, model + ((int64_t)b * K + kk) * 4, pp.inject ? pp.inject + ((int64_t)b * K + kk) * 4 : nullptr);
         return;
     }
-    const int groups = (K + PL_THREADS / 64 - 1) / (PL_THREADS / 64), g = blockIdx.x - nbig;
+    const int groups = (K + PL_THREADS / 64 - 1) / (PL_THREADS / 64), g = wg - nbig;
     const int b = g / groups, k = (g % groups) * (PL_THREADS / 64) + wave;
     const uint32_t fid = pp.frame_ids ? (uint32_t)pp.frame_ids[b] : (uint32_t)b;
     if (k >= K) return;
@@ -505,4 +505,36 @@ __global__ __launch_bounds__(PL_THREADS) __attribute__((amdgpu_waves_per_eu(PL_W
         const float mean = np_mean_wave(pts, n, npw[wave]);
         if (lane < 4) row[lane] = lane == 3 ? mean : 0.0f;
     }
+}
+template <int MAXH>
+__global__ __launch_bounds__(PL_THREADS) __attribute__((amdgpu_waves_per_eu(PL_WAVES, 8))) void plane_model_kernel(const float *__restrict__ tm,
+                                                                 const uint32_t *__restrict__ order_all,
+                                                                 const float4 *__restrict__ pts_all,
+                                                                 const uint32_t *__restrict__ hist,
+                                                                 const int32_t *__restrict__ counts,
+                                                                 const double *__restrict__ ground, int B, int P, int M, int KP, int T,
+                                                                 PlaneParams pp, int big, float *__restrict__ model) {
+    plane_model_body<MAXH>(tm, order_all, pts_all, hist, counts, ground, B, P, M, KP, T, pp, big, model, blockIdx.x);
+}
+// the labels of several geometry groups in one launch (rpcc_compress_batch_mixed; fps_kernels.h: fps_regtab_planar_multi_kernel)
+struct PlaneGroupArgs {
+    const float *tm;
+    const uint32_t *order_all;
+    const float4 *pts_all;
+    const uint32_t *hist;
+    const int32_t *counts;
+    const double *ground;
+    int B, P, T;
+    PlaneParams pp;
+    float *model;
+};
+struct PlaneMulti {
+    int n, first[RPCC_MAX_GROUPS + 1];
+    PlaneGroupArgs a[RPCC_MAX_GROUPS];
+};
+template <int MAXH>
+__global__ __launch_bounds__(PL_THREADS) __attribute__((amdgpu_waves_per_eu(PL_WAVES, 8))) void plane_model_multi_kernel(const PlaneMulti m, int M, int KP, int big) {
+    const int gi = multi_group_of(m.first, m.n, blockIdx.x);
+    const PlaneGroupArgs &a = m.a[gi];
+    plane_model_body<MAXH>(a.tm, a.order_all, a.pts_all, a.hist, a.counts, a.ground, a.B, a.P, M, KP, a.T, a.pp, big, a.model, (int)blockIdx.x - m.first[gi]);
 }

@@ -261,3 +261,10 @@ __device__ __forceinline__ unsigned long long fps_key(float v, uint32_t idx) {
 __device__ __forceinline__ uint32_t fps_key_index(unsigned long long k) { return 0xFFFFFFFFu - (uint32_t)k; }
 
 }  // namespace rpcc
+
+// launches over the frames of several geometry groups (rpcc_compress_batch_mixed): group i owns the workgroups first[i] .. first[i + 1] - 1
+__device__ __forceinline__ int multi_group_of(const int *first, int n, int wg) {   // (workgroup-uniform)
+    int gi = 0;
+    for (int i = 1; i < n; i++) gi += wg >= first[i] ? 1 : 0;
+    return gi;
+}

@@ -1277,21 +1277,21 @@ __device__ __forceinline__ uint32_t udiv32(uint32_t a, const UDiv32 u) {
 #define RS_GROUND_MAXH 104
 #define RS_GROUND_PU 4   // candidates per lane in flight in the scoring loop (LDS reads; 1 / 2 / 4: 108.5 / 106.9 / 105.3 us)
 #define RS_VGPR_ATTR
-__global__ __launch_bounds__(RS_THREADS) RS_VGPR_ATTR void ground_ransac_kernel(const float *__restrict__ ri_all,
-                                                                   const float *__restrict__ tm, int P, float zthr,
-                                                                   int max_pts, int min_pts, int ransac_n, int iters,
-                                                                   double thr, uint32_t seed0, int raw,
-                                                                   double *__restrict__ ground,
-                                                                   int32_t *__restrict__ ninl,
-                                                                   const int32_t *__restrict__ zcnt,
-                                                                   const int64_t *__restrict__ frame_ids) {
+__device__ __forceinline__ void ground_ransac_body(const float *__restrict__ ri_all,
+                                                   const float *__restrict__ tm, int P, float zthr,
+                                                   int max_pts, int min_pts, int ransac_n, int iters,
+                                                   double thr, uint32_t seed0, int raw,
+                                                   double *__restrict__ ground,
+                                                   int32_t *__restrict__ ninl,
+                                                   const int32_t *__restrict__ zcnt,
+                                                   const int64_t *__restrict__ frame_ids, const int b) {   // b: the workgroup's frame
     extern __shared__ __attribute__((aligned(16))) unsigned char rs_smem[];
     double *sred = reinterpret_cast<double *>(rs_smem);          // [6*256]
     double *swin = sred + 6 * RS_NT;                             // [64] + [RS_MAX_HYP*4] fp64 hypotheses
     int *sbest = reinterpret_cast<int *>(swin + 64 + RS_MAX_HYP * 4);  // [32]
     int *swave = sbest + 32;                                     // [16]
     float *list = reinterpret_cast<float *>(swave + 16);         // [max_pts*3]
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float *ri = ri_all + (int64_t)b * P;
     DBG_STAMP(0);
     // each wave owns a contiguous run of pixels (rounded up to whole 64-pixel steps)
@@ -1381,15 +1381,57 @@ __global__ __launch_bounds__(RS_THREADS) RS_VGPR_ATTR void ground_ransac_kernel(
         if (ninl) ninl[b] = inl;
     }
 }
+__global__ __launch_bounds__(RS_THREADS) RS_VGPR_ATTR void ground_ransac_kernel(const float *__restrict__ ri_all,
+                                                                   const float *__restrict__ tm, int P, float zthr,
+                                                                   int max_pts, int min_pts, int ransac_n, int iters,
+                                                                   double thr, uint32_t seed0, int raw,
+                                                                   double *__restrict__ ground,
+                                                                   int32_t *__restrict__ ninl,
+                                                                   const int32_t *__restrict__ zcnt,
+                                                                   const int64_t *__restrict__ frame_ids) {
+    ground_ransac_body(ri_all, tm, P, zthr, max_pts, min_pts, ransac_n, iters, thr, seed0, raw, ground, ninl, zcnt, frame_ids, blockIdx.x);
+}
+// the frames of several geometry groups in one launch (rpcc_compress_batch_mixed; fps_kernels.h: fps_regtab_planar_multi_kernel)
+struct RansacGroupArgs {
+    const float *ri_all, *tm;
+    int P;
+    uint32_t seed0;
+    double *ground;
+    const int32_t *zcnt;
+    const int64_t *frame_ids;
+};
+struct RansacMulti {
+    int n, first[RPCC_MAX_GROUPS + 1];
+    RansacGroupArgs a[RPCC_MAX_GROUPS];
+};
+__global__ __launch_bounds__(RS_THREADS) RS_VGPR_ATTR void ground_ransac_multi_kernel(const RansacMulti m, float zthr, int max_pts, int min_pts,
+                                                                                      int ransac_n, int iters, double thr) {
+    const int gi = multi_group_of(m.first, m.n, blockIdx.x);
+    const RansacGroupArgs &a = m.a[gi];
+    ground_ransac_body(a.ri_all, a.tm, a.P, zthr, max_pts, min_pts, ransac_n, iters, thr, a.seed0, 0, a.ground, nullptr, a.zcnt, a.frame_ids,
+                       (int)blockIdx.x - m.first[gi]);
+}
 
+#define RS_GROUND_MAX_PTS 5000
+#define RS_GROUND_MIN_PTS 800
+static inline size_t ground_ransac_lds_bytes() {
+    return (size_t)6 * RS_NT * 8 + (64 + RS_MAX_HYP * 4) * 8 + 32 * 4 + 16 * 4 + (size_t)RS_GROUND_MAX_PTS * 3 * 4;
+}
 static int launch_ground_ransac(const float *ri, const float *tm, int B, int P, uint32_t seed0, bool raw, double *ground,
                                 int32_t *ninl, hipStream_t st, const int32_t *zcnt = nullptr,
                                 const int64_t *frame_ids = nullptr) {
-    const int max_pts = 5000, min_pts = 800;
-    const size_t sh = (size_t)6 * RS_NT * 8 + (64 + RS_MAX_HYP * 4) * 8 + 32 * 4 + 16 * 4 + (size_t)max_pts * 3 * 4;
+    const int max_pts = RS_GROUND_MAX_PTS, min_pts = RS_GROUND_MIN_PTS;
+    const size_t sh = ground_ransac_lds_bytes();
     HIP_TRY(ensure_dyn_lds(reinterpret_cast<const void *>(&ground_ransac_kernel), (int)sh));
     ground_ransac_kernel<<<B, RS_THREADS, sh, st>>>(ri, tm, P, -1.5f, max_pts, min_pts, 10, 100, 0.1, seed0, raw ? 1 : 0,
                                                     ground, ninl, zcnt, frame_ids);
+    LAUNCH_CHECK();
+    return RPCC_OK;
+}
+static int launch_ground_ransac_multi(const RansacMulti &m, hipStream_t st) {
+    const size_t sh = ground_ransac_lds_bytes();
+    HIP_TRY(ensure_dyn_lds(reinterpret_cast<const void *>(&ground_ransac_multi_kernel), (int)sh));
+    ground_ransac_multi_kernel<<<m.first[m.n], RS_THREADS, sh, st>>>(m, -1.5f, RS_GROUND_MAX_PTS, RS_GROUND_MIN_PTS, 10, 100, 0.1);
     LAUNCH_CHECK();
     return RPCC_OK;
 }
@@ -2751,24 +2793,39 @@ static int launch_label_scan(const uint8_t *seg, int B, int P, int M, int32_t *c
     LAUNCH_CHECK();
     return RPCC_OK;
 }
-// plane rows from a segmentation whose tile offsets (launch_label_scan) are in ws; extra = order | pts4 scratch
-static int launch_plane_rows(const float *ri, const float *tm, const uint8_t *seg, const double *ground, int B, int P, int M,
-                             double cos_cut, uint32_t seed, const int64_t *frame_ids, float *model, const int32_t *counts,
-                             void *ws, void *extra, hipStream_t st, const double *inject = nullptr) {
-    const int KP = kpad(M), T = ntiles(P), K = M + 2;
+// plane rows from a segmentation whose tile offsets (launch_label_scan) are in ws; extra = order | pts4 scratch.  Two launches: the
+// label-ordered lists, then the fits.
+static inline float4 *plane_pts4(void *extra, int B, int P) {
+    return reinterpret_cast<float4 *>(reinterpret_cast<char *>(extra) + (((size_t)B * P * 4 + 255) & ~(size_t)255));
+}
+static int launch_label_order(const float *ri, const float *tm, const uint8_t *seg, int B, int P, int M, void *ws, void *extra, hipStream_t st) {
+    const int KP = kpad(M), T = ntiles(P);
     WsLayout L = ws_layout(ws, B, P, M);
-    uint32_t *order = reinterpret_cast<uint32_t *>(extra);
-    float4 *pts4 = reinterpret_cast<float4 *>(reinterpret_cast<char *>(order) + (((size_t)B * P * 4 + 255) & ~(size_t)255));
     // (the quantiser's round-3 layout -- four consecutive pixels per lane -- was tried here as well: 121 us against 97 us, because a
     // lane's four 16-byte point stores then lie 64 bytes apart from the next lane's; this kernel is bound by its 255 MB of stores)
-    label_order_kernel<<<dim3(T, B), 256, (size_t)16 * (KP + 1) * 4 + (size_t)KP * 4, st>>>(seg, L.hist, P, M, KP, T, order, ri, tm, pts4);
-    PlaneParams pp;
-    pp.cos_cut = cos_cut; pp.thr = 0.1f; pp.min_points = 30; pp.iters = 10; pp.seed = seed; pp.frame_ids = frame_ids; pp.inject = inject;
+    label_order_kernel<<<dim3(T, B), 256, (size_t)16 * (KP + 1) * 4 + (size_t)KP * 4, st>>>(seg, L.hist, P, M, KP, T, reinterpret_cast<uint32_t *>(extra), ri, tm,
+                                                                                            plane_pts4(extra, B, P));
+    LAUNCH_CHECK();
+    return RPCC_OK;
+}
+static PlaneGroupArgs plane_group_args(const float *tm, const double *ground, int B, int P, int M, double cos_cut, uint32_t seed,
+                                       const int64_t *frame_ids, float *model, const int32_t *counts, void *ws, void *extra, const double *inject) {
+    WsLayout L = ws_layout(ws, B, P, M);
+    PlaneGroupArgs a;
+    a.tm = tm; a.order_all = reinterpret_cast<const uint32_t *>(extra); a.pts_all = plane_pts4(extra, B, P); a.hist = L.hist; a.counts = counts;
+    a.ground = ground; a.B = B; a.P = P; a.T = ntiles(P); a.model = model;
+    a.pp.cos_cut = cos_cut; a.pp.thr = 0.1f; a.pp.min_points = 30; a.pp.iters = 10; a.pp.seed = seed; a.pp.frame_ids = frame_ids; a.pp.inject = inject;
+    return a;
+}
+static int launch_plane_fits(const float *tm, const double *ground, int B, int P, int M, double cos_cut, uint32_t seed, const int64_t *frame_ids,
+                             float *model, const int32_t *counts, void *ws, void *extra, hipStream_t st, const double *inject = nullptr) {
+    const int K = M + 2;
+    const PlaneGroupArgs a = plane_group_args(tm, ground, B, P, M, cos_cut, seed, frame_ids, model, counts, ws, extra, inject);
     // B x (K-2) workgroups that exist for the labels above PL_BIG points (they start first: the long ones are the tail of
     // the launch), then one wavefront per label for the rest
     const int wpg = PL_THREADS / 64, groups = (K + wpg - 1) / wpg;
-    plane_model_kernel<10><<<B * (K - 2) + B * groups, PL_THREADS, 0, st>>>(tm, order, pts4, L.hist, counts, ground, B, P, M, KP, T, pp,
-                                                                            PL_BIG, model);
+    plane_model_kernel<10><<<B * (K - 2) + B * groups, PL_THREADS, 0, st>>>(a.tm, a.order_all, a.pts_all, a.hist, a.counts, a.ground, B, P, M, kpad(M), a.T,
+                                                                            a.pp, PL_BIG, a.model);
     LAUNCH_CHECK();
     return RPCC_OK;
 }
@@ -2780,84 +2837,111 @@ extern "C" int rpcc_plane_model(const float *ri, const float *tm, const uint8_t 
     hipStream_t st = (hipStream_t)stream;
     int rc;
     if ((rc = launch_label_scan(seg, B, P, M, counts, nullptr, ws, st, false))) return rc;
-    return launch_plane_rows(ri, tm, seg, ground, B, P, M, cos_cut, seed, frame_ids, model, counts, ws,
-                             reinterpret_cast<char *>(ws) + ws_layout(nullptr, B, P, M).bytes + 256, st, inject_planes);
+    void *extra = reinterpret_cast<char *>(ws) + ws_layout(nullptr, B, P, M).bytes + 256;
+    if ((rc = launch_label_order(ri, tm, seg, B, P, M, ws, extra, st))) return rc;
+    return launch_plane_fits(tm, ground, B, P, M, cos_cut, seed, frame_ids, model, counts, ws, extra, st, inject_planes);
 }
 
 // ================================================================================================
 // fused batch entry (uniform framework, FPS segmentation, point model): a2 .. a11
 // ================================================================================================
-static int run_batch(const rpcc_batch_io *io, int Bs, int64_t npts, rpcc_geom g, int M, double ground_threshold, float acc,
-                     char *ws, hipStream_t st) {
-    const int P = g.H * g.W;
-    const bool fit_ground = io->ground_seed >= 0;  // >= 0: fit the ground plane here (seed + frame identity)
-    WsLayout L = ws_layout(ws, Bs, P, M);
-    char *proj_scratch = ws + L.bytes + 256;
-    const size_t proj_bytes = (project_scratch_bytes(npts, Bs, P) + 255) & ~(size_t)255;
-    float *temp = reinterpret_cast<float *>(proj_scratch + proj_bytes);
-    float *rays_soa = temp + (size_t)Bs * P;
-    float *tiletab = rays_soa + (size_t)3 * P + 64;
-    float *ri = io->ri;
-    double *ground = io->ground;
-    int32_t *info = io->info;
-    int rc;
-    int32_t *zcnt = fit_ground ? reinterpret_cast<int32_t *>(tiletab) : nullptr;  // the tile table is written later
+// Everything a call derives from its arguments for ONE geometry group (one io, one rpcc_geom): the carve-up of the workspace and the
+// choices that follow from the flags.  rpcc_compress_batch has one plan, rpcc_compress_batch_mixed one per group.
+struct BatchPlan {
+    const rpcc_batch_io *io;
+    int Bs, M, P;
+    int64_t npts;
+    rpcc_geom g;
+    double ground_threshold;
+    float acc;
+    char *ws;
+    WsLayout L;
+    bool fit_ground, brute, tiled;
+    char *proj_scratch, *extra;
+    size_t proj_bytes;
+    float *temp, *rays_soa, *tiletab, *label_acc;
+    int32_t *zcnt, *epoch, *kpn;
+    BatchInit bi;
+};
+static BatchPlan plan_batch(const rpcc_batch_io *io, int Bs, int64_t npts, rpcc_geom g, int M, double ground_threshold, float acc, char *ws) {
+    BatchPlan p;
+    p.io = io; p.Bs = Bs; p.M = M; p.P = g.H * g.W; p.npts = npts; p.g = g; p.ground_threshold = ground_threshold; p.acc = acc; p.ws = ws;
+    const int P = p.P;
+    p.fit_ground = io->ground_seed >= 0;  // >= 0: fit the ground plane here (seed + frame identity)
+    p.L = ws_layout(ws, Bs, P, M);
+    p.proj_scratch = ws + p.L.bytes + 256;
+    p.proj_bytes = (project_scratch_bytes(npts, Bs, P) + 255) & ~(size_t)255;
+    p.temp = reinterpret_cast<float *>(p.proj_scratch + p.proj_bytes);
+    p.rays_soa = p.temp + (size_t)Bs * P;
+    p.tiletab = p.rays_soa + (size_t)3 * P + 64;
+    p.zcnt = p.fit_ground ? reinterpret_cast<int32_t *>(p.tiletab) : nullptr;  // the tile table is written later
     // The first kernel of the batch (the pixel kernel) also writes the planar ray table (band kernel's z), initialises the info
     // counters of the ground mask and clears the RANSAC candidate counts and the label sums; the projection's per-frame
     // flags are marked with an epoch kept in the workspace (BatchInit), so the batch has no initialisation launch.
-    int32_t *epoch = reinterpret_cast<int32_t *>(ws + L.bytes);   // the 256 bytes between the model part and the projection scratch
-    BatchInit bi;
-    bi.tm = io->tm; bi.soa = rays_soa; bi.P = P; bi.info = info; bi.B = Bs; bi.on = 1;
-    bi.z0 = {reinterpret_cast<uint32_t *>(zcnt), zcnt ? Bs * (RS_CHUNKS + 1) : 0};
-    bi.z1 = {reinterpret_cast<uint32_t *>(L.sums), (int)(((char *)L.hist - (char *)L.sums) / 4)};
+    p.epoch = reinterpret_cast<int32_t *>(ws + p.L.bytes);   // the 256 bytes between the model part and the projection scratch
+    p.bi.tm = io->tm; p.bi.soa = p.rays_soa; p.bi.P = P; p.bi.info = io->info; p.bi.B = Bs; p.bi.on = 1;
+    p.bi.z0 = {reinterpret_cast<uint32_t *>(p.zcnt), p.zcnt ? Bs * (RS_CHUNKS + 1) : 0};
+    p.bi.z1 = {reinterpret_cast<uint32_t *>(p.L.sums), (int)(((char *)p.L.hist - (char *)p.L.sums) / 4)};
     // model rows + the tile offsets of the ordered scatter (built once, used by the plane list and by the quantiser)
-    char *extra = reinterpret_cast<char *>(tiletab) + (((size_t)Bs * FPS_TAB_ROWS * ((P + 31) / 32 + 4096) * 4 + 255) & ~(size_t)255) + 256;
+    p.extra = reinterpret_cast<char *>(p.tiletab) + (((size_t)Bs * FPS_TAB_ROWS * ((P + 31) / 32 + 4096) * 4 + 255) & ~(size_t)255) + 256;
     const size_t ksz = (((size_t)Bs * (M + 2) * 4 + 255) & ~(size_t)255);
-    float *label_acc = io->nonuniform ? reinterpret_cast<float *>(extra + plane_extra_bytes(Bs, P, M) - 256 - ksz) : nullptr;
-    int32_t *kpn = io->nonuniform ? reinterpret_cast<int32_t *>(extra + plane_extra_bytes(Bs, P, M) - 256 - 2 * ksz) : nullptr;
-    bi.z2 = {reinterpret_cast<uint32_t *>(kpn), kpn ? Bs * (M + 2) : 0};  // key points per label
-    if ((rc = launch_project(io->xyz, io->offsets, npts, 0, Bs, g, ri, proj_scratch, proj_bytes, st,
-                             rays_soa + 2 * (int64_t)P, zcnt, &bi, epoch, point_floats(io->point_stride_bytes))))
-        return rc;
-    if (fit_ground &&
-        (rc = launch_ground_ransac(ri, io->tm, Bs, P, (uint32_t)io->ground_seed, false, ground, nullptr, st, zcnt, io->frame_ids)))
-        return rc;
-    const bool brute = (io->flags & (RPCC_FPS_BRUTEFORCE | RPCC_FPS_MODE_BITS)) != 0;   // a mode flag selects the reference kernel too
-    const bool tiled = !brute && fps_tiling_range(g.H, g.W).T <= FPS_TILED_MAX_TILES;
-    if ((rc = launch_ground_mask(ri, io->tm, ground, ground_threshold, Bs, g.H, g.W, temp, info,
-                                 tiled ? tiletab : nullptr, st, false, true)))
-        return rc;
-    if ((rc = launch_fps_range(ri, io->tm, temp, info, Bs, g.H, g.W, M, io->cen_pix, io->centers, io->flags, false,
-                               tiled ? tiletab : nullptr, io->timer, st, FPS_SOA ? rays_soa : nullptr)))
-        return rc;
-    if ((rc = launch_assign(ri, io->tm, ground, io->centers, Bs, g.H, g.W, M, io->seg, st))) return rc;
-    if (io->model_method == 0) {
-        if ((rc = launch_point_model(ri, io->seg, ground, Bs, P, M, io->model, io->counts, io->nnz, ws, st, true))) return rc;
-    } else {
-        if ((rc = launch_label_scan(io->seg, Bs, P, M, io->counts, io->nnz, ws, st, true))) return rc;
-        if ((rc = launch_plane_rows(ri, io->tm, io->seg, ground, Bs, P, M, io->plane_cos_cut, (uint32_t)io->plane_seed,
-                                    io->frame_ids, io->model, io->counts, ws, extra, st)))
-            return rc;
+    p.label_acc = io->nonuniform ? reinterpret_cast<float *>(p.extra + plane_extra_bytes(Bs, P, M) - 256 - ksz) : nullptr;
+    p.kpn = io->nonuniform ? reinterpret_cast<int32_t *>(p.extra + plane_extra_bytes(Bs, P, M) - 256 - 2 * ksz) : nullptr;
+    p.bi.z2 = {reinterpret_cast<uint32_t *>(p.kpn), p.kpn ? Bs * (M + 2) : 0};  // key points per label
+    p.brute = (io->flags & (RPCC_FPS_BRUTEFORCE | RPCC_FPS_MODE_BITS)) != 0;   // a mode flag selects the reference kernel too
+    p.tiled = !p.brute && fps_tiling_range(g.H, g.W).T <= FPS_TILED_MAX_TILES;
+    return p;
+}
+// The launches of a batch in order, as stages: the three marked (*) are the kernels with one workgroup per frame or per label, which
+// rpcc_compress_batch_mixed runs as one launch over all groups (the others it runs group after group).
+enum { ST_PROJECT, ST_GROUND /* (*) */, ST_MASK, ST_FPS /* (*) */, ST_ASSIGN_LABELS, ST_PLANES /* (*) */, ST_QUANTISE, ST_COUNT };
+static int run_stage(const BatchPlan &p, int stage, hipStream_t st) {
+    const rpcc_batch_io *io = p.io;
+    const int Bs = p.Bs, M = p.M, P = p.P;
+    int rc;
+    switch (stage) {
+    case ST_PROJECT:
+        return launch_project(io->xyz, io->offsets, p.npts, 0, Bs, p.g, io->ri, p.proj_scratch, p.proj_bytes, st,
+                              p.rays_soa + 2 * (int64_t)P, p.zcnt, &p.bi, p.epoch, point_floats(io->point_stride_bytes));
+    case ST_GROUND:
+        if (!p.fit_ground) return RPCC_OK;
+        return launch_ground_ransac(io->ri, io->tm, Bs, P, (uint32_t)io->ground_seed, false, io->ground, nullptr, st, p.zcnt, io->frame_ids);
+    case ST_MASK:
+        return launch_ground_mask(io->ri, io->tm, io->ground, p.ground_threshold, Bs, p.g.H, p.g.W, p.temp, io->info,
+                                  p.tiled ? p.tiletab : nullptr, st, false, true);
+    case ST_FPS:
+        return launch_fps_range(io->ri, io->tm, p.temp, io->info, Bs, p.g.H, p.g.W, M, io->cen_pix, io->centers, io->flags, false,
+                                p.tiled ? p.tiletab : nullptr, io->timer, st, FPS_SOA ? p.rays_soa : nullptr);
+    case ST_ASSIGN_LABELS:
+        if ((rc = launch_assign(io->ri, io->tm, io->ground, io->centers, Bs, p.g.H, p.g.W, M, io->seg, st))) return rc;
+        if (io->model_method == 0) return launch_point_model(io->ri, io->seg, io->ground, Bs, P, M, io->model, io->counts, io->nnz, p.ws, st, true);
+        if ((rc = launch_label_scan(io->seg, Bs, P, M, io->counts, io->nnz, p.ws, st, true))) return rc;
+        return launch_label_order(io->ri, io->tm, io->seg, Bs, P, M, p.ws, p.extra, st);
+    case ST_PLANES:
+        if (io->model_method == 0) return RPCC_OK;
+        return launch_plane_fits(io->tm, io->ground, Bs, P, M, io->plane_cos_cut, (uint32_t)io->plane_seed, io->frame_ids, io->model,
+                                 io->counts, p.ws, p.extra, st);
+    case ST_QUANTISE:
+        if (io->nonuniform) {   // key points -> salience level and quantisation step per label
+            const rpcc_nonuniform_cfg *nu = io->nonuniform;
+            if ((rc = launch_features(io->ri, io->seg, Bs, p.g.H, p.g.W, nu->feature_region, nu->segments, nu->sharp_num, nu->less_sharp_num,
+                                      nu->flat_num, nullptr, io->key_point_map, st, p.kpn, M + 2)))
+                return rc;
+            SalienceParams sp;
+            for (int i = 0; i < 8; i++) { sp.level_kp_num[i] = i < nu->levels ? nu->level_kp_num[i] : 0; sp.level_acc[i] = i < nu->levels ? nu->level_acc[i] : 0.f; }
+            sp.levels = nu->levels;
+            sp.ground_level = nu->ground_level;
+            // levels from the per-label totals (pixels: the scan's counts; key points: counted by the key-point kernel)
+            salience_levels_kernel<<<Bs, 256, 0, st>>>(io->counts, p.kpn, M, sp, io->salience, p.label_acc);
+            LAUNCH_CHECK();
+        }
+        return launch_predict_quantize(io->ri, io->tm, io->seg, io->model, p.acc, p.label_acc, nullptr, Bs, P, M, io->q16,
+                                       nullptr, nullptr, p.ws, st, p.epoch);
     }
-    if (io->nonuniform) {   // key points -> salience level and quantisation step per label
-        const rpcc_nonuniform_cfg *nu = io->nonuniform;
-        if ((rc = launch_features(ri, io->seg, Bs, g.H, g.W, nu->feature_region, nu->segments, nu->sharp_num, nu->less_sharp_num,
-                                  nu->flat_num, nullptr, io->key_point_map, st, kpn, M + 2)))
-            return rc;
-        SalienceParams sp;
-        for (int i = 0; i < 8; i++) { sp.level_kp_num[i] = i < nu->levels ? nu->level_kp_num[i] : 0; sp.level_acc[i] = i < nu->levels ? nu->level_acc[i] : 0.f; }
-        sp.levels = nu->levels;
-        sp.ground_level = nu->ground_level;
-        // levels from the per-label totals (pixels: the scan's counts; key points: counted by the key-point kernel)
-        salience_levels_kernel<<<Bs, 256, 0, st>>>(io->counts, kpn, M, sp, io->salience, label_acc);
-        LAUNCH_CHECK();
-    }
-    return launch_predict_quantize(ri, io->tm, io->seg, io->model, acc, label_acc, nullptr, Bs, P, M, io->q16,
-                                   nullptr, nullptr, ws, st, epoch);
+    return RPCC_ERR_ARG;
 }
 
-extern "C" int rpcc_compress_batch(const rpcc_batch_io *io, int B, rpcc_geom g, int M, double ground_threshold,
-                                   float acc, void *ws, void *stream) {
+static int check_batch_io(const rpcc_batch_io *io, int B, rpcc_geom g, int M, const void *ws) {
     ARG_TRY(io != nullptr && ws != nullptr && B > 0 && B <= RPCC_MAX_BATCH && M > 0 && M <= RPCC_MAX_CLUSTERS && g.H > 1 && g.W > 0);
     ARG_TRY(io->offsets && io->tm && io->ground && io->ri && io->seg && io->cen_pix && io->centers && io->model &&
             io->counts && io->q16 && io->nnz && io->info);
@@ -2870,5 +2954,101 @@ extern "C" int rpcc_compress_batch(const rpcc_batch_io *io, int B, rpcc_geom g, 
         const rpcc_nonuniform_cfg *nu = io->nonuniform;
         ARG_TRY(io->salience && io->key_point_map && nu->levels >= 1 && nu->levels <= 8 && nu->ground_level >= 0 && nu->ground_level < nu->levels);
     }
-    return run_batch(io, B, io->total, g, M, ground_threshold, acc, reinterpret_cast<char *>(ws), (hipStream_t)stream);
+    return RPCC_OK;
+}
+
+extern "C" int rpcc_compress_batch(const rpcc_batch_io *io, int B, rpcc_geom g, int M, double ground_threshold,
+                                   float acc, void *ws, void *stream) {
+    int rc;
+    if ((rc = check_batch_io(io, B, g, M, ws))) return rc;
+    const BatchPlan p = plan_batch(io, B, io->total, g, M, ground_threshold, acc, reinterpret_cast<char *>(ws));
+    for (int stage = 0; stage < ST_COUNT; stage++)
+        if ((rc = run_stage(p, stage, (hipStream_t)stream))) return rc;
+    return RPCC_OK;
+}
+
+// ---- several geometry groups in one call ----------------------------------------------------------------------------------------
+// (*) stages as one launch over the groups that take the common kernel; a group that does not (injected ground, brute-force FPS or a
+// CUDA-binary mode, an image too large for the register-table FPS, the point model) runs that stage by itself.
+static int mixed_ground(const BatchPlan *pl, int G, hipStream_t st) {
+    RansacMulti m;
+    m.n = 0; m.first[0] = 0;
+    for (int i = 0; i < G; i++) {
+        if (!pl[i].fit_ground) continue;
+        const rpcc_batch_io *io = pl[i].io;
+        m.a[m.n] = {io->ri, io->tm, pl[i].P, (uint32_t)io->ground_seed, io->ground, pl[i].zcnt, io->frame_ids};
+        m.first[m.n + 1] = m.first[m.n] + pl[i].Bs;
+        m.n++;
+    }
+    if (m.n == 0) return RPCC_OK;
+    return launch_ground_ransac_multi(m, st);
+}
+static int mixed_fps(const BatchPlan *pl, int G, hipStream_t st) {
+    int rc, total = 0;
+    bool common[RPCC_MAX_GROUPS], edge[RPCC_MAX_GROUPS];
+    for (int i = 0; i < G; i++) {   // the planar register-table kernel (launch_fps_tiled's first branch)
+        const BatchPlan &p = pl[i];
+        const bool vec = (p.g.W % 4 == 0) && aligned16(p.io->ri) && aligned16(p.temp) && aligned16(p.io->tm);
+        edge[i] = !vec;
+        common[i] = p.tiled && p.P < (1 << 22) && FPS_SOA && p.io->timer == nullptr;
+        if (common[i]) total += p.Bs;
+    }
+    const int tt = total <= 128 ? FPS_TT_SMALL : FPS_TT_BATCH;
+    for (int i = 0; i < G; i++) common[i] = common[i] && fps_tiling_range(pl[i].g.H, pl[i].g.W).T <= tt;
+    FpsMulti m;
+    m.n = 0; m.first[0] = 0;
+    for (int i = 0; i < G; i++) {
+        if (!common[i]) continue;
+        const BatchPlan &p = pl[i];
+        m.a[m.n] = {p.io->ri, p.io->tm, p.temp, p.io->info, fps_tiling_range(p.g.H, p.g.W), p.io->cen_pix, p.io->centers, p.tiletab, p.rays_soa};
+        m.edge[m.n] = edge[i] ? 1 : 0;
+        m.first[m.n + 1] = m.first[m.n] + p.Bs;
+        m.n++;
+    }
+    if (m.n > 0) {
+        if (tt == FPS_TT_SMALL) fps_regtab_planar_multi_kernel<FPS_TT_SMALL><<<m.first[m.n], FPS_TT_SMALL, 0, st>>>(m, pl[0].M, 0);
+        else                    fps_regtab_planar_multi_kernel<FPS_TT_BATCH><<<m.first[m.n], FPS_TT_BATCH, 0, st>>>(m, pl[0].M, 0);
+        LAUNCH_CHECK();
+    }
+    for (int i = 0; i < G; i++)
+        if (!common[i] && (rc = run_stage(pl[i], ST_FPS, st))) return rc;
+    return RPCC_OK;
+}
+static int mixed_planes(const BatchPlan *pl, int G, hipStream_t st) {
+    PlaneMulti m;
+    m.n = 0; m.first[0] = 0;
+    const int M = pl[0].M, K = M + 2, wpg = PL_THREADS / 64, groups = (K + wpg - 1) / wpg;
+    for (int i = 0; i < G; i++) {
+        const BatchPlan &p = pl[i];
+        if (p.io->model_method == 0) continue;
+        m.a[m.n] = plane_group_args(p.io->tm, p.io->ground, p.Bs, p.P, M, p.io->plane_cos_cut, (uint32_t)p.io->plane_seed, p.io->frame_ids,
+                                    p.io->model, p.io->counts, p.ws, p.extra, nullptr);
+        m.first[m.n + 1] = m.first[m.n] + p.Bs * (K - 2) + p.Bs * groups;
+        m.n++;
+    }
+    if (m.n == 0) return RPCC_OK;
+    plane_model_multi_kernel<10><<<m.first[m.n], PL_THREADS, 0, st>>>(m, M, kpad(M), PL_BIG);
+    LAUNCH_CHECK();
+    return RPCC_OK;
+}
+
+extern "C" int rpcc_compress_batch_mixed(const rpcc_batch_io *ios, const int *Bs, const rpcc_geom *geoms, int G, int M,
+                                         double ground_threshold, float acc, void *const *wss, void *stream) {
+    ARG_TRY(ios != nullptr && Bs != nullptr && geoms != nullptr && wss != nullptr && G >= 1 && G <= RPCC_MAX_GROUPS);
+    int rc;
+    BatchPlan pl[RPCC_MAX_GROUPS];
+    for (int i = 0; i < G; i++) {
+        if ((rc = check_batch_io(&ios[i], Bs[i], geoms[i], M, wss[i]))) return rc;
+        pl[i] = plan_batch(&ios[i], Bs[i], ios[i].total, geoms[i], M, ground_threshold, acc, reinterpret_cast<char *>(wss[i]));
+    }
+    hipStream_t st = (hipStream_t)stream;
+    for (int stage = 0; stage < ST_COUNT; stage++) {
+        if (stage == ST_GROUND) rc = mixed_ground(pl, G, st);
+        else if (stage == ST_FPS) rc = mixed_fps(pl, G, st);
+        else if (stage == ST_PLANES) rc = mixed_planes(pl, G, st);
+        else
+            for (int i = 0; i < G && !(rc = run_stage(pl[i], stage, st)); i++) {}
+        if (rc) return rc;
+    }
+    return RPCC_OK;
 }

@@ -379,6 +379,16 @@ def compress_batch(xyz, offsets, tm, ground, buf, ground_threshold=0.1, acc=0.04
     salience levels (buf.salience) and per-label steps; None = uniform framework with step `acc`.
     fps_fma / fps_cuda_tie: the CUDA-binary FPS modes (_lib.fps_mode_flags); None = the environment variables RPCC_FPS_FMA
     (0 / 1 / 2) and RPCC_FPS_TIE_CUDA, so every front-end (tools, pipeline, loader) honours them."""
+    io = _batch_io(xyz, offsets, tm, ground, buf, ground_seed, frame_ids, fps_bruteforce, timer, model_method, angle_threshold, plane_seed,
+                   nonuniform, fps_fma, fps_cuda_tie)
+    check(_lib.lib().rpcc_compress_batch(C.byref(io), buf.B, buf.geom, buf.M, float(ground_threshold), float(acc),
+                                         ptr(buf.ws), stream()))
+    return buf
+
+
+def _batch_io(xyz, offsets, tm, ground, buf, ground_seed=-1, frame_ids=None, fps_bruteforce=False, timer=None, model_method="point",
+              angle_threshold=75, plane_seed=0, nonuniform=None, fps_fma=None, fps_cuda_tie=None):
+    """The rpcc_batch_io of one geometry group (compress_batch's arguments); grows the group's workspace when the batch holds more points."""
     general = model_method != "point" or nonuniform is not None
     assert not general or buf.general, "BatchBuffers(..., general=True) is needed for the plane model / non-uniform framework"
     if xyz.shape[0] > buf.max_points:
@@ -387,20 +397,35 @@ def compress_batch(xyz, offsets, tm, ground, buf, ground_threshold=0.1, acc=0.04
     fid = _frame_ids(frame_ids, buf.B, xyz.device)
     buf._frame_ids = fid          # keep the tensor alive until the stream has consumed it
     buf._nonuniform = nonuniform  # (host struct read during the call only; kept for symmetry)
-    io = BatchIO(ptr(xyz).value, ptr(offsets).value, int(xyz.shape[0]), ptr(tm).value, ptr(ground).value,
-                 int(ground_seed), ptr(fid).value if fid is not None else None, ptr(buf.ri).value, ptr(buf.seg).value,
-                 ptr(buf.cen_pix).value, ptr(buf.centers).value, ptr(buf.model).value, ptr(buf.counts).value,
-                 ptr(buf.q16).value, ptr(buf.nnz).value, ptr(buf.info).value,
-                 (_lib.FPS_BRUTEFORCE if fps_bruteforce else 0) | _lib.fps_mode_flags(fps_fma, fps_cuda_tie),
-                 timer.h if timer is not None else None,
-                 0 if model_method == "point" else 1, angle_cos_cut(angle_threshold) if model_method != "point" else 0.0,
-                 int(plane_seed), C.addressof(nonuniform) if nonuniform is not None else None,
-                 ptr(buf.salience).value if nonuniform is not None else None,
-                 ptr(buf.key_point_map).value if nonuniform is not None else None,
-                 _point_stride(xyz))
-    check(_lib.lib().rpcc_compress_batch(C.byref(io), buf.B, buf.geom, buf.M, float(ground_threshold), float(acc),
-                                         ptr(buf.ws), stream()))
-    return buf
+    return BatchIO(ptr(xyz).value, ptr(offsets).value, int(xyz.shape[0]), ptr(tm).value, ptr(ground).value,
+                   int(ground_seed), ptr(fid).value if fid is not None else None, ptr(buf.ri).value, ptr(buf.seg).value,
+                   ptr(buf.cen_pix).value, ptr(buf.centers).value, ptr(buf.model).value, ptr(buf.counts).value,
+                   ptr(buf.q16).value, ptr(buf.nnz).value, ptr(buf.info).value,
+                   (_lib.FPS_BRUTEFORCE if fps_bruteforce else 0) | _lib.fps_mode_flags(fps_fma, fps_cuda_tie),
+                   timer.h if timer is not None else None,
+                   0 if model_method == "point" else 1, angle_cos_cut(angle_threshold) if model_method != "point" else 0.0,
+                   int(plane_seed), C.addressof(nonuniform) if nonuniform is not None else None,
+                   ptr(buf.salience).value if nonuniform is not None else None,
+                   ptr(buf.key_point_map).value if nonuniform is not None else None,
+                   _point_stride(xyz))
+
+
+def compress_batch_mixed(groups, ground_threshold=0.1, acc=0.04):
+    """Fused a2..a13 for a batch that holds sweeps of several lidar geometries (variable H x W: BASELINE configs[4]), one call on the
+    current stream.  groups: one dict per geometry with compress_batch's arguments (xyz, offsets, tm, ground, buf and, optionally,
+    ground_seed, frame_ids, model_method, angle_threshold, plane_seed, nonuniform, fps_bruteforce, fps_fma, fps_cuda_tie); every buf is
+    a BatchBuffers of that geometry with the same cluster count.  The kernels with one workgroup per frame or label (ground RANSAC,
+    FPS, plane fits) run once over all groups (include/rpcc_hip.h: rpcc_compress_batch_mixed).  -> the list of the groups' buffers."""
+    G = len(groups)
+    assert 1 <= G <= _lib.MAX_GROUPS, "at most %d geometry groups per call" % _lib.MAX_GROUPS
+    M = groups[0]["buf"].M
+    assert all(g["buf"].M == M for g in groups), "one cluster count per call"
+    ios = (BatchIO * G)(*[_batch_io(**g) for g in groups])
+    Bs = (C.c_int * G)(*[g["buf"].B for g in groups])
+    geoms = (_lib.Geom * G)(*[g["buf"].geom for g in groups])
+    wss = (C.c_void_p * G)(*[ptr(g["buf"].ws).value for g in groups])
+    check(_lib.lib().rpcc_compress_batch_mixed(ios, Bs, geoms, G, M, float(ground_threshold), float(acc), wss, stream()))
+    return [g["buf"] for g in groups]
 
 
 @functools.lru_cache(maxsize=64)

@@ -35,36 +35,53 @@ class BatchCompressor:
             self._codec_ws = ops.codec_workspace(B, self.T.H * self.T.W, self.M, self.device)
         return self._buf
 
-    def compress_device(self, xyz, offsets, ground=None, frame_ids=None):
-        """Device part.  xyz f32 [sum N,3], offsets i64 [B+1] on the device.  Returns the BatchBuffers plus
-        contour bits / index sequences (and salience for the non-uniform framework), all still in HBM.
-        frame_ids: stable identities of the frames (utils.frame_identity) for the seeded plane fits."""
+    def _group_args(self, xyz, offsets, ground=None, frame_ids=None):
+        """ops.compress_batch's arguments for this compressor's settings (one geometry group of ops.compress_batch_mixed)."""
         B = offsets.numel() - 1
         buf = self._buffers(B)
         fit = ground is None
         g = torch.zeros((B, 4), dtype=torch.float64, device=self.device) if fit else ground
         # one fused call for all four framework / model combinations (tools/compress.py:109-124)
         nu = None if self.uniform else ops.nonuniform_cfg(self.acc, self.cfg)
-        ops.compress_batch(xyz, offsets, self.T.tm_dev, g, buf, self.ground_threshold, self.acc,
-                           ground_seed=self.seed if fit else -1, frame_ids=frame_ids, model_method=self.model_method,
-                           angle_threshold=self.cfg.get("plane_angle_threshold", 75), plane_seed=self.seed, nonuniform=nu)
+        return dict(xyz=xyz, offsets=offsets, tm=self.T.tm_dev, ground=g, buf=buf, ground_seed=self.seed if fit else -1, frame_ids=frame_ids,
+                    model_method=self.model_method, angle_threshold=self.cfg.get("plane_angle_threshold", 75), plane_seed=self.seed, nonuniform=nu)
+
+    def _encode(self, args):
+        """Contour bits / index sequences of the segmentation a fused call left in args["buf"]."""
+        buf = args["buf"]
         sal = None if self.uniform else buf.salience
         bits, seq, nseq = ops.contour_encode(buf.seg, self.M, ws=self._codec_ws)
-        return buf, g, bits, seq, nseq, sal
+        return buf, args["ground"], bits, seq, nseq, sal
 
-    def submit(self, frames, ground=None, frame_ids=None):
-        """Device part of compress() on the current stream, nothing waited for.  -> a context for collect()."""
+    def compress_device(self, xyz, offsets, ground=None, frame_ids=None):
+        """Device part.  xyz f32 [sum N,3], offsets i64 [B+1] on the device.  Returns the BatchBuffers plus
+        contour bits / index sequences (and salience for the non-uniform framework), all still in HBM.
+        frame_ids: stable identities of the frames (utils.frame_identity) for the seeded plane fits."""
+        args = self._group_args(xyz, offsets, ground, frame_ids)
+        ops.compress_batch(ground_threshold=self.ground_threshold, acc=self.acc, **args)
+        return self._encode(args)
+
+    def _upload(self, frames, ground=None):
+        """Host arrays of a batch -> device (xyz, offsets, ground or None) on the current stream."""
         offs = np.zeros(len(frames) + 1, np.int64)
         offs[1:] = np.cumsum([f.shape[0] for f in frames])
         xyz = torch.from_numpy(np.ascontiguousarray(np.concatenate([f[:, :3] for f in frames]), dtype=np.float32)).to(self.device)
         gnd = None if ground is None else torch.from_numpy(np.asarray(ground, np.float64).reshape(-1, 4)).to(self.device)
-        buf, g, bits, seq, nseq, sal = self.compress_device(xyz, torch.from_numpy(offs).to(self.device), gnd, frame_ids)
-        # the two variable-length 16-bit streams leave the device with the frames back to back (rpcc_pack_payload), not
-        # as the padded [B,P] arrays: nnz <= points of the frame, one index per contour start <= pixels
-        qp, qtot = ops.pack_payload(buf.q16, buf.nnz, capacity=int(offs[-1]))
+        return xyz, torch.from_numpy(offs).to(self.device), gnd, int(offs[-1])
+
+    def _payload(self, n, npts, xyz, dev_out):
+        """The two variable-length 16-bit streams leave the device with the frames back to back (rpcc_pack_payload), not as the padded
+        [B,P] arrays: nnz <= points of the frame, one index per contour start <= pixels.  -> the context collect() takes."""
+        buf, g, bits, seq, nseq, sal = dev_out
+        qp, qtot = ops.pack_payload(buf.q16, buf.nnz, capacity=npts)
         sp, stot = ops.pack_payload(seq.view(torch.int16), nseq)
-        return dict(n=len(frames), buf=buf, bits=bits, nseq=nseq, sal=sal, qp=qp, qtot=qtot, sp=sp, stot=stot,
+        return dict(n=n, buf=buf, bits=bits, nseq=nseq, sal=sal, qp=qp, qtot=qtot, sp=sp, stot=stot,
                     stream=torch.cuda.current_stream(self.device), keep=(xyz, g, seq))
+
+    def submit(self, frames, ground=None, frame_ids=None):
+        """Device part of compress() on the current stream, nothing waited for.  -> a context for collect()."""
+        xyz, offs, gnd, npts = self._upload(frames, ground)
+        return self._payload(len(frames), npts, xyz, self.compress_device(xyz, offs, gnd, frame_ids))
 
     def collect(self, ctx, pool=None):
         """Waits for submit()'s stream and assembles the .rpcc byte strings (host part: casts, container, entropy coder).
@@ -101,29 +118,45 @@ class BatchCompressor:
 
 
 class MixedBatchCompressor:
-    """BASELINE configs[4]: one batch holding sweeps of several lidar geometries (variable H x W).  The frames are grouped
-    by geometry, every group runs as its own batch on its own HIP stream -- the small images are latency-bound (one
-    workgroup per frame in FPS / RANSAC), so the groups overlap -- and the results come back in input order.
+    """BASELINE configs[4]: one batch holding sweeps of several lidar geometries (variable H x W).  The frames are grouped by
+    geometry and the groups go through ONE fused call (ops.compress_batch_mixed / rpcc_compress_batch_mixed): the kernels with one
+    workgroup per frame or per label -- ground RANSAC, FPS, plane fits: latency-bound whatever the image size -- run once over all
+    groups, the pixel-parallel ones group after group; the results come back in input order.  (Until round 4 every group ran as its
+    own chain of launches on its own stream: the device runs three or four kernels side by side, so three chains of small
+    launches left most of it idle -- profiles/HISTORY.md.)
     transformers: {lidar name: PCTransformer}; the other arguments are BatchCompressor's."""
 
-    SLOTS = 1      # mixed batches in flight of the streaming form (submit / collect); bench.py's secondary measures it
+    SLOTS = 4      # mixed batches in flight of the streaming form (submit / collect on SLOTS streams); bench.py's secondary measures it
 
     def __init__(self, transformers, **kw):
         self.bcs = {name: BatchCompressor(t, **kw) for name, t in transformers.items()}
-        dev = next(iter(self.bcs.values())).device
-        self.streams = {name: torch.cuda.Stream(device=dev) for name in self.bcs}
+        first = next(iter(self.bcs.values()))
+        self.device, self.ground_threshold, self.acc = first.device, first.ground_threshold, first.acc
 
-    def compress(self, frames, lidars):
-        """frames: list of [N,3] arrays; lidars: the lidar name of every frame.  -> list of .rpcc byte strings."""
+    def compress_device(self, parts):
+        """parts: {lidar name: (xyz, offsets, ground or None, frame_ids or None)} on the device.  One fused call on the current stream
+        -> {lidar name: what BatchCompressor.compress_device returns}."""
+        args = {name: self.bcs[name]._group_args(*part) for name, part in parts.items()}
+        ops.compress_batch_mixed(list(args.values()), ground_threshold=self.ground_threshold, acc=self.acc)
+        return {name: self.bcs[name]._encode(a) for name, a in args.items()}
+
+    def submit(self, frames, lidars):
+        """Device part of compress() on the current stream, nothing waited for.  -> a context for collect()."""
         groups = {}
         for i, name in enumerate(lidars):
             groups.setdefault(name, []).append(i)
-        ctxs = {}
-        for name, idx in groups.items():                       # all device work is queued before anything is waited for
-            with torch.cuda.stream(self.streams[name]):
-                ctxs[name] = self.bcs[name].submit([frames[i] for i in idx])
-        out = [None] * len(frames)
-        for name, idx in groups.items():
-            for i, blob in zip(idx, self.bcs[name].collect(ctxs[name])):
+        up = {name: self.bcs[name]._upload([frames[i] for i in idx]) for name, idx in groups.items()}
+        outs = self.compress_device({name: (xyz, offs, gnd, None) for name, (xyz, offs, gnd, _) in up.items()})
+        ctxs = {name: self.bcs[name]._payload(len(groups[name]), up[name][3], up[name][0], outs[name]) for name in groups}
+        return dict(n=len(frames), groups=groups, ctxs=ctxs)
+
+    def collect(self, ctx, pool=None):
+        out = [None] * ctx["n"]
+        for name, idx in ctx["groups"].items():
+            for i, blob in zip(idx, self.bcs[name].collect(ctx["ctxs"][name], pool=pool)):
                 out[i] = blob
         return out
+
+    def compress(self, frames, lidars):
+        """frames: list of [N,3] arrays; lidars: the lidar name of every frame.  -> list of .rpcc byte strings."""
+        return self.collect(self.submit(frames, lidars))

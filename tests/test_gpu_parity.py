@@ -1156,3 +1156,73 @@ def test_plane_model_large_labels(env, angle):
         assert not (exp[1:, :3] != 0).any()
     else:
         assert (exp[:, :3] != 0).any(1).sum() > 5
+
+
+def _mixed_groups(env, specs, M=100):
+    """specs: [(lidar name, frames, keyword overrides)] -> (list of compress_batch argument dicts on fresh buffers, frame lists)."""
+    torch, ops, orc, synth = env["torch"], env["ops"], env["orc"], env["synth"]
+    groups = []
+    for k, (name, n, over) in enumerate(specs):
+        g, geom, tm = _geom(env, name)
+        gd = orc.GEOMS[name]
+        frames = [synth.make_frame(5100 + 31 * k + i, g.H, g.W, vmax_deg=gd["vmax_deg"], vmin_deg=gd["vmin_deg"]).numpy() for i in range(n)]
+        offs = np.zeros(n + 1, np.int64)
+        offs[1:] = np.cumsum([f.shape[0] for f in frames])
+        general = over.get("model_method", "point") != "point" or over.get("nonuniform") is not None
+        a = dict(xyz=_to(env, np.concatenate(frames)), offsets=_to(env, offs), tm=_to(env, tm),
+                 ground=torch.zeros((n, 4), dtype=torch.float64, device=env["dev"]), buf=ops.BatchBuffers(n, geom, M, env["dev"], general=general),
+                 ground_seed=70 + k, frame_ids=_to(env, np.arange(900 + 10 * k, 900 + 10 * k + n, dtype=np.int64)))
+        a.update(over)
+        if a["ground_seed"] < 0:      # injected ground models
+            a["ground"] = _to(env, np.tile(np.array([[0.01, -0.02, 1.0, 1.7]]), (n, 1)))
+        groups.append(a)
+    return groups
+
+
+_MIXED_CASES = {
+    "uniform_point": lambda ops: [("Velodyne64E", 3, {}), ("Velodyne32E", 2, {}), ("VelodyneVLP16", 4, {})],
+    "nonuniform_plane": lambda ops: [(n, b, dict(model_method="plane", plane_seed=5, nonuniform=ops.nonuniform_cfg(0.04)))
+                                     for n, b in (("VelodyneVLP16", 3), ("Velodyne64E", 2), ("Velodyne32E", 3))],
+    # groups that differ in everything a group may differ in: injected ground, the brute-force FPS kernel, a CUDA-binary FPS mode, model, framework
+    "every_group_different": lambda ops: [("Velodyne32E", 2, dict(ground_seed=-1)), ("VelodyneVLP16", 3, dict(fps_bruteforce=True, model_method="plane")),
+                                          ("Velodyne64E", 2, dict(nonuniform=ops.nonuniform_cfg(0.04))), ("VelodyneVLP16", 2, dict(fps_fma=1))],
+    "one_group": lambda ops: [("Velodyne32E", 3, dict(model_method="plane"))],
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", sorted(_MIXED_CASES))
+def test_compress_batch_mixed_equals_the_groups_alone(env, case):
+    """rpcc_compress_batch_mixed (variable H x W inside one call; the ground RANSAC, FPS and plane-fit launches shared by the groups):
+    every output buffer of every group is bit for bit what rpcc_compress_batch gives for that group alone -- which the tests above
+    hold to the oracle -- for the uniform / point and non-uniform / plane paths, for groups whose settings differ, and for one group."""
+    torch, ops = env["torch"], env["ops"]
+    specs = _MIXED_CASES[case](ops)
+    alone = _mixed_groups(env, specs)
+    for a in alone:
+        ops.compress_batch(**a)
+    mixed = _mixed_groups(env, specs)
+    ops.compress_batch_mixed(mixed)
+    torch.cuda.synchronize()
+    for k, (a, m) in enumerate(zip(alone, mixed)):
+        ba, bm = a["buf"], m["buf"]
+        assert _beq(a["ground"].cpu().numpy(), m["ground"].cpu().numpy()), (case, k)
+        for f in ("ri", "seg", "cen_pix", "centers", "model", "counts", "nnz"):
+            assert _beq(getattr(ba, f).cpu().numpy(), getattr(bm, f).cpu().numpy()), (case, k, f)
+        nz = ba.nnz.cpu().numpy()
+        qa, qm = ba.q16.cpu().numpy(), bm.q16.cpu().numpy()
+        assert all(np.array_equal(qa[i, :nz[i]], qm[i, :nz[i]]) for i in range(ba.B)), (case, k)
+        if a.get("nonuniform") is not None:
+            assert np.array_equal(ba.salience.cpu().numpy(), bm.salience.cpu().numpy()) and np.array_equal(ba.key_point_map.cpu().numpy(), bm.key_point_map.cpu().numpy())
+
+
+@pytest.mark.gpu
+def test_compress_batch_mixed_argument_errors(env):
+    """More groups than RPCC_MAX_GROUPS, differing cluster counts and a missing output buffer are refused before anything is launched."""
+    ops = env["ops"]
+    g5 = _mixed_groups(env, [("VelodyneVLP16", 1, {})] * 5)
+    with pytest.raises(AssertionError):
+        ops.compress_batch_mixed(g5)
+    two = _mixed_groups(env, [("VelodyneVLP16", 1, {})]) + _mixed_groups(env, [("VelodyneVLP16", 1, {})], M=50)
+    with pytest.raises(AssertionError):
+        ops.compress_batch_mixed(two)

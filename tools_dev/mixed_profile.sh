@@ -6,7 +6,7 @@ cat > /tmp/mx/run.py <<'PY'
 import os, sys, types, torch
 sys.path.insert(0, os.getcwd())
 import rpcc_amd, bench
-r = bench.run_mixed(types.SimpleNamespace(accuracy=0.02), dict(dev=torch.device("cuda:0")), per=int(sys.argv[1]), reps=12, slots=1)
+r = bench.run_mixed(types.SimpleNamespace(accuracy=0.02), dict(dev=torch.device("cuda:0")), per=int(sys.argv[1]), reps=12, slots=int(os.environ.get("SLOTS", "1")))
 print(r["value"], r["ms_per_mixed_batch"])
 PY
 for per in 85 256; do
