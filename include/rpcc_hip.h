@@ -314,7 +314,7 @@ int rpcc_compress_batch(const rpcc_batch_io *io, int B, rpcc_geom g, int M, doub
 
 /* The same for a batch that holds sweeps of several lidar geometries (variable H x W inside one call: BASELINE configs[4]; the
  * reference compresses such a list frame by frame with one dataset / transformer per lidar, tools/compress_datalist.py:160-206,
- * dataset/lidar_cfg/*.yaml).  The frames are grouped by geometry: group i = ios[i] (its own buffers, laid out for Bs[i] frames of
+ * the YAML files of dataset/lidar_cfg).  The frames are grouped by geometry: group i = ios[i] (its own buffers, laid out for Bs[i] frames of
  * geoms[i], exactly as for rpcc_compress_batch), workspace wss[i] of rpcc_workspace_bytes[_general](Bs[i], P_i, M, total_i) bytes.
  * Everything is queued on `stream`; the kernels with one workgroup per frame or per label (ground RANSAC, FPS, plane fits) run
  * as ONE launch over the frames of all groups, the pixel-parallel kernels group after group.  Results per group are what

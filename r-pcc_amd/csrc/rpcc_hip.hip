@@ -2166,6 +2166,132 @@ extern "C" size_t rpcc_workspace_bytes_general(int B, int P, int M, int64_t tota
     return slice_workspace_bytes(B, P, M, total_points) + 4096 + plane_extra_bytes(B, P, M);
 }
 
+// Round 3: thread k walks label k's column of the tile x label table straight from global memory (the loads of consecutive
+// threads are consecutive words; SCAN_U tiles' loads in flight per thread) in two passes -- totals, then offsets with the label's
+// base added -- instead of staging the table in LDS (64 KB per workgroup for 64x2048: its footprint kept everything else off
+// the CU, and the 128 dependent LDS round trips of the in-LDS scan were most of the kernel's time).
+#define SCAN_U 32
+#define SCAN_THREADS 512
+// Thread (g, k): label k of tile group g.  The SCAN_THREADS threads form NG = SCAN_THREADS / KP2 groups (KP2 = K rounded up to a
+// power of two: 4 groups for 102 labels), a group owns T / NG consecutive tiles; with at most SCAN_U tiles per group (128 tiles, 4
+// groups) a thread's counts stay in registers between the totals and the offsets: ONE trip to memory per thread instead of eight
+// dependent ones (12.8 -> 10.2 us alone; this kernel sits on every batch's chain between the histogram and the quantiser).
+struct ScanArgs {
+    const float *ri;
+    const uint8_t *seg;
+    const double *ground;
+    int P, M, KP, T, KP2;
+    const int64_t *sums;
+    const int32_t *flags;
+    uint32_t *hist;
+    float *model;
+    int32_t *counts, *nnz;
+};
+__global__ __launch_bounds__(SCAN_THREADS) void model_scan_kernel(const ScanArgs A) {
+    const int b = blockIdx.x;
+    const float *__restrict__ ri = A.ri;
+    const uint8_t *__restrict__ seg = A.seg;
+    const double *__restrict__ ground = A.ground;
+    const int P = A.P, M = A.M, KP = A.KP, T = A.T, KP2 = A.KP2;
+    const int64_t *__restrict__ sums = A.sums;
+    const int32_t *__restrict__ flags = A.flags;
+    uint32_t *__restrict__ hist = A.hist;
+    float *__restrict__ model = A.model;
+    int32_t *__restrict__ counts = A.counts, *__restrict__ nnz = A.nnz;
+    __shared__ uint32_t gtot[SCAN_THREADS];   // [group][KP2] counts of a label in a tile group
+    __shared__ uint32_t base[256];
+    __shared__ uint32_t wsum[4];
+    const int K = M + 2;
+    const int NG = SCAN_THREADS / KP2, k = threadIdx.x & (KP2 - 1), grp = threadIdx.x / KP2;
+    const int TG = (T + NG - 1) / NG, tbeg = grp * TG, tend = min(T, tbeg + TG);
+    uint32_t *gh = hist + (int64_t)b * T * KP;
+    const uint32_t kp4 = (uint32_t)KP * 4u, k4 = (uint32_t)k * 4u;
+    const bool held = TG <= SCAN_U;   // (workgroup-uniform)
+    uint32_t c[SCAN_U];
+    uint32_t part = 0;
+    if (k < K) {
+        if (held) {
+#pragma unroll
+            for (int j = 0; j < SCAN_U; j++) c[j] = ld_at(gh, (uint32_t)min(tbeg + j, T - 1) * kp4 + k4);   // unconditional (clamped) loads
+#pragma unroll
+            for (int j = 0; j < SCAN_U; j++) { if (tbeg + j >= tend) c[j] = 0u; part += c[j]; }
+        } else {
+            for (int t0 = tbeg; t0 < tend; t0 += SCAN_U) {
+                uint32_t d[SCAN_U];
+#pragma unroll
+                for (int j = 0; j < SCAN_U; j++) d[j] = ld_at(gh, (uint32_t)min(t0 + j, T - 1) * kp4 + k4);
+#pragma unroll
+                for (int j = 0; j < SCAN_U; j++) part += t0 + j < tend ? d[j] : 0u;
+            }
+        }
+    }
+    gtot[grp * KP2 + k] = k < K ? part : 0u;
+    __syncthreads();
+    // label totals, then their exclusive prefix (label 1 = empty pixels has no residuals): DPP scans of the first 256 threads
+    uint32_t total = 0;
+    for (int g2 = 0; g2 < NG; g2++) total += gtot[g2 * KP2 + k];
+    {
+        const int kk = threadIdx.x;   // label kk for the prefix (threads 0 .. 255)
+        uint32_t v = 0u;
+        if (kk < 256 && kk < K && kk != 1) { for (int g2 = 0; g2 < NG; g2++) v += gtot[g2 * KP2 + kk]; }
+        const uint32_t incl = dpp_scan_incl_u32(v);
+        if (kk < 256 && (kk & 63) == 63) wsum[kk >> 6] = incl;
+        __syncthreads();
+        if (kk < 256) {
+            uint32_t off = 0u;
+            for (int w = 0; w < (kk >> 6); w++) off += wsum[w];
+            base[kk] = off + incl - v;
+            if (kk == 255 && nnz) nnz[b] = (int32_t)(off + incl);
+        }
+    }
+    __syncthreads();
+    if (k < K) {
+        uint32_t run = base[k];   // exclusive prefix over tiles, seeded with the label's base and the groups before
+        for (int g2 = 0; g2 < grp; g2++) run += gtot[g2 * KP2 + k];
+        if (held) {
+#pragma unroll
+            for (int j = 0; j < SCAN_U; j++) {
+                if (tbeg + j < tend) { st_at(gh, (uint32_t)(tbeg + j) * kp4 + k4, run); run += c[j]; }
+            }
+        } else {
+            for (int t0 = tbeg; t0 < tend; t0 += SCAN_U) {
+                uint32_t d[SCAN_U];
+#pragma unroll
+                for (int j = 0; j < SCAN_U; j++) d[j] = ld_at(gh, (uint32_t)min(t0 + j, T - 1) * kp4 + k4);
+#pragma unroll
+                for (int j = 0; j < SCAN_U; j++) {
+                    if (t0 + j < tend) { st_at(gh, (uint32_t)(t0 + j) * kp4 + k4, run); run += d[j]; }
+                }
+            }
+        }
+        if (counts && grp == 0) counts[(int64_t)b * K + k] = (int32_t)total;
+    }
+    if (k < K && grp == 0 && model != nullptr) {
+        float *row = model + ((int64_t)b * K + k) * 4;
+        if (k == 0) {
+            row[0] = (float)ground[4 * b]; row[1] = (float)ground[4 * b + 1];
+            row[2] = (float)ground[4 * b + 2]; row[3] = (float)ground[4 * b + 3];
+        } else if (k == 1) {
+            row[0] = row[1] = row[2] = row[3] = 0.0f;
+        } else {
+            double s;
+            if (flags[4 * b]) {
+                // exact sequential double accumulation in row-major order (cpp_modules.cpp:514) for frames
+                // whose ranges fall outside the fixed-point window; one thread per label, rare.
+                s = 0.0;
+                const uint8_t *sg = seg + (int64_t)b * P;
+                const float *rr = ri + (int64_t)b * P;
+                for (int p = 0; p < P; p++)
+                    if (sg[p] == k) s += (double)rr[p];
+            } else {
+                s = (double)sums[(int64_t)b * KP + k] * (1.0 / 268435456.0);  // exact: sum < 2^53 units
+            }
+            const double n = (double)total;
+            row[0] = row[1] = row[2] = 0.0f;
+            row[3] = (total == 0) ? u2f(0xFFC00000u) : (float)(s / n);  // 0.0/0 on x86 = default NaN
+        }
+    }
+}
 // A lane owns FOUR CONSECUTIVE pixels of the tile (VEC: one 4-byte load of labels, one 16-byte load of ranges), a wavefront
 // 256 consecutive pixels.  Labels are spatially coherent, so the pixels that carry the label of the wavefront's first pixel
 // -- usually most of the 256 -- are aggregated once per wavefront (four compare masks counted in scalar registers, two DPP
@@ -2272,138 +2398,31 @@ __global__ __launch_bounds__(256) void model_hist_kernel(const float *__restrict
         if (ssum[k]) atomicAdd(reinterpret_cast<unsigned long long *>(&sums[(int64_t)b * KP + k]), ssum[k]);
     }
 }
-static void launch_model_hist(const float *ri, const uint8_t *seg, int B, int P, int KP, int T, int64_t *sums, int32_t *flags,
-                              uint32_t *hist, hipStream_t st) {
+static inline int scan_kp2(int M) { int v = 1; while (v < M + 2) v <<= 1; return v; }   // labels rounded up to a power of two (<= 256)
+// histogram + scan: tile x label counts (and the labels' range sums when ri is given), then the offsets of the ordered scatter, counts, nnz and
+// -- with `model` -- the point model's rows.  The sums / flags block must be zero (memset or BatchInit).
+static int launch_hist_scan(const float *ri, const uint8_t *seg, const double *ground, int B, int P, int M, const WsLayout &L, float *model,
+                            int32_t *counts, int32_t *nnz, hipStream_t st) {
+    const int KP = kpad(M), T = ntiles(P);
     const bool vec = (P & 3) == 0 && ((uintptr_t)seg & 3u) == 0 && (ri == nullptr || ((uintptr_t)ri & 15u) == 0);
-    if (vec) model_hist_kernel<true><<<dim3(T, B), 256, (size_t)KP * 12, st>>>(ri, seg, P, KP, T, sums, flags, hist);
-    else     model_hist_kernel<false><<<dim3(T, B), 256, (size_t)KP * 12, st>>>(ri, seg, P, KP, T, sums, flags, hist);
+    const ScanArgs sa = {ri, seg, ground, P, M, KP, T, scan_kp2(M), L.sums, L.flags, L.hist, model, counts, nnz};
+    // (The scan as the tail of the histogram kernel -- the frame's last workgroup to finish runs it -- was measured in round 4: a workgroup must
+    // release its rows device-wide before it draws its ticket, and an agent-scope fence writes the XCD's L2 back: 62 us -> 2.9 ms.)
+    if (vec) model_hist_kernel<true><<<dim3(T, B), 256, (size_t)KP * 12, st>>>(ri, seg, P, KP, T, L.sums, L.flags, L.hist);
+    else     model_hist_kernel<false><<<dim3(T, B), 256, (size_t)KP * 12, st>>>(ri, seg, P, KP, T, L.sums, L.flags, L.hist);
+    LAUNCH_CHECK();
+    model_scan_kernel<<<B, SCAN_THREADS, 0, st>>>(sa);
+    LAUNCH_CHECK();
+    return RPCC_OK;
 }
 
 // One workgroup per frame: label totals, tile offsets, label bases, means, model rows.
-// Round 3: thread k walks label k's column of the tile x label table straight from global memory (the loads of consecutive
-// threads are consecutive words; SCAN_U tiles' loads in flight per thread) in two passes -- totals, then offsets with the label's
-// base added -- instead of staging the table in LDS (64 KB per workgroup for 64x2048: its footprint kept everything else off
-// the CU, and the 128 dependent LDS round trips of the in-LDS scan were most of the kernel's time).
-#define SCAN_U 32
-#define SCAN_THREADS 512
-// Thread (g, k): label k of tile group g.  The SCAN_THREADS threads form NG = SCAN_THREADS / KP2 groups (KP2 = K rounded up to a
-// power of two: 4 groups for 102 labels), a group owns T / NG consecutive tiles; with at most SCAN_U tiles per group (128 tiles, 4
-// groups) a thread's counts stay in registers between the totals and the offsets: ONE trip to memory per thread instead of eight
-// dependent ones (12.8 -> 10.2 us alone; this kernel sits on every batch's chain between the histogram and the quantiser).
-__global__ __launch_bounds__(SCAN_THREADS) void model_scan_kernel(const float *__restrict__ ri, const uint8_t *__restrict__ seg,
-                                                         const double *__restrict__ ground, int P, int M, int KP, int T, int KP2,
-                                                         const int64_t *__restrict__ sums,
-                                                         const int32_t *__restrict__ flags, uint32_t *__restrict__ hist,
-                                                         float *__restrict__ model, int32_t *__restrict__ counts,
-                                                         int32_t *__restrict__ nnz) {
-    __shared__ uint32_t gtot[SCAN_THREADS];   // [group][KP2] counts of a label in a tile group
-    __shared__ uint32_t tot[256];
-    __shared__ uint32_t base[256];
-    __shared__ uint32_t wsum[4];
-    const int b = blockIdx.x, K = M + 2;
-    const int NG = SCAN_THREADS / KP2, k = threadIdx.x & (KP2 - 1), grp = threadIdx.x / KP2;
-    const int TG = (T + NG - 1) / NG, tbeg = grp * TG, tend = min(T, tbeg + TG);
-    uint32_t *gh = hist + (int64_t)b * T * KP;
-    const uint32_t kp4 = (uint32_t)KP * 4u, k4 = (uint32_t)k * 4u;
-    const bool held = TG <= SCAN_U;   // (workgroup-uniform)
-    uint32_t c[SCAN_U];
-    uint32_t part = 0;
-    if (k < K) {
-        if (held) {
-#pragma unroll
-            for (int j = 0; j < SCAN_U; j++) c[j] = ld_at(gh, (uint32_t)min(tbeg + j, T - 1) * kp4 + k4);   // unconditional (clamped) loads
-#pragma unroll
-            for (int j = 0; j < SCAN_U; j++) { if (tbeg + j >= tend) c[j] = 0u; part += c[j]; }
-        } else {
-            for (int t0 = tbeg; t0 < tend; t0 += SCAN_U) {
-                uint32_t d[SCAN_U];
-#pragma unroll
-                for (int j = 0; j < SCAN_U; j++) d[j] = ld_at(gh, (uint32_t)min(t0 + j, T - 1) * kp4 + k4);
-#pragma unroll
-                for (int j = 0; j < SCAN_U; j++) part += t0 + j < tend ? d[j] : 0u;
-            }
-        }
-    }
-    gtot[grp * KP2 + k] = k < K ? part : 0u;
-    __syncthreads();
-    // label totals, then their exclusive prefix (label 1 = empty pixels has no residuals): DPP scans of the first 256 threads
-    uint32_t total = 0;
-    for (int g2 = 0; g2 < NG; g2++) total += gtot[g2 * KP2 + k];
-    {
-        const int kk = threadIdx.x;   // label kk for the prefix (threads 0 .. 255)
-        uint32_t v = 0u;
-        if (kk < 256 && kk < K && kk != 1) { for (int g2 = 0; g2 < NG; g2++) v += gtot[g2 * KP2 + kk]; }
-        const uint32_t incl = dpp_scan_incl_u32(v);
-        if (kk < 256 && (kk & 63) == 63) wsum[kk >> 6] = incl;
-        __syncthreads();
-        if (kk < 256) {
-            uint32_t off = 0u;
-            for (int w = 0; w < (kk >> 6); w++) off += wsum[w];
-            base[kk] = off + incl - v;
-            if (kk == 255 && nnz) nnz[b] = (int32_t)(off + incl);
-        }
-    }
-    __syncthreads();
-    if (k < K) {
-        uint32_t run = base[k];   // exclusive prefix over tiles, seeded with the label's base and the groups before
-        for (int g2 = 0; g2 < grp; g2++) run += gtot[g2 * KP2 + k];
-        if (held) {
-#pragma unroll
-            for (int j = 0; j < SCAN_U; j++) {
-                if (tbeg + j < tend) { st_at(gh, (uint32_t)(tbeg + j) * kp4 + k4, run); run += c[j]; }
-            }
-        } else {
-            for (int t0 = tbeg; t0 < tend; t0 += SCAN_U) {
-                uint32_t d[SCAN_U];
-#pragma unroll
-                for (int j = 0; j < SCAN_U; j++) d[j] = ld_at(gh, (uint32_t)min(t0 + j, T - 1) * kp4 + k4);
-#pragma unroll
-                for (int j = 0; j < SCAN_U; j++) {
-                    if (t0 + j < tend) { st_at(gh, (uint32_t)(t0 + j) * kp4 + k4, run); run += d[j]; }
-                }
-            }
-        }
-        if (counts && grp == 0) counts[(int64_t)b * K + k] = (int32_t)total;
-    }
-    if (k < K && grp == 0 && model != nullptr) {
-        float *row = model + ((int64_t)b * K + k) * 4;
-        if (k == 0) {
-            row[0] = (float)ground[4 * b]; row[1] = (float)ground[4 * b + 1];
-            row[2] = (float)ground[4 * b + 2]; row[3] = (float)ground[4 * b + 3];
-        } else if (k == 1) {
-            row[0] = row[1] = row[2] = row[3] = 0.0f;
-        } else {
-            double s;
-            if (flags[4 * b]) {
-                // exact sequential double accumulation in row-major order (cpp_modules.cpp:514) for frames
-                // whose ranges fall outside the fixed-point window; one thread per label, rare.
-                s = 0.0;
-                const uint8_t *sg = seg + (int64_t)b * P;
-                const float *rr = ri + (int64_t)b * P;
-                for (int p = 0; p < P; p++)
-                    if (sg[p] == k) s += (double)rr[p];
-            } else {
-                s = (double)sums[(int64_t)b * KP + k] * (1.0 / 268435456.0);  // exact: sum < 2^53 units
-            }
-            const double n = (double)total;
-            row[0] = row[1] = row[2] = 0.0f;
-            row[3] = (total == 0) ? u2f(0xFFC00000u) : (float)(s / n);  // 0.0/0 on x86 = default NaN
-        }
-    }
-}
-
-static inline int scan_kp2(int M) { int v = 1; while (v < M + 2) v <<= 1; return v; }   // labels rounded up to a power of two (<= 256)
-
 static int launch_point_model(const float *ri, const uint8_t *seg, const double *ground, int B, int P, int M,
                               float *model, int32_t *counts, int32_t *nnz, void *ws, hipStream_t st, bool cleared = false) {
     const int KP = kpad(M), T = ntiles(P);
     WsLayout L = ws_layout(ws, B, P, M);
     if (!cleared) HIP_TRY(hipMemsetAsync(L.sums, 0, (size_t)((char *)L.hist - (char *)L.sums), st));
-    launch_model_hist(ri, seg, B, P, KP, T, L.sums, L.flags, L.hist, st);
-    LAUNCH_CHECK();
-    model_scan_kernel<<<B, SCAN_THREADS, 0, st>>>(ri, seg, ground, P, M, KP, T, scan_kp2(M), L.sums, L.flags, L.hist, model, counts, nnz);
-    LAUNCH_CHECK();
-    return RPCC_OK;
+    return launch_hist_scan(ri, seg, ground, B, P, M, L, model, counts, nnz, st);
 }
 
 extern "C" int rpcc_point_model(const float *ri, const uint8_t *seg, const double *ground, int B, int P, int M,
@@ -2621,10 +2640,8 @@ extern "C" int rpcc_predict_quantize(const float *ri, const float *tm, const uin
     const int KP = kpad(M), T = ntiles(P);
     WsLayout L = ws_layout(ws, B, P, M);
     HIP_TRY(hipMemsetAsync(L.sums, 0, (size_t)((char *)L.hist - (char *)L.sums), st));
-    launch_model_hist(ri, seg, B, P, KP, T, L.sums, L.flags, L.hist, st);
-    LAUNCH_CHECK();
-    model_scan_kernel<<<B, SCAN_THREADS, 0, st>>>(ri, seg, nullptr, P, M, KP, T, scan_kp2(M), L.sums, L.flags, L.hist, nullptr, nullptr, nnz);
-    LAUNCH_CHECK();
+    int rc;
+    if ((rc = launch_hist_scan(ri, seg, nullptr, B, P, M, L, nullptr, nullptr, nnz, st))) return rc;
     return launch_predict_quantize(ri, tm, seg, model, acc, label_acc, residual_in, B, P, M, q16, q32, pred, ws, st);
 }
 
@@ -2673,9 +2690,8 @@ extern "C" int rpcc_decode(const uint8_t *seg, const int16_t *q16, const float *
     const int KP = kpad(M), T = ntiles(P);
     WsLayout L = ws_layout(ws, B, P, M);
     HIP_TRY(hipMemsetAsync(L.sums, 0, (size_t)((char *)L.hist - (char *)L.sums), st));
-    launch_model_hist(nullptr, seg, B, P, KP, T, L.sums, L.flags, L.hist, st);
-    model_scan_kernel<<<B, SCAN_THREADS, 0, st>>>(nullptr, seg, nullptr, P, M, KP, T, scan_kp2(M), L.sums, L.flags, L.hist,
-                                                            nullptr, nullptr, nullptr);
+    int rc;
+    if ((rc = launch_hist_scan(nullptr, seg, nullptr, B, P, M, L, nullptr, nullptr, nullptr, st))) return rc;
     DecodeSteps steps;
     steps.levels = levels;
     for (int i = 0; i < 8; i++) steps.acc[i] = i < (levels ? levels : 1) ? level_acc[i] : 0.0;
@@ -2787,11 +2803,7 @@ static int launch_label_scan(const uint8_t *seg, int B, int P, int M, int32_t *c
     const int KP = kpad(M), T = ntiles(P);
     WsLayout L = ws_layout(ws, B, P, M);
     if (!cleared) HIP_TRY(hipMemsetAsync(L.sums, 0, (size_t)((char *)L.hist - (char *)L.sums), st));
-    launch_model_hist(nullptr, seg, B, P, KP, T, L.sums, L.flags, L.hist, st);
-    model_scan_kernel<<<B, SCAN_THREADS, 0, st>>>(nullptr, seg, nullptr, P, M, KP, T, scan_kp2(M), L.sums, L.flags, L.hist,
-                                                            nullptr, counts, nnz);
-    LAUNCH_CHECK();
-    return RPCC_OK;
+    return launch_hist_scan(nullptr, seg, nullptr, B, P, M, L, nullptr, counts, nnz, st);
 }
 // plane rows from a segmentation whose tile offsets (launch_label_scan) are in ws; extra = order | pts4 scratch.  Two launches: the
 // label-ordered lists, then the fits.
