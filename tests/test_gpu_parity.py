@@ -1226,3 +1226,56 @@ def test_compress_batch_mixed_argument_errors(env):
     two = _mixed_groups(env, [("VelodyneVLP16", 1, {})]) + _mixed_groups(env, [("VelodyneVLP16", 1, {})], M=50)
     with pytest.raises(AssertionError):
         ops.compress_batch_mixed(two)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_fuzz_mixed_call_vs_groups_alone(env, seed):
+    """Randomised mixed batches: one to four geometry groups with random image shapes (odd widths, few rows), frame counts, cluster
+    count, thresholds and per-group settings (ground fitted or injected, point / plane model, uniform / non-uniform framework, brute-force
+    FPS): rpcc_compress_batch_mixed == rpcc_compress_batch per group, every output buffer, bit for bit."""
+    torch, ops, orc, synth = env["torch"], env["ops"], env["orc"], env["synth"]
+    rng = np.random.default_rng(4200 + seed)
+    G = int(rng.integers(1, 5))
+    M = int(rng.integers(5, 101))
+    acc = float(rng.choice([0.02, 0.04, 0.1]))
+    thr = float(rng.choice([0.05, 0.1, 0.2]))
+
+    def build():
+        r = np.random.default_rng(77 + seed)     # the same draws for both runs
+        groups = []
+        for k in range(G):
+            H, W = int(r.integers(4, 41)), int(r.integers(96, 1500))
+            vmax, vmin = float(r.uniform(1.0, 16.0)), float(-r.uniform(10.0, 31.0))
+            n = int(r.integers(1, 7))
+            g = orc.LidarGeom(H, W, 360.0, vmax, vmin)
+            tm = ops.transform_map(g.H, g.W, g.horizontal_FOV, g.vertical_max, g.vertical_min)
+            geom = ops.make_geom(g.H, g.W, g.horizontal_FOV, g.vertical_max, g.vertical_min)
+            frames = [synth.make_frame(8800 + 100 * seed + 10 * k + i, H, W, vmax_deg=vmax, vmin_deg=vmin).numpy() for i in range(n)]
+            offs = np.zeros(n + 1, np.int64)
+            offs[1:] = np.cumsum([f.shape[0] for f in frames])
+            plane, nonuni, inject, brute = (bool(r.integers(0, 2)) for _ in range(4))
+            a = dict(xyz=_to(env, np.concatenate(frames)), offsets=_to(env, offs), tm=_to(env, tm),
+                     ground=torch.zeros((n, 4), dtype=torch.float64, device=env["dev"]),
+                     buf=ops.BatchBuffers(n, geom, M, env["dev"], general=plane or nonuni), ground_seed=int(r.integers(0, 1000)),
+                     frame_ids=_to(env, r.integers(0, 1 << 20, n).astype(np.int64)), model_method="plane" if plane else "point",
+                     plane_seed=int(r.integers(0, 1000)), nonuniform=ops.nonuniform_cfg(acc) if nonuni else None, fps_bruteforce=brute and H * W % 4 == 0)
+            if inject:
+                a["ground_seed"] = -1
+                a["ground"] = _to(env, np.tile(np.array([[0.02, 0.01, 1.0, 1.7]]), (n, 1)))
+            groups.append(a)
+        return groups
+    alone, mixed = build(), build()
+    for a in alone:
+        ops.compress_batch(ground_threshold=thr, acc=acc, **a)
+    ops.compress_batch_mixed(mixed, ground_threshold=thr, acc=acc)
+    torch.cuda.synchronize()
+    for k, (a, m) in enumerate(zip(alone, mixed)):
+        ba, bm = a["buf"], m["buf"]
+        assert _beq(a["ground"].cpu().numpy(), m["ground"].cpu().numpy()), (seed, k)
+        for f in ("ri", "seg", "cen_pix", "centers", "model", "counts", "nnz"):
+            assert _beq(getattr(ba, f).cpu().numpy(), getattr(bm, f).cpu().numpy()), (seed, k, f)
+        nz, qa, qm = ba.nnz.cpu().numpy(), ba.q16.cpu().numpy(), bm.q16.cpu().numpy()
+        assert all(np.array_equal(qa[i, :nz[i]], qm[i, :nz[i]]) for i in range(ba.B)), (seed, k)
+        if a["nonuniform"] is not None:
+            assert np.array_equal(ba.salience.cpu().numpy(), bm.salience.cpu().numpy()), (seed, k)
