@@ -1024,6 +1024,9 @@ struct RsPoints {
     }
 };
 
+#define RS_GLOBAL_PU 8   // points per lane / thread in flight when a RANSAC pass reads its points from the range image instead of a list in LDS
+__device__ __forceinline__ bool pts_in_memory(const RsPoints &p) { return p.lds == nullptr; }
+template <class PTS> __device__ __forceinline__ bool pts_in_memory(const PTS &) { return false; }   // (other sources choose their own RS_PU / RS_RU)
 typedef float rs_v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float rfl_f32(float v) { return u2f((uint32_t)__builtin_amdgcn_readfirstlane((int)f2u(v))); }
 // inlier test of the specification: fp32, un-fused, plane narrowed to fp32
@@ -1166,13 +1169,18 @@ __device__ int ransac_plane_wg(const PTS &pts, int iters, double thr, uint32_t s
             cnt[q] = 0;
         }
         // (wave-uniform trip count: with a per-lane bound the loop is divergent and the scalar counters are copied to VGPRs at every exit test)
-        for (int ib = 0; ib < n; ib += 64 * RS_PU) {  // RS_PU points per lane in flight (unconditional, clamped loads)
+        // PU points per lane in flight (unconditional, clamped loads): RS_PU for a list in LDS, RS_GLOBAL_PU when the points are read from the
+        // range image (the ground fit on the whole cloud -- a frame with fewer than 800 candidates: every wavefront walks all P pixels, and with
+        // four loads in flight that walk was the launch: 242 us for 16 x 1800 images against 86-113 us for the frames that fit from their list)
+        auto score = [&](auto pu_tag) {
+        constexpr int PU = decltype(pu_tag)::value;
+        for (int ib = 0; ib < n; ib += 64 * PU) {
             const int i0 = ib + lane;
-            float x[RS_PU], y[RS_PU], z[RS_PU];
+            float x[PU], y[PU], z[PU];
 #pragma unroll
-            for (int u = 0; u < RS_PU; u++) pts.getf(min(i0 + 64 * u, n - 1), x[u], y[u], z[u]);
+            for (int u = 0; u < PU; u++) pts.getf(min(i0 + 64 * u, n - 1), x[u], y[u], z[u]);
 #pragma unroll
-            for (int u = 0; u < RS_PU; u++) {
+            for (int u = 0; u < PU; u++) {
                 // past the end: the point (inf, y, z) -- inf or NaN on every plane, never an inlier (no per-lane `in` mask)
                 const float xq = i0 + 64 * u < n ? x[u] : __builtin_inff();
                 // two hypotheses per packed-fp32 instruction (v_pk_mul_f32 / v_pk_add_f32: each half rounds like the scalar
@@ -1189,6 +1197,9 @@ __device__ int ransac_plane_wg(const PTS &pts, int iters, double thr, uint32_t s
                 if (RS_HPW & 1) cnt[RS_HPW - 1] += (int)__popcll(__ballot(plane_inlier(pf[RS_HPW - 1], xq, y[u], z[u], thr_f)));
             }
         }
+        };
+        if (pts_in_memory(pts)) score(std::integral_constant<int, RS_GLOBAL_PU>{});   // (workgroup-uniform)
+        else score(std::integral_constant<int, RS_PU>{});
         int best_cnt = -1, best_h = 0x7fffffff;
 #pragma unroll
         for (int q = 0; q < RS_HPW; q++) {
@@ -1217,32 +1228,44 @@ __device__ int ransac_plane_wg(const PTS &pts, int iters, double thr, uint32_t s
     const float wf[4] = {(float)plane[0], (float)plane[1], (float)plane[2], (float)plane[3]};
     // refit on the winner's inliers (fp64 moments, ordered sums)
     double c[3] = {0, 0, 0};
-    if (tid < RS_NT)
-        for (int i0 = tid; i0 < n; i0 += RS_NT * RS_RU) {  // partial tid accumulates its points in index order
-            float x[RS_RU], y[RS_RU], z[RS_RU];
+    auto centroid = [&](auto ru_tag) {   // RU points per thread in flight; partial tid accumulates its points in index order whatever RU
+        constexpr int RU = decltype(ru_tag)::value;
+        for (int i0 = tid; i0 < n; i0 += RS_NT * RU) {
+            float x[RU], y[RU], z[RU];
 #pragma unroll
-            for (int u = 0; u < RS_RU; u++) pts.getf(min(i0 + RS_NT * u, n - 1), x[u], y[u], z[u]);
+            for (int u = 0; u < RU; u++) pts.getf(min(i0 + RS_NT * u, n - 1), x[u], y[u], z[u]);
 #pragma unroll
-            for (int u = 0; u < RS_RU; u++)
+            for (int u = 0; u < RU; u++)
                 if (i0 + RS_NT * u < n && plane_inlier(wf, x[u], y[u], z[u], thr_f)) { c[0] += (double)x[u]; c[1] += (double)y[u]; c[2] += (double)z[u]; }
         }
+    };
+    if (tid < RS_NT) {
+        if (pts_in_memory(pts)) centroid(std::integral_constant<int, (RS_RU > RS_GLOBAL_PU ? RS_RU : RS_GLOBAL_PU)>{});
+        else centroid(std::integral_constant<int, RS_RU>{});
+    }
     DBG_STAMP(4);
     rs_treesum<3>(c, sred);
     DBG_STAMP(5);
     c[0] /= (double)wcnt; c[1] /= (double)wcnt; c[2] /= (double)wcnt;
     double m[6] = {0, 0, 0, 0, 0, 0};
-    if (tid < RS_NT)
-        for (int i0 = tid; i0 < n; i0 += RS_NT * RS_RU) {
-            float x[RS_RU], y[RS_RU], z[RS_RU];
+    auto moments = [&](auto ru_tag) {
+        constexpr int RU = decltype(ru_tag)::value;
+        for (int i0 = tid; i0 < n; i0 += RS_NT * RU) {
+            float x[RU], y[RU], z[RU];
 #pragma unroll
-            for (int u = 0; u < RS_RU; u++) pts.getf(min(i0 + RS_NT * u, n - 1), x[u], y[u], z[u]);
+            for (int u = 0; u < RU; u++) pts.getf(min(i0 + RS_NT * u, n - 1), x[u], y[u], z[u]);
 #pragma unroll
-            for (int u = 0; u < RS_RU; u++)
+            for (int u = 0; u < RU; u++)
                 if (i0 + RS_NT * u < n && plane_inlier(wf, x[u], y[u], z[u], thr_f)) {
                     const double rx = (double)x[u] - c[0], ry = (double)y[u] - c[1], rz = (double)z[u] - c[2];
                     m[0] += rx * rx; m[1] += rx * ry; m[2] += rx * rz; m[3] += ry * ry; m[4] += ry * rz; m[5] += rz * rz;
                 }
         }
+    };
+    if (tid < RS_NT) {
+        if (pts_in_memory(pts)) moments(std::integral_constant<int, (RS_RU > RS_GLOBAL_PU ? RS_RU : RS_GLOBAL_PU)>{});
+        else moments(std::integral_constant<int, RS_RU>{});
+    }
     rs_treesum<6>(m, sred);
     double pl[4];
     if (plane_from_moments(c, m[0], m[1], m[2], m[3], m[4], m[5], pl)) { plane[0] = pl[0]; plane[1] = pl[1]; plane[2] = pl[2]; plane[3] = pl[3]; }
