@@ -172,11 +172,16 @@ __device__ __forceinline__ void fps_tile_box(const float (&x)[4], const float (&
     const float inf = __builtin_inff();
     lo[0] = lo[1] = lo[2] = inf;
     hi[0] = hi[1] = hi[2] = -inf;
+    // non-candidates enter as quiet NaNs, which v_min3 / v_max3 skip (rpcc_device.h): one select per coordinate, two points per instruction
+    const float qnan = u2f(0x7FC00000u);
+    float bx[4], by[4], bz[4];
 #pragma unroll
-    for (int e = 0; e < 4; e++) {
-        lo[0] = fmin_raw(lo[0], cand[e] ? x[e] : inf); hi[0] = fmax_raw(hi[0], cand[e] ? x[e] : -inf);
-        lo[1] = fmin_raw(lo[1], cand[e] ? y[e] : inf); hi[1] = fmax_raw(hi[1], cand[e] ? y[e] : -inf);
-        lo[2] = fmin_raw(lo[2], cand[e] ? z[e] : inf); hi[2] = fmax_raw(hi[2], cand[e] ? z[e] : -inf);
+    for (int e = 0; e < 4; e++) { bx[e] = cand[e] ? x[e] : qnan; by[e] = cand[e] ? y[e] : qnan; bz[e] = cand[e] ? z[e] : qnan; }
+#pragma unroll
+    for (int e = 0; e < 4; e += 2) {
+        lo[0] = fmin3_raw(lo[0], bx[e], bx[e + 1]); hi[0] = fmax3_raw(hi[0], bx[e], bx[e + 1]);
+        lo[1] = fmin3_raw(lo[1], by[e], by[e + 1]); hi[1] = fmax3_raw(hi[1], by[e], by[e + 1]);
+        lo[2] = fmin3_raw(lo[2], bz[e], bz[e + 1]); hi[2] = fmax3_raw(hi[2], bz[e], bz[e + 1]);
     }
     dpp_box6(lo[0], lo[1], lo[2], hi[0], hi[1], hi[2]);
 }

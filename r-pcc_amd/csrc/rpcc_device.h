@@ -108,6 +108,10 @@ __device__ __forceinline__ float atan2f_fdlibm(float y, float x) {
 // pixel kernel, round 3).  Only use these on values that come from plain VALU arithmetic, selects or loads.
 __device__ __forceinline__ float fmin_raw(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float fmax_raw(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// three operands at once; a quiet-NaN operand is skipped (IEEE mode: v_min / v_max return the other operand), so "value or NaN" masks an element
+// with one select instead of one per bound
+__device__ __forceinline__ float fmin3_raw(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float fmax3_raw(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 
 // ---------------------------------------------------------------------------------------------
 // Loads / stores at "wave-uniform base + 32-bit byte offset".  Written with an explicit unsigned byte offset so that the

@@ -2056,11 +2056,18 @@ __global__ __launch_bounds__(64 * ASSIGN_WAVES) ASSIGN_VGPR_ATTR void assign_ker
             continue;
         }
         float lo0 = inf, lo1 = inf, lo2 = inf, hi0 = -inf, hi1 = -inf, hi2 = -inf;
+        {   // empty pixels enter as quiet NaNs, which v_min3 / v_max3 skip: one select per coordinate, two pixels per instruction
+            const float qnan = u2f(0x7FC00000u);
+            float bx[ASSIGN_PX], by[ASSIGN_PX], bz[ASSIGN_PX];
 #pragma unroll
-        for (int e = 0; e < ASSIGN_PX; e++) {
-            lo0 = fmin_raw(lo0, live[e] ? x[e] : inf); hi0 = fmax_raw(hi0, live[e] ? x[e] : -inf);
-            lo1 = fmin_raw(lo1, live[e] ? y[e] : inf); hi1 = fmax_raw(hi1, live[e] ? y[e] : -inf);
-            lo2 = fmin_raw(lo2, live[e] ? z[e] : inf); hi2 = fmax_raw(hi2, live[e] ? z[e] : -inf);
+            for (int e = 0; e < ASSIGN_PX; e++) { bx[e] = live[e] ? x[e] : qnan; by[e] = live[e] ? y[e] : qnan; bz[e] = live[e] ? z[e] : qnan; }
+            static_assert(ASSIGN_PX % 2 == 0, "pixels in pairs");
+#pragma unroll
+            for (int e = 0; e < ASSIGN_PX; e += 2) {
+                lo0 = fmin3_raw(lo0, bx[e], bx[e + 1]); hi0 = fmax3_raw(hi0, bx[e], bx[e + 1]);
+                lo1 = fmin3_raw(lo1, by[e], by[e + 1]); hi1 = fmax3_raw(hi1, by[e], by[e + 1]);
+                lo2 = fmin3_raw(lo2, bz[e], bz[e + 1]); hi2 = fmax3_raw(hi2, bz[e], bz[e + 1]);
+            }
         }
         dpp_box6(lo0, lo1, lo2, hi0, hi1, hi2);
         // screen the centres: lane handles centres lane, lane+64, ...
