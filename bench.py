@@ -771,7 +771,7 @@ def run_mixed(a, ctx, per=85, reps=24, slots=None, by_streams=False):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     ok = True
-    nver = 4
+    nver = min(per, 32)
     for n, gd, sl, xyz, offs, fid in groups:
         buf, g_fit, bits, seq, nseq, sal = outs[n]
         g = orc.LidarGeom(**gd)
