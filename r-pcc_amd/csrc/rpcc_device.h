@@ -256,6 +256,18 @@ __device__ __forceinline__ float dpp_min_f32_native(float v) {
     return u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(v), 63));
 }
 
+__device__ __forceinline__ float dpp_max_f32_native(float v) {
+    asm volatile("s_nop 1\n\t"
+                 "v_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
+                 : "+v"(v));
+    return u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(v), 63));
+}
+
 // FPS arg-max key: larger squared distance first, then LOWER index (the sequential strict-'>' scan of
 // ops/fps/src/sampling_gpu.cu:67-68 restated as a total order).  value < 0 means "not a candidate".
 __device__ __forceinline__ unsigned long long fps_key(float v, uint32_t idx) {
