@@ -2100,8 +2100,16 @@ __global__ __launch_bounds__(64 * ASSIGN_WAVES) ASSIGN_VGPR_ATTR void assign_ker
         // No centre beyond the largest reach of the tile's pixels (assign_reach) matters: on ground every centre is farther than the ground
         // term -- no survivor at all, the tile is labelled without a single distance --, on objects the nearest centre is known from the FPS.
         float reach = 0.0f;
+        bool unknown = false;   // a live pixel the FPS knows nothing about (not a candidate, or no `temp`)
 #pragma unroll
-        for (int e = 0; e < ASSIGN_PX; e++) reach = fmaxf(reach, live[e] ? assign_reach(r[e], tx[e], ty[e], tz[e], tp[e], G) : 0.0f);
+        for (int e = 0; e < ASSIGN_PX; e++) unknown |= live[e] && !(tp[e] >= 0.0f);
+        if (__ballot(unknown) == 0ull) {   // (wave-uniform) candidates only -- objects: their nearest distances bound the tile, the ground term adds nothing
+#pragma unroll
+            for (int e = 0; e < ASSIGN_PX; e++) reach = fmaxf(reach, live[e] ? tp[e] : 0.0f);
+        } else {
+#pragma unroll
+            for (int e = 0; e < ASSIGN_PX; e++) reach = fmaxf(reach, live[e] ? assign_reach(r[e], tx[e], ty[e], tz[e], tp[e], G) : 0.0f);
+        }
         reach = dpp_max_f32_native(reach);
         const bool bounded = reach < inf;   // (wave-uniform) otherwise: the box bound min_j dmax_j of the header
         // screen the centres: lane handles centres lane, lane+64, ...
