@@ -930,8 +930,14 @@ __global__ __launch_bounds__(64 * MASK_WAVES) MASK_VGPR_ATTR void ground_mask_ta
         if (fast) {
             float lo[3], hi[3], wt, wx, wy, wz;
             uint32_t widx;
-            fps_tile_box(x, y, z, boxc, lo, hi);
-            fps_tile_argmax(x, y, z, key, q[k].p0, wt, wx, wy, wz, widx);
+            if ((__ballot(boxc[0]) | __ballot(boxc[1]) | __ballot(boxc[2]) | __ballot(boxc[3])) == 0ull) {
+                // (wave-uniform) a tile without a candidate -- the ground, two tiles in five: the entry fps_tile_box / fps_tile_argmax give for it, without them
+                lo[0] = lo[1] = lo[2] = __builtin_inff(); hi[0] = hi[1] = hi[2] = -__builtin_inff();
+                wt = -1.0f; wx = wy = wz = 0.0f; widx = 0u;
+            } else {
+                fps_tile_box(x, y, z, boxc, lo, hi);
+                fps_tile_argmax(x, y, z, key, q[k].p0, wt, wx, wy, wz, widx);
+            }
             if (lane < 3) {
                 float4 v = make_float4(lo[0], lo[1], lo[2], wt);
                 if (lane == 1) v = make_float4(hi[0], hi[1], hi[2], u2f(widx));
