@@ -2022,7 +2022,7 @@ __device__ __forceinline__ int assign_label(float r, float tx, float ty, float t
 #define ASSIGN_PX 4     // pixels per lane: a tile is (2 * ASSIGN_PX) rows x 32 columns, lane l pixel e -> row (l >> 4) + 4 * (e >> 1), column 2 * (l & 15) + (e & 1)
 #define ASSIGN_ROWS (2 * ASSIGN_PX)
 #define ASSIGN_TILES_PER_WAVE (4 / ASSIGN_PX)
-#define ASSIGN_WAVES 2   // wavefronts per workgroup (they share the centre table in LDS, nothing else)
+#define ASSIGN_WAVES 4   // wavefronts per workgroup (they share the centre table in LDS, nothing else)
 #define ASSIGN_VGPR_ATTR
 __global__ __launch_bounds__(64 * ASSIGN_WAVES) ASSIGN_VGPR_ATTR void assign_kernel(const float *__restrict__ ri, const float *__restrict__ tm,
                                                      const double *__restrict__ ground,
