@@ -37,6 +37,8 @@ class NonuniformCfg(C.Structure):
 INFO_INTS = 8          # RPCC_INFO_INTS
 FPS_BRUTEFORCE = 1     # RPCC_FPS_BRUTEFORCE
 FPS_FMA1, FPS_FMA2, FPS_TIE_CUDA = 2, 4, 8   # RPCC_FPS_FMA1 / RPCC_FPS_FMA2 / RPCC_FPS_TIE_CUDA
+ASSIGN_SEARCH = 16     # RPCC_ASSIGN_SEARCH
+ABI_VERSION = 101      # RPCC_ABI_VERSION: the layout of rpcc_batch_io / rpcc_geom this binding was written for
 
 
 def fps_mode_flags(fma=0, cuda_tie=False):
@@ -140,11 +142,15 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RpccError("librpcc_hip.so is not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'`"
                             % LIB_PATH)
-        _lib = C.CDLL(LIB_PATH)
+        h = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
-            fn = getattr(_lib, name)
+            fn = getattr(h, name)
             fn.restype = res
             fn.argtypes = args
+        if h.rpcc_version() != ABI_VERSION:   # the structs carry no size field: a library of another layout must not be called
+            raise RpccError("librpcc_hip.so (%s) reports interface version %d, this binding needs %d (stale build: rebuild with "
+                            "`python -c 'import __graft_entry__ as g; g.build()'`)" % (LIB_PATH, h.rpcc_version(), ABI_VERSION))
+        _lib = h
     return _lib
 
 

@@ -412,3 +412,56 @@ def test_ground_ransac_statistics(env):
         assert abs(np.linalg.norm(pl[:3]) - 1.0) < 1e-9 and mine >= 0.5 * cand.shape[0], k       # a unit normal, a real ground plane
     print("ground RANSAC vs an independent trimmed least-squares reference over %d frames: worst inlier ratio %.4f, worst normal "
           "angle %.4f deg; vs the refit from its own plane: worst ratio %.4f" % (len(cases), worst_ratio, worst_angle, worst_local))
+
+
+def _lattice_shells(env, radii):
+    """Sweeps without noise: every pixel's own ray times one radius.  The symmetric lattice puts pixels (almost) equally far from two
+    centres -- squared distances that differ in their last bits and round to ONE sqrtf, where numpy's argmax keeps the lower index
+    (utils/segment_utils.py:21-23,131): 2-14 such pixels per sweep, most of them with the lower index NOT at the minimum squared distance."""
+    frames = [(env["tm"].reshape(-1, 3).astype(np.float64) * r).astype(np.float32) for r in radii]
+    offs = np.zeros(len(frames) + 1, np.int64)
+    offs[1:] = np.cumsum([f.shape[0] for f in frames])
+    return np.concatenate(frames), offs
+
+
+@pytest.mark.parametrize("scene", ["default", "shell", "noise", "corridor", "lattice"])
+def test_assignment_from_the_fps_state_equals_the_search(env, scene):
+    """a7 in the fused batch takes every candidate pixel's nearest centre from what the pruned FPS leaves (its minimum squared distance
+    in temp, the index that reached it, the tie marks: assign_near_kernel); RPCC_ASSIGN_SEARCH makes it search as rpcc_assign does.
+    Both equal the oracle's labels (argmax over the fp64 ground term and the 100 fp32 radii, first maximum) on the headline scene, the
+    adversarial ones and on noise-free lattice sweeps that hold square-root ties between distinct squared distances."""
+    torch, ops, synth, orc = env["torch"], env["ops"], env["synth"], env["orc"]
+    g, tm, dev = env["g"], env["tm"], env["dev"]
+    if scene == "lattice":
+        xyz_h, offs_h = _lattice_shells(env, (30.0, 12.5, 7.3, 55.0))
+        xyz, offs = torch.from_numpy(xyz_h).to(dev), torch.from_numpy(offs_h).to(dev)
+    else:
+        xyz, offs = synth.make_batch(range(9700, 9704), g.H, g.W, device=dev, scene=scene)
+        xyz_h, offs_h = xyz.cpu().numpy(), offs.cpu().numpy()
+    B = offs_h.shape[0] - 1
+    gm_h = np.tile(np.array([0.004, -0.003, 0.99998, 1.73]), (B, 1))
+    gms = torch.from_numpy(gm_h).to(dev)
+    out = {}
+    for search in (False, True):
+        buf = ops.BatchBuffers(B, env["geom"], 100, dev)
+        ops.compress_batch(xyz, offs, env["d_tm"], gms, buf, assign_search=search)
+        torch.cuda.synchronize()
+        out[search] = (buf.seg.cpu().numpy().reshape(B, -1), buf.q16.cpu().numpy(), buf.nnz.cpu().numpy(), buf.cen_pix.cpu().numpy())
+    for a, b, what in zip(out[False], out[True], ("labels", "quantised residuals", "counts", "FPS pixels")):
+        assert np.array_equal(a, b), (scene, what)
+    ties = 0
+    for i in range(B):
+        o = orc.compress_frame(xyz_h[offs_h[i]:offs_h[i + 1]], g, tm, gm_h[i])
+        assert np.array_equal(out[False][3][i], o["fps_pix"]), (scene, i, "FPS pixels")
+        bad = np.flatnonzero(out[False][0][i] != o["seg_idx"].reshape(-1))
+        assert bad.size == 0, (scene, i, "labels", bad[:8], out[False][0][i][bad[:8]], o["seg_idx"].reshape(-1)[bad[:8]])
+        n = int(out[False][2][i])
+        assert n == o["q"].shape[0] and np.array_equal(out[False][1][i, :n], o["q"].astype(np.int16)), (scene, i, "quantised residuals")
+        if scene == "lattice":   # the sweep does hold what the test is about
+            pc, cen = o["pc"].reshape(-1, 3), o["centers"].astype(np.float32)
+            d = pc[:, None, :] - cen[None, :, :]
+            d2 = ((d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]).astype(np.float32)
+            m1, k1 = d2.min(1), d2.argmin(1)
+            tie = (np.sqrt(d2) == np.sqrt(m1)[:, None]) & (d2 != m1[:, None]) & (np.arange(cen.shape[0])[None, :] < k1[:, None])
+            ties += int(tie.any(1).sum())
+    assert scene != "lattice" or ties >= 4, ties
