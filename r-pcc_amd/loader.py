@@ -136,7 +136,14 @@ class StreamingCompressor:
         assert 0 < n <= self.B
         rows = self.ingest == "rows"
         if rows:
-            sizes = np.fromiter((os.path.getsize(f) // 16 if isinstance(f, (str, os.PathLike)) else f.shape[0] for f in frames), dtype=np.int64, count=n)
+            def rows_of(f):
+                if not isinstance(f, (str, os.PathLike)):
+                    return f.shape[0]
+                nbytes = os.path.getsize(f)
+                if nbytes % 16:   # the reference's np.fromfile(...).reshape(-1, 4) raises on such a file (dataset/dataset.py:48-50), and so does ingest="xyz"
+                    raise ValueError("%s: %d bytes is no whole number of (x, y, z, intensity) float32 rows" % (f, nbytes))
+                return nbytes // 16
+            sizes = np.fromiter((rows_of(f) for f in frames), dtype=np.int64, count=n)
         else:
             sizes = np.fromiter((f.shape[0] for f in frames), dtype=np.int64, count=n)
         offs = np.zeros(self.B + 1, np.int64)
@@ -153,9 +160,11 @@ class StreamingCompressor:
                 if not rows:
                     dst[offs[i]:offs[i + 1]] = f[:, :3]   # .bin rows are (x, y, z, intensity): the strided copy drops the 4th column
                 elif isinstance(f, (str, os.PathLike)):       # the file's bytes land in the pinned slot: no pass over the points at all
-                    if offs[i + 1] == offs[i]:
-                        continue
                     with open(f, "rb", buffering=0) as fh:
+                        if os.fstat(fh.fileno()).st_size != 16 * int(offs[i + 1] - offs[i]):   # grew or shrank since it was sized
+                            raise ValueError("%s changed size while the batch was staged" % f)
+                        if offs[i + 1] == offs[i]:
+                            continue
                         view = memoryview(dst[offs[i]:offs[i + 1]].reshape(-1).view(np.uint8))
                         got = fh.readinto(view)
                         while 0 < got < len(view):            # (short reads: network file systems)
@@ -163,7 +172,8 @@ class StreamingCompressor:
                             if not m:
                                 break
                             got += m
-                        assert got == len(view), "%s changed size while it was read" % f
+                        if got != len(view):
+                            raise ValueError("%s changed size while it was read" % f)
                 else:
                     assert f.ndim == 2 and f.shape[1] == 4 and f.dtype == np.float32, 'ingest="rows" takes [N,4] float32 rows or .bin paths'
                     dst[offs[i]:offs[i + 1]] = f           # contiguous rows: one memcpy

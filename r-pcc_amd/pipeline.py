@@ -10,6 +10,8 @@ from .compress_utils import BasicCompressor, pack_bitstream, pack_frames  # noqa
 
 
 class BatchCompressor:
+    SLOTS = 4      # batches in flight one instance supports (submit() without collect()): every one owns its output buffers
+
     def __init__(self, transformer, cluster_num=100, accuracy=0.02, ground_threshold=0.1, uniform=True,
                  model_method="point", compressor_cfg=None, basic_compressor="bzip2", device=None, seed=0):
         self.T = transformer
@@ -22,18 +24,29 @@ class BatchCompressor:
         self.cfg = compressor_cfg or {}
         self.bc = BasicCompressor(method_name=basic_compressor)
         self.seed = int(seed)
-        self._buf = None
+        self._buf = None        # the buffers of the most recent call (tests read them after compress())
         self._codec_ws = None
+        self._ring = {}         # frames per batch -> up to SLOTS BatchBuffers (+ codec workspace), busy between submit() and collect()
 
     @property
     def general(self):
         return not (self.uniform and self.model_method == "point")
 
     def _buffers(self, B):
-        if self._buf is None or self._buf.B != B:
-            self._buf = ops.BatchBuffers(B, self.T.geom, self.M, self.device, general=self.general)
-            self._codec_ws = ops.codec_workspace(B, self.T.H * self.T.W, self.M, self.device)
-        return self._buf
+        """Output buffers for a batch of B frames: the first set no submit() holds (collect() reads a batch's counts, models, salience and
+        contour bits from them, so a second submit() before the first collect() must not land in the same set); at most SLOTS sets per
+        batch size, created when first needed.  compress_device() alone never holds a set: its results are valid until the next call."""
+        ring = self._ring.setdefault(B, [])
+        buf = next((b for b in ring if not b.in_flight), None)
+        if buf is None:
+            if len(ring) >= self.SLOTS:
+                raise RuntimeError("BatchCompressor: %d batches submitted and not collected; collect() one before the next submit()" % len(ring))
+            buf = ops.BatchBuffers(B, self.T.geom, self.M, self.device, general=self.general)
+            buf.codec_ws = ops.codec_workspace(B, self.T.H * self.T.W, self.M, self.device)
+            buf.in_flight = False
+            ring.append(buf)
+        self._buf, self._codec_ws = buf, buf.codec_ws
+        return buf
 
     def _group_args(self, xyz, offsets, ground=None, frame_ids=None):
         """ops.compress_batch's arguments for this compressor's settings (one geometry group of ops.compress_batch_mixed)."""
@@ -50,7 +63,7 @@ class BatchCompressor:
         """Contour bits / index sequences of the segmentation a fused call left in args["buf"]."""
         buf = args["buf"]
         sal = None if self.uniform else buf.salience
-        bits, seq, nseq = ops.contour_encode(buf.seg, self.M, ws=self._codec_ws)
+        bits, seq, nseq = ops.contour_encode(buf.seg, self.M, ws=buf.codec_ws)
         return buf, args["ground"], bits, seq, nseq, sal
 
     def compress_device(self, xyz, offsets, ground=None, frame_ids=None):
@@ -75,6 +88,7 @@ class BatchCompressor:
         buf, g, bits, seq, nseq, sal = dev_out
         qp, qtot = ops.pack_payload(buf.q16, buf.nnz, capacity=npts)
         sp, stot = ops.pack_payload(seq.view(torch.int16), nseq)
+        buf.in_flight = True    # until collect() has read it (_buffers)
         return dict(n=n, buf=buf, bits=bits, nseq=nseq, sal=sal, qp=qp, qtot=qtot, sp=sp, stot=stot,
                     stream=torch.cuda.current_stream(self.device), keep=(xyz, g, seq))
 
@@ -96,6 +110,7 @@ class BatchCompressor:
         qo, so = np.concatenate([[0], np.cumsum(nnz)]), np.concatenate([[0], np.cumsum(nseq_h)])
         bits_h, model = bits.cpu().numpy(), buf.model.cpu().numpy()
         sal_h = None if sal is None else sal.cpu().numpy()
+        buf.in_flight = False   # everything collect() needs is on the host
         def assemble(b):
             nrow = int(np.flatnonzero(seg_max[b])[-1]) + 1          # max(seg)+1 rows (tools/compress.py:102)
             od = {"residual_quantized": q16[qo[b]: qo[b + 1]]}
@@ -126,7 +141,8 @@ class MixedBatchCompressor:
     launches left most of it idle -- profiles/HISTORY.md.)
     transformers: {lidar name: PCTransformer}; the other arguments are BatchCompressor's."""
 
-    SLOTS = 4      # mixed batches in flight of the streaming form (submit / collect on SLOTS streams); bench.py's secondary measures it
+    SLOTS = BatchCompressor.SLOTS   # mixed batches in flight of the streaming form (submit / collect on SLOTS streams): every lidar's compressor
+                                    # keeps that many buffer sets, a further submit() before a collect() raises
 
     def __init__(self, transformers, **kw):
         self.bcs = {name: BatchCompressor(t, **kw) for name, t in transformers.items()}

@@ -96,6 +96,13 @@ def compress(args):
                          model_method=model_cfg["model_method"], compressor_cfg=dict(cfg),
                          basic_compressor=basic_compressor.method_name, seed=args.seed)
     mine = shard_indices(len(dataset), rank, world)
+    # the ingest mode follows from the WHOLE datalist -- the same decision on every rank, also on one whose shard is empty -- and is
+    # settled before the process group forms, so that a datalist --ingest rows cannot take fails on all ranks together
+    want = getattr(args, "ingest", "auto")
+    all_bin = all(str(name).endswith(".bin") for name in dataset.data_list)
+    if want == "rows" and not all_bin:
+        raise SystemExit("--ingest rows needs a datalist of .bin files (float32 rows x, y, z, intensity)")
+    ingest = "rows" if (len(dataset) > 0 and (want == "rows" or (want == "auto" and all_bin))) else "xyz"
     gather = None
     if getattr(args, "gather", False):
         import torch
@@ -108,10 +115,6 @@ def compress(args):
         # entropy coding + file output of batch n-1 overlap
         # .bin sweeps (float32 rows x, y, z, intensity: dataset/dataset.py:48-50) are read straight into the pinned staging slot
         # and go to the device as stored -- no np.fromfile + [:, :3] pass on the host; other formats are loaded and sliced
-        want = getattr(args, "ingest", "auto")
-        all_bin = len(mine) > 0 and all(str(dataset.data_list[i]).endswith(".bin") for i in mine)
-        ingest = "rows" if (want == "rows" or (want == "auto" and all_bin)) else "xyz"
-        assert ingest == "xyz" or all_bin, "--ingest rows needs a datalist of .bin files"
         sc = StreamingCompressor(bc, batch=min(args.batch, max(len(mine), 1)), depth=4, workers=args.workers, pool=pool,
                                  points_per_frame=getattr(args, "points_per_frame", None), ingest=ingest)
         names_of = {}

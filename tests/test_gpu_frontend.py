@@ -331,6 +331,35 @@ def test_mixed_lidar_batch(fe):
             assert mixed[i] == blob, (n, i)
 
 
+def test_submits_in_flight_own_their_buffers(fe):
+    """submit() / collect(): several batches of the SAME size submitted before the first collect() -- single geometry and mixed -- return
+    what one compress() per batch returns (every batch in flight owns its output buffers); one submit() more than SLOTS raises."""
+    from oracle import oracle as orc
+    from rpcc_amd import synth
+    names = ["VelodyneVLP16", "Velodyne32E", "VelodyneVLP16", "Velodyne32E"]
+    T = {n: fe.ds.build_dataset(lidar_type=n).PCTransformer for n in set(names)}
+    def batch(k):
+        return [synth.make_frame(4100 + 10 * k + i, orc.GEOMS[n]["H"], orc.GEOMS[n]["W"], vmax_deg=orc.GEOMS[n]["vmax_deg"],
+                                 vmin_deg=orc.GEOMS[n]["vmin_deg"]).numpy() for i, n in enumerate(names)]
+    batches = [batch(k) for k in range(3)]
+    kw = dict(accuracy=0.02, uniform=False, model_method="plane", seed=3)
+    mc = fe.pl.MixedBatchCompressor(T, **kw)
+    want = [mc.compress(b, names) for b in batches]
+    assert want[0] != want[1]
+    ctxs = [mc.submit(b, names) for b in batches]            # nothing collected in between
+    assert [mc.collect(c) for c in ctxs] == want
+    bc = fe.pl.BatchCompressor(T["VelodyneVLP16"], accuracy=0.02, seed=4)
+    vlp = [[b[0], b[2]] for b in batches]
+    want1 = [bc.compress(v) for v in vlp]
+    ctxs = [bc.submit(v) for v in vlp]
+    assert [bc.collect(c) for c in reversed(ctxs)][::-1] == want1
+    ctxs = [bc.submit(vlp[0]) for _ in range(bc.SLOTS)]
+    with pytest.raises(RuntimeError, match="not collected"):
+        bc.submit(vlp[0])
+    assert all(bc.collect(c) == want1[0] for c in ctxs)
+    assert bc.compress(vlp[1]) == want1[1]
+
+
 def test_entropy_coding_on_a_thread_pool(fe):
     """collect(pool=...) -- the frames' entropy coding on executor threads, as the reference's --workers pool does -- gives the
     same .rpcc strings in the same order."""
