@@ -78,6 +78,7 @@ GEOMS = {
     "Velodyne64E_2048": dict(H=64, W=2048, hfov_deg=360, vmax_deg=2.0, vmin_deg=-24.9),
     "Velodyne32E": dict(H=32, W=2250, hfov_deg=360, vmax_deg=10.67, vmin_deg=-30.67),
     "VelodyneVLP16": dict(H=16, W=1800, hfov_deg=360, vmax_deg=15, vmin_deg=-15),
+    "Velodyne64E_unofficial": dict(H=80, W=2000, hfov_deg=360, vmax_deg=2.5, vmin_deg=-23.6),   # dataset/__init__.py:21 'KITTI_test'
 }
 
 

@@ -163,18 +163,62 @@ def run_reference(xyz, lidar_yaml, ground_model, uniform, plane_rows=None, accur
     return out
 
 
-def main():
+SHA_GEOMS = ("Velodyne64E", "Velodyne64E_2048", "Velodyne32E", "VelodyneVLP16", "Velodyne64E_unofficial")   # every shipped lidar YAML + BASELINE's
+SHA_FRAMES = tuple(range(100, 108))   # eight seeded sweeps per geometry
+
+
+def sha_cases(tmp):
+    """Breadth: eight seeded sweeps per geometry through the genuine reference, kept as SHA-256 digests only (no arrays): the inputs
+    are regenerated from their seeds (synth.make_frame on the CPU; the digest of xyz guards that) -> manifest_sha.json."""
+    lacc = np.array([0.04] * 4) + np.array([0, 0.02, 0.04, 0.06])
+    from ops.cpp_modules import quantization_utils_cpp
+    out = {"numpy": np.__version__, "glibc": os.confstr("CS_GNU_LIBC_VERSION"), "frames": list(SHA_FRAMES), "cases": {}}
+    for geom in SHA_GEOMS:
+        g = orc.GEOMS[geom]
+        yml = os.path.join(tmp, geom + ".yaml")
+        write_lidar_yaml(yml, g)
+        rows = []
+        for fid in SHA_FRAMES:
+            xyz = synth.make_frame(fid, g["H"], g["W"], vmax_deg=g["vmax_deg"], vmin_deg=g["vmin_deg"]).numpy()
+            gm = estimate_ground(xyz)
+            ref = run_reference(xyz, yml, gm, uniform=True)
+            # non-uniform framework with the zero-initialised key point map (see main()): the reference's own C++ on the oracle's map
+            _, kp = orc.extract_features_with_segment(ref["ri"][..., 0], ref["seg_idx"])
+            q_n, sal_n = quantization_utils_cpp.nonuniform_quantize(ref["seg_idx"], ref["residual"], kp, np.array([30, 10, 3, 0]), lacc, 2)
+            rows.append(dict(frame=int(fid), n_points=int(xyz.shape[0]), nnz=int((ref["ri"] != 0).sum()), n_left=int(ref["mask"].sum()),
+                             labels=int(ref["seg_idx"].max()) + 1, rpcc_bytes=len(ref["rpcc"]), ground_model=[float(v) for v in gm],
+                             sha=dict(xyz=sha(xyz), ri=sha(ref["ri"]), mask=sha(ref["mask"]), seg_idx=sha(ref["seg_idx"].astype(np.uint8)),
+                                      model_param=sha(ref["model_param"].astype(np.float32)), q=sha(ref["q"].astype(np.int16)),
+                                      key_point_map=sha(kp.astype(np.uint8)), q_nonuniform=sha(q_n.astype(np.int16)),
+                                      salience=sha(sal_n.astype(np.uint8)), rpcc=hashlib.sha256(ref["rpcc"]).hexdigest())))
+            print(geom, fid, rows[-1]["nnz"], rows[-1]["n_left"], rows[-1]["rpcc_bytes"], flush=True)
+        out["cases"][geom] = rows
+    json.dump(out, open(os.path.join(HERE, "manifest_sha.json"), "w"), indent=1, sort_keys=True)
+
+
+def main(argv):
+    """python gen_golden.py [full] [kitti_test] [sha]   (default: all; `kitti_test` alone adds that case to the committed manifest)"""
+    what = set(argv) or {"full", "sha"}
     install_stubs()
     tmp = "/tmp/rpcc_golden_tmp"
     os.makedirs(tmp, exist_ok=True)
+    if "sha" in what:
+        sha_cases(tmp)
+    if not (what & {"full", "kitti_test"}):
+        return
     manifest = {"numpy": np.__version__, "glibc": os.confstr("CS_GNU_LIBC_VERSION"), "cases": {}}
+    if "full" not in what:   # add to the committed manifest without regenerating the other fixtures
+        manifest = json.load(open(os.path.join(HERE, "manifest.json")))
 
     cases = []
-    ex = np.fromfile(os.path.join(REF, "assets/example_data/example.bin"), dtype=np.float32).reshape(-1, 4)[:, :3]
-    cases.append(("example_64E", "Velodyne64E", np.ascontiguousarray(ex),
-                  np.array([0.00721658, -0.0544943, -0.998488, -1.75882636])))
+    if "full" in what:
+        ex = np.fromfile(os.path.join(REF, "assets/example_data/example.bin"), dtype=np.float32).reshape(-1, 4)[:, :3]
+        cases.append(("example_64E", "Velodyne64E", np.ascontiguousarray(ex),
+                      np.array([0.00721658, -0.0544943, -0.998488, -1.75882636])))
     for name, geom, fid in (("synth_64x2048", "Velodyne64E_2048", 0), ("synth_32E", "Velodyne32E", 1),
-                            ("synth_vlp16", "VelodyneVLP16", 2)):
+                            ("synth_vlp16", "VelodyneVLP16", 2), ("synth_kitti_test", "Velodyne64E_unofficial", 3)):
+        if "full" not in what and name != "synth_kitti_test":
+            continue
         g = orc.GEOMS[geom]
         xyz = synth.make_frame(fid, g["H"], g["W"], vmax_deg=g["vmax_deg"], vmin_deg=g["vmin_deg"]).numpy()
         cases.append((name, geom, xyz, estimate_ground(xyz)))
@@ -223,4 +267,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    main(sys.argv[1:])

@@ -13,6 +13,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 MAN = json.load(open(os.path.join(HERE, "golden", "manifest.json")))
 LIDAR = {"Velodyne64E": "Velodyne64E", "Velodyne64E_2048": "Velodyne64E_2048", "Velodyne32E": "Velodyne32E",
          "VelodyneVLP16": "VelodyneVLP16"}
+SHA = json.load(open(os.path.join(HERE, "golden", "manifest_sha.json")))
+
+
+def _dataset(fe, geom):
+    """The registry entry of a golden geometry: a lidar type, or -- for the 80 x 2000 table -- the dataset that uses it
+    (dataset/__init__.py:21 'KITTI_test')."""
+    if geom == "Velodyne64E_unofficial":
+        return fe.ds.build_dataset(dataset_name="KITTI_test")
+    return fe.ds.build_dataset(lidar_type=LIDAR[geom])
 
 
 @pytest.fixture(scope="module")
@@ -32,7 +41,7 @@ def test_reference_style_driver_matches_golden_bytes(fe, case):
     through PointCloudSegment.ransac_plane_segmentation like a user of the reference would."""
     c = MAN["cases"][case]
     z = np.load(os.path.join(HERE, "golden", case + ".npz"))
-    ds = fe.ds.build_dataset(lidar_type=LIDAR[c["geom"]])
+    ds = _dataset(fe, c["geom"])
     T = ds.PCTransformer
     ri = np.expand_dims(T.point_cloud_to_range_image(z["xyz"]), -1)
     pc = T.range_image_to_point_cloud(ri)
@@ -329,6 +338,44 @@ def test_mixed_lidar_batch(fe):
         single = fe.pl.BatchCompressor(T[n], **kw).compress([frames[i] for i in idx])
         for i, blob in zip(idx, single):
             assert mixed[i] == blob, (n, i)
+
+
+@pytest.mark.parametrize("geom", sorted(SHA["cases"]))
+def test_breadth_digests_batch_front_end(fe, geom):
+    """The eight seeded sweeps per geometry the genuine reference was run on (tests/golden/manifest_sha.json; every shipped lidar YAML
+    incl. KITTI_test's 80 x 2000, and 64 x 2048) as ONE fused batch per geometry and framework: range images, labels, model rows,
+    quantised integers, key points, salience levels and the .rpcc bytes have the reference's digests."""
+    import hashlib
+    from oracle import oracle as orc
+    from rpcc_amd import synth
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    gd = orc.GEOMS[geom]
+    T = _dataset(fe, geom).PCTransformer
+    rows = SHA["cases"][geom]
+    frames = [synth.make_frame(r["frame"], gd["H"], gd["W"], vmax_deg=gd["vmax_deg"], vmin_deg=gd["vmin_deg"]).numpy() for r in rows]
+    for f, r in zip(frames, rows):
+        assert sha(f) == r["sha"]["xyz"], "the synthetic input is not the one the fixture was made from"
+    gms = np.array([r["ground_model"] for r in rows])
+    bc = fe.pl.BatchCompressor(T, accuracy=0.02)
+    blobs = bc.compress(frames, ground=gms)
+    buf = bc._buf
+    for b, r in enumerate(rows):
+        s, tag = r["sha"], (geom, r["frame"])
+        assert sha(buf.ri[b].cpu().numpy()) == s["ri"], tag
+        assert sha(buf.seg[b].cpu().numpy()) == s["seg_idx"], tag
+        assert sha(buf.model[b, :r["labels"]].cpu().numpy()) == s["model_param"], tag
+        n = int(buf.nnz[b])
+        assert n == r["nnz"] and sha(buf.q16[b, :n].cpu().numpy()) == s["q"], tag
+        assert len(blobs[b]) == r["rpcc_bytes"] and hashlib.sha256(blobs[b]).hexdigest() == s["rpcc"], tag
+    bn = fe.pl.BatchCompressor(T, accuracy=0.02, uniform=False, compressor_cfg=dict(orc.DEFAULT_CFG))
+    bn.compress(frames, ground=gms)
+    buf = bn._buf
+    for b, r in enumerate(rows):
+        s, tag = r["sha"], (geom, r["frame"], "non-uniform")
+        assert sha(buf.key_point_map[b].cpu().numpy()) == s["key_point_map"], tag
+        assert sha(buf.salience[b, :r["labels"]].cpu().numpy()) == s["salience"], tag
+        n = int(buf.nnz[b])
+        assert sha(buf.q16[b, :n].cpu().numpy()) == s["q_nonuniform"], tag
 
 
 def test_submits_in_flight_own_their_buffers(fe):
