@@ -36,8 +36,6 @@ extern "C" {
 #define RPCC_FPS_FMA2 4        /* ... or fma(dz,dz,fma(dy,dy,dx*dx)) */
 #define RPCC_FPS_TIE_CUDA 8    /* winner among exactly equal values = the survivor of the kernel's shared-memory tree
                                   (sampling_gpu.cu:16-21,55-69,74-134): smallest bit-reversed (k mod block), then smallest k */
-#define RPCC_ASSIGN_SEARCH 16  /* rpcc_batch_io.flags: the assignment (a7) searches the nearest centre of every pixel itself instead of
-                                  taking it from the state the pruned FPS leaves (identical labels; test reference for that hand-over) */
 
 /* Re-entrancy: the library keeps no per-call state of its own (a cache of kernel attributes already set, behind a
  * mutex, is all it holds); every call works on the caller's buffers and stream, so host threads may call concurrently
@@ -46,7 +44,7 @@ extern "C" {
 
 /* Interface version: changes whenever the layout of a struct below or the meaning of an argument changes (the structs carry no size
  * field).  A binding compares rpcc_version() with the RPCC_ABI_VERSION of the header it was built against before it calls anything else
- * (r-pcc_amd/_lib.py does).  100: round 3.  101: rpcc_batch_io.point_stride_bytes, RPCC_ASSIGN_SEARCH. */
+ * (r-pcc_amd/_lib.py does).  100: round 3.  101: rpcc_batch_io.point_stride_bytes. */
 #define RPCC_ABI_VERSION 101
 int rpcc_version(void);
 const char *rpcc_last_error(void);
@@ -298,7 +296,7 @@ typedef struct rpcc_batch_io {
     int16_t *q16;            /* dev i16 [B,P] out */
     int32_t *nnz;            /* dev i32 [B] out */
     int32_t *info;           /* dev i32 [B,8] out */
-    int32_t flags;           /* 0, RPCC_FPS_BRUTEFORCE, the CUDA-binary FPS modes RPCC_FPS_FMA1 / _FMA2 / _TIE_CUDA, RPCC_ASSIGN_SEARCH */
+    int32_t flags;           /* 0, RPCC_FPS_BRUTEFORCE, or the CUDA-binary FPS modes RPCC_FPS_FMA1 / _FMA2 / _TIE_CUDA */
     void *timer;             /* rpcc_timer_create() handle or NULL: times this call's FPS launch (bench.py) */
     /* framework / model selection (tools/compress.py:109-124, cfgs/compressor.yaml: compress_framework, modeling_method) */
     int32_t model_method;    /* 0: point model (a8);  1: plane model (a9: rpcc_plane_model with plane_cos_cut, plane_seed,

@@ -37,7 +37,6 @@ class NonuniformCfg(C.Structure):
 INFO_INTS = 8          # RPCC_INFO_INTS
 FPS_BRUTEFORCE = 1     # RPCC_FPS_BRUTEFORCE
 FPS_FMA1, FPS_FMA2, FPS_TIE_CUDA = 2, 4, 8   # RPCC_FPS_FMA1 / RPCC_FPS_FMA2 / RPCC_FPS_TIE_CUDA
-ASSIGN_SEARCH = 16     # RPCC_ASSIGN_SEARCH
 ABI_VERSION = 101      # RPCC_ABI_VERSION: the layout of rpcc_batch_io / rpcc_geom this binding was written for
 
 

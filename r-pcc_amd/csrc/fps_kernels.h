@@ -207,16 +207,13 @@ __device__ __forceinline__ void fps_load_point(const float *__restrict__ src, co
 #define FPS_TT_SMALL 1024
 #define FPS_GROUP 2
 #define FPS_FLAG_FINALIZE_TEMP 1  // write the origin class's value back to the empty pixels' temp entries at the end
-#define FPS_NEAR_TIE 255
-#define FPS_TIE_WINDOW 1.0000005f
-#define FPS_FLAG_LAST_PASS 2      // the last centre's distances enter temp / near as well (fused batch: the assignment reads them)
 
 template <bool RANGE, bool VEC, int FPS_TT>
 __global__ __launch_bounds__(FPS_TT) void fps_tiled_kernel(const float *__restrict__ src, const float *__restrict__ rays,
                                                            float *__restrict__ temp, const int32_t *__restrict__ info,
                                                            FpsTiling g, int M, int flags, int32_t *__restrict__ out_idx,
                                                            float *__restrict__ out_cen,
-                                                           const float *__restrict__ tiletab, uint8_t *__restrict__ near) {
+                                                           const float *__restrict__ tiletab) {
     extern __shared__ __attribute__((aligned(16))) unsigned char fps_smem[];
     __shared__ unsigned long long red[FPS_TT / 64];
     __shared__ int redt[FPS_TT / 64];
@@ -226,7 +223,6 @@ __global__ __launch_bounds__(FPS_TT) void fps_tiled_kernel(const float *__restri
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     src += (int64_t)b * N * (RANGE ? 1 : 3);
     temp += (int64_t)b * N;
-    if (near) near += (int64_t)b * N;
     out_idx += (int64_t)b * M;
     if (out_cen) out_cen += (int64_t)b * M * 3;
     if (M <= 0) return;
@@ -279,7 +275,7 @@ __global__ __launch_bounds__(FPS_TT) void fps_tiled_kernel(const float *__restri
     };
     // distance update against the current centre, tile maximum, (optionally) bounding box and the check that the
     // origin class is what the header says (all empty pixels candidates with one common temp)
-    auto compute_tile = [&](int t, const FpsQuad &q, bool with_box, int jc, bool last = false) {   // jc: index of the centre (c0, c1, c2); near, last: fps_tile_update
+    auto compute_tile = [&](int t, const FpsQuad &q, bool with_box) {
         float x[4], y[4], z[4], nt[4];
         uint32_t key[4];
         bool cand[4], ch = false, viol = false;
@@ -299,13 +295,12 @@ __global__ __launch_bounds__(FPS_TT) void fps_tiled_kernel(const float *__restri
             const bool c = nt[e] != tp;
             ch |= c;
             if (!VEC && c) st_f32(temp, (uint32_t)(q.p0 + e) * 4u, nt[e]);
-            if (near && c) st_at(near, (uint32_t)(q.p0 + e), (uint8_t)(tp <= d * FPS_TIE_WINDOW ? FPS_NEAR_TIE : jc));
             if (!c) nt[e] = q.tp[e];   // value to write back for an unchanged element
         }
         if (VEC && ch) st_at(reinterpret_cast<float4 *>(temp), (uint32_t)q.p0 * 4u, make_float4(nt[0], nt[1], nt[2], nt[3]));
         if (with_box && __ballot(viol) != 0ull && lane == 0) s_viol = 1;
         // nothing changed in this tile: its table entry (maximum, arg, coordinates) is still exact
-        if (last || (!with_box && __ballot(ch) == 0ull)) return;
+        if (!with_box && __ballot(ch) == 0ull) return;
         if (with_box) {
             float lo[3], hi[3];
             fps_tile_box(x, y, z, cand, lo, hi);
@@ -384,7 +379,7 @@ __global__ __launch_bounds__(FPS_TT) void fps_tiled_kernel(const float *__restri
                     fps_quad_load<RANGE, VEC>(src, rays, temp, q[gi]);
                 }
 #pragma unroll
-                for (int gi = 0; gi < GROUP; gi++) if (t + gi * NW < T) compute_tile(t + gi * NW, q[gi], true, 0);
+                for (int gi = 0; gi < GROUP; gi++) if (t + gi * NW < T) compute_tile(t + gi * NW, q[gi], true);
             }
             __syncthreads();
             // the origin class must be uniform (it is when temp comes from rpcc_ground_mask); a caller-made temp that
@@ -399,8 +394,7 @@ __global__ __launch_bounds__(FPS_TT) void fps_tiled_kernel(const float *__restri
         select_next();
         if (tid == 0) { out_idx[1] = old; if (out_cen) { out_cen[3] = c0; out_cen[4] = c1; out_cen[5] = c2; } }
     }
-    const int jend = (M > 1 && (flags & FPS_FLAG_LAST_PASS)) ? M + 1 : M;   // (the last centre's pass: fps_regtab_body)
-    for (int j = 2; j < jend; j++) {
+    for (int j = 2; j < M; j++) {
         // tile test against the new centre; active tiles go to the work list
         for (int t = tid; t < T; t += FPS_TT) {
             const float4 lo = L.lo4[t], hi = L.hi4[t];
@@ -431,10 +425,9 @@ __global__ __launch_bounds__(FPS_TT) void fps_tiled_kernel(const float *__restri
                 fps_quad_load<RANGE, VEC>(src, rays, temp, q[gi]);   // unconditional (a repeated tile for the tail is harmless and unused)
             }
 #pragma unroll
-            for (int gi = 0; gi < GROUP; gi++) if (e + gi * NW < n) compute_tile(tt[gi], q[gi], false, j - 1, j == M);
+            for (int gi = 0; gi < GROUP; gi++) if (e + gi * NW < n) compute_tile(tt[gi], q[gi], false);
         }
         __syncthreads();
-        if (j == M) break;
         if (tid == 0) wcount = 0;
         select_next();
         if (tid == 0) { out_idx[j] = old; if (out_cen) { out_cen[3 * j] = c0; out_cen[3 * j + 1] = c1; out_cen[3 * j + 2] = c2; } }
@@ -464,16 +457,9 @@ struct FpsTileOut { float lo[3], hi[3], wt, wx, wy, wz; uint32_t widx; };
 
 // update of one tile against centre (c0,c1,c2): returns true (wave-uniform) when its table entry changed (always with
 // with_box); the new entry comes back in `o`.  viol: an empty pixel is not what the origin class assumes (first pass only).
-// near (or NULL): u8 per point, the index jc of the centre that lowered the point's temp last -- with the strict '<' of the update that is
-// the LOWEST index among the centres at the point's minimum squared distance -- or FPS_NEAR_TIE when the minimum it replaced lies inside the
-// square root's tie window of the new one (the assignment then searches: two squared distances that round to one sqrtf tie, and
-// numpy's argmax keeps the lower index, utils/segment_utils.py:21-23,131).  Any lower-indexed centre inside the window of the FINAL minimum
-// was at or above the minimum replaced by the final one, so the mark is conservative.  last: the pass of the last centre (no selection follows:
-// no table entry).
 template <bool RANGE, bool VEC, bool EDGE = false>
 __device__ __forceinline__ bool fps_tile_update(const FpsQuad &q, bool org_on, float t_org0, float c0, float c1, float c2,
-                                                float *__restrict__ temp, bool with_box, FpsTileOut &o, bool &viol,
-                                                uint8_t *__restrict__ near = nullptr, int jc = 0, bool last = false) {
+                                                float *__restrict__ temp, bool with_box, FpsTileOut &o, bool &viol) {
     float x[4], y[4], z[4], nt[4];
     uint32_t key[4];
     bool cand[4], ch = false;
@@ -495,12 +481,11 @@ __device__ __forceinline__ bool fps_tile_update(const FpsQuad &q, bool org_on, f
         const bool c = nt[e] != tp;
         ch |= c;
         if ((!VEC || (EDGE && q.nval != 4)) && c) st_f32(temp, (uint32_t)(q.p0 + e) * 4u, nt[e]);   // (c implies a valid element)
-        if (near && c) st_at(near + e, (uint32_t)q.p0, (uint8_t)(tp <= d * FPS_TIE_WINDOW ? FPS_NEAR_TIE : jc));   // (the element as a constant offset of the base: one address register for the four)
         if (!c) nt[e] = q.tp[e];   // value to write back for an unchanged element
     }
     if (QUAD && ch) st_at(reinterpret_cast<float4 *>(temp), (uint32_t)q.p0 * 4u, make_float4(nt[0], nt[1], nt[2], nt[3]));
     if (VEC && EDGE && ch && q.nval == 4) st_at(reinterpret_cast<f32x4u *>(temp), (uint32_t)q.p0 * 4u, f32x4u{nt[0], nt[1], nt[2], nt[3]});
-    if (last || (!with_box && __ballot(ch) == 0ull)) return false;
+    if (!with_box && __ballot(ch) == 0ull) return false;
     // (Leaving the arg-max out when the point that holds the tile's maximum did not change -- the entry is then provably what it
     // was -- was measured in round 3: the holder has the largest temp of the tile, so it is the FIRST point a centre in reach
     // lowers; the test fired rarely, cost four compares per visit, and the kernel got 2 % slower.)
@@ -514,8 +499,7 @@ __device__ __forceinline__ void fps_regtab_body(const float *__restrict__ src, c
                                                 float *__restrict__ temp, const int32_t *__restrict__ info,
                                                 FpsTiling g, int M, int flags, int32_t *__restrict__ out_idx,
                                                 float *__restrict__ out_cen, const float *__restrict__ tiletab,
-                                                const float *__restrict__ rays_soa, const int b,   // b: the workgroup's frame
-                                                uint8_t *__restrict__ near = nullptr) {             // [B,N] nearest-centre indices (fps_tile_update) or NULL
+                                                const float *__restrict__ rays_soa, const int b) {   // b: the workgroup's frame
     constexpr int NW = FPS_TT / 64;
     TRACE_FPS_DECLS();      // (developer trace hooks: empty unless the library is built with -DRPCC_DEVTRACE, rpcc_trace.h)
     TRACE_FPS_WG(0);
@@ -526,7 +510,6 @@ __device__ __forceinline__ void fps_regtab_body(const float *__restrict__ src, c
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     src += (int64_t)b * N * (RANGE ? 1 : 3);
     temp += (int64_t)b * N;
-    if (near) near += (int64_t)b * N;
     out_idx += (int64_t)b * M;
     if (out_cen) out_cen += (int64_t)b * M * 3;
     if (M <= 0) return;
@@ -603,7 +586,7 @@ __device__ __forceinline__ void fps_regtab_body(const float *__restrict__ src, c
     // software-pipelined visits: 7 % faster alone, 3 % slower with batches in flight.)
     constexpr int FPS_VISIT = 2;          // tiles per visit round
     constexpr int FPS_VISIT_UNCOND = 1;   // tiles of a round loaded unconditionally; the second tile's loads are issued only when there is one
-    auto visit = [&](unsigned long long m, bool with_box, int jc, bool last = false) {   // jc: index of the centre (c0, c1, c2)
+    auto visit = [&](unsigned long long m, bool with_box) {
         bool viol = false;
         while (m) {
             int l[FPS_VISIT];
@@ -624,7 +607,7 @@ __device__ __forceinline__ void fps_regtab_body(const float *__restrict__ src, c
 #pragma unroll
             for (int u = 0; u < FPS_VISIT; u++) {
                 FpsTileOut o;
-                if (on[u] && fps_tile_update<RANGE, VEC, EDGE>(q[u], org_on, t_org0, c0, c1, c2, temp, with_box, o, viol, near, jc, last)) store_entry(l[u], o, with_box);
+                if (on[u] && fps_tile_update<RANGE, VEC, EDGE>(q[u], org_on, t_org0, c0, c1, c2, temp, with_box, o, viol)) store_entry(l[u], o, with_box);
             }
             TRACE_FPS_VISIT(2);
         }
@@ -698,13 +681,13 @@ __device__ __forceinline__ void fps_regtab_body(const float *__restrict__ src, c
         update_origin();  // (idempotent: temp of the empty pixels already holds the first centre's distance)
     } else if (M > 1) {
         __syncthreads();   // s_viol = 0 visible
-        visit(have_m, true, 0);
+        visit(have_m, true);
         __syncthreads();
         // the origin class must be uniform (it is when temp comes from rpcc_ground_mask); a caller-made temp that
         // treats the empty pixels individually is handled by a second pass without the class
         if (org_on && s_viol) {
             org_on = false; t_org = -1.0f;
-            visit(have_m, true, 0);
+            visit(have_m, true);
         }
         update_origin();
     }
@@ -713,10 +696,7 @@ __device__ __forceinline__ void fps_regtab_body(const float *__restrict__ src, c
         if (tid == 0) { out_idx[1] = old; if (out_cen) { out_cen[3] = c0; out_cen[4] = c1; out_cen[5] = c2; } }
     }
     TRACE_FPS_PHASE(0);
-    // FPS_FLAG_LAST_PASS: one more pass, with the last centre and without a selection -- temp then holds the minimum over ALL M centres
-    // and `near` the index that reaches it, which is what the assignment needs (assign_near_kernel); the reference's kernel stops before it
-    const int jend = (M > 1 && (flags & FPS_FLAG_LAST_PASS)) ? M + 1 : M;
-    for (int j = 2; j < jend; j++) {
+    for (int j = 2; j < M; j++) {
         // this wavefront's tiles against the new centre
         const float g0 = fmaxf(fmaxf(lo0 - c0, c0 - hi0), 0.0f);
         const float g1 = fmaxf(fmaxf(lo1 - c1, c1 - hi1), 0.0f);
@@ -725,8 +705,7 @@ __device__ __forceinline__ void fps_regtab_body(const float *__restrict__ src, c
         const unsigned long long vm = __ballot(have && bound < tmax);
         TRACE_FPS_TILES(vm, j);
         TRACE_FPS_PHASE(1);
-        if (j == M) { visit(vm, false, j - 1, true); update_origin(); break; }
-        visit(vm, false, j - 1);
+        visit(vm, false);
         TRACE_FPS_PHASE(2);
         update_origin();
         select_next();
@@ -752,15 +731,14 @@ __device__ __forceinline__ void fps_regtab_body(const float *__restrict__ src, c
 template <bool RANGE, bool VEC, int FPS_TT, bool EDGE = false>
 __global__ __launch_bounds__(FPS_TT) __attribute__((amdgpu_waves_per_eu(4, 8))) void fps_regtab_kernel(
     const float *__restrict__ src, const float *__restrict__ rays, float *__restrict__ temp, const int32_t *__restrict__ info, FpsTiling g, int M,
-    int flags, int32_t *__restrict__ out_idx, float *__restrict__ out_cen, const float *__restrict__ tiletab, uint8_t *__restrict__ near) {
-    fps_regtab_body<RANGE, VEC, FPS_TT, false, EDGE>(src, rays, temp, info, g, M, flags, out_idx, out_cen, tiletab, nullptr, blockIdx.x, near);
+    int flags, int32_t *__restrict__ out_idx, float *__restrict__ out_cen, const float *__restrict__ tiletab) {
+    fps_regtab_body<RANGE, VEC, FPS_TT, false, EDGE>(src, rays, temp, info, g, M, flags, out_idx, out_cen, tiletab, nullptr, blockIdx.x);
 }
 template <int FPS_TT, bool EDGE = false>
 __global__ __launch_bounds__(FPS_TT) __attribute__((amdgpu_waves_per_eu(5, 8))) void fps_regtab_planar_kernel(
     const float *__restrict__ src, const float *__restrict__ rays, float *__restrict__ temp, const int32_t *__restrict__ info, FpsTiling g, int M,
-    int flags, int32_t *__restrict__ out_idx, float *__restrict__ out_cen, const float *__restrict__ tiletab, const float *__restrict__ rays_soa,
-    uint8_t *__restrict__ near) {
-    fps_regtab_body<true, true, FPS_TT, true, EDGE>(src, rays, temp, info, g, M, flags, out_idx, out_cen, tiletab, rays_soa, blockIdx.x, near);
+    int flags, int32_t *__restrict__ out_idx, float *__restrict__ out_cen, const float *__restrict__ tiletab, const float *__restrict__ rays_soa) {
+    fps_regtab_body<true, true, FPS_TT, true, EDGE>(src, rays, temp, info, g, M, flags, out_idx, out_cen, tiletab, rays_soa, blockIdx.x);
 }
 // The same for the frames of several geometry groups in ONE launch (rpcc_compress_batch_mixed: variable H x W inside one call).  The device runs
 // as many kernels side by side as the process has hardware queues -- three or four -- and this kernel keeps one CU per frame busy for 99
@@ -774,7 +752,6 @@ struct FpsGroupArgs {
     int32_t *out_idx;
     float *out_cen;
     const float *tiletab, *rays_soa;
-    uint8_t *near;
 };
 struct FpsMulti {
     int n, first[RPCC_MAX_GROUPS + 1];   // group i owns the workgroups first[i] .. first[i + 1] - 1
@@ -787,8 +764,8 @@ __global__ __launch_bounds__(FPS_TT) __attribute__((amdgpu_waves_per_eu(5, 8))) 
     const FpsGroupArgs &a = m.a[gi];
     const int b = (int)blockIdx.x - m.first[gi];
     // (both access variants in one kernel, chosen per workgroup: the launch lasts as long as its slowest frame, two launches as long as both)
-    if (m.edge[gi]) fps_regtab_body<true, true, FPS_TT, true, true>(a.src, a.rays, a.temp, a.info, a.g, M, flags, a.out_idx, a.out_cen, a.tiletab, a.rays_soa, b, a.near);
-    else            fps_regtab_body<true, true, FPS_TT, true, false>(a.src, a.rays, a.temp, a.info, a.g, M, flags, a.out_idx, a.out_cen, a.tiletab, a.rays_soa, b, a.near);
+    if (m.edge[gi]) fps_regtab_body<true, true, FPS_TT, true, true>(a.src, a.rays, a.temp, a.info, a.g, M, flags, a.out_idx, a.out_cen, a.tiletab, a.rays_soa, b);
+    else            fps_regtab_body<true, true, FPS_TT, true, false>(a.src, a.rays, a.temp, a.info, a.g, M, flags, a.out_idx, a.out_cen, a.tiletab, a.rays_soa, b);
 }
 
 // ------------------------------------------------------------------------------------------------

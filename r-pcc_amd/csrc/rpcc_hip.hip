@@ -374,7 +374,6 @@ struct BatchInit {
     const float *tm; float *soa; int P;
     int32_t *info; int B;
     ZeroRange z0, z1, z2;
-    uint4 *zq; int nq;   // 16-byte words to clear (the nearest-centre indices: 0 = the first centre, whose pass the mask kernel runs)
     int on;
 };
 __device__ __forceinline__ int flag_mark(const int32_t *epoch) { return epoch ? *epoch + 1 : 1; }
@@ -475,7 +474,6 @@ __device__ __forceinline__ void batch_init(const BatchInit &init, int nthr, int 
     for (int p = t; p < init.z0.n; p += nthr) init.z0.p[p] = 0u;
     for (int p = t; p < init.z1.n; p += nthr) init.z1.p[p] = 0u;
     for (int p = t; p < init.z2.n; p += nthr) init.z2.p[p] = 0u;
-    for (int p = t; p < init.nq; p += nthr) init.zq[p] = make_uint4(0u, 0u, 0u, 0u);
 }
 // (the device-atomic projection path has no pixel kernel to carry the initialisations)
 __global__ __launch_bounds__(256) void batch_init_kernel(BatchInit init) { batch_init(init, gridDim.x * 256, blockIdx.x * 256 + threadIdx.x); }
@@ -1807,27 +1805,27 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_modes_kernel(const float *__r
 template <bool RANGE>
 static int launch_fps_tiled(const float *src, const float *rays, float *temp, const int32_t *info, int B, const FpsTiling &g,
                             int M, int kflags, int32_t *idx, float *cen, const float *tiletab, bool vec, hipStream_t st,
-                            const float *rays_soa = nullptr, bool edge = false, uint8_t *near = nullptr) {
+                            const float *rays_soa = nullptr, bool edge = false) {
     // edge (range images only): the width is no multiple of four -- the quad kernels run with 4-byte aligned 16-byte accesses
     const size_t sh = fps_tiled_lds_bytes(g.T);
     // register-table form: every tile owned by one lane (at most 64 tiles per wavefront)
-#define FPS_RT_LAUNCH(VEC_, TT_) fps_regtab_kernel<RANGE, VEC_, TT_><<<B, TT_, 0, st>>>(src, rays, temp, info, g, M, kflags, idx, cen, tiletab, near)
+#define FPS_RT_LAUNCH(VEC_, TT_) fps_regtab_kernel<RANGE, VEC_, TT_><<<B, TT_, 0, st>>>(src, rays, temp, info, g, M, kflags, idx, cen, tiletab)
     {
         const int tt = B <= 128 ? FPS_TT_SMALL : FPS_TT_BATCH;
         if constexpr (RANGE) if (g.T <= tt && (vec || edge) && rays_soa != nullptr) {   // planar copy of the ray table (the fused batch has one)
             if (edge) {
-                if (B <= 128) fps_regtab_planar_kernel<FPS_TT_SMALL, true><<<B, FPS_TT_SMALL, 0, st>>>(src, rays, temp, info, g, M, kflags, idx, cen, tiletab, rays_soa, near);
-                else          fps_regtab_planar_kernel<FPS_TT_BATCH, true><<<B, FPS_TT_BATCH, 0, st>>>(src, rays, temp, info, g, M, kflags, idx, cen, tiletab, rays_soa, near);
+                if (B <= 128) fps_regtab_planar_kernel<FPS_TT_SMALL, true><<<B, FPS_TT_SMALL, 0, st>>>(src, rays, temp, info, g, M, kflags, idx, cen, tiletab, rays_soa);
+                else          fps_regtab_planar_kernel<FPS_TT_BATCH, true><<<B, FPS_TT_BATCH, 0, st>>>(src, rays, temp, info, g, M, kflags, idx, cen, tiletab, rays_soa);
             } else {
-                if (B <= 128) fps_regtab_planar_kernel<FPS_TT_SMALL><<<B, FPS_TT_SMALL, 0, st>>>(src, rays, temp, info, g, M, kflags, idx, cen, tiletab, rays_soa, near);
-                else          fps_regtab_planar_kernel<FPS_TT_BATCH><<<B, FPS_TT_BATCH, 0, st>>>(src, rays, temp, info, g, M, kflags, idx, cen, tiletab, rays_soa, near);
+                if (B <= 128) fps_regtab_planar_kernel<FPS_TT_SMALL><<<B, FPS_TT_SMALL, 0, st>>>(src, rays, temp, info, g, M, kflags, idx, cen, tiletab, rays_soa);
+                else          fps_regtab_planar_kernel<FPS_TT_BATCH><<<B, FPS_TT_BATCH, 0, st>>>(src, rays, temp, info, g, M, kflags, idx, cen, tiletab, rays_soa);
             }
             LAUNCH_CHECK();
             return RPCC_OK;
         }
         if constexpr (RANGE) if (g.T <= tt && edge) {
-            if (B <= 128) fps_regtab_kernel<true, true, FPS_TT_SMALL, true><<<B, FPS_TT_SMALL, 0, st>>>(src, rays, temp, info, g, M, kflags, idx, cen, tiletab, near);
-            else          fps_regtab_kernel<true, true, FPS_TT_BATCH, true><<<B, FPS_TT_BATCH, 0, st>>>(src, rays, temp, info, g, M, kflags, idx, cen, tiletab, near);
+            if (B <= 128) fps_regtab_kernel<true, true, FPS_TT_SMALL, true><<<B, FPS_TT_SMALL, 0, st>>>(src, rays, temp, info, g, M, kflags, idx, cen, tiletab);
+            else          fps_regtab_kernel<true, true, FPS_TT_BATCH, true><<<B, FPS_TT_BATCH, 0, st>>>(src, rays, temp, info, g, M, kflags, idx, cen, tiletab);
             LAUNCH_CHECK();
             return RPCC_OK;
         }
@@ -1842,7 +1840,7 @@ static int launch_fps_tiled(const float *src, const float *rays, float *temp, co
 #define FPS_LAUNCH(VEC_, TT_)                                                                                        \
     do {                                                                                                             \
         HIP_TRY(ensure_dyn_lds(reinterpret_cast<const void *>(&fps_tiled_kernel<RANGE, VEC_, TT_>), (int)sh));       \
-        fps_tiled_kernel<RANGE, VEC_, TT_><<<B, TT_, sh, st>>>(src, rays, temp, info, g, M, kflags, idx, cen, tiletab, near); \
+        fps_tiled_kernel<RANGE, VEC_, TT_><<<B, TT_, sh, st>>>(src, rays, temp, info, g, M, kflags, idx, cen, tiletab); \
     } while (0)
     if (B <= 128) { if (vec) FPS_LAUNCH(true, FPS_TT_SMALL); else FPS_LAUNCH(false, FPS_TT_SMALL); }
     else          { if (vec) FPS_LAUNCH(true, FPS_TT_BATCH); else FPS_LAUNCH(false, FPS_TT_BATCH); }
@@ -1887,7 +1885,7 @@ extern "C" int rpcc_fps_xyz_mode(int B, int N, int M, const float *points, float
 // flags: RPCC_FPS_BRUTEFORCE -> the one-pass-per-centre kernel; finalize_temp: temp is read by the caller afterwards
 static int launch_fps_range(const float *ri, const float *tm, float *temp, const int32_t *info, int B, int H, int W, int M,
                             int32_t *cen_pix, float *centers, int flags, bool finalize_temp, const float *tiletab,
-                            void *timer, hipStream_t st, const float *rays_soa = nullptr, uint8_t *near = nullptr) {   // near: also runs the last centre's pass
+                            void *timer, hipStream_t st, const float *rays_soa = nullptr) {
     const int P = H * W;
     const FpsTiling g = fps_tiling_range(H, W);
     const bool brute = (flags & RPCC_FPS_BRUTEFORCE) != 0;
@@ -1903,8 +1901,8 @@ static int launch_fps_range(const float *ri, const float *tm, float *temp, const
     if (!brute && g.T <= FPS_TILED_MAX_TILES && P < (1 << 22)) {
         const bool vec = (W % 4 == 0) && aligned16(ri) && aligned16(temp) && aligned16(tm);
         FpsTimer tmr(st, timer);
-        return launch_fps_tiled<true>(ri, tm, temp, info, B, g, M, (finalize_temp ? FPS_FLAG_FINALIZE_TEMP : 0) | (near ? FPS_FLAG_LAST_PASS : 0),
-                                      cen_pix, centers, tiletab, vec, st, rays_soa, !vec, near);
+        return launch_fps_tiled<true>(ri, tm, temp, info, B, g, M, finalize_temp ? FPS_FLAG_FINALIZE_TEMP : 0, cen_pix, centers,
+                                      tiletab, vec, st, rays_soa, !vec);
     }
     if (tiletab != nullptr && !brute)
         return set_err(RPCC_ERR_ARG, "fps_range: an FPS table was produced but the tiled kernel cannot run (image too large)%s%s");
@@ -2186,199 +2184,11 @@ __global__ __launch_bounds__(64 * ASSIGN_WAVES) ASSIGN_VGPR_ATTR void assign_ker
     }
 }
 
-
-// v6 (round 5): the FPS hands over its answer.  Every pass of the pruned FPS lowers temp where the new centre is nearer; with
-// FPS_FLAG_LAST_PASS the last centre's pass runs too, so for a candidate pixel temp IS the minimum squared distance over all M
-// centres (the same un-fused fp32 expression on the same operands) and `near` the lowest index that reaches it -- or FPS_NEAR_TIE when a
-// lower-indexed centre may lie inside the square root's tie window (fps_tile_update).  Such a pixel needs no distance at all: only the
-// ground-versus-cluster compare of assign_label.  The pixels that need the SEARCH of the kernel above are the ones the FPS knows
-// nothing about -- non-candidates (the ground), the tie marks, a temp that never fell below its initial 1e10 -- and only they enter the
-// tile's box and reach, so a tile of objects runs no centre screen and a mixed tile keeps fewer survivors.
-// Tiles are the FPS's: 8 rows x 32 columns, four consecutive pixels per lane (one 16-byte load of the range image, of temp and of each
-// plane of the planar ray table, one 4-byte load of near, one 4-byte store of the labels).  VEC: W % 4 == 0.
-#define ASSIGN_NEAR_WAVES 4
-template <bool VEC>
-__global__ __launch_bounds__(64 * ASSIGN_NEAR_WAVES) void assign_near_kernel(const float *__restrict__ ri, const float *__restrict__ rays_soa,
-                                                                            const double *__restrict__ ground, const float *__restrict__ centers,
-                                                                            int H, int W, int M, uint8_t *__restrict__ seg,
-                                                                            const float *__restrict__ temp, const uint8_t *__restrict__ near) {
-    extern __shared__ __attribute__((aligned(16))) float4 cen4[];  // [M] (x,y,z,0)
-    const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int P = H * W;
-    const int tcols = (W + 31) >> 5, ntile = ((H + FPS_TROWS - 1) / FPS_TROWS) * tcols;
-    const int t0 = blockIdx.x * ASSIGN_NEAR_WAVES + wave;
-    const float *ri_b = ri + (int64_t)b * P, *temp_b = temp + (int64_t)b * P;
-    const uint8_t *near_b = near + (int64_t)b * P;
-    uint8_t *seg_b = seg + (int64_t)b * P;
-    // the tile's loads go out first (unconditional, clamped), then the centres: one trip to memory before the barrier, not two
-    int nval, p0;
-    float r[4], tx[4], ty[4], tz[4], tp[4];
-    uint32_t nb4;
-    {
-        const int t = min(t0, ntile - 1);
-        const int tr = t / tcols, tc = t - tr * tcols;
-        const int row = FPS_TROWS * tr + (lane >> 3), col = 32 * tc + 4 * (lane & 7);
-        nval = (t0 < ntile && row < H) ? min(max(W - col, 0), 4) : 0;
-        p0 = nval > 0 ? row * W + col : 0;
-        if (VEC) {
-            const float4 rv = ld_at(reinterpret_cast<const float4 *>(ri_b), (uint32_t)p0 * 4u);
-            const float4 tv = ld_at(reinterpret_cast<const float4 *>(temp_b), (uint32_t)p0 * 4u);
-            const float4 a = ld_at(reinterpret_cast<const float4 *>(rays_soa), (uint32_t)p0 * 4u);
-            const float4 bq = ld_at(reinterpret_cast<const float4 *>(rays_soa + P), (uint32_t)p0 * 4u);
-            const float4 c = ld_at(reinterpret_cast<const float4 *>(rays_soa + 2 * (size_t)P), (uint32_t)p0 * 4u);
-            nb4 = ld_at(reinterpret_cast<const uint32_t *>(near_b), (uint32_t)p0);
-            r[0] = rv.x; r[1] = rv.y; r[2] = rv.z; r[3] = rv.w; tp[0] = tv.x; tp[1] = tv.y; tp[2] = tv.z; tp[3] = tv.w;
-            tx[0] = a.x; tx[1] = a.y; tx[2] = a.z; tx[3] = a.w; ty[0] = bq.x; ty[1] = bq.y; ty[2] = bq.z; ty[3] = bq.w;
-            tz[0] = c.x; tz[1] = c.y; tz[2] = c.z; tz[3] = c.w;
-        } else {
-            nb4 = 0u;
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const uint32_t pe = (uint32_t)(p0 + (e < nval ? e : 0));
-                r[e] = ld_f32(ri_b, pe * 4u); tp[e] = ld_f32(temp_b, pe * 4u);
-                tx[e] = ld_f32(rays_soa, pe * 4u); ty[e] = ld_f32(rays_soa + P, pe * 4u); tz[e] = ld_f32(rays_soa + 2 * (size_t)P, pe * 4u);
-                nb4 |= (uint32_t)ld_at(near_b, pe) << (8 * e);
-            }
-        }
-    }
-    for (int i = threadIdx.x; i < M; i += blockDim.x) {
-        const float *c = centers + ((int64_t)b * M + i) * 3;
-        cen4[i] = make_float4(c[0], c[1], c[2], 0.0f);
-    }
-    __syncthreads();
-    if (t0 >= ntile) return;
-    AssignGround G;
-    G.a = ground[4 * b]; G.b = ground[4 * b + 1]; G.c = ground[4 * b + 2]; G.d = ground[4 * b + 3];
-    G.af = (float)G.a; G.bf = (float)G.b; G.cf = (float)G.c; G.df = (float)G.d;
-    G.S = (float)((fabs(G.a) + fabs(G.b) + fabs(G.c)) * 1.001);
-    const float inf = __builtin_inff();
-    bool live[4], search[4], fastp[4];
-    float x[4], y[4], z[4], m1[4], m2[4];
-    int k1[4];
-    bool any_live = false, any_search = false;
-#pragma unroll
-    for (int e = 0; e < 4; e++) {
-        const bool valid = e < nval;
-        if (!valid) r[e] = 0.0f;
-        x[e] = r[e] * tx[e]; y[e] = r[e] * ty[e]; z[e] = r[e] * tz[e];
-        live[e] = r[e] != 0.0f;
-        const int nb = (int)((nb4 >> (8 * e)) & 255u);
-        fastp[e] = live[e] && tp[e] >= 0.0f && tp[e] < 1e10f && nb != FPS_NEAR_TIE;
-        search[e] = live[e] && !fastp[e];
-        m1[e] = fastp[e] ? tp[e] : inf; m2[e] = inf; k1[e] = fastp[e] ? nb : -1;
-        any_live |= live[e]; any_search |= search[e];
-    }
-    auto store_labels = [&](const int (&lab)[4]) {
-        if (VEC) {
-            if (nval > 0) st_at(reinterpret_cast<uint32_t *>(seg_b), (uint32_t)p0, (uint32_t)lab[0] | ((uint32_t)lab[1] << 8) | ((uint32_t)lab[2] << 16) | ((uint32_t)lab[3] << 24));
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; e++) if (e < nval) st_at(seg_b, (uint32_t)(p0 + e), (uint8_t)lab[e]);
-        }
-    };
-    if (__ballot(any_live) == 0ull) {  // nothing but empty pixels
-        const int lab[4] = {1, 1, 1, 1};
-        store_labels(lab);
-        return;
-    }
-    if (__ballot(any_search) != 0ull) {   // (wave-uniform) the search of assign_kernel over the pixels that need it
-        float lo0 = inf, lo1 = inf, lo2 = inf, hi0 = -inf, hi1 = -inf, hi2 = -inf;
-        {
-            const float qnan = u2f(0x7FC00000u);
-            float bx[4], by[4], bz[4];
-#pragma unroll
-            for (int e = 0; e < 4; e++) { bx[e] = search[e] ? x[e] : qnan; by[e] = search[e] ? y[e] : qnan; bz[e] = search[e] ? z[e] : qnan; }
-#pragma unroll
-            for (int e = 0; e < 4; e += 2) {
-                lo0 = fmin3_raw(lo0, bx[e], bx[e + 1]); hi0 = fmax3_raw(hi0, bx[e], bx[e + 1]);
-                lo1 = fmin3_raw(lo1, by[e], by[e + 1]); hi1 = fmax3_raw(hi1, by[e], by[e + 1]);
-                lo2 = fmin3_raw(lo2, bz[e], bz[e + 1]); hi2 = fmax3_raw(hi2, bz[e], bz[e + 1]);
-            }
-        }
-        dpp_box6(lo0, lo1, lo2, hi0, hi1, hi2);
-        float reach = 0.0f;
-#pragma unroll
-        for (int e = 0; e < 4; e++)   // (a temp that never fell below 1e10 bounds nothing)
-            reach = fmaxf(reach, search[e] ? assign_reach(r[e], tx[e], ty[e], tz[e], tp[e] < 1e10f ? tp[e] : -1.0f, G) : 0.0f);
-        reach = dpp_max_f32_native(reach);
-        const bool bounded = reach < inf;   // (wave-uniform) otherwise: the box bound min_j dmax_j of assign_kernel's header
-        float my_dmin[4], upper = inf;
-#pragma unroll
-        for (int rd = 0; rd < 4; rd++) {
-            const int k = rd * 64 + lane;
-            my_dmin[rd] = inf;
-            if (rd * 64 < M && k < M) {
-                const float4 cc = cen4[k];
-                const float a0 = lo0 - cc.x, b0 = cc.x - hi0, a1 = lo1 - cc.y, b1 = cc.y - hi1, a2 = lo2 - cc.z, b2 = cc.z - hi2;
-                const float g0 = fmaxf(fmaxf(a0, b0), 0.0f), g1 = fmaxf(fmaxf(a1, b1), 0.0f), g2 = fmaxf(fmaxf(a2, b2), 0.0f);
-                my_dmin[rd] = (g0 * g0 + g1 * g1) + g2 * g2;
-                if (!bounded) {
-                    const float f0 = fmaxf(fabsf(a0), fabsf(b0)), f1 = fmaxf(fabsf(a1), fabsf(b1)), f2 = fmaxf(fabsf(a2), fabsf(b2));
-                    upper = fminf(upper, (f0 * f0 + f1 * f1) + f2 * f2);
-                }
-            }
-        }
-        if (!bounded) upper = dpp_min_f32_native(upper);
-        const float cut = (bounded ? reach : upper) * 1.000002f;
-        rs_v2f xv[2], yv[2], zv[2];
-#pragma unroll
-        for (int e2 = 0; e2 < 2; e2++) {
-            xv[e2] = rs_v2f{x[2 * e2], x[2 * e2 + 1]}; yv[e2] = rs_v2f{y[2 * e2], y[2 * e2 + 1]}; zv[e2] = rs_v2f{z[2 * e2], z[2 * e2 + 1]};
-        }
-#pragma unroll
-        for (int rd = 0; rd < 4; rd++) {
-            if (rd * 64 >= M) break;
-            unsigned long long surv = __ballot(my_dmin[rd] <= cut);
-            while (surv) {
-                const int k = rd * 64 + (int)__ffsll((long long)surv) - 1;
-                surv &= surv - 1ull;
-                const float4 cc = cen4[k];
-#pragma unroll
-                for (int e2 = 0; e2 < 2; e2++) {
-                    const rs_v2f dx = xv[e2] - rs_v2f{cc.x, cc.x}, dy = yv[e2] - rs_v2f{cc.y, cc.y}, dz = zv[e2] - rs_v2f{cc.z, cc.z};
-                    const rs_v2f dd = (dx * dx + dy * dy) + dz * dz;
-#pragma unroll
-                    for (int e1 = 0; e1 < 2; e1++) {
-                        const int e = 2 * e2 + e1;
-                        const float d2 = e1 ? dd.y : dd.x;
-                        // (a pixel the FPS answered holds the true minimum already: d2 < m1 never fires for it)
-                        const bool lt = d2 < m1[e];
-                        m2[e] = __builtin_amdgcn_fmed3f(m1[e], m2[e], d2);
-                        k1[e] = lt ? k : k1[e];
-                        m1[e] = lt ? d2 : m1[e];
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < 4; e++) m2[e] = fastp[e] ? inf : m2[e];   // no tie search for the pixels the FPS answered
-    }
-    int lab[4];
-#pragma unroll
-    for (int e = 0; e < 4; e++) {
-        lab[e] = live[e] ? assign_label(r[e], tx[e], ty[e], tz[e], x[e], y[e], z[e], m1[e], m2[e], k1[e], cen4, G) : 1;
-    }
-    store_labels(lab);
-}
-
 static int launch_assign(const float *ri, const float *tm, const double *ground, const float *centers, int B, int H,
                          int W, int M, uint8_t *seg, hipStream_t st, const float *temp = nullptr) {
     const int ntile = ((H + ASSIGN_ROWS - 1) / ASSIGN_ROWS) * ((W + 31) / 32);
     const dim3 grid((ntile + ASSIGN_WAVES * ASSIGN_TILES_PER_WAVE - 1) / (ASSIGN_WAVES * ASSIGN_TILES_PER_WAVE), B);
     assign_kernel<<<grid, 64 * ASSIGN_WAVES, (size_t)M * sizeof(float4), st>>>(ri, tm, ground, centers, H, W, M, seg, temp);
-    LAUNCH_CHECK();
-    return RPCC_OK;
-}
-
-
-// near != NULL (with temp and the planar ray table): assign_near_kernel on what the FPS left (launch_fps_range with `near`)
-static int launch_assign_near(const float *ri, const float *rays_soa, const double *ground, const float *centers, int B, int H,
-                              int W, int M, uint8_t *seg, hipStream_t st, const float *temp, const uint8_t *near) {
-    const int ntile = ((H + FPS_TROWS - 1) / FPS_TROWS) * ((W + 31) / 32);
-    const dim3 grid((ntile + ASSIGN_NEAR_WAVES - 1) / ASSIGN_NEAR_WAVES, B);
-    const bool vec = (W % 4 == 0) && aligned16(ri) && aligned16(temp) && aligned16(rays_soa) && ((uintptr_t)near & 3u) == 0 && ((uintptr_t)seg & 3u) == 0;
-    if (vec) assign_near_kernel<true><<<grid, 64 * ASSIGN_NEAR_WAVES, (size_t)M * sizeof(float4), st>>>(ri, rays_soa, ground, centers, H, W, M, seg, temp, near);
-    else     assign_near_kernel<false><<<grid, 64 * ASSIGN_NEAR_WAVES, (size_t)M * sizeof(float4), st>>>(ri, rays_soa, ground, centers, H, W, M, seg, temp, near);
     LAUNCH_CHECK();
     return RPCC_OK;
 }
@@ -2423,12 +2233,10 @@ static WsLayout ws_layout(void *ws, int B, int P, int M) {
 static size_t plane_extra_bytes(int B, int P, int M) {   // label-ordered pixel list u32 [B,P] | points float4 [B,P] | key points per label i32 [B,K] | label steps f32 [B,K]
     return (((size_t)B * P * 4 + 255) & ~(size_t)255) + (size_t)B * P * 16 + 2 * (((size_t)B * (M + 2) * 4 + 255) & ~(size_t)255) + 256;
 }
-static inline size_t near_bytes(int B, int P) { return (((size_t)B * P) + 255) & ~(size_t)255; }
 static size_t slice_workspace_bytes(int B, int P, int M, int64_t total_points) {
     const size_t model_ws = ws_layout(nullptr, B, P, M).bytes;
     const size_t proj_ws = (project_scratch_bytes(total_points, B, P) + 255) & ~(size_t)255;
     return model_ws + 256 + proj_ws + (size_t)B * P * 4        // + FPS temp [B,P] f32
-           + near_bytes(B, P)                                   // + nearest-centre indices [B,P] u8
            + (size_t)3 * P * 4 + 256                            // + SoA copy of the ray table
            + (size_t)B * FPS_TAB_ROWS * ((P + 31) / 32 + 4096) * 4 + 256;  // + FPS tile table (generous bound)
 }
@@ -3147,7 +2955,6 @@ struct BatchPlan {
     char *proj_scratch, *extra;
     size_t proj_bytes;
     float *temp, *rays_soa, *tiletab, *label_acc;
-    uint8_t *near;   // nearest-centre indices the FPS leaves for the assignment (NULL: the FPS kernel in use does not write them)
     int32_t *zcnt, *epoch, *kpn;
     BatchInit bi;
 };
@@ -3160,8 +2967,7 @@ static BatchPlan plan_batch(const rpcc_batch_io *io, int Bs, int64_t npts, rpcc_
     p.proj_scratch = ws + p.L.bytes + 256;
     p.proj_bytes = (project_scratch_bytes(npts, Bs, P) + 255) & ~(size_t)255;
     p.temp = reinterpret_cast<float *>(p.proj_scratch + p.proj_bytes);
-    p.near = reinterpret_cast<uint8_t *>(p.temp + (size_t)Bs * P);
-    p.rays_soa = reinterpret_cast<float *>(p.near + near_bytes(Bs, P));
+    p.rays_soa = p.temp + (size_t)Bs * P;
     p.tiletab = p.rays_soa + (size_t)3 * P + 64;
     p.zcnt = p.fit_ground ? reinterpret_cast<int32_t *>(p.tiletab) : nullptr;  // the tile table is written later
     // The first kernel of the batch (the pixel kernel) also writes the planar ray table (band kernel's z), initialises the info
@@ -3179,9 +2985,6 @@ static BatchPlan plan_batch(const rpcc_batch_io *io, int Bs, int64_t npts, rpcc_
     p.bi.z2 = {reinterpret_cast<uint32_t *>(p.kpn), p.kpn ? Bs * (M + 2) : 0};  // key points per label
     p.brute = (io->flags & (RPCC_FPS_BRUTEFORCE | RPCC_FPS_MODE_BITS)) != 0;   // a mode flag selects the reference kernel too
     p.tiled = !p.brute && fps_tiling_range(g.H, g.W).T <= FPS_TILED_MAX_TILES;
-    p.bi.zq = nullptr; p.bi.nq = 0;
-    if (!p.tiled || P >= (1 << 22) || M > FPS_NEAR_TIE || !FPS_SOA || (io->flags & RPCC_ASSIGN_SEARCH)) p.near = nullptr;   // (launch_fps_range's conditions for the pruned kernels)
-    if (p.near) { p.bi.zq = reinterpret_cast<uint4 *>(p.near); p.bi.nq = (int)(near_bytes(Bs, P) / 16); }
     return p;
 }
 // The launches of a batch in order, as stages: the three marked (*) are the kernels with one workgroup per frame or per label, which
@@ -3203,13 +3006,11 @@ static int run_stage(const BatchPlan &p, int stage, hipStream_t st) {
                                   p.tiled ? p.tiletab : nullptr, st, false, true);
     case ST_FPS:
         return launch_fps_range(io->ri, io->tm, p.temp, io->info, Bs, p.g.H, p.g.W, M, io->cen_pix, io->centers, io->flags, false,
-                                p.tiled ? p.tiletab : nullptr, io->timer, st, FPS_SOA ? p.rays_soa : nullptr, p.near);
+                                p.tiled ? p.tiletab : nullptr, io->timer, st, FPS_SOA ? p.rays_soa : nullptr);
     case ST_ASSIGN_LABELS:
         // (the FPS state is the un-fused minimum the assignment's bound needs; a CUDA-binary mode contracts it)
-        if (p.near) rc = launch_assign_near(io->ri, p.rays_soa, io->ground, io->centers, Bs, p.g.H, p.g.W, M, io->seg, st, p.temp, p.near);
-        else rc = launch_assign(io->ri, io->tm, io->ground, io->centers, Bs, p.g.H, p.g.W, M, io->seg, st,
-                                (io->flags & RPCC_FPS_MODE_BITS) ? nullptr : p.temp);
-        if (rc) return rc;
+        if ((rc = launch_assign(io->ri, io->tm, io->ground, io->centers, Bs, p.g.H, p.g.W, M, io->seg, st,
+                                (io->flags & RPCC_FPS_MODE_BITS) ? nullptr : p.temp))) return rc;
         if (io->model_method == 0) return launch_point_model(io->ri, io->seg, io->ground, Bs, P, M, io->model, io->counts, io->nnz, p.ws, st, true);
         if ((rc = launch_label_scan(io->seg, Bs, P, M, io->counts, io->nnz, p.ws, st, true))) return rc;
         return launch_label_order(io->ri, io->tm, io->seg, Bs, P, M, p.ws, p.extra, st);
@@ -3296,18 +3097,14 @@ static int mixed_fps(const BatchPlan *pl, int G, hipStream_t st) {
     for (int i = 0; i < G; i++) {
         if (!common[i]) continue;
         const BatchPlan &p = pl[i];
-        m.a[m.n] = {p.io->ri, p.io->tm, p.temp, p.io->info, fps_tiling_range(p.g.H, p.g.W), p.io->cen_pix, p.io->centers, p.tiletab, p.rays_soa, p.near};
+        m.a[m.n] = {p.io->ri, p.io->tm, p.temp, p.io->info, fps_tiling_range(p.g.H, p.g.W), p.io->cen_pix, p.io->centers, p.tiletab, p.rays_soa};
         m.edge[m.n] = edge[i] ? 1 : 0;
         m.first[m.n + 1] = m.first[m.n] + p.Bs;
         m.n++;
     }
     if (m.n > 0) {
-        bool all_near = true;   // (the last centre's pass is a property of the launch; a NULL near would only cost that pass)
-        for (int i = 0; i < m.n; i++) all_near = all_near && m.a[i].near != nullptr;
-        if (!all_near) for (int i = 0; i < m.n; i++) m.a[i].near = nullptr;
-        const int lastp = all_near ? FPS_FLAG_LAST_PASS : 0;
-        if (tt == FPS_TT_SMALL) fps_regtab_planar_multi_kernel<FPS_TT_SMALL><<<m.first[m.n], FPS_TT_SMALL, 0, st>>>(m, pl[0].M, lastp);
-        else                    fps_regtab_planar_multi_kernel<FPS_TT_BATCH><<<m.first[m.n], FPS_TT_BATCH, 0, st>>>(m, pl[0].M, lastp);
+        if (tt == FPS_TT_SMALL) fps_regtab_planar_multi_kernel<FPS_TT_SMALL><<<m.first[m.n], FPS_TT_SMALL, 0, st>>>(m, pl[0].M, 0);
+        else                    fps_regtab_planar_multi_kernel<FPS_TT_BATCH><<<m.first[m.n], FPS_TT_BATCH, 0, st>>>(m, pl[0].M, 0);
         LAUNCH_CHECK();
     }
     for (int i = 0; i < G; i++)

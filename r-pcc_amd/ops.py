@@ -369,7 +369,7 @@ def nonuniform_cfg(acc, cfg=None):
 
 def compress_batch(xyz, offsets, tm, ground, buf, ground_threshold=0.1, acc=0.04, ground_seed=-1, frame_ids=None,
                    fps_bruteforce=False, timer=None, model_method="point", angle_threshold=75, plane_seed=0, nonuniform=None,
-                   fps_fma=None, fps_cuda_tie=None, assign_search=False):
+                   fps_fma=None, fps_cuda_tie=None):
     """Fused a2..a13 for a batch, one call: FPS segmentation, point or plane model, uniform or non-uniform framework
     (tools/compress.py:93-125).  xyz: f32 [total,3], or the stored (x, y, z, intensity) rows f32 [total,4] (16-byte stride,
     no host-side slice).  ground f64 [B,4]: injected models when ground_seed < 0, otherwise output of the seeded
@@ -378,17 +378,16 @@ def compress_batch(xyz, offsets, tm, ground, buf, ground_threshold=0.1, acc=0.04
     (plane_seed, frame_ids) with the reference's angle validation.  nonuniform: a nonuniform_cfg() struct -> key points,
     salience levels (buf.salience) and per-label steps; None = uniform framework with step `acc`.
     fps_fma / fps_cuda_tie: the CUDA-binary FPS modes (_lib.fps_mode_flags); None = the environment variables RPCC_FPS_FMA
-    (0 / 1 / 2) and RPCC_FPS_TIE_CUDA, so every front-end (tools, pipeline, loader) honours them.
-    assign_search (test reference): the assignment searches every pixel's nearest centre instead of taking it from the FPS's state."""
+    (0 / 1 / 2) and RPCC_FPS_TIE_CUDA, so every front-end (tools, pipeline, loader) honours them."""
     io = _batch_io(xyz, offsets, tm, ground, buf, ground_seed, frame_ids, fps_bruteforce, timer, model_method, angle_threshold, plane_seed,
-                   nonuniform, fps_fma, fps_cuda_tie, assign_search)
+                   nonuniform, fps_fma, fps_cuda_tie)
     check(_lib.lib().rpcc_compress_batch(C.byref(io), buf.B, buf.geom, buf.M, float(ground_threshold), float(acc),
                                          ptr(buf.ws), stream()))
     return buf
 
 
 def _batch_io(xyz, offsets, tm, ground, buf, ground_seed=-1, frame_ids=None, fps_bruteforce=False, timer=None, model_method="point",
-              angle_threshold=75, plane_seed=0, nonuniform=None, fps_fma=None, fps_cuda_tie=None, assign_search=False):
+              angle_threshold=75, plane_seed=0, nonuniform=None, fps_fma=None, fps_cuda_tie=None):
     """The rpcc_batch_io of one geometry group (compress_batch's arguments); grows the group's workspace when the batch holds more points."""
     general = model_method != "point" or nonuniform is not None
     assert not general or buf.general, "BatchBuffers(..., general=True) is needed for the plane model / non-uniform framework"
@@ -402,8 +401,7 @@ def _batch_io(xyz, offsets, tm, ground, buf, ground_seed=-1, frame_ids=None, fps
                    int(ground_seed), ptr(fid).value if fid is not None else None, ptr(buf.ri).value, ptr(buf.seg).value,
                    ptr(buf.cen_pix).value, ptr(buf.centers).value, ptr(buf.model).value, ptr(buf.counts).value,
                    ptr(buf.q16).value, ptr(buf.nnz).value, ptr(buf.info).value,
-                   (_lib.FPS_BRUTEFORCE if fps_bruteforce else 0) | _lib.fps_mode_flags(fps_fma, fps_cuda_tie) |
-                   (_lib.ASSIGN_SEARCH if assign_search else 0),
+                   (_lib.FPS_BRUTEFORCE if fps_bruteforce else 0) | _lib.fps_mode_flags(fps_fma, fps_cuda_tie),
                    timer.h if timer is not None else None,
                    0 if model_method == "point" else 1, angle_cos_cut(angle_threshold) if model_method != "point" else 0.0,
                    int(plane_seed), C.addressof(nonuniform) if nonuniform is not None else None,
@@ -415,7 +413,7 @@ def _batch_io(xyz, offsets, tm, ground, buf, ground_seed=-1, frame_ids=None, fps
 def compress_batch_mixed(groups, ground_threshold=0.1, acc=0.04):
     """Fused a2..a13 for a batch that holds sweeps of several lidar geometries (variable H x W: BASELINE configs[4]), one call on the
     current stream.  groups: one dict per geometry with compress_batch's arguments (xyz, offsets, tm, ground, buf and, optionally,
-    ground_seed, frame_ids, model_method, angle_threshold, plane_seed, nonuniform, fps_bruteforce, fps_fma, fps_cuda_tie, assign_search); every buf is
+    ground_seed, frame_ids, model_method, angle_threshold, plane_seed, nonuniform, fps_bruteforce, fps_fma, fps_cuda_tie); every buf is
     a BatchBuffers of that geometry with the same cluster count.  The kernels with one workgroup per frame or label (ground RANSAC,
     FPS, plane fits) run once over all groups (include/rpcc_hip.h: rpcc_compress_batch_mixed).  -> the list of the groups' buffers."""
     G = len(groups)

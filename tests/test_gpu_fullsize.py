@@ -424,12 +424,11 @@ def _lattice_shells(env, radii):
     return np.concatenate(frames), offs
 
 
-@pytest.mark.parametrize("scene", ["default", "shell", "noise", "corridor", "lattice"])
-def test_assignment_from_the_fps_state_equals_the_search(env, scene):
-    """a7 in the fused batch takes every candidate pixel's nearest centre from what the pruned FPS leaves (its minimum squared distance
-    in temp, the index that reached it, the tie marks: assign_near_kernel); RPCC_ASSIGN_SEARCH makes it search as rpcc_assign does.
-    Both equal the oracle's labels (argmax over the fp64 ground term and the 100 fp32 radii, first maximum) on the headline scene, the
-    adversarial ones and on noise-free lattice sweeps that hold square-root ties between distinct squared distances."""
+@pytest.mark.parametrize("scene", ["shell", "noise", "corridor", "lattice"])
+def test_fused_labels_on_adversarial_and_tie_scenes(env, scene):
+    """a7 inside the fused batch (its bound is the nearest-centre distance the pruned FPS leaves in temp) against the oracle's labels --
+    argmax over the fp64 ground term and the 100 fp32 radii, first maximum -- on the adversarial scenes and on noise-free lattice sweeps
+    that hold square-root ties between DISTINCT squared distances with the lower index off the minimum."""
     torch, ops, synth, orc = env["torch"], env["ops"], env["synth"], env["orc"]
     g, tm, dev = env["g"], env["tm"], env["dev"]
     if scene == "lattice":
@@ -440,25 +439,18 @@ def test_assignment_from_the_fps_state_equals_the_search(env, scene):
         xyz_h, offs_h = xyz.cpu().numpy(), offs.cpu().numpy()
     B = offs_h.shape[0] - 1
     gm_h = np.tile(np.array([0.004, -0.003, 0.99998, 1.73]), (B, 1))
-    gms = torch.from_numpy(gm_h).to(dev)
-    out = {}
-    for search in (False, True):
-        buf = ops.BatchBuffers(B, env["geom"], 100, dev)
-        ops.compress_batch(xyz, offs, env["d_tm"], gms, buf, assign_search=search)
-        torch.cuda.synchronize()
-        out[search] = (buf.seg.cpu().numpy().reshape(B, -1), buf.q16.cpu().numpy(), buf.nnz.cpu().numpy(), buf.cen_pix.cpu().numpy())
-    for k, what in ((0, "labels"), (2, "counts"), (3, "FPS pixels")):
-        assert np.array_equal(out[False][k], out[True][k]), (scene, what)
-    for i in range(B):
-        assert np.array_equal(out[False][1][i, :out[False][2][i]], out[True][1][i, :out[True][2][i]]), (scene, i, "quantised residuals")
+    buf = ops.BatchBuffers(B, env["geom"], 100, dev)
+    ops.compress_batch(xyz, offs, env["d_tm"], torch.from_numpy(gm_h).to(dev), buf)
+    torch.cuda.synchronize()
+    seg, q16, nnz, pix = buf.seg.cpu().numpy().reshape(B, -1), buf.q16.cpu().numpy(), buf.nnz.cpu().numpy(), buf.cen_pix.cpu().numpy()
     ties = 0
     for i in range(B):
         o = orc.compress_frame(xyz_h[offs_h[i]:offs_h[i + 1]], g, tm, gm_h[i])
-        assert np.array_equal(out[False][3][i], o["fps_pix"]), (scene, i, "FPS pixels")
-        bad = np.flatnonzero(out[False][0][i] != o["seg_idx"].reshape(-1))
-        assert bad.size == 0, (scene, i, "labels", bad[:8], out[False][0][i][bad[:8]], o["seg_idx"].reshape(-1)[bad[:8]])
-        n = int(out[False][2][i])
-        assert n == o["q"].shape[0] and np.array_equal(out[False][1][i, :n], o["q"].astype(np.int16)), (scene, i, "quantised residuals")
+        assert np.array_equal(pix[i], o["fps_pix"]), (scene, i, "FPS pixels")
+        bad = np.flatnonzero(seg[i] != o["seg_idx"].reshape(-1))
+        assert bad.size == 0, (scene, i, "labels", bad[:8], seg[i][bad[:8]], o["seg_idx"].reshape(-1)[bad[:8]])
+        n = int(nnz[i])
+        assert n == o["q"].shape[0] and np.array_equal(q16[i, :n], o["q"].astype(np.int16)), (scene, i, "quantised residuals")
         if scene == "lattice":   # the sweep does hold what the test is about
             pc, cen = o["pc"].reshape(-1, 3), o["centers"].astype(np.float32)
             d = pc[:, None, :] - cen[None, :, :]
