@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)   # about one step, so very short runs under-report (5 steps: -8 %, 20: -2 %)
     ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
     ap.add_argument("--geom", default=None, help="HxW (default 64x2048; 64x2000 with --input)")
+    ap.add_argument("--lidar", default=None, help="geometry by registry name instead of --geom: a lidar type or a dataset of r-pcc_amd/dataset.py "
+                    "(Velodyne64E, Velodyne32E, VelodyneVLP16, KITTI_test = 80x2000, ...); the synthetic sweeps follow its field of view")
     ap.add_argument("--clusters", type=int, default=100)
     ap.add_argument("--accuracy", type=float, default=0.02)
     ap.add_argument("--config", type=int, default=1, choices=(1, 2),
@@ -307,7 +309,14 @@ def run_workload(a, ctx):
 
     geom_s = a.geom or ("64x2000" if a.input else "64x2048")
     H, W = (int(v) for v in geom_s.split("x"))
-    hfov, vmax, vmin = 360 * (np.pi / 180), 2.0 * (np.pi / 180), -24.9 * (np.pi / 180)
+    hfov_deg, vmax_deg, vmin_deg = 360, 2.0, -24.9
+    if getattr(a, "lidar", None):
+        from rpcc_amd import dataset as reg
+        from rpcc_amd.utils import load_yaml
+        y = load_yaml(reg.__lidar_cfg__[a.lidar] if a.lidar in reg.__lidar_cfg__ else reg.__dataset_cfg__[a.lidar])
+        H, W, hfov_deg, vmax_deg, vmin_deg = int(y["RANGE_IMAGE_HEIGHT"]), int(y["RANGE_IMAGE_WIDTH"]), y["HORIZONTAL_FOV"], y["VERTICAL_ANGLE_MAX"], y["VERTICAL_ANGLE_MIN"]
+        geom_s = "%dx%d" % (H, W)
+    hfov, vmax, vmin = hfov_deg * (np.pi / 180), vmax_deg * (np.pi / 180), vmin_deg * (np.pi / 180)
     geom = ops.make_geom(H, W, hfov, vmax, vmin)
     tm_np = ops.transform_map(H, W, hfov, vmax, vmin)
     P, M, B = H * W, a.clusters, a.batch
@@ -319,7 +328,7 @@ def run_workload(a, ctx):
     if a.input:
         xyz, offs = load_real_batch(a.input, ids, H, W, dev, shuffle=a.input_shuffle)
     else:
-        xyz, offs = synth.make_batch(ids, H, W, device=dev, scene=a.scene)
+        xyz, offs = synth.make_batch(ids, H, W, device=dev, scene=a.scene, vmax_deg=vmax_deg, vmin_deg=vmin_deg, hfov_deg=hfov_deg)
     offs_host = offs.cpu().numpy()
     fid = torch.as_tensor(np.asarray(ids, np.int64), device=dev)
     tm = torch.from_numpy(tm_np).to(dev)
@@ -525,7 +534,7 @@ def run_workload(a, ctx):
 
     # ---- after the timed region: the outputs of EVERY pipeline slot against the CPU oracle (sampled frames) ------------
     from oracle import oracle as orc
-    g_o = orc.LidarGeom(H=H, W=W, hfov_deg=360, vmax_deg=2.0, vmin_deg=-24.9)
+    g_o = orc.LidarGeom(H=H, W=W, hfov_deg=hfov_deg, vmax_deg=vmax_deg, vmin_deg=vmin_deg)
     cfg_o = dict(orc.DEFAULT_CFG, accuracy=a.accuracy, cluster_num=M)
     from rpcc_amd.utils import available_cpus
     threads = available_cpus()   # affinity mask capped by the cgroup quota: the CPUs the host leg really gets
@@ -598,7 +607,7 @@ def run_workload(a, ctx):
         valu_peak = VALU_SIMD_CYCLES_PER_S / mean_cyc if mean_cyc else None       # wave-instructions per second of THIS instruction mix
         step_valu_frac = pm["step_cycles"] / step_s / VALU_SIMD_CYCLES_PER_S if mean_cyc else None
         step_traffic_frac = pm["step_traffic"] / step_s / 1e9 / HBM_PEAK_GBS if pm and pm.get("step_traffic") else None
-        workload = ("configs[%d]: batch=%d %s Velodyne-64E frames (%dx%d) per GPU, %s, accuracy=%g, cluster_num=%d, ground plane by "
+        workload = ("configs[%d]: batch=%d %s " + ("%s" % a.lidar if getattr(a, "lidar", None) else "Velodyne-64E") + " frames (%dx%d) per GPU, %s, accuracy=%g, cluster_num=%d, ground plane by "
                     "seeded RANSAC inside the step" % (a.config, B, "real (%s, rotated copies, %s)" % (os.path.basename(a.input), "shuffled" if a.input_shuffle else "points in stored order") if a.input
                                                        else ("synthetic" if a.scene == "default" else "synthetic ADVERSARIAL scene '%s'" % a.scene),
                                                        H, W, "non-uniform + FPS + plane-model" if general else "uniform + FPS + point-model", a.accuracy, M))
@@ -810,7 +819,9 @@ def run_secondary(a, ctx):
         except Exception as e:  # noqa: BLE001
             sec[name] = {"error": str(e).splitlines()[0][:300] if str(e) else repr(e)}
     for name, kw in (("configs2_fused", dict(config=2, geom="64x2000", input=None)),
-                     ("real_sweep", dict(config=1, geom=None, input=os.path.join(ROOT, "tests", "golden", "example_64E.npz")))):
+                     ("real_sweep", dict(config=1, geom=None, input=os.path.join(ROOT, "tests", "golden", "example_64E.npz"))),
+                     # the reference's own KITTI_test table (dataset/__init__.py:21: 80 x 2000, 630 FPS tiles)
+                     ("kitti_test_80x2000", dict(config=1, geom=None, input=None, lidar="KITTI_test"))):
         b = copy.copy(a)
         for k, v in kw.items():
             setattr(b, k, v)

@@ -494,7 +494,8 @@ __device__ __forceinline__ bool fps_tile_update(const FpsQuad &q, bool org_on, f
     return true;
 }
 
-template <bool RANGE, bool VEC, int FPS_TT, bool SOA, bool EDGE = false>
+// TPL: tiles per lane (1; 2 for images with more tiles than the workgroup has lanes -- 80 x 2000, 128 x 2048: slot s of lane l is position (l + 64 s) NW + wave)
+template <bool RANGE, bool VEC, int FPS_TT, bool SOA, bool EDGE = false, int TPL = 1>
 __device__ __forceinline__ void fps_regtab_body(const float *__restrict__ src, const float *__restrict__ rays,
                                                 float *__restrict__ temp, const int32_t *__restrict__ info,
                                                 FpsTiling g, int M, int flags, int32_t *__restrict__ out_idx,
@@ -534,46 +535,60 @@ __device__ __forceinline__ void fps_regtab_body(const float *__restrict__ src, c
     }
     const float t_org0 = t_org;
 
-    // this lane's tile: position pos = lane * NW + wave in the skewed order -> tile id, packed origin
-    const int pos = lane * NW + wave;
-    const bool have = pos < T;
-    int my_t = 0;
-    uint32_t my_org = 0u;
-    if (have) {
-        if (RANGE) {
-            const int tr = pos / g.tcols, q = pos - tr * g.tcols;
-            int tc = q - (3 * tr) % g.tcols;
-            if (tc < 0) tc += g.tcols;
-            my_t = tr * g.tcols + tc;
-            const int ncol = min(32, g.W - 32 * tc), nrow = min(FPS_TROWS, g.H - FPS_TROWS * tr);
-            my_org = (uint32_t)(FPS_TROWS * tr * g.W + 32 * tc) | ((uint32_t)(ncol - 1) << 22) | ((uint32_t)(nrow - 1) << 27);
-        } else {
-            my_t = pos;
-        }
-    }
+    // this lane's tiles: position pos = (lane + 64 s) * NW + wave in the skewed order -> tile id, packed origin
+    bool have[TPL];
+    int my_t[TPL];
+    uint32_t my_org[TPL];
     const float inf = __builtin_inff();
-    float lo0 = inf, lo1 = inf, lo2 = inf, hi0 = -inf, hi1 = -inf, hi2 = -inf, tmax = -1.0f, cx = 0.0f, cy = 0.0f, cz = 0.0f;
-    uint32_t targ = 0u;
-    const unsigned long long have_m = __ballot(have);
+    float lo0[TPL], lo1[TPL], lo2[TPL], hi0[TPL], hi1[TPL], hi2[TPL], tmax[TPL], cx[TPL], cy[TPL], cz[TPL];
+    uint32_t targ[TPL];
+    unsigned long long have_m[TPL];
+#pragma unroll
+    for (int s = 0; s < TPL; s++) {
+        const int pos = (lane + 64 * s) * NW + wave;
+        have[s] = pos < T;
+        my_t[s] = 0; my_org[s] = 0u;
+        if (have[s]) {
+            if (RANGE) {
+                const int tr = pos / g.tcols, q = pos - tr * g.tcols;
+                int tc = q - (3 * tr) % g.tcols;
+                if (tc < 0) tc += g.tcols;
+                my_t[s] = tr * g.tcols + tc;
+                const int ncol = min(32, g.W - 32 * tc), nrow = min(FPS_TROWS, g.H - FPS_TROWS * tr);
+                my_org[s] = (uint32_t)(FPS_TROWS * tr * g.W + 32 * tc) | ((uint32_t)(ncol - 1) << 22) | ((uint32_t)(nrow - 1) << 27);
+            } else {
+                my_t[s] = pos;
+            }
+        }
+        lo0[s] = lo1[s] = lo2[s] = inf; hi0[s] = hi1[s] = hi2[s] = -inf; tmax[s] = -1.0f; cx[s] = cy[s] = cz[s] = 0.0f; targ[s] = 0u;
+        have_m[s] = __ballot(have[s]);
+    }
     const int lrow = lane >> 3, lcol = 4 * (lane & 7);
-    // the quad of this lane in the tile owned by lane `l` (wave-uniform l)
-    auto locate = [&](int l, FpsQuad &q) {
+    // the quad of this lane in the tile owned by slot s of lane `l` (wave-uniform l, s)
+    auto locate = [&](int l, int s, FpsQuad &q) {
         if (RANGE) {
-            const uint32_t org = (uint32_t)__builtin_amdgcn_readlane((int)my_org, l);
+            uint32_t org = (uint32_t)__builtin_amdgcn_readlane((int)my_org[0], l);
+            if (TPL > 1 && s) org = (uint32_t)__builtin_amdgcn_readlane((int)my_org[TPL - 1], l);
             const int ncol = (int)((org >> 22) & 31u) + 1, nrow = (int)(org >> 27) + 1;
             const int nv = lrow < nrow ? min(max(ncol - lcol, 0), 4) : 0;
             q.nval = nv;
             q.p0 = nv > 0 ? (int)(org & 0x3FFFFFu) + lrow * g.W + lcol : 0;
         } else {
-            const int p = __builtin_amdgcn_readlane(my_t, l) * FPS_TILE + 4 * lane;
+            int tl = __builtin_amdgcn_readlane(my_t[0], l);
+            if (TPL > 1 && s) tl = __builtin_amdgcn_readlane(my_t[TPL - 1], l);
+            const int p = tl * FPS_TILE + 4 * lane;
             q.nval = min(max(N - p, 0), 4);
             q.p0 = q.nval > 0 ? p : 0;
         }
     };
-    auto store_entry = [&](int l, const FpsTileOut &o, bool with_box) {
-        if (lane == l) {
-            if (with_box) { lo0 = o.lo[0]; lo1 = o.lo[1]; lo2 = o.lo[2]; hi0 = o.hi[0]; hi1 = o.hi[1]; hi2 = o.hi[2]; }
-            tmax = o.wt; targ = o.widx; cx = o.wx; cy = o.wy; cz = o.wz;
+    static_assert(TPL == 1 || TPL == 2, "one or two tiles per lane");
+    auto store_entry = [&](int l, int s, const FpsTileOut &o, bool with_box) {
+#pragma unroll
+        for (int t = 0; t < TPL; t++) {
+            if (lane == l && s == t) {
+                if (with_box) { lo0[t] = o.lo[0]; lo1[t] = o.lo[1]; lo2[t] = o.lo[2]; hi0[t] = o.hi[0]; hi1[t] = o.hi[1]; hi2[t] = o.hi[2]; }
+                tmax[t] = o.wt; targ[t] = o.widx; cx[t] = o.wx; cy[t] = o.wy; cz[t] = o.wz;
+            }
         }
     };
     // visits the tiles of the lanes in mask m, FPS_VISIT = 2 at a time (all loads of a pair are in flight before either is used).
@@ -586,10 +601,14 @@ __device__ __forceinline__ void fps_regtab_body(const float *__restrict__ src, c
     // software-pipelined visits: 7 % faster alone, 3 % slower with batches in flight.)
     constexpr int FPS_VISIT = 2;          // tiles per visit round
     constexpr int FPS_VISIT_UNCOND = 1;   // tiles of a round loaded unconditionally; the second tile's loads are issued only when there is one
-    auto visit = [&](unsigned long long m, bool with_box) {
+    // (mv[s]: the lanes whose slot-s tile is to be visited; slot 0's tiles first)
+    auto visit = [&](const unsigned long long (&mv)[TPL], bool with_box) {
         bool viol = false;
+        unsigned long long m = mv[0], m1 = TPL > 1 ? mv[TPL - 1] : 0ull;
+        int cur = 0;
+        if (TPL > 1 && m == 0ull) { m = m1; m1 = 0ull; cur = 1; }
         while (m) {
-            int l[FPS_VISIT];
+            int l[FPS_VISIT], sl[FPS_VISIT];
             bool on[FPS_VISIT];
             FpsQuad q[FPS_VISIT];
             TRACE_FPS_VISIT(0);
@@ -597,9 +616,11 @@ __device__ __forceinline__ void fps_regtab_body(const float *__restrict__ src, c
             for (int u = 0; u < FPS_VISIT; u++) {
                 on[u] = m != 0ull;
                 l[u] = on[u] ? (int)__ffsll((long long)m) - 1 : l[0];
+                sl[u] = on[u] ? cur : sl[0];
                 m &= m - 1ull;     // (0 & anything stays 0)
+                if (TPL > 1 && m == 0ull && m1 != 0ull) { m = m1; m1 = 0ull; cur = 1; }   // slot 0's tiles are done: on to slot 1's
                 if (u < FPS_VISIT_UNCOND || on[u]) {   // (wave-uniform) the first pair unconditionally, the rest only when there is a tile
-                    locate(l[u], q[u]);
+                    locate(l[u], sl[u], q[u]);
                     fps_quad_load<RANGE, VEC, SOA, EDGE>(src, SOA ? rays_soa : rays, temp, q[u], N);
                 }
             }
@@ -607,7 +628,7 @@ __device__ __forceinline__ void fps_regtab_body(const float *__restrict__ src, c
 #pragma unroll
             for (int u = 0; u < FPS_VISIT; u++) {
                 FpsTileOut o;
-                if (on[u] && fps_tile_update<RANGE, VEC, EDGE>(q[u], org_on, t_org0, c0, c1, c2, temp, with_box, o, viol)) store_entry(l[u], o, with_box);
+                if (on[u] && fps_tile_update<RANGE, VEC, EDGE>(q[u], org_on, t_org0, c0, c1, c2, temp, with_box, o, viol)) store_entry(l[u], sl[u], o, with_box);
             }
             TRACE_FPS_VISIT(2);
         }
@@ -622,23 +643,31 @@ __device__ __forceinline__ void fps_regtab_body(const float *__restrict__ src, c
     int par = 0;
     // arg-max over all tiles and the origin class -> next centre (index and coordinates); one barrier
     auto select_next = [&]() {
-        const uint32_t key = have ? fps_val_key(tmax) : 0u;
+        // (two tiles per lane: the lane's better one first -- larger key, lower index among equals)
+        uint32_t key = have[0] ? fps_val_key(tmax[0]) : 0u, targ_b = targ[0];
+        float cx_b = cx[0], cy_b = cy[0], cz_b = cz[0];
+        if (TPL > 1) {
+            const uint32_t k1 = have[TPL - 1] ? fps_val_key(tmax[TPL - 1]) : 0u;
+            const bool sec = k1 > key || (k1 == key && targ[TPL - 1] < targ_b);
+            key = sec ? k1 : key; targ_b = sec ? targ[TPL - 1] : targ_b;
+            cx_b = sec ? cx[TPL - 1] : cx_b; cy_b = sec ? cy[TPL - 1] : cy_b; cz_b = sec ? cz[TPL - 1] : cz_b;
+        }
         uint32_t vmax = dpp_max_u32(key);
         // lowest index among the lanes that hold the maximum: almost always one lane, whose index is read directly (the second
         // reduction is 7 dependent DPP steps)
         unsigned long long mm = __ballot(key == vmax);
         uint32_t imin;
         if (__popcll(mm) == 1) {
-            imin = (uint32_t)__builtin_amdgcn_readlane((int)targ, (int)__ffsll((long long)mm) - 1);
+            imin = (uint32_t)__builtin_amdgcn_readlane((int)targ_b, (int)__ffsll((long long)mm) - 1);
         } else {
-            imin = dpp_min_u32(key == vmax ? targ : 0xFFFFFFFFu);
-            mm = __ballot(key == vmax && targ == imin);
+            imin = dpp_min_u32(key == vmax ? targ_b : 0xFFFFFFFFu);
+            mm = __ballot(key == vmax && targ_b == imin);
         }
         {
             const int wl = mm ? (int)__ffsll((long long)mm) - 1 : 0;
-            const float wx = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(cx), wl));
-            const float wy = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(cy), wl));
-            const float wz = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(cz), wl));
+            const float wx = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(cx_b), wl));
+            const float wy = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(cy_b), wl));
+            const float wz = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(cz_b), wl));
             if (lane == 0) { slot_k[par][wave] = make_uint2(vmax, vmax >= FPS_KEY_MIN ? imin : 0xFFFFFFFFu); slot_c[par][wave] = make_float4(wx, wy, wz, 0.0f); }
         }
         TRACE_FPS_PHASE(3);
@@ -673,10 +702,14 @@ __device__ __forceinline__ void fps_regtab_body(const float *__restrict__ src, c
 
     const bool have_tab = RANGE && tiletab != nullptr && info[RPCC_INFO * b + 3] == 1;
     if (M > 1 && have_tab) {   // the ground-mask kernel ran the first pass: this lane's entry
-        if (have) {
-            const float4 *t4 = reinterpret_cast<const float4 *>(tiletab + (int64_t)b * FPS_TAB_ROWS * T);
-            const float4 a = t4[my_t], h = t4[T + my_t], c = t4[2 * T + my_t];
-            lo0 = a.x; lo1 = a.y; lo2 = a.z; tmax = a.w; hi0 = h.x; hi1 = h.y; hi2 = h.z; targ = f2u(h.w); cx = c.x; cy = c.y; cz = c.z;
+#pragma unroll
+        for (int s = 0; s < TPL; s++) {
+            if (have[s]) {
+                const float4 *t4 = reinterpret_cast<const float4 *>(tiletab + (int64_t)b * FPS_TAB_ROWS * T);
+                const float4 a = t4[my_t[s]], h = t4[T + my_t[s]], c = t4[2 * T + my_t[s]];
+                lo0[s] = a.x; lo1[s] = a.y; lo2[s] = a.z; tmax[s] = a.w; hi0[s] = h.x; hi1[s] = h.y; hi2[s] = h.z; targ[s] = f2u(h.w);
+                cx[s] = c.x; cy[s] = c.y; cz[s] = c.z;
+            }
         }
         update_origin();  // (idempotent: temp of the empty pixels already holds the first centre's distance)
     } else if (M > 1) {
@@ -698,12 +731,16 @@ __device__ __forceinline__ void fps_regtab_body(const float *__restrict__ src, c
     TRACE_FPS_PHASE(0);
     for (int j = 2; j < M; j++) {
         // this wavefront's tiles against the new centre
-        const float g0 = fmaxf(fmaxf(lo0 - c0, c0 - hi0), 0.0f);
-        const float g1 = fmaxf(fmaxf(lo1 - c1, c1 - hi1), 0.0f);
-        const float g2 = fmaxf(fmaxf(lo2 - c2, c2 - hi2), 0.0f);
-        const float bound = (g0 * g0 + g1 * g1) + g2 * g2;
-        const unsigned long long vm = __ballot(have && bound < tmax);
-        TRACE_FPS_TILES(vm, j);
+        unsigned long long vm[TPL];
+#pragma unroll
+        for (int s = 0; s < TPL; s++) {
+            const float g0 = fmaxf(fmaxf(lo0[s] - c0, c0 - hi0[s]), 0.0f);
+            const float g1 = fmaxf(fmaxf(lo1[s] - c1, c1 - hi1[s]), 0.0f);
+            const float g2 = fmaxf(fmaxf(lo2[s] - c2, c2 - hi2[s]), 0.0f);
+            const float bound = (g0 * g0 + g1 * g1) + g2 * g2;
+            vm[s] = __ballot(have[s] && bound < tmax[s]);
+        }
+        TRACE_FPS_TILES(vm[0] | (TPL > 1 ? vm[TPL - 1] : 0ull), j);
         TRACE_FPS_PHASE(1);
         visit(vm, false);
         TRACE_FPS_PHASE(2);
@@ -739,6 +776,14 @@ __global__ __launch_bounds__(FPS_TT) __attribute__((amdgpu_waves_per_eu(5, 8))) 
     const float *__restrict__ src, const float *__restrict__ rays, float *__restrict__ temp, const int32_t *__restrict__ info, FpsTiling g, int M,
     int flags, int32_t *__restrict__ out_idx, float *__restrict__ out_cen, const float *__restrict__ tiletab, const float *__restrict__ rays_soa) {
     fps_regtab_body<true, true, FPS_TT, true, EDGE>(src, rays, temp, info, g, M, flags, out_idx, out_cen, tiletab, rays_soa, blockIdx.x);
+}
+// Two tiles per lane: images with more tiles than the workgroup has lanes (80 x 2000: 630, 128 x 2048: 1024) keep the register table -- the
+// LDS-table kernel above pays three barriers per iteration.  The second table entry costs 11 registers: four wavefronts per SIMD instead of five.
+template <int FPS_TT, bool EDGE = false>
+__global__ __launch_bounds__(FPS_TT) __attribute__((amdgpu_waves_per_eu(4, 8))) void fps_regtab_planar2_kernel(
+    const float *__restrict__ src, const float *__restrict__ rays, float *__restrict__ temp, const int32_t *__restrict__ info, FpsTiling g, int M,
+    int flags, int32_t *__restrict__ out_idx, float *__restrict__ out_cen, const float *__restrict__ tiletab, const float *__restrict__ rays_soa) {
+    fps_regtab_body<true, true, FPS_TT, true, EDGE, 2>(src, rays, temp, info, g, M, flags, out_idx, out_cen, tiletab, rays_soa, blockIdx.x);
 }
 // The same for the frames of several geometry groups in ONE launch (rpcc_compress_batch_mixed: variable H x W inside one call).  The device runs
 // as many kernels side by side as the process has hardware queues -- three or four -- and this kernel keeps one CU per frame busy for 99

@@ -1823,6 +1823,17 @@ static int launch_fps_tiled(const float *src, const float *rays, float *temp, co
             LAUNCH_CHECK();
             return RPCC_OK;
         }
+        if constexpr (RANGE) if (g.T > tt && g.T <= 2 * tt && (vec || edge) && rays_soa != nullptr) {   // two tiles per lane
+            if (edge) {
+                if (B <= 128) fps_regtab_planar2_kernel<FPS_TT_SMALL, true><<<B, FPS_TT_SMALL, 0, st>>>(src, rays, temp, info, g, M, kflags, idx, cen, tiletab, rays_soa);
+                else          fps_regtab_planar2_kernel<FPS_TT_BATCH, true><<<B, FPS_TT_BATCH, 0, st>>>(src, rays, temp, info, g, M, kflags, idx, cen, tiletab, rays_soa);
+            } else {
+                if (B <= 128) fps_regtab_planar2_kernel<FPS_TT_SMALL><<<B, FPS_TT_SMALL, 0, st>>>(src, rays, temp, info, g, M, kflags, idx, cen, tiletab, rays_soa);
+                else          fps_regtab_planar2_kernel<FPS_TT_BATCH><<<B, FPS_TT_BATCH, 0, st>>>(src, rays, temp, info, g, M, kflags, idx, cen, tiletab, rays_soa);
+            }
+            LAUNCH_CHECK();
+            return RPCC_OK;
+        }
         if constexpr (RANGE) if (g.T <= tt && edge) {
             if (B <= 128) fps_regtab_kernel<true, true, FPS_TT_SMALL, true><<<B, FPS_TT_SMALL, 0, st>>>(src, rays, temp, info, g, M, kflags, idx, cen, tiletab);
             else          fps_regtab_kernel<true, true, FPS_TT_BATCH, true><<<B, FPS_TT_BATCH, 0, st>>>(src, rays, temp, info, g, M, kflags, idx, cen, tiletab);

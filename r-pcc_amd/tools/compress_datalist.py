@@ -25,7 +25,7 @@ from rpcc_amd.loader import StreamingCompressor  # noqa: E402
 from rpcc_amd.pipeline import BatchCompressor  # noqa: E402
 from rpcc_amd.sharding import RoundGather, shard_indices  # noqa: E402
 from rpcc_amd.tools.compress import apply_fps_mode, make_parser, resolve_cfg  # noqa: E402
-from rpcc_amd.utils import frame_identity  # noqa: E402
+from rpcc_amd.utils import available_cpus, frame_identity, pin_rank_cpus  # noqa: E402
 
 
 def output_path_for(output_dir, file_name):
@@ -83,11 +83,17 @@ def init_gather_group(rank, world, local):
     return dist
 
 
-def compress(args):
+def compress(args, streaming_factory=None):
+    """streaming_factory (tests): builds the object that turns batches into .rpcc strings -- loader.StreamingCompressor's constructor
+    arguments and run() -- so that the sharding / gathering / file-writing logic of this driver can run on hosts without a GPU."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     device = "cuda:%d" % local
+    # one process per GPU: every rank keeps its own slice of the host's CPUs (the feed is host-bound: DESIGN.md section 7)
+    pinned = pin_rank_cpus(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+    if pinned is not None:
+        args.workers = max(1, min(args.workers, available_cpus()))
     apply_fps_mode(args)
     cfg, accuracy, segment_cfg, model_cfg, basic_compressor, uniform = resolve_cfg(args)
     dataset = build_dataset(datalist=args.datalist, lidar_type=args.lidar, device=device)
@@ -107,7 +113,8 @@ def compress(args):
     if getattr(args, "gather", False):
         import torch
         init_gather_group(rank, world, local)
-        gather = RoundGather(len(dataset), rank, world, torch.device(device), round_items=args.gather_round)
+        gdev = torch.device(device if os.environ.get("RPCC_DIST_BACKEND", "nccl") == "nccl" else "cpu")   # (gloo: CPU tensors)
+        gather = RoundGather(len(dataset), rank, world, gdev, round_items=args.gather_round)
     t0 = time.time()
     stats = {"bytes": 0, "files": 0}
     with futures.ThreadPoolExecutor(args.workers) as pool:
@@ -115,8 +122,8 @@ def compress(args):
         # entropy coding + file output of batch n-1 overlap
         # .bin sweeps (float32 rows x, y, z, intensity: dataset/dataset.py:48-50) are read straight into the pinned staging slot
         # and go to the device as stored -- no np.fromfile + [:, :3] pass on the host; other formats are loaded and sliced
-        sc = StreamingCompressor(bc, batch=min(args.batch, max(len(mine), 1)), depth=4, workers=args.workers, pool=pool,
-                                 points_per_frame=getattr(args, "points_per_frame", None), ingest=ingest)
+        sc = (streaming_factory or StreamingCompressor)(bc, batch=min(args.batch, max(len(mine), 1)), depth=4, workers=args.workers, pool=pool,
+                                                        points_per_frame=getattr(args, "points_per_frame", None), ingest=ingest)
         names_of = {}
 
         def batches():
@@ -143,6 +150,8 @@ def compress(args):
         if gather is not None:
             write_all([(dataset.data_list[i], blob) for i, blob in gather.finish()])
     dt = time.time() - t0
+    if pinned is not None:
+        print("rank %d/%d: pinned to CPUs %s" % (rank, world, ",".join(str(c) for c in pinned)))
     print("rank %d/%d: %d frames in %.3f s (%.1f frames/s incl. file I/O and entropy coding), %d files / %d bytes written%s"
           % (rank, world, len(mine), dt, len(mine) / max(dt, 1e-9), stats["files"], stats["bytes"],
              " (gathered to rank 0 over the process group)" if gather is not None else ""))

@@ -89,3 +89,25 @@ def visible_gpus():
         elif v.strip() == "":
             n = 0
     return n
+
+
+def pin_rank_cpus(local_rank, local_world):
+    """One process per GPU on one host: rank r keeps the r-th of `local_world` equal, contiguous slices of the CPUs the job may use, so
+    that the ranks' feeder threads (file reads, staging copies, entropy coding: loader.StreamingCompressor) do not migrate over each other's
+    cores and caches.  -> the CPUs kept (sorted), or None when nothing was changed (single rank, RPCC_NO_AFFINITY=1, fewer CPUs than
+    ranks, or a platform without sched_setaffinity)."""
+    if local_world <= 1 or os.environ.get("RPCC_NO_AFFINITY") == "1":
+        return None
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        return None
+    per = len(cpus) // local_world
+    if per < 1:
+        return None
+    mine = cpus[local_rank * per:(local_rank + 1) * per]
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return None
+    return mine

@@ -459,3 +459,35 @@ def test_fused_labels_on_adversarial_and_tie_scenes(env, scene):
             tie = (np.sqrt(d2) == np.sqrt(m1)[:, None]) & (d2 != m1[:, None]) & (np.arange(cen.shape[0])[None, :] < k1[:, None])
             ties += int(tie.any(1).sum())
     assert scene != "lattice" or ties >= 4, ties
+
+
+@pytest.mark.parametrize("name,gd", [("KITTI_test 80x2000", None),
+                                     ("128 beams x 2048", dict(H=128, W=2048, hfov_deg=360, vmax_deg=15.0, vmin_deg=-25.0))])
+def test_images_with_more_tiles_than_lanes(env, name, gd):
+    """The reference's own KITTI_test table (dataset/__init__.py:21, lidar_cfg/Velodyne_HDL_64E_unofficial.yaml: 80 x 2000 = 630 FPS
+    tiles) and a 128-beam image (1024 tiles) in batches of more than 128 frames: the FPS keeps its register table with two tiles per
+    lane (fps_regtab_planar2_kernel).  Every frame of a 130-frame batch equals the oracle -- fitted ground plane, FPS pixels, centres,
+    labels, model rows, quantised integers -- and the same frames in a batch of 8 (the 1024-thread, one-tile-per-lane kernel) give the same."""
+    torch, ops, synth, orc = env["torch"], env["ops"], env["synth"], env["orc"]
+    gd = gd or orc.GEOMS["Velodyne64E_unofficial"]
+    g = orc.LidarGeom(**gd)
+    tm = ops.transform_map(g.H, g.W, g.horizontal_FOV, g.vertical_max, g.vertical_min)
+    assert np.array_equal(tm, orc.transform_map(g))
+    geom = ops.make_geom(g.H, g.W, g.horizontal_FOV, g.vertical_max, g.vertical_min)
+    e2 = dict(env, g=g, tm=tm, geom=geom, d_tm=torch.from_numpy(tm).to(env["dev"]))
+    B = 130
+    ids = list(range(6500, 6500 + B))
+    xyz, offs = synth.make_batch(ids, g.H, g.W, device=env["dev"], vmax_deg=gd["vmax_deg"], vmin_deg=gd["vmin_deg"])
+    fid = torch.as_tensor(np.asarray(ids, np.int64), device=env["dev"])
+    exp = _oracle_batch(e2, xyz.cpu().numpy(), offs.cpu().numpy(), ids, seed=3)
+    buf = ops.BatchBuffers(B, geom, 100, env["dev"])
+    gms = torch.zeros((B, 4), dtype=torch.float64, device=env["dev"])
+    ops.compress_batch(xyz, offs, e2["d_tm"], gms, buf, ground_seed=3, frame_ids=fid)
+    torch.cuda.synchronize()
+    _check_all(buf, gms, exp, name)
+    o_h = offs.cpu().numpy()
+    small = ops.BatchBuffers(8, geom, 100, env["dev"])
+    gm8 = torch.zeros((8, 4), dtype=torch.float64, device=env["dev"])
+    ops.compress_batch(xyz[:o_h[8]], offs[:9].clone(), e2["d_tm"], gm8, small, ground_seed=3, frame_ids=fid[:8].clone())
+    torch.cuda.synchronize()
+    _check_all(small, gm8, exp[:8], name + ", batch of 8")

@@ -354,3 +354,79 @@ def test_bench_finds_its_pmc_numbers():
     assert all(2.0 <= k["valu_mean_cycles_static"] <= 8.0 for k in pm["kernels"].values())
     src = open(os.path.join(root, "bench.py")).read()
     assert 'startswith(("fps_regtab_planar_kernel", "fps_regtab_kernel<true", "fps_tiled_kernel<true"))' in src
+
+
+def _stub_blob(name):
+    import zlib
+    c = zlib.crc32(name.encode())
+    return b"RPCC" + name.encode() * (1 + c % 5) + c.to_bytes(4, "little")
+
+
+class _StubStreaming:
+    """Stands in for loader.StreamingCompressor (the device part) in the datalist driver: same constructor arguments and run()."""
+
+    def __init__(self, bc, batch, depth, workers, pool, points_per_frame, ingest):
+        assert ingest == "rows"          # a datalist of .bin names: the driver hands the PATHS over
+        self.B = batch
+
+    def run(self, batches, sink, entropy=True):
+        n = 0
+        for k, (frames, fids) in enumerate(batches):
+            assert len(frames) == len(fids) <= self.B
+            sink(k, [_stub_blob(str(f)) for f in frames])
+            n += len(frames)
+        return n
+
+
+def _datalist_rank(rank, world, port, datalist, outdir, logdir):
+    """One rank of `tools/compress_datalist.py --gather` as torchrun would start it (environment variables), gloo instead of RCCL, the
+    device part replaced by the stub above."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), LOCAL_WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), RPCC_DIST_BACKEND="gloo")
+    sys.stdout = open(os.path.join(logdir, "rank%d.log" % rank), "w")
+    import rpcc_amd  # noqa: F401
+    from rpcc_amd.tools import compress_datalist as cd
+    from rpcc_amd.tools.compress import make_parser
+    a = make_parser(datalist=True).parse_args(["--datalist", datalist, "--output_dir", outdir, "--lidar", "VelodyneVLP16", "--gather",
+                                               "--gather-round", "16", "--batch", "8", "--workers", "2", "--output"])
+    cd.compress(a, streaming_factory=_StubStreaming)
+    print("affinity %s" % ",".join(str(c) for c in sorted(os.sched_getaffinity(0))))
+    sys.stdout.flush()
+
+
+def test_eight_rank_datalist_gather_dry_run(tmp_path):
+    """SURVEY 8e / configs[3] without hardware: EIGHT gloo ranks run the datalist driver with --gather on a 1 000-entry datalist (the
+    device part stubbed).  Rank 0 writes every file exactly once, with the right bytes, in datalist order; the other ranks write nothing;
+    with enough CPUs every rank pins itself to its own slice of them."""
+    world, n = 8, 1000
+    names = ["/data/kitti/seq%02d/velodyne/%06d.bin" % (i % 11, i) for i in range(n)]
+    datalist = tmp_path / "list.txt"
+    datalist.write_text("\n".join(names) + "\n")
+    outdir, logdir = tmp_path / "out", tmp_path / "log"
+    outdir.mkdir(); logdir.mkdir()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_datalist_rank, args=(r, world, 29911, str(datalist), str(outdir), str(logdir))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    logs = [open(os.path.join(logdir, "rank%d.log" % r)).read() for r in range(world)]
+    written = [ln.split(" -> ")[0] for ln in logs[0].splitlines() if " -> " in ln and ln.endswith("bytes")]
+    assert written == names                                   # rank 0: every entry once, in datalist order
+    for r in range(1, world):
+        assert not any(" -> " in ln and ln.endswith("bytes") for ln in logs[r].splitlines()), r
+    files = []
+    for root, _, fs in os.walk(outdir):
+        files += [os.path.join(root, f) for f in fs]
+    assert len(files) == n
+    for name in names:
+        out = os.path.join(str(outdir), name[1:]).replace("bin", "rpcc")
+        assert open(out, "rb").read() == _stub_blob(name), name
+    import re
+    frames = [int(re.search(r"rank %d/8: (\d+) frames" % r, logs[r]).group(1)) for r in range(world)]
+    assert frames == [125] * 8 and sum("gathered to rank 0" in lg for lg in logs) == world
+    aff = [set(int(c) for c in re.search(r"affinity ([\d,]+)", lg).group(1).split(",")) for lg in logs]
+    if len(os.sched_getaffinity(0)) >= world:                  # every rank on its own CPUs
+        assert all(aff[i].isdisjoint(aff[j]) for i in range(world) for j in range(i)), aff
