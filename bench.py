@@ -607,8 +607,8 @@ def run_workload(a, ctx):
         valu_peak = VALU_SIMD_CYCLES_PER_S / mean_cyc if mean_cyc else None       # wave-instructions per second of THIS instruction mix
         step_valu_frac = pm["step_cycles"] / step_s / VALU_SIMD_CYCLES_PER_S if mean_cyc else None
         step_traffic_frac = pm["step_traffic"] / step_s / 1e9 / HBM_PEAK_GBS if pm and pm.get("step_traffic") else None
-        workload = ("configs[%d]: batch=%d %s " + ("%s" % a.lidar if getattr(a, "lidar", None) else "Velodyne-64E") + " frames (%dx%d) per GPU, %s, accuracy=%g, cluster_num=%d, ground plane by "
-                    "seeded RANSAC inside the step" % (a.config, B, "real (%s, rotated copies, %s)" % (os.path.basename(a.input), "shuffled" if a.input_shuffle else "points in stored order") if a.input
+        workload = (("configs[%d]: batch=%d %s " + (a.lidar if getattr(a, "lidar", None) else "Velodyne-64E") + " frames (%dx%d) per GPU, %s, accuracy=%g, cluster_num=%d, ground plane by "
+                     "seeded RANSAC inside the step") % (a.config, B, "real (%s, rotated copies, %s)" % (os.path.basename(a.input), "shuffled" if a.input_shuffle else "points in stored order") if a.input
                                                        else ("synthetic" if a.scene == "default" else "synthetic ADVERSARIAL scene '%s'" % a.scene),
                                                        H, W, "non-uniform + FPS + plane-model" if general else "uniform + FPS + point-model", a.accuracy, M))
         exch_s = ("no exchange" if not exchange else
