@@ -37,6 +37,7 @@ class NonuniformCfg(C.Structure):
 INFO_INTS = 8          # RPCC_INFO_INTS
 FPS_BRUTEFORCE = 1     # RPCC_FPS_BRUTEFORCE
 FPS_FMA1, FPS_FMA2, FPS_TIE_CUDA = 2, 4, 8   # RPCC_FPS_FMA1 / RPCC_FPS_FMA2 / RPCC_FPS_TIE_CUDA
+MAX_CLUSTERS = 254     # RPCC_MAX_CLUSTERS: labels 0 .. cluster_num + 1 are stored as uint8 on the device
 ABI_VERSION = 101      # RPCC_ABI_VERSION: the layout of rpcc_batch_io / rpcc_geom this binding was written for
 
 

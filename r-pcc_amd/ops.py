@@ -296,11 +296,23 @@ def pack_payload(q16, nnz, packed=None, capacity=None, total=None):
     return packed, total
 
 
+def check_cluster_num(M):
+    """cluster_num as this build takes it.  The reference accepts any value (cfgs/compressor.yaml:22; its labels travel as uint16,
+    utils/compress_utils.py:160); here the device keeps a pixel's label 0 .. cluster_num + 1 in ONE byte (segmentation map, label
+    histograms, the contour codec), so cluster_num <= 254.  A larger value is refused here, by name, before any buffer is allocated."""
+    M = int(M)
+    if not 1 <= M <= _lib.MAX_CLUSTERS:
+        raise _lib.RpccError("cluster_num = %d: this build supports 1 <= cluster_num <= %d (device labels are uint8: RPCC_MAX_CLUSTERS in "
+                             "include/rpcc_hip.h); the reference's default is 100 (cfgs/compressor.yaml:22)" % (M, _lib.MAX_CLUSTERS))
+    return M
+
+
 class BatchBuffers:
     """Device buffers of one batch (B frames, one geometry), allocated once and reused.  general=True adds what the
     plane model / the non-uniform framework need (salience levels, key-point map, the larger work buffer)."""
 
     def __init__(self, B, geom, M, device, max_points=None, general=False):
+        M = check_cluster_num(M)
         P = geom.H * geom.W
         K = M + 2
         self.B, self.P, self.M, self.K, self.geom = B, P, M, K, geom

@@ -29,7 +29,7 @@ def test_header_symbols_exported(built):
 
 def test_version_and_workspace(built):
     lib = built.lib()
-    assert lib.rpcc_version() >= 100
+    assert lib.rpcc_version() == built.ABI_VERSION
     assert lib.rpcc_workspace_bytes(256, 64 * 2048, 100, 0) > 0
     assert lib.rpcc_workspace_bytes(0, 64 * 2048, 100, 0) == 0
 
@@ -47,3 +47,21 @@ def test_product_never_imports_oracle():
         for f in fs:
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 assert not bad.search(open(os.path.join(dp, f)).read()), (dp, f)
+
+
+def test_cluster_num_limit_is_named():
+    """The reference takes any cluster_num (cfgs/compressor.yaml:22); this build keeps device labels in a byte.  A preserved YAML with a
+    larger value must fail with the limit spelled out -- in the front-end, before anything touches the device -- not with a bare argument error."""
+    import re
+    import pytest
+    import rpcc_amd  # noqa: F401
+    from rpcc_amd import _lib, ops
+    hdr = open(os.path.join(ROOT, "include", "rpcc_hip.h")).read()
+    assert int(re.search(r"#define RPCC_MAX_CLUSTERS (\d+)", hdr).group(1)) == _lib.MAX_CLUSTERS == 254
+    assert ops.check_cluster_num(254) == 254 and ops.check_cluster_num(1) == 1
+    for bad in (255, 300, 65533, 0):
+        with pytest.raises(_lib.RpccError, match=r"cluster_num = %d.*<= 254.*uint8" % bad):
+            ops.check_cluster_num(bad)
+    from rpcc_amd.pipeline import BatchCompressor
+    with pytest.raises(_lib.RpccError, match="cluster_num = 300"):
+        BatchCompressor(None, cluster_num=300)
