@@ -143,3 +143,16 @@ def test_decoder_rejects_inconsistent_streams(env):
         env["dec"].decode_frame(as_u8(dict(raw, salience_level=np.zeros(nrow - 1, np.uint8).tobytes())), bc, T16, 100, 0.04, lv, False)
     with pytest.raises(ValueError):                                                  # a uniform stream read as non-uniform
         env["dec"].decode_frame(as_u8(raw), bc, T16, 100, 0.04, lv, False)
+
+
+def test_assignment_tie_order_matches_reference(env):
+    """rpcc_assign on the tie fixture (tests/golden/pins_ties_vlp16.npz: labels produced by the GENUINE reference's segment() on a constructed
+    image with a prescribed centre list): fp32 radii that are equal although the squared distances differ, exact duplicate centres, empty
+    pixels -- the first maximum of np.argmax(-np.abs(distance)) (utils/segment_utils.py:21-23,127-131,168-169), bit for bit."""
+    from test_oracle_pins import tie_fixture
+    torch, ops, dev = env["torch"], env["ops"], env["dev"]
+    man, g, tm, ri, gm, cen, want = tie_fixture()
+    to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    seg = ops.assign(to(ri[None]), to(tm), to(np.asarray(gm, np.float64).reshape(1, 4)), to(cen[None]))[0].cpu().numpy()
+    bad = np.flatnonzero(seg.reshape(-1) != want.reshape(-1))
+    assert bad.size == 0, (bad[:8], seg.reshape(-1)[bad[:8]], want.reshape(-1)[bad[:8]])

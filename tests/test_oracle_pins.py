@@ -109,3 +109,35 @@ def test_fps_modes_closed_form_equals_the_cuda_kernel_thread_by_thread():
     pts = rng.normal(0, 10, (4000, 3)).astype(np.float32)
     i0, i1, i2 = (orc.fps_modes(pts, 50, f, False) for f in (0, 1, 2))
     assert i0[0] == i1[0] == i2[0] == 0 and i0[1] == i1[1] == i2[1]
+
+
+def tie_fixture():
+    """tests/golden/pins_ties_vlp16.npz (gen_golden_ties.py: the reference's own segment() on a constructed image and a prescribed centre
+    list) -> (geometry, ray table, range image, ground model, centres f32 [100,3], labels the reference produced)."""
+    z = np.load(os.path.join(HERE, "golden", "pins_ties_vlp16.npz"))
+    man = json.load(open(os.path.join(HERE, "golden", "pins_ties_manifest.json")))
+    g = orc.LidarGeom(**orc.GEOMS[man["geom"]])
+    tm = orc.transform_map(g)
+    ri = np.repeat(z["row_ranges"][:, None], g.W, 1).astype(np.float32)
+    ri.reshape(-1)[::int(z["empty_stride"])] = 0
+    ri.reshape(-1)[z["tuned_pixels"]] = z["tuned_ranges"]
+    pc = orc.backproject(ri, tm)
+    cen = pc.reshape(-1, 3)[z["centre_pixels"]].astype(np.float32)
+    return man, g, tm, ri, z["ground_model"], cen, z["seg_idx"]
+
+
+def test_assignment_tie_order_matches_reference():
+    """a7: np.argmax(-np.abs(distance)) keeps the FIRST maximum -- the ground before a cluster, the lower cluster index among fp32 radii that are
+    equal although their squared distances differ, and among exact duplicates (utils/segment_utils.py:21-23,127-131).  The labels come from
+    the genuine reference; 114 of the pixels carry a label that is NOT the arg-min of the squared distance."""
+    man, g, tm, ri, gm, cen, want = tie_fixture()
+    assert man["decided_by_tie_order"] >= 100 and sha(want) == man["sha_seg_idx"]
+    pc = orc.backproject(ri, tm)
+    got = orc.assign(ri, pc, tm, gm, cen)
+    assert np.array_equal(got.astype(np.uint8), want)
+    assert np.array_equal(orc.np_assign(ri.reshape(g.H, g.W, 1), pc, tm, gm, cen).astype(np.uint8), want)
+    # the fixture does what it says: for those pixels a squared-distance arg-min would answer differently
+    d = pc.reshape(-1, 1, 3) - cen[None]
+    d2 = ((d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]).astype(np.float32)
+    lab = want.reshape(-1).astype(np.int64)
+    assert int(((lab >= 2) & (lab - 2 != d2.argmin(1)) & (ri.reshape(-1) != 0)).sum()) >= man["decided_by_tie_order"]
