@@ -291,10 +291,14 @@ def pmc_numbers(a, B, geom_s, M):
             return None
         key = [k for k in pm["kernels"] if k.startswith(("fps_regtab_planar_kernel", "fps_regtab_kernel<true", "fps_tiled_kernel<true"))][0]   # template arguments vary
         return dict(kernel=key, traffic=pm["kernels"][key]["traffic_bytes_per_launch"],
-                    valu=pm["kernels"][key].get("valu_wave_insts_per_launch"), valu_cyc=pm["kernels"][key].get("valu_mean_cycles_static"),
+                    valu=pm["kernels"][key].get("valu_wave_insts_per_launch"),
+                    valu_cyc=pm["kernels"][key].get("valu_mean_cycles_dynamic", pm["kernels"][key].get("valu_mean_cycles_static")),
                     step_traffic=pm.get("step_traffic_bytes"), step_valu=pm.get("step_valu_wave_insts"), step_cycles=pm.get("step_valu_simd_cycles"),
-                    src="profiles/%s_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU, separate passes, serial steps, x2 read "
-                        "correction) + profiles/isa_mix_current.json (static cycle mix); constants of the committed profile, not measured in this run" % pm.get("tag", "?"))
+                    step_cycles_static=pm.get("step_valu_simd_cycles_static_mix"), step_cycles_lo=pm.get("step_valu_simd_cycles_lo"),
+                    step_cycles_hi=pm.get("step_valu_simd_cycles_hi"), cycles_source=pm.get("valu_cycles_source", "static mix"),
+                    src="profiles/%s_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU and the SQ_INSTS_VALU_<class> counters, separate passes, "
+                        "serial steps, x2 read correction) + profiles/isa_mix_current.json (cycles per class); constants of the committed profile, not "
+                        "measured in this run" % pm.get("tag", "?"))
     except Exception:
         return None
 
@@ -623,8 +627,17 @@ def run_workload(a, ctx):
         # move those bytes, so it exceeds the peak and bounds nothing.
         roof = {"bound": "valu", "scope": "whole step (all launches of one batch, %d batches in flight)" % depth,
                 "what": "VALU pipe time of the step / measured step time: wave-level VALU instructions per kernel (PMC SQ_INSTS_VALU) x the mean SIMD "
-                        "cycles per instruction of the kernel's static instruction mix (2 / 4 / 8 cycles by class, measured: profiles/r04_valu_peak.md), "
-                        "summed over the step's launches, against 1024 SIMDs x 2.4 GHz; achieved / peak in wave-instructions of this mix",
+                        "cycles per instruction (2 / 4 / 8 cycles by class, measured: profiles/r04_valu_peak.md; the kernel's DYNAMIC class counts -- "
+                        "SQ_INSTS_VALU_ADD_F32 ... -- weighted with the static cycles inside each class when the committed profile holds them, else the "
+                        "static mix), summed over the step's launches, against 1024 SIMDs x 2.4 GHz; achieved / peak in wave-instructions of this mix",
+                "cycles_from": (pm["cycles_source"] if pm else None),
+                # the same instruction count priced differently: every instruction at the guide's 2 cycles / at 4 cycles, the static mix alone,
+                # and every counter class at the least / largest cycles its static instructions have
+                "frac_if": ({"all_2_cycles": round(2.0 * pm["step_valu"] / step_s / VALU_SIMD_CYCLES_PER_S, 4),
+                             "all_4_cycles": round(4.0 * pm["step_valu"] / step_s / VALU_SIMD_CYCLES_PER_S, 4),
+                             "static_mix": (round(pm["step_cycles_static"] / step_s / VALU_SIMD_CYCLES_PER_S, 4) if pm.get("step_cycles_static") else None),
+                             "class_bounds": ([round(pm["step_cycles_lo"] / step_s / VALU_SIMD_CYCLES_PER_S, 4), round(pm["step_cycles_hi"] / step_s / VALU_SIMD_CYCLES_PER_S, 4)]
+                                              if pm.get("step_cycles_lo") else None)} if mean_cyc else None),
                 "achieved": (round(pm["step_valu"] / step_s / 1e9, 2) if mean_cyc else None),
                 "peak": (round(valu_peak / 1e9, 1) if valu_peak else None), "unit": "G wave-instr/s",
                 "frac": (round(step_valu_frac, 4) if step_valu_frac is not None else None),

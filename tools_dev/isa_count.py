@@ -92,6 +92,28 @@ def valu_cycles(op):
     return 2 if base in FAST2 else 4
 
 
+# Which SQ_INSTS_VALU_* class counter sees an instruction (calibrated with one-instruction kernels: profiles/raw/r04_valu_mix_cal_A.txt, _B):
+# the counters count plain, packed and DPP forms alike; compares, selects, fp32 min / max / med3, bit operations, left / logical right shifts,
+# moves, lane operations, roundings count in NONE of them ("uncounted").  tools_profiles.py weights the DYNAMIC class counts of a kernel with
+# the mean cycles of the kernel's static instructions of that class.
+PMC_CLASS_RULES = (
+    ("TRANS_F64", r"v_(rcp|rsq|sqrt)_f64"), ("FMA_F64", r"v_fma_f64"), ("MUL_F64", r"v_mul_f64"), ("ADD_F64", r"v_add_f64"),
+    ("TRANS_F32", r"v_(rcp|rsq|sqrt|exp|log|sin|cos)_(f32|legacy_f32|iflag_f32)"),
+    ("FMA_F32", r"v_(pk_)?(fma|fmac|mad|mac)_f32"), ("MUL_F32", r"v_(pk_)?mul_(legacy_)?f32"), ("ADD_F32", r"v_(pk_)?(add|sub|subrev)_f32"),
+    ("CVT", r"v_cvt_"), ("INT64", r"v_mad_[ui]64_[ui]32"),
+    ("INT32", r"v_(add|sub|subrev|addc|subb|subbrev)(_co)?_[ui]32|v_(lshl_add|add_lshl|add3|xad)_u32|v_mbcnt_|v_mul_(lo|hi)_[ui]32|v_mul_[ui]32_[ui]24|"
+              r"v_mad_[ui]32_[ui]24|v_ashrrev_i32|v_(min|max)_[ui]32|v_bfe_[ui]32|v_ffb[hl]_"),
+)
+
+
+def pmc_class(op):
+    base = re.sub(r"_(e32|e64|sdwa|dpp|e64_dpp)$", "", op)
+    for name, rx in PMC_CLASS_RULES:
+        if re.match(rx, base):
+            return name
+    return "UNCOUNTED"
+
+
 def parse(path):
     kernels, cur, body = {}, None, []
     meta = collections.defaultdict(dict)
@@ -139,6 +161,11 @@ def main():
         vops = [op for op in kernels[k] if op.startswith("v_")]
         c["cyc"] = sum(valu_cycles(op) for op in vops) / max(len(vops), 1)
         c["fast2"] = sum(1 for op in vops if valu_cycles(op) == 2) / max(len(vops), 1)
+        per = collections.defaultdict(list)
+        for op in vops:
+            per[pmc_class(op)].append(valu_cycles(op))
+        # per class counter: static instruction count, their mean / least / largest cycles
+        c["pmc"] = {k: {"n": len(v), "cycles": round(sum(v) / len(v), 4), "lo": min(v), "hi": max(v)} for k, v in sorted(per.items())}
         rows.append((dm[k], tot_valu, c, meta[k]))
         if dump and dump in dm[k]:
             print("==== " + dm[k])
@@ -154,7 +181,7 @@ def main():
     text = "\n".join(L) + "\n"
     if js:   # kernel -> static mean VALU cycles per instruction and share of 2-cycle operations (tools_profiles.py, bench.py's roofline)
         import json
-        json.dump({n: {"valu_mean_cycles": round(c["cyc"], 4), "share_2cycle": round(c["fast2"], 4), "valu_static": tv} for n, tv, c, m in rows},
+        json.dump({n: {"valu_mean_cycles": round(c["cyc"], 4), "share_2cycle": round(c["fast2"], 4), "valu_static": tv, "pmc_classes": c["pmc"]} for n, tv, c, m in rows},
                   open(js, "w"), indent=1, sort_keys=True)
     if md:
         open(md, "w").write("# Static gfx950 instruction counts per kernel (hipcc --save-temps, product flags%s)\n\n" % ((" + " + " ".join(args)) if args else "") +
