@@ -475,10 +475,10 @@ __global__ __launch_bounds__(SAL_THREADS) void salience_kernel(const uint8_t *__
 
 // a13 (salience) from per-label totals: pixels per label (the model scan's counts) and key points per label (counted by
 // features_kernel): the same rule as salience_kernel below without another pass over the frame.
-__global__ __launch_bounds__(256) void salience_levels_kernel(const int32_t *__restrict__ counts, const int32_t *__restrict__ kpn,
-                                                              int M, SalienceParams sp, uint8_t *__restrict__ salience,
-                                                              float *__restrict__ label_acc) {
-    const int b = blockIdx.x, K = M + 2, k = threadIdx.x;
+__device__ __forceinline__ void salience_levels_body(const int32_t *__restrict__ counts, const int32_t *__restrict__ kpn,
+                                                     int M, const SalienceParams &sp, uint8_t *__restrict__ salience,
+                                                     float *__restrict__ label_acc, const int b) {
+    const int K = M + 2, k = threadIdx.x;
     if (k >= K) return;
     const int pn = counts[(int64_t)b * K + k], kn = kpn[(int64_t)b * K + k];
     int lv = 0;
@@ -490,6 +490,22 @@ __global__ __launch_bounds__(256) void salience_levels_kernel(const int32_t *__r
             if (kn >= sp.level_kp_num[l]) { lv = l; break; }
     salience[(int64_t)b * K + k] = (uint8_t)lv;
     label_acc[(int64_t)b * K + k] = sp.level_acc[lv];
+}
+__global__ __launch_bounds__(256) void salience_levels_kernel(const int32_t *__restrict__ counts, const int32_t *__restrict__ kpn,
+                                                              int M, SalienceParams sp, uint8_t *__restrict__ salience,
+                                                              float *__restrict__ label_acc) {
+    salience_levels_body(counts, kpn, M, sp, salience, label_acc, blockIdx.x);
+}
+struct SalienceGroup {   // one geometry group of rpcc_compress_batch_mixed (the groups may differ in their non-uniform settings)
+    const int32_t *counts, *kpn;
+    SalienceParams sp;
+    uint8_t *salience;
+    float *label_acc;
+};
+__global__ __launch_bounds__(256) void salience_levels_multi_kernel(const MultiArgs<SalienceGroup> m, int M) {
+    int b, t;
+    const SalienceGroup &a = multi_locate(m, b, t);
+    salience_levels_body(a.counts, a.kpn, M, a.sp, a.salience, a.label_acc, b);
 }
 
 // a10 as its own entry: intra_predict (cpp_modules.cpp:248-285)

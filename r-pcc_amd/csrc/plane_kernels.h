@@ -18,15 +18,15 @@
 // their positions are left unwritten (about half of a frame's pixels).
 // pts4 (optional): the same list as points (x, y, z, r) so that the plane model streams a label's points instead of
 // gathering them through the pixel index.
-__global__ __launch_bounds__(256) void label_order_kernel(const uint8_t *__restrict__ seg, const uint32_t *__restrict__ hist,
-                                                          int P, int M, int KP, int T, uint32_t *__restrict__ order,
-                                                          const float *__restrict__ ri, const float *__restrict__ tm,
-                                                          float4 *__restrict__ pts4) {
+__device__ __forceinline__ void label_order_body(const uint8_t *__restrict__ seg, const uint32_t *__restrict__ hist,
+                                                 int P, int M, int KP, int T, uint32_t *__restrict__ order,
+                                                 const float *__restrict__ ri, const float *__restrict__ tm,
+                                                 float4 *__restrict__ pts4, const int b, const int t) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint32_t *segcnt = reinterpret_cast<uint32_t *>(smem_raw);  // [16][KP+1]
     const int SEGP = KP + 1;
     uint32_t *soff = segcnt + 16 * SEGP;                        // [KP] this tile's offsets per label
-    const int b = blockIdx.y, t = blockIdx.x, K = M + 2;
+    const int K = M + 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // per-frame bases + byte offsets; all loads of the tile first (unconditional, clamped)
     seg += (int64_t)b * P;
@@ -75,6 +75,25 @@ __global__ __launch_bounds__(256) void label_order_kernel(const uint8_t *__restr
             order[o] = (uint32_t)p;
             if (pts4) pts4[o] = make_float4(rr[j] * ray[j].x, rr[j] * ray[j].y, rr[j] * ray[j].z, rr[j]);  // transformer.py:94-101
         }
+}
+__global__ __launch_bounds__(256) void label_order_kernel(const uint8_t *__restrict__ seg, const uint32_t *__restrict__ hist,
+                                                          int P, int M, int KP, int T, uint32_t *__restrict__ order,
+                                                          const float *__restrict__ ri, const float *__restrict__ tm,
+                                                          float4 *__restrict__ pts4) {
+    label_order_body(seg, hist, P, M, KP, T, order, ri, tm, pts4, blockIdx.y, blockIdx.x);
+}
+struct OrderGroup {   // one geometry group of rpcc_compress_batch_mixed
+    const uint8_t *seg;
+    const uint32_t *hist;
+    int P, T;
+    uint32_t *order;
+    const float *ri, *tm;
+    float4 *pts4;
+};
+__global__ __launch_bounds__(256) void label_order_multi_kernel(const MultiArgs<OrderGroup> m, int M, int KP) {
+    int b, t;
+    const OrderGroup &a = multi_locate(m, b, t);
+    label_order_body(a.seg, a.hist, a.P, M, KP, a.T, a.order, a.ri, a.tm, a.pts4, b, t);
 }
 
 // points of one label, through the ordered pixel list

@@ -284,3 +284,21 @@ __device__ __forceinline__ int multi_group_of(const int *first, int n, int wg) {
     for (int i = 1; i < n; i++) gi += wg >= first[i] ? 1 : 0;
     return gi;
 }
+// The same for the pixel-parallel kernels, whose workgroups are (frame, tile workgroup of the frame) pairs: group i owns the workgroups
+// first[i] .. first[i + 1] - 1 = its frames x per[i] workgroups per frame.  A: the kernel's arguments for one group.
+#ifndef RPCC_MAX_GROUPS
+#define RPCC_MAX_GROUPS 4
+#endif
+template <class A>
+struct MultiArgs {
+    int n, first[RPCC_MAX_GROUPS + 1], per[RPCC_MAX_GROUPS];
+    A a[RPCC_MAX_GROUPS];
+};
+template <class A>
+__device__ __forceinline__ const A &multi_locate(const MultiArgs<A> &m, int &b, int &t) {   // (workgroup-uniform)
+    const int gi = multi_group_of(m.first, m.n, (int)blockIdx.x);
+    const int w = (int)blockIdx.x - m.first[gi];
+    b = w / m.per[gi];
+    t = w - b * m.per[gi];
+    return m.a[gi];
+}

@@ -2281,8 +2281,7 @@ struct ScanArgs {
     float *model;
     int32_t *counts, *nnz;
 };
-__global__ __launch_bounds__(SCAN_THREADS) void model_scan_kernel(const ScanArgs A) {
-    const int b = blockIdx.x;
+__device__ __forceinline__ void model_scan_body(const ScanArgs &A, const int b) {
     const float *__restrict__ ri = A.ri;
     const uint8_t *__restrict__ seg = A.seg;
     const double *__restrict__ ground = A.ground;
@@ -2386,6 +2385,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void model_scan_kernel(const ScanArgs
         }
     }
 }
+__global__ __launch_bounds__(SCAN_THREADS) void model_scan_kernel(const ScanArgs A) { model_scan_body(A, blockIdx.x); }
+// (the frames of several geometry groups in one launch, rpcc_compress_batch_mixed: one workgroup per frame, per[] = 1)
+__global__ __launch_bounds__(SCAN_THREADS) void model_scan_multi_kernel(const MultiArgs<ScanArgs> m) {
+    int b, t;
+    const ScanArgs &A = multi_locate(m, b, t);
+    model_scan_body(A, b);
+}
 // A lane owns FOUR CONSECUTIVE pixels of the tile (VEC: one 4-byte load of labels, one 16-byte load of ranges), a wavefront
 // 256 consecutive pixels.  Labels are spatially coherent, so the pixels that carry the label of the wavefront's first pixel
 // -- usually most of the 256 -- are aggregated once per wavefront (four compare masks counted in scalar registers, two DPP
@@ -2393,13 +2399,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void model_scan_kernel(const ScanArgs
 // range r in [2^-5, 2^8) is read off its bit pattern: r * 2^28 = mantissa << (exponent + 5), an integer below 2^36, kept as
 // an 18-bit low part and a high part whose sums over a wavefront stay below 2^32.
 template <bool VEC>
-__global__ __launch_bounds__(256) void model_hist_kernel(const float *__restrict__ ri, const uint8_t *__restrict__ seg,
-                                                         int P, int KP, int T, int64_t *__restrict__ sums,
-                                                         int32_t *__restrict__ flags, uint32_t *__restrict__ hist) {
+__device__ __forceinline__ void model_hist_body(const float *__restrict__ ri, const uint8_t *__restrict__ seg,
+                                                int P, int KP, int T, int64_t *__restrict__ sums,
+                                                int32_t *__restrict__ flags, uint32_t *__restrict__ hist, const int b, const int t) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned long long *ssum = reinterpret_cast<unsigned long long *>(smem_raw);  // [KP]
     uint32_t *scnt = reinterpret_cast<uint32_t *>(ssum + KP);                      // [KP]
-    const int b = blockIdx.y, t = blockIdx.x, lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63;
     const uint8_t *seg_b = seg + (int64_t)b * P;
     const float *ri_b = ri != nullptr ? ri + (int64_t)b * P : nullptr;
     const bool want_sum = ri != nullptr;
@@ -2492,6 +2498,26 @@ __global__ __launch_bounds__(256) void model_hist_kernel(const float *__restrict
         if (ssum[k]) atomicAdd(reinterpret_cast<unsigned long long *>(&sums[(int64_t)b * KP + k]), ssum[k]);
     }
 }
+template <bool VEC>
+__global__ __launch_bounds__(256) void model_hist_kernel(const float *__restrict__ ri, const uint8_t *__restrict__ seg,
+                                                         int P, int KP, int T, int64_t *__restrict__ sums,
+                                                         int32_t *__restrict__ flags, uint32_t *__restrict__ hist) {
+    model_hist_body<VEC>(ri, seg, P, KP, T, sums, flags, hist, blockIdx.y, blockIdx.x);
+}
+struct HistGroup {
+    const float *ri;
+    const uint8_t *seg;
+    int P, T, vec;
+    int64_t *sums;
+    int32_t *flags;
+    uint32_t *hist;
+};
+__global__ __launch_bounds__(256) void model_hist_multi_kernel(const MultiArgs<HistGroup> m, int KP) {
+    int b, t;
+    const HistGroup &a = multi_locate(m, b, t);
+    if (a.vec) model_hist_body<true>(a.ri, a.seg, a.P, KP, a.T, a.sums, a.flags, a.hist, b, t);
+    else       model_hist_body<false>(a.ri, a.seg, a.P, KP, a.T, a.sums, a.flags, a.hist, b, t);
+}
 static inline int scan_kp2(int M) { int v = 1; while (v < M + 2) v <<= 1; return v; }   // labels rounded up to a power of two (<= 256)
 // histogram + scan: tile x label counts (and the labels' range sums when ri is given), then the offsets of the ordered scatter, counts, nnz and
 // -- with `model` -- the point model's rows.  The sums / flags block must be zero (memset or BatchInit).
@@ -2560,23 +2586,23 @@ __device__ __forceinline__ void segment_prefix(uint32_t *segcnt, int SEGP, const
 // earlier pixels.  The cross-wavefront prefix is four counters per label, one thread per label.  (Until round 3 the tile
 // was 16 segments of 64 pixels, one pixel per lane and pass: a 16 x K counter matrix, cleared and prefix-scanned per tile.)
 template <bool RESIDUAL_ONLY, bool VEC>
-__global__ __launch_bounds__(256) void predict_quantize_kernel(const float *__restrict__ ri, const float *__restrict__ tm,
-                                                               const uint8_t *__restrict__ seg,
-                                                               const float *__restrict__ model,
-                                                               const uint32_t *__restrict__ hist, float acc,
-                                                               const float *__restrict__ label_acc,
-                                                               const float *__restrict__ residual_in, int P, int M,
-                                                               int KP, int T, int16_t *__restrict__ q16,
-                                                               int32_t *__restrict__ q32, float *__restrict__ pred_out,
-                                                               int32_t *__restrict__ epoch_inc) {
+__device__ __forceinline__ void predict_quantize_body(const float *__restrict__ ri, const float *__restrict__ tm,
+                                                      const uint8_t *__restrict__ seg,
+                                                      const float *__restrict__ model,
+                                                      const uint32_t *__restrict__ hist, float acc,
+                                                      const float *__restrict__ label_acc,
+                                                      const float *__restrict__ residual_in, int P, int M,
+                                                      int KP, int T, int16_t *__restrict__ q16,
+                                                      int32_t *__restrict__ q32, float *__restrict__ pred_out,
+                                                      int32_t *__restrict__ epoch_inc, const int b, const int t) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     // last kernel of a fused batch: the next call's projection flags get a new mark (BatchInit)
-    if (epoch_inc && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *epoch_inc += 1;
+    if (epoch_inc && b == 0 && t == 0 && threadIdx.x == 0) *epoch_inc += 1;
     float4 *smodel = reinterpret_cast<float4 *>(smem_raw);               // [KP] model rows
     uint32_t *wcnt = reinterpret_cast<uint32_t *>(smodel + KP);          // [4][KP]: pixels of label k in wavefront w -> its first output slot
     uint32_t *soff = wcnt + 4 * KP;                                      // [KP] this tile's output offsets per label
     float *sacc = reinterpret_cast<float *>(soff + KP);                  // [KP] quantisation step per label (non-uniform)
-    const int b = blockIdx.y, t = blockIdx.x, K = M + 2;
+    const int K = M + 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // per-frame bases (wave-uniform): scalar base + 32-bit lane offset instead of 64-bit address arithmetic per access
     seg += (int64_t)b * P;
@@ -2703,6 +2729,33 @@ __global__ __launch_bounds__(256) void predict_quantize_kernel(const float *__re
             if (q32) st_at(q32, o * 4u, (int32_t)qv[e]);
         }
     }
+}
+
+template <bool RESIDUAL_ONLY, bool VEC>
+__global__ __launch_bounds__(256) void predict_quantize_kernel(const float *__restrict__ ri, const float *__restrict__ tm,
+                                                               const uint8_t *__restrict__ seg,
+                                                               const float *__restrict__ model,
+                                                               const uint32_t *__restrict__ hist, float acc,
+                                                               const float *__restrict__ label_acc,
+                                                               const float *__restrict__ residual_in, int P, int M,
+                                                               int KP, int T, int16_t *__restrict__ q16,
+                                                               int32_t *__restrict__ q32, float *__restrict__ pred_out,
+                                                               int32_t *__restrict__ epoch_inc) {
+    predict_quantize_body<RESIDUAL_ONLY, VEC>(ri, tm, seg, model, hist, acc, label_acc, residual_in, P, M, KP, T, q16, q32, pred_out, epoch_inc, blockIdx.y, blockIdx.x);
+}
+struct QuantGroup {   // one geometry group of rpcc_compress_batch_mixed (the fused batch's form: prediction from model rows, int16 output)
+    const float *ri, *tm, *model, *label_acc;
+    const uint8_t *seg;
+    const uint32_t *hist;
+    int P, T, vec;
+    int16_t *q16;
+    int32_t *epoch_inc;
+};
+__global__ __launch_bounds__(256) void predict_quantize_multi_kernel(const MultiArgs<QuantGroup> m, float acc, int M, int KP) {
+    int b, t;
+    const QuantGroup &a = multi_locate(m, b, t);
+    if (a.vec) predict_quantize_body<false, true>(a.ri, a.tm, a.seg, a.model, a.hist, acc, a.label_acc, nullptr, a.P, M, KP, a.T, a.q16, nullptr, nullptr, a.epoch_inc, b, t);
+    else       predict_quantize_body<false, false>(a.ri, a.tm, a.seg, a.model, a.hist, acc, a.label_acc, nullptr, a.P, M, KP, a.T, a.q16, nullptr, nullptr, a.epoch_inc, b, t);
 }
 
 static int launch_predict_quantize(const float *ri, const float *tm, const uint8_t *seg, const float *model, float acc,
@@ -3140,6 +3193,84 @@ static int mixed_planes(const BatchPlan *pl, int G, hipStream_t st) {
     return RPCC_OK;
 }
 
+// The pixel-parallel stages as ONE launch over the groups as well (round 5): a workgroup finds its group, frame and tile through the table in the
+// kernel arguments (MultiArgs, rpcc_device.h); every group keeps its own buffers, image size and access variant.  Per group the results are
+// what its own launch gives (same kernel bodies).
+template <class A>
+static void multi_add(MultiArgs<A> &m, const A &a, int frames, int per_frame) {
+    m.a[m.n] = a; m.per[m.n] = per_frame; m.first[m.n + 1] = m.first[m.n] + frames * per_frame; m.n++;
+}
+static int mixed_assign(const BatchPlan *pl, int G, hipStream_t st) {
+    int rc;
+    for (int i = 0; i < G; i++) {
+        const rpcc_batch_io *io = pl[i].io;
+        if ((rc = launch_assign(io->ri, io->tm, io->ground, io->centers, pl[i].Bs, pl[i].g.H, pl[i].g.W, pl[i].M, io->seg, st,
+                                (io->flags & RPCC_FPS_MODE_BITS) ? nullptr : pl[i].temp))) return rc;
+    }
+    return RPCC_OK;
+}
+// label histograms + scan (+ the point model's rows, or the plane model's label-ordered lists)
+static int mixed_labels(const BatchPlan *pl, int G, hipStream_t st) {
+    const int M = pl[0].M, KP = kpad(M);
+    MultiArgs<HistGroup> mh; MultiArgs<ScanArgs> ms; MultiArgs<OrderGroup> mo;
+    mh.n = ms.n = mo.n = 0; mh.first[0] = ms.first[0] = mo.first[0] = 0;
+    for (int i = 0; i < G; i++) {
+        const BatchPlan &p = pl[i];
+        const rpcc_batch_io *io = p.io;
+        const int T = ntiles(p.P);
+        const bool point = io->model_method == 0;
+        const float *ri = point ? io->ri : nullptr;   // (the plane model needs no range sums)
+        const bool vec = (p.P & 3) == 0 && ((uintptr_t)io->seg & 3u) == 0 && (ri == nullptr || ((uintptr_t)ri & 15u) == 0);
+        multi_add(mh, HistGroup{ri, io->seg, p.P, T, vec ? 1 : 0, p.L.sums, p.L.flags, p.L.hist}, p.Bs, T);
+        multi_add(ms, ScanArgs{ri, io->seg, point ? io->ground : nullptr, p.P, M, KP, T, scan_kp2(M), p.L.sums, p.L.flags, p.L.hist,
+                               point ? io->model : nullptr, io->counts, io->nnz}, p.Bs, 1);
+        if (!point) multi_add(mo, OrderGroup{io->seg, p.L.hist, p.P, T, reinterpret_cast<uint32_t *>(p.extra), io->ri, io->tm, plane_pts4(p.extra, p.Bs, p.P)}, p.Bs, T);
+    }
+    model_hist_multi_kernel<<<mh.first[mh.n], 256, (size_t)KP * 12, st>>>(mh, KP);
+    LAUNCH_CHECK();
+    model_scan_multi_kernel<<<ms.first[ms.n], SCAN_THREADS, 0, st>>>(ms);
+    LAUNCH_CHECK();
+    if (mo.n > 0) {
+        label_order_multi_kernel<<<mo.first[mo.n], 256, (size_t)16 * (KP + 1) * 4 + (size_t)KP * 4, st>>>(mo, M, KP);
+        LAUNCH_CHECK();
+    }
+    return RPCC_OK;
+}
+// key points per group (the kernel's shape follows the image width), then salience levels and the quantiser once over the groups
+static int mixed_quantise(const BatchPlan *pl, int G, hipStream_t st) {
+    int rc;
+    const int M = pl[0].M, KP = kpad(M);
+    MultiArgs<SalienceGroup> msal; MultiArgs<QuantGroup> mq;
+    msal.n = mq.n = 0; msal.first[0] = mq.first[0] = 0;
+    for (int i = 0; i < G; i++) {
+        const BatchPlan &p = pl[i];
+        const rpcc_batch_io *io = p.io;
+        if (io->nonuniform) {
+            const rpcc_nonuniform_cfg *nu = io->nonuniform;
+            if ((rc = launch_features(io->ri, io->seg, p.Bs, p.g.H, p.g.W, nu->feature_region, nu->segments, nu->sharp_num, nu->less_sharp_num,
+                                      nu->flat_num, nullptr, io->key_point_map, st, p.kpn, M + 2)))
+                return rc;
+            SalienceGroup sg;
+            sg.counts = io->counts; sg.kpn = p.kpn; sg.salience = io->salience; sg.label_acc = p.label_acc;
+            for (int l = 0; l < 8; l++) { sg.sp.level_kp_num[l] = l < nu->levels ? nu->level_kp_num[l] : 0; sg.sp.level_acc[l] = l < nu->levels ? nu->level_acc[l] : 0.f; }
+            sg.sp.levels = nu->levels; sg.sp.ground_level = nu->ground_level;
+            multi_add(msal, sg, p.Bs, 1);
+        }
+        const int T = ntiles(p.P);
+        const bool vec = (p.P & 3) == 0 && ((uintptr_t)io->seg & 3u) == 0 && aligned16(io->ri) && aligned16(io->tm);
+        // (every group's kernel advances its own workspace's epoch: its frame 0 / tile 0 workgroup)
+        multi_add(mq, QuantGroup{io->ri, io->tm, io->model, p.label_acc, io->seg, p.L.hist, p.P, T, vec ? 1 : 0, io->q16, p.epoch}, p.Bs, T);
+    }
+    if (msal.n > 0) {
+        salience_levels_multi_kernel<<<msal.first[msal.n], 256, 0, st>>>(msal, M);
+        LAUNCH_CHECK();
+    }
+    const size_t sh = (size_t)KP * 16 + (size_t)4 * KP * 4 + (size_t)KP * 4 + (size_t)KP * 4;
+    predict_quantize_multi_kernel<<<mq.first[mq.n], 256, sh, st>>>(mq, pl[0].acc, M, KP);
+    LAUNCH_CHECK();
+    return RPCC_OK;
+}
+
 extern "C" int rpcc_compress_batch_mixed(const rpcc_batch_io *ios, const int *Bs, const rpcc_geom *geoms, int G, int M,
                                          double ground_threshold, float acc, void *const *wss, void *stream) {
     ARG_TRY(ios != nullptr && Bs != nullptr && geoms != nullptr && wss != nullptr && G >= 1 && G <= RPCC_MAX_GROUPS);
@@ -3154,6 +3285,8 @@ extern "C" int rpcc_compress_batch_mixed(const rpcc_batch_io *ios, const int *Bs
         if (stage == ST_GROUND) rc = mixed_ground(pl, G, st);
         else if (stage == ST_FPS) rc = mixed_fps(pl, G, st);
         else if (stage == ST_PLANES) rc = mixed_planes(pl, G, st);
+        else if (stage == ST_ASSIGN_LABELS) { if (!(rc = mixed_assign(pl, G, st))) rc = mixed_labels(pl, G, st); }
+        else if (stage == ST_QUANTISE) rc = mixed_quantise(pl, G, st);
         else
             for (int i = 0; i < G && !(rc = run_stage(pl[i], stage, st)); i++) {}
         if (rc) return rc;
