@@ -494,7 +494,8 @@ __device__ __forceinline__ bool fps_tile_update(const FpsQuad &q, bool org_on, f
     return true;
 }
 
-// TPL: tiles per lane (1; 2 for images with more tiles than the workgroup has lanes -- 80 x 2000, 128 x 2048: slot s of lane l is position (l + 64 s) NW + wave)
+// TPL: tiles per lane (1; 2 for images with more tiles than the workgroup has lanes -- 80 x 2000, 128 x 2048: slot s of lane l is position (l + 64 s) NW + wave).
+// (Round 5 ran the headline with 4 / 2 / 1 wavefronts per frame and 2 / 4 / 8 tiles per lane: every step towards fewer wavefronts is slower, profiles/HISTORY.md.)
 template <bool RANGE, bool VEC, int FPS_TT, bool SOA, bool EDGE = false, int TPL = 1>
 __device__ __forceinline__ void fps_regtab_body(const float *__restrict__ src, const float *__restrict__ rays,
                                                 float *__restrict__ temp, const int32_t *__restrict__ info,
@@ -568,20 +569,22 @@ __device__ __forceinline__ void fps_regtab_body(const float *__restrict__ src, c
     auto locate = [&](int l, int s, FpsQuad &q) {
         if (RANGE) {
             uint32_t org = (uint32_t)__builtin_amdgcn_readlane((int)my_org[0], l);
-            if (TPL > 1 && s) org = (uint32_t)__builtin_amdgcn_readlane((int)my_org[TPL - 1], l);
+#pragma unroll
+            for (int t = 1; t < TPL; t++) if (s == t) org = (uint32_t)__builtin_amdgcn_readlane((int)my_org[t], l);   // (s is wave-uniform)
             const int ncol = (int)((org >> 22) & 31u) + 1, nrow = (int)(org >> 27) + 1;
             const int nv = lrow < nrow ? min(max(ncol - lcol, 0), 4) : 0;
             q.nval = nv;
             q.p0 = nv > 0 ? (int)(org & 0x3FFFFFu) + lrow * g.W + lcol : 0;
         } else {
             int tl = __builtin_amdgcn_readlane(my_t[0], l);
-            if (TPL > 1 && s) tl = __builtin_amdgcn_readlane(my_t[TPL - 1], l);
+#pragma unroll
+            for (int t = 1; t < TPL; t++) if (s == t) tl = __builtin_amdgcn_readlane(my_t[t], l);
             const int p = tl * FPS_TILE + 4 * lane;
             q.nval = min(max(N - p, 0), 4);
             q.p0 = q.nval > 0 ? p : 0;
         }
     };
-    static_assert(TPL == 1 || TPL == 2, "one or two tiles per lane");
+    static_assert(TPL >= 1 && TPL <= 8, "tiles per lane");
     auto store_entry = [&](int l, int s, const FpsTileOut &o, bool with_box) {
 #pragma unroll
         for (int t = 0; t < TPL; t++) {
@@ -604,9 +607,14 @@ __device__ __forceinline__ void fps_regtab_body(const float *__restrict__ src, c
     // (mv[s]: the lanes whose slot-s tile is to be visited; slot 0's tiles first)
     auto visit = [&](const unsigned long long (&mv)[TPL], bool with_box) {
         bool viol = false;
-        unsigned long long m = mv[0], m1 = TPL > 1 ? mv[TPL - 1] : 0ull;
+        // (the slots' masks one after the other: `next` steps to the next slot that has tiles)
+        unsigned long long m = mv[0];
         int cur = 0;
-        if (TPL > 1 && m == 0ull) { m = m1; m1 = 0ull; cur = 1; }
+        auto next = [&]() {
+#pragma unroll
+            for (int t = 1; t < TPL; t++) if (m == 0ull && cur < t) { m = mv[t]; cur = t; }
+        };
+        if (TPL > 1) next();
         while (m) {
             int l[FPS_VISIT], sl[FPS_VISIT];
             bool on[FPS_VISIT];
@@ -618,7 +626,7 @@ __device__ __forceinline__ void fps_regtab_body(const float *__restrict__ src, c
                 l[u] = on[u] ? (int)__ffsll((long long)m) - 1 : l[0];
                 sl[u] = on[u] ? cur : sl[0];
                 m &= m - 1ull;     // (0 & anything stays 0)
-                if (TPL > 1 && m == 0ull && m1 != 0ull) { m = m1; m1 = 0ull; cur = 1; }   // slot 0's tiles are done: on to slot 1's
+                if (TPL > 1) next();   // this slot's tiles are done: on to the next slot that has any
                 if (u < FPS_VISIT_UNCOND || on[u]) {   // (wave-uniform) the first pair unconditionally, the rest only when there is a tile
                     locate(l[u], sl[u], q[u]);
                     fps_quad_load<RANGE, VEC, SOA, EDGE>(src, SOA ? rays_soa : rays, temp, q[u], N);
@@ -646,11 +654,12 @@ __device__ __forceinline__ void fps_regtab_body(const float *__restrict__ src, c
         // (two tiles per lane: the lane's better one first -- larger key, lower index among equals)
         uint32_t key = have[0] ? fps_val_key(tmax[0]) : 0u, targ_b = targ[0];
         float cx_b = cx[0], cy_b = cy[0], cz_b = cz[0];
-        if (TPL > 1) {
-            const uint32_t k1 = have[TPL - 1] ? fps_val_key(tmax[TPL - 1]) : 0u;
-            const bool sec = k1 > key || (k1 == key && targ[TPL - 1] < targ_b);
-            key = sec ? k1 : key; targ_b = sec ? targ[TPL - 1] : targ_b;
-            cx_b = sec ? cx[TPL - 1] : cx_b; cy_b = sec ? cy[TPL - 1] : cy_b; cz_b = sec ? cz[TPL - 1] : cz_b;
+#pragma unroll
+        for (int t = 1; t < TPL; t++) {
+            const uint32_t k1 = have[t] ? fps_val_key(tmax[t]) : 0u;
+            const bool sec = k1 > key || (k1 == key && targ[t] < targ_b);
+            key = sec ? k1 : key; targ_b = sec ? targ[t] : targ_b;
+            cx_b = sec ? cx[t] : cx_b; cy_b = sec ? cy[t] : cy_b; cz_b = sec ? cz[t] : cz_b;
         }
         uint32_t vmax = dpp_max_u32(key);
         // lowest index among the lanes that hold the maximum: almost always one lane, whose index is read directly (the second
@@ -740,7 +749,7 @@ __device__ __forceinline__ void fps_regtab_body(const float *__restrict__ src, c
             const float bound = (g0 * g0 + g1 * g1) + g2 * g2;
             vm[s] = __ballot(have[s] && bound < tmax[s]);
         }
-        TRACE_FPS_TILES(vm[0] | (TPL > 1 ? vm[TPL - 1] : 0ull), j);
+        TRACE_FPS_TILES(vm[0], j);
         TRACE_FPS_PHASE(1);
         visit(vm, false);
         TRACE_FPS_PHASE(2);
