@@ -25,6 +25,9 @@ import torch  # first: the library binds to the HIP runtime torch has loaded
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _l = C.CDLL(os.environ.get("RPCC_HIP_LIB", os.path.join(_HERE, "..", "r-pcc_amd", "lib", "librpcc_hip.so")))
+RPCC_ABI_VERSION = 101      # include/rpcc_hip.h: the structs carry no size field, so a binding checks the library's version before anything else
+if _l.rpcc_version() != RPCC_ABI_VERSION:
+    raise ImportError("librpcc_hip.so reports interface version %d, this binding was written for %d" % (_l.rpcc_version(), RPCC_ABI_VERSION))
 _l.rpcc_last_error.restype = C.c_char_p
 for _n in ("rpcc_workspace_bytes", "rpcc_project_scratch_bytes", "rpcc_fps_table_bytes", "rpcc_codec_workspace_bytes"):
     getattr(_l, _n).restype = C.c_size_t
