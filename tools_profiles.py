@@ -87,7 +87,8 @@ L = [f"# {tag} PMC passes: HBM-side traffic and VALU instructions per kernel lau
      "`assign_kernel` reads the 134 MB range image; both report about half, so read = 2 x FETCH_SIZE also for 4 B/lane loads.",
      "WRITE_SIZE needs no correction (`project_pix_kernel` writes 232 MB of records, `assign_kernel` 33.5 MB of labels).",
      "SQ_INSTS_VALU counts wave-level VALU instructions.  A wave64 instruction occupies its SIMD for 2, 4 or 8 cycles depending on its class (measured: profiles/r04_valu_peak.md);",
-     "mean cycles = the kernel's static instruction mix weighted with those classes (profiles/isa_mix_current.json); VALU busy = instructions x mean cycles / (1024 SIMDs x 2.4 GHz x duration).", "",
+     "mean cycles = the launch's dynamic class counts (below) weighted with the static cycles inside each class -- the kernel's static mix alone when the class passes are missing --",
+     "(profiles/isa_mix_current.json); VALU busy = instructions x mean cycles / (1024 SIMDs x 2.4 GHz x duration).", "",
      "| kernel | launches | FETCH_SIZE raw MB | read MB (x2) | WRITE_SIZE MB | HBM-side traffic MB/launch | VALU M wave-instr./launch | mean cycles / instr. | avg us (profiled) | traffic TB/s | VALU busy % |", "|---|---|---|---|---|---|---|---|---|---|---|"]
 js = {}
 for n in names:
