@@ -24,7 +24,7 @@ extern "C" {
 #define RPCC_OK 0
 #define RPCC_ERR_ARG (-1)
 #define RPCC_ERR_HIP (-2)
-#define RPCC_MAX_CLUSTERS 254 /* labels are stored as uint8 */
+#define RPCC_MAX_CLUSTERS 254 /* labels are stored as uint8 (more clusters: the rpcc_*_wide entries below) */
 #define RPCC_MAX_BATCH 65535   /* frames per call: the frame index is a grid dimension */
 #define RPCC_INFO_INTS 8       /* int32 per frame in the `info` arrays below */
 #define RPCC_FPS_BRUTEFORCE 1  /* flag: farthest point sampling by the one-pass-per-centre kernel (test reference) */
@@ -44,8 +44,8 @@ extern "C" {
 
 /* Interface version: changes whenever the layout of a struct below or the meaning of an argument changes (the structs carry no size
  * field).  A binding compares rpcc_version() with the RPCC_ABI_VERSION of the header it was built against before it calls anything else
- * (r-pcc_amd/_lib.py does).  100: round 3.  101: rpcc_batch_io.point_stride_bytes. */
-#define RPCC_ABI_VERSION 101
+ * (r-pcc_amd/_lib.py does).  100: round 3.  101: rpcc_batch_io.point_stride_bytes.  102: the uint16-label entries (rpcc_*_wide). */
+#define RPCC_ABI_VERSION 102
 int rpcc_version(void);
 const char *rpcc_last_error(void);
 
@@ -327,6 +327,20 @@ int rpcc_compress_batch(const rpcc_batch_io *io, int B, rpcc_geom g, int M, doub
 #define RPCC_MAX_GROUPS 4
 int rpcc_compress_batch_mixed(const rpcc_batch_io *ios, const int *Bs, const rpcc_geom *geoms, int G, int M,
                               double ground_threshold, float acc, void *const *wss, void *stream);
+
+/* cluster_num above RPCC_MAX_CLUSTERS (the reference takes any value, cfgs/compressor.yaml:22; its labels travel as uint16,
+ * utils/compress_utils.py:160): the same batch with `io->seg` pointing to uint16 [B,P] labels, 255 <= M <= RPCC_MAX_CLUSTERS_WIDE (smaller M work too).
+ * Same stages, same arithmetic, same results as rpcc_compress_batch -- one thread per pixel or label, per-label totals by global atomics, the ordered
+ * scatter through one stable radix sort of (frame, label) keys: written for correctness, not for speed (csrc/wide_kernels.h).  All four framework / model
+ * combinations; the CUDA-binary FPS modes are not available here.  ws: rpcc_wide_workspace_bytes(B, P, M, total_points) bytes.
+ * The container's side of it: the contour codec and the decoder body on uint16 label maps (rpcc_decode_wide: ws of rpcc_wide_workspace_bytes(B, P, M, 0)). */
+#define RPCC_MAX_CLUSTERS_WIDE 65533
+size_t rpcc_wide_workspace_bytes(int B, int P, int M, int64_t total_points);
+int rpcc_compress_batch_wide(const rpcc_batch_io *io, int B, rpcc_geom g, int M, double ground_threshold, float acc, void *ws, void *stream);
+int rpcc_contour_encode_wide(const uint16_t *seg, int B, int H, int W, uint8_t *contour_bits, uint16_t *idx_sequence, int32_t *nseq, void *ws, void *stream);
+int rpcc_contour_decode_wide(const uint8_t *contour_bits, const uint16_t *idx_sequence, int B, int H, int W, uint16_t *seg, void *ws, void *stream);
+int rpcc_decode_wide(const uint16_t *seg, const int16_t *q16, const float *model, const float *tm, const double *level_acc, int levels,
+                     const uint8_t *salience, int B, int P, int M, float *ri_rec, float *pc_rec, void *ws, void *stream);
 
 /* Developer hook (libraries built with -DRPCC_DEVTRACE only; the shipped one returns RPCC_ERR_ARG for a non-NULL buffer):
  * register a device int64 buffer of at least RPCC_DEBUG_STAMPS_WORDS words; instrumented kernels store the shader clock at

@@ -38,7 +38,8 @@ INFO_INTS = 8          # RPCC_INFO_INTS
 FPS_BRUTEFORCE = 1     # RPCC_FPS_BRUTEFORCE
 FPS_FMA1, FPS_FMA2, FPS_TIE_CUDA = 2, 4, 8   # RPCC_FPS_FMA1 / RPCC_FPS_FMA2 / RPCC_FPS_TIE_CUDA
 MAX_CLUSTERS = 254     # RPCC_MAX_CLUSTERS: labels 0 .. cluster_num + 1 are stored as uint8 on the device
-ABI_VERSION = 101      # RPCC_ABI_VERSION: the layout of rpcc_batch_io / rpcc_geom this binding was written for
+MAX_CLUSTERS_WIDE = 65533   # RPCC_MAX_CLUSTERS_WIDE: the uint16-label entries (rpcc_*_wide)
+ABI_VERSION = 102      # RPCC_ABI_VERSION: the layout of rpcc_batch_io / rpcc_geom this binding was written for
 
 
 def fps_mode_flags(fma=0, cuda_tie=False):
@@ -91,6 +92,11 @@ _SIGS = {
     "rpcc_workspace_bytes_general": (C.c_size_t, [_I, _I, _I, _I64]),
     "rpcc_compress_batch": (C.c_int, [C.POINTER(BatchIO), _I, Geom, _I, _D, _F, _VP, _VP]),
     "rpcc_compress_batch_mixed": (C.c_int, [C.POINTER(BatchIO), C.POINTER(C.c_int), C.POINTER(Geom), _I, _I, _D, _F, C.POINTER(C.c_void_p), _VP]),
+    "rpcc_wide_workspace_bytes": (C.c_size_t, [_I, _I, _I, _I64]),
+    "rpcc_compress_batch_wide": (C.c_int, [C.POINTER(BatchIO), _I, Geom, _I, _D, _F, _VP, _VP]),
+    "rpcc_contour_encode_wide": (C.c_int, [_VP, _I, _I, _I, _VP, _VP, _VP, _VP, _VP]),
+    "rpcc_contour_decode_wide": (C.c_int, [_VP, _VP, _I, _I, _I, _VP, _VP, _VP]),
+    "rpcc_decode_wide": (C.c_int, [_VP, _VP, _VP, _VP, C.POINTER(C.c_double), _I, _VP, _I, _I, _I, _VP, _VP, _VP, _VP]),
     "rpcc_debug_stamps": (C.c_int, [_VP]),
     "rpcc_timer_create": (_VP, []),
     "rpcc_timer_destroy": (None, [_VP]),

@@ -12,16 +12,19 @@
 // Pass 1 counts contour bits per 1024-pixel tile, pass 2 turns the counts into offsets (one workgroup
 // per frame), pass 3 writes the packed bits and scatters the labels.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool contour_bit(const uint8_t *__restrict__ seg, int p, int W) {
+// (L: the label type -- uint8_t, or uint16_t for cluster_num above RPCC_MAX_CLUSTERS, wide_kernels.h)
+template <class L>
+__device__ __forceinline__ bool contour_bit(const L *__restrict__ seg, int p, int W) {
     const int col = p % W;
     return col == 0 || seg[p] != seg[p - 1];
 }
 
-__global__ __launch_bounds__(256) void contour_count_kernel(const uint8_t *__restrict__ seg, int P, int W, int T,
+template <class L>
+__global__ __launch_bounds__(256) void contour_count_kernel(const L *__restrict__ seg, int P, int W, int T,
                                                             uint32_t *__restrict__ tile_cnt) {
     __shared__ int s[4];
     const int b = blockIdx.y, t = blockIdx.x;
-    const uint8_t *sg = seg + (int64_t)b * P;
+    const L *sg = seg + (int64_t)b * P;
     int cnt = 0;
 #pragma unroll
     for (int j = 0; j < TILE / 256; j++) {
@@ -58,12 +61,13 @@ __global__ __launch_bounds__(256) void tile_scan_kernel(uint32_t *__restrict__ t
     if (threadIdx.x == 0 && total) total[b] = (int32_t)run;
 }
 
-__global__ __launch_bounds__(256) void contour_write_kernel(const uint8_t *__restrict__ seg, int P, int W, int T,
+template <class L>
+__global__ __launch_bounds__(256) void contour_write_kernel(const L *__restrict__ seg, int P, int W, int T,
                                                             const uint32_t *__restrict__ tile_off,
                                                             uint8_t *__restrict__ bits, uint16_t *__restrict__ seq) {
     __shared__ uint32_t segcnt[16];
     const int b = blockIdx.y, t = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint8_t *sg = seg + (int64_t)b * P;
+    const L *sg = seg + (int64_t)b * P;
     const int nbytes = (P + 7) >> 3;
     uint8_t *ob = bits + (int64_t)b * nbytes;
     uint16_t *os = seq + (int64_t)b * P;
@@ -124,9 +128,10 @@ __global__ __launch_bounds__(256) void contour_bits_count_kernel(const uint8_t *
     if (threadIdx.x == 0) tile_cnt[(int64_t)b * T + t] = (uint32_t)(s[0] + s[1] + s[2] + s[3]);
 }
 
+template <class L>
 __global__ __launch_bounds__(256) void recover_map_kernel(const uint8_t *__restrict__ bits, const uint16_t *__restrict__ seq,
                                                           int P, int T, const uint32_t *__restrict__ tile_off,
-                                                          uint8_t *__restrict__ seg) {
+                                                          L *__restrict__ seg) {
     __shared__ uint32_t segcnt[16];
     const int b = blockIdx.y, t = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nbytes = (P + 7) >> 3;
@@ -152,7 +157,7 @@ __global__ __launch_bounds__(256) void recover_map_kernel(const uint8_t *__restr
                 const int p = t * TILE + j * 256 + threadIdx.x;
                 // inclusive count of contour bits up to this pixel
                 const uint32_t k = run + (uint32_t)__popcll(m[j] & ((2ull << lane) - 1ull));
-                if (p < P) seg[(int64_t)b * P + p] = (uint8_t)(k ? is[k - 1] : 0);
+                if (p < P) seg[(int64_t)b * P + p] = (L)(k ? is[k - 1] : 0);
             }
             run += segcnt[j * 4 + w];
         }

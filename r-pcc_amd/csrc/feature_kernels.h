@@ -92,8 +92,9 @@ __device__ __forceinline__ void bot3_insert(feat_key x, feat_key &c1, feat_key &
 // Q: keys per lane (chunk <= 64 * Q) or FEAT_ROWMODE; GP: 64-column groups per wavefront (W <= 256 * GP);
 // FEATOUT = false (row mode only, ranges >= 0): no curvature image is produced, the curvatures take the place of the row in
 // LDS with the "accepted" flag in their sign bit -- 11 bytes of LDS per column instead of 16: 7 workgroups per CU, not 5.
-template <int Q, int GP = FEAT_GPW, bool FEATOUT = true>
-__global__ __launch_bounds__(FEAT_THREADS) void features_kernel(const float *__restrict__ ri, const uint8_t *__restrict__ seg,
+// LabelT: the label type (uint16_t for cluster_num above RPCC_MAX_CLUSTERS: the key points per label then go straight to the global counters)
+template <int Q, int GP = FEAT_GPW, bool FEATOUT = true, class LabelT = uint8_t>
+__global__ __launch_bounds__(FEAT_THREADS) void features_kernel(const float *__restrict__ ri, const LabelT *__restrict__ seg,
                                                                 int H, int W, FeatParams fp, float *__restrict__ feat,
                                                                 uint8_t *__restrict__ kp, int32_t *__restrict__ kpn = nullptr,
                                                                 int K = 0) {
@@ -407,9 +408,12 @@ __global__ __launch_bounds__(FEAT_THREADS) void features_kernel(const float *__r
         kp[base + c] = kprow[c];
         // key points per label for the salience levels (sparse: a few dozen per row), tallied in LDS first: one device
         // atomic per label present in the row instead of one per key point (1.6 M atomics per batch cost 0.2 ms)
-        if (kpn && kprow[c] > 0) atomicAdd(&kcnt[seg[base + c]], 1);
+        if (kpn && kprow[c] > 0) {
+            if (sizeof(LabelT) == 1) atomicAdd(&kcnt[seg[base + c]], 1);
+            else atomicAdd(&kpn[(int64_t)b * K + seg[base + c]], 1);
+        }
     }
-    if (kpn) {  // kpn is zeroed by the caller
+    if (kpn && sizeof(LabelT) == 1) {  // kpn is zeroed by the caller
         __syncthreads();
         if (tid < K && kcnt[tid] > 0) atomicAdd(&kpn[(int64_t)b * K + tid], kcnt[tid]);
     }

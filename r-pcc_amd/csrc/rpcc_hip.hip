@@ -2808,9 +2808,9 @@ extern "C" int rpcc_contour_encode(const uint8_t *seg, int B, int H, int W, uint
     hipStream_t st = (hipStream_t)stream;
     const int P = H * W, T = ntiles(P);
     uint32_t *tile_cnt = reinterpret_cast<uint32_t *>(ws);
-    contour_count_kernel<<<dim3(T, B), 256, 0, st>>>(seg, P, W, T, tile_cnt);
+    contour_count_kernel<uint8_t><<<dim3(T, B), 256, 0, st>>>(seg, P, W, T, tile_cnt);
     tile_scan_kernel<<<B, 256, 0, st>>>(tile_cnt, T, nseq);
-    contour_write_kernel<<<dim3(T, B), 256, 0, st>>>(seg, P, W, T, tile_cnt, contour_bits, idx_sequence);
+    contour_write_kernel<uint8_t><<<dim3(T, B), 256, 0, st>>>(seg, P, W, T, tile_cnt, contour_bits, idx_sequence);
     LAUNCH_CHECK();
     return RPCC_OK;
 }
@@ -2823,7 +2823,7 @@ extern "C" int rpcc_contour_decode(const uint8_t *contour_bits, const uint16_t *
     uint32_t *tile_cnt = reinterpret_cast<uint32_t *>(ws);
     contour_bits_count_kernel<<<dim3(T, B), 256, 0, st>>>(contour_bits, P, T, tile_cnt);
     tile_scan_kernel<<<B, 256, 0, st>>>(tile_cnt, T, nullptr);
-    recover_map_kernel<<<dim3(T, B), 256, 0, st>>>(contour_bits, idx_sequence, P, T, tile_cnt, seg);
+    recover_map_kernel<uint8_t><<<dim3(T, B), 256, 0, st>>>(contour_bits, idx_sequence, P, T, tile_cnt, seg);
     LAUNCH_CHECK();
     return RPCC_OK;
 }
@@ -2870,7 +2870,8 @@ extern "C" int rpcc_backproject(const float *ri, const float *tm, int B, int P, 
 #include "feature_kernels.h"
 
 // feat may be NULL (the fused entry only needs the key-point map)
-static int launch_features(const float *ri, const uint8_t *seg, int B, int H, int W, int feature_region, int segments,
+template <class L = uint8_t>
+static int launch_features(const float *ri, const L *seg, int B, int H, int W, int feature_region, int segments,
                            int sharp_num, int less_sharp_num, int flat_num, float *feat, uint8_t *key_point_map,
                            hipStream_t st, int32_t *kpn = nullptr, int K = 0) {
     ARG_TRY(feature_region >= 1 && feature_region <= 16 && segments >= 1 && W < 65536);
@@ -2883,8 +2884,8 @@ static int launch_features(const float *ri, const uint8_t *seg, int B, int H, in
     const int need = ((W - 2 * feature_region) / segments + 63) / 64;  // keys per lane
 #define FEAT_LAUNCH_G(Q_, G_, F_)                                                                                         \
     do {                                                                                                                  \
-        HIP_TRY(ensure_dyn_lds(reinterpret_cast<const void *>(&features_kernel<Q_, G_, F_>), (int)sh));                   \
-        features_kernel<Q_, G_, F_><<<dim3(H, B), FEAT_THREADS, sh, st>>>(ri, seg, H, W, fp, feat, key_point_map, kpn, K); \
+        HIP_TRY(ensure_dyn_lds(reinterpret_cast<const void *>(&features_kernel<Q_, G_, F_, L>), (int)sh));                   \
+        features_kernel<Q_, G_, F_, L><<<dim3(H, B), FEAT_THREADS, sh, st>>>(ri, seg, H, W, fp, feat, key_point_map, kpn, K); \
     } while (0)
 #define FEAT_LAUNCH(Q_, F_)                                                \
     do {                                                                   \
@@ -3291,5 +3292,166 @@ extern "C" int rpcc_compress_batch_mixed(const rpcc_batch_io *ios, const int *Bs
             for (int i = 0; i < G && !(rc = run_stage(pl[i], stage, st)); i++) {}
         if (rc) return rc;
     }
+    return RPCC_OK;
+}
+
+// ================================================================================================
+// cluster_num above RPCC_MAX_CLUSTERS: uint16 labels, the plain kernels of wide_kernels.h
+// ================================================================================================
+#include "wide_kernels.h"
+
+// carve-up of a wide workspace: [ keys, vals (in / out) u32 4 x [B,P] | pos i32 [B,P] | order u32 [B,P] | pts4 float4 [B,P] | sums u64 [B,K] |
+//   base u32 [B,K] | kpn i32 [B,K] | label_acc f32 [B,K] | flags i32 [B,4] | cen4 float4 [B,M] | FPS temp f32 [B,P] | FPS tile table |
+//   projection scratch | radix sort scratch ]
+struct WideWs {
+    uint32_t *keys_in, *vals_in, *keys_out, *vals_out, *order, *base;
+    int32_t *pos, *kpn, *flags;
+    float4 *pts4, *cen4;
+    unsigned long long *sums;
+    float *label_acc, *temp, *tiletab;
+    char *proj;
+    size_t proj_bytes;
+    void *sort_tmp;
+    size_t sort_bytes, bytes;
+};
+static size_t wide_sort_bytes(int64_t n, int end_bit) {
+    size_t b = 0;
+    uint32_t *z = nullptr;
+    (void)rocprim::radix_sort_pairs(nullptr, b, z, z, z, z, (size_t)n, 0u, (unsigned)end_bit, (hipStream_t)0);
+    return b;
+}
+static inline int wide_key_bits(int B) { int v = 16; while ((1 << (v - 16)) < B) v++; return v; }
+static WideWs wide_layout(void *ws, int B, int P, int M, int64_t total_points) {
+    WideWs w;
+    const size_t BP = (size_t)B * P, K = (size_t)M + 2, a = 255;
+    char *p = reinterpret_cast<char *>(ws);
+    size_t off = 0;
+    auto take = [&](size_t n) { char *r = p + off; off += (n + a) & ~a; return r; };
+    w.keys_in = (uint32_t *)take(BP * 4); w.vals_in = (uint32_t *)take(BP * 4); w.keys_out = (uint32_t *)take(BP * 4); w.vals_out = (uint32_t *)take(BP * 4);
+    w.pos = (int32_t *)take(BP * 4); w.order = (uint32_t *)take(BP * 4); w.pts4 = (float4 *)take(BP * 16);
+    w.sums = (unsigned long long *)take((size_t)B * K * 8); w.base = (uint32_t *)take((size_t)B * K * 4); w.kpn = (int32_t *)take((size_t)B * K * 4);
+    w.label_acc = (float *)take((size_t)B * K * 4); w.flags = (int32_t *)take((size_t)B * 16); w.cen4 = (float4 *)take((size_t)B * M * 16);
+    w.temp = (float *)take(BP * 4);
+    w.tiletab = (float *)take((size_t)B * FPS_TAB_ROWS * ((P + 31) / 32 + 4096) * 4);
+    w.proj_bytes = (project_scratch_bytes(total_points, B, P) + 255) & ~(size_t)255;
+    w.proj = take(w.proj_bytes);
+    w.sort_bytes = wide_sort_bytes((int64_t)BP, wide_key_bits(B));
+    w.sort_tmp = take(w.sort_bytes + 256);
+    w.bytes = off;
+    return w;
+}
+extern "C" size_t rpcc_wide_workspace_bytes(int B, int P, int M, int64_t total_points) {
+    if (B <= 0 || P <= 0 || M <= 0) return 0;
+    return wide_layout(nullptr, B, P, M, total_points).bytes + 4096;
+}
+// counts, sums, the sort and the positions of a segmentation (encoder and decoder)
+template <class L>
+static int wide_order(const L *seg, const float *ri_for_sums, const float *ri, const float *tm, int B, int P, int M, const WideWs &w, int32_t *counts,
+                      int32_t *nnz, bool want_pts, hipStream_t st) {
+    const int K = M + 2;
+    const int64_t n = (int64_t)B * P;
+    HIP_TRY(hipMemsetAsync(counts, 0, (size_t)B * K * 4, st));
+    HIP_TRY(hipMemsetAsync(w.sums, 0, (size_t)B * K * 8, st));
+    HIP_TRY(hipMemsetAsync(w.flags, 0, (size_t)B * 16, st));
+    wide_keys_kernel<L><<<dim3((P + 255) / 256, B), 256, 0, st>>>(seg, ri_for_sums, P, K, w.keys_in, w.vals_in, counts, w.sums, w.flags);
+    LAUNCH_CHECK();
+    size_t sb = w.sort_bytes;
+    HIP_TRY(rocprim::radix_sort_pairs(w.sort_tmp, sb, w.keys_in, w.keys_out, w.vals_in, w.vals_out, (size_t)n, 0u, (unsigned)wide_key_bits(B), st));
+    wide_bases_kernel<<<B, 256, 0, st>>>(counts, K, w.base, nnz);
+    wide_positions_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(w.keys_out, w.vals_out, counts, P, K, n, w.pos, w.order, ri, tm, want_pts ? w.pts4 : nullptr);
+    LAUNCH_CHECK();
+    return RPCC_OK;
+}
+
+extern "C" int rpcc_compress_batch_wide(const rpcc_batch_io *io, int B, rpcc_geom g, int M, double ground_threshold, float acc, void *ws, void *stream) {
+    ARG_TRY(io != nullptr && ws != nullptr && B > 0 && B <= RPCC_MAX_BATCH && M > 0 && M <= RPCC_MAX_CLUSTERS_WIDE && g.H > 1 && g.W > 0);
+    ARG_TRY(io->offsets && io->tm && io->ground && io->ri && io->seg && io->cen_pix && io->centers && io->model && io->counts && io->q16 && io->nnz && io->info);
+    ARG_TRY(io->model_method == 0 || io->model_method == 1);
+    ARG_TRY(!(io->flags & RPCC_FPS_MODE_BITS));
+    ARG_TRY(point_floats(io->point_stride_bytes) > 0 && (io->point_stride_bytes != 16 || (reinterpret_cast<uintptr_t>(io->xyz) & 15u) == 0));
+    if (io->nonuniform) ARG_TRY(io->salience && io->key_point_map && io->nonuniform->levels >= 1 && io->nonuniform->levels <= 8 &&
+                                io->nonuniform->ground_level >= 0 && io->nonuniform->ground_level < io->nonuniform->levels);
+    hipStream_t st = (hipStream_t)stream;
+    const int P = g.H * g.W, K = M + 2;
+    ARG_TRY(fps_tiling_range(g.H, g.W).T <= FPS_TILED_MAX_TILES && P < (1 << 22));
+    const WideWs w = wide_layout(ws, B, P, M, io->total);
+    uint16_t *seg = reinterpret_cast<uint16_t *>(io->seg);
+    int rc;
+    if ((rc = launch_project(io->xyz, io->offsets, io->total, 0, B, g, io->ri, w.proj, w.proj_bytes, st, nullptr, nullptr, nullptr, nullptr,
+                             point_floats(io->point_stride_bytes)))) return rc;
+    if (io->ground_seed >= 0 && (rc = launch_ground_ransac(io->ri, io->tm, B, P, (uint32_t)io->ground_seed, false, io->ground, nullptr, st, nullptr, io->frame_ids))) return rc;
+    const bool brute = (io->flags & RPCC_FPS_BRUTEFORCE) != 0;
+    if ((rc = launch_ground_mask(io->ri, io->tm, io->ground, ground_threshold, B, g.H, g.W, w.temp, io->info, brute ? nullptr : w.tiletab, st, false))) return rc;
+    if ((rc = launch_fps_range(io->ri, io->tm, w.temp, io->info, B, g.H, g.W, M, io->cen_pix, io->centers, io->flags, false, brute ? nullptr : w.tiletab, nullptr, st))) return rc;
+    wide_cen4_kernel<<<(B * M + 255) / 256, 256, 0, st>>>(io->centers, B * M, w.cen4);
+    wide_assign_kernel<<<dim3((P + 255) / 256, B), 256, 0, st>>>(io->ri, io->tm, io->ground, w.cen4, P, M, seg);
+    LAUNCH_CHECK();
+    const bool point = io->model_method == 0;
+    if ((rc = wide_order<uint16_t>(seg, point ? io->ri : nullptr, io->ri, io->tm, B, P, M, w, io->counts, io->nnz, !point, st))) return rc;
+    if (point) {
+        wide_point_model_kernel<uint16_t><<<dim3((K + 255) / 256, B), 256, 0, st>>>(io->ri, seg, io->ground, io->counts, w.sums, w.flags, P, K, io->model);
+        LAUNCH_CHECK();
+    } else {   // the plane fits read a label's slice of the ordered lists through "tile 0" of a one-tile offset table: base[b][k]
+        PlaneParams pp;   // (as plane_group_args sets them)
+        pp.cos_cut = io->plane_cos_cut; pp.thr = 0.1f; pp.min_points = 30; pp.iters = 10; pp.seed = (uint32_t)io->plane_seed; pp.frame_ids = io->frame_ids; pp.inject = nullptr;
+        const int wpg = PL_THREADS / 64, groups = (K + wpg - 1) / wpg;
+        plane_model_kernel<10><<<B * (K - 2) + B * groups, PL_THREADS, 0, st>>>(io->tm, w.order, w.pts4, w.base, io->counts, io->ground, B, P, M, K, 1, pp, PL_BIG, io->model);
+        LAUNCH_CHECK();
+    }
+    const float *label_acc = nullptr;
+    if (io->nonuniform) {
+        const rpcc_nonuniform_cfg *nu = io->nonuniform;
+        HIP_TRY(hipMemsetAsync(w.kpn, 0, (size_t)B * K * 4, st));
+        if ((rc = launch_features<uint16_t>(io->ri, seg, B, g.H, g.W, nu->feature_region, nu->segments, nu->sharp_num, nu->less_sharp_num, nu->flat_num,
+                                            nullptr, io->key_point_map, st, w.kpn, K))) return rc;
+        SalienceParams sp;
+        for (int i = 0; i < 8; i++) { sp.level_kp_num[i] = i < nu->levels ? nu->level_kp_num[i] : 0; sp.level_acc[i] = i < nu->levels ? nu->level_acc[i] : 0.f; }
+        sp.levels = nu->levels; sp.ground_level = nu->ground_level;
+        wide_salience_levels_kernel<<<dim3((K + 255) / 256, B), 256, 0, st>>>(io->counts, w.kpn, K, sp, io->salience, w.label_acc);
+        LAUNCH_CHECK();
+        label_acc = w.label_acc;
+    }
+    wide_quantise_kernel<uint16_t><<<dim3((P + 255) / 256, B), 256, 0, st>>>(io->ri, io->tm, seg, io->model, w.pos, acc, label_acc, P, K, io->q16);
+    LAUNCH_CHECK();
+    return RPCC_OK;
+}
+
+extern "C" int rpcc_contour_encode_wide(const uint16_t *seg, int B, int H, int W, uint8_t *contour_bits, uint16_t *idx_sequence, int32_t *nseq, void *ws, void *stream) {
+    ARG_TRY(B > 0 && B <= RPCC_MAX_BATCH && H > 0 && W > 0 && seg && contour_bits && idx_sequence && nseq && ws);
+    hipStream_t st = (hipStream_t)stream;
+    const int P = H * W, T = ntiles(P);
+    uint32_t *tile_cnt = reinterpret_cast<uint32_t *>(ws);
+    contour_count_kernel<uint16_t><<<dim3(T, B), 256, 0, st>>>(seg, P, W, T, tile_cnt);
+    tile_scan_kernel<<<B, 256, 0, st>>>(tile_cnt, T, nseq);
+    contour_write_kernel<uint16_t><<<dim3(T, B), 256, 0, st>>>(seg, P, W, T, tile_cnt, contour_bits, idx_sequence);
+    LAUNCH_CHECK();
+    return RPCC_OK;
+}
+extern "C" int rpcc_contour_decode_wide(const uint8_t *contour_bits, const uint16_t *idx_sequence, int B, int H, int W, uint16_t *seg, void *ws, void *stream) {
+    ARG_TRY(B > 0 && B <= RPCC_MAX_BATCH && H > 0 && W > 0 && seg && contour_bits && idx_sequence && ws);
+    hipStream_t st = (hipStream_t)stream;
+    const int P = H * W, T = ntiles(P);
+    uint32_t *tile_cnt = reinterpret_cast<uint32_t *>(ws);
+    contour_bits_count_kernel<<<dim3(T, B), 256, 0, st>>>(contour_bits, P, T, tile_cnt);
+    tile_scan_kernel<<<B, 256, 0, st>>>(tile_cnt, T, nullptr);
+    recover_map_kernel<uint16_t><<<dim3(T, B), 256, 0, st>>>(contour_bits, idx_sequence, P, T, tile_cnt, seg);
+    LAUNCH_CHECK();
+    return RPCC_OK;
+}
+// ws: rpcc_wide_workspace_bytes(B, P, M, 0) bytes
+extern "C" int rpcc_decode_wide(const uint16_t *seg, const int16_t *q16, const float *model, const float *tm, const double *level_acc, int levels,
+                                const uint8_t *salience, int B, int P, int M, float *ri_rec, float *pc_rec, void *ws, void *stream) {
+    ARG_TRY(B > 0 && B <= RPCC_MAX_BATCH && P > 0 && M > 0 && M <= RPCC_MAX_CLUSTERS_WIDE && seg && q16 && model && tm && level_acc && ri_rec && ws);
+    ARG_TRY(levels >= 0 && levels <= 8 && (levels == 0 || salience != nullptr));
+    hipStream_t st = (hipStream_t)stream;
+    const WideWs w = wide_layout(ws, B, P, M, 0);
+    int rc;
+    // (the per-label counts land in the workspace's key-point counters: the decoder has no use for either)
+    if ((rc = wide_order<uint16_t>(seg, nullptr, nullptr, nullptr, B, P, M, w, w.kpn, nullptr, false, st))) return rc;
+    DecodeSteps steps;
+    steps.levels = levels;
+    for (int i = 0; i < 8; i++) steps.acc[i] = i < (levels ? levels : 1) ? level_acc[i] : 0.0;
+    wide_decode_kernel<uint16_t><<<dim3((P + 255) / 256, B), 256, 0, st>>>(seg, q16, model, tm, w.pos, salience, steps, P, M + 2, ri_rec, pc_rec);
+    LAUNCH_CHECK();
     return RPCC_OK;
 }

@@ -158,7 +158,7 @@ def assign(ri, tm, ground, centers, out=None):
 
 def workspace(B, P, M, device, total_points=0, general=False):
     """Work buffer of the fused entry; general=True: large enough for the plane model / the non-uniform framework too."""
-    fn = _lib.lib().rpcc_workspace_bytes_general if general else _lib.lib().rpcc_workspace_bytes
+    fn = _lib.lib().rpcc_wide_workspace_bytes if is_wide(M) else _lib.lib().rpcc_workspace_bytes_general if general else _lib.lib().rpcc_workspace_bytes
     n = fn(B, P, M, int(total_points))
     return torch.empty((n + 255) // 256 * 256, dtype=torch.uint8, device=device)
 
@@ -238,7 +238,9 @@ def backproject(ri, tm):
 
 
 def codec_workspace(B, P, M, device):
-    return torch.empty(_lib.lib().rpcc_codec_workspace_bytes(B, P, M), dtype=torch.uint8, device=device)
+    """Work buffer of the contour codec and the decoder (cluster_num > 254: the wide decoder's sort buffers as well)."""
+    n = _lib.lib().rpcc_wide_workspace_bytes(B, P, M, 0) if is_wide(M) else _lib.lib().rpcc_codec_workspace_bytes(B, P, M)
+    return torch.empty(n, dtype=torch.uint8, device=device)
 
 
 def contour_encode(seg, M=DEFAULT_CLUSTERS, ws=None):
@@ -249,7 +251,8 @@ def contour_encode(seg, M=DEFAULT_CLUSTERS, ws=None):
     bits = torch.empty((B, (P + 7) // 8), dtype=torch.uint8, device=_dev(seg))
     seq = torch.empty((B, P), dtype=torch.uint16, device=_dev(seg))
     nseq = torch.empty((B,), dtype=torch.int32, device=_dev(seg))
-    check(_lib.lib().rpcc_contour_encode(ptr(seg), B, H, W, ptr(bits), ptr(seq), ptr(nseq), ptr(ws), stream()))
+    entry = _lib.lib().rpcc_contour_encode_wide if seg.dtype == torch.uint16 else _lib.lib().rpcc_contour_encode
+    check(entry(ptr(seg), B, H, W, ptr(bits), ptr(seq), ptr(nseq), ptr(ws), stream()))
     return bits, seq, nseq
 
 
@@ -258,8 +261,9 @@ def contour_decode(bits, seq, H, W, M=DEFAULT_CLUSTERS, ws=None):
     B = bits.shape[0]
     P = H * W
     ws = codec_workspace(B, P, M, _dev(bits)) if ws is None else ws
-    seg = torch.empty((B, H, W), dtype=torch.uint8, device=_dev(bits))
-    check(_lib.lib().rpcc_contour_decode(ptr(bits), ptr(seq), B, H, W, ptr(seg), ptr(ws), stream()))
+    wide = is_wide(M)
+    seg = torch.empty((B, H, W), dtype=torch.uint16 if wide else torch.uint8, device=_dev(bits))
+    check((_lib.lib().rpcc_contour_decode_wide if wide else _lib.lib().rpcc_contour_decode)(ptr(bits), ptr(seq), B, H, W, ptr(seg), ptr(ws), stream()))
     return seg
 
 
@@ -275,8 +279,9 @@ def decode(seg, q16, model, tm, level_acc, salience=None, want_points=False, ws=
     arr = (C.c_double * len(acc))(*acc)
     rec = torch.empty((B, H, W), dtype=torch.float32, device=_dev(seg))
     pc = torch.empty((B, H, W, 3), dtype=torch.float32, device=_dev(seg)) if want_points else None
-    check(_lib.lib().rpcc_decode(ptr(seg), ptr(q16), ptr(model), ptr(tm), arr, 0 if uniform else len(acc),
-                                 ptr(salience), B, P, M, ptr(rec), ptr(pc), ptr(ws), stream()))
+    entry = _lib.lib().rpcc_decode_wide if seg.dtype == torch.uint16 else _lib.lib().rpcc_decode
+    check(entry(ptr(seg), ptr(q16), ptr(model), ptr(tm), arr, 0 if uniform else len(acc),
+                ptr(salience), B, P, M, ptr(rec), ptr(pc), ptr(ws), stream()))
     return rec, pc
 
 
@@ -296,15 +301,24 @@ def pack_payload(q16, nnz, packed=None, capacity=None, total=None):
     return packed, total
 
 
-def check_cluster_num(M):
+def check_cluster_num(M, wide=True):
     """cluster_num as this build takes it.  The reference accepts any value (cfgs/compressor.yaml:22; its labels travel as uint16,
-    utils/compress_utils.py:160); here the device keeps a pixel's label 0 .. cluster_num + 1 in ONE byte (segmentation map, label
-    histograms, the contour codec), so cluster_num <= 254.  A larger value is refused here, by name, before any buffer is allocated."""
+    utils/compress_utils.py:160).  Up to 254 the device keeps a pixel's label 0 .. cluster_num + 1 in ONE byte (the tuned kernels); above,
+    the batch front-end (BatchBuffers / compress_batch / contour_encode / decode) takes the uint16 entries (rpcc_*_wide: the same results by
+    plain kernels) up to 65 533.  wide=False: a caller that only has the byte-label stage entries (the mirror classes' per-stage calls) --
+    a larger value is refused by name, before any buffer is allocated."""
     M = int(M)
-    if not 1 <= M <= _lib.MAX_CLUSTERS:
-        raise _lib.RpccError("cluster_num = %d: this build supports 1 <= cluster_num <= %d (device labels are uint8: RPCC_MAX_CLUSTERS in "
-                             "include/rpcc_hip.h); the reference's default is 100 (cfgs/compressor.yaml:22)" % (M, _lib.MAX_CLUSTERS))
+    top = _lib.MAX_CLUSTERS_WIDE if wide else _lib.MAX_CLUSTERS
+    if not 1 <= M <= top:
+        raise _lib.RpccError("cluster_num = %d: %s supports 1 <= cluster_num <= %d (%s); the reference's default is 100 (cfgs/compressor.yaml:22)"
+                             % (M, "this build" if wide else "the stage-by-stage entries", top,
+                                "labels are uint16 in the container" if wide else
+                                "their device labels are uint8: RPCC_MAX_CLUSTERS in include/rpcc_hip.h; pipeline.BatchCompressor takes up to 65533"))
     return M
+
+
+def is_wide(M):
+    return int(M) > _lib.MAX_CLUSTERS
 
 
 class BatchBuffers:
@@ -313,12 +327,14 @@ class BatchBuffers:
 
     def __init__(self, B, geom, M, device, max_points=None, general=False):
         M = check_cluster_num(M)
+        self.wide = is_wide(M)     # uint16 labels, the rpcc_*_wide entries
+        general = general or self.wide   # (the wide entry serves every framework / model combination from one workspace)
         P = geom.H * geom.W
         K = M + 2
         self.B, self.P, self.M, self.K, self.geom = B, P, M, K, geom
         f32, i32 = torch.float32, torch.int32
         self.ri = torch.empty((B, geom.H, geom.W), dtype=f32, device=device)
-        self.seg = torch.empty((B, geom.H, geom.W), dtype=torch.uint8, device=device)
+        self.seg = torch.empty((B, geom.H, geom.W), dtype=torch.uint16 if self.wide else torch.uint8, device=device)
         self.cen_pix = torch.empty((B, M), dtype=i32, device=device)
         self.centers = torch.empty((B, M, 3), dtype=f32, device=device)
         self.model = torch.empty((B, K, 4), dtype=f32, device=device)
@@ -393,8 +409,8 @@ def compress_batch(xyz, offsets, tm, ground, buf, ground_threshold=0.1, acc=0.04
     (0 / 1 / 2) and RPCC_FPS_TIE_CUDA, so every front-end (tools, pipeline, loader) honours them."""
     io = _batch_io(xyz, offsets, tm, ground, buf, ground_seed, frame_ids, fps_bruteforce, timer, model_method, angle_threshold, plane_seed,
                    nonuniform, fps_fma, fps_cuda_tie)
-    check(_lib.lib().rpcc_compress_batch(C.byref(io), buf.B, buf.geom, buf.M, float(ground_threshold), float(acc),
-                                         ptr(buf.ws), stream()))
+    entry = _lib.lib().rpcc_compress_batch_wide if buf.wide else _lib.lib().rpcc_compress_batch   # (cluster_num > 254: uint16 labels)
+    check(entry(C.byref(io), buf.B, buf.geom, buf.M, float(ground_threshold), float(acc), ptr(buf.ws), stream()))
     return buf
 
 
@@ -432,6 +448,10 @@ def compress_batch_mixed(groups, ground_threshold=0.1, acc=0.04):
     assert 1 <= G <= _lib.MAX_GROUPS, "at most %d geometry groups per call" % _lib.MAX_GROUPS
     M = groups[0]["buf"].M
     assert all(g["buf"].M == M for g in groups), "one cluster count per call"
+    if is_wide(M):   # (no mixed-geometry form of the uint16-label entry: the groups one after the other, same results)
+        for g in groups:
+            compress_batch(ground_threshold=ground_threshold, acc=acc, **g)
+        return [g["buf"] for g in groups]
     ios = (BatchIO * G)(*[_batch_io(**g) for g in groups])
     Bs = (C.c_int * G)(*[g["buf"].B for g in groups])
     geoms = (_lib.Geom * G)(*[g["buf"].geom for g in groups])

@@ -14,7 +14,7 @@ class BatchCompressor:
 
     def __init__(self, transformer, cluster_num=100, accuracy=0.02, ground_threshold=0.1, uniform=True,
                  model_method="point", compressor_cfg=None, basic_compressor="bzip2", device=None, seed=0):
-        self.M = ops.check_cluster_num(cluster_num)   # (raises for a value the uint8 device labels cannot hold)
+        self.M = ops.check_cluster_num(cluster_num)   # (above 254: uint16 labels through the rpcc_*_wide entries; above 65533: refused by name)
         self.T = transformer
         self.device = torch.device(device) if device is not None else transformer.device
         self.acc = accuracy * 2                     # tools/compress.py:46

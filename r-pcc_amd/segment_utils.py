@@ -46,7 +46,7 @@ class PointCloudSegment:
         if method != "FPS":
             raise NotImplementedError("DBSCAN segmentation is out of scope (SURVEY.md section 2)")
         thr = segment_cfg["ground_vertical_threshold"]
-        M = ops.check_cluster_num(segment_cfg["cluster_num"])   # <= 254 here (uint8 device labels); the limit is named in the error
+        M = ops.check_cluster_num(segment_cfg["cluster_num"], wide=False)   # the per-stage entries keep labels in a byte: <= 254, named in the error (BatchCompressor: up to 65533)
         ri = self._ri(range_image)
         inject = type(self).ransac_plane_segmentation
         if inject is not None:

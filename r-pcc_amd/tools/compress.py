@@ -103,9 +103,50 @@ def make_quantizer(cfg, accuracy, uniform):
                               less_sharp_num=cfg["less_sharp_num"], flat_num=cfg["flat_num"])
 
 
+def compress_wide(args, cfg, accuracy, segment_cfg, model_cfg, basic_compressor, uniform):
+    """cluster_num above 254 (labels as uint16): the per-stage mirror classes keep labels in a byte, so the frame goes through the batch front-end
+    (pipeline.BatchCompressor -> rpcc_compress_batch_wide) as a batch of one.  Same container, same decoder."""
+    from rpcc_amd.pipeline import BatchCompressor
+    dataset = build_dataset(lidar_type=args.lidar)
+    t0 = time.time()
+    frame = dataset.load_data(args.input)
+    bc = BatchCompressor(dataset.PCTransformer, cluster_num=segment_cfg["cluster_num"], accuracy=accuracy / 2,
+                         ground_threshold=segment_cfg["ground_vertical_threshold"], uniform=uniform, model_method=model_cfg["model_method"],
+                         compressor_cfg=dict(cfg), basic_compressor=basic_compressor.method_name, seed=args.seed)
+    blob = bc.compress([frame], frame_ids=[frame_identity(args.input)])[0]
+    with open(args.output, "wb") as f:
+        f.write(blob)
+    t1 = time.time()
+    buf = bc._buf
+    point_num = int((buf.ri[0] != 0).sum().item())
+    print("\nCompression finished (cluster_num = %d: uint16 labels, batch front-end)." % segment_cfg["cluster_num"])
+    print("binary bitstream save in ", args.output)
+    print("    Total time cost: ", t1 - t0)
+    bits = os.path.getsize(args.output) * 8
+    print("\nCompression Results: ")
+    print("    Compression ratio: ", (point_num * 32 * 3) / bits)
+    print("    BPP: ", bits / point_num)
+    if args.eval:
+        from rpcc_amd.tools.decompress import decode_frame
+        level_acc = np.array([accuracy] * len(cfg["level_key_point_num"])) + np.array(cfg["level_delta_acc"])
+        rec, _, _ = decode_frame(read_compressed_bitstream(args.output, uniform=uniform), basic_compressor, dataset.PCTransformer,
+                                 segment_cfg["cluster_num"], accuracy, level_acc, uniform, want_points=False)
+        ri = buf.ri[0].cpu().numpy()
+        dif = np.abs(rec - ri)[ri != 0]
+        bound = accuracy + (0.0 if uniform else 0.06) + 0.00001   # (the bound of compress() below: tools/compress.py:176-181)
+        print("\nReconstruction quality: ")
+        print("    Depth Error (mean): ", float(np.mean(dif)))
+        print("    Depth Error (max): ", float(np.max(dif)))
+        if float(np.max(dif)) > bound:
+            raise AssertionError("Reconstruction error... Please check...")
+
+
 def compress(args):
     apply_fps_mode(args)
     cfg, accuracy, segment_cfg, model_cfg, basic_compressor, uniform = resolve_cfg(args)
+    from rpcc_amd import ops
+    if ops.is_wide(ops.check_cluster_num(segment_cfg["cluster_num"])):
+        return compress_wide(args, cfg, accuracy, segment_cfg, model_cfg, basic_compressor, uniform)
     dataset = build_dataset(lidar_type=args.lidar)
     model_num = segment_cfg["cluster_num"] + 1
     pc_seg = PointCloudSegment(dataset.transform_map, seed=args.seed, frame_id=frame_identity(args.input))

@@ -63,7 +63,7 @@ def decode_frame(blob_dict, basic_compressor, transformer, cluster_num, accuracy
     seg = ops.contour_decode(bits, seq, H, W, cluster_num)
     q = torch.zeros((1, H * W), dtype=torch.int16, device=dev)
     qq = np.frombuffer(d["residual_quantized"], dtype=np.int16)
-    n_nonempty = int((seg != 1).sum().item())
+    n_nonempty = int(((seg.view(torch.int16) if seg.dtype == torch.uint16 else seg) != 1).sum().item())   # (uint16 labels: cluster_num > 254)
     if qq.size != n_nonempty:
         raise ValueError("residual_quantized holds %d values, the label map has %d non-empty pixels" % (qq.size, n_nonempty))
     q[0, : qq.size] = torch.from_numpy(qq.copy()).to(dev)

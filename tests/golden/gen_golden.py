@@ -103,7 +103,7 @@ def estimate_ground(xyz):
     return np.array([n[0], n[1], n[2], -n @ c])
 
 
-def run_reference(xyz, lidar_yaml, ground_model, uniform, plane_rows=None, accuracy=0.02):
+def run_reference(xyz, lidar_yaml, ground_model, uniform, plane_rows=None, accuracy=0.02, cluster_num=None):
     """The body of tools/compress.py:44-131 driven through the genuine reference modules."""
     from dataset.transformer import PCTransformer
     from utils.segment_utils import PointCloudSegment
@@ -111,6 +111,8 @@ def run_reference(xyz, lidar_yaml, ground_model, uniform, plane_rows=None, accur
     import yaml
 
     cfg = yaml.safe_load(open(os.path.join(REF, "cfgs/compressor.yaml")))
+    if cluster_num is not None:
+        cfg["cluster_num"] = int(cluster_num)      # (the --cluster_num flag of tools/compress.py:20-37)
     acc = accuracy * 2
     T = PCTransformer(lidar_yaml, None)
     tm = T.transform_map
@@ -193,6 +195,22 @@ def sha_cases(tmp):
                                       salience=sha(sal_n.astype(np.uint8)), rpcc=hashlib.sha256(ref["rpcc"]).hexdigest())))
             print(geom, fid, rows[-1]["nnz"], rows[-1]["n_left"], rows[-1]["rpcc_bytes"], flush=True)
         out["cases"][geom] = rows
+    # cluster_num above 254 (labels beyond a byte; the reference writes them as uint16, utils/compress_utils.py:160): two VLP-16 sweeps at 300 clusters
+    geom, M = "VelodyneVLP16", 300
+    g = orc.GEOMS[geom]
+    yml = os.path.join(tmp, geom + ".yaml")
+    rows = []
+    for fid in (100, 101):
+        xyz = synth.make_frame(fid, g["H"], g["W"], vmax_deg=g["vmax_deg"], vmin_deg=g["vmin_deg"]).numpy()
+        gm = estimate_ground(xyz)
+        ref = run_reference(xyz, yml, gm, uniform=True, cluster_num=M)
+        assert int(ref["seg_idx"].max()) == M + 1
+        rows.append(dict(frame=int(fid), cluster_num=M, nnz=int((ref["ri"] != 0).sum()), labels=int(ref["seg_idx"].max()) + 1, rpcc_bytes=len(ref["rpcc"]),
+                         ground_model=[float(v) for v in gm],
+                         sha=dict(xyz=sha(xyz), seg_idx=sha(ref["seg_idx"].astype(np.uint16)), model_param=sha(ref["model_param"].astype(np.float32)),
+                                  q=sha(ref["q"].astype(np.int16)), rpcc=hashlib.sha256(ref["rpcc"]).hexdigest())))
+        print("wide", geom, fid, rows[-1]["nnz"], rows[-1]["rpcc_bytes"], flush=True)
+    out["wide"] = {"geom": geom, "rows": rows}
     json.dump(out, open(os.path.join(HERE, "manifest_sha.json"), "w"), indent=1, sort_keys=True)
 
 

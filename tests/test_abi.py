@@ -49,19 +49,25 @@ def test_product_never_imports_oracle():
                 assert not bad.search(open(os.path.join(dp, f)).read()), (dp, f)
 
 
-def test_cluster_num_limit_is_named():
-    """The reference takes any cluster_num (cfgs/compressor.yaml:22); this build keeps device labels in a byte.  A preserved YAML with a
-    larger value must fail with the limit spelled out -- in the front-end, before anything touches the device -- not with a bare argument error."""
+def test_cluster_num_limits_are_named():
+    """The reference takes any cluster_num (cfgs/compressor.yaml:22; uint16 labels in the stream).  The batch front-end does too (above 254 through the
+    uint16-label entries, up to 65 533); the mirror classes' per-stage entries keep labels in a byte and must refuse a larger value with the limit
+    spelled out -- in the front-end, before anything touches the device -- not with a bare argument error."""
     import re
     import pytest
     import rpcc_amd  # noqa: F401
     from rpcc_amd import _lib, ops
     hdr = open(os.path.join(ROOT, "include", "rpcc_hip.h")).read()
     assert int(re.search(r"#define RPCC_MAX_CLUSTERS (\d+)", hdr).group(1)) == _lib.MAX_CLUSTERS == 254
-    assert ops.check_cluster_num(254) == 254 and ops.check_cluster_num(1) == 1
-    for bad in (255, 300, 65533, 0):
-        with pytest.raises(_lib.RpccError, match=r"cluster_num = %d.*<= 254.*uint8" % bad):
+    assert int(re.search(r"#define RPCC_MAX_CLUSTERS_WIDE (\d+)", hdr).group(1)) == _lib.MAX_CLUSTERS_WIDE == 65533
+    assert ops.check_cluster_num(254) == 254 and ops.check_cluster_num(1) == 1 and ops.check_cluster_num(300) == 300 and ops.check_cluster_num(65533) == 65533
+    assert not ops.is_wide(254) and ops.is_wide(255)
+    for bad in (65534, 0):
+        with pytest.raises(_lib.RpccError, match=r"cluster_num = %d.*<= 65533" % bad):
             ops.check_cluster_num(bad)
+    for bad in (255, 300):
+        with pytest.raises(_lib.RpccError, match=r"cluster_num = %d.*stage-by-stage.*<= 254.*uint8.*BatchCompressor" % bad):
+            ops.check_cluster_num(bad, wide=False)
     from rpcc_amd.pipeline import BatchCompressor
-    with pytest.raises(_lib.RpccError, match="cluster_num = 300"):
-        BatchCompressor(None, cluster_num=300)
+    with pytest.raises(_lib.RpccError, match="cluster_num = 70000"):
+        BatchCompressor(None, cluster_num=70000)

@@ -116,3 +116,22 @@ def test_breadth_digests_match_reference(geom):
         on = orc.compress_frame(xyz, g, tm, gm, uniform=False)
         assert sha(on["key_point_map"].astype(np.uint8)) == s["key_point_map"]
         assert sha(on["q"].astype(np.int16)) == s["q_nonuniform"] and sha(on["salience"].astype(np.uint8)) == s["salience"]
+
+
+def test_wide_cluster_num_digests_match_reference():
+    """cluster_num = 300 (labels beyond a byte; uint16 in the container, utils/compress_utils.py:160) on two VLP-16 sweeps through the genuine reference:
+    the oracle reproduces labels, model rows, quantised integers and the .rpcc bytes."""
+    from rpcc_amd import synth
+    w = SHA["wide"]
+    gd = orc.GEOMS[w["geom"]]
+    g = orc.LidarGeom(**gd)
+    tm = orc.transform_map(g)
+    for row in w["rows"]:
+        xyz = synth.make_frame(row["frame"], g.H, g.W, vmax_deg=gd["vmax_deg"], vmin_deg=gd["vmin_deg"]).numpy()
+        s = row["sha"]
+        assert sha(xyz) == s["xyz"]
+        o = orc.compress_frame(xyz, g, tm, np.array(row["ground_model"]), dict(orc.DEFAULT_CFG, cluster_num=row["cluster_num"]))
+        assert int(o["seg_idx"].max()) + 1 == row["labels"] and sha(o["seg_idx"].astype(np.uint16)) == s["seg_idx"]
+        assert sha(np.asarray(o["model_param"]).astype(np.float32)) == s["model_param"] and sha(o["q"].astype(np.int16)) == s["q"]
+        bs = orc.bitstream_bytes(orc.pack_payload(o["model_param"], o["seg_idx"], None, o["q"]))
+        assert len(bs) == row["rpcc_bytes"] and hashlib.sha256(bs).hexdigest() == s["rpcc"]
