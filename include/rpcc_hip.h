@@ -316,6 +316,13 @@ size_t rpcc_workspace_bytes_general(int B, int P, int M, int64_t total_points); 
 int rpcc_compress_batch(const rpcc_batch_io *io, int B, rpcc_geom g, int M, double ground_threshold, float acc,
                         void *ws, void *stream);
 
+/* A subset of rpcc_compress_batch's stages, in order: bit 0 projection, 1 ground fit, 2 mask (+ first FPS pass), 3 FPS, 4 assignment + label histograms +
+ * scan (+ the plane model's label order), 5 plane fits, 6 key points + salience + quantiser.  For callers that interleave the stages of several batches on
+ * several streams themselves; every stage needs the stages before it to have run on the same io / ws.  All bits (127) = rpcc_compress_batch. */
+#define RPCC_STAGE_ALL 127
+int rpcc_compress_batch_stages(const rpcc_batch_io *io, int B, rpcc_geom g, int M, double ground_threshold, float acc, void *ws,
+                               int stage_mask, void *stream);
+
 /* The same for a batch that holds sweeps of several lidar geometries (variable H x W inside one call: BASELINE configs[4]; the
  * reference compresses such a list frame by frame with one dataset / transformer per lidar, tools/compress_datalist.py:160-206,
  * the YAML files of dataset/lidar_cfg).  The frames are grouped by geometry: group i = ios[i] (its own buffers, laid out for Bs[i] frames of

@@ -91,6 +91,7 @@ _SIGS = {
     "rpcc_workspace_bytes": (C.c_size_t, [_I, _I, _I, _I64]),
     "rpcc_workspace_bytes_general": (C.c_size_t, [_I, _I, _I, _I64]),
     "rpcc_compress_batch": (C.c_int, [C.POINTER(BatchIO), _I, Geom, _I, _D, _F, _VP, _VP]),
+    "rpcc_compress_batch_stages": (C.c_int, [C.POINTER(BatchIO), _I, Geom, _I, _D, _F, _VP, _I, _VP]),
     "rpcc_compress_batch_mixed": (C.c_int, [C.POINTER(BatchIO), C.POINTER(C.c_int), C.POINTER(Geom), _I, _I, _D, _F, C.POINTER(C.c_void_p), _VP]),
     "rpcc_wide_workspace_bytes": (C.c_size_t, [_I, _I, _I, _I64]),
     "rpcc_compress_batch_wide": (C.c_int, [C.POINTER(BatchIO), _I, Geom, _I, _D, _F, _VP, _VP]),

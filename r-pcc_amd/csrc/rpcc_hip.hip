@@ -3129,6 +3129,20 @@ extern "C" int rpcc_compress_batch(const rpcc_batch_io *io, int B, rpcc_geom g, 
     return RPCC_OK;
 }
 
+// A subset of the batch's stages (bit i of stage_mask = stage i of the enum above: projection, ground fit, mask, FPS, assignment + label
+// histograms + scan (+ label order), plane fits, key points + quantiser), in order, on `stream`.  For callers that schedule the stages of several batches
+// themselves (tools_dev/tick_bench.py: the one-workgroup-per-frame kernels of different batches back to back on one stream, the pixel-parallel ones on
+// others); running all bits is rpcc_compress_batch.
+extern "C" int rpcc_compress_batch_stages(const rpcc_batch_io *io, int B, rpcc_geom g, int M, double ground_threshold, float acc, void *ws,
+                                          int stage_mask, void *stream) {
+    int rc;
+    if ((rc = check_batch_io(io, B, g, M, ws))) return rc;
+    const BatchPlan p = plan_batch(io, B, io->total, g, M, ground_threshold, acc, reinterpret_cast<char *>(ws));
+    for (int stage = 0; stage < ST_COUNT; stage++)
+        if (((stage_mask >> stage) & 1) && (rc = run_stage(p, stage, (hipStream_t)stream))) return rc;
+    return RPCC_OK;
+}
+
 // ---- several geometry groups in one call ----------------------------------------------------------------------------------------
 // (*) stages as one launch over the groups that take the common kernel; a group that does not (injected ground, brute-force FPS or a
 // CUDA-binary mode, an image too large for the register-table FPS, the point model) runs that stage by itself.

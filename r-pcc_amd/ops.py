@@ -414,6 +414,18 @@ def compress_batch(xyz, offsets, tm, ground, buf, ground_threshold=0.1, acc=0.04
     return buf
 
 
+STAGE_PROJECT, STAGE_GROUND, STAGE_MASK, STAGE_FPS, STAGE_LABELS, STAGE_PLANES, STAGE_QUANTISE = (1 << i for i in range(7))
+
+
+def compress_batch_stages(stage_mask, xyz, offsets, tm, ground, buf, ground_threshold=0.1, acc=0.04, **kw):
+    """The stages of compress_batch whose bits are set in stage_mask (STAGE_*), in order, on the current stream: for a caller that interleaves the
+    stages of several batches on several streams (tools_dev/tick_bench.py).  Every stage needs its predecessors to have run on the same buffers."""
+    assert not buf.wide
+    io = _batch_io(xyz, offsets, tm, ground, buf, **kw)
+    check(_lib.lib().rpcc_compress_batch_stages(C.byref(io), buf.B, buf.geom, buf.M, float(ground_threshold), float(acc), ptr(buf.ws), int(stage_mask), stream()))
+    return buf
+
+
 def _batch_io(xyz, offsets, tm, ground, buf, ground_seed=-1, frame_ids=None, fps_bruteforce=False, timer=None, model_method="point",
               angle_threshold=75, plane_seed=0, nonuniform=None, fps_fma=None, fps_cuda_tie=None):
     """The rpcc_batch_io of one geometry group (compress_batch's arguments); grows the group's workspace when the batch holds more points."""

@@ -1279,3 +1279,35 @@ def test_fuzz_mixed_call_vs_groups_alone(env, seed):
         assert all(np.array_equal(qa[i, :nz[i]], qm[i, :nz[i]]) for i in range(ba.B)), (seed, k)
         if a["nonuniform"] is not None:
             assert np.array_equal(ba.salience.cpu().numpy(), bm.salience.cpu().numpy()), (seed, k)
+
+
+def test_compress_batch_stages_equal_the_single_call(env):
+    """rpcc_compress_batch_stages: the batch's stages issued one by one (and in two groups on two streams joined by an event) give the outputs of
+    rpcc_compress_batch; all bits at once is the same call."""
+    torch, ops, synth = env["torch"], env["ops"], env["synth"]
+    g, geom, tm = _geom(env, "VelodyneVLP16")
+    gd = env["orc"].GEOMS["VelodyneVLP16"]
+    xyz, offs = synth.make_batch(range(880, 885), g.H, g.W, device=env["dev"], vmax_deg=gd["vmax_deg"], vmin_deg=gd["vmin_deg"])
+    d_tm = _to(env, tm)
+    def fresh():
+        return ops.BatchBuffers(5, geom, 100, env["dev"]), torch.zeros((5, 4), dtype=torch.float64, device=env["dev"])
+    ref, g0 = fresh()
+    ops.compress_batch(xyz, offs, d_tm, g0, ref, ground_seed=3)
+    one, g1 = fresh()
+    for bit in range(7):
+        ops.compress_batch_stages(1 << bit, xyz, offs, d_tm, g1, one, ground_seed=3)
+    two, g2 = fresh()
+    s2 = torch.cuda.Stream(device=env["dev"])
+    ops.compress_batch_stages(ops.STAGE_PROJECT | ops.STAGE_GROUND | ops.STAGE_MASK, xyz, offs, d_tm, g2, two, ground_seed=3)
+    e = torch.cuda.Event(); e.record()
+    with torch.cuda.stream(s2):
+        s2.wait_event(e)
+        ops.compress_batch_stages(ops.STAGE_FPS | ops.STAGE_LABELS | ops.STAGE_PLANES | ops.STAGE_QUANTISE, xyz, offs, d_tm, g2, two, ground_seed=3)
+    allb, g3 = fresh()
+    ops.compress_batch_stages(127, xyz, offs, d_tm, g3, allb, ground_seed=3)
+    torch.cuda.synchronize()
+    for b, gg in ((one, g1), (two, g2), (allb, g3)):
+        assert torch.equal(gg, g0) and torch.equal(b.seg, ref.seg) and torch.equal(b.nnz, ref.nnz) and torch.equal(b.cen_pix, ref.cen_pix)
+        assert _beq(b.model.cpu().numpy()[:, :102], ref.model.cpu().numpy()[:, :102])
+        for i in range(5):
+            assert torch.equal(b.q16[i, :int(ref.nnz[i])], ref.q16[i, :int(ref.nnz[i])])
