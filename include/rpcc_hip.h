@@ -44,7 +44,7 @@ extern "C" {
 
 /* Interface version: changes whenever the layout of a struct below or the meaning of an argument changes (the structs carry no size
  * field).  A binding compares rpcc_version() with the RPCC_ABI_VERSION of the header it was built against before it calls anything else
- * (r-pcc_amd/_lib.py does).  100: round 3.  101: rpcc_batch_io.point_stride_bytes.  102: the uint16-label entries (rpcc_*_wide). */
+ * (r-pcc_amd/_lib.py does).  100: round 3.  101: rpcc_batch_io.point_stride_bytes.  102: the uint16-label entries (rpcc_*_wide), rpcc_compress_batch_stages. */
 #define RPCC_ABI_VERSION 102
 int rpcc_version(void);
 const char *rpcc_last_error(void);
