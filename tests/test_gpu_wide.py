@@ -185,3 +185,41 @@ def test_wide_digests_of_the_reference(env):
         n = int(buf.nnz[b])
         assert n == r["nnz"] and sha(buf.q16[b, :n].cpu().numpy()) == s["q"]
         assert len(blobs[b]) == r["rpcc_bytes"] and hashlib.sha256(blobs[b]).hexdigest() == s["rpcc"]
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzz_wide_vs_oracle(env, seed):
+    """Randomised breadth for the uint16-label path: image shape (odd widths too), fields of view, cluster count 255 .. 700, accuracy, framework and model
+    drawn per seed; labels, model rows, salience levels, quantised integers and the .rpcc bytes equal the oracle's."""
+    orc = env["orc"]
+    rng = np.random.default_rng(9100 + seed)
+    H, W = int(rng.integers(8, 41)), int(rng.integers(300, 1500))
+    vmax, vmin = float(rng.uniform(1.0, 16.0)), float(-rng.uniform(10.0, 31.0))
+    M = int(rng.integers(255, 701))
+    accuracy = float(rng.choice([0.01, 0.02, 0.05]))
+    uniform, method = bool(rng.integers(0, 2)), ("plane" if rng.integers(0, 2) else "point")
+    T = env["T"](dict(HORIZONTAL_FOV=360, VERTICAL_ANGLE_MAX=vmax, VERTICAL_ANGLE_MIN=vmin, RANGE_IMAGE_HEIGHT=H, RANGE_IMAGE_WIDTH=W))
+    g = orc.LidarGeom(H, W, 360, vmax, vmin)
+    tm = orc.transform_map(g)
+    frames = [env["synth"].make_frame(9300 + 10 * seed + i, H, W, vmax_deg=vmax, vmin_deg=vmin).numpy() for i in range(2)]
+    cfg = dict(orc.DEFAULT_CFG, accuracy=accuracy, cluster_num=M, plane_angle_threshold=75)
+    bc = env["pl"].BatchCompressor(T, cluster_num=M, accuracy=accuracy, uniform=uniform, model_method=method, compressor_cfg=cfg, seed=31)
+    blobs = bc.compress(frames)
+    buf = bc._buf
+    tag = (seed, H, W, M, uniform, method)
+    compared = 0
+    for b, f in enumerate(frames):
+        ri = orc.project(f, g)
+        gm = orc.ground_model(ri, tm, seed=31 + b)
+        o = orc.compress_frame(f, g, tm, gm, cfg, uniform=uniform, plane=None if method == "point" else dict(angle_deg=75, seed=31, frame=b))
+        if len(set(o["fps_pix"].tolist())) < M:      # fewer candidates than clusters: the centre list repeats (degenerate input)
+            continue
+        assert np.array_equal(buf.seg[b].cpu().numpy().astype(np.int64), o["seg_idx"]), tag
+        mp = np.asarray(o["model_param"]).astype(np.float32)
+        assert np.array_equal(buf.model[b, :mp.shape[0]].cpu().numpy().view(np.uint32), mp.view(np.uint32)), tag
+        n = int(buf.nnz[b])
+        assert n == o["q"].shape[0] and np.array_equal(buf.q16[b, :n].cpu().numpy(), o["q"].astype(np.int16)), tag
+        od = orc.pack_payload(o["model_param"], o["seg_idx"], None if uniform else o["salience"], o["q"])
+        assert blobs[b] == orc.bitstream_bytes(od, uniform=uniform), tag
+        compared += 1
+    assert compared >= 1, tag
