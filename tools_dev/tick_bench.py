@@ -63,6 +63,38 @@ def run(variant, n):
     return (time.perf_counter() - t0) / n
 
 
+def run_relaxed(n, two_latency=False):
+    """The same roles per stream, but only the true dependencies as events (no tick boundary): L: ground fit(t-1), FPS(t-3);  Ta: pix + band(t), mask(t-2);
+    Tb: assign .. quantiser(t-4).  At most one FPS / ground-fit kernel runs at a time (two_latency: one of each)."""
+    sl, sa, sb, sl2 = (torch.cuda.Stream(device=dev) for _ in range(4))
+    E = lambda: [None] * (n + 8)
+    e_band, e_rs, e_mask, e_fps, e_done = E(), E(), E(), E(), E()
+    rec = lambda s: (lambda ev: (ev.record(s), ev)[1])(torch.cuda.Event())
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(n + 4):
+        if t < n:
+            with torch.cuda.stream(sa):
+                if t >= D and e_done[t - D] is not None: sa.wait_event(e_done[t - D])     # the slot's buffers are free again
+                stages(S.STAGE_PROJECT, t % D)
+                e_band[t] = rec(sa)
+        if 0 <= t - 1 < n:
+            with torch.cuda.stream(sl):
+                sl.wait_event(e_band[t - 1]); stages(S.STAGE_GROUND, (t - 1) % D); e_rs[t - 1] = rec(sl)
+        if 0 <= t - 2 < n:
+            with torch.cuda.stream(sa):
+                sa.wait_event(e_rs[t - 2]); stages(S.STAGE_MASK, (t - 2) % D); e_mask[t - 2] = rec(sa)
+        if 0 <= t - 3 < n:
+            lf = sl2 if two_latency else sl
+            with torch.cuda.stream(lf):
+                lf.wait_event(e_mask[t - 3]); stages(S.STAGE_FPS, (t - 3) % D); e_fps[t - 3] = rec(lf)
+        if 0 <= t - 4 < n:
+            with torch.cuda.stream(sb):
+                sb.wait_event(e_fps[t - 4]); stages(S.STAGE_LABELS | S.STAGE_PLANES | S.STAGE_QUANTISE, (t - 4) % D); e_done[t - 4] = rec(sb)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
 def run_free(n, depth=3):
     st = [torch.cuda.Stream(device=dev) for _ in range(depth)]
     torch.cuda.synchronize()
@@ -79,6 +111,10 @@ for rep in range(2):
         run(v, 30)
         dt = run(v, ticks)
         print("tick schedule, %s: %.4f ms per batch, %.0f frames/s" % (v, dt * 1e3, B / dt), flush=True)
+    for two in (False, True):
+        run_relaxed(30, two)
+        dt = run_relaxed(ticks, two)
+        print("roles per stream, dependencies only (L%s | Ta | Tb): %.4f ms per batch, %.0f frames/s" % (" | L2" if two else "", dt * 1e3, B / dt), flush=True)
     run_free(30)
     dt = run_free(ticks)
     print("free-running, three batches on three streams (bench.py): %.4f ms per batch, %.0f frames/s" % (dt * 1e3, B / dt), flush=True)
