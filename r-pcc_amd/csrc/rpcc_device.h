@@ -125,7 +125,10 @@ __device__ __forceinline__ void st_f32(float *base, uint32_t byte_off, float v) 
     *reinterpret_cast<float *>(reinterpret_cast<char *>(base) + byte_off) = v;
 }
 struct f32x3 { float x, y, z; };  // one ray of the transform map: a single 12-byte load
-struct f32x4u { float x, y, z, w; };  // four floats at a 4-byte aligned address: one global_load_dwordx4 (dword alignment is all the hardware asks)
+// four floats at a 4-byte aligned address: one global_load_dwordx4 (dword alignment is all the hardware asks).  A VECTOR type on purpose: a struct of four
+// floats is four scalar loads to the optimiser, which then folds the element-wise row-end branch and the quad branch of the EDGE kernels into one set of
+// sixteen scalar loads with selected addresses (rounds 3-5 shipped that: 156 global_load_dword in the EDGE FPS kernel, no dwordx4).
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 template <class T>
 __device__ __forceinline__ T ld_at(const T *base, uint32_t byte_off) {
     return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_off);
