@@ -554,7 +554,7 @@ def run_workload(a, ctx):
             o = orc.compress_frame(frames_h[i], g_o, tm_np, gm, cfg_o, uniform=False, plane=dict(angle_deg=75, seed=0, frame=ids[i]))
         else:
             o = orc.compress_frame(frames_h[i], g_o, tm_np, gm, cfg_o)
-        oracle_out[i] = dict(ri=o["range_image"], gm=gm, pix=o["fps_pix"], seg=o["seg_idx"].astype(np.uint8),
+        oracle_out[i] = dict(ri=o["range_image"], gm=gm, pix=o["fps_pix"], seg=o["seg_idx"].astype(np.uint16),   # (labels above 255: cluster_num > 254, the uint16 entries)
                              model=np.asarray(o["model_param"]).astype(np.float32), q=o["q"].astype(np.int16),
                              sal=o.get("salience"))
         return 1
@@ -580,7 +580,7 @@ def run_workload(a, ctx):
                 nrow = o["model"].shape[0]
                 ok = (np.array_equal(ri_d[i].view(np.uint32), o["ri"].view(np.uint32)) and
                       np.array_equal(gm_d[i].view(np.uint64), np.asarray(o["gm"], np.float64).view(np.uint64)) and
-                      np.array_equal(pix_d[i], o["pix"]) and np.array_equal(seg_d[i].reshape(-1), o["seg"].reshape(-1)) and
+                      np.array_equal(pix_d[i], o["pix"]) and np.array_equal(seg_d[i].reshape(-1).astype(np.uint16), o["seg"].reshape(-1)) and
                       np.array_equal(mo_d[i, :nrow].view(np.uint32), o["model"].view(np.uint32)) and
                       int(nz_d[i]) == o["q"].shape[0] and np.array_equal(q_d[i, :nz_d[i]], o["q"]))
                 if ok and general and o["sal"] is not None:

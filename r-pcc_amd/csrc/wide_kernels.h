@@ -5,18 +5,26 @@
 // clusters: one thread per pixel or per label, per-label totals by global atomics, and the ordered scatter (residuals grouped by label ascending,
 // row-major inside a label: cpp_modules.cpp:326-331) through ONE stable radix sort of (frame, label) keys -- the position of every pixel in its
 // frame's stream (wide_positions_kernel) then serves the quantiser, the plane model's label-ordered lists and the decoder alike.  Same arithmetic,
-// same results as the byte-label kernels (tests: test_gpu_wide.py against the oracle); written for correctness, not for speed.
+// same results as the byte-label kernels (tests: test_gpu_wide.py against the oracle); written for correctness first (89 k frames/s of 64 x 2048 at
+// 300 clusters against 360 k of the byte-label kernels at 100).
 #pragma once
 #include <cstring>
 #include <rocprim/rocprim.hpp>
 
 #define RPCC_MAX_CLUSTERS_WIDE 65533
 
-// a7: first minimum over the ground term and the M radii (utils/segment_utils.py:21-23,64-67,127-131,168-169): every centre, two smallest
-// squared distances, then assign_label's tie window and ground screen.  cen4: float4 [B,M] (x, y, z, 0).
+// a7: first minimum over the ground term and the M radii (utils/segment_utils.py:21-23,64-67,127-131,168-169): two smallest squared distances,
+// then assign_label's tie window and ground screen.  cen4: float4 [B,M] (x, y, z, 0).
+// A wavefront owns 64 consecutive pixels.  It first lists the centres that can matter to any of them (64 centres per step, one per lane): with the box
+// of its non-empty pixels, u = min over the centres of the bound ABOVE every pixel's distance (per-axis farthest gap), and a centre stays when its bound
+// BELOW every pixel's distance (per-axis nearest gap) is <= u * 1.00001 -- both in the operation order of the distance itself on gaps that bracket every
+// pixel's (rounding is monotone), so a dropped centre is farther than the nearest one by more than assign_label's tie window for every pixel: same m1,
+// k1, same tie decision.  The list keeps ascending centre order (the first minimum wins).  More than WIDE_ASSIGN_CAP survivors: every centre, as before.
+#define WIDE_ASSIGN_CAP 256
 __global__ __launch_bounds__(256) void wide_assign_kernel(const float *__restrict__ ri, const float *__restrict__ tm, const double *__restrict__ ground,
                                                           const float4 *__restrict__ cen4, int P, int M, uint16_t *__restrict__ seg) {
-    const int b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x, pc = min(p, P - 1);
+    __shared__ uint16_t s_list[4][WIDE_ASSIGN_CAP];
+    const int b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x, pc = min(p, P - 1), lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float r = ri[(int64_t)b * P + pc];
     const float tx = tm[3 * pc], ty = tm[3 * pc + 1], tz = tm[3 * pc + 2];
     const float x = r * tx, y = r * ty, z = r * tz;
@@ -26,9 +34,41 @@ __global__ __launch_bounds__(256) void wide_assign_kernel(const float *__restric
     G.af = (float)G.a; G.bf = (float)G.b; G.cf = (float)G.c; G.df = (float)G.d;
     G.S = (float)((fabs(G.a) + fabs(G.b) + fabs(G.c)) * 1.001);
     const float inf = __builtin_inff();
+    // the wavefront's box (empty pixels become label 1 whatever their distances: left out)
+    const bool in = p < P && r != 0.0f;
+    float lo0 = in ? x : inf, lo1 = in ? y : inf, lo2 = in ? z : inf, hi0 = in ? x : -inf, hi1 = in ? y : -inf, hi2 = in ? z : -inf;
+    dpp_box6(lo0, lo1, lo2, hi0, hi1, hi2);
+    int n = 0;   // listed centres; -1: all of them (a wavefront of empty pixels: none)
+    if (lo0 <= hi0) {   // (wave-uniform) some pixel is not empty
+        float u = inf;
+        for (int k0 = 0; k0 < M; k0 += 64) {
+            const float4 cc = cb[min(k0 + lane, M - 1)];
+            const float fx = fmaxf(fabsf(lo0 - cc.x), fabsf(hi0 - cc.x)), fy = fmaxf(fabsf(lo1 - cc.y), fabsf(hi1 - cc.y)),
+                        fz = fmaxf(fabsf(lo2 - cc.z), fabsf(hi2 - cc.z));
+            u = fminf(u, (fx * fx + fy * fy) + fz * fz);
+        }
+        u = dpp_min_f32_native(u);
+        const float cut = u * 1.00001f;
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        n = 0;
+        for (int k0 = 0; k0 < M; k0 += 64) {
+            const int k = k0 + lane;
+            const float4 cc = cb[min(k, M - 1)];
+            const float gx = fmaxf(fmaxf(lo0 - cc.x, cc.x - hi0), 0.0f), gy = fmaxf(fmaxf(lo1 - cc.y, cc.y - hi1), 0.0f),
+                        gz = fmaxf(fmaxf(lo2 - cc.z, cc.z - hi2), 0.0f);
+            const bool keep = k < M && !((gx * gx + gy * gy) + gz * gz > cut);   // (an unordered compare keeps the centre)
+            const unsigned long long m = __ballot(keep);
+            const int pos = n + (int)__popcll(m & lt);
+            if (keep && pos < WIDE_ASSIGN_CAP) s_list[wave][pos] = (uint16_t)k;
+            n += (int)__popcll(m);
+        }
+        if (n > WIDE_ASSIGN_CAP) n = -1;
+    }
     float m1 = inf, m2 = inf;
     int k1 = -1;
-    for (int k = 0; k < M; k++) {   // (wave-uniform index: the centre is one scalar load)
+    const int cnt = n < 0 ? M : n;
+    for (int i = 0; i < cnt; i++) {   // (wave-uniform index: the centre is one scalar load)
+        const int k = n < 0 ? i : __builtin_amdgcn_readfirstlane((int)s_list[wave][i]);
         const float4 cc = cb[k];
         const float dx = x - cc.x, dy = y - cc.y, dz = z - cc.z;
         const float d2 = (dx * dx + dy * dy) + dz * dz;
@@ -48,26 +88,52 @@ __global__ __launch_bounds__(256) void wide_cen4_kernel(const float *__restrict_
 
 // sort keys (frame << 16 | label; value = pixel) and the per-label totals: pixel counts and, for the point model, the exact fixed-point range
 // sums of model_hist_kernel (r * 2^28 as an integer for 2^-5 <= r < 2^8, else the frame's flag: sequential fp64 loop in wide_point_model_kernel)
+// (Labels are spatially coherent: the 64 consecutive pixels of a wavefront hold a handful of labels.  Up to WIDE_KEY_ROUNDS of them -- the label of the
+// first pixel still pending -- are counted and summed once per wavefront, the rest adds itself; integer sums, any order.  One device atomic per pixel on
+// a frame's few hundred counters took 12 ms per 256 frames.)
+#define WIDE_KEY_ROUNDS 6
 template <class L>
 __global__ __launch_bounds__(256) void wide_keys_kernel(const L *__restrict__ seg, const float *__restrict__ ri, int P, int K, uint32_t *__restrict__ keys,
                                                         uint32_t *__restrict__ vals, int32_t *__restrict__ counts, unsigned long long *__restrict__ sums,
                                                         int32_t *__restrict__ flags) {
-    const int b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= P) return;
-    const int64_t g = (int64_t)b * P + p;
+    const int b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
+    const bool valid = p < P;
+    const int64_t g = (int64_t)b * P + (valid ? p : P - 1);
     const uint32_t l = seg[g];
-    keys[g] = ((uint32_t)b << 16) | l;
-    vals[g] = (uint32_t)p;
-    atomicAdd(&counts[(int64_t)b * K + l], 1);
-    if (ri != nullptr && l >= 2u) {
+    if (valid) { keys[g] = ((uint32_t)b << 16) | l; vals[g] = (uint32_t)p; }
+    uint32_t lo = 0u, hi = 0u;   // r * 2^28 = hi << 18 | lo: the sums of either part over a wavefront stay below 2^32
+    bool bad = false;
+    if (valid && ri != nullptr && l >= 2u) {
         const uint32_t rb = f2u(ri[g]);
         const float r = u2f(rb);
         if (!(r >= 0.03125f && r < 256.0f)) {
-            flags[4 * b] = 1;
+            bad = true;
         } else {   // biased exponent 122 .. 134: r * 2^28 = mantissa << (exponent - 122)
-            const uint32_t sh = (rb >> 23) - 122u;
-            atomicAdd(&sums[(int64_t)b * K + l], (unsigned long long)((rb & 0x7FFFFFu) | 0x800000u) << sh);
+            const uint32_t sh = (rb >> 23) - 122u, m = (rb & 0x7FFFFFu) | 0x800000u;
+            lo = (m << sh) & 0x3FFFFu;
+            hi = m >> (18u - sh);
         }
+    }
+    if (__any(bad) && lane == 0) flags[4 * b] = 1;
+    unsigned long long pend = __ballot(valid);
+#pragma unroll 1
+    for (int round = 0; round < WIDE_KEY_ROUNDS && pend != 0ull; round++) {
+        const int first = (int)__ffsll((long long)pend) - 1;
+        const uint32_t cur = (uint32_t)__builtin_amdgcn_readlane((int)l, first);
+        const bool mine = valid && l == cur;
+        const unsigned long long m = __ballot(mine);
+        pend &= ~m;
+        const uint32_t slo = dpp_sum_u32(mine ? lo : 0u), shi = dpp_sum_u32(mine ? hi : 0u);
+        if (lane == 0) {
+            atomicAdd(&counts[(int64_t)b * K + cur], (int32_t)__popcll(m));
+            const unsigned long long sv = (unsigned long long)slo + ((unsigned long long)shi << 18);
+            if (sv) atomicAdd(&sums[(int64_t)b * K + cur], sv);
+        }
+    }
+    if ((pend >> lane) & 1ull) {
+        atomicAdd(&counts[(int64_t)b * K + l], 1);
+        const unsigned long long sv = (unsigned long long)lo + ((unsigned long long)hi << 18);
+        if (sv) atomicAdd(&sums[(int64_t)b * K + l], sv);
     }
 }
 // exclusive prefix of the label counts of a frame without label 1 (the empty pixels have no residual: cpp_modules.cpp:314): base[b][k] = first

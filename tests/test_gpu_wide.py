@@ -26,8 +26,8 @@ def _geom(env, name):
     return gd, g, ops.make_geom(g.H, g.W, g.horizontal_FOV, g.vertical_max, g.vertical_min), tm
 
 
-def _batch(env, gd, g, ids):
-    frames = [env["synth"].make_frame(i, g.H, g.W, vmax_deg=gd["vmax_deg"], vmin_deg=gd["vmin_deg"]).numpy() for i in ids]
+def _batch(env, gd, g, ids, scene="default"):
+    frames = [env["synth"].make_frame(i, g.H, g.W, vmax_deg=gd["vmax_deg"], vmin_deg=gd["vmin_deg"], scene=scene).numpy() for i in ids]
     offs = np.zeros(len(frames) + 1, np.int64)
     offs[1:] = np.cumsum([f.shape[0] for f in frames])
     to = lambda a: env["torch"].from_numpy(np.ascontiguousarray(a)).to(env["dev"])
@@ -71,16 +71,19 @@ def test_wide_batch_vs_oracle(env, M, uniform, method):
             assert np.array_equal(buf.salience[i, :o["salience"].shape[0]].cpu().numpy(), o["salience"].astype(np.uint8)), tag
 
 
-@pytest.mark.parametrize("uniform,method", [(True, "point"), (False, "plane")])
-def test_wide_kernels_equal_the_byte_label_kernels(env, uniform, method):
+@pytest.mark.parametrize("uniform,method,scene", [(True, "point", "default"), (False, "plane", "default"), (True, "point", "shell"),
+                                                  (True, "point", "noise"), (True, "point", "corridor")])
+def test_wide_kernels_equal_the_byte_label_kernels(env, uniform, method, scene):
     """The uint16 entries are a second, independent implementation of the same stages: at cluster_num = 100 on 64 x 2048 sweeps -- where the tuned
-    byte-label kernels run as well -- both produce the same labels, model rows, counts, salience levels and quantised integers."""
+    byte-label kernels run as well -- both produce the same labels, model rows, counts, salience levels and quantised integers.  The adversarial
+    scenes of the FPS study (all points equally far / independent ranges per pixel / a corridor) stress the centre screen of wide_assign_kernel:
+    flat boxes with many near-ties, boxes that exclude nothing, very near and very far centres."""
     torch, ops, orc, dev = env["torch"], env["ops"], env["orc"], env["dev"]
     from rpcc_amd import _lib
     import ctypes as C
     gd, g, geom, tm = _geom(env, "Velodyne64E_2048")
     ids = [7200, 7201, 7202, 7203]
-    frames, xyz, offs = _batch(env, gd, g, ids)
+    frames, xyz, offs = _batch(env, gd, g, ids, scene)
     B, M = len(ids), 100
     d_tm = torch.from_numpy(tm).to(dev)
     fid = torch.as_tensor(np.asarray(ids, np.int64), device=dev)
