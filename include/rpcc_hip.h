@@ -147,6 +147,10 @@ int rpcc_fps_xyz_bruteforce(int B, int N, int M, const float *points, float *tem
 /* rpcc_fps_xyz with flags: RPCC_FPS_BRUTEFORCE, RPCC_FPS_FMA1 / RPCC_FPS_FMA2, RPCC_FPS_TIE_CUDA (k = the point's index,
  * block = opt_n_threads(N) as sampling_gpu.cu:9-13 computes it). */
 int rpcc_fps_xyz_mode(int B, int N, int M, const float *points, float *temp, int32_t *idx, int flags, void *stream);
+/* rpcc_fps_xyz sends every list to the kernel its point order suits: tiles of 256 consecutive points that are compact in space (the reference's
+ * row-major candidate list, a sweep in its stored order) -> the tile-pruned kernel; no locality (a shuffled cloud) -> one pass per centre.  Same
+ * indices either way.  Test hook: the decision alone.   marks dev i32 [B] out: -1 = one pass per centre, 0 = tile-pruned */
+int rpcc_fps_xyz_probe(int B, int N, const float *points, int32_t *marks, void *stream);
 
 /* ---- a7: ground / cluster assignment + relabel ---------------------------------------------- *
  * replaces calc_plane_residual_depth, calc_cluster_residual_radius, concatenate + argmax and the

@@ -73,6 +73,7 @@ _SIGS = {
     "rpcc_fps_xyz": (C.c_int, [_I, _I, _I, _VP, _VP, _VP, _VP]),
     "rpcc_fps_xyz_bruteforce": (C.c_int, [_I, _I, _I, _VP, _VP, _VP, _VP]),
     "rpcc_fps_xyz_mode": (C.c_int, [_I, _I, _I, _VP, _VP, _VP, _I, _VP]),
+    "rpcc_fps_xyz_probe": (C.c_int, [_I, _I, _VP, _VP, _VP]),
     "rpcc_fps_range": (C.c_int, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP, _I, _VP, _VP]),
     "rpcc_assign": (C.c_int, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP]),
     "rpcc_point_model": (C.c_int, [_VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP]),

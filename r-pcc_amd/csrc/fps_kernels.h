@@ -207,6 +207,7 @@ __device__ __forceinline__ void fps_load_point(const float *__restrict__ src, co
 #define FPS_TT_SMALL 1024
 #define FPS_GROUP 2
 #define FPS_FLAG_FINALIZE_TEMP 1  // write the origin class's value back to the empty pixels' temp entries at the end
+#define FPS_FLAG_PROBED 2         // point lists: fps_list_probe_kernel has marked the frames the one-pass-per-centre kernel takes (out_idx[b][0] < 0)
 
 template <bool RANGE, bool VEC, int FPS_TT>
 __global__ __launch_bounds__(FPS_TT) void fps_tiled_kernel(const float *__restrict__ src, const float *__restrict__ rays,
@@ -226,6 +227,7 @@ __global__ __launch_bounds__(FPS_TT) void fps_tiled_kernel(const float *__restri
     out_idx += (int64_t)b * M;
     if (out_cen) out_cen += (int64_t)b * M * 3;
     if (M <= 0) return;
+    if (!RANGE && (flags & FPS_FLAG_PROBED) && out_idx[0] < 0) return;   // (workgroup-uniform) this list goes to fps_xyz_kernel
 
     int old = 0;
     if (RANGE) { old = info[RPCC_INFO * b + 1]; if (old >= N) old = 0; }
@@ -515,6 +517,7 @@ __device__ __forceinline__ void fps_regtab_body(const float *__restrict__ src, c
     out_idx += (int64_t)b * M;
     if (out_cen) out_cen += (int64_t)b * M * 3;
     if (M <= 0) return;
+    if (!RANGE && (flags & FPS_FLAG_PROBED) && out_idx[0] < 0) return;   // (workgroup-uniform) this list goes to fps_xyz_kernel
 
     int old = 0;
     if (RANGE) { old = info[RPCC_INFO * b + 1]; if (old >= N) old = 0; }

@@ -1584,14 +1584,19 @@ __device__ __forceinline__ uint32_t block_argmax(unsigned long long key, unsigne
     return fps_key_index(k);
 }
 
+// probed: only the lists fps_list_probe_kernel has marked (idxs[b][0] < 0) -- the others ran in the tile-pruned kernel before this launch.
+// VEC (n % 4 == 0, 16-byte aligned arrays): a thread owns four consecutive points per 4096-point stride -- three 16-byte loads of coordinates, one of
+// temp, two strides in flight; element order inside a thread is ascending, so the strict '>' keeps the lowest index as the scalar form does.
+template <bool VEC>
 __global__ __launch_bounds__(FPS_THREADS) void fps_xyz_kernel(int n, int m, const float *__restrict__ dataset,
-                                                              float *__restrict__ temp, int32_t *__restrict__ idxs) {
+                                                              float *__restrict__ temp, int32_t *__restrict__ idxs, int probed) {
     __shared__ unsigned long long sm[16];
     if (m <= 0) return;
     const int b = blockIdx.x;
     dataset += (int64_t)b * n * 3;
     temp += (int64_t)b * n;
     idxs += (int64_t)b * m;
+    if (probed && idxs[0] >= 0) return;   // (workgroup-uniform)
     const int tid = threadIdx.x;
     int old = 0;
     if (tid == 0) idxs[0] = 0;
@@ -1599,16 +1604,86 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_xyz_kernel(int n, int m, cons
         const float x1 = dataset[old * 3 + 0], y1 = dataset[old * 3 + 1], z1 = dataset[old * 3 + 2];
         float best = -1.0f;
         int besti = 0;
-        for (int k = tid; k < n; k += FPS_THREADS) {
-            const float dx = dataset[k * 3 + 0] - x1, dy = dataset[k * 3 + 1] - y1, dz = dataset[k * 3 + 2] - z1;
-            const float d = (dx * dx + dy * dy) + dz * dz;  // sampling_gpu.cu:64, un-fused
-            const float t = temp[k];
-            const float d2 = fminf(d, t);
-            if (d2 != t) temp[k] = d2;
-            if (d2 > best) { best = d2; besti = k; }
+        if (VEC) {
+            const float4 *d4 = reinterpret_cast<const float4 *>(dataset);
+            float4 *t4 = reinterpret_cast<float4 *>(temp);
+            const int nq = n >> 2;
+#pragma unroll 2
+            for (int q = tid; q < nq; q += FPS_THREADS) {
+                const float4 a = d4[3 * q], bq = d4[3 * q + 1], c = d4[3 * q + 2];
+                float4 t = t4[q];
+                const float px[4] = {a.x, a.w, bq.z, c.y}, py[4] = {a.y, bq.x, bq.w, c.z}, pz[4] = {a.z, bq.y, c.x, c.w};
+                float tv[4] = {t.x, t.y, t.z, t.w};
+                bool ch = false;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float dx = px[e] - x1, dy = py[e] - y1, dz = pz[e] - z1;
+                    const float d = (dx * dx + dy * dy) + dz * dz;  // sampling_gpu.cu:64, un-fused
+                    const float d2 = fminf(d, tv[e]);
+                    ch = ch || d2 != tv[e];
+                    tv[e] = d2;
+                    if (d2 > best) { best = d2; besti = 4 * q + e; }
+                }
+                if (ch) t4[q] = make_float4(tv[0], tv[1], tv[2], tv[3]);
+            }
+        } else {
+            for (int k = tid; k < n; k += FPS_THREADS) {
+                const float dx = dataset[k * 3 + 0] - x1, dy = dataset[k * 3 + 1] - y1, dz = dataset[k * 3 + 2] - z1;
+                const float d = (dx * dx + dy * dy) + dz * dz;  // sampling_gpu.cu:64, un-fused
+                const float t = temp[k];
+                const float d2 = fminf(d, t);
+                if (d2 != t) temp[k] = d2;
+                if (d2 > best) { best = d2; besti = k; }
+            }
         }
         old = (int)block_argmax(fps_key(best, (uint32_t)besti), sm);
         if (tid == 0) idxs[j] = old;
+    }
+}
+
+// Which kernel a point list takes.  The tile-pruned kernel wins when consecutive points are neighbours in space (a tile of 256 consecutive points is
+// compact: the reference's row-major candidate list, a sweep in its stored order -- 6-12 % of the tiles touched per centre), the one-pass-per-centre kernel
+// when they are not (a shuffled cloud: 80 % touched, and a touched tile costs 3.6 x a streamed one).  Measure of the order: mean over 16 sampled tiles of
+// the squared box diagonal / squared diagonal of the sample's box (row-major lists 0.02-0.05, shuffled 0.44; break-even about 0.07: profiles/HISTORY.md).
+// Marks idxs[b][0] = -1 (one pass per centre) or 0.  Any answer is correct -- both kernels return the same indices.
+#define FPS_PROBE_TILES 16
+__global__ __launch_bounds__(256) void fps_list_probe_kernel(const float *__restrict__ pts, int n, int m, int T, int32_t *__restrict__ idxs) {
+    __shared__ float s_box[4][6], s_sum[4];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    pts += (int64_t)b * n * 3;
+    const float inf = __builtin_inff();
+    float g0 = inf, g1 = inf, g2 = inf, h0 = -inf, h1 = -inf, h2 = -inf, sum = 0.0f;
+    float x[FPS_PROBE_TILES / 4][4], y[FPS_PROBE_TILES / 4][4], z[FPS_PROBE_TILES / 4][4];
+#pragma unroll
+    for (int k = 0; k < FPS_PROBE_TILES / 4; k++) {   // all loads first
+        const int t = (int)(((int64_t)(4 * k + wave) * T) / FPS_PROBE_TILES);
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int p = min(t * FPS_TILE + 64 * e + lane, n - 1);
+            x[k][e] = pts[3 * (int64_t)p]; y[k][e] = pts[3 * (int64_t)p + 1]; z[k][e] = pts[3 * (int64_t)p + 2];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < FPS_PROBE_TILES / 4; k++) {
+        float l0 = fminf(fminf(x[k][0], x[k][1]), fminf(x[k][2], x[k][3])), u0 = fmaxf(fmaxf(x[k][0], x[k][1]), fmaxf(x[k][2], x[k][3]));
+        float l1 = fminf(fminf(y[k][0], y[k][1]), fminf(y[k][2], y[k][3])), u1 = fmaxf(fmaxf(y[k][0], y[k][1]), fmaxf(y[k][2], y[k][3]));
+        float l2 = fminf(fminf(z[k][0], z[k][1]), fminf(z[k][2], z[k][3])), u2 = fmaxf(fmaxf(z[k][0], z[k][1]), fmaxf(z[k][2], z[k][3]));
+        dpp_box6(l0, l1, l2, u0, u1, u2);
+        sum += ((u0 - l0) * (u0 - l0) + (u1 - l1) * (u1 - l1)) + (u2 - l2) * (u2 - l2);
+        g0 = fminf(g0, l0); g1 = fminf(g1, l1); g2 = fminf(g2, l2); h0 = fmaxf(h0, u0); h1 = fmaxf(h1, u1); h2 = fmaxf(h2, u2);
+    }
+    if (lane == 0) { s_box[wave][0] = g0; s_box[wave][1] = g1; s_box[wave][2] = g2; s_box[wave][3] = h0; s_box[wave][4] = h1; s_box[wave][5] = h2; s_sum[wave] = sum; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float tot = 0.0f;
+        for (int w = 0; w < 4; w++) {
+            tot += s_sum[w];
+            g0 = fminf(g0, s_box[w][0]); g1 = fminf(g1, s_box[w][1]); g2 = fminf(g2, s_box[w][2]);
+            h0 = fmaxf(h0, s_box[w][3]); h1 = fmaxf(h1, s_box[w][4]); h2 = fmaxf(h2, s_box[w][5]);
+        }
+        const float all = ((h0 - g0) * (h0 - g0) + (h1 - g1) * (h1 - g1)) + (h2 - g2) * (h2 - g2);
+        const bool streamed = !(tot < 0.07f * (float)FPS_PROBE_TILES * all);   // (NaN / infinite coordinates: one pass per centre)
+        idxs[(int64_t)b * m] = streamed ? -1 : 0;
     }
 }
 
@@ -1875,11 +1950,18 @@ static int fps_xyz_impl(int B, int N, int M, const float *points, float *temp, i
         return RPCC_OK;
     }
     const FpsTiling g = fps_tiling_list(N);
+    const bool vec = (N % 4 == 0) && aligned16(points) && aligned16(temp);
+    int probed = 0;
     if (!brute && g.T <= FPS_TILED_MAX_TILES && N < (1 << 30) / 3) {
-        const bool vec = (N % 4 == 0) && aligned16(points) && aligned16(temp);
-        return launch_fps_tiled<false>(points, nullptr, temp, nullptr, B, g, M, 0, idx, nullptr, nullptr, vec, st);
+        // every list takes the kernel its order suits: the probe marks idx[b][0], the pruned kernel skips the marked lists, the streamed one the others
+        fps_list_probe_kernel<<<B, 256, 0, st>>>(points, N, M, g.T, idx);
+        LAUNCH_CHECK();
+        const int rc = launch_fps_tiled<false>(points, nullptr, temp, nullptr, B, g, M, FPS_FLAG_PROBED, idx, nullptr, nullptr, vec, st);
+        if (rc != RPCC_OK) return rc;
+        probed = 1;
     }
-    fps_xyz_kernel<<<B, FPS_THREADS, 0, st>>>(N, M, points, temp, idx);
+    if (vec && N < (1 << 29)) fps_xyz_kernel<true><<<B, FPS_THREADS, 0, st>>>(N, M, points, temp, idx, probed);
+    else fps_xyz_kernel<false><<<B, FPS_THREADS, 0, st>>>(N, M, points, temp, idx, probed);
     LAUNCH_CHECK();
     return RPCC_OK;
 }
@@ -1888,6 +1970,13 @@ extern "C" int rpcc_fps_xyz(int B, int N, int M, const float *points, float *tem
 }
 extern "C" int rpcc_fps_xyz_bruteforce(int B, int N, int M, const float *points, float *temp, int32_t *idx, void *stream) {
     return fps_xyz_impl(B, N, M, points, temp, idx, true, (hipStream_t)stream);
+}
+extern "C" int rpcc_fps_xyz_probe(int B, int N, const float *points, int32_t *marks, void *stream) {
+    ARG_TRY(B > 0 && B <= RPCC_MAX_BATCH && N > 0 && points && marks);
+    hipStream_t st = (hipStream_t)stream;
+    fps_list_probe_kernel<<<B, 256, 0, st>>>(points, N, 1, fps_tiling_list(N).T, marks);
+    LAUNCH_CHECK();
+    return RPCC_OK;
 }
 extern "C" int rpcc_fps_xyz_mode(int B, int N, int M, const float *points, float *temp, int32_t *idx, int flags, void *stream) {
     return fps_xyz_impl(B, N, M, points, temp, idx, (flags & RPCC_FPS_BRUTEFORCE) != 0, (hipStream_t)stream, flags);

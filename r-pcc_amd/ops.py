@@ -136,6 +136,15 @@ def fps_xyz(points, npoint, temp=None, bruteforce=False, fma=0, cuda_tie=False):
     return idx
 
 
+def fps_xyz_probe(points):
+    """Which kernel fps_xyz gives each list of points f32 [B,N,3]: i32 [B], -1 = one pass per centre (no locality in the point order),
+    0 = tile-pruned (consecutive points are neighbours).  Test hook; the indices are the same either way."""
+    B, N, _ = points.shape
+    marks = torch.empty((B,), dtype=torch.int32, device=_dev(points))
+    check(_lib.lib().rpcc_fps_xyz_probe(B, N, ptr(points), ptr(marks), stream()))
+    return marks
+
+
 def fps_range(ri, tm, temp, info, M, fps_table=None, cen_pix=None, centers=None, bruteforce=False, fma=0, cuda_tie=False):
     """a6 on the range image.  fma / cuda_tie: the CUDA-binary modes (_lib.fps_mode_flags); they need temp / info from
     ground_mask(..., fps_table=False)."""

@@ -310,6 +310,42 @@ def test_fps_xyz_operator(env):
             assert np.array_equal(idx[b], orc.fps(pts[b], M)), (B, N, M, b)
 
 
+def test_fps_xyz_takes_the_kernel_the_point_order_suits(env):
+    """rpcc_fps_xyz probes every list: consecutive points that are neighbours in space (the reference's row-major candidate list, a sweep in its
+    stored order) run in the tile-pruned kernel, lists without locality in the one-pass-per-centre kernel -- per list, inside one call.  Both paths
+    (and both load forms of each: N a multiple of four or not) against the brute-force entry and the oracle, incl. the final temp."""
+    torch, ops, orc, synth = env["torch"], env["ops"], env["orc"], env["synth"]
+    g, geom, tm = _geom(env, "Velodyne64E_2048")
+    rng = np.random.default_rng(41)
+    z = np.load(os.path.join(HERE, "golden", "example_64E.npz"))
+    ri = orc.project(synth.make_frame(31, g.H, g.W).numpy(), g)
+    rowmajor = orc.backproject(ri, tm).reshape(-1, 3)[ri.reshape(-1) != 0].astype(np.float32)   # pixels in row-major order: compact tiles
+    stored = np.ascontiguousarray(z["xyz"], np.float32)                                          # the reference's example sweep as stored
+    for base, name in ((rowmajor, "row-major"), (stored, "stored order")):
+        for cut in (0, 3):                                   # N % 4 == 0 -> 16-byte loads; else the scalar forms
+            n = (base.shape[0] // 4) * 4 - cut
+            coherent = base[:n]
+            shuffled = coherent[rng.permutation(n)]
+            pts = np.stack([coherent, shuffled, coherent[::-1].copy()])
+            marks = ops.fps_xyz_probe(_to(env, pts)).cpu().numpy()
+            assert list(marks) == [0, -1, 0], (name, cut, marks)          # one call, both kernels
+            out = {}
+            for mode in (True, False):
+                temp = torch.full((3, n), 1e10, dtype=torch.float32, device=env["dev"])
+                idx = ops.fps_xyz(_to(env, pts), 100, temp=temp, bruteforce=mode)
+                out[mode] = (idx.cpu().numpy(), temp.cpu().numpy())
+            assert _beq(out[True][0], out[False][0]) and _beq(out[True][1], out[False][1]), (name, cut)
+            for b in range(3):
+                assert np.array_equal(out[False][0][b], orc.fps(pts[b], 100)), (name, cut, b)
+    # small and degenerate lists: any decision is a correct one
+    for pts in (np.zeros((2, 300, 3), np.float32), rng.normal(0, 1, (1, 5, 3)).astype(np.float32),
+                np.full((1, 1024, 3), np.nan, np.float32)):
+        m = min(pts.shape[1], 20)
+        a = ops.fps_xyz(_to(env, pts), m).cpu().numpy()
+        b = ops.fps_xyz(_to(env, pts), m, bruteforce=True).cpu().numpy()
+        assert np.array_equal(a, b)
+
+
 def test_point_model_sequential_fallback(env):
     """Ranges outside the fixed-point window [2^-5, 2^8) take the exact sequential fp64 path."""
     torch, ops, orc = env["torch"], env["ops"], env["orc"]
