@@ -61,9 +61,9 @@ pl = torch.stack([p[:n] for p in pts]).contiguous()
 timed("fps_xyz: 4 point lists of %d points, 100 samples" % n, lambda: ops.fps_xyz(pl, 100))
 timed("fps_xyz: 1 point list", lambda: ops.fps_xyz(pl[:1].contiguous(), 100))
 timed("fps_xyz brute force: 1 point list", lambda: ops.fps_xyz(pl[:1].contiguous(), 100, bruteforce=True))
-timed("fps_xyz: 1 point list, N %% 4 != 0 (scalar loads)", lambda: ops.fps_xyz(pl[:1, :n - 1].contiguous(), 100))
+timed("fps_xyz: 1 point list, N % 4 != 0 (scalar loads)", lambda: ops.fps_xyz(pl[:1, :n - 1].contiguous(), 100))
 # the same clouds with consecutive points neighbours in space: the pixels of the range image in row-major order
-pc = ops.backproject(buf.ri, tm)[0].reshape(4, -1, 3) if False else ops.backproject(buf.ri, tm).reshape(B, -1, 3)
+pc = ops.backproject(buf.ri, tm).reshape(B, -1, 3)
 keep = [pc[i][buf.ri[i].reshape(-1) != 0] for i in range(4)]
 n2 = (min(k.shape[0] for k in keep) // 4) * 4
 cl = torch.stack([k[:n2] for k in keep]).contiguous()
