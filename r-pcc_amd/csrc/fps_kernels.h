@@ -432,7 +432,7 @@ __global__ __launch_bounds__(FPS_TT) void fps_tiled_kernel(const float *__restri
         __syncthreads();
         if (tid == 0) wcount = 0;
         select_next();
-        if (tid == 0) { out_idx[j] = old; if (out_cen) { out_cen[3 * j] = c0; out_cen[3 * j + 1] = c1; out_cen[3 * j + 2] = c2; } }
+        if (lane == 0 && wave == (j & (NW - 1))) { out_idx[j] = old; if (out_cen) { out_cen[3 * j] = c0; out_cen[3 * j + 1] = c1; out_cen[3 * j + 2] = c2; } }
     }
     if (RANGE && org_on && (flags & FPS_FLAG_FINALIZE_TEMP)) {
         // the empty pixels' temp entries were not touched while the class was carried as a scalar
@@ -758,9 +758,9 @@ __device__ __forceinline__ void fps_regtab_body(const float *__restrict__ src, c
         TRACE_FPS_PHASE(2);
         update_origin();
         select_next();
-        // (collecting the centres in 4 KB of LDS and writing them once at the end takes 2 us off the kernel alone and 5 % off
-        // the step with batches in flight: this kernel's LDS footprint decides what it shares a CU with)
-        if (tid == 0) { out_idx[j] = old; if (out_cen) { out_cen[3 * j] = c0; out_cen[3 * j + 1] = c1; out_cen[3 * j + 2] = c2; } }
+        // (every wavefront knows the winner; they take turns writing it: a wavefront's loads of the next iteration wait behind its stores on the one
+        // vmcnt, and one wavefront carrying all of them was 1.7 us of the launch.  Collecting the centres in LDS for one write at the end: the same alone.)
+        if (lane == 0 && wave == (j & (NW - 1))) { out_idx[j] = old; if (out_cen) { out_cen[3 * j] = c0; out_cen[3 * j + 1] = c1; out_cen[3 * j + 2] = c2; } }
         TRACE_FPS_PHASE(5);
     }
     TRACE_FPS_WG(1);
