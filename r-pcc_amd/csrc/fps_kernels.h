@@ -91,7 +91,7 @@ template <bool RANGE, bool VEC, bool SOA = false, bool EDGE = false>
 __device__ __forceinline__ void fps_quad_load(const float *__restrict__ src, const float *__restrict__ rays,
                                               const float *__restrict__ temp, FpsQuad &q, int n_plane = 0) {
     const uint32_t p0 = (uint32_t)q.p0;
-    using float4 = typename std::conditional<EDGE, f32x4u, ::float4>::type;   // EDGE: the same 16-byte loads, 4-byte aligned
+    // (EDGE: the same 16-byte loads, 4-byte aligned: ld_quad<true>)
     if (VEC && EDGE && q.nval != 4) {   // a quad cut short by the row end (or a lane outside the frame): element loads, clamped
 #pragma unroll
         for (int e = 0; e < 4; e++) {
@@ -104,26 +104,26 @@ __device__ __forceinline__ void fps_quad_load(const float *__restrict__ src, con
         return;
     }
     if (VEC && RANGE && SOA) {
-        const float4 tp = ld_at(reinterpret_cast<const float4 *>(temp), p0 * 4u);
+        const float4 tp = ld_quad<EDGE>(temp, p0 * 4u);
         q.tp[0] = tp.x; q.tp[1] = tp.y; q.tp[2] = tp.z; q.tp[3] = tp.w;
-        const float4 a = ld_at(reinterpret_cast<const float4 *>(rays), p0 * 4u);
-        const float4 b = ld_at(reinterpret_cast<const float4 *>(rays + n_plane), p0 * 4u);
-        const float4 c = ld_at(reinterpret_cast<const float4 *>(rays + 2 * (size_t)n_plane), p0 * 4u);
+        const float4 a = ld_quad<EDGE>(rays, p0 * 4u);
+        const float4 b = ld_quad<EDGE>(rays + n_plane, p0 * 4u);
+        const float4 c = ld_quad<EDGE>(rays + 2 * (size_t)n_plane, p0 * 4u);
         q.t[0] = a.x; q.t[3] = a.y; q.t[6] = a.z; q.t[9] = a.w; q.t[1] = b.x; q.t[4] = b.y; q.t[7] = b.z; q.t[10] = b.w;
         q.t[2] = c.x; q.t[5] = c.y; q.t[8] = c.z; q.t[11] = c.w;
-        const float4 r = ld_at(reinterpret_cast<const float4 *>(src), p0 * 4u);
+        const float4 r = ld_quad<EDGE>(src, p0 * 4u);
         q.r[0] = r.x; q.r[1] = r.y; q.r[2] = r.z; q.r[3] = r.w;
     } else if (VEC) {  // 16-byte loads at wave-uniform base + 32-bit byte offset
-        const float4 tp = ld_at(reinterpret_cast<const float4 *>(temp), p0 * 4u);
+        const float4 tp = ld_quad<EDGE>(temp, p0 * 4u);
         q.tp[0] = tp.x; q.tp[1] = tp.y; q.tp[2] = tp.z; q.tp[3] = tp.w;
         const float *tb = RANGE ? rays : src;
-        const float4 a = ld_at(reinterpret_cast<const float4 *>(tb), p0 * 12u);
-        const float4 b = ld_at(reinterpret_cast<const float4 *>(tb), p0 * 12u + 16u);
-        const float4 c = ld_at(reinterpret_cast<const float4 *>(tb), p0 * 12u + 32u);
+        const float4 a = ld_quad<EDGE>(tb, p0 * 12u);
+        const float4 b = ld_quad<EDGE>(tb, p0 * 12u + 16u);
+        const float4 c = ld_quad<EDGE>(tb, p0 * 12u + 32u);
         q.t[0] = a.x; q.t[1] = a.y; q.t[2] = a.z; q.t[3] = a.w; q.t[4] = b.x; q.t[5] = b.y; q.t[6] = b.z; q.t[7] = b.w;
         q.t[8] = c.x; q.t[9] = c.y; q.t[10] = c.z; q.t[11] = c.w;
         if (RANGE) {
-            const float4 r = ld_at(reinterpret_cast<const float4 *>(src), p0 * 4u);
+            const float4 r = ld_quad<EDGE>(src, p0 * 4u);
             q.r[0] = r.x; q.r[1] = r.y; q.r[2] = r.z; q.r[3] = r.w;
         }
     } else {
@@ -486,7 +486,7 @@ __device__ __forceinline__ bool fps_tile_update(const FpsQuad &q, bool org_on, f
         if (!c) nt[e] = q.tp[e];   // value to write back for an unchanged element
     }
     if (QUAD && ch) st_at(reinterpret_cast<float4 *>(temp), (uint32_t)q.p0 * 4u, make_float4(nt[0], nt[1], nt[2], nt[3]));
-    if (VEC && EDGE && ch && q.nval == 4) st_at(reinterpret_cast<f32x4u *>(temp), (uint32_t)q.p0 * 4u, f32x4u{nt[0], nt[1], nt[2], nt[3]});
+    if (VEC && EDGE && ch && q.nval == 4) st_quad<true>(temp, (uint32_t)q.p0 * 4u, nt[0], nt[1], nt[2], nt[3]);
     if (!with_box && __ballot(ch) == 0ull) return false;
     // (Leaving the arg-max out when the point that holds the tile's maximum did not change -- the entry is then provably what it
     // was -- was measured in round 3: the holder has the largest temp of the tile, so it is the FIRST point a centre in reach
@@ -864,13 +864,12 @@ __global__ __launch_bounds__(64 * MASK_WAVES) MASK_VGPR_ATTR void ground_mask_ta
         q[k].nval = row < g.H ? min(max(g.W - col, 0), 4) : 0;
         q[k].p0 = q[k].nval > 0 ? row * g.W + col : 0;
         const uint32_t p0 = (uint32_t)q[k].p0;
-        using V4 = typename std::conditional<EDGE, f32x4u, float4>::type;
         if (VEC && (!EDGE || q[k].nval == 4)) {
-            const V4 r = ld_at(reinterpret_cast<const V4 *>(ri_b), p0 * 4u);
+            const float4 r = ld_quad<EDGE>(ri_b, p0 * 4u);
             q[k].r[0] = r.x; q[k].r[1] = r.y; q[k].r[2] = r.z; q[k].r[3] = r.w;
-            const V4 ra = ld_at(reinterpret_cast<const V4 *>(tm), p0 * 12u);
-            const V4 rb = ld_at(reinterpret_cast<const V4 *>(tm), p0 * 12u + 16u);
-            const V4 rc = ld_at(reinterpret_cast<const V4 *>(tm), p0 * 12u + 32u);
+            const float4 ra = ld_quad<EDGE>(tm, p0 * 12u);
+            const float4 rb = ld_quad<EDGE>(tm, p0 * 12u + 16u);
+            const float4 rc = ld_quad<EDGE>(tm, p0 * 12u + 32u);
             q[k].t[0] = ra.x; q[k].t[1] = ra.y; q[k].t[2] = ra.z; q[k].t[3] = ra.w; q[k].t[4] = rb.x; q[k].t[5] = rb.y;
             q[k].t[6] = rb.z; q[k].t[7] = rb.w; q[k].t[8] = rc.x; q[k].t[9] = rc.y; q[k].t[10] = rc.z; q[k].t[11] = rc.w;
         } else {
@@ -979,8 +978,8 @@ __global__ __launch_bounds__(64 * MASK_WAVES) MASK_VGPR_ATTR void ground_mask_ta
             st_at(reinterpret_cast<float4 *>(temp_b), (uint32_t)q[k].p0 * 4u, make_float4(nt[0], nt[1], nt[2], nt[3]));
         }
         if (VEC && EDGE && q[k].nval == 4) {
-            if (RAW) st_at(reinterpret_cast<f32x4u *>(ri_b), (uint32_t)q[k].p0 * 4u, f32x4u{rr[0], rr[1], rr[2], rr[3]});
-            st_at(reinterpret_cast<f32x4u *>(temp_b), (uint32_t)q[k].p0 * 4u, f32x4u{nt[0], nt[1], nt[2], nt[3]});
+            if (RAW) st_quad<true>(ri_b, (uint32_t)q[k].p0 * 4u, rr[0], rr[1], rr[2], rr[3]);
+            st_quad<true>(temp_b, (uint32_t)q[k].p0 * 4u, nt[0], nt[1], nt[2], nt[3]);
         }
         if (fast) {
             float lo[3], hi[3], wt, wx, wy, wz;

@@ -129,6 +129,20 @@ struct f32x3 { float x, y, z; };  // one ray of the transform map: a single 12-b
 // floats is four scalar loads to the optimiser, which then folds the element-wise row-end branch and the quad branch of the EDGE kernels into one set of
 // sixteen scalar loads with selected addresses (rounds 3-5 shipped that: 156 global_load_dword in the EDGE FPS kernel, no dwordx4).
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+// A quad of floats at base + byte_off: U (unaligned) -> the 4-byte aligned vector type named in the access itself (a template parameter would drop the
+// typedef's alignment and type the access as 16-byte aligned), else one aligned 16-byte access.
+template <bool U>
+__device__ __forceinline__ float4 ld_quad(const float *base, uint32_t byte_off) {
+    const char *a = reinterpret_cast<const char *>(base) + byte_off;
+    if (U) { const f32x4u v = *reinterpret_cast<const f32x4u *>(a); return make_float4(v.x, v.y, v.z, v.w); }
+    return *reinterpret_cast<const float4 *>(a);
+}
+template <bool U>
+__device__ __forceinline__ void st_quad(float *base, uint32_t byte_off, float x, float y, float z, float w) {
+    char *a = reinterpret_cast<char *>(base) + byte_off;
+    if (U) { f32x4u v; v.x = x; v.y = y; v.z = z; v.w = w; *reinterpret_cast<f32x4u *>(a) = v; }
+    else *reinterpret_cast<float4 *>(a) = make_float4(x, y, z, w);
+}
 template <class T>
 __device__ __forceinline__ T ld_at(const T *base, uint32_t byte_off) {
     return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_off);
