@@ -153,7 +153,13 @@ def pack_frames(basic_compressor, frames, uniform=True):
 def unpack_bitstream(blob, uniform=True):
     out, off = {}, 0
     for k in (() if uniform else ("salience_level",)) + _ORDER:
+        # (the reference reads whatever f.read(n) returns; a truncated or foreign file then fails somewhere inside the entropy decoder)
+        if off + 4 > len(blob):
+            raise ValueError("bitstream ends before the length of '%s' (%d bytes; written with the %s framework?)"
+                             % (k, len(blob), "non-uniform" if uniform else "uniform"))
         (n,) = struct.unpack_from("i", blob, off)
+        if n < 0 or off + 4 + n > len(blob):
+            raise ValueError("bitstream: payload '%s' claims %d bytes, %d are left" % (k, n, len(blob) - off - 4))
         out[k] = blob[off + 4: off + 4 + n]
         off += 4 + n
     return out

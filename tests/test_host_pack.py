@@ -53,6 +53,24 @@ def test_native_container_equals_python_path(cu, uniform):
     assert np.array_equal(np.frombuffer(bc.decompress(back["residual_quantized"]), np.int16), frames[3]["residual_quantized"])
 
 
+def test_container_reader_names_truncated_and_foreign_files(cu):
+    """unpack_bitstream: a file cut short, a length that runs past the end (or is negative) and a container of the other framework are ValueErrors
+    that name the payload -- not a struct.error, a silently short slice or a failure inside the entropy decoder."""
+    rng = np.random.default_rng(3)
+    bc = cu.BasicCompressor(method_name="bzip2")
+    blob = cu.pack_frames(bc, _frames(rng, 2, True), uniform=True)[1]
+    assert set(cu.unpack_bitstream(blob, uniform=True)) == {"contour_map", "idx_sequence", "plane_param", "residual_quantized"}
+    for cut in (0, 3, 4, 10, len(blob) // 2, len(blob) - 1):
+        with pytest.raises(ValueError, match="bitstream"):
+            cu.unpack_bitstream(blob[:cut], uniform=True)
+    bad = bytearray(blob)
+    bad[0:4] = (-5).to_bytes(4, "little", signed=True)
+    with pytest.raises(ValueError, match="claims -5 bytes"):
+        cu.unpack_bitstream(bytes(bad), uniform=True)
+    with pytest.raises(ValueError, match="bitstream"):          # four payloads read as five
+        cu.unpack_bitstream(blob, uniform=False)
+
+
 def test_other_back_ends_take_the_python_path(cu):
     rng = np.random.default_rng(3)
     bc = cu.BasicCompressor(method_name="gzip")
