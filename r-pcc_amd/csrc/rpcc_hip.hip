@@ -1198,13 +1198,49 @@ __device__ int ransac_plane_wg(const PTS &pts, int iters, double thr, uint32_t s
             }
         }
         };
-        if (pts_in_memory(pts)) score(std::integral_constant<int, RS_GLOBAL_PU>{});   // (workgroup-uniform)
-        else score(std::integral_constant<int, RS_PU>{});
+        // The fit on the whole cloud (points in memory: a frame with fewer than 800 ground candidates) shares the POINTS among the wavefronts instead:
+        // every wavefront walking all P pixels for its 13 planes is eight walks with two wavefronts per SIMD to hide them behind (1.22 ms per launch of 64 x 2048
+        // sweeps, 0.25 ms of 16 x 1800 ones).  A wavefront now loads its eighth of the points once -- RS_GLOBAL_PU per lane in flight -- and runs all the planes
+        // over them, two per packed instruction, the planes read from LDS (broadcast); the counts meet in LDS (integers: any order).  Same tests, same counts.
+        int *cnt_all = reinterpret_cast<int *>(sred) + 1024;   // [MAXH] behind the fp32 planes in the (not yet used) sum area
+        const bool shared_pts = pts_in_memory(pts);             // (workgroup-uniform)
+        if (shared_pts) {
+            for (int q = tid; q < MAXH; q += NTH) cnt_all[q] = 0;
+            __syncthreads();
+            constexpr int PU = RS_GLOBAL_PU;
+            for (int ib = wave * 64 * PU; ib < n; ib += NTH * PU) {   // (wave-uniform trip count)
+                const int i0 = ib + lane;
+                float x[PU], y[PU], z[PU];
+#pragma unroll
+                for (int u = 0; u < PU; u++) {
+                    pts.getf(min(i0 + 64 * u, n - 1), x[u], y[u], z[u]);
+                    if (i0 + 64 * u >= n) x[u] = __builtin_inff();   // past the end: inf or NaN on every plane, never an inlier
+                }
+                for (int q = 0; q < iters; q += 2) {
+                    const int q1 = min(q + 1, iters - 1);
+                    const bool ok0 = hyp[5 * q + 4] != 0.0f, ok1 = q + 1 < iters && hyp[5 * q1 + 4] != 0.0f;
+                    const rs_v2f a = {hyp[5 * q], hyp[5 * q1]}, b2 = {hyp[5 * q + 1], hyp[5 * q1 + 1]}, c2 = {hyp[5 * q + 2], hyp[5 * q1 + 2]},
+                                 d2 = {ok0 ? hyp[5 * q + 3] : __builtin_inff(), ok1 ? hyp[5 * q1 + 3] : __builtin_inff()};
+                    int c0 = 0, c1 = 0;
+#pragma unroll
+                    for (int u = 0; u < PU; u++) {
+                        const rs_v2f xx = {x[u], x[u]}, yy = {y[u], y[u]}, zz = {z[u], z[u]};
+                        const rs_v2f dd = ((a * xx + b2 * yy) + c2 * zz) + d2;   // plane_inlier() twice (each half rounds like the scalar operation)
+                        c0 += (int)__popcll(__ballot(fabsf(dd.x) < thr_f));
+                        c1 += (int)__popcll(__ballot(fabsf(dd.y) < thr_f));
+                    }
+                    if (lane == 0) { if (c0) atomicAdd(&cnt_all[q], c0); if (c1 && q + 1 < iters) atomicAdd(&cnt_all[q + 1], c1); }
+                }
+            }
+            __syncthreads();
+        } else {
+            score(std::integral_constant<int, RS_PU>{});
+        }
         int best_cnt = -1, best_h = 0x7fffffff;
 #pragma unroll
         for (int q = 0; q < RS_HPW; q++) {
             const int h = wave + q * (NTH / 64);
-            const int c = cnt[q];
+            const int c = shared_pts ? cnt_all[h < iters ? h : 0] : cnt[q];
             if (h < iters && hyp[5 * h + 4] != 0.0f && c > best_cnt) { best_cnt = c; best_h = h; }
         }
         double best[4] = {0, 0, 1, 0};
