@@ -622,6 +622,12 @@ __global__ __launch_bounds__(256) void project_fastcheck_kernel(const float *__r
 // (frames with a depth-0 point are re-projected afterwards and count for themselves).
 #define RS_CHUNKS 16
 static inline int rs_chunk_px(int P) { return (((P + RS_CHUNKS - 1) / RS_CHUNKS) + 63) & ~63; }
+// Beside the counts (P % 64 == 0: the quad write-out, whole 64-pixel words): WHICH pixels have z < zthr, a byte per quad of pixels (bit e = pixel 4 q + e),
+// [B][P / 4] bytes behind the B x (RS_CHUNKS + 1) count words (16-byte aligned); zcnt[b][RS_CHUNKS] = 3 when counts and bytes are valid (1: counts only).
+// The ground fit compacts its candidates from these bytes instead of testing every pixel again.
+__host__ __device__ __forceinline__ uint8_t *rs_zmask_of(const int32_t *zcnt, int B) {
+    return reinterpret_cast<uint8_t *>(const_cast<int32_t *>(zcnt)) + (((size_t)B * (RS_CHUNKS + 1) * 4 + 15) & ~(size_t)15);
+}
 __device__ void project_fixup_frame(const float *__restrict__ xyz, const int64_t *__restrict__ offs, int b, rpcc_geom g,
                                     uint32_t *__restrict__ ri, int32_t *__restrict__ lastz, int ps);
 
@@ -763,6 +769,8 @@ __global__ __launch_bounds__(BAND_THREADS) BAND_VGPR_ATTR void project_band_kern
         const float4 *tz4 = reinterpret_cast<const float4 *>(tz + band0);
         uint4 *out4 = reinterpret_cast<uint4 *>(out);
         const uint32_t nq = npx >> 2;
+        const bool want_bytes = (P & 63) == 0;
+        uint8_t *zm = rs_zmask_of(zcnt, B) + (int64_t)b * (P >> 2) + (band0 >> 2);
         // (whole wavefronts stay in the loop: the DPP sum below needs every lane)
         for (uint32_t q0 = threadIdx.x; q0 - (threadIdx.x & 63u) < nq; q0 += BAND_THREADS * 4) {  // 4 quads per lane in flight
             uint4 rv[4];
@@ -782,8 +790,10 @@ __global__ __launch_bounds__(BAND_THREADS) BAND_VGPR_ATTR void project_band_kern
                 const uint32_t q = q0 + u * BAND_THREADS;
                 const bool in = q < nq;
                 if (in) out4[q] = rv[u];
-                const int c = in ? (int)(u2f(rv[u].x) * zr[u].x < zthr) + (int)(u2f(rv[u].y) * zr[u].y < zthr) +
-                                   (int)(u2f(rv[u].z) * zr[u].z < zthr) + (int)(u2f(rv[u].w) * zr[u].w < zthr) : 0;
+                const int t0 = (int)(u2f(rv[u].x) * zr[u].x < zthr), t1 = (int)(u2f(rv[u].y) * zr[u].y < zthr),
+                          t2 = (int)(u2f(rv[u].z) * zr[u].z < zthr), t3 = (int)(u2f(rv[u].w) * zr[u].w < zthr);
+                const int c = in ? (t0 + t1) + (t2 + t3) : 0;
+                if (in && want_bytes) zm[q] = (uint8_t)(t0 | (t1 << 1) | (t2 << 2) | (t3 << 3));
                 const uint32_t ch = (band0 + 4u * min(q, nq - 1)) / (uint32_t)rs_chunk;
                 const uint32_t ch0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ch);
                 if (__ballot(ch != ch0) == 0ull) {
@@ -796,7 +806,7 @@ __global__ __launch_bounds__(BAND_THREADS) BAND_VGPR_ATTR void project_band_kern
         }
         __syncthreads();
         if (threadIdx.x < RS_CHUNKS && zc[threadIdx.x]) atomicAdd(&zcnt[b * (RS_CHUNKS + 1) + threadIdx.x], zc[threadIdx.x]);
-        if (kband == 0 && threadIdx.x == 0) zcnt[b * (RS_CHUNKS + 1) + RS_CHUNKS] = 1;
+        if (kband == 0 && threadIdx.x == 0) zcnt[b * (RS_CHUNKS + 1) + RS_CHUNKS] = want_bytes ? 3 : 1;
         continue;
     }
     // a wavefront covers 64 consecutive pixels per step; rs_chunk is a multiple of 64, so the chunk is wave-uniform
@@ -1343,7 +1353,7 @@ __device__ __forceinline__ void ground_ransac_body(const float *__restrict__ ri_
                                                    double *__restrict__ ground,
                                                    int32_t *__restrict__ ninl,
                                                    const int32_t *__restrict__ zcnt,
-                                                   const int64_t *__restrict__ frame_ids, const int b) {   // b: the workgroup's frame
+                                                   const int64_t *__restrict__ frame_ids, const int b, const int nframes) {   // b: the workgroup's frame of nframes
     extern __shared__ __attribute__((aligned(16))) unsigned char rs_smem[];
     double *sred = reinterpret_cast<double *>(rs_smem);          // [6*256]
     double *swin = sred + 6 * RS_NT;                             // [64] + [RS_MAX_HYP*4] fp64 hypotheses
@@ -1387,7 +1397,84 @@ __device__ __forceinline__ void ground_ransac_body(const float *__restrict__ ri_
         by_nc.magic = (uint32_t)__builtin_amdgcn_readfirstlane((int)by_nc.magic);
         by_nc.shift = (uint32_t)__builtin_amdgcn_readfirstlane((int)by_nc.shift);
     }
-    if (nc >= min_pts) {
+    const bool have_bytes = have_cnt && zcnt[b * (RS_CHUNKS + 1) + RS_CHUNKS] == 3 && (P & 63) == 0 && !raw;
+    if (nc >= min_pts && have_bytes) {
+        // The band kernel left a byte per quad of pixels saying which of them are candidates: a lane takes a word of 64 pixels (16 bytes), ranks its
+        // candidates with one scan over the wavefront and walks only the SET bits; candidate i goes to slot floor(i * max_pts / nc) when the next one
+        // goes to another -- carried along as a = (i * max_pts) mod nc: kept iff a + max_pts >= nc -- which is the rule of the loop below, integer for
+        // integer.  Kept pixels are noted in the list first; their coordinates follow in one round of loads (<= 10 per thread, all in flight).
+        const uint8_t *zm = rs_zmask_of(zcnt, nframes) + (int64_t)b * (P >> 2);
+        uint32_t *listp = reinterpret_cast<uint32_t *>(list);
+        const bool sub = nc > max_pts;
+        const uint32_t ncu = (uint32_t)nc, maxu = (uint32_t)max_pts;
+        // (the words are dealt to the threads round-robin, not a contiguous eighth of the image per wavefront: the ground fills the lower rows, and the
+        // wavefronts that owned those walked 64 set bits per word while the others had none; the ranks then need a scan over the workgroup per round)
+        const int nwords = P >> 6;
+        uint32_t run = 0u;
+        __syncthreads();   // (every thread has read the chunk counts in swave: the rounds write it again)
+        for (int wi0 = 0; wi0 < nwords; wi0 += RS_THREADS) {   // (workgroup-uniform trip count)
+            const int wi = wi0 + tid;
+            const int pw = wi << 6;                    // this thread's word: pixels pw .. pw + 63
+            unsigned long long word = 0ull;
+            if (wi < nwords) {
+                const uint4 v = ld_at(reinterpret_cast<const uint4 *>(zm), (uint32_t)(pw >> 2));
+                const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int j = 0; j < 4; j++) {   // 4 bytes of nibbles -> 16 bits
+                    const uint32_t x = d[j] & 0x0F0F0F0Fu;
+                    const uint32_t h = (x | (x >> 4)) & 0x00FF00FFu;
+                    word |= (unsigned long long)((h | (h >> 8)) & 0xFFFFu) << (16 * j);
+                }
+            }
+            const uint32_t c = (uint32_t)__popcll(word);
+            const uint32_t incl = dpp_scan_incl_u32(c);
+            if (lane == 63) swave[wave] = (int)incl;
+            __syncthreads();
+            uint32_t before = 0u, all = 0u;
+            for (int w = 0; w < RS_THREADS / 64; w++) { const uint32_t t = (uint32_t)swave[w]; if (w < wave) before += t; all += t; }
+            __syncthreads();                           // (swave is written again in the next round)
+            uint32_t i = run + before + incl - c;      // rank of this thread's first candidate in the frame
+            run += all;
+            if (c) {
+                if (!sub) {
+                    while (word) { listp[3 * i] = (uint32_t)pw + (uint32_t)__builtin_ctzll(word); i++; word &= word - 1ull; }
+                } else {
+                    uint32_t slot, a;
+                    if (small_prod) { slot = udiv32(i * maxu, by_nc); a = i * maxu - slot * ncu; }
+                    else { const unsigned long long pr = (unsigned long long)i * maxu; slot = (uint32_t)(pr / ncu); a = (uint32_t)(pr - (unsigned long long)slot * ncu); }
+                    while (word) {
+                        const uint32_t t = a + maxu;
+                        const bool keep = t >= ncu;
+                        if (keep) listp[3 * slot] = (uint32_t)pw + (uint32_t)__builtin_ctzll(word);
+                        a = keep ? t - ncu : t;
+                        slot += keep ? 1u : 0u;
+                        word &= word - 1ull;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        DBG_STAMP(8);
+        const int nl = sub ? max_pts : nc;
+        constexpr int LU = 10;   // (5000 slots over 512 threads)
+        for (int s0 = tid; s0 < nl; s0 += RS_THREADS * LU) {
+            float r[LU];
+            f32x3 ray[LU];
+#pragma unroll
+            for (int u = 0; u < LU; u++) {
+                const uint32_t pp = listp[3 * min(s0 + u * RS_THREADS, nl - 1)];
+                r[u] = ld_at(ri, pp * 4u);
+                ray[u] = ld_at(reinterpret_cast<const f32x3 *>(tm), pp * 12u);
+            }
+#pragma unroll
+            for (int u = 0; u < LU; u++) {
+                const int sl = s0 + u * RS_THREADS;
+                if (sl < nl) { list[3 * sl] = r[u] * ray[u].x; list[3 * sl + 1] = r[u] * ray[u].y; list[3 * sl + 2] = r[u] * ray[u].z; }
+            }
+        }
+        pts.lds = list;
+        pts.n = nl;
+    } else if (nc >= min_pts) {
         int run = base;
         for (int p00 = w0; p00 < w1; p00 += 64 * RS_CU) {  // all loads of RS_CU steps are issued before any is used
             float xv[RS_CU], yv[RS_CU], zv[RS_CU];
@@ -1448,7 +1535,7 @@ __global__ __launch_bounds__(RS_THREADS) RS_VGPR_ATTR void ground_ransac_kernel(
                                                                    int32_t *__restrict__ ninl,
                                                                    const int32_t *__restrict__ zcnt,
                                                                    const int64_t *__restrict__ frame_ids) {
-    ground_ransac_body(ri_all, tm, P, zthr, max_pts, min_pts, ransac_n, iters, thr, seed0, raw, ground, ninl, zcnt, frame_ids, blockIdx.x);
+    ground_ransac_body(ri_all, tm, P, zthr, max_pts, min_pts, ransac_n, iters, thr, seed0, raw, ground, ninl, zcnt, frame_ids, blockIdx.x, gridDim.x);
 }
 // the frames of several geometry groups in one launch (rpcc_compress_batch_mixed; fps_kernels.h: fps_regtab_planar_multi_kernel)
 struct RansacGroupArgs {
@@ -1468,7 +1555,7 @@ __global__ __launch_bounds__(RS_THREADS) RS_VGPR_ATTR void ground_ransac_multi_k
     const int gi = multi_group_of(m.first, m.n, blockIdx.x);
     const RansacGroupArgs &a = m.a[gi];
     ground_ransac_body(a.ri_all, a.tm, a.P, zthr, max_pts, min_pts, ransac_n, iters, thr, a.seed0, 0, a.ground, nullptr, a.zcnt, a.frame_ids,
-                       (int)blockIdx.x - m.first[gi]);
+                       (int)blockIdx.x - m.first[gi], m.first[gi + 1] - m.first[gi]);
 }
 
 #define RS_GROUND_MAX_PTS 5000
