@@ -1,5 +1,5 @@
 """Rebuild profiles/<round>_valu_mix_dynamic.md from a round's committed sets: the per-kernel tables of <tag>_pmc.md, <tag>_c2_pmc.md, <tag>_real_pmc.md
-and the prices of profiles/pmc_current.json against the un-profiled bench line of the same session.   usage: python tools_dev/valu_mix_md.py r05_v2"""
+and the prices of profiles/pmc_current.json against the un-profiled bench line of the same session.   usage: python tools_dev/valu_mix_md.py r05_v3"""
 import json
 import os
 import sys
