@@ -1317,6 +1317,38 @@ def test_fuzz_mixed_call_vs_groups_alone(env, seed):
             assert np.array_equal(ba.salience.cpu().numpy(), bm.salience.cpu().numpy()), (seed, k)
 
 
+def test_ground_fit_hand_over_equals_the_fit_alone(env):
+    """Inside the fused call the band kernel hands the ground fit its candidate counts and, for images of whole 64-pixel words, a byte per pixel quad that
+    says which pixels are candidates (the fit then walks set bits instead of testing every pixel).  Every variant -- bytes (P % 64 == 0), counts only
+    (P % 4 == 0), the scalar write-out (odd P), no hand-over (a frame with a depth-0 point) -- must give the plane of rpcc_ground_ransac run alone on
+    the same range image, bit for bit: more than 5000 candidates (systematic subsample), 800 .. 5000 (all kept), fewer than 800 (the whole cloud)."""
+    torch, ops, orc, synth = env["torch"], env["ops"], env["orc"], env["synth"]
+    for (H, W, vmax, vmin) in ((64, 2048, 2.0, -24.9), (32, 2250, 10.67, -30.67), (16, 1800, 15.0, -15.0),   # whole words
+                               (20, 1250, 3.0, -25.0),      # P = 25000: quads, no whole words
+                               (21, 1001, 3.0, -25.0)):     # P odd: scalar write-out
+        g = orc.LidarGeom(H, W, 360.0, vmax, vmin)
+        tm = ops.transform_map(g.H, g.W, g.horizontal_FOV, g.vertical_max, g.vertical_min)
+        geom = ops.make_geom(g.H, g.W, g.horizontal_FOV, g.vertical_max, g.vertical_min)
+        f0 = synth.make_frame(4400 + H, H, W, vmax_deg=vmax, vmin_deg=vmin).numpy()
+        low = np.flatnonzero(f0[:, 2] < -1.5)
+        frames = [f0,
+                  np.concatenate([f0[f0[:, 2] >= -1.5], f0[low[:2500]]]),        # ~2500 candidates: all kept
+                  f0[f0[:, 2] > -1.45],                                            # none: the whole cloud
+                  np.concatenate([f0, np.zeros((1, 3), np.float32)])]              # a depth-0 point: the exact projection path, no hand-over
+        n = len(frames)
+        offs = np.zeros(n + 1, np.int64)
+        offs[1:] = np.cumsum([f.shape[0] for f in frames])
+        fid = _to(env, np.arange(n, dtype=np.int64) + 17)
+        buf = ops.BatchBuffers(n, geom, 20, env["dev"])
+        gms = torch.zeros((n, 4), dtype=torch.float64, device=env["dev"])
+        ops.compress_batch(_to(env, np.concatenate(frames)), _to(env, offs), _to(env, tm), gms, buf, ground_seed=3, frame_ids=fid)
+        alone, _ = ops.ground_ransac(buf.ri, _to(env, tm), seed=3, frame_ids=fid)
+        assert _beq(gms.cpu().numpy(), alone.cpu().numpy()), (H, W)
+        for i in (0, 1):
+            ri = orc.project(frames[i], g)
+            assert _beq(gms[i].cpu().numpy(), np.asarray(orc.ground_model(ri, tm, seed=3 + 17 + i), np.float64)), (H, W, i)
+
+
 def test_compress_batch_stages_equal_the_single_call(env):
     """rpcc_compress_batch_stages: the batch's stages issued one by one (and in two groups on two streams joined by an event) give the outputs of
     rpcc_compress_batch; all bits at once is the same call."""
