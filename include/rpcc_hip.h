@@ -344,7 +344,9 @@ int rpcc_compress_batch_mixed(const rpcc_batch_io *ios, const int *Bs, const rpc
  * Same stages, same arithmetic, same results as rpcc_compress_batch -- one thread per pixel or label, per-label totals by global atomics, the ordered
  * scatter through one stable radix sort of (frame, label) keys: written for correctness, not for speed (csrc/wide_kernels.h).  All four framework / model
  * combinations; the CUDA-binary FPS modes are not available here.  ws: rpcc_wide_workspace_bytes(B, P, M, total_points) bytes.
- * The container's side of it: the contour codec and the decoder body on uint16 label maps (rpcc_decode_wide: ws of rpcc_wide_workspace_bytes(B, P, M, 0)). */
+ * The container's side of it: the contour codec and the decoder body on uint16 label maps (rpcc_decode_wide: ws of rpcc_wide_workspace_bytes(B, P, M, 0)).
+ * rpcc_decode_wide takes label maps of foreign streams: a label above M + 1 (no row of `model`) is read as M + 1 -- memory-safe, the pixel's value is then
+ * meaningless as the stream's was; callers that must reject such a stream check the label range first (compress_utils.decode_frame does). */
 #define RPCC_MAX_CLUSTERS_WIDE 65533
 size_t rpcc_wide_workspace_bytes(int B, int P, int M, int64_t total_points);
 int rpcc_compress_batch_wide(const rpcc_batch_io *io, int B, rpcc_geom g, int M, double ground_threshold, float acc, void *ws, void *stream);

@@ -75,7 +75,9 @@ static hipError_t ensure_dyn_lds(const void *fn, int bytes) {
     if (slot && slot->bytes >= bytes) return hipSuccess;   // the largest size asked for so far is in force
     e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) return e;
-    if (slot) slot->bytes = bytes; else g_attr_done.push_back({dev, fn, bytes});
+    if (slot) { slot->bytes = bytes; return hipSuccess; }
+    // (nothing throws across the C ABI: a failed growth of the table only means the attribute is set again next time)
+    try { g_attr_done.push_back({dev, fn, bytes}); } catch (...) { }
     return hipSuccess;
 }
 
@@ -99,10 +101,16 @@ extern "C" int rpcc_timer_reserve(void *t, int launches) {
     rpcc_timer *tm = reinterpret_cast<rpcc_timer *>(t);
     ARG_TRY(tm != nullptr && launches >= 0 && launches <= (1 << 20));
     std::lock_guard<std::mutex> lk(tm->mu);
-    while (tm->ev0.size() < (size_t)launches) {
+    try {   // (nothing throws across the C ABI: the vectors' growth is the only thing here that can)
+        tm->ev0.reserve((size_t)launches);
+        tm->ev1.reserve((size_t)launches);
+    } catch (...) {
+        return set_err(RPCC_ERR_HIP, "rpcc_timer_reserve: out of host memory%s%s");
+    }
+    while (tm->ev0.size() < (size_t)launches) {   // (capacity reserved: push_back cannot throw)
         hipEvent_t a, b;
         HIP_TRY(hipEventCreate(&a));
-        HIP_TRY(hipEventCreate(&b));
+        if (hipEventCreate(&b) != hipSuccess) { (void)hipEventDestroy(a); return set_err(RPCC_ERR_HIP, "rpcc_timer_reserve: hipEventCreate failed%s%s"); }
         tm->ev0.push_back(a);
         tm->ev1.push_back(b);
     }
@@ -131,14 +139,20 @@ struct FpsTimer {
     FpsTimer(hipStream_t st, void *timer) : s(st), tm(reinterpret_cast<rpcc_timer *>(timer)) {
         if (!tm) return;
         std::lock_guard<std::mutex> lk(tm->mu);
-        slot = tm->used++;
-        while (tm->ev0.size() <= slot) {
-            hipEvent_t a, b;
-            (void)hipEventCreate(&a);
-            (void)hipEventCreate(&b);
-            tm->ev0.push_back(a);
-            tm->ev1.push_back(b);
-        }
+        slot = tm->used;
+        // a launch that cannot get its pair of events (host memory, event creation) goes untimed: nothing throws across the C ABI
+        try {
+            while (tm->ev0.size() <= slot) {
+                tm->ev0.reserve(tm->ev0.size() + 1);
+                tm->ev1.reserve(tm->ev1.size() + 1);
+                hipEvent_t a, b;
+                if (hipEventCreate(&a) != hipSuccess) { tm = nullptr; return; }
+                if (hipEventCreate(&b) != hipSuccess) { (void)hipEventDestroy(a); tm = nullptr; return; }
+                tm->ev0.push_back(a);
+                tm->ev1.push_back(b);
+            }
+        } catch (...) { tm = nullptr; return; }
+        tm->used = slot + 1;
         (void)hipEventRecord(tm->ev0[slot], s);
     }
     ~FpsTimer() {
@@ -1462,7 +1476,10 @@ __device__ __forceinline__ void ground_ransac_body(const float *__restrict__ ri_
             f32x3 ray[LU];
 #pragma unroll
             for (int u = 0; u < LU; u++) {
-                const uint32_t pp = listp[3 * min(s0 + u * RS_THREADS, nl - 1)];
+                // (past the end: the thread's OWN first slot again -- slot nl - 1 belongs to another thread, which may already have
+                // replaced its pixel index by coordinates: float bits taken as an index would be an address anywhere in 4 GiB)
+                const int sl = s0 + u * RS_THREADS;
+                const uint32_t pp = listp[3 * (sl < nl ? sl : s0)];
                 r[u] = ld_at(ri, pp * 4u);
                 ray[u] = ld_at(reinterpret_cast<const f32x3 *>(tm), pp * 12u);
             }

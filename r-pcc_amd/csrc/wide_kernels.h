@@ -99,7 +99,11 @@ __global__ __launch_bounds__(256) void wide_keys_kernel(const L *__restrict__ se
     const int b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
     const bool valid = p < P;
     const int64_t g = (int64_t)b * P + (valid ? p : P - 1);
-    const uint32_t l = seg[g];
+    // A label map from a foreign or damaged stream (rpcc_decode_wide) may hold values above K - 1: they count as label K - 1 here and in
+    // wide_decode_kernel (memory-safe; flags[4 b + 1] says so), never as an index behind the frame's K counters.
+    const uint32_t lraw = seg[g];
+    const uint32_t l = min(lraw, (uint32_t)(K - 1));
+    if (__any(valid && lraw != l) && lane == 0) flags[4 * b + 1] = 1;
     if (valid) { keys[g] = ((uint32_t)b << 16) | l; vals[g] = (uint32_t)p; }
     uint32_t lo = 0u, hi = 0u;   // r * 2^28 = hi << 18 | lo: the sums of either part over a wavefront stay below 2^32
     bool bad = false;
@@ -244,7 +248,7 @@ __global__ __launch_bounds__(256) void wide_decode_kernel(const L *__restrict__ 
     const int b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
     if (p >= P) return;
     const int64_t g = (int64_t)b * P + p;
-    const int l = seg[g], o = pos[g];
+    const int l = min((int)seg[g], K - 1), o = pos[g];   // (wide_keys_kernel: labels above K - 1 count as K - 1)
     const float *m = model + ((int64_t)b * K + l) * 4;
     const float p0 = m[0], p1 = m[1], p2 = m[2], p3 = m[3];
     const float tx = tm[3 * p], ty = tm[3 * p + 1], tz = tm[3 * p + 2];

@@ -101,16 +101,19 @@ class BatchCompressor:
         """Waits for submit()'s stream and assembles the .rpcc byte strings (host part: casts, container, entropy coder).
         pool: a concurrent.futures executor -- the frames' entropy coding then runs on its threads (bz2 / zlib / lz4
         release the GIL), like the reference's --workers ThreadPoolExecutor (tools/compress_datalist.py:202-206)."""
-        ctx["stream"].synchronize()
-        buf, bits, nseq, sal = ctx["buf"], ctx["bits"], ctx["nseq"], ctx["sal"]
-        nnz, nseq_h = buf.nnz.cpu().numpy(), nseq.cpu().numpy()
-        seg_max = buf.counts.cpu().numpy()
-        q16 = ctx["qp"][: int(ctx["qtot"].item())].cpu().numpy()
-        seq_h = ctx["sp"][: int(ctx["stot"].item())].cpu().numpy().view(np.uint16)
-        qo, so = np.concatenate([[0], np.cumsum(nnz)]), np.concatenate([[0], np.cumsum(nseq_h)])
-        bits_h, model = bits.cpu().numpy(), buf.model.cpu().numpy()
-        sal_h = None if sal is None else sal.cpu().numpy()
-        buf.in_flight = False   # everything collect() needs is on the host
+        buf = ctx["buf"]
+        try:
+            ctx["stream"].synchronize()
+            bits, nseq, sal = ctx["bits"], ctx["nseq"], ctx["sal"]
+            nnz, nseq_h = buf.nnz.cpu().numpy(), nseq.cpu().numpy()
+            seg_max = buf.counts.cpu().numpy()
+            q16 = ctx["qp"][: int(ctx["qtot"].item())].cpu().numpy()
+            seq_h = ctx["sp"][: int(ctx["stot"].item())].cpu().numpy().view(np.uint16)
+            qo, so = np.concatenate([[0], np.cumsum(nnz)]), np.concatenate([[0], np.cumsum(nseq_h)])
+            bits_h, model = bits.cpu().numpy(), buf.model.cpu().numpy()
+            sal_h = None if sal is None else sal.cpu().numpy()
+        finally:
+            buf.in_flight = False   # everything collect() needs is on the host -- or the call failed: either way the slot is free again
         def assemble(b):
             nrow = int(np.flatnonzero(seg_max[b])[-1]) + 1          # max(seg)+1 rows (tools/compress.py:102)
             od = {"residual_quantized": q16[qo[b]: qo[b + 1]]}
@@ -126,6 +129,14 @@ class BatchCompressor:
         chunk = lambda lo: pack_frames(self.bc, [assemble(b) for b in range(lo, min(lo + step, n))], uniform=self.uniform)
         parts = list(pool.map(chunk, range(0, n, step))) if pool is not None else [chunk(lo) for lo in range(0, n, step)]
         return [blob for part in parts for blob in part]
+
+    def discard(self, ctx):
+        """Gives up a submit() whose results are not wanted (a caller that aborts a batch): waits for its stream -- the kernels may still
+        be writing the slot -- and frees the slot.  Without it (or collect()) the slot stays busy and the ring runs out after SLOTS such calls."""
+        try:
+            ctx["stream"].synchronize()
+        finally:
+            ctx["buf"].in_flight = False
 
     def compress(self, frames, ground=None, pool=None, frame_ids=None):
         """frames: list of [N,3] arrays.  -> list of .rpcc byte strings (one per frame)."""

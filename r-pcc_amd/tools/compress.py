@@ -27,7 +27,7 @@ def make_parser(datalist=False):
     if datalist:
         p.add_argument("--datalist", help="datalist of point cloud files.")
         p.add_argument("--output_dir", help="output folder.")
-        p.add_argument("--workers", type=int, default=4, help="host threads for entropy coding and file output.")
+        p.add_argument("--workers", type=int, default=1, help="host threads for entropy coding and file output (tools/compress_datalist.py:25).")
         p.add_argument("--output", action="store_true", help="print per-frame information.")
         p.add_argument("--batch", type=int, default=64, help="frames per device batch.")
         p.add_argument("--points-per-frame", dest="points_per_frame", type=int, default=None,
@@ -132,8 +132,8 @@ def compress_wide(args, cfg, accuracy, segment_cfg, model_cfg, basic_compressor,
         rec, _, _ = decode_frame(read_compressed_bitstream(args.output, uniform=uniform), basic_compressor, dataset.PCTransformer,
                                  segment_cfg["cluster_num"], accuracy, level_acc, uniform, want_points=False)
         ri = buf.ri[0].cpu().numpy()
-        dif = np.abs(rec - ri)[ri != 0]
-        bound = accuracy + (0.0 if uniform else 0.06) + 0.00001   # (the bound of compress() below: tools/compress.py:176-181)
+        dif = np.abs(rec - ri)   # every pixel, empty ones included, as compress() below and tools/compress.py:172-181
+        bound = accuracy + (0.0 if uniform else 0.06) + 0.00001
         print("\nReconstruction quality: ")
         print("    Depth Error (mean): ", float(np.mean(dif)))
         print("    Depth Error (max): ", float(np.max(dif)))

@@ -25,7 +25,7 @@ from rpcc_amd.loader import StreamingCompressor  # noqa: E402
 from rpcc_amd.pipeline import BatchCompressor  # noqa: E402
 from rpcc_amd.sharding import RoundGather, shard_indices  # noqa: E402
 from rpcc_amd.tools.compress import apply_fps_mode, make_parser, resolve_cfg  # noqa: E402
-from rpcc_amd.utils import available_cpus, frame_identity, pin_rank_cpus  # noqa: E402
+from rpcc_amd.utils import available_cpus, frame_identity, local_rank_env, pin_rank_cpus  # noqa: E402
 
 
 def output_path_for(output_dir, file_name):
@@ -91,7 +91,10 @@ def compress(args, streaming_factory=None):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     device = "cuda:%d" % local
     # one process per GPU: every rank keeps its own slice of the host's CPUs (the feed is host-bound: DESIGN.md section 7)
-    pinned = pin_rank_cpus(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+    # (only when the launcher names both LOCAL_RANK and LOCAL_WORLD_SIZE, as torchrun does: with WORLD_SIZE as the fall-back a multi-node job
+    # would cut slices by the global world, and every rank of a host that lacks LOCAL_RANK would take the first one)
+    lenv = local_rank_env()
+    pinned = pin_rank_cpus(lenv[0], lenv[1]) if lenv is not None else None
     if pinned is not None:
         args.workers = max(1, min(args.workers, available_cpus()))
     apply_fps_mode(args)

@@ -91,6 +91,23 @@ def visible_gpus():
     return n
 
 
+def log_affinity_skipped(why):
+    import sys
+    print("rpcc_amd: CPU pinning skipped: " + why, file=sys.stderr)
+
+
+def local_rank_env():
+    """(LOCAL_RANK, LOCAL_WORLD_SIZE) when the launcher set BOTH (torchrun does), else None: without them a multi-node job would size the
+    slices by the global world and pin every rank of a host to the same first slice."""
+    lr, lw = os.environ.get("LOCAL_RANK"), os.environ.get("LOCAL_WORLD_SIZE")
+    if lr is None or lw is None:
+        return None
+    try:
+        return int(lr), int(lw)
+    except ValueError:
+        return None
+
+
 def pin_rank_cpus(local_rank, local_world):
     """One process per GPU on one host: rank r keeps the r-th of `local_world` equal, contiguous slices of the CPUs the job may use, so
     that the ranks' feeder threads (file reads, staging copies, entropy coding: loader.StreamingCompressor) do not migrate over each other's
@@ -101,6 +118,14 @@ def pin_rank_cpus(local_rank, local_world):
     try:
         cpus = sorted(os.sched_getaffinity(0))
     except (AttributeError, OSError):
+        return None
+    # A launcher that has already bound this rank to its own CPU set (numactl, a scheduler's cgroup cpuset per task) must not be cut again:
+    # the slices below assume that every rank starts from the same host-wide mask.  A mask smaller than the machine says it has been.
+    if len(cpus) < (os.cpu_count() or len(cpus)) and os.environ.get("RPCC_FORCE_AFFINITY") != "1":
+        log_affinity_skipped("the process already runs on %d of %d CPUs (bound by its launcher)" % (len(cpus), os.cpu_count()))
+        return None
+    if not 0 <= local_rank < local_world:
+        log_affinity_skipped("LOCAL_RANK %d outside LOCAL_WORLD_SIZE %d" % (local_rank, local_world))
         return None
     per = len(cpus) // local_world
     if per < 1:

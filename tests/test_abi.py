@@ -71,3 +71,72 @@ def test_cluster_num_limits_are_named():
     from rpcc_amd.pipeline import BatchCompressor
     with pytest.raises(_lib.RpccError, match="cluster_num = 70000"):
         BatchCompressor(None, cluster_num=70000)
+
+
+def test_nothing_throws_across_the_abi(built):
+    """include/rpcc_hip.h promises `int` status codes and no C++ exception across the boundary.  The only throwing operations in the library are the
+    growth of its two host-side tables (kernel attributes, timer events): every push_back sits behind a reserve inside a try block or inside one
+    itself, and the timer entry points answer with a status where there is no device at all (here) instead of terminating the process."""
+    src = open(os.path.join(ROOT, "r-pcc_amd", "csrc", "rpcc_hip.hip")).read().splitlines()
+    for i, line in enumerate(src):
+        if "push_back(" in line and not line.lstrip().startswith("//"):
+            ctx = "\n".join(src[max(0, i - 14):i + 1])
+            assert "try {" in ctx, "push_back outside a try block / reserve: line %d" % (i + 1)
+    lib = built.lib()
+    lib.rpcc_timer_create.restype = ctypes.c_void_p
+    t = ctypes.c_void_p(lib.rpcc_timer_create())
+    assert t.value
+    assert lib.rpcc_timer_reserve(t, (1 << 20) + 1) == -1            # RPCC_ERR_ARG
+    rc = lib.rpcc_timer_reserve(t, 4)                                # no device here: a HIP status, not an exception (0 on a GPU box)
+    assert rc in (0, -2), rc
+    lib.rpcc_timer_destroy.argtypes = [ctypes.c_void_p]
+    lib.rpcc_timer_destroy(t)
+
+
+def test_a_failed_collect_frees_its_ring_slot():
+    """pipeline.BatchCompressor keeps SLOTS buffer sets per batch size; a collect() that raises (stream error, host OOM in a copy) or a submit()
+    whose caller gives up (discard) must free the slot, or the ring is exhausted after SLOTS such events."""
+    import rpcc_amd  # noqa: F401
+    from rpcc_amd.pipeline import BatchCompressor
+
+    class Buf:
+        in_flight = True
+
+    class BadStream:
+        def synchronize(self):
+            raise RuntimeError("stream error")
+
+    bc = object.__new__(BatchCompressor)
+    b = Buf()
+    with pytest.raises(RuntimeError, match="stream error"):
+        bc.collect(dict(buf=b, stream=BadStream()))
+    assert b.in_flight is False
+    b.in_flight = True
+    with pytest.raises(RuntimeError, match="stream error"):
+        bc.discard(dict(buf=b, stream=BadStream()))
+    assert b.in_flight is False
+
+
+def test_cpu_pinning_only_with_explicit_local_ranks(monkeypatch):
+    """utils.pin_rank_cpus slices the host's CPUs by LOCAL_RANK: only when the launcher named LOCAL_RANK and LOCAL_WORLD_SIZE, and not when the
+    process already runs on a subset of the machine (bound by its launcher)."""
+    import rpcc_amd  # noqa: F401
+    from rpcc_amd import utils
+    for k in ("LOCAL_RANK", "LOCAL_WORLD_SIZE", "RPCC_NO_AFFINITY", "RPCC_FORCE_AFFINITY"):
+        monkeypatch.delenv(k, raising=False)
+    assert utils.local_rank_env() is None
+    monkeypatch.setenv("LOCAL_RANK", "1")
+    assert utils.local_rank_env() is None
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "4")
+    assert utils.local_rank_env() == (1, 4)
+    got = {}
+    monkeypatch.setattr(os, "cpu_count", lambda: 16)
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(16)), raising=False)
+    monkeypatch.setattr(os, "sched_setaffinity", lambda pid, cpus: got.update(cpus=list(cpus)), raising=False)
+    assert utils.pin_rank_cpus(1, 4) == [4, 5, 6, 7] and got["cpus"] == [4, 5, 6, 7]
+    assert utils.pin_rank_cpus(4, 4) is None                       # a rank outside its local world
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(4, 8)), raising=False)
+    got.clear()
+    assert utils.pin_rank_cpus(1, 4) is None and not got           # already bound to 4 of 16 CPUs: left alone
+    monkeypatch.setenv("RPCC_FORCE_AFFINITY", "1")
+    assert utils.pin_rank_cpus(1, 4) == [5]
