@@ -25,7 +25,7 @@ import torch  # first: the library binds to the HIP runtime torch has loaded
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _l = C.CDLL(os.environ.get("RPCC_HIP_LIB", os.path.join(_HERE, "..", "r-pcc_amd", "lib", "librpcc_hip.so")))
-RPCC_ABI_VERSION = 102      # include/rpcc_hip.h: the structs carry no size field, so a binding checks the library's version before anything else
+RPCC_ABI_VERSION = 103      # include/rpcc_hip.h: the structs carry no size field, so a binding checks the library's version before anything else
 if _l.rpcc_version() != RPCC_ABI_VERSION:
     raise ImportError("librpcc_hip.so reports interface version %d, this binding was written for %d" % (_l.rpcc_version(), RPCC_ABI_VERSION))
 _l.rpcc_last_error.restype = C.c_char_p

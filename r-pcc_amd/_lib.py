@@ -39,7 +39,7 @@ FPS_BRUTEFORCE = 1     # RPCC_FPS_BRUTEFORCE
 FPS_FMA1, FPS_FMA2, FPS_TIE_CUDA = 2, 4, 8   # RPCC_FPS_FMA1 / RPCC_FPS_FMA2 / RPCC_FPS_TIE_CUDA
 MAX_CLUSTERS = 254     # RPCC_MAX_CLUSTERS: labels 0 .. cluster_num + 1 are stored as uint8 on the device
 MAX_CLUSTERS_WIDE = 65533   # RPCC_MAX_CLUSTERS_WIDE: the uint16-label entries (rpcc_*_wide)
-ABI_VERSION = 102      # RPCC_ABI_VERSION: the layout of rpcc_batch_io / rpcc_geom this binding was written for
+ABI_VERSION = 103      # RPCC_ABI_VERSION: the layout of rpcc_batch_io / rpcc_geom this binding was written for
 
 
 def fps_mode_flags(fma=0, cuda_tie=False):
@@ -67,6 +67,7 @@ _SIGS = {
     "rpcc_project_fastpath_check": (C.c_int, [_VP, _I64, Geom, _VP, _VP]),
     "rpcc_project": (C.c_int, [_VP, _VP, _I64, _I, Geom, _VP, _VP, C.c_size_t, _VP]),
     "rpcc_project_strided": (C.c_int, [_VP, _I, _VP, _I64, _I, Geom, _VP, _VP, C.c_size_t, _VP]),
+    "rpcc_project_ordered": (C.c_int, [_VP, _I, _VP, _I64, _I, Geom, _VP, _VP, C.c_size_t, _I, _VP, _VP]),
     "rpcc_ground_ransac": (C.c_int, [_VP, _VP, _I, _I, C.c_uint32, _VP, _VP, _VP, _VP]),
     "rpcc_ground_mask": (C.c_int, [_VP, _VP, _VP, _D, _I, _I, _I, _VP, _VP, _VP, _VP]),
     "rpcc_fps_table_bytes": (C.c_size_t, [_I, _I, _I]),

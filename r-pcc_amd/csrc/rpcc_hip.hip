@@ -162,6 +162,28 @@ struct FpsTimer {
     }
 };
 
+// a / d for 32-bit unsigned a and a divisor d >= 2 that is the same for a whole frame: multiply-high by a 33-bit reciprocal
+// prepared once (the "branch-free" form of invariant division: q = mulhi(a, magic); ((a - q) >> 1) + q) >> shift; exact for
+// every a < 2^32) -- five VALU instructions instead of the ~20 of a hardware-assisted 32-bit division per use.
+struct UDiv32 { uint32_t magic, shift; };
+__device__ __forceinline__ UDiv32 udiv32_make(uint32_t d) {
+    UDiv32 u;
+    const uint32_t L = 31u - (uint32_t)__builtin_clz(d);
+    if ((d & (d - 1u)) == 0u) { u.magic = 0u; u.shift = L - 1u; return u; }
+    const unsigned long long num = (1ull << L) << 32;
+    uint32_t m = (uint32_t)(num / d);
+    const uint32_t rem = (uint32_t)(num - (unsigned long long)m * d);
+    m += m;
+    const uint32_t tw = rem + rem;
+    if (tw >= d || tw < rem) m += 1u;
+    u.magic = 1u + m; u.shift = L;
+    return u;
+}
+__device__ __forceinline__ uint32_t udiv32(uint32_t a, const UDiv32 u) {
+    const uint32_t q = __umulhi(a, u.magic);
+    return (((a - q) >> 1) + q) >> u.shift;
+}
+
 // ================================================================================================
 // a2  spherical projection  (cpp_modules.cpp:427-467)
 // ================================================================================================
@@ -344,7 +366,7 @@ __device__ __forceinline__ float sqrt_rn_normal(float s) {
 
 // -> true when pix is certainly the reference's pixel
 __device__ __forceinline__ bool project_point_fast(float x, float y, float z, const rpcc_geom g, const PixFastCfg c, int &pix,
-                                                   float *colf_out = nullptr, float *rowf_out = nullptr) {
+                                                   float *colf_out = nullptr, float *rowf_out = nullptr, int *row_out = nullptr, int *col_out = nullptr) {
     const float ax = fabsf(x), ay = fabsf(y), az = fabsf(z);
     // max / min of non-negative floats as unsigned integers (one instruction each; fmaxf / fminf on the loaded values would be
     // preceded by a canonicalising v_max x, x).  A NaN orders above everything: mx is then NaN and `ok` false.
@@ -368,6 +390,7 @@ __device__ __forceinline__ bool project_point_fast(float x, float y, float z, co
     ok = ok && fabsf(rowf - r0) < c.crow;
     pix = (int)r0 * g.W + (int)c0;
     if (colf_out) { *colf_out = colf; *rowf_out = (e - c.vmin) * c.krow; }
+    if (row_out) { *row_out = (int)r0; *col_out = (int)c0; }
     return ok;
 }
 
@@ -498,7 +521,8 @@ template <int PS>   // floats per point: 3 (packed xyz) or 4 (x, y, z, intensity
 __global__ __launch_bounds__(PIX_THREADS) PIX_VGPR_ATTR void project_pix_kernel(const float *__restrict__ xyz, const int64_t *__restrict__ offs,
                                                                   int64_t total, int64_t base, int B, rpcc_geom g, PixFastCfg cfg,
                                                                   BandBins bb, int32_t *__restrict__ flags,
-                                                                  const int32_t *__restrict__ epoch, BatchInit init) {
+                                                                  const int32_t *__restrict__ epoch, BatchInit init,
+                                                                  const int32_t *__restrict__ accept) {
     __shared__ uint32_t queue[(PIX_PPT + 1) * PIX_THREADS];   // launch-relative point indices (launch_project: total < 2^32)
     __shared__ uint32_t qn;
     __shared__ uint32_t bcnt[PIX_MAX_BANDS];   // records per band of the chunk so far
@@ -521,6 +545,7 @@ __global__ __launch_bounds__(PIX_THREADS) PIX_VGPR_ATTR void project_pix_kernel(
         const int64_t o0 = offs[f] - base, o1 = offs[f + 1] - base;
         first = o0 + ((k - ((o0 >> PIX_CH_SHIFT) + f)) << PIX_CH_SHIFT);
         room = min((int64_t)(PIX_PPT * PIX_THREADS), o1 - first);
+        if (accept && accept[f]) room = 0;   // the frame was projected by project_ordered_kernel (the band kernel skips it too)
     };
     int fnext = 0;
     int64_t il_next = 0, room_next = 0;
@@ -656,7 +681,7 @@ __global__ __launch_bounds__(BAND_THREADS) BAND_VGPR_ATTR void project_band_kern
                                                                     const float *__restrict__ tz, float zthr, int rs_chunk,
                                                                     int32_t *__restrict__ zcnt, const int32_t *__restrict__ epoch,
                                                                     int band_wgs, const float *__restrict__ xyz, rpcc_geom g,
-                                                                    int32_t *__restrict__ lastz, int ps) {
+                                                                    int32_t *__restrict__ lastz, int ps, const int32_t *__restrict__ accept) {
     extern __shared__ __attribute__((aligned(16))) uint32_t band[];  // [BAND_PX]
     __shared__ uint16_t ldq[BAND_ROUND * 16];   // queued loads: share of the round << 2 | 64-pair step
     __shared__ uint16_t cntl[BAND_ROUND];          // records per share
@@ -682,6 +707,7 @@ __global__ __launch_bounds__(BAND_THREADS) BAND_VGPR_ATTR void project_band_kern
     for (int slot = blockIdx.x >> 3;; slot += slots) {
     const int b = xcd + 8 * (slot / nbands), kband = slot % nbands;
     if (b >= B) break;
+    if (accept && accept[b]) continue;   // (workgroup-uniform) image, candidate counts and bytes are project_ordered_kernel's
     const int flagged = flags[b] == mark;
     const int64_t o0 = offs[b] - base, o1 = offs[b + 1] - base;
     const int bin = (int)(((uint32_t)kband * BAND_PX) >> BIN_SHIFT);   // the record bin this band lies in
@@ -888,6 +914,8 @@ __device__ void project_fixup_frame(const float *__restrict__ xyz, const int64_t
         if (__hip_atomic_load(&img[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == RI_EMPTY) img[p] = 0u;
 }
 
+#include "project_ordered.h"
+
 static inline int band_bins_even(int P) { return (((P + BIN_PX - 1) / BIN_PX) + 1) & ~1; }   // record bins per frame, rounded up to even
 static inline int64_t pix_chunk_ids(int64_t total, int B) { return ((total > 0 ? total : 0) >> PIX_CH_SHIFT) + B; }
 static inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
@@ -912,9 +940,14 @@ extern "C" int rpcc_project_fastpath_check(const float *xyz, int64_t total, rpcc
 
 // On return ri is final (0 = empty pixel).  scratch_bytes < rpcc_project_scratch_bytes() selects the
 // atomic path, which only needs B*(P+8)*4 bytes.
+// order_mode: ORD_MODE_PROBE (a frame whose points come in scanner order is projected by project_ordered_kernel, the others by the
+// pixel + band kernels), ORD_MODE_FORCE (test hook: every frame by the former), ORD_MODE_OFF (no probe launch).  tm: the [P,3] ray table
+// (needed by the ordered kernel when zcnt is wanted).  accept_out: dev i32 [B] or nullptr -- which frames the ordered kernel took.
+#define ORD_MODE_OFF 2
 static int launch_project(const float *xyz, const int64_t *offsets, int64_t total, int64_t base, int B, rpcc_geom g,
                           float *ri, void *scratch, size_t scratch_bytes, hipStream_t st, const float *tz_plane = nullptr,
-                          int32_t *zcnt = nullptr, const BatchInit *init = nullptr, const int32_t *epoch = nullptr, int ps = 3) {
+                          int32_t *zcnt = nullptr, const BatchInit *init = nullptr, const int32_t *epoch = nullptr, int ps = 3,
+                          int order_mode = ORD_MODE_OFF, const float *tm = nullptr, int32_t *accept_out = nullptr) {
     const bool cleared = init != nullptr;   // fused batch: the pixel kernel initialises, flags are marked by epoch
     const int P = g.H * g.W;
     uint32_t *rb = reinterpret_cast<uint32_t *>(ri);
@@ -938,21 +971,44 @@ static int launch_project(const float *xyz, const int64_t *offsets, int64_t tota
         BatchInit bi;
         memset(&bi, 0, sizeof(bi));
         if (init) bi = *init;
+        if (zcnt && !cleared) HIP_TRY(hipMemsetAsync(zcnt, 0, (size_t)B * (RS_CHUNKS + 1) * 4, st));
+        // Sweeps in scanner order: one workgroup per frame probes the order of its points and, if they move through the image ring by
+        // ring, projects the frame without records (project_ordered.h); accept[b] tells the two kernels below to leave that frame alone.
+        int32_t *accept = nullptr;
+        const bool want_z = tz_plane != nullptr && zcnt != nullptr;
+        if (order_mode != ORD_MODE_OFF && total > 0 && ordered_geometry_ok(g) && ((uintptr_t)ri & 15u) == 0 &&
+            (!want_z || (tm != nullptr && ((uintptr_t)tm & 15u) == 0))) {
+            accept = accept_out ? accept_out : flags + (B + 1);   // (the flag area has 8 B words)
+            OrdArgs oa;
+            oa.xyz = xyz; oa.offs = offsets; oa.base = base; oa.B = B; oa.g = g; oa.cfg = pix_fast_cfg(g); oa.ri = rb; oa.flags = flags; oa.epoch = epoch;
+            oa.accept = accept; oa.mode = order_mode; oa.tm = tm; oa.zthr = -1.5f; oa.rs_chunk = rs_chunk_px(P); oa.zcnt = want_z ? zcnt : nullptr;
+            if (ps == 4) {
+                HIP_TRY(ensure_dyn_lds(reinterpret_cast<const void *>(&project_ordered_kernel<4>), ORD_WIN_PX * 4));
+                project_ordered_kernel<4><<<B, ORD_THREADS, ORD_WIN_PX * 4, st>>>(oa);
+            } else {
+                HIP_TRY(ensure_dyn_lds(reinterpret_cast<const void *>(&project_ordered_kernel<3>), ORD_WIN_PX * 4));
+                project_ordered_kernel<3><<<B, ORD_THREADS, ORD_WIN_PX * 4, st>>>(oa);
+            }
+            LAUNCH_CHECK();
+            if (want_z) bi.z0.n = 0;   // (every frame's candidate counts were cleared -- and maybe filled -- by its workgroup above)
+        } else if (accept_out) {
+            HIP_TRY(hipMemsetAsync(accept_out, 0, (size_t)B * 4, st));
+        }
         // (also for a batch without points: every chunk id's share counts are written by this kernel, the band kernel reads them)
         const unsigned pix_wgs = (unsigned)std::max<int64_t>(std::min<int64_t>(pix_chunk_ids(total, B), 256 * PIX_WG_PER_CU), 1);
-        if (ps == 4) project_pix_kernel<4><<<pix_wgs, PIX_THREADS, 0, st>>>(xyz, offsets, total, base, B, g, pix_fast_cfg(g), bb, flags, epoch, bi);
-        else project_pix_kernel<3><<<pix_wgs, PIX_THREADS, 0, st>>>(xyz, offsets, total, base, B, g, pix_fast_cfg(g), bb, flags, epoch, bi);
+        if (ps == 4) project_pix_kernel<4><<<pix_wgs, PIX_THREADS, 0, st>>>(xyz, offsets, total, base, B, g, pix_fast_cfg(g), bb, flags, epoch, bi, accept);
+        else project_pix_kernel<3><<<pix_wgs, PIX_THREADS, 0, st>>>(xyz, offsets, total, base, B, g, pix_fast_cfg(g), bb, flags, epoch, bi, accept);
         HIP_TRY(ensure_dyn_lds(reinterpret_cast<const void *>(&project_band_kernel), BAND_PX * 4));
-        if (zcnt && !cleared) HIP_TRY(hipMemsetAsync(zcnt, 0, (size_t)B * (RS_CHUNKS + 1) * 4, st));
         // persistent: at most one workgroup per CU (8 XCDs x 32), each walking over its XCD's (frame, band) items
         const int nbands = (P + BAND_PX - 1) / BAND_PX;
         const int band_wgs = 8 * std::min(((B + 7) / 8) * nbands, std::max(BAND_WG_PER_XCD / nbands, 1) * nbands);
         // + B workgroups for the exact input-order semantics of frames with depth-0 points (a no-op otherwise)
         project_band_kernel<<<band_wgs + (total > 0 ? B : 0), BAND_THREADS, BAND_PX * 4, st>>>(
-            bb, offsets, base, B, P, rb, flags, tz_plane, -1.5f, rs_chunk_px(P), tz_plane ? zcnt : nullptr, epoch, band_wgs, xyz, g, lastz, ps);
+            bb, offsets, base, B, P, rb, flags, tz_plane, -1.5f, rs_chunk_px(P), tz_plane ? zcnt : nullptr, epoch, band_wgs, xyz, g, lastz, ps, accept);
         LAUNCH_CHECK();
         return RPCC_OK;
     }
+    if (accept_out) HIP_TRY(hipMemsetAsync(accept_out, 0, (size_t)B * 4, st));
     if (zcnt && !cleared) HIP_TRY(hipMemsetAsync(zcnt, 0, (size_t)B * (RS_CHUNKS + 1) * 4, st));
     if (init && init->on) batch_init_kernel<<<256, 256, 0, st>>>(*init);   // (clears zcnt: the RANSAC kernel counts for itself)
     project_fill_kernel<false><<<fg, 256, 0, st>>>(rb, lastz, flags, P);
@@ -972,16 +1028,26 @@ static int launch_project(const float *xyz, const int64_t *offsets, int64_t tota
 // point_stride_bytes -> floats per point (0 = 12); only packed xyz (12) and the stored (x, y, z, intensity) rows (16) exist
 static inline int point_floats(int point_stride_bytes) { return point_stride_bytes == 0 || point_stride_bytes == 12 ? 3 : point_stride_bytes == 16 ? 4 : -1; }
 
-extern "C" int rpcc_project_strided(const float *points, int point_stride_bytes, const int64_t *offsets, int64_t total, int B,
-                                    rpcc_geom g, float *ri, void *scratch, size_t scratch_bytes, void *stream) {
+// flags of rpcc_batch_io / order argument of rpcc_project_ordered -> launch_project's order_mode
+static inline int order_mode_of(int flags) {
+    return (flags & RPCC_PROJECT_FORCE_ORDERED) ? ORD_MODE_FORCE : (flags & RPCC_PROJECT_NO_ORDER_PROBE) ? ORD_MODE_OFF : ORD_MODE_PROBE;
+}
+extern "C" int rpcc_project_ordered(const float *points, int point_stride_bytes, const int64_t *offsets, int64_t total, int B,
+                                    rpcc_geom g, float *ri, void *scratch, size_t scratch_bytes, int order_flags, int32_t *accepted,
+                                    void *stream) {
     ARG_TRY(B > 0 && B <= RPCC_MAX_BATCH && g.H > 1 && g.W > 0 && total >= 0);
     ARG_TRY(ri != nullptr && scratch != nullptr && offsets != nullptr);
     ARG_TRY(total == 0 || points != nullptr);
     ARG_TRY(point_floats(point_stride_bytes) > 0);
     ARG_TRY(point_stride_bytes != 16 || (reinterpret_cast<uintptr_t>(points) & 15u) == 0);   // rows are read with 16-byte loads
     ARG_TRY(scratch_bytes >= ((size_t)B * ((size_t)g.H * g.W + 8)) * 4);
+    ARG_TRY((order_flags & ~(RPCC_PROJECT_NO_ORDER_PROBE | RPCC_PROJECT_FORCE_ORDERED)) == 0);
     return launch_project(points, offsets, total, 0, B, g, ri, scratch, scratch_bytes, (hipStream_t)stream, nullptr, nullptr, nullptr, nullptr,
-                          point_floats(point_stride_bytes));
+                          point_floats(point_stride_bytes), order_mode_of(order_flags), nullptr, accepted);
+}
+extern "C" int rpcc_project_strided(const float *points, int point_stride_bytes, const int64_t *offsets, int64_t total, int B,
+                                    rpcc_geom g, float *ri, void *scratch, size_t scratch_bytes, void *stream) {
+    return rpcc_project_ordered(points, point_stride_bytes, offsets, total, B, g, ri, scratch, scratch_bytes, 0, nullptr, stream);
 }
 extern "C" int rpcc_project(const float *xyz, const int64_t *offsets, int64_t total, int B, rpcc_geom g, float *ri,
                             void *scratch, size_t scratch_bytes, void *stream) {
@@ -1330,28 +1396,6 @@ __device__ int ransac_plane_wg(const PTS &pts, int iters, double thr, uint32_t s
     double pl[4];
     if (plane_from_moments(c, m[0], m[1], m[2], m[3], m[4], m[5], pl)) { plane[0] = pl[0]; plane[1] = pl[1]; plane[2] = pl[2]; plane[3] = pl[3]; }
     return wcnt;
-}
-
-// a / d for 32-bit unsigned a and a divisor d >= 2 that is the same for a whole frame: multiply-high by a 33-bit reciprocal
-// prepared once (the "branch-free" form of invariant division: q = mulhi(a, magic); ((a - q) >> 1) + q) >> shift; exact for
-// every a < 2^32) -- five VALU instructions instead of the ~20 of a hardware-assisted 32-bit division per use.
-struct UDiv32 { uint32_t magic, shift; };
-__device__ __forceinline__ UDiv32 udiv32_make(uint32_t d) {
-    UDiv32 u;
-    const uint32_t L = 31u - (uint32_t)__builtin_clz(d);
-    if ((d & (d - 1u)) == 0u) { u.magic = 0u; u.shift = L - 1u; return u; }
-    const unsigned long long num = (1ull << L) << 32;
-    uint32_t m = (uint32_t)(num / d);
-    const uint32_t rem = (uint32_t)(num - (unsigned long long)m * d);
-    m += m;
-    const uint32_t tw = rem + rem;
-    if (tw >= d || tw < rem) m += 1u;
-    u.magic = 1u + m; u.shift = L;
-    return u;
-}
-__device__ __forceinline__ uint32_t udiv32(uint32_t a, const UDiv32 u) {
-    const uint32_t q = __umulhi(a, u.magic);
-    return (((a - q) >> 1) + q) >> u.shift;
 }
 
 #define RS_CU 16  // pixels per lane in flight during the compaction pass
@@ -3291,7 +3335,7 @@ static int run_stage(const BatchPlan &p, int stage, hipStream_t st) {
     switch (stage) {
     case ST_PROJECT:
         return launch_project(io->xyz, io->offsets, p.npts, 0, Bs, p.g, io->ri, p.proj_scratch, p.proj_bytes, st,
-                              p.rays_soa + 2 * (int64_t)P, p.zcnt, &p.bi, p.epoch, point_floats(io->point_stride_bytes));
+                              p.rays_soa + 2 * (int64_t)P, p.zcnt, &p.bi, p.epoch, point_floats(io->point_stride_bytes), order_mode_of(io->flags), io->tm);
     case ST_GROUND:
         if (!p.fit_ground) return RPCC_OK;
         return launch_ground_ransac(io->ri, io->tm, Bs, P, (uint32_t)io->ground_seed, false, io->ground, nullptr, st, p.zcnt, io->frame_ids);
@@ -3621,7 +3665,7 @@ extern "C" int rpcc_compress_batch_wide(const rpcc_batch_io *io, int B, rpcc_geo
     uint16_t *seg = reinterpret_cast<uint16_t *>(io->seg);
     int rc;
     if ((rc = launch_project(io->xyz, io->offsets, io->total, 0, B, g, io->ri, w.proj, w.proj_bytes, st, nullptr, nullptr, nullptr, nullptr,
-                             point_floats(io->point_stride_bytes)))) return rc;
+                             point_floats(io->point_stride_bytes), order_mode_of(io->flags), io->tm))) return rc;
     if (io->ground_seed >= 0 && (rc = launch_ground_ransac(io->ri, io->tm, B, P, (uint32_t)io->ground_seed, false, io->ground, nullptr, st, nullptr, io->frame_ids))) return rc;
     const bool brute = (io->flags & RPCC_FPS_BRUTEFORCE) != 0;
     if ((rc = launch_ground_mask(io->ri, io->tm, io->ground, ground_threshold, B, g.H, g.W, w.temp, io->info, brute ? nullptr : w.tiletab, st, false))) return rc;

@@ -49,11 +49,16 @@ def _point_stride(xyz):
     return 4 * int(xyz.shape[1])
 
 
-def project(xyz, offsets, geom, ri=None, scratch=None, atomic_path=False):
+PROJECT_NO_ORDER_PROBE, PROJECT_FORCE_ORDERED = 16, 32    # include/rpcc_hip.h: RPCC_PROJECT_*
+
+
+def project(xyz, offsets, geom, ri=None, scratch=None, atomic_path=False, order_flags=0, accepted=None):
     """a2 batched.  xyz f32 [total,3] -- or the stored rows f32 [total,4] (x, y, z, intensity), read with a 16-byte stride --,
     offsets i64 [B+1] (device) -> ri f32 [B,H,W].
     atomic_path=True gives the library only the small scratch, which selects the device-atomic kernels
-    (same result as the default LDS-band kernels)."""
+    (same result as the default LDS-band kernels).  order_flags: 0 (a frame whose points come in scanner order takes the record-free
+    window kernel, chosen by a probe), PROJECT_NO_ORDER_PROBE, PROJECT_FORCE_ORDERED (rpcc_project_ordered); accepted: i32 [B] tensor
+    that receives which frames the window kernel took."""
     B = offsets.numel() - 1
     P = geom.H * geom.W
     xyz = xyz.contiguous()
@@ -62,8 +67,9 @@ def project(xyz, offsets, geom, ri=None, scratch=None, atomic_path=False):
     if scratch is None:
         n = B * (P + 8) * 4 if atomic_path else _lib.lib().rpcc_project_scratch_bytes(xyz.shape[0], B, P)
         scratch = torch.empty(n, dtype=torch.uint8, device=_dev(offsets))
-    check(_lib.lib().rpcc_project_strided(ptr(xyz) if xyz.numel() else None, _point_stride(xyz), ptr(offsets), xyz.shape[0], B, geom,
-                                          ptr(ri), ptr(scratch), scratch.numel() * scratch.element_size(), stream()))
+    check(_lib.lib().rpcc_project_ordered(ptr(xyz) if xyz.numel() else None, _point_stride(xyz), ptr(offsets), xyz.shape[0], B, geom,
+                                          ptr(ri), ptr(scratch), scratch.numel() * scratch.element_size(), int(order_flags),
+                                          ptr(accepted) if accepted is not None else None, stream()))
     return ri
 
 
@@ -406,7 +412,7 @@ def nonuniform_cfg(acc, cfg=None):
 
 def compress_batch(xyz, offsets, tm, ground, buf, ground_threshold=0.1, acc=0.04, ground_seed=-1, frame_ids=None,
                    fps_bruteforce=False, timer=None, model_method="point", angle_threshold=75, plane_seed=0, nonuniform=None,
-                   fps_fma=None, fps_cuda_tie=None):
+                   fps_fma=None, fps_cuda_tie=None, project_flags=0):
     """Fused a2..a13 for a batch, one call: FPS segmentation, point or plane model, uniform or non-uniform framework
     (tools/compress.py:93-125).  xyz: f32 [total,3], or the stored (x, y, z, intensity) rows f32 [total,4] (16-byte stride,
     no host-side slice).  ground f64 [B,4]: injected models when ground_seed < 0, otherwise output of the seeded
@@ -415,9 +421,11 @@ def compress_batch(xyz, offsets, tm, ground, buf, ground_threshold=0.1, acc=0.04
     (plane_seed, frame_ids) with the reference's angle validation.  nonuniform: a nonuniform_cfg() struct -> key points,
     salience levels (buf.salience) and per-label steps; None = uniform framework with step `acc`.
     fps_fma / fps_cuda_tie: the CUDA-binary FPS modes (_lib.fps_mode_flags); None = the environment variables RPCC_FPS_FMA
-    (0 / 1 / 2) and RPCC_FPS_TIE_CUDA, so every front-end (tools, pipeline, loader) honours them."""
+    (0 / 1 / 2) and RPCC_FPS_TIE_CUDA, so every front-end (tools, pipeline, loader) honours them.
+    project_flags: 0 (frames in scanner order take the record-free projection kernel, chosen by a probe), PROJECT_NO_ORDER_PROBE,
+    PROJECT_FORCE_ORDERED (see project())."""
     io = _batch_io(xyz, offsets, tm, ground, buf, ground_seed, frame_ids, fps_bruteforce, timer, model_method, angle_threshold, plane_seed,
-                   nonuniform, fps_fma, fps_cuda_tie)
+                   nonuniform, fps_fma, fps_cuda_tie, project_flags)
     entry = _lib.lib().rpcc_compress_batch_wide if buf.wide else _lib.lib().rpcc_compress_batch   # (cluster_num > 254: uint16 labels)
     check(entry(C.byref(io), buf.B, buf.geom, buf.M, float(ground_threshold), float(acc), ptr(buf.ws), stream()))
     return buf
@@ -436,7 +444,7 @@ def compress_batch_stages(stage_mask, xyz, offsets, tm, ground, buf, ground_thre
 
 
 def _batch_io(xyz, offsets, tm, ground, buf, ground_seed=-1, frame_ids=None, fps_bruteforce=False, timer=None, model_method="point",
-              angle_threshold=75, plane_seed=0, nonuniform=None, fps_fma=None, fps_cuda_tie=None):
+              angle_threshold=75, plane_seed=0, nonuniform=None, fps_fma=None, fps_cuda_tie=None, project_flags=0):
     """The rpcc_batch_io of one geometry group (compress_batch's arguments); grows the group's workspace when the batch holds more points."""
     general = model_method != "point" or nonuniform is not None
     assert not general or buf.general, "BatchBuffers(..., general=True) is needed for the plane model / non-uniform framework"
@@ -450,7 +458,7 @@ def _batch_io(xyz, offsets, tm, ground, buf, ground_seed=-1, frame_ids=None, fps
                    int(ground_seed), ptr(fid).value if fid is not None else None, ptr(buf.ri).value, ptr(buf.seg).value,
                    ptr(buf.cen_pix).value, ptr(buf.centers).value, ptr(buf.model).value, ptr(buf.counts).value,
                    ptr(buf.q16).value, ptr(buf.nnz).value, ptr(buf.info).value,
-                   (_lib.FPS_BRUTEFORCE if fps_bruteforce else 0) | _lib.fps_mode_flags(fps_fma, fps_cuda_tie),
+                   (_lib.FPS_BRUTEFORCE if fps_bruteforce else 0) | _lib.fps_mode_flags(fps_fma, fps_cuda_tie) | int(project_flags),
                    timer.h if timer is not None else None,
                    0 if model_method == "point" else 1, angle_cos_cut(angle_threshold) if model_method != "point" else 0.0,
                    int(plane_seed), C.addressof(nonuniform) if nonuniform is not None else None,
