@@ -116,7 +116,6 @@ __global__ __launch_bounds__(ORD_THREADS) void project_ordered_kernel(const OrdA
         rmax = (int)dpp_max_u32((uint32_t)(rmax + 1)) - 1;
         if (lane == 0) { S.pmin[wave] = rmin; S.pmax[wave] = rmax; }
     }
-    __threadfence();
     __syncthreads();
     if (tid == 0 && sized) {
         int tv = 0, prev = -1, first = -1, spanmax = 0, seen = 0;
@@ -233,7 +232,9 @@ __global__ __launch_bounds__(ORD_THREADS) void project_ordered_kernel(const OrdA
         }
     };
     load_chunk(0u);
+    TRACE_ORD_DECLS();
     for (uint32_t c = 0; c < nchunks; c++) {
+        TRACE_ORD_PHASE(0);
         const uint32_t il0 = c * (uint32_t)ORD_CHUNK;
         const uint32_t room = min((uint32_t)ORD_CHUNK, n - il0);
         int lo = __builtin_amdgcn_readfirstlane(S.lo);
@@ -263,12 +264,15 @@ __global__ __launch_bounds__(ORD_THREADS) void project_ordered_kernel(const OrdA
                 if (slow) S.queue[q0 + __popcll(sm & lt)] = (uint16_t)ci;
             }
         }
+        TRACE_ORD_PHASE(1);
         if (c + 1u < nchunks) load_chunk(c + 1u);   // in flight while this chunk is resolved
 #pragma unroll
         for (int u = 0; u < ORD_PPT; u++) {
             ord_note_pending(ppix[u] != ORD_NONE, (int)(ppix[u] >> 24), S);
         }
+        TRACE_ORD_PHASE(2);
         __syncthreads();
+        TRACE_ORD_PHASE(3);
         const uint32_t nq = S.qn;
         uint32_t qpos = 0u;
         do {
@@ -296,7 +300,9 @@ __global__ __launch_bounds__(ORD_THREADS) void project_ordered_kernel(const OrdA
                 ord_note_pending(epix != ORD_NONE, (int)(epix >> 24), S);
             }
             qpos += ORD_THREADS;
+            TRACE_ORD_PHASE(4);
             __syncthreads();
+            TRACE_ORD_PHASE(5);
             // move the window until nothing is pending
             while (S.npend != 0u) {   // (workgroup-uniform: read between barriers)
                 if (tid <= H - WR) {
@@ -305,6 +311,7 @@ __global__ __launch_bounds__(ORD_THREADS) void project_ordered_kernel(const OrdA
                     const uint32_t dist = (uint32_t)abs(tid - lo);
                     atomicMax(&S.best, (cover << 16) | ((255u - dist) << 8) | (uint32_t)tid);   // most pending points, then the shortest move
                 }
+                TRACE_ORD_COUNT(14);
                 __syncthreads();
                 const int nlo = (int)(S.best & 255u);
                 // (cover > 0 for the best position, and no pending point lies in the current window: nlo != lo)
@@ -346,13 +353,16 @@ __global__ __launch_bounds__(ORD_THREADS) void project_ordered_kernel(const OrdA
                 }
                 __syncthreads();
             }
+            TRACE_ORD_PHASE(6);
         } while (qpos < nq);
+        TRACE_ORD_COUNT(15);
         if (tid == 0) S.qn = 0u;
         // (the next chunk's queue pushes come after its compute phase started; a barrier lies between: the one at the top of the drain
         // loop of THIS chunk was the last read of qn)
         __syncthreads();
     }
     // ---- the rows still in the window, then the rows no point ever asked for ----
+    TRACE_ORD_PHASE(7);
     const int lo_end = __builtin_amdgcn_readfirstlane(S.lo);
     move_rows(lo_end, 0, -1);
     __syncthreads();
@@ -365,6 +375,8 @@ __global__ __launch_bounds__(ORD_THREADS) void project_ordered_kernel(const OrdA
             if (want_bytes) zm[lp >> 2] = 0;
         }
     }
+    TRACE_ORD_PHASE(8);
+    TRACE_ORD_END();
     if (want_cnt) {
         if (tid < RS_CHUNKS) A.zcnt[b * (RS_CHUNKS + 1) + tid] = S.zc[tid];
         // (a frame with a depth-0 point is projected again by the fix-up workgroup and counts for itself)

@@ -58,6 +58,10 @@ extern "C" int rpcc_debug_stamps(void *dev_i64_buffer) {
 #define TRACE_FPS_VISIT(k_) do { } while (0)
 #define TRACE_FPS_TILES(vm_, j_) do { } while (0)
 #define TRACE_FPS_WG(end_) do { } while (0)
+#define TRACE_ORD_DECLS() do { } while (0)
+#define TRACE_ORD_PHASE(i_) do { } while (0)
+#define TRACE_ORD_COUNT(i_) do { } while (0)
+#define TRACE_ORD_END() do { } while (0)
 #endif
 
 // Kernel attributes (dynamic LDS size) are set once per (device, kernel), not per launch.
@@ -530,6 +534,11 @@ __global__ __launch_bounds__(PIX_THREADS) PIX_VGPR_ATTR void project_pix_kernel(
     if (threadIdx.x < PIX_MAX_BANDS) bcnt[threadIdx.x] = 0u;
     const int mark = flag_mark(epoch);
     if (init.on) batch_init(init, gridDim.x * PIX_THREADS, blockIdx.x * PIX_THREADS + threadIdx.x);   // (nothing of it is read by this launch)
+    if (accept) {   // every frame taken by project_ordered_kernel (a batch of stored sweeps): nothing to walk
+        int rej = 0;
+        for (int i = threadIdx.x; i < B; i += PIX_THREADS) rej |= accept[i] == 0;
+        if (!__syncthreads_or(rej)) return;
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -697,6 +706,11 @@ __global__ __launch_bounds__(BAND_THREADS) BAND_VGPR_ATTR void project_band_kern
     // XCD x serves the frames b = x (mod 8), and the list is fetched into that L2 once instead of nbands times.
     // The workgroups are persistent: workgroup (xcd, slot) takes the items slot, slot + slots, ... of its XCD (same band, the
     // next frames), so a 1024-thread / 128 KB workgroup is launched once per CU instead of once per item.
+    if (accept) {   // every frame taken by project_ordered_kernel: no band to build
+        int rej = 0;
+        for (int i = threadIdx.x; i < B; i += BAND_THREADS) rej |= accept[i] == 0;
+        if (!__syncthreads_or(rej)) return;
+    }
     const int nbands = (P + BAND_PX - 1) / BAND_PX;
     const int xcd = blockIdx.x & 7, slots = band_wgs >> 3;
     // the LDS band is cleared once; every item's write-out leaves it cleared for the next

@@ -45,3 +45,9 @@ extern "C" int rpcc_debug_stamps(void *dev_i64_buffer) {
             for (int i_ = 0; i_ < 4; i_++) g_dbg_stamps[3000 + (threadIdx.x >> 6) * 4 + i_] = tr_v[i_];                       \
         }                                                                                                                     \
     } while (0)
+
+// ---- project_ordered_kernel: cycles per phase of the chunk loop, summed over the chunks (thread 0 of block 0) -> stamps[900 + phase]; phase 15: chunks
+#define TRACE_ORD_DECLS() long long to_p[16] = {0}, to_last = (long long)__builtin_readcyclecounter()
+#define TRACE_ORD_PHASE(i_) do { const long long t_ = (long long)__builtin_readcyclecounter(); to_p[i_] += t_ - to_last; to_last = t_; } while (0)
+#define TRACE_ORD_COUNT(i_) do { to_p[i_] += 1; } while (0)
+#define TRACE_ORD_END() do { if (g_dbg_stamps != nullptr && blockIdx.x == 0 && threadIdx.x == 0) for (int i_ = 0; i_ < 16; i_++) g_dbg_stamps[900 + i_] = to_p[i_]; } while (0)
