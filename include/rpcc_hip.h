@@ -87,18 +87,19 @@ int rpcc_project(const float *xyz, const int64_t *offsets, int64_t total, int B,
  * 16-byte row per point (points 16-byte aligned); 12 (or 0) = packed xyz = rpcc_project.  offsets / total count POINTS. */
 int rpcc_project_strided(const float *points, int point_stride_bytes, const int64_t *offsets, int64_t total, int B,
                          rpcc_geom g, float *ri, void *scratch, size_t scratch_bytes, void *stream);
-/* Sweeps in SCANNER ORDER.  The reference's inputs are .bin files as the scanner wrote them (dataset/dataset.py:48-50): ring after ring, so
- * consecutive points fall into neighbouring rows of the range image.  Every projection entry of this library (rpcc_project, rpcc_project_strided,
- * the batch calls) first lets one workgroup per frame PROBE the order of the frame's points (16 runs of 64 points); a frame whose points move
- * through the image ring by ring is projected by one kernel that keeps a window of image rows in LDS and never writes a per-point record
- * (csrc/project_ordered.h), any other frame -- shuffled points, as the synthetic benchmark sweeps -- by the two record kernels.  Both give the
- * reference's image bit for bit for ANY order (the window kernel re-opens rows it has already written when a late point asks for one); the probe
- * only chooses the faster one.  order_flags / rpcc_batch_io.flags:
- *   RPCC_PROJECT_NO_ORDER_PROBE   no probe launch, every frame through the record kernels
+/* Sweeps in SCANNER ORDER (opt-in).  The reference's inputs are .bin files as the scanner wrote them (dataset/dataset.py:48-50): ring after ring, so
+ * consecutive points fall into neighbouring rows of the range image.  With RPCC_PROJECT_ORDER_PROBE one workgroup per frame first PROBES the order
+ * of the frame's points (16 runs of 64 points); a frame whose points move through the image ring by ring is projected by one kernel that keeps a
+ * window of image rows in LDS and never writes a per-point record (csrc/project_ordered.h), any other frame -- shuffled points, as the synthetic
+ * benchmark sweeps -- by the two record kernels.  Both give the reference's image bit for bit for ANY order (the window kernel re-opens rows it has
+ * already written when a late point asks for one); the probe only chooses.  Off by default: measured on MI355X the window kernel -- one
+ * 1024-thread workgroup per frame, 4 wavefronts per SIMD -- takes 290 us per 256 stored sweeps against 236 us of the two record kernels, and the
+ * probe launch costs the shuffled benchmark 1.3 % (profiles/HISTORY.md, round 6).  order_flags / rpcc_batch_io.flags:
+ *   RPCC_PROJECT_ORDER_PROBE      probe every frame's point order, window kernel for the frames that pass
  *   RPCC_PROJECT_FORCE_ORDERED    test hook: every frame with a point through the window kernel, whatever its order
  * rpcc_project_ordered = rpcc_project_strided with those flags and, in `accepted` (dev i32 [B], may be NULL), which frames the window kernel took.
  * Images the window kernel does not take (more than 128 rows, a width that is no multiple of four or above 16384) are never probed. */
-#define RPCC_PROJECT_NO_ORDER_PROBE 16
+#define RPCC_PROJECT_ORDER_PROBE 16
 #define RPCC_PROJECT_FORCE_ORDERED 32
 int rpcc_project_ordered(const float *points, int point_stride_bytes, const int64_t *offsets, int64_t total, int B,
                          rpcc_geom g, float *ri, void *scratch, size_t scratch_bytes, int order_flags, int32_t *accepted, void *stream);
@@ -316,7 +317,7 @@ typedef struct rpcc_batch_io {
     int16_t *q16;            /* dev i16 [B,P] out */
     int32_t *nnz;            /* dev i32 [B] out */
     int32_t *info;           /* dev i32 [B,8] out */
-    int32_t flags;           /* 0, RPCC_FPS_BRUTEFORCE, or the CUDA-binary FPS modes RPCC_FPS_FMA1 / _FMA2 / _TIE_CUDA; | RPCC_PROJECT_NO_ORDER_PROBE /
+    int32_t flags;           /* 0, RPCC_FPS_BRUTEFORCE, or the CUDA-binary FPS modes RPCC_FPS_FMA1 / _FMA2 / _TIE_CUDA; | RPCC_PROJECT_ORDER_PROBE /
                                 RPCC_PROJECT_FORCE_ORDERED (see rpcc_project_ordered) */
     void *timer;             /* rpcc_timer_create() handle or NULL: times this call's FPS launch (bench.py) */
     /* framework / model selection (tools/compress.py:109-124, cfgs/compressor.yaml: compress_framework, modeling_method) */

@@ -535,9 +535,9 @@ __global__ __launch_bounds__(PIX_THREADS) PIX_VGPR_ATTR void project_pix_kernel(
     const int mark = flag_mark(epoch);
     if (init.on) batch_init(init, gridDim.x * PIX_THREADS, blockIdx.x * PIX_THREADS + threadIdx.x);   // (nothing of it is read by this launch)
     if (accept) {   // every frame taken by project_ordered_kernel (a batch of stored sweeps): nothing to walk
-        int rej = 0;
-        for (int i = threadIdx.x; i < B; i += PIX_THREADS) rej |= accept[i] == 0;
-        if (!__syncthreads_or(rej)) return;
+        int rej = 0;    // (every wavefront looks at all B words and finds the same answer: no barrier, no LDS)
+        for (int i = threadIdx.x & 63; i < B; i += 64) rej |= accept[i] == 0;
+        if (__ballot(rej) == 0ull) return;
     }
     __syncthreads();
     const int lane = threadIdx.x & 63;
@@ -708,8 +708,8 @@ __global__ __launch_bounds__(BAND_THREADS) BAND_VGPR_ATTR void project_band_kern
     // next frames), so a 1024-thread / 128 KB workgroup is launched once per CU instead of once per item.
     if (accept) {   // every frame taken by project_ordered_kernel: no band to build
         int rej = 0;
-        for (int i = threadIdx.x; i < B; i += BAND_THREADS) rej |= accept[i] == 0;
-        if (!__syncthreads_or(rej)) return;
+        for (int i = threadIdx.x & 63; i < B; i += 64) rej |= accept[i] == 0;
+        if (__ballot(rej) == 0ull) return;
     }
     const int nbands = (P + BAND_PX - 1) / BAND_PX;
     const int xcd = blockIdx.x & 7, slots = band_wgs >> 3;
@@ -954,8 +954,8 @@ extern "C" int rpcc_project_fastpath_check(const float *xyz, int64_t total, rpcc
 
 // On return ri is final (0 = empty pixel).  scratch_bytes < rpcc_project_scratch_bytes() selects the
 // atomic path, which only needs B*(P+8)*4 bytes.
-// order_mode: ORD_MODE_PROBE (a frame whose points come in scanner order is projected by project_ordered_kernel, the others by the
-// pixel + band kernels), ORD_MODE_FORCE (test hook: every frame by the former), ORD_MODE_OFF (no probe launch).  tm: the [P,3] ray table
+// order_mode: ORD_MODE_OFF (the default: pixel + band kernels), ORD_MODE_PROBE (a frame whose points come in scanner order is projected by
+// project_ordered_kernel, the others by the pixel + band kernels), ORD_MODE_FORCE (test hook: every frame by the former).  tm: the [P,3] ray table
 // (needed by the ordered kernel when zcnt is wanted).  accept_out: dev i32 [B] or nullptr -- which frames the ordered kernel took.
 #define ORD_MODE_OFF 2
 static int launch_project(const float *xyz, const int64_t *offsets, int64_t total, int64_t base, int B, rpcc_geom g,
@@ -1044,7 +1044,7 @@ static inline int point_floats(int point_stride_bytes) { return point_stride_byt
 
 // flags of rpcc_batch_io / order argument of rpcc_project_ordered -> launch_project's order_mode
 static inline int order_mode_of(int flags) {
-    return (flags & RPCC_PROJECT_FORCE_ORDERED) ? ORD_MODE_FORCE : (flags & RPCC_PROJECT_NO_ORDER_PROBE) ? ORD_MODE_OFF : ORD_MODE_PROBE;
+    return (flags & RPCC_PROJECT_FORCE_ORDERED) ? ORD_MODE_FORCE : (flags & RPCC_PROJECT_ORDER_PROBE) ? ORD_MODE_PROBE : ORD_MODE_OFF;
 }
 extern "C" int rpcc_project_ordered(const float *points, int point_stride_bytes, const int64_t *offsets, int64_t total, int B,
                                     rpcc_geom g, float *ri, void *scratch, size_t scratch_bytes, int order_flags, int32_t *accepted,
@@ -1055,7 +1055,7 @@ extern "C" int rpcc_project_ordered(const float *points, int point_stride_bytes,
     ARG_TRY(point_floats(point_stride_bytes) > 0);
     ARG_TRY(point_stride_bytes != 16 || (reinterpret_cast<uintptr_t>(points) & 15u) == 0);   // rows are read with 16-byte loads
     ARG_TRY(scratch_bytes >= ((size_t)B * ((size_t)g.H * g.W + 8)) * 4);
-    ARG_TRY((order_flags & ~(RPCC_PROJECT_NO_ORDER_PROBE | RPCC_PROJECT_FORCE_ORDERED)) == 0);
+    ARG_TRY((order_flags & ~(RPCC_PROJECT_ORDER_PROBE | RPCC_PROJECT_FORCE_ORDERED)) == 0);
     return launch_project(points, offsets, total, 0, B, g, ri, scratch, scratch_bytes, (hipStream_t)stream, nullptr, nullptr, nullptr, nullptr,
                           point_floats(point_stride_bytes), order_mode_of(order_flags), nullptr, accepted);
 }

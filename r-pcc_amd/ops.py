@@ -6,6 +6,7 @@ librpcc_hip.so.  Every function enqueues on torch's current HIP stream and does 
 import ctypes as C
 import functools
 import math
+import os
 
 import numpy as np
 import torch
@@ -49,16 +50,23 @@ def _point_stride(xyz):
     return 4 * int(xyz.shape[1])
 
 
-PROJECT_NO_ORDER_PROBE, PROJECT_FORCE_ORDERED = 16, 32    # include/rpcc_hip.h: RPCC_PROJECT_*
+PROJECT_ORDER_PROBE, PROJECT_FORCE_ORDERED = 16, 32    # include/rpcc_hip.h: RPCC_PROJECT_*
+
+
+def _project_flags(flags):
+    """The caller's RPCC_PROJECT_* bits | the environment's (RPCC_PROJECT_FLAGS=16: probe the point order of every frame and project the frames in
+    scanner order without records, 32: every frame through that kernel -- like RPCC_FPS_FMA a process-wide switch that every front-end honours;
+    results do not depend on it)."""
+    return (int(flags) | int(os.environ.get("RPCC_PROJECT_FLAGS", "0") or 0)) & (PROJECT_ORDER_PROBE | PROJECT_FORCE_ORDERED)
 
 
 def project(xyz, offsets, geom, ri=None, scratch=None, atomic_path=False, order_flags=0, accepted=None):
     """a2 batched.  xyz f32 [total,3] -- or the stored rows f32 [total,4] (x, y, z, intensity), read with a 16-byte stride --,
     offsets i64 [B+1] (device) -> ri f32 [B,H,W].
     atomic_path=True gives the library only the small scratch, which selects the device-atomic kernels
-    (same result as the default LDS-band kernels).  order_flags: 0 (a frame whose points come in scanner order takes the record-free
-    window kernel, chosen by a probe), PROJECT_NO_ORDER_PROBE, PROJECT_FORCE_ORDERED (rpcc_project_ordered); accepted: i32 [B] tensor
-    that receives which frames the window kernel took."""
+    (same result as the default LDS-band kernels).  order_flags: 0, PROJECT_ORDER_PROBE (a frame whose points come in scanner order takes
+    the record-free window kernel, chosen by a probe) or PROJECT_FORCE_ORDERED (rpcc_project_ordered); accepted: i32 [B] tensor that
+    receives which frames the window kernel took."""
     B = offsets.numel() - 1
     P = geom.H * geom.W
     xyz = xyz.contiguous()
@@ -68,7 +76,7 @@ def project(xyz, offsets, geom, ri=None, scratch=None, atomic_path=False, order_
         n = B * (P + 8) * 4 if atomic_path else _lib.lib().rpcc_project_scratch_bytes(xyz.shape[0], B, P)
         scratch = torch.empty(n, dtype=torch.uint8, device=_dev(offsets))
     check(_lib.lib().rpcc_project_ordered(ptr(xyz) if xyz.numel() else None, _point_stride(xyz), ptr(offsets), xyz.shape[0], B, geom,
-                                          ptr(ri), ptr(scratch), scratch.numel() * scratch.element_size(), int(order_flags),
+                                          ptr(ri), ptr(scratch), scratch.numel() * scratch.element_size(), _project_flags(order_flags),
                                           ptr(accepted) if accepted is not None else None, stream()))
     return ri
 
@@ -422,7 +430,7 @@ def compress_batch(xyz, offsets, tm, ground, buf, ground_threshold=0.1, acc=0.04
     salience levels (buf.salience) and per-label steps; None = uniform framework with step `acc`.
     fps_fma / fps_cuda_tie: the CUDA-binary FPS modes (_lib.fps_mode_flags); None = the environment variables RPCC_FPS_FMA
     (0 / 1 / 2) and RPCC_FPS_TIE_CUDA, so every front-end (tools, pipeline, loader) honours them.
-    project_flags: 0 (frames in scanner order take the record-free projection kernel, chosen by a probe), PROJECT_NO_ORDER_PROBE,
+    project_flags: 0, PROJECT_ORDER_PROBE (frames in scanner order take the record-free projection kernel, chosen by a probe),
     PROJECT_FORCE_ORDERED (see project())."""
     io = _batch_io(xyz, offsets, tm, ground, buf, ground_seed, frame_ids, fps_bruteforce, timer, model_method, angle_threshold, plane_seed,
                    nonuniform, fps_fma, fps_cuda_tie, project_flags)
@@ -458,7 +466,7 @@ def _batch_io(xyz, offsets, tm, ground, buf, ground_seed=-1, frame_ids=None, fps
                    int(ground_seed), ptr(fid).value if fid is not None else None, ptr(buf.ri).value, ptr(buf.seg).value,
                    ptr(buf.cen_pix).value, ptr(buf.centers).value, ptr(buf.model).value, ptr(buf.counts).value,
                    ptr(buf.q16).value, ptr(buf.nnz).value, ptr(buf.info).value,
-                   (_lib.FPS_BRUTEFORCE if fps_bruteforce else 0) | _lib.fps_mode_flags(fps_fma, fps_cuda_tie) | int(project_flags),
+                   (_lib.FPS_BRUTEFORCE if fps_bruteforce else 0) | _lib.fps_mode_flags(fps_fma, fps_cuda_tie) | _project_flags(project_flags),
                    timer.h if timer is not None else None,
                    0 if model_method == "point" else 1, angle_cos_cut(angle_threshold) if model_method != "point" else 0.0,
                    int(plane_seed), C.addressof(nonuniform) if nonuniform is not None else None,

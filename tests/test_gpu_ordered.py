@@ -11,7 +11,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-NOPROBE, FORCE = 16, 32      # include/rpcc_hip.h: RPCC_PROJECT_NO_ORDER_PROBE, RPCC_PROJECT_FORCE_ORDERED
+PROBE, FORCE = 16, 32      # include/rpcc_hip.h: RPCC_PROJECT_ORDER_PROBE, RPCC_PROJECT_FORCE_ORDERED
 
 
 @pytest.fixture(scope="module")
@@ -73,7 +73,7 @@ def test_stored_order_is_accepted_and_equals_the_oracle(env):
     half = xyz.shape[0] // 2
     frames = [xyz, xyz[::-1].copy(), xyz[rng.permutation(xyz.shape[0])], ringshuf, np.concatenate([xyz[half:], xyz[:half]]), xyz[:3000].copy()]
     want = [orc.project(f, g) for f in frames]
-    ri, acc = _project(env, frames, geom, 0)
+    ri, acc = _project(env, frames, geom, PROBE)
     assert list(acc) == [1, 1, 0, 0, 1, 0], acc        # stored, reversed: taken; shuffled, random rings: records; halves swapped: taken; small: records
     for i in range(len(frames)):
         assert _beq(ri[i], want[i]), i
@@ -81,9 +81,9 @@ def test_stored_order_is_accepted_and_equals_the_oracle(env):
     assert list(acc_f) == [1] * len(frames)
     for i in range(len(frames)):
         assert _beq(ri_f[i], want[i]), ("forced", i)
-    ri_n, acc_n = _project(env, frames, geom, NOPROBE)
+    ri_n, acc_n = _project(env, frames, geom, 0)
     assert list(acc_n) == [0] * len(frames) and _beq(ri_n, ri)
-    ri_r, acc_r = _project(env, frames, geom, 0, rows=True)        # the rows as a .bin stores them (16-byte loads, garbage 4th column)
+    ri_r, acc_r = _project(env, frames, geom, PROBE, rows=True)        # the rows as a .bin stores them (16-byte loads, garbage 4th column)
     assert list(acc_r) == list(acc) and _beq(ri_r, ri)
     ri_rf, _ = _project(env, frames, geom, FORCE, rows=True)
     assert _beq(ri_rf, ri)
@@ -112,7 +112,7 @@ def test_window_reopens_rows_for_late_points(env):
     frames = [two, strag, special, zero, f[:5000].copy(), np.zeros((0, 3), np.float32), f[:1].copy()]
     want = [orc.project(two, gb), orc.project(strag, gb), orc.project(special[keep], gb), orc.project(zero, gb), orc.project(f[:5000], gb),
             orc.project(np.zeros((0, 3), np.float32), gb), orc.project(f[:1], gb)]
-    for flags in (0, FORCE):
+    for flags in (PROBE, FORCE):
         for rows in (False, True):
             ri, acc = _project(env, frames, geomb, flags, rows=rows)
             for i in range(len(frames)):
@@ -132,7 +132,7 @@ def test_forced_window_kernel_on_every_shipped_geometry(env, gname):
     frames[1] = _ring_order(frames[1], g.H)
     frames[3] = frames[3][:1500].copy()
     want = [orc.project(f, g) for f in frames]
-    for flags in (0, FORCE):
+    for flags in (PROBE, FORCE):
         ri, acc = _project(env, frames, geom, flags)
         for i in range(len(frames)):
             assert _beq(ri[i], want[i]), (flags, i)
@@ -163,7 +163,7 @@ def test_fused_batch_mixes_accepted_and_rejected_frames(env):
     xyz = _to(env, np.concatenate(frames))
     fid = torch.arange(100, 100 + len(frames), dtype=torch.int64, device=env["dev"])
     outs = []
-    for flags in (0, NOPROBE, FORCE):
+    for flags in (PROBE, 0, FORCE):
         buf = ops.BatchBuffers(len(frames), geomb, 100, env["dev"])
         gms = torch.zeros((len(frames), 4), dtype=torch.float64, device=env["dev"])
         ops.compress_batch(xyz, _to(env, offs), _to(env, tm), gms, buf, ground_seed=3, frame_ids=fid, project_flags=flags)
@@ -216,8 +216,8 @@ def test_random_orders_and_shapes(env):
             if n > 10 and rng.random() < 0.25:
                 a[rng.integers(0, n, 2)] = 0
             frames.append(a)
-        ref, _ = _project(env, frames, geom, NOPROBE)
-        for flags in (0, FORCE):
+        ref, _ = _project(env, frames, geom, 0)
+        for flags in (PROBE, FORCE):
             ri, acc = _project(env, frames, geom, flags, rows=bool(draw & 1))
             assert _beq(ri, ref), (draw, H, W, B, flags, acc)
         if draw % 6 == 0:

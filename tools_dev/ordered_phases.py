@@ -21,21 +21,21 @@ xyz = torch.from_numpy(np.tile(xyz1, (B, 1))).to(dev)
 offs = torch.arange(B + 1, dtype=torch.int64, device=dev) * xyz1.shape[0]
 acc = torch.zeros(B, dtype=torch.int32, device=dev)
 for _ in range(3):
-    ops.project(xyz, offs, geom, accepted=acc)
+    ops.project(xyz, offs, geom, accepted=acc, order_flags=ops.PROJECT_ORDER_PROBE)
 torch.cuda.synchronize()
 stamps = torch.zeros(4096, dtype=torch.int64, device=dev)
 _lib.check(_lib.lib().rpcc_debug_stamps(_lib.ptr(stamps)))
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
-ops.project(xyz, offs, geom, accepted=acc)
+ops.project(xyz, offs, geom, accepted=acc, order_flags=ops.PROJECT_ORDER_PROBE)
 e1.record()
 torch.cuda.synchronize()
 _lib.lib().rpcc_debug_stamps(None)
 s = stamps.cpu().numpy()[900:916]
-names = ["chunk end barrier", "compute + window atomics", "next loads + pending notes", "barrier 1", "exact drain", "barrier 2", "window moves",
-         "(tail)", "final write-out"]
+names = {0: "chunk top", 4: "exact sequence (previous chunk's queue)", 1: "compute + window atomics", 2: "next loads + pending notes", 3: "barrier 1",
+         6: "window moves", 7: "(tail)", 8: "final write-out + zero rows", 9: "hand-off pass (candidate bytes)"}
 print("accepted %d of %d; whole projection %.1f us (events)" % (int(acc.sum()), B, e0.elapsed_time(e1) * 1e3))
-tot = s[:9].sum()
-for i, nme in enumerate(names):
-    print("   %-28s %9d cycles  %5.1f %%" % (nme, s[i], 100.0 * s[i] / max(tot, 1)))
+tot = s[:10].sum()
+for i in (0, 4, 1, 2, 3, 6, 7, 8, 9):
+    print("   %-40s %9d cycles  %5.1f %%" % (names[i], s[i], 100.0 * s[i] / max(tot, 1)))
 print("   chunks %d, window moves %d, total %d cycles = %.1f us at 2.4 GHz" % (s[15], s[14], tot, tot / 2400.0))

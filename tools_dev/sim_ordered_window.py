@@ -51,3 +51,34 @@ for c0 in range(0, len(row), chunk):
 nchunks = (len(row) + chunk - 1) // chunk
 print("points %d chunks %d WR %d: moves %d, rows retired %d, rows re-opened %d, passes %d (%.2f per chunk)" %
       (len(row), nchunks, WR, moves, retire_rows, reopen_rows, passes, passes / nchunks))
+
+# ---- the same with 3 % of the points (the exact-sequence queue) applied one chunk late
+rng = np.random.default_rng(0)
+late = rng.random(len(row)) < 0.03
+lo = None; retired[:] = False; moves = retire_rows = reopen_rows = 0
+prev_late = np.zeros(0, int)
+for c0 in range(0, len(row) + chunk, chunk):
+    idx = np.arange(c0, min(c0 + chunk, len(row)))
+    r = np.concatenate([row[idx][~late[idx]], prev_late])
+    prev_late = row[idx][late[idx]]
+    pend = np.ones(len(r), bool)
+    while pend.any():
+        if lo is not None:
+            pend &= ~((r >= lo) & (r < lo + WR))
+            if not pend.any():
+                break
+        hist = np.bincount(r[pend], minlength=H)
+        cover = np.array([hist[l:l + WR].sum() for l in range(0, H - WR + 1)])
+        cands = np.flatnonzero(cover == cover.max())
+        new = cands[np.argmin(np.abs(cands - (lo if lo is not None else cands[0])))]
+        if lo is None:
+            lo = new
+            continue
+        old_rows = set(range(lo, lo + WR)); new_rows = set(range(new, new + WR))
+        retire_rows += len(old_rows - new_rows)
+        for rr in old_rows - new_rows:
+            retired[rr] = True
+        reopen_rows += sum(1 for rr in new_rows - old_rows if retired[rr])
+        moves += 1
+        lo = new
+print("with the uncertain 3 %% one chunk late: moves %d, rows retired %d, rows re-opened %d" % (moves, retire_rows, reopen_rows))
