@@ -290,6 +290,13 @@ def pmc_numbers(a, B, geom_s, M):
         if pm["config"] != {"batch": B, "geom": geom_s, "clusters": M, "config": a.config, "input": bool(a.input)} or a.fps_bruteforce or a.scene != "default":
             return None
         key = [k for k in pm["kernels"] if k.startswith(("fps_regtab_planar_kernel", "fps_regtab_kernel<true", "fps_tiled_kernel<true"))][0]   # template arguments vary
+        # The counters were taken on one build of the kernels: they describe this run only if the sources are the same (sha256 over
+        # csrc/* + include/rpcc_hip.h, written by tools_profiles.py).  Another tree -> "pmc_stale": true and no counter-derived number.
+        from rpcc_amd.build import source_digest
+        have, want = pm.get("source_sha256"), source_digest()
+        if have != want:
+            return dict(stale=True, kernel=key, why="profiles/%s was taken on sources %s, this tree is %s: re-run the PMC passes (tools_dev/round_profiles.sh, "
+                                                    "tools_profiles.py)" % (name, (have or "without a recorded hash")[:12], want[:12]))
         return dict(kernel=key, traffic=pm["kernels"][key]["traffic_bytes_per_launch"],
                     valu=pm["kernels"][key].get("valu_wave_insts_per_launch"),
                     valu_cyc=pm["kernels"][key].get("valu_mean_cycles_dynamic", pm["kernels"][key].get("valu_mean_cycles_static")),
@@ -559,6 +566,28 @@ def run_workload(a, ctx):
                              sal=o.get("salience"))
         return 1
 
+    def oracle_stage_latency(k):
+        """the C port stage by stage on ONE host thread, k of the same frames -> mean ms per frame and stage"""
+        t = dict.fromkeys(("a2 projection", "a4 ground fit", "a3+a5 back-projection, residual, mask", "a6 FPS", "a7 assignment", "a8 model", "a10+a11 prediction, residual, quantiser"), 0.0)
+        for i in range(k):
+            c = [time.perf_counter()]
+            tick = lambda: c.append(time.perf_counter())
+            ri = orc.project(frames_h[i], g_o); tick()
+            gm = orc.ground_model(ri, tm_np, seed=ids[i]); tick()
+            pc = orc.backproject(ri, tm_np)
+            mask = orc.vertical_residual(pc, gm) > cfg_o["ground_threshold"]
+            pc_left = pc[np.where(mask)]; tick()
+            centers = pc_left[orc.fps(pc_left, M)]; tick()
+            seg = orc.assign(ri, pc, tm_np, gm, centers).astype(np.int64); tick()
+            mp = orc.cluster_modeling_plane(pc, ri, seg, tm_np, 75, 0, ids[i]) if general else None
+            mp = np.concatenate((np.asarray(gm, np.float64).reshape(1, 4), mp), 0) if general else orc.point_model_param(ri, seg, gm); tick()
+            res = ri.reshape(H, W, 1) - orc.intra_predict(seg, mp, tm_np)
+            orc.uniform_quantize(seg, res, acc); tick()
+            for name, d in zip(t, np.diff(c)):
+                t[name] += d
+        return {"frames": k, "ms_per_frame": round(sum(t.values()) / k * 1e3, 2), "stages_ms": {n: round(v / k * 1e3, 3) for n, v in t.items()},
+                "what": "C port of the reference's cpu=True path (oracle/), one thread, stage by stage" + (" (uniform quantiser timed in place of the non-uniform one)" if general else "")}
+
     verified, cpu_rate = None, None
     if not a.no_verify or want_cpu:
         from concurrent.futures import ThreadPoolExecutor
@@ -568,6 +597,7 @@ def run_workload(a, ctx):
         with ThreadPoolExecutor(threads) as ex:       # frame-parallel like the reference's --workers pool; ctypes releases the GIL
             list(ex.map(oracle_frame, range(S)))
         cpu_rate = S / (time.perf_counter() - t1)
+    cpu_single = oracle_stage_latency(min(S, 4)) if want_cpu else None
     if not a.no_verify:
         verified = True
         why = None
@@ -606,6 +636,9 @@ def run_workload(a, ctx):
         stream_once = fps_bytes / lt / 1e9 if fps_n else 0.0
         pm = pmc_numbers(a, B, geom_s, M)
         fps_kernel = "fps_range_kernel (brute force)" if a.fps_bruteforce else (pm["kernel"] if pm else "fps_regtab_kernel")
+        pmc_stale = pm.get("why") if pm and pm.get("stale") else None
+        if pmc_stale:
+            pm = None      # (every counter-derived field below stays null)
         step_s = dt / steps
         mean_cyc = (pm["step_cycles"] / pm["step_valu"]) if pm and pm.get("step_valu") and pm.get("step_cycles") else None
         valu_peak = VALU_SIMD_CYCLES_PER_S / mean_cyc if mean_cyc else None       # wave-instructions per second of THIS instruction mix
@@ -630,6 +663,7 @@ def run_workload(a, ctx):
                         "cycles per instruction (2 / 4 / 8 cycles by class, measured: profiles/r04_valu_peak.md; the kernel's DYNAMIC class counts -- "
                         "SQ_INSTS_VALU_ADD_F32 ... -- weighted with the static cycles inside each class when the committed profile holds them, else the "
                         "static mix), summed over the step's launches, against 1024 SIMDs x 2.4 GHz; achieved / peak in wave-instructions of this mix",
+                "pmc_stale": bool(pmc_stale), **({"pmc_stale_why": pmc_stale} if pmc_stale else {}),
                 "cycles_from": (pm["cycles_source"] if pm else None),
                 # the same instruction count priced differently: every instruction at the guide's 2 cycles / at 4 cycles, the static mix alone,
                 # and every counter class at the least / largest cycles its static instructions have
@@ -691,7 +725,8 @@ def run_workload(a, ctx):
         if want_cpu:
             out["cpu_baseline"] = {"value": round(cpu_rate, 3), "unit": "frames/s", "cores": threads, "kind": "port",
                                    "sample": "%d of the same frames, C port of the reference cpu=True path "
-                                             "(oracle/), frame-parallel over %d threads" % (S, threads)}
+                                             "(oracle/), frame-parallel over %d threads" % (S, threads),
+                                   "single_thread": cpu_single}
     del bufs, gms_l, xyz
     torch.cuda.synchronize()
     torch.cuda.empty_cache()

@@ -17,6 +17,18 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
                "-shared", "-Wno-unused-value"]
 
 
+def source_digest():
+    """sha256 over the sources librpcc_hip.so is built from (csrc/*, include/rpcc_hip.h; names and bytes, sorted): what a committed set of
+    profiler counters (profiles/pmc_current*.json) is tied to -- bench.py prints no counter-derived fraction for another build."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in DEPS:
+        h.update(os.path.basename(d).encode() + b"\0")
+        h.update(open(d, "rb").read())
+        h.update(b"\0")
+    return h.hexdigest()
+
+
 def build_host(force=False, verbose=False):
     """librpcc_host.so: the plain-C container packer (bzip2 through the libbz2 the interpreter's bz2 module links)."""
     os.makedirs(os.path.dirname(HOST_LIB), exist_ok=True)

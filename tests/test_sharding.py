@@ -356,6 +356,55 @@ def test_bench_finds_its_pmc_numbers():
     assert 'startswith(("fps_regtab_planar_kernel", "fps_regtab_kernel<true", "fps_tiled_kernel<true"))' in src
 
 
+def test_bench_refuses_counters_of_another_build(tmp_path, monkeypatch):
+    """roofline.frac / traffic come from committed profiler passes: they describe a run only when the kernels are the ones that were
+    profiled.  profiles/pmc_current*.json carry a sha256 of csrc/* + include/rpcc_hip.h (tools_profiles.py); bench.pmc_numbers() recomputes
+    it and answers "stale" -- the JSON line then says "pmc_stale": true and carries no counter-derived number -- for any other tree."""
+    import argparse
+    import json
+    import shutil
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import rpcc_amd  # noqa: F401
+    from rpcc_amd.build import DEPS, source_digest
+    import bench
+    digest = source_digest()
+    assert len(digest) == 64 and digest == source_digest()
+    a = argparse.Namespace(config=1, input=None, fps_bruteforce=False, scene="default")
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    pm = json.load(open(os.path.join(root, "profiles", "pmc_current.json")))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    # (1) the hash of this tree: the numbers are used
+    pm["source_sha256"] = digest
+    json.dump(pm, open(prof / "pmc_current.json", "w"))
+    got = bench.pmc_numbers(a, 256, "64x2048", 100)
+    assert got and not got.get("stale") and got["step_traffic"] == pm["step_traffic_bytes"] and got["valu"] > 0
+    # (2) another hash, and (3) a file from before the hashes: stale, nothing but the reason
+    for bad in ("0" * 64, None):
+        if bad is None:
+            pm.pop("source_sha256")
+        else:
+            pm["source_sha256"] = bad
+        json.dump(pm, open(prof / "pmc_current.json", "w"))
+        got = bench.pmc_numbers(a, 256, "64x2048", 100)
+        assert got["stale"] is True and "re-run the PMC passes" in got["why"] and "traffic" not in got and "step_valu" not in got
+    # (4) the digest follows the sources: one more byte in a kernel file changes it
+    k = [d for d in DEPS if d.endswith("codec_kernels.h")][0]
+    keep = k + ".keep"
+    shutil.copy2(k, keep)      # (keeps the modification time: no rebuild of the library after the test)
+    try:
+        open(k, "a").write("\n")
+        assert source_digest() != digest
+    finally:
+        shutil.move(keep, k)
+    assert source_digest() == digest
+    # another configuration than the profiled one: no numbers either way (as before)
+    assert bench.pmc_numbers(a, 128, "64x2048", 100) is None
+    src = open(os.path.join(root, "bench.py")).read()
+    assert '"pmc_stale": bool(pmc_stale)' in src and "cpu_single" in src
+
+
 def _stub_blob(name):
     import zlib
     c = zlib.crc32(name.encode())

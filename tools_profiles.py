@@ -131,7 +131,11 @@ if "--no-current" not in sys.argv:
     geom = wl.split("(")[-1].split(")")[0] if "x" in wl else "64x2048"
     import re
     m = re.search(r"\((\d+x\d+)\)", wl)
-    json.dump({"tag": tag, "config": {"batch": B, "geom": m.group(1) if m else "64x2048", "clusters": 100, "config": cfg, "input": real},
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import rpcc_amd  # noqa: F401
+    from rpcc_amd.build import source_digest
+    # the counters describe the kernels of THIS source tree: run this script on the tree the passes were taken with (bench.py checks)
+    json.dump({"tag": tag, "source_sha256": source_digest(), "config": {"batch": B, "geom": m.group(1) if m else "64x2048", "clusters": 100, "config": cfg, "input": real},
                "step_traffic_bytes": tot, "step_valu_wave_insts": totv, "step_valu_simd_cycles": int(totc), "step_valu_simd_cycles_static_mix": int(totc_static),
                "step_valu_simd_cycles_lo": int(totc_lo), "step_valu_simd_cycles_hi": int(totc_hi), "valu_cycles_source": "dynamic class counters" if dyn else "static mix", "kernels": js,
                "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU, separate passes, serial steps; read = 2 x FETCH_SIZE (gfx950, calibrated); "
