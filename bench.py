@@ -73,6 +73,8 @@ def parse():
                          "roofline case) instead of the exact tile-pruned one; same results")
     ap.add_argument("--scene", default="default", choices=("default", "shell", "noise", "corridor"),
                     help="synthetic scene: the headline's (default) or an adversarial input of the FPS pruning study (synth.make_frame)")
+    ap.add_argument("--groundless", type=int, default=0, help="this many of the batch's sweeps (spread evenly) lose every return below z = -1.45 m: fewer than 800 "
+                                                              "ground candidates, the fit runs on the whole cloud (segment_utils.py:105-106)")
     ap.add_argument("--pipeline", type=int, default=3, help="batches in flight (streams); 1 = strictly serial steps")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary measurements (configs[2] fused, the real sweep, the datalist feed) that follow the headline at N=1")
@@ -287,7 +289,7 @@ def pmc_numbers(a, B, geom_s, M):
     try:
         name = "pmc_current.json" if a.config == 1 and not a.input else "pmc_current_c%d%s.json" % (a.config, "_real" if a.input else "")
         pm = json.load(open(os.path.join(ROOT, "profiles", name)))
-        if pm["config"] != {"batch": B, "geom": geom_s, "clusters": M, "config": a.config, "input": bool(a.input)} or a.fps_bruteforce or a.scene != "default":
+        if pm["config"] != {"batch": B, "geom": geom_s, "clusters": M, "config": a.config, "input": bool(a.input)} or a.fps_bruteforce or a.scene != "default" or getattr(a, "groundless", 0):
             return None
         key = [k for k in pm["kernels"] if k.startswith(("fps_regtab_planar_kernel", "fps_regtab_kernel<true", "fps_tiled_kernel<true"))][0]   # template arguments vary
         # The counters were taken on one build of the kernels: they describe this run only if the sources are the same (sha256 over
@@ -340,6 +342,13 @@ def run_workload(a, ctx):
         xyz, offs = load_real_batch(a.input, ids, H, W, dev, shuffle=a.input_shuffle)
     else:
         xyz, offs = synth.make_batch(ids, H, W, device=dev, scene=a.scene, vmax_deg=vmax_deg, vmin_deg=vmin_deg, hfov_deg=hfov_deg)
+    if getattr(a, "groundless", 0):
+        o_h = offs.cpu().numpy()
+        sel = set(int(v) for v in np.linspace(0, B - 1, min(a.groundless, B)).round())
+        fr = [xyz[o_h[i]:o_h[i + 1]] for i in range(B)]
+        fr = [f[f[:, 2] > -1.45] if i in sel else f for i, f in enumerate(fr)]
+        offs = torch.as_tensor(np.concatenate([[0], np.cumsum([f.shape[0] for f in fr])]).astype(np.int64), device=dev)
+        xyz = torch.cat(fr, 0).contiguous()
     offs_host = offs.cpu().numpy()
     fid = torch.as_tensor(np.asarray(ids, np.int64), device=dev)
     tm = torch.from_numpy(tm_np).to(dev)
@@ -648,6 +657,8 @@ def run_workload(a, ctx):
                      "seeded RANSAC inside the step") % (a.config, B, "real (%s, rotated copies, %s)" % (os.path.basename(a.input), "shuffled" if a.input_shuffle else "points in stored order") if a.input
                                                        else ("synthetic" if a.scene == "default" else "synthetic ADVERSARIAL scene '%s'" % a.scene),
                                                        H, W, "non-uniform + FPS + plane-model" if general else "uniform + FPS + point-model", a.accuracy, M))
+        if getattr(a, "groundless", 0):
+            workload += "; %d of the %d sweeps without any return below z = -1.45 m (ground fit on the whole cloud)" % (min(a.groundless, B), B)
         exch_s = ("no exchange" if not exchange else
                   ("RCCL all_gather of the per-frame payload lengths + gather of the packed pre-entropy residual streams to rank 0, every step" if a.gather_payloads
                    else "RCCL all_gather of the per-frame payload lengths, %d steps per collective (payload bytes stay with the rank that writes the files)" % LEN_EVERY))
@@ -869,11 +880,18 @@ def run_secondary(a, ctx):
     for name, kw in (("configs2_fused", dict(config=2, geom="64x2000", input=None)),
                      ("real_sweep", dict(config=1, geom=None, input=os.path.join(ROOT, "tests", "golden", "example_64E.npz"))),
                      # the reference's own KITTI_test table (dataset/__init__.py:21: 80 x 2000, 630 FPS tiles)
-                     ("kitti_test_80x2000", dict(config=1, geom=None, input=None, lidar="KITTI_test"))):
+                     ("kitti_test_80x2000", dict(config=1, geom=None, input=None, lidar="KITTI_test")),
+                     # the two inputs the exact kernels are slowest on: sweeps without ground returns (whole-cloud ground fit) and ranges that are independent from
+                     # pixel to pixel (nothing for the FPS to prune)
+                     ("groundless_8_of_256", dict(config=1, geom=None, input=None, groundless=8)),
+                     ("scene_noise", dict(config=1, geom=None, input=None, scene="noise"))):
         b = copy.copy(a)
         for k, v in kw.items():
             setattr(b, k, v)
         b.cpu_sample, b.steps, b.warmup, b.h2d, b.fps_bruteforce = 0, max(20, min(a.steps, 50)), 5, False, False
+        b.groundless, b.scene = kw.get("groundless", 0), kw.get("scene", "default")
+        if "lidar" not in kw:
+            b.lidar = None
         try:
             if b.input and not os.path.exists(b.input):
                 raise FileNotFoundError(b.input)

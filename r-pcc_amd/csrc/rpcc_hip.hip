@@ -673,8 +673,9 @@ static inline int rs_chunk_px(int P) { return (((P + RS_CHUNKS - 1) / RS_CHUNKS)
 // Beside the counts (P % 64 == 0: the quad write-out, whole 64-pixel words): WHICH pixels have z < zthr, a byte per quad of pixels (bit e = pixel 4 q + e),
 // [B][P / 4] bytes behind the B x (RS_CHUNKS + 1) count words (16-byte aligned); zcnt[b][RS_CHUNKS] = 3 when counts and bytes are valid (1: counts only).
 // The ground fit compacts its candidates from these bytes instead of testing every pixel again.
+__host__ __device__ __forceinline__ size_t rs_count_words(int B) { return (size_t)B * (RS_CHUNKS + 1); }
 __host__ __device__ __forceinline__ uint8_t *rs_zmask_of(const int32_t *zcnt, int B) {
-    return reinterpret_cast<uint8_t *>(const_cast<int32_t *>(zcnt)) + (((size_t)B * (RS_CHUNKS + 1) * 4 + 15) & ~(size_t)15);
+    return reinterpret_cast<uint8_t *>(const_cast<int32_t *>(zcnt)) + ((rs_count_words(B) * 4 + 15) & ~(size_t)15);
 }
 __device__ void project_fixup_frame(const float *__restrict__ xyz, const int64_t *__restrict__ offs, int b, rpcc_geom g,
                                     uint32_t *__restrict__ ri, int32_t *__restrict__ lastz, int ps);
@@ -985,7 +986,7 @@ static int launch_project(const float *xyz, const int64_t *offsets, int64_t tota
         BatchInit bi;
         memset(&bi, 0, sizeof(bi));
         if (init) bi = *init;
-        if (zcnt && !cleared) HIP_TRY(hipMemsetAsync(zcnt, 0, (size_t)B * (RS_CHUNKS + 1) * 4, st));
+        if (zcnt && !cleared) HIP_TRY(hipMemsetAsync(zcnt, 0, rs_count_words(B) * 4, st));
         // Sweeps in scanner order: one workgroup per frame probes the order of its points and, if they move through the image ring by
         // ring, projects the frame without records (project_ordered.h); accept[b] tells the two kernels below to leave that frame alone.
         int32_t *accept = nullptr;
@@ -1023,7 +1024,7 @@ static int launch_project(const float *xyz, const int64_t *offsets, int64_t tota
         return RPCC_OK;
     }
     if (accept_out) HIP_TRY(hipMemsetAsync(accept_out, 0, (size_t)B * 4, st));
-    if (zcnt && !cleared) HIP_TRY(hipMemsetAsync(zcnt, 0, (size_t)B * (RS_CHUNKS + 1) * 4, st));
+    if (zcnt && !cleared) HIP_TRY(hipMemsetAsync(zcnt, 0, rs_count_words(B) * 4, st));
     if (init && init->on) batch_init_kernel<<<256, 256, 0, st>>>(*init);   // (clears zcnt: the RANSAC kernel counts for itself)
     project_fill_kernel<false><<<fg, 256, 0, st>>>(rb, lastz, flags, P);
     LAUNCH_CHECK();
@@ -1160,24 +1161,12 @@ __device__ __forceinline__ void rs_treesum(double (&v)[NV], double *sred) {
     for (int q = 0; q < NV; q++) v[q] = sred[q * RS_NT];
 }
 
-// Workgroup-wide RANSAC on `pts` (RN = sample size, NTH = threads of the workgroup (>= RS_NT), MAXH = most
-// hypotheses); every thread calls it.  Returns the
-// winner's inlier count.  sred [6*RS_NT] doubles, swin [16*4] doubles, sbest [16*2] ints.
-// RS_PU: points per lane in flight in the scoring / refit loops (1 for points in LDS, more for points in global memory)
-// BYPTS: the wavefronts share the POINTS instead of the hypotheses (every wavefront scores all MAXH <= 32 planes on its
-// part): for a long list in global memory and few hypotheses, where a pass over the list costs more than the tests.
-// RS_RU: points per thread in flight in the two ordered refit passes (only 256 threads walk those).
-template <int RN, int NTH, int MAXH, int RS_PU, class PTS, bool BYPTS = false, int RS_RU = RS_PU>
-__device__ int ransac_plane_wg(const PTS &pts, int iters, double thr, uint32_t seed, double plane[4], double *sred,
-                               double *swin, int *sbest) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n = pts.n;
-    const float thr_f = (float)thr;
-    plane[0] = 0; plane[1] = 0; plane[2] = 1; plane[3] = 0;
-    if (n < RN || iters > MAXH) return 0;
-    // (1) fits: one hypothesis per lane (iters <= RS_MAX_HYP), results narrowed to fp32 in LDS
-    float *hyp = reinterpret_cast<float *>(sred);  // [iters][4] fp32 planes + validity, reused before the sums
-    double *hypd = swin + 64;                      // [iters][4] fp64 planes (winner is read back from here)
+// Step (1) of the RANSAC: thread h < iters draws and fits hypothesis h -- RN distinct points by the counter-based hash, centroid + centred
+// moments in fp64, largest-determinant closed form -- and leaves the plane narrowed to fp32 with a validity word in hyp[5 h ..] and in
+// fp64 in hypd[4 h ..].  (Every thread calls; no barrier inside.)
+template <int RN, class PTS>
+__device__ __forceinline__ void ransac_hypotheses(const PTS &pts, int iters, uint32_t seed, float *hyp, double *hypd) {
+    const int tid = threadIdx.x, n = pts.n;
     if (tid < iters) {
         const int h = tid;
         int idx[RN];
@@ -1211,6 +1200,82 @@ __device__ int ransac_plane_wg(const PTS &pts, int iters, double thr, uint32_t s
         hyp[5 * h + 4] = ok ? 1.0f : 0.0f;
         hypd[4 * h] = pl[0]; hypd[4 * h + 1] = pl[1]; hypd[4 * h + 2] = pl[2]; hypd[4 * h + 3] = pl[3];
     }
+}
+
+// The end of the RANSAC: plane = the winning hypothesis with wcnt inliers (wcnt < 0: none was valid) -> the refit on its inliers, fp64 moments with
+// ordered sums: thread t < RS_NT accumulates the inliers among points t, t + RS_NT, ... in index order (whatever RU, the points in flight), then a
+// binary tree.  Every thread of the workgroup calls; sred: [6 * RS_NT] doubles of LDS.  Returns the inlier count reported for the frame.
+template <int RS_RU, class PTS>
+__device__ __forceinline__ int ransac_refit(const PTS &pts, int wcnt, float thr_f, double plane[4], double *sred) {
+    const int tid = threadIdx.x, n = pts.n;
+    if (wcnt < 0) return 0;
+    if (wcnt < 3) return wcnt;
+    const float wf[4] = {(float)plane[0], (float)plane[1], (float)plane[2], (float)plane[3]};
+    // refit on the winner's inliers (fp64 moments, ordered sums)
+    double c[3] = {0, 0, 0};
+    auto centroid = [&](auto ru_tag) {   // RU points per thread in flight; partial tid accumulates its points in index order whatever RU
+        constexpr int RU = decltype(ru_tag)::value;
+        for (int i0 = tid; i0 < n; i0 += RS_NT * RU) {
+            float x[RU], y[RU], z[RU];
+#pragma unroll
+            for (int u = 0; u < RU; u++) pts.getf(min(i0 + RS_NT * u, n - 1), x[u], y[u], z[u]);
+#pragma unroll
+            for (int u = 0; u < RU; u++)
+                if (i0 + RS_NT * u < n && plane_inlier(wf, x[u], y[u], z[u], thr_f)) { c[0] += (double)x[u]; c[1] += (double)y[u]; c[2] += (double)z[u]; }
+        }
+    };
+    if (tid < RS_NT) {
+        if (pts_in_memory(pts)) centroid(std::integral_constant<int, (RS_RU > RS_GLOBAL_PU ? RS_RU : RS_GLOBAL_PU)>{});
+        else centroid(std::integral_constant<int, RS_RU>{});
+    }
+    DBG_STAMP(4);
+    rs_treesum<3>(c, sred);
+    DBG_STAMP(5);
+    c[0] /= (double)wcnt; c[1] /= (double)wcnt; c[2] /= (double)wcnt;
+    double m[6] = {0, 0, 0, 0, 0, 0};
+    auto moments = [&](auto ru_tag) {
+        constexpr int RU = decltype(ru_tag)::value;
+        for (int i0 = tid; i0 < n; i0 += RS_NT * RU) {
+            float x[RU], y[RU], z[RU];
+#pragma unroll
+            for (int u = 0; u < RU; u++) pts.getf(min(i0 + RS_NT * u, n - 1), x[u], y[u], z[u]);
+#pragma unroll
+            for (int u = 0; u < RU; u++)
+                if (i0 + RS_NT * u < n && plane_inlier(wf, x[u], y[u], z[u], thr_f)) {
+                    const double rx = (double)x[u] - c[0], ry = (double)y[u] - c[1], rz = (double)z[u] - c[2];
+                    m[0] += rx * rx; m[1] += rx * ry; m[2] += rx * rz; m[3] += ry * ry; m[4] += ry * rz; m[5] += rz * rz;
+                }
+        }
+    };
+    if (tid < RS_NT) {
+        if (pts_in_memory(pts)) moments(std::integral_constant<int, (RS_RU > RS_GLOBAL_PU ? RS_RU : RS_GLOBAL_PU)>{});
+        else moments(std::integral_constant<int, RS_RU>{});
+    }
+    rs_treesum<6>(m, sred);
+    double pl[4];
+    if (plane_from_moments(c, m[0], m[1], m[2], m[3], m[4], m[5], pl)) { plane[0] = pl[0]; plane[1] = pl[1]; plane[2] = pl[2]; plane[3] = pl[3]; }
+    return wcnt;
+}
+
+// Workgroup-wide RANSAC on `pts` (RN = sample size, NTH = threads of the workgroup (>= RS_NT), MAXH = most
+// hypotheses); every thread calls it.  Returns the
+// winner's inlier count.  sred [6*RS_NT] doubles, swin [16*4] doubles, sbest [16*2] ints.
+// RS_PU: points per lane in flight in the scoring / refit loops (1 for points in LDS, more for points in global memory)
+// BYPTS: the wavefronts share the POINTS instead of the hypotheses (every wavefront scores all MAXH <= 32 planes on its
+// part): for a long list in global memory and few hypotheses, where a pass over the list costs more than the tests.
+// RS_RU: points per thread in flight in the two ordered refit passes (only 256 threads walk those).
+template <int RN, int NTH, int MAXH, int RS_PU, class PTS, bool BYPTS = false, int RS_RU = RS_PU>
+__device__ int ransac_plane_wg(const PTS &pts, int iters, double thr, uint32_t seed, double plane[4], double *sred,
+                               double *swin, int *sbest) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = pts.n;
+    const float thr_f = (float)thr;
+    plane[0] = 0; plane[1] = 0; plane[2] = 1; plane[3] = 0;
+    if (n < RN || iters > MAXH) return 0;
+    // (1) fits: one hypothesis per lane (iters <= RS_MAX_HYP), results narrowed to fp32 in LDS
+    float *hyp = reinterpret_cast<float *>(sred);  // [iters][4] fp32 planes + validity, reused before the sums
+    double *hypd = swin + 64;                      // [iters][4] fp64 planes (winner is read back from here)
+    ransac_hypotheses<RN>(pts, iters, seed, hyp, hypd);
     if (BYPTS && tid < 32) sbest[tid] = 0;
     __syncthreads();
     DBG_STAMP(7);
@@ -1363,53 +1428,26 @@ __device__ int ransac_plane_wg(const PTS &pts, int iters, double thr, uint32_t s
         }
         if (wcnt >= 0) { plane[0] = swin[4 * wbest]; plane[1] = swin[4 * wbest + 1]; plane[2] = swin[4 * wbest + 2]; plane[3] = swin[4 * wbest + 3]; }
     }
-    if (wcnt < 0) return 0;
-    if (wcnt < 3) return wcnt;
-    const float wf[4] = {(float)plane[0], (float)plane[1], (float)plane[2], (float)plane[3]};
-    // refit on the winner's inliers (fp64 moments, ordered sums)
-    double c[3] = {0, 0, 0};
-    auto centroid = [&](auto ru_tag) {   // RU points per thread in flight; partial tid accumulates its points in index order whatever RU
-        constexpr int RU = decltype(ru_tag)::value;
-        for (int i0 = tid; i0 < n; i0 += RS_NT * RU) {
-            float x[RU], y[RU], z[RU];
-#pragma unroll
-            for (int u = 0; u < RU; u++) pts.getf(min(i0 + RS_NT * u, n - 1), x[u], y[u], z[u]);
-#pragma unroll
-            for (int u = 0; u < RU; u++)
-                if (i0 + RS_NT * u < n && plane_inlier(wf, x[u], y[u], z[u], thr_f)) { c[0] += (double)x[u]; c[1] += (double)y[u]; c[2] += (double)z[u]; }
-        }
-    };
-    if (tid < RS_NT) {
-        if (pts_in_memory(pts)) centroid(std::integral_constant<int, (RS_RU > RS_GLOBAL_PU ? RS_RU : RS_GLOBAL_PU)>{});
-        else centroid(std::integral_constant<int, RS_RU>{});
-    }
-    DBG_STAMP(4);
-    rs_treesum<3>(c, sred);
-    DBG_STAMP(5);
-    c[0] /= (double)wcnt; c[1] /= (double)wcnt; c[2] /= (double)wcnt;
-    double m[6] = {0, 0, 0, 0, 0, 0};
-    auto moments = [&](auto ru_tag) {
-        constexpr int RU = decltype(ru_tag)::value;
-        for (int i0 = tid; i0 < n; i0 += RS_NT * RU) {
-            float x[RU], y[RU], z[RU];
-#pragma unroll
-            for (int u = 0; u < RU; u++) pts.getf(min(i0 + RS_NT * u, n - 1), x[u], y[u], z[u]);
-#pragma unroll
-            for (int u = 0; u < RU; u++)
-                if (i0 + RS_NT * u < n && plane_inlier(wf, x[u], y[u], z[u], thr_f)) {
-                    const double rx = (double)x[u] - c[0], ry = (double)y[u] - c[1], rz = (double)z[u] - c[2];
-                    m[0] += rx * rx; m[1] += rx * ry; m[2] += rx * rz; m[3] += ry * ry; m[4] += ry * rz; m[5] += rz * rz;
-                }
-        }
-    };
-    if (tid < RS_NT) {
-        if (pts_in_memory(pts)) moments(std::integral_constant<int, (RS_RU > RS_GLOBAL_PU ? RS_RU : RS_GLOBAL_PU)>{});
-        else moments(std::integral_constant<int, RS_RU>{});
-    }
-    rs_treesum<6>(m, sred);
-    double pl[4];
-    if (plane_from_moments(c, m[0], m[1], m[2], m[3], m[4], m[5], pl)) { plane[0] = pl[0]; plane[1] = pl[1]; plane[2] = pl[2]; plane[3] = pl[3]; }
-    return wcnt;
+    return ransac_refit<RS_RU>(pts, wcnt, thr_f, plane, sred);
+}
+
+// Scratch of the deferred whole-cloud fits of a batch of nframes frames: flag i32 [nframes] (1: the frame's fit is deferred; written for EVERY frame by
+// every ground-fit launch, so nothing needs clearing), then per frame cnt i32 [RS_WC_H] inliers per hypothesis | hyp f32 [RS_WC_H * 5] | hypd f64 [RS_WC_H * 4].
+#define RS_WC_H 104   // = RS_GROUND_MAXH
+#define RS_WC_SLOT_BYTES (RS_WC_H * 4 + RS_WC_H * 20 + RS_WC_H * 32)
+static_assert(RS_WC_SLOT_BYTES % 8 == 0 && (RS_WC_H * 24) % 8 == 0, "the fp64 planes of a slot are 8-byte aligned");
+struct WcSlot { int32_t *cnt; float *hyp; double *hypd; };
+__host__ __device__ __forceinline__ int32_t *wc_flags_of(char *wc) { return reinterpret_cast<int32_t *>(wc); }
+__host__ __device__ __forceinline__ WcSlot wc_slot_of(char *wc, int nframes, int b) {
+    char *p = wc + (((size_t)nframes * 4 + 63) & ~(size_t)63) + (size_t)b * RS_WC_SLOT_BYTES;
+    WcSlot w;
+    w.cnt = reinterpret_cast<int32_t *>(p); w.hyp = reinterpret_cast<float *>(w.cnt + RS_WC_H);
+    w.hypd = reinterpret_cast<double *>(p + RS_WC_H * 24);
+    return w;
+}
+// where the scratch lies: behind the candidate bytes of the band kernel's hand-off (all of it inside the FPS tile table's area, which is written later)
+__host__ __device__ __forceinline__ char *rs_wc_of(const int32_t *zcnt, int B, int P) {
+    return reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(rs_zmask_of(zcnt, B)) + (size_t)B * (size_t)(P >> 2) + 63) & ~(uintptr_t)63);
 }
 
 #define RS_CU 16  // pixels per lane in flight during the compaction pass
@@ -1425,7 +1463,8 @@ __device__ __forceinline__ void ground_ransac_body(const float *__restrict__ ri_
                                                    double *__restrict__ ground,
                                                    int32_t *__restrict__ ninl,
                                                    const int32_t *__restrict__ zcnt,
-                                                   const int64_t *__restrict__ frame_ids, const int b, const int nframes) {   // b: the workgroup's frame of nframes
+                                                   const int64_t *__restrict__ frame_ids, const int b, const int nframes,   // b: the workgroup's frame of nframes
+                                                   char *__restrict__ wc = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rs_smem[];
     double *sred = reinterpret_cast<double *>(rs_smem);          // [6*256]
     double *swin = sred + 6 * RS_NT;                             // [64] + [RS_MAX_HYP*4] fp64 hypotheses
@@ -1595,6 +1634,23 @@ __device__ __forceinline__ void ground_ransac_body(const float *__restrict__ ri_
     (void)ransac_n;  // the ground fit samples 10 points (utils/segment_utils.py:75)
     // the frame's seed follows its identity (datalist index), not its position in the batch
     const uint32_t fid = frame_ids ? (uint32_t)frame_ids[b] : (uint32_t)b;
+    const bool defer = pts.lds == nullptr && wc != nullptr && P >= 10 && iters <= RS_GROUND_MAXH;   // (workgroup-uniform)
+    if (wc != nullptr && tid == 0) wc_flags_of(wc)[b] = defer ? 1 : 0;
+    if (defer) {
+        // Fewer than min_pts candidates: the fit runs on EVERY pixel (segment_utils.py:105-106), 100 planes x P pixels of scoring -- 1.06 ms for the one CU
+        // this workgroup sits on, and a launch lasts as long as its slowest frame.  Here only the hypotheses are drawn and fitted; the frame is marked,
+        // ground_wc_score_kernel scores its planes with workgroups all over the chip, ground_wc_refit_kernel picks the winner and refits (same tests,
+        // same ordered sums: the same plane to the bit).
+        float *hyp = reinterpret_cast<float *>(sred);
+        double *hypd = swin + 64;
+        ransac_hypotheses<10>(pts, iters, seed0 + fid, hyp, hypd);
+        __syncthreads();
+        const WcSlot w = wc_slot_of(wc, nframes, b);
+        for (int q = tid; q < RS_WC_H; q += RS_THREADS) w.cnt[q] = 0;
+        for (int q = tid; q < 5 * RS_WC_H; q += RS_THREADS) w.hyp[q] = q < 5 * iters ? hyp[q] : 0.0f;   // (validity word 0 beyond the iterations)
+        for (int q = tid; q < 4 * iters; q += RS_THREADS) w.hypd[q] = hypd[q];
+        return;
+    }
     const int inl = ransac_plane_wg<10, RS_THREADS, RS_GROUND_MAXH, RS_GROUND_PU, RsPoints, false, 1>(pts, iters, thr, seed0 + fid, plane, sred, swin, sbest);
     DBG_STAMP(6);
     if (tid == 0) {
@@ -1609,8 +1665,8 @@ __global__ __launch_bounds__(RS_THREADS) RS_VGPR_ATTR void ground_ransac_kernel(
                                                                    double *__restrict__ ground,
                                                                    int32_t *__restrict__ ninl,
                                                                    const int32_t *__restrict__ zcnt,
-                                                                   const int64_t *__restrict__ frame_ids) {
-    ground_ransac_body(ri_all, tm, P, zthr, max_pts, min_pts, ransac_n, iters, thr, seed0, raw, ground, ninl, zcnt, frame_ids, blockIdx.x, gridDim.x);
+                                                                   const int64_t *__restrict__ frame_ids, char *__restrict__ wc) {
+    ground_ransac_body(ri_all, tm, P, zthr, max_pts, min_pts, ransac_n, iters, thr, seed0, raw, ground, ninl, zcnt, frame_ids, blockIdx.x, gridDim.x, wc);
 }
 // the frames of several geometry groups in one launch (rpcc_compress_batch_mixed; fps_kernels.h: fps_regtab_planar_multi_kernel)
 struct RansacGroupArgs {
@@ -1620,6 +1676,8 @@ struct RansacGroupArgs {
     double *ground;
     const int32_t *zcnt;
     const int64_t *frame_ids;
+    char *wc;        // the group's scratch for deferred whole-cloud fits (flags, slots) or nullptr: such frames are fitted by their own workgroup
+    int iters;       // hypotheses per fit
 };
 struct RansacMulti {
     int n, first[RPCC_MAX_GROUPS + 1];
@@ -1630,7 +1688,104 @@ __global__ __launch_bounds__(RS_THREADS) RS_VGPR_ATTR void ground_ransac_multi_k
     const int gi = multi_group_of(m.first, m.n, blockIdx.x);
     const RansacGroupArgs &a = m.a[gi];
     ground_ransac_body(a.ri_all, a.tm, a.P, zthr, max_pts, min_pts, ransac_n, iters, thr, a.seed0, 0, a.ground, nullptr, a.zcnt, a.frame_ids,
-                       (int)blockIdx.x - m.first[gi], m.first[gi + 1] - m.first[gi]);
+                       (int)blockIdx.x - m.first[gi], m.first[gi + 1] - m.first[gi], a.wc);
+}
+
+// ---- the deferred whole-cloud fits (frames with fewer than min_pts candidates; ground_ransac_body) -------------------------------------------
+// Scoring: every listed frame's P pixels against its <= 104 planes, spread over the chip -- a workgroup takes 2048 pixels of one frame, a wavefront
+// loads 8 per lane and runs all planes over them, two per packed instruction (plane_inlier() twice: each half rounds like the scalar operation),
+// counts per plane meet in LDS and then in the slot (integers: any order).  The same tests as ransac_plane_wg's walk over a cloud in memory.
+#define WC_SCORE_WGS 1024
+#define WC_SCORE_THREADS 256
+#define WC_PU 8
+#define WC_LIST 1024      // frames whose marks a workgroup lists at a time
+__global__ __launch_bounds__(WC_SCORE_THREADS) void ground_wc_score_kernel(const RansacMulti m, double thr) {
+    __shared__ float s_hyp[RS_WC_H * 5];
+    __shared__ int s_cnt[RS_WC_H];
+    __shared__ uint16_t s_list[WC_LIST];
+    __shared__ int s_n;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float thr_f = (float)thr;
+    for (int gi = 0; gi < m.n; gi++) {
+        const RansacGroupArgs &a = m.a[gi];
+        if (a.wc == nullptr) continue;
+        const int nframes = m.first[gi + 1] - m.first[gi];
+        for (int fb = 0; fb < nframes; fb += WC_LIST) {   // WC_LIST frames at a time
+        // the marked frames in ascending order (every workgroup finds the same list: the first wavefront, 64 flags per step)
+        __syncthreads();
+        if (wave == 0) {
+            int nl = 0;
+            for (int f0 = fb; f0 < min(nframes, fb + WC_LIST); f0 += 64) {
+                const bool on = f0 + lane < nframes && wc_flags_of(a.wc)[f0 + lane] != 0;
+                const unsigned long long mk = __ballot(on);
+                if (on) s_list[nl + __popcll(mk & ((1ull << lane) - 1ull))] = (uint16_t)(f0 + lane - fb);
+                nl += (int)__popcll(mk);
+            }
+            if (lane == 0) s_n = nl;
+        }
+        __syncthreads();
+        const int nl = s_n;
+        if (nl == 0) continue;   // (the common case: every frame of the batch had its ground candidates)
+        const int P = a.P, tiles = (P + WC_SCORE_THREADS * WC_PU - 1) / (WC_SCORE_THREADS * WC_PU), iters = a.iters;
+        for (int item = blockIdx.x; item < nl * tiles; item += gridDim.x) {
+            const int li = item / tiles, t = item - li * tiles, b = fb + (int)s_list[li];
+            const WcSlot w = wc_slot_of(a.wc, nframes, b);
+            __syncthreads();
+            for (int q = tid; q < 5 * iters; q += WC_SCORE_THREADS) s_hyp[q] = w.hyp[q];
+            if (tid < RS_WC_H) s_cnt[tid] = 0;
+            __syncthreads();
+            const float *ri = a.ri_all + (int64_t)b * P;
+            const int i0 = t * (WC_SCORE_THREADS * WC_PU) + wave * 64 * WC_PU + lane;
+            float x[WC_PU], y[WC_PU], z[WC_PU];
+#pragma unroll
+            for (int u = 0; u < WC_PU; u++) {
+                const int i = min(i0 + 64 * u, P - 1);
+                const float r = ri[i];
+                x[u] = r * a.tm[3 * i]; y[u] = r * a.tm[3 * i + 1]; z[u] = r * a.tm[3 * i + 2];   // RsPoints::getf
+                if (i0 + 64 * u >= P) x[u] = __builtin_inff();   // past the end: inf or NaN on every plane, never an inlier
+            }
+            for (int q = 0; q < iters; q += 2) {
+                const int q1 = min(q + 1, iters - 1);
+                const bool ok0 = s_hyp[5 * q + 4] != 0.0f, ok1 = q + 1 < iters && s_hyp[5 * q1 + 4] != 0.0f;
+                const rs_v2f pa = {s_hyp[5 * q], s_hyp[5 * q1]}, pb = {s_hyp[5 * q + 1], s_hyp[5 * q1 + 1]}, pc = {s_hyp[5 * q + 2], s_hyp[5 * q1 + 2]},
+                             pd = {ok0 ? s_hyp[5 * q + 3] : __builtin_inff(), ok1 ? s_hyp[5 * q1 + 3] : __builtin_inff()};
+                int c0 = 0, c1 = 0;
+#pragma unroll
+                for (int u = 0; u < WC_PU; u++) {
+                    const rs_v2f xx = {x[u], x[u]}, yy = {y[u], y[u]}, zz = {z[u], z[u]};
+                    const rs_v2f dd = ((pa * xx + pb * yy) + pc * zz) + pd;
+                    c0 += (int)__popcll(__ballot(fabsf(dd.x) < thr_f));
+                    c1 += (int)__popcll(__ballot(fabsf(dd.y) < thr_f));
+                }
+                if (lane == 0) { if (c0) atomicAdd(&s_cnt[q], c0); if (c1 && q + 1 < iters) atomicAdd(&s_cnt[q + 1], c1); }
+            }
+            __syncthreads();
+            if (tid < iters && s_cnt[tid]) atomicAdd(&w.cnt[tid], s_cnt[tid]);
+        }
+        }
+    }
+}
+// Winner and refit: one workgroup per frame, at work only for a marked one; most inliers among the valid hypotheses, the lower one among
+// equals, then ransac_refit on every pixel -- the ordered sums of the specification, 16 points per thread in flight.
+__global__ __launch_bounds__(RS_NT) void ground_wc_refit_kernel(const RansacMulti m, double thr) {
+    __shared__ double sred[6 * RS_NT];
+    const int gi = multi_group_of(m.first, m.n, blockIdx.x);
+    const RansacGroupArgs &a = m.a[gi];
+    const int b = (int)blockIdx.x - m.first[gi], nframes = m.first[gi + 1] - m.first[gi];
+    if (a.wc == nullptr || wc_flags_of(a.wc)[b] == 0) return;
+    const WcSlot w = wc_slot_of(a.wc, nframes, b);
+    const int iters = a.iters;
+    int wcnt = -1, wh = 0;
+    for (int q = 0; q < iters; q++) {
+        const int c = w.cnt[q];
+        if (w.hyp[5 * q + 4] != 0.0f && c > wcnt) { wcnt = c; wh = q; }
+    }
+    double plane[4] = {0, 0, 1, 0};
+    if (wcnt >= 0) { plane[0] = w.hypd[4 * wh]; plane[1] = w.hypd[4 * wh + 1]; plane[2] = w.hypd[4 * wh + 2]; plane[3] = w.hypd[4 * wh + 3]; }
+    RsPoints pts;
+    pts.ri = a.ri_all + (int64_t)b * a.P; pts.tm = a.tm; pts.lds = nullptr; pts.n = a.P; pts.raw = 0;
+    ransac_refit<16>(pts, wcnt, (float)thr, plane, sred);
+    if (threadIdx.x == 0) { a.ground[4 * b] = plane[0]; a.ground[4 * b + 1] = plane[1]; a.ground[4 * b + 2] = plane[2]; a.ground[4 * b + 3] = plane[3]; }
 }
 
 #define RS_GROUND_MAX_PTS 5000
@@ -1638,15 +1793,34 @@ __global__ __launch_bounds__(RS_THREADS) RS_VGPR_ATTR void ground_ransac_multi_k
 static inline size_t ground_ransac_lds_bytes() {
     return (size_t)6 * RS_NT * 8 + (64 + RS_MAX_HYP * 4) * 8 + 32 * 4 + 16 * 4 + (size_t)RS_GROUND_MAX_PTS * 3 * 4;
 }
+// the two launches behind the per-frame fits: nothing to do (a read of the list's length per workgroup) unless a frame of the batch lacked ground candidates
+static int launch_ground_wc(const RansacMulti &m, hipStream_t st) {
+    bool any = false;
+    for (int i = 0; i < m.n; i++) any = any || m.a[i].wc != nullptr;
+    if (!any) return RPCC_OK;
+    ground_wc_score_kernel<<<WC_SCORE_WGS, WC_SCORE_THREADS, 0, st>>>(m, 0.1);
+    ground_wc_refit_kernel<<<m.first[m.n], RS_NT, 0, st>>>(m, 0.1);
+    LAUNCH_CHECK();
+    return RPCC_OK;
+}
 static int launch_ground_ransac(const float *ri, const float *tm, int B, int P, uint32_t seed0, bool raw, double *ground,
                                 int32_t *ninl, hipStream_t st, const int32_t *zcnt = nullptr,
                                 const int64_t *frame_ids = nullptr) {
     const int max_pts = RS_GROUND_MAX_PTS, min_pts = RS_GROUND_MIN_PTS;
     const size_t sh = ground_ransac_lds_bytes();
     HIP_TRY(ensure_dyn_lds(reinterpret_cast<const void *>(&ground_ransac_kernel), (int)sh));
+    // (with the projection's hand-off comes room for the deferred whole-cloud fits; the stand-alone entry has none: such a frame is fitted by its workgroup)
+    const bool defer = zcnt != nullptr && !raw && ninl == nullptr;
+    char *wc = defer ? rs_wc_of(zcnt, B, P) : nullptr;
     ground_ransac_kernel<<<B, RS_THREADS, sh, st>>>(ri, tm, P, -1.5f, max_pts, min_pts, 10, 100, 0.1, seed0, raw ? 1 : 0,
-                                                    ground, ninl, zcnt, frame_ids);
+                                                    ground, ninl, zcnt, frame_ids, wc);
     LAUNCH_CHECK();
+    if (defer) {
+        RansacMulti m;
+        m.n = 1; m.first[0] = 0; m.first[1] = B;
+        m.a[0] = {ri, tm, P, seed0, ground, zcnt, frame_ids, wc, 100};
+        return launch_ground_wc(m, st);
+    }
     return RPCC_OK;
 }
 static int launch_ground_ransac_multi(const RansacMulti &m, hipStream_t st) {
@@ -1654,7 +1828,7 @@ static int launch_ground_ransac_multi(const RansacMulti &m, hipStream_t st) {
     HIP_TRY(ensure_dyn_lds(reinterpret_cast<const void *>(&ground_ransac_multi_kernel), (int)sh));
     ground_ransac_multi_kernel<<<m.first[m.n], RS_THREADS, sh, st>>>(m, -1.5f, RS_GROUND_MAX_PTS, RS_GROUND_MIN_PTS, 10, 100, 0.1);
     LAUNCH_CHECK();
-    return RPCC_OK;
+    return launch_ground_wc(m, st);
 }
 
 extern "C" int rpcc_ground_ransac(const float *ri, const float *tm, int B, int P, uint32_t seed, const int64_t *frame_ids,
@@ -3327,7 +3501,7 @@ static BatchPlan plan_batch(const rpcc_batch_io *io, int Bs, int64_t npts, rpcc_
     // flags are marked with an epoch kept in the workspace (BatchInit), so the batch has no initialisation launch.
     p.epoch = reinterpret_cast<int32_t *>(ws + p.L.bytes);   // the 256 bytes between the model part and the projection scratch
     p.bi.tm = io->tm; p.bi.soa = p.rays_soa; p.bi.P = P; p.bi.info = io->info; p.bi.B = Bs; p.bi.on = 1;
-    p.bi.z0 = {reinterpret_cast<uint32_t *>(p.zcnt), p.zcnt ? Bs * (RS_CHUNKS + 1) : 0};
+    p.bi.z0 = {reinterpret_cast<uint32_t *>(p.zcnt), p.zcnt ? (int)rs_count_words(Bs) : 0};
     p.bi.z1 = {reinterpret_cast<uint32_t *>(p.L.sums), (int)(((char *)p.L.hist - (char *)p.L.sums) / 4)};
     // model rows + the tile offsets of the ordered scatter (built once, used by the plane list and by the quantiser)
     p.extra = reinterpret_cast<char *>(p.tiletab) + (((size_t)Bs * FPS_TAB_ROWS * ((P + 31) / 32 + 4096) * 4 + 255) & ~(size_t)255) + 256;
@@ -3439,7 +3613,8 @@ static int mixed_ground(const BatchPlan *pl, int G, hipStream_t st) {
     for (int i = 0; i < G; i++) {
         if (!pl[i].fit_ground) continue;
         const rpcc_batch_io *io = pl[i].io;
-        m.a[m.n] = {io->ri, io->tm, pl[i].P, (uint32_t)io->ground_seed, io->ground, pl[i].zcnt, io->frame_ids};
+        m.a[m.n] = {io->ri, io->tm, pl[i].P, (uint32_t)io->ground_seed, io->ground, pl[i].zcnt, io->frame_ids,
+                    pl[i].zcnt ? rs_wc_of(pl[i].zcnt, pl[i].Bs, pl[i].P) : nullptr, 100};
         m.first[m.n + 1] = m.first[m.n] + pl[i].Bs;
         m.n++;
     }

@@ -1349,6 +1349,71 @@ def test_ground_fit_hand_over_equals_the_fit_alone(env):
             assert _beq(gms[i].cpu().numpy(), np.asarray(orc.ground_model(ri, tm, seed=3 + 17 + i), np.float64)), (H, W, i)
 
 
+def test_ground_less_frames_are_fitted_chip_wide_to_the_same_plane(env):
+    """A sweep with fewer than 800 ground candidates is fitted on EVERY pixel (segment_utils.py:105-106).  Inside the fused calls such a frame only draws
+    its hypotheses in the per-frame launch; ground_wc_score_kernel scores them with workgroups all over the chip and ground_wc_refit_kernel refits
+    (a whole-cloud fit inside one workgroup lasts 1 ms and the launch lasts as long as its slowest frame).  The planes must be those of rpcc_ground_ransac
+    run alone (the one-workgroup form) and of the oracle, bit for bit: batches with one, several and only ground-less sweeps, the mixed-geometry call,
+    and the ground stage issued twice (nothing left over from the first run)."""
+    torch, ops, orc, synth = env["torch"], env["ops"], env["orc"], env["synth"]
+    cases = {}
+    for name, (H, W, vmax, vmin) in (("64", (64, 2048, 2.0, -24.9)), ("16", (16, 1800, 15.0, -15.0)), ("32", (32, 2250, 10.67, -30.67))):
+        g = orc.LidarGeom(H, W, 360.0, vmax, vmin)
+        tm = ops.transform_map(g.H, g.W, g.horizontal_FOV, g.vertical_max, g.vertical_min)
+        geom = ops.make_geom(g.H, g.W, g.horizontal_FOV, g.vertical_max, g.vertical_min)
+        full = [synth.make_frame(5200 + i, H, W, vmax_deg=vmax, vmin_deg=vmin).numpy() for i in range(6)]
+        bare = [f[f[:, 2] > -1.45] for f in full]                      # no ground return at all
+        few = [np.concatenate([b, f[f[:, 2] < -1.5][:500]]) for b, f in zip(bare, full)]   # 500 candidates: below the 800
+        cases[name] = (g, geom, tm, full, bare, few)
+    for name, pick in (("64", lambda full, bare, few: [full[0], bare[1], full[2], full[3], few[4], full[5]]),       # two of six
+                       ("64", lambda full, bare, few: bare + few),                                                   # all twelve
+                       ("16", lambda full, bare, few: [bare[0]] + full[1:]), ("32", lambda full, bare, few: [full[0], few[1], bare[2]])):
+        g, geom, tm, full, bare, few = cases[name]
+        frames = pick(full, bare, few)
+        n = len(frames)
+        offs = np.zeros(n + 1, np.int64)
+        offs[1:] = np.cumsum([f.shape[0] for f in frames])
+        fid = _to(env, np.arange(n, dtype=np.int64) + 40)
+        buf = ops.BatchBuffers(n, geom, 20, env["dev"])
+        gms = torch.zeros((n, 4), dtype=torch.float64, device=env["dev"])
+        xyz, d_offs, d_tm = _to(env, np.concatenate(frames)), _to(env, offs), _to(env, tm)
+        ops.compress_batch(xyz, d_offs, d_tm, gms, buf, ground_seed=5, frame_ids=fid)
+        alone, _ = ops.ground_ransac(buf.ri, d_tm, seed=5, frame_ids=fid)
+        assert _beq(gms.cpu().numpy(), alone.cpu().numpy()), (name, n)
+        for i in range(min(n, 3)):
+            assert _beq(gms[i].cpu().numpy(), np.asarray(orc.ground_model(orc.project(frames[i], g), tm, seed=5 + 40 + i), np.float64)), (name, i)
+        # the ground stage again on the same buffers (twice), then the rest: the outputs of the single call
+        seg0, q0, nz0 = buf.seg.clone(), buf.q16.clone(), buf.nnz.clone()
+        gms2 = torch.zeros_like(gms)
+        buf2 = ops.BatchBuffers(n, geom, 20, env["dev"])
+        kw = dict(ground_seed=5, frame_ids=fid)
+        ops.compress_batch_stages(ops.STAGE_PROJECT | ops.STAGE_GROUND, xyz, d_offs, d_tm, gms2, buf2, **kw)
+        ops.compress_batch_stages(ops.STAGE_GROUND, xyz, d_offs, d_tm, gms2, buf2, **kw)
+        ops.compress_batch_stages(127 & ~(ops.STAGE_PROJECT | ops.STAGE_GROUND), xyz, d_offs, d_tm, gms2, buf2, **kw)
+        assert _beq(gms2.cpu().numpy(), gms.cpu().numpy()) and torch.equal(buf2.seg, seg0) and torch.equal(buf2.nnz, nz0), name
+        assert all(torch.equal(buf2.q16[i, :int(nz0[i])], q0[i, :int(nz0[i])]) for i in range(n))
+    # the mixed-geometry call: one launch over the groups' frames, ground-less sweeps in two of three groups
+    groups, want = [], []
+    for name, sel in (("64", lambda full, bare, few: [full[0], bare[1]]), ("16", lambda full, bare, few: [bare[0], few[1], full[2]]),
+                      ("32", lambda full, bare, few: [full[0], full[1]])):
+        g, geom, tm, full, bare, few = cases[name]
+        frames = sel(full, bare, few)
+        n = len(frames)
+        offs = np.zeros(n + 1, np.int64)
+        offs[1:] = np.cumsum([f.shape[0] for f in frames])
+        fid = _to(env, np.arange(n, dtype=np.int64) + 7)
+        buf = ops.BatchBuffers(n, geom, 20, env["dev"], general=True)
+        groups.append(dict(xyz=_to(env, np.concatenate(frames)), offsets=_to(env, offs), tm=_to(env, tm), ground=torch.zeros((n, 4), dtype=torch.float64, device=env["dev"]),
+                           buf=buf, ground_seed=9, frame_ids=fid))
+        want.append((frames, g, tm))
+    ops.compress_batch_mixed(groups)
+    torch.cuda.synchronize()
+    for gr, (frames, g, tm) in zip(groups, want):
+        alone, _ = ops.ground_ransac(gr["buf"].ri, gr["tm"], seed=9, frame_ids=gr["frame_ids"])
+        assert _beq(gr["ground"].cpu().numpy(), alone.cpu().numpy()), g.H
+        assert _beq(gr["ground"][1].cpu().numpy(), np.asarray(orc.ground_model(orc.project(frames[1], g), tm, seed=9 + 7 + 1), np.float64)), g.H
+
+
 def test_compress_batch_stages_equal_the_single_call(env):
     """rpcc_compress_batch_stages: the batch's stages issued one by one (and in two groups on two streams joined by an event) give the outputs of
     rpcc_compress_batch; all bits at once is the same call."""
