@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256) void project_finalize_kernel(uint32_t *__restr
 // sequences and seven correctly rounded divisions -- but only the INTEGER pixel (row, col) is kept.  The fast
 // path computes the two angles with ~1e-6 rad accuracy (hardware rcp/sqrt, fma Horner polynomial), and
 // accepts its pixel only when both pre-rounding coordinates are farther from a rounding boundary than a
-// margin of 8x the worst-case discrepancy to the reference arithmetic (error budget: DESIGN.md "Projection").
+// margin of PIX_MARGIN x the worst-case discrepancy to the reference arithmetic (error budget: DESIGN.md "Projection").
 // Points that are not certain (about 3 % for 64x2048; every point with a special value, a zero depth or
 // column 0 / W) are queued in LDS and recomputed by the exact sequence.  The depth itself -- the payload --
 // is always the reference's sqrtf(x*x + y*y + z*z).  rpcc_project_fastpath_check() counts disagreements
@@ -321,14 +321,20 @@ struct PixFastCfg {
 };
 #define PIX_ANGLE_ERR 2.0e-6f
 #define PIX_REL_ERR 6.0e-7f
+// Safety factor on the analytic budget.  8 until round 5; the largest discrepancy ever observed (8e8 points per geometry, the adversarial sets of
+// test_projection_fast_path_never_disagrees) is 0.13 of the budget in the column coordinate and 0.17 in the row, so 4 still keeps the margin 24-30 x
+// above it -- and halves the points that take the exact sequence.  That matters for REAL sweeps only: the synthetic generator jitters a ray inside
+// +-0.45 of its cell, 0.05 % of its points are uncertain at any factor, while a stored sweep's points are spread evenly over the cell (3.4 % at 8:
+// the exact sequence was a quarter of the pixel kernel's instructions on the example sweep, 68.7 M against 52.6 M on synthetic ones).
+#define PIX_MARGIN 4.0f
 static PixFastCfg pix_fast_cfg(const rpcc_geom g) {
     PixFastCfg c;
     const float vres = (g.vertical_max - g.vertical_min) / (float)(g.H - 1);
     c.kcol = (float)g.W / g.horizontal_fov;
     c.krow = 1.0f / vres;
     c.vmin = g.vertical_min;
-    const float mcol = 8.0f * (PIX_ANGLE_ERR * fabsf(c.kcol) + PIX_REL_ERR * (float)g.W);
-    const float mrow = 8.0f * ((PIX_ANGLE_ERR + 1.0e-7f) * fabsf(c.krow) + PIX_REL_ERR * ((float)g.H + fabsf(c.vmin * c.krow)));
+    const float mcol = PIX_MARGIN * (PIX_ANGLE_ERR * fabsf(c.kcol) + PIX_REL_ERR * (float)g.W);
+    const float mrow = PIX_MARGIN * ((PIX_ANGLE_ERR + 1.0e-7f) * fabsf(c.krow) + PIX_REL_ERR * ((float)g.H + fabsf(c.vmin * c.krow)));
     c.ccol = 0.5f - mcol;
     c.crow = 0.5f - mrow;
     c.on = (g.H >= 2 && g.W >= 2 && g.horizontal_fov > 0.0f && vres > 0.0f && mcol < 0.2f && mrow < 0.2f &&
@@ -2496,10 +2502,12 @@ __device__ __forceinline__ int assign_label(float r, float tx, float ty, float t
 #define ASSIGN_TILES_PER_WAVE (4 / ASSIGN_PX)
 #define ASSIGN_WAVES 4   // wavefronts per workgroup (they share the centre table in LDS, nothing else)
 #define ASSIGN_VGPR_ATTR
+// L: label type (uint8_t: cluster_num <= 254; uint16_t: up to RPCC_MAX_CLUSTERS_MID), NR: screening rounds of 64 centres (4 / 16)
+template <class L = uint8_t, int NR = 4>
 __global__ __launch_bounds__(64 * ASSIGN_WAVES) ASSIGN_VGPR_ATTR void assign_kernel(const float *__restrict__ ri, const float *__restrict__ tm,
                                                      const double *__restrict__ ground,
                                                      const float *__restrict__ centers, int H, int W, int M,
-                                                     uint8_t *__restrict__ seg, const float *__restrict__ temp) {   // temp: the FPS state after its last iteration, or NULL
+                                                     L *__restrict__ seg, const float *__restrict__ temp) {   // temp: the FPS state after its last iteration, or NULL
     extern __shared__ __attribute__((aligned(16))) float4 cen4[];  // [M] (x,y,z,0)
     const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int P = H * W;
@@ -2507,7 +2515,7 @@ __global__ __launch_bounds__(64 * ASSIGN_WAVES) ASSIGN_VGPR_ATTR void assign_ker
     const int tcols = (W + 31) >> 5, ntile = ((H + ASSIGN_ROWS - 1) / ASSIGN_ROWS) * tcols;
     const int t0 = (blockIdx.x * ASSIGN_WAVES + wave) * ASSIGN_TILES_PER_WAVE;
     const float *ri_b = ri + (int64_t)b * P;
-    uint8_t *seg_b = seg + (int64_t)b * P;
+    L *seg_b = seg + (int64_t)b * P;
     // the tile's loads go out first (unconditional, clamped), then the centres: one trip to memory before the barrier, not two
     bool valid[ASSIGN_PX];
     int p[ASSIGN_PX];
@@ -2551,7 +2559,7 @@ __global__ __launch_bounds__(64 * ASSIGN_WAVES) ASSIGN_VGPR_ATTR void assign_ker
         if (__ballot(any_live) == 0ull) {  // nothing but empty pixels
 #pragma unroll
             for (int e = 0; e < ASSIGN_PX; e++)
-                if (valid[e]) st_at(seg_b, (uint32_t)p[e], (uint8_t)1);
+                if (valid[e]) st_at(seg_b, (uint32_t)p[e] * (uint32_t)sizeof(L), (L)1);
             continue;
         }
         float lo0 = inf, lo1 = inf, lo2 = inf, hi0 = -inf, hi1 = -inf, hi2 = -inf;
@@ -2585,9 +2593,9 @@ __global__ __launch_bounds__(64 * ASSIGN_WAVES) ASSIGN_VGPR_ATTR void assign_ker
         reach = dpp_max_f32_native(reach);
         const bool bounded = reach < inf;   // (wave-uniform) otherwise: the box bound min_j dmax_j of the header
         // screen the centres: lane handles centres lane, lane+64, ...
-        float my_dmin[4], upper = inf;
+        float my_dmin[NR], upper = inf;
 #pragma unroll
-        for (int rd = 0; rd < 4; rd++) {
+        for (int rd = 0; rd < NR; rd++) {
             const int k = rd * 64 + lane;
             my_dmin[rd] = inf;
             if (rd * 64 < M && k < M) {
@@ -2603,13 +2611,13 @@ __global__ __launch_bounds__(64 * ASSIGN_WAVES) ASSIGN_VGPR_ATTR void assign_ker
         }
         if (!bounded) upper = dpp_min_f32_native(upper);
         const float cut = (bounded ? reach : upper) * 1.000002f;
-        unsigned long long surv_m[4];
+        unsigned long long surv_m[NR], surv_any = 0ull;
 #pragma unroll
-        for (int rd = 0; rd < 4; rd++) surv_m[rd] = rd * 64 < M ? __ballot(my_dmin[rd] <= cut) : 0ull;
-        if ((surv_m[0] | surv_m[1] | surv_m[2] | surv_m[3]) == 0ull) {   // no centre within reach of any pixel: ground (0), empty pixels 1
+        for (int rd = 0; rd < NR; rd++) { surv_m[rd] = rd * 64 < M ? __ballot(my_dmin[rd] <= cut) : 0ull; surv_any |= surv_m[rd]; }
+        if (surv_any == 0ull) {   // no centre within reach of any pixel: ground (0), empty pixels 1
 #pragma unroll
             for (int e = 0; e < ASSIGN_PX; e++)
-                if (valid[e]) st_at(seg_b, (uint32_t)p[e], (uint8_t)(r[e] == 0.0f ? 1 : 0));
+                if (valid[e]) st_at(seg_b, (uint32_t)p[e] * (uint32_t)sizeof(L), (L)(r[e] == 0.0f ? 1 : 0));
             continue;
         }
         float m1[ASSIGN_PX], m2[ASSIGN_PX];
@@ -2622,7 +2630,7 @@ __global__ __launch_bounds__(64 * ASSIGN_WAVES) ASSIGN_VGPR_ATTR void assign_ker
             xv[e2] = rs_v2f{x[2 * e2], x[2 * e2 + 1]}; yv[e2] = rs_v2f{y[2 * e2], y[2 * e2 + 1]}; zv[e2] = rs_v2f{z[2 * e2], z[2 * e2 + 1]};
         }
 #pragma unroll
-        for (int rd = 0; rd < 4; rd++) {
+        for (int rd = 0; rd < NR; rd++) {
             if (rd * 64 >= M) break;
             unsigned long long surv = surv_m[rd];
             while (surv) {
@@ -2651,7 +2659,7 @@ __global__ __launch_bounds__(64 * ASSIGN_WAVES) ASSIGN_VGPR_ATTR void assign_ker
         for (int e = 0; e < ASSIGN_PX; e++) {
             int label = assign_label(r[e], tx[e], ty[e], tz[e], x[e], y[e], z[e], m1[e], m2[e], k1[e], cen4, G);
             if (r[e] == 0.0f) label = 1;
-            if (valid[e]) st_at(seg_b, (uint32_t)p[e], (uint8_t)label);
+            if (valid[e]) st_at(seg_b, (uint32_t)p[e] * (uint32_t)sizeof(L), (L)label);
         }
     }
 }
@@ -2660,7 +2668,7 @@ static int launch_assign(const float *ri, const float *tm, const double *ground,
                          int W, int M, uint8_t *seg, hipStream_t st, const float *temp = nullptr) {
     const int ntile = ((H + ASSIGN_ROWS - 1) / ASSIGN_ROWS) * ((W + 31) / 32);
     const dim3 grid((ntile + ASSIGN_WAVES * ASSIGN_TILES_PER_WAVE - 1) / (ASSIGN_WAVES * ASSIGN_TILES_PER_WAVE), B);
-    assign_kernel<<<grid, 64 * ASSIGN_WAVES, (size_t)M * sizeof(float4), st>>>(ri, tm, ground, centers, H, W, M, seg, temp);
+    assign_kernel<uint8_t, 4><<<grid, 64 * ASSIGN_WAVES, (size_t)M * sizeof(float4), st>>>(ri, tm, ground, centers, H, W, M, seg, temp);
     LAUNCH_CHECK();
     return RPCC_OK;
 }
@@ -2859,15 +2867,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void model_scan_multi_kernel(const Mu
 // sums for the range total), the others add themselves to LDS directly: integer sums, any order.  The fixed-point value of a
 // range r in [2^-5, 2^8) is read off its bit pattern: r * 2^28 = mantissa << (exponent + 5), an integer below 2^36, kept as
 // an 18-bit low part and a high part whose sums over a wavefront stay below 2^32.
-template <bool VEC>
-__device__ __forceinline__ void model_hist_body(const float *__restrict__ ri, const uint8_t *__restrict__ seg,
+template <bool VEC, class L = uint8_t>
+__device__ __forceinline__ void model_hist_body(const float *__restrict__ ri, const L *__restrict__ seg,
                                                 int P, int KP, int T, int64_t *__restrict__ sums,
                                                 int32_t *__restrict__ flags, uint32_t *__restrict__ hist, const int b, const int t) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned long long *ssum = reinterpret_cast<unsigned long long *>(smem_raw);  // [KP]
     uint32_t *scnt = reinterpret_cast<uint32_t *>(ssum + KP);                      // [KP]
     const int lane = threadIdx.x & 63;
-    const uint8_t *seg_b = seg + (int64_t)b * P;
+    const L *seg_b = seg + (int64_t)b * P;
     const float *ri_b = ri != nullptr ? ri + (int64_t)b * P : nullptr;
     const bool want_sum = ri != nullptr;
     const int p0 = t * TILE + 4 * (int)threadIdx.x;
@@ -2877,8 +2885,13 @@ __device__ __forceinline__ void model_hist_body(const float *__restrict__ ri, co
     // all loads first (unconditional, clamped)
     if (VEC) {
         const uint32_t q = (uint32_t)(nval > 0 ? p0 : 0);
-        const uint32_t l4 = ld_at(reinterpret_cast<const uint32_t *>(seg_b), q);
-        lab[0] = (int)(l4 & 255u); lab[1] = (int)((l4 >> 8) & 255u); lab[2] = (int)((l4 >> 16) & 255u); lab[3] = (int)(l4 >> 24);
+        if (sizeof(L) == 1) {
+            const uint32_t l4 = ld_at(reinterpret_cast<const uint32_t *>(seg_b), q);
+            lab[0] = (int)(l4 & 255u); lab[1] = (int)((l4 >> 8) & 255u); lab[2] = (int)((l4 >> 16) & 255u); lab[3] = (int)(l4 >> 24);
+        } else {   // four 16-bit labels: one 8-byte load
+            const uint2 l8 = ld_at(reinterpret_cast<const uint2 *>(seg_b), q * 2u);
+            lab[0] = (int)(l8.x & 0xFFFFu); lab[1] = (int)(l8.x >> 16); lab[2] = (int)(l8.y & 0xFFFFu); lab[3] = (int)(l8.y >> 16);
+        }
         if (want_sum) {
             const uint4 r4 = ld_at(reinterpret_cast<const uint4 *>(ri_b), q * 4u);
             rb[0] = r4.x; rb[1] = r4.y; rb[2] = r4.z; rb[3] = r4.w;
@@ -2889,7 +2902,7 @@ __device__ __forceinline__ void model_hist_body(const float *__restrict__ ri, co
 #pragma unroll
         for (int e = 0; e < 4; e++) {
             const uint32_t gp = (uint32_t)min(p0 + e, P - 1);
-            lab[e] = ld_at(seg_b, gp);
+            lab[e] = ld_at(seg_b, gp * (uint32_t)sizeof(L));
             rb[e] = want_sum ? f2u(ld_at(ri_b, gp * 4u)) : 0x3F800000u;
         }
     }
@@ -2959,11 +2972,11 @@ __device__ __forceinline__ void model_hist_body(const float *__restrict__ ri, co
         if (ssum[k]) atomicAdd(reinterpret_cast<unsigned long long *>(&sums[(int64_t)b * KP + k]), ssum[k]);
     }
 }
-template <bool VEC>
-__global__ __launch_bounds__(256) void model_hist_kernel(const float *__restrict__ ri, const uint8_t *__restrict__ seg,
+template <bool VEC, class L = uint8_t>
+__global__ __launch_bounds__(256) void model_hist_kernel(const float *__restrict__ ri, const L *__restrict__ seg,
                                                          int P, int KP, int T, int64_t *__restrict__ sums,
                                                          int32_t *__restrict__ flags, uint32_t *__restrict__ hist) {
-    model_hist_body<VEC>(ri, seg, P, KP, T, sums, flags, hist, blockIdx.y, blockIdx.x);
+    model_hist_body<VEC, L>(ri, seg, P, KP, T, sums, flags, hist, blockIdx.y, blockIdx.x);
 }
 struct HistGroup {
     const float *ri;
@@ -3046,9 +3059,9 @@ __device__ __forceinline__ void segment_prefix(uint32_t *segcnt, int SEGP, const
 // before + in the lanes before (four compare masks per label of the wavefront, counted with mbcnt) + in the lane's own
 // earlier pixels.  The cross-wavefront prefix is four counters per label, one thread per label.  (Until round 3 the tile
 // was 16 segments of 64 pixels, one pixel per lane and pass: a 16 x K counter matrix, cleared and prefix-scanned per tile.)
-template <bool RESIDUAL_ONLY, bool VEC>
+template <bool RESIDUAL_ONLY, bool VEC, class L = uint8_t>
 __device__ __forceinline__ void predict_quantize_body(const float *__restrict__ ri, const float *__restrict__ tm,
-                                                      const uint8_t *__restrict__ seg,
+                                                      const L *__restrict__ seg,
                                                       const float *__restrict__ model,
                                                       const uint32_t *__restrict__ hist, float acc,
                                                       const float *__restrict__ label_acc,
@@ -3082,8 +3095,13 @@ __device__ __forceinline__ void predict_quantize_body(const float *__restrict__ 
     float rv[4], ray[12], rin[4];
     if (VEC) {
         const uint32_t q = (uint32_t)(nval > 0 ? p0 : 0);
-        const uint32_t l4 = ld_at(reinterpret_cast<const uint32_t *>(seg), q);
-        lab[0] = (int)(l4 & 255u); lab[1] = (int)((l4 >> 8) & 255u); lab[2] = (int)((l4 >> 16) & 255u); lab[3] = (int)(l4 >> 24);
+        if (sizeof(L) == 1) {
+            const uint32_t l4 = ld_at(reinterpret_cast<const uint32_t *>(seg), q);
+            lab[0] = (int)(l4 & 255u); lab[1] = (int)((l4 >> 8) & 255u); lab[2] = (int)((l4 >> 16) & 255u); lab[3] = (int)(l4 >> 24);
+        } else {   // four 16-bit labels: one 8-byte load
+            const uint2 l8 = ld_at(reinterpret_cast<const uint2 *>(seg), q * 2u);
+            lab[0] = (int)(l8.x & 0xFFFFu); lab[1] = (int)(l8.x >> 16); lab[2] = (int)(l8.y & 0xFFFFu); lab[3] = (int)(l8.y >> 16);
+        }
         if (RESIDUAL_ONLY) {
 #pragma unroll
             for (int e = 0; e < 4; e++) rv[e] = 0.0f;
@@ -3107,20 +3125,20 @@ __device__ __forceinline__ void predict_quantize_body(const float *__restrict__ 
 #pragma unroll
         for (int e = 0; e < 4; e++) {
             const uint32_t up = (uint32_t)min(p0 + e, P - 1);
-            lab[e] = ld_at(seg, up);
+            lab[e] = ld_at(seg, up * (uint32_t)sizeof(L));
             rv[e] = RESIDUAL_ONLY ? 0.0f : ld_at(ri, up * 4u);
             if (RESIDUAL_ONLY) { ray[3 * e] = ray[3 * e + 1] = ray[3 * e + 2] = 0.0f; }
             else { ray[3 * e] = ld_f32(tm, up * 12u); ray[3 * e + 1] = ld_f32(tm, up * 12u + 4u); ray[3 * e + 2] = ld_f32(tm, up * 12u + 8u); }
             rin[e] = residual_in ? ld_at(residual_in, up * 4u) : 0.0f;
         }
     }
-    // staging (K <= 256: one step each); model rows as 16-byte copies
-    if ((int)threadIdx.x < K) {
-        const uint32_t i = threadIdx.x;
+    // staging (byte labels: K <= 256, one step each); model rows as 16-byte copies
+    for (uint32_t i = threadIdx.x; i < (uint32_t)K; i += 256u) {   // (one trip for byte labels)
         smodel[i] = RESIDUAL_ONLY ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(model[4 * i], model[4 * i + 1], model[4 * i + 2], model[4 * i + 3]);
         soff[i] = hist[i];
         if (label_acc) sacc[i] = label_acc[i];
         wcnt[i] = 0u; wcnt[KP + i] = 0u; wcnt[2 * KP + i] = 0u; wcnt[3 * KP + i] = 0u;
+        if (sizeof(L) == 1) break;
     }
     __syncthreads();
     int qv[4], rank[4];
@@ -3176,10 +3194,10 @@ __device__ __forceinline__ void predict_quantize_body(const float *__restrict__ 
         if (lane == 0) wcnt[wave * KP + cur] = (uint32_t)total;
     }
     __syncthreads();
-    if ((int)threadIdx.x < K) {   // exclusive prefix over the four wavefronts, seeded with the tile's offset
-        const uint32_t i = threadIdx.x;
+    for (uint32_t i = threadIdx.x; i < (uint32_t)K; i += 256u) {   // exclusive prefix over the four wavefronts, seeded with the tile's offset
         const uint32_t c0 = wcnt[i], c1 = wcnt[KP + i], c2 = wcnt[2 * KP + i], base = soff[i];
         wcnt[i] = base; wcnt[KP + i] = base + c0; wcnt[2 * KP + i] = base + c0 + c1; wcnt[3 * KP + i] = base + c0 + c1 + c2;
+        if (sizeof(L) == 1) break;
     }
     __syncthreads();
 #pragma unroll
@@ -3192,9 +3210,9 @@ __device__ __forceinline__ void predict_quantize_body(const float *__restrict__ 
     }
 }
 
-template <bool RESIDUAL_ONLY, bool VEC>
+template <bool RESIDUAL_ONLY, bool VEC, class L = uint8_t>
 __global__ __launch_bounds__(256) void predict_quantize_kernel(const float *__restrict__ ri, const float *__restrict__ tm,
-                                                               const uint8_t *__restrict__ seg,
+                                                               const L *__restrict__ seg,
                                                                const float *__restrict__ model,
                                                                const uint32_t *__restrict__ hist, float acc,
                                                                const float *__restrict__ label_acc,
@@ -3202,7 +3220,7 @@ __global__ __launch_bounds__(256) void predict_quantize_kernel(const float *__re
                                                                int KP, int T, int16_t *__restrict__ q16,
                                                                int32_t *__restrict__ q32, float *__restrict__ pred_out,
                                                                int32_t *__restrict__ epoch_inc) {
-    predict_quantize_body<RESIDUAL_ONLY, VEC>(ri, tm, seg, model, hist, acc, label_acc, residual_in, P, M, KP, T, q16, q32, pred_out, epoch_inc, blockIdx.y, blockIdx.x);
+    predict_quantize_body<RESIDUAL_ONLY, VEC, L>(ri, tm, seg, model, hist, acc, label_acc, residual_in, P, M, KP, T, q16, q32, pred_out, epoch_inc, blockIdx.y, blockIdx.x);
 }
 struct QuantGroup {   // one geometry group of rpcc_compress_batch_mixed (the fused batch's form: prediction from model rows, int16 output)
     const float *ri, *tm, *model, *label_acc;
@@ -3776,6 +3794,72 @@ extern "C" int rpcc_compress_batch_mixed(const rpcc_batch_io *ios, const int *Bs
 // ================================================================================================
 #include "wide_kernels.h"
 
+// ---- 255 .. RPCC_MAX_CLUSTERS_MID clusters with the point model: the tuned assignment / histogram / quantiser kernels on uint16 labels ----------------
+// The label tables of those kernels live in LDS (16 B per centre, 12 and 40 B per label): up to 1022 clusters they still fit, so the kernels are
+// instantiated for uint16_t labels (assign_kernel<uint16_t, 16>: sixteen screening rounds of 64 centres) instead of going through the radix sort of
+// wide_kernels.h (89 k frames/s at 300 clusters against 367 k at 100: a 4 x cliff at 254 -> 255).  The scan between histogram and quantiser is
+// model_scan_kernel's job with a thread per label (K <= 1024): label totals, their exclusive prefix without label 1, the tiles' offsets, counts, nnz and the
+// point model's rows (cpp_modules.cpp:471-518).
+#define RPCC_MAX_CLUSTERS_MID 1022
+#define SCANW_THREADS 1024
+template <class L>
+__global__ __launch_bounds__(SCANW_THREADS) void model_scan_wide_kernel(const float *__restrict__ ri, const L *__restrict__ seg, const double *__restrict__ ground,
+                                                                        int P, int M, int KP, int T, const int64_t *__restrict__ sums,
+                                                                        const int32_t *__restrict__ flags, uint32_t *__restrict__ hist,
+                                                                        float *__restrict__ model, int32_t *__restrict__ counts, int32_t *__restrict__ nnz) {
+    __shared__ uint32_t wsum[SCANW_THREADS / 64];
+    const int b = blockIdx.x, k = threadIdx.x, K = M + 2, lane = k & 63, wave = k >> 6;
+    uint32_t *gh = hist + (int64_t)b * T * KP;
+    const uint32_t kp4 = (uint32_t)KP * 4u, k4 = (uint32_t)min(k, KP - 1) * 4u;
+    uint32_t total = 0u;
+    for (int t0 = 0; t0 < T; t0 += SCAN_U) {
+        uint32_t d[SCAN_U];
+#pragma unroll
+        for (int j = 0; j < SCAN_U; j++) d[j] = ld_at(gh, (uint32_t)min(t0 + j, T - 1) * kp4 + k4);   // unconditional (clamped) loads
+#pragma unroll
+        for (int j = 0; j < SCAN_U; j++) total += (t0 + j < T && k < K) ? d[j] : 0u;
+    }
+    const uint32_t v = (k < K && k != 1) ? total : 0u;   // label 1 = empty pixels: no residuals (cpp_modules.cpp:314)
+    const uint32_t incl = dpp_scan_incl_u32(v);
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t off = 0u;
+    for (int w = 0; w < wave; w++) off += wsum[w];
+    if (k == SCANW_THREADS - 1 && nnz) nnz[b] = (int32_t)(off + incl);
+    if (k >= K) return;
+    uint32_t run = off + incl - v;
+    for (int t0 = 0; t0 < T; t0 += SCAN_U) {
+        uint32_t d[SCAN_U];
+#pragma unroll
+        for (int j = 0; j < SCAN_U; j++) d[j] = ld_at(gh, (uint32_t)min(t0 + j, T - 1) * kp4 + k4);
+#pragma unroll
+        for (int j = 0; j < SCAN_U; j++)
+            if (t0 + j < T) { st_at(gh, (uint32_t)(t0 + j) * kp4 + k4, run); run += d[j]; }
+    }
+    if (counts) counts[(int64_t)b * K + k] = (int32_t)total;
+    if (model != nullptr) {
+        float *row = model + ((int64_t)b * K + k) * 4;
+        if (k == 0) {
+            row[0] = (float)ground[4 * b]; row[1] = (float)ground[4 * b + 1]; row[2] = (float)ground[4 * b + 2]; row[3] = (float)ground[4 * b + 3];
+        } else if (k == 1) {
+            row[0] = row[1] = row[2] = row[3] = 0.0f;
+        } else {
+            double sm;
+            if (flags[4 * b]) {   // sequential double accumulation in row-major order (cpp_modules.cpp:514): ranges outside the fixed-point window, rare
+                sm = 0.0;
+                for (int p = 0; p < P; p++)
+                    if (seg[(int64_t)b * P + p] == (L)k) sm += (double)ri[(int64_t)b * P + p];
+            } else {
+                sm = (double)sums[(int64_t)b * KP + k] * (1.0 / 268435456.0);
+            }
+            row[0] = row[1] = row[2] = 0.0f;
+            row[3] = total == 0 ? u2f(0xFFC00000u) : (float)(sm / (double)total);
+        }
+    }
+}
+// the model part of the tuned kernels' workspace (ws_layout) for KP labels, carved from the sort buffers of a wide workspace
+static inline size_t mid_model_bytes(int B, int P, int M) { return ws_layout(nullptr, B, P, M).bytes; }
+
 // carve-up of a wide workspace: [ keys, vals (in / out) u32 4 x [B,P] | pos i32 [B,P] | order u32 [B,P] | pts4 float4 [B,P] | sums u64 [B,K] |
 //   base u32 [B,K] | kpn i32 [B,K] | label_acc f32 [B,K] | flags i32 [B,4] | cen4 float4 [B,M] | FPS temp f32 [B,P] | FPS tile table |
 //   projection scratch | radix sort scratch ]
@@ -3859,10 +3943,43 @@ extern "C" int rpcc_compress_batch_wide(const rpcc_batch_io *io, int B, rpcc_geo
     const bool brute = (io->flags & RPCC_FPS_BRUTEFORCE) != 0;
     if ((rc = launch_ground_mask(io->ri, io->tm, io->ground, ground_threshold, B, g.H, g.W, w.temp, io->info, brute ? nullptr : w.tiletab, st, false))) return rc;
     if ((rc = launch_fps_range(io->ri, io->tm, w.temp, io->info, B, g.H, g.W, M, io->cen_pix, io->centers, io->flags, false, brute ? nullptr : w.tiletab, nullptr, st))) return rc;
+    const bool point = io->model_method == 0;
+    // up to 1022 clusters with the point model: the tuned kernels on uint16 labels (their model workspace lies in the four sort buffers)
+    if (point && M <= RPCC_MAX_CLUSTERS_MID && mid_model_bytes(B, P, M) <= (size_t)4 * B * P * 4 && P < (1 << 22)) {
+        const WsLayout L = ws_layout(w.keys_in, B, P, M);
+        const int KP = kpad(M), T = ntiles(P);
+        const int ntile = ((g.H + ASSIGN_ROWS - 1) / ASSIGN_ROWS) * ((g.W + 31) / 32);
+        const dim3 agrid((ntile + ASSIGN_WAVES * ASSIGN_TILES_PER_WAVE - 1) / (ASSIGN_WAVES * ASSIGN_TILES_PER_WAVE), B);
+        assign_kernel<uint16_t, 16><<<agrid, 64 * ASSIGN_WAVES, (size_t)M * sizeof(float4), st>>>(io->ri, io->tm, io->ground, io->centers, g.H, g.W, M, seg, w.temp);
+        LAUNCH_CHECK();
+        HIP_TRY(hipMemsetAsync(L.sums, 0, (size_t)((char *)L.hist - (char *)L.sums), st));
+        const bool vec = (P & 3) == 0 && ((uintptr_t)seg & 7u) == 0 && ((uintptr_t)io->ri & 15u) == 0 && ((uintptr_t)io->tm & 15u) == 0;
+        if (vec) model_hist_kernel<true, uint16_t><<<dim3(T, B), 256, (size_t)KP * 12, st>>>(io->ri, seg, P, KP, T, L.sums, L.flags, L.hist);
+        else     model_hist_kernel<false, uint16_t><<<dim3(T, B), 256, (size_t)KP * 12, st>>>(io->ri, seg, P, KP, T, L.sums, L.flags, L.hist);
+        model_scan_wide_kernel<uint16_t><<<B, SCANW_THREADS, 0, st>>>(io->ri, seg, io->ground, P, M, KP, T, L.sums, L.flags, L.hist, io->model, io->counts, io->nnz);
+        LAUNCH_CHECK();
+        const float *lacc = nullptr;
+        if (io->nonuniform) {
+            const rpcc_nonuniform_cfg *nu = io->nonuniform;
+            HIP_TRY(hipMemsetAsync(w.kpn, 0, (size_t)B * K * 4, st));
+            if ((rc = launch_features<uint16_t>(io->ri, seg, B, g.H, g.W, nu->feature_region, nu->segments, nu->sharp_num, nu->less_sharp_num, nu->flat_num,
+                                                nullptr, io->key_point_map, st, w.kpn, K))) return rc;
+            SalienceParams sp;
+            for (int i = 0; i < 8; i++) { sp.level_kp_num[i] = i < nu->levels ? nu->level_kp_num[i] : 0; sp.level_acc[i] = i < nu->levels ? nu->level_acc[i] : 0.f; }
+            sp.levels = nu->levels; sp.ground_level = nu->ground_level;
+            wide_salience_levels_kernel<<<dim3((K + 255) / 256, B), 256, 0, st>>>(io->counts, w.kpn, K, sp, io->salience, w.label_acc);
+            LAUNCH_CHECK();
+            lacc = w.label_acc;
+        }
+        const size_t sh = (size_t)KP * 40;
+        if (vec) predict_quantize_kernel<false, true, uint16_t><<<dim3(T, B), 256, sh, st>>>(io->ri, io->tm, seg, io->model, L.hist, acc, lacc, nullptr, P, M, KP, T, io->q16, nullptr, nullptr, nullptr);
+        else     predict_quantize_kernel<false, false, uint16_t><<<dim3(T, B), 256, sh, st>>>(io->ri, io->tm, seg, io->model, L.hist, acc, lacc, nullptr, P, M, KP, T, io->q16, nullptr, nullptr, nullptr);
+        LAUNCH_CHECK();
+        return RPCC_OK;
+    }
     wide_cen4_kernel<<<(B * M + 255) / 256, 256, 0, st>>>(io->centers, B * M, w.cen4);
     wide_assign_kernel<<<dim3((P + 255) / 256, B), 256, 0, st>>>(io->ri, io->tm, io->ground, w.cen4, P, M, seg);
     LAUNCH_CHECK();
-    const bool point = io->model_method == 0;
     if ((rc = wide_order<uint16_t>(seg, point ? io->ri : nullptr, io->ri, io->tm, B, P, M, w, io->counts, io->nnz, !point, st))) return rc;
     if (point) {
         wide_point_model_kernel<uint16_t><<<dim3((K + 255) / 256, B), 256, 0, st>>>(io->ri, seg, io->ground, io->counts, w.sums, w.flags, P, K, io->model);

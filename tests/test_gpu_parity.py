@@ -992,16 +992,16 @@ def test_projection_fast_path_never_disagrees(env, gname):
         sure, bad, slow, dcol, drow = ops.project_fastpath_check(xyz.contiguous(), geom)
         assert sure + slow == xyz.shape[0]
         assert bad == 0, (name, sure, bad, slow)
-        # the margins are 8x the analytic worst case (pix_fast_cfg): the observed discrepancy must stay below the
-        # budget itself, i.e. below 1/8 of the margin
-        mcol = 8 * (2.0e-6 * g.W / g.horizontal_FOV + 6.0e-7 * g.W)
-        mrow = 8 * (2.1e-6 * (g.H - 1) / vfov + 6.0e-7 * (g.H + abs(g.vertical_min) * (g.H - 1) / vfov))
-        assert dcol < mcol / 8 and drow < mrow / 8, (name, dcol, mcol, drow, mrow)
+        # the margins are 4x the analytic worst case (pix_fast_cfg: PIX_MARGIN): the observed discrepancy must stay well below the
+        # budget itself -- below a QUARTER of it, i.e. the margin is at least 16 x what any of these 8e8 points shows
+        bcol = 2.0e-6 * g.W / g.horizontal_FOV + 6.0e-7 * g.W
+        brow = 2.1e-6 * (g.H - 1) / vfov + 6.0e-7 * (g.H + abs(g.vertical_min) * (g.H - 1) / vfov)
+        assert dcol < bcol / 4 and drow < brow / 4, (name, dcol, bcol, drow, brow)
         print("fastpath %-13s %-16s sure %.4f  dcol %.2e (budget %.2e)  drow %.2e (budget %.2e)"
-              % (name, gname, sure / xyz.shape[0], dcol, mcol / 8, drow, mrow / 8))
+              % (name, gname, sure / xyz.shape[0], dcol, bcol, drow, brow))
         tot_sure += sure
         if name == "sweep":
-            assert slow < 0.1 * n, (name, slow / n)     # the fast path must carry the ordinary points
+            assert slow < 0.03 * n, (name, slow / n)     # the fast path must carry the ordinary points (1.8 % uncertain with directions spread evenly)
     assert tot_sure > 0
 
 
