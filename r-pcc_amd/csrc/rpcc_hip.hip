@@ -3857,8 +3857,48 @@ __global__ __launch_bounds__(SCANW_THREADS) void model_scan_wide_kernel(const fl
         }
     }
 }
-// the model part of the tuned kernels' workspace (ws_layout) for KP labels, carved from the sort buffers of a wide workspace
-static inline size_t mid_model_bytes(int B, int P, int M) { return ws_layout(nullptr, B, P, M).bytes; }
+// The whole batch for such a cluster count: the fused batch's own plan and stages up to the FPS (projection with its hand-over to the ground fit, planar
+// ray table, the batch's initialisations inside the first kernel), then the label kernels on uint16_t.  ws: laid out as for rpcc_compress_batch
+// (rpcc_wide_workspace_bytes covers rpcc_workspace_bytes_general for these counts).
+static bool mid_clusters_ok(const rpcc_batch_io *io, rpcc_geom g, int M) {
+    const int P = g.H * g.W;
+    return io->model_method == 0 && M <= RPCC_MAX_CLUSTERS_MID && P < (1 << 22) && fps_tiling_range(g.H, g.W).T <= FPS_TILED_MAX_TILES;
+}
+static int compress_batch_mid(const rpcc_batch_io *io, int B, rpcc_geom g, int M, double ground_threshold, float acc, void *ws, hipStream_t st) {
+    const BatchPlan p = plan_batch(io, B, io->total, g, M, ground_threshold, acc, reinterpret_cast<char *>(ws));
+    int rc;
+    for (int stage = ST_PROJECT; stage <= ST_FPS; stage++)
+        if ((rc = run_stage(p, stage, st))) return rc;
+    const int P = p.P, K = M + 2, KP = kpad(M), T = ntiles(P);
+    uint16_t *seg = reinterpret_cast<uint16_t *>(io->seg);
+    const int ntile = ((g.H + ASSIGN_ROWS - 1) / ASSIGN_ROWS) * ((g.W + 31) / 32);
+    const dim3 agrid((ntile + ASSIGN_WAVES * ASSIGN_TILES_PER_WAVE - 1) / (ASSIGN_WAVES * ASSIGN_TILES_PER_WAVE), B);
+    if (M <= 510) assign_kernel<uint16_t, 8><<<agrid, 64 * ASSIGN_WAVES, (size_t)M * sizeof(float4), st>>>(io->ri, io->tm, io->ground, io->centers, g.H, g.W, M, seg, p.temp);
+    else          assign_kernel<uint16_t, 16><<<agrid, 64 * ASSIGN_WAVES, (size_t)M * sizeof(float4), st>>>(io->ri, io->tm, io->ground, io->centers, g.H, g.W, M, seg, p.temp);
+    LAUNCH_CHECK();
+    // (sums / flags were cleared by the batch's first kernel: BatchInit)
+    const bool vec = (P & 3) == 0 && ((uintptr_t)seg & 7u) == 0 && ((uintptr_t)io->ri & 15u) == 0 && ((uintptr_t)io->tm & 15u) == 0;
+    if (vec) model_hist_kernel<true, uint16_t><<<dim3(T, B), 256, (size_t)KP * 12, st>>>(io->ri, seg, P, KP, T, p.L.sums, p.L.flags, p.L.hist);
+    else     model_hist_kernel<false, uint16_t><<<dim3(T, B), 256, (size_t)KP * 12, st>>>(io->ri, seg, P, KP, T, p.L.sums, p.L.flags, p.L.hist);
+    model_scan_wide_kernel<uint16_t><<<B, SCANW_THREADS, 0, st>>>(io->ri, seg, io->ground, P, M, KP, T, p.L.sums, p.L.flags, p.L.hist, io->model, io->counts, io->nnz);
+    LAUNCH_CHECK();
+    if (io->nonuniform) {
+        const rpcc_nonuniform_cfg *nu = io->nonuniform;
+        if ((rc = launch_features<uint16_t>(io->ri, seg, B, g.H, g.W, nu->feature_region, nu->segments, nu->sharp_num, nu->less_sharp_num, nu->flat_num,
+                                            nullptr, io->key_point_map, st, p.kpn, K))) return rc;
+        SalienceParams sp;
+        for (int i = 0; i < 8; i++) { sp.level_kp_num[i] = i < nu->levels ? nu->level_kp_num[i] : 0; sp.level_acc[i] = i < nu->levels ? nu->level_acc[i] : 0.f; }
+        sp.levels = nu->levels; sp.ground_level = nu->ground_level;
+        wide_salience_levels_kernel<<<dim3((K + 255) / 256, B), 256, 0, st>>>(io->counts, p.kpn, K, sp, io->salience, p.label_acc);
+        LAUNCH_CHECK();
+    }
+    const size_t sh = (size_t)KP * 40;
+    // (the last kernel of the batch gives the next call's projection flags a new mark: p.epoch)
+    if (vec) predict_quantize_kernel<false, true, uint16_t><<<dim3(T, B), 256, sh, st>>>(io->ri, io->tm, seg, io->model, p.L.hist, acc, p.label_acc, nullptr, P, M, KP, T, io->q16, nullptr, nullptr, p.epoch);
+    else     predict_quantize_kernel<false, false, uint16_t><<<dim3(T, B), 256, sh, st>>>(io->ri, io->tm, seg, io->model, p.L.hist, acc, p.label_acc, nullptr, P, M, KP, T, io->q16, nullptr, nullptr, p.epoch);
+    LAUNCH_CHECK();
+    return RPCC_OK;
+}
 
 // carve-up of a wide workspace: [ keys, vals (in / out) u32 4 x [B,P] | pos i32 [B,P] | order u32 [B,P] | pts4 float4 [B,P] | sums u64 [B,K] |
 //   base u32 [B,K] | kpn i32 [B,K] | label_acc f32 [B,K] | flags i32 [B,4] | cen4 float4 [B,M] | FPS temp f32 [B,P] | FPS tile table |
@@ -3902,7 +3942,9 @@ static WideWs wide_layout(void *ws, int B, int P, int M, int64_t total_points) {
 }
 extern "C" size_t rpcc_wide_workspace_bytes(int B, int P, int M, int64_t total_points) {
     if (B <= 0 || P <= 0 || M <= 0) return 0;
-    return wide_layout(nullptr, B, P, M, total_points).bytes + 4096;
+    const size_t sorted = wide_layout(nullptr, B, P, M, total_points).bytes + 4096;
+    // (up to RPCC_MAX_CLUSTERS_MID clusters the point model runs on the fused batch's own layout: compress_batch_mid)
+    return M <= RPCC_MAX_CLUSTERS_MID ? std::max(sorted, rpcc_workspace_bytes_general(B, P, M, total_points)) : sorted;
 }
 // counts, sums, the sort and the positions of a segmentation (encoder and decoder)
 template <class L>
@@ -3934,6 +3976,7 @@ extern "C" int rpcc_compress_batch_wide(const rpcc_batch_io *io, int B, rpcc_geo
     hipStream_t st = (hipStream_t)stream;
     const int P = g.H * g.W, K = M + 2;
     ARG_TRY(fps_tiling_range(g.H, g.W).T <= FPS_TILED_MAX_TILES && P < (1 << 22));
+    if (mid_clusters_ok(io, g, M)) return compress_batch_mid(io, B, g, M, ground_threshold, acc, ws, st);
     const WideWs w = wide_layout(ws, B, P, M, io->total);
     uint16_t *seg = reinterpret_cast<uint16_t *>(io->seg);
     int rc;
@@ -3944,39 +3987,6 @@ extern "C" int rpcc_compress_batch_wide(const rpcc_batch_io *io, int B, rpcc_geo
     if ((rc = launch_ground_mask(io->ri, io->tm, io->ground, ground_threshold, B, g.H, g.W, w.temp, io->info, brute ? nullptr : w.tiletab, st, false))) return rc;
     if ((rc = launch_fps_range(io->ri, io->tm, w.temp, io->info, B, g.H, g.W, M, io->cen_pix, io->centers, io->flags, false, brute ? nullptr : w.tiletab, nullptr, st))) return rc;
     const bool point = io->model_method == 0;
-    // up to 1022 clusters with the point model: the tuned kernels on uint16 labels (their model workspace lies in the four sort buffers)
-    if (point && M <= RPCC_MAX_CLUSTERS_MID && mid_model_bytes(B, P, M) <= (size_t)4 * B * P * 4 && P < (1 << 22)) {
-        const WsLayout L = ws_layout(w.keys_in, B, P, M);
-        const int KP = kpad(M), T = ntiles(P);
-        const int ntile = ((g.H + ASSIGN_ROWS - 1) / ASSIGN_ROWS) * ((g.W + 31) / 32);
-        const dim3 agrid((ntile + ASSIGN_WAVES * ASSIGN_TILES_PER_WAVE - 1) / (ASSIGN_WAVES * ASSIGN_TILES_PER_WAVE), B);
-        assign_kernel<uint16_t, 16><<<agrid, 64 * ASSIGN_WAVES, (size_t)M * sizeof(float4), st>>>(io->ri, io->tm, io->ground, io->centers, g.H, g.W, M, seg, w.temp);
-        LAUNCH_CHECK();
-        HIP_TRY(hipMemsetAsync(L.sums, 0, (size_t)((char *)L.hist - (char *)L.sums), st));
-        const bool vec = (P & 3) == 0 && ((uintptr_t)seg & 7u) == 0 && ((uintptr_t)io->ri & 15u) == 0 && ((uintptr_t)io->tm & 15u) == 0;
-        if (vec) model_hist_kernel<true, uint16_t><<<dim3(T, B), 256, (size_t)KP * 12, st>>>(io->ri, seg, P, KP, T, L.sums, L.flags, L.hist);
-        else     model_hist_kernel<false, uint16_t><<<dim3(T, B), 256, (size_t)KP * 12, st>>>(io->ri, seg, P, KP, T, L.sums, L.flags, L.hist);
-        model_scan_wide_kernel<uint16_t><<<B, SCANW_THREADS, 0, st>>>(io->ri, seg, io->ground, P, M, KP, T, L.sums, L.flags, L.hist, io->model, io->counts, io->nnz);
-        LAUNCH_CHECK();
-        const float *lacc = nullptr;
-        if (io->nonuniform) {
-            const rpcc_nonuniform_cfg *nu = io->nonuniform;
-            HIP_TRY(hipMemsetAsync(w.kpn, 0, (size_t)B * K * 4, st));
-            if ((rc = launch_features<uint16_t>(io->ri, seg, B, g.H, g.W, nu->feature_region, nu->segments, nu->sharp_num, nu->less_sharp_num, nu->flat_num,
-                                                nullptr, io->key_point_map, st, w.kpn, K))) return rc;
-            SalienceParams sp;
-            for (int i = 0; i < 8; i++) { sp.level_kp_num[i] = i < nu->levels ? nu->level_kp_num[i] : 0; sp.level_acc[i] = i < nu->levels ? nu->level_acc[i] : 0.f; }
-            sp.levels = nu->levels; sp.ground_level = nu->ground_level;
-            wide_salience_levels_kernel<<<dim3((K + 255) / 256, B), 256, 0, st>>>(io->counts, w.kpn, K, sp, io->salience, w.label_acc);
-            LAUNCH_CHECK();
-            lacc = w.label_acc;
-        }
-        const size_t sh = (size_t)KP * 40;
-        if (vec) predict_quantize_kernel<false, true, uint16_t><<<dim3(T, B), 256, sh, st>>>(io->ri, io->tm, seg, io->model, L.hist, acc, lacc, nullptr, P, M, KP, T, io->q16, nullptr, nullptr, nullptr);
-        else     predict_quantize_kernel<false, false, uint16_t><<<dim3(T, B), 256, sh, st>>>(io->ri, io->tm, seg, io->model, L.hist, acc, lacc, nullptr, P, M, KP, T, io->q16, nullptr, nullptr, nullptr);
-        LAUNCH_CHECK();
-        return RPCC_OK;
-    }
     wide_cen4_kernel<<<(B * M + 255) / 256, 256, 0, st>>>(io->centers, B * M, w.cen4);
     wide_assign_kernel<<<dim3((P + 255) / 256, B), 256, 0, st>>>(io->ri, io->tm, io->ground, w.cen4, P, M, seg);
     LAUNCH_CHECK();
