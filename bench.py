@@ -75,6 +75,11 @@ def parse():
                     help="synthetic scene: the headline's (default) or an adversarial input of the FPS pruning study (synth.make_frame)")
     ap.add_argument("--groundless", type=int, default=0, help="this many of the batch's sweeps (spread evenly) lose every return below z = -1.45 m: fewer than 800 "
                                                               "ground candidates, the fit runs on the whole cloud (segment_utils.py:105-106)")
+    ap.add_argument("--preflight", action="store_true",
+                    help="with --gpus N on a ONE-GPU box: no ranks are spawned; everything of an N-rank run that depends on the rank count is exercised with "
+                         "the world faked at the sharding layer (frame ids and seeds of every rank, the agreed exchange capacity and its receive buffers, "
+                         "agree_steps, the datalist gather's rounds) on a single-rank RCCL group, one verified step per virtual rank, and the per-rank host / "
+                         "pinned-memory budget is printed")
     ap.add_argument("--pipeline", type=int, default=3, help="batches in flight (streams); 1 = strictly serial steps")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary measurements (configs[2] fused, the real sweep, the datalist feed) that follow the headline at N=1")
@@ -733,6 +738,8 @@ def run_workload(a, ctx):
             out["config"]["min_timed_region_ms"] = float(os.environ.get("RPCC_BENCH_MIN_REGION_MS", "200"))
         if exchange_modes is not None:
             out["exchange_modes"] = exchange_modes
+        if world > 1:
+            out["cpu_baseline"] = None      # (rank 0 at N = 1 only: the task statement's rule; the roofline object above is carried at every N)
         if want_cpu:
             out["cpu_baseline"] = {"value": round(cpu_rate, 3), "unit": "frames/s", "cores": threads, "kind": "port",
                                    "sample": "%d of the same frames, C port of the reference cpu=True path "
@@ -884,12 +891,14 @@ def run_secondary(a, ctx):
                      # the two inputs the exact kernels are slowest on: sweeps without ground returns (whole-cloud ground fit) and ranges that are independent from
                      # pixel to pixel (nothing for the FPS to prune)
                      ("groundless_8_of_256", dict(config=1, geom=None, input=None, groundless=8)),
-                     ("scene_noise", dict(config=1, geom=None, input=None, scene="noise"))):
+                     ("scene_noise", dict(config=1, geom=None, input=None, scene="noise")),
+                     # cluster_num is a free value of the reference's YAML (cfgs/compressor.yaml:22): 300 needs uint16 labels
+                     ("clusters_300", dict(config=1, geom=None, input=None, clusters=300))):
         b = copy.copy(a)
         for k, v in kw.items():
             setattr(b, k, v)
         b.cpu_sample, b.steps, b.warmup, b.h2d, b.fps_bruteforce = 0, max(20, min(a.steps, 50)), 5, False, False
-        b.groundless, b.scene = kw.get("groundless", 0), kw.get("scene", "default")
+        b.groundless, b.scene, b.clusters = kw.get("groundless", 0), kw.get("scene", "default"), kw.get("clusters", a.clusters)
         if "lidar" not in kw:
             b.lidar = None
         try:
@@ -901,9 +910,107 @@ def run_secondary(a, ctx):
     return sec
 
 
+def preflight(a):
+    """First contact with an N-GPU node cannot be rehearsed on the one-GPU boxes this build has seen (SCALE has been skipped every round), so this runs
+    every rank-count-dependent piece of the N-rank path HERE with the world faked: for each virtual rank r of N its frame ids (disjoint, seeds follow
+    them), its batch on the device, one verified step; the exchange capacity all ranks would agree on and rank 0's receive buffers for N ranks
+    (allocated for real); agree_steps on the virtual ranks' step times; the datalist gather's round count for every rank of N; a real single-rank RCCL
+    group for the collectives' code path.  Prints ONE JSON line ("preflight": true; never a benchmark value)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    N, B = max(a.gpus, 1), a.batch
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29544")
+    assert torch.cuda.is_available(), "bench.py --preflight needs one GPU"
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    import rpcc_amd  # noqa: F401
+    from rpcc_amd import ops, synth
+    from rpcc_amd.sharding import PackedExchange, RoundGather, agree_steps, shard_indices
+    from rpcc_amd.utils import available_cpus
+    from oracle import oracle as orc
+    H, W, M = 64, 2048, a.clusters
+    hfov, vmax, vmin = 2 * np.pi, 2.0 * np.pi / 180, -24.9 * np.pi / 180
+    geom = ops.make_geom(H, W, hfov, vmax, vmin)
+    tm_np = ops.transform_map(H, W, hfov, vmax, vmin)
+    tm = torch.from_numpy(tm_np).to(dev)
+    g_o = orc.LidarGeom(H=H, W=W, hfov_deg=360, vmax_deg=2.0, vmin_deg=-24.9)
+    buf = ops.BatchBuffers(B, geom, M, dev)
+    gms = torch.zeros((B, 4), dtype=torch.float64, device=dev)
+    seen, pts, step_s, ok = set(), [], [], True
+    for r in range(N):                                   # what rank r of N would hold and do
+        ids = list(range(r * B, r * B + B))
+        assert not (seen & set(ids)), "frame ids of two ranks overlap"
+        seen |= set(ids)
+        xyz, offs = synth.make_batch(ids, H, W, device=dev)
+        fid = torch.as_tensor(np.asarray(ids, np.int64), device=dev)
+        pts.append(int(xyz.shape[0]))
+        for _ in range(2):
+            ops.compress_batch(xyz, offs, tm, gms, buf, ground_seed=0, frame_ids=fid, acc=a.accuracy * 2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            ops.compress_batch(xyz, offs, tm, gms, buf, ground_seed=0, frame_ids=fid, acc=a.accuracy * 2)
+        torch.cuda.synchronize()
+        step_s.append((time.perf_counter() - t0) / 5)
+        o_h = offs.cpu().numpy()
+        for i in (0, B - 1):                            # the rank's first and last frame against the oracle (seeds = frame ids)
+            f = xyz[o_h[i]:o_h[i + 1]].cpu().numpy()
+            gm = orc.ground_model(orc.project(f, g_o), tm_np, seed=ids[i])
+            o = orc.compress_frame(f, g_o, tm_np, gm, dict(orc.DEFAULT_CFG, accuracy=a.accuracy, cluster_num=M))
+            n = int(buf.nnz[i])
+            ok = ok and n == o["q"].shape[0] and np.array_equal(buf.q16[i, :n].cpu().numpy(), o["q"].astype(np.int16)) and \
+                np.array_equal(gms[i].cpu().numpy().view(np.uint64), np.asarray(gm, np.float64).view(np.uint64))
+        del xyz, offs
+    # the exchange: the capacity the N ranks would agree on (a MAX all_reduce: run on the real group with this process's largest value), rank 0's
+    # receive buffers for N ranks allocated for real, one collective through RCCL
+    cap = PackedExchange.agree_capacity(max(pts), dev)
+    assert cap == max(pts)
+    free0 = torch.cuda.mem_get_info(dev)[0]
+    recv = [torch.empty((2 * cap,), dtype=torch.uint8, device=dev) for _ in range(N)]      # PackedExchange.pay_all of rank 0 in an N-rank job
+    lens = [torch.empty((8 * B,), dtype=torch.int32, device=dev) for _ in range(N)]
+    recv_bytes = free0 - torch.cuda.mem_get_info(dev)[0]
+    ex = PackedExchange(B, cap, dev, payloads=True)
+    packed = torch.zeros((cap,), dtype=torch.int16, device=dev)
+    ops.pack_payload(buf.q16, buf.nnz, packed=packed, capacity=cap, total=torch.zeros((1,), dtype=torch.int64, device=dev))
+    ex.step(packed, buf.nnz)
+    torch.cuda.synchronize()
+    ok = ok and torch.equal(ex.nnz_all[0], buf.nnz)
+    del recv, lens
+    steps = agree_steps(a.steps, max(step_s), 0.2, dev)
+    # the datalist driver's gather (tools/compress_datalist.py --gather): every rank of N must arrive at the same number of rounds, and the shards
+    # must partition the datalist (13 386 entries: the reference's largest list, data/*.txt)
+    n_items = 13386
+    rounds = {RoundGather(n_items, r, N, dev, round_items=4096).rounds for r in range(N)}
+    shards = [shard_indices(n_items, r, N) for r in range(N)]
+    assert len(rounds) == 1 and sorted(i for sh in shards for i in sh) == list(range(n_items))
+    P = H * W
+    per_rank_pinned = 4 * B * P * 16 + 4 * B * P * 3      # loader.StreamingCompressor: 4 slots of B frames, rows ingest (16 B per point) + payload staging
+    cpus = available_cpus()
+    out = {"preflight": True, "metric": "preflight of an N-rank run on one GPU (no benchmark value)", "value": None, "n_gpus_rehearsed": N, "frames_per_rank_per_step": B,
+           "verified": bool(ok), "frame_ids": "rank r: [r*%d, (r+1)*%d): %d disjoint ids, seeds follow them" % (B, B, len(seen)),
+           "points_per_rank": {"min": min(pts), "max": max(pts)}, "exchange_capacity_entries": cap,
+           "rank0_receive_buffers_bytes": int(recv_bytes), "rank0_receive_buffers_note": "payload mode: %d ranks x 2 x capacity bytes + lengths; allocated here for real" % N,
+           "single_gpu_step_ms_per_virtual_rank": [round(t * 1e3, 3) for t in step_s], "agree_steps": {"requested": a.steps, "agreed": steps, "min_region_ms": 200},
+           "datalist_gather": {"entries": n_items, "rounds_every_rank": rounds.pop(), "round_items": 4096, "shard_sizes": [len(sh) for sh in shards]},
+           "host_budget_per_rank": {"pinned_bytes": per_rank_pinned, "pinned_bytes_all_ranks": N * per_rank_pinned, "cpus_visible_here": cpus,
+                                    "cpus_per_rank_if_sliced": cpus // N, "note": "tools/compress_datalist.py pins rank r to slice r of the CPUs when the launcher names LOCAL_RANK and LOCAL_WORLD_SIZE"},
+           "device_memory": {"free_bytes_now": int(torch.cuda.mem_get_info(dev)[0]), "batch_workspace_bytes": int(buf.ws.numel())},
+           "rccl": "single-rank group formed, all_gather + gather + all_reduce(MAX) executed"}
+    dist.barrier()
+    dist.destroy_process_group()
+    print(json.dumps(out), flush=True)
+    if not ok:
+        sys.exit(3)
+
+
 def main():
     a = parse()
     env_world = os.environ.get("WORLD_SIZE")
+    if a.preflight:
+        return preflight(a)
     if env_world is None and a.gpus > 1:
         sys.exit(spawn_ranks(a.gpus))
     world = int(env_world or "1")

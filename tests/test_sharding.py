@@ -479,3 +479,23 @@ def test_eight_rank_datalist_gather_dry_run(tmp_path):
     aff = [set(int(c) for c in re.search(r"affinity ([\d,]+)", lg).group(1).split(",")) for lg in logs]
     if len(os.sched_getaffinity(0)) >= world:                  # every rank on its own CPUs
         assert all(aff[i].isdisjoint(aff[j]) for i in range(world) for j in range(i)), aff
+
+
+def test_bench_preflight_and_n_rank_line_fields(monkeypatch):
+    """bench.py --gpus 8 --preflight is the rehearsal of an 8-rank run on a one-GPU box (no ranks spawned); an N > 1 line carries the roofline object
+    and says `"cpu_baseline": null` explicitly (the baseline is rank 0's at N = 1 only)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--preflight", "--batch", "64"])
+    a = bench.parse()
+    assert a.preflight and a.gpus == 8 and a.batch == 64
+    src = open(os.path.join(root, "bench.py")).read()
+    assert 'if a.preflight:\n        return preflight(a)' in src                     # before any rank is spawned
+    assert 'if world > 1:\n            out["cpu_baseline"] = None' in src
+    # the sharding pieces the rehearsal leans on: every rank of 8 arrives at the same number of gather rounds, the shards partition the list
+    from rpcc_amd.sharding import RoundGather, shard_indices
+    rounds = {RoundGather(13386, r, 8, "cpu", round_items=4096).rounds for r in range(8)}
+    assert rounds == {1}
+    assert sorted(i for r in range(8) for i in shard_indices(13386, r, 8)) == list(range(13386))
+    assert {RoundGather(100000, r, 8, "cpu", round_items=4096).rounds for r in range(8)} == {4}
