@@ -968,10 +968,9 @@ def preflight(a):
     # receive buffers for N ranks allocated for real, one collective through RCCL
     cap = PackedExchange.agree_capacity(max(pts), dev)
     assert cap == max(pts)
-    free0 = torch.cuda.mem_get_info(dev)[0]
     recv = [torch.empty((2 * cap,), dtype=torch.uint8, device=dev) for _ in range(N)]      # PackedExchange.pay_all of rank 0 in an N-rank job
     lens = [torch.empty((8 * B,), dtype=torch.int32, device=dev) for _ in range(N)]
-    recv_bytes = free0 - torch.cuda.mem_get_info(dev)[0]
+    recv_bytes = sum(t.numel() * t.element_size() for t in recv + lens)
     ex = PackedExchange(B, cap, dev, payloads=True)
     packed = torch.zeros((cap,), dtype=torch.int16, device=dev)
     ops.pack_payload(buf.q16, buf.nnz, packed=packed, capacity=cap, total=torch.zeros((1,), dtype=torch.int64, device=dev))
