@@ -45,7 +45,7 @@ extern "C" {
 /* Interface version: changes whenever the layout of a struct below or the meaning of an argument changes (the structs carry no size
  * field).  A binding compares rpcc_version() with the RPCC_ABI_VERSION of the header it was built against before it calls anything else
  * (r-pcc_amd/_lib.py does).  100: round 3.  101: rpcc_batch_io.point_stride_bytes.  102: the uint16-label entries (rpcc_*_wide), rpcc_compress_batch_stages.
- * 103: rpcc_project_ordered, the RPCC_PROJECT_* bits of rpcc_batch_io.flags. */
+ * 103: rpcc_project_ordered, the RPCC_PROJECT_* bits of rpcc_batch_io.flags, the uint16 stage entries (rpcc_assign_wide ...). */
 #define RPCC_ABI_VERSION 103
 int rpcc_version(void);
 const char *rpcc_last_error(void);
@@ -366,6 +366,17 @@ int rpcc_compress_batch_mixed(const rpcc_batch_io *ios, const int *Bs, const rpc
  * rpcc_decode_wide takes label maps of foreign streams: a label above M + 1 (no row of `model`) is read as M + 1 -- memory-safe, the pixel's value is then
  * meaningless as the stream's was; callers that must reject such a stream check the label range first (compress_utils.decode_frame does). */
 #define RPCC_MAX_CLUSTERS_WIDE 65533
+/* Up to RPCC_MAX_CLUSTERS_MID clusters the per-label tables of the tuned kernels still fit LDS: rpcc_compress_batch_wide then runs the assignment, the
+ * label histogram and the quantiser of rpcc_compress_batch on uint16 labels (point model; 250 k frames/s at 300 clusters against 89 k through the
+ * radix sort), and the reference's STAGE seams exist for such counts too -- the uint16 forms of rpcc_assign, rpcc_point_model, rpcc_intra_predict
+ * and rpcc_predict_quantize (same arguments, `seg` as uint16; ws of rpcc_workspace_bytes(B, P, M, 0) bytes):
+ * PointCloudSegment.segment / cluster_modeling('point') / intra_predict and the uniform quantize_residual stage by stage at cluster_num 255 .. 1022. */
+#define RPCC_MAX_CLUSTERS_MID 1022
+int rpcc_assign_wide(const float *ri, const float *tm, const double *ground, const float *centers, int B, int H, int W, int M, uint16_t *seg, void *stream);
+int rpcc_point_model_wide(const float *ri, const uint16_t *seg, const double *ground, int B, int P, int M, float *model, int32_t *counts, void *ws, void *stream);
+int rpcc_intra_predict_wide(const uint16_t *seg, const float *model, const float *tm, int B, int P, int M, float *pred, void *stream);
+int rpcc_predict_quantize_wide(const float *ri, const float *tm, const uint16_t *seg, const float *model, const float *label_acc, const float *residual_in,
+                               float acc, int B, int P, int M, int16_t *q16, int32_t *q32, int32_t *nnz, float *pred, void *ws, void *stream);
 size_t rpcc_wide_workspace_bytes(int B, int P, int M, int64_t total_points);
 int rpcc_compress_batch_wide(const rpcc_batch_io *io, int B, rpcc_geom g, int M, double ground_threshold, float acc, void *ws, void *stream);
 int rpcc_contour_encode_wide(const uint16_t *seg, int B, int H, int W, uint8_t *contour_bits, uint16_t *idx_sequence, int32_t *nseq, void *ws, void *stream);

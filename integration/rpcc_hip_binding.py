@@ -59,12 +59,17 @@ def _ws(B, P, M, total=0):
     return torch.empty((n,), dtype=torch.uint8, device="cuda")
 
 
-def _labels(seg_idx):
+def _labels(seg_idx, wide_ok=True):
+    """Labels for a stage entry: a byte up to cluster_num 254; uint16 for 255 .. 1022, where the library has uint16 forms of the seams the reference
+    calls stage by stage (`<entry>_wide`: point model, prediction, uniform quantiser, contour codec); -> (device labels, M, entry-name suffix)."""
     seg_idx = np.asarray(seg_idx)
     M = max(int(seg_idx.max()) - 1, 1)
-    if M > 254:
-        raise ValueError("librpcc_hip stores labels as uint8: cluster_num <= 254")
-    return _dev(seg_idx, np.uint8).reshape(1, -1), M
+    if M <= 254:
+        return _dev(seg_idx, np.uint8).reshape(1, -1), M, ""
+    if M > 1022 or not wide_ok:
+        raise ValueError("cluster_num = %d: this stage seam of librpcc_hip takes cluster_num <= %d (the fused batch entry rpcc_compress_batch_wide: 65533)"
+                         % (M, 1022 if wide_ok else 254))
+    return _dev(seg_idx, np.uint16).reshape(1, -1), M, "_wide"
 
 
 # ---- dataset_utils_cpp -------------------------------------------------------------------------------
@@ -106,47 +111,50 @@ def segment_range_image(range_image, transform_map, ground_model, cluster_num, g
     cen_pix = torch.empty((1, M), dtype=torch.int32, device="cuda")
     centers = torch.empty((1, M, 3), dtype=torch.float32, device="cuda")
     _ok(_l.rpcc_fps_range(_p(ri), _p(tm), _p(temp), _p(info), 1, H, W, M, _p(cen_pix), _p(centers), 0, _p(table), _s()))
-    seg = torch.empty((1, P), dtype=torch.uint8, device="cuda")
-    _ok(_l.rpcc_assign(_p(ri), _p(tm), _p(ground), _p(centers), 1, H, W, M, _p(seg), _s()))
+    if M > 1022:
+        raise ValueError("cluster_num = %d: the stage seams of librpcc_hip take cluster_num <= 1022 (the fused batch entry rpcc_compress_batch_wide: 65533)" % M)
+    wide = M > 254                # labels 0 .. cluster_num + 1: uint16 on the device above 254 (rpcc_assign_wide)
+    seg = torch.empty((1, P), dtype=torch.uint16 if wide else torch.uint8, device="cuda")
+    _ok((_l.rpcc_assign_wide if wide else _l.rpcc_assign)(_p(ri), _p(tm), _p(ground), _p(centers), 1, H, W, M, _p(seg), _s()))
     return seg.view(H, W).cpu().numpy().astype(np.int64), centers[0].cpu().numpy()
 
 
 # ---- segment_utils_cpp ---------------------------------------------------------------------------------
 def point_modeling(range_image, seg_idx):
     """-> fp32 [max(seg)+1]: 0 for labels 0 and 1, mean range of every cluster label >= 2 (cpp_modules.cpp:471-518)."""
-    seg, M = _labels(seg_idx)
+    seg, M, sfx = _labels(seg_idx)
     P = seg.shape[1]
     ri = _dev(range_image, np.float32).reshape(1, P)
     model = torch.empty((1, M + 2, 4), dtype=torch.float32, device="cuda")
     counts = torch.empty((1, M + 2), dtype=torch.int32, device="cuda")
     ground = torch.zeros((1, 4), dtype=torch.float64, device="cuda")     # row 0 is assembled by the caller (segment_utils.py:183)
-    _ok(_l.rpcc_point_model(_p(ri), _p(seg), _p(ground), 1, P, M, _p(model), _p(counts), _p(_ws(1, P, M)), _s()))
+    _ok(getattr(_l, "rpcc_point_model" + sfx)(_p(ri), _p(seg), _p(ground), 1, P, M, _p(model), _p(counts), _p(_ws(1, P, M)), _s()))
     out = model[0, :int(np.asarray(seg_idx).max()) + 1, 3].cpu().numpy()
     out[:2] = 0.0
     return out
 
 
 def intra_predict(seg_idx, model_param, transform_map):
-    seg, M = _labels(seg_idx)
+    seg, M, sfx = _labels(seg_idx)
     H, W = np.asarray(seg_idx).shape[:2]
     mp = np.zeros((1, M + 2, 4), np.float32)
     rows = min(M + 2, np.asarray(model_param).shape[0])
     mp[0, :rows] = np.asarray(model_param)[:rows]          # fp64 -> fp32: the pybind11 cast of py::array_t<float>
     tm = _dev(transform_map, np.float32).reshape(-1, 3)
     pred = torch.empty((1, H * W), dtype=torch.float32, device="cuda")
-    _ok(_l.rpcc_intra_predict(_p(seg), _p(_dev(mp, np.float32)), _p(tm), 1, H * W, M, _p(pred), _s()))
+    _ok(getattr(_l, "rpcc_intra_predict" + sfx)(_p(seg), _p(_dev(mp, np.float32)), _p(tm), 1, H * W, M, _p(pred), _s()))
     return pred.view(H, W, 1).cpu().numpy()
 
 
 # ---- quantization_utils_cpp ----------------------------------------------------------------------------
 def _quantize(seg_idx, residual, acc, label_acc):
-    seg, M = _labels(seg_idx)
+    seg, M, sfx = _labels(seg_idx)
     P = seg.shape[1]
     res = _dev(residual, np.float32).reshape(1, P)
     q32 = torch.empty((1, P), dtype=torch.int32, device="cuda")
     nnz = torch.empty((1,), dtype=torch.int32, device="cuda")
-    _ok(_l.rpcc_predict_quantize(None, None, _p(seg), None, _p(label_acc), _p(res), C.c_float(acc), 1, P, M, None,
-                                 _p(q32), _p(nnz), None, _p(_ws(1, P, M)), _s()))
+    _ok(getattr(_l, "rpcc_predict_quantize" + sfx)(None, None, _p(seg), None, _p(label_acc), _p(res), C.c_float(acc), 1, P, M, None,
+                                                   _p(q32), _p(nnz), None, _p(_ws(1, P, M)), _s()))
     return q32[0, :int(nnz[0])].cpu().numpy()
 
 
@@ -156,7 +164,7 @@ def uniform_quantize(seg_idx, residual, acc):
 
 def nonuniform_quantize(seg_idx, residual, key_point_map, level_kp_num, level_acc, ground_level):
     """-> (quantized residual int32 [nnz], salience level per label int32 [max(seg)+1])."""
-    seg, M = _labels(seg_idx)
+    seg, M, _ = _labels(seg_idx, wide_ok=False)      # (the salience seam keeps labels in a byte)
     P, L = seg.shape[1], len(level_kp_num)
     kp = _dev(key_point_map, np.uint8).reshape(1, P)
     sal = torch.empty((1, M + 2), dtype=torch.uint8, device="cuda")
@@ -170,7 +178,7 @@ def nonuniform_quantize(seg_idx, residual, key_point_map, level_kp_num, level_ac
 
 # ---- feature_extractor_cpp -----------------------------------------------------------------------------
 def extract_features_with_segment(range_image, seg_idx, feature_region, segments, sharp_num, less_sharp_num, flat_num):
-    seg, _ = _labels(seg_idx)
+    seg, _, _ = _labels(seg_idx, wide_ok=False)      # (the key-point seam keeps labels in a byte)
     H, W = np.asarray(seg_idx).shape[:2]
     ri = _dev(range_image, np.float32).reshape(1, H * W)
     feat = torch.empty((1, H, W), dtype=torch.float32, device="cuda")
@@ -183,14 +191,14 @@ def extract_features_with_segment(range_image, seg_idx, feature_region, segments
 # ---- contour_utils_cpp ---------------------------------------------------------------------------------
 def extract_contour(idx_map):
     """-> (contour_map int32 [H,W] of 0/1, idx_sequence int32 [n])."""
-    seg, M = _labels(idx_map)
+    seg, M, sfx = _labels(idx_map)
     H, W = np.asarray(idx_map).shape[:2]
     P = H * W
     bits = torch.empty((1, (P + 7) // 8), dtype=torch.uint8, device="cuda")
     seq = torch.empty((1, P), dtype=torch.int16, device="cuda")   # uint16 payload
     nseq = torch.empty((1,), dtype=torch.int32, device="cuda")
-    ws = torch.empty((_l.rpcc_codec_workspace_bytes(1, P, M),), dtype=torch.uint8, device="cuda")
-    _ok(_l.rpcc_contour_encode(_p(seg), 1, H, W, _p(bits), _p(seq), _p(nseq), _p(ws), _s()))
+    ws = torch.empty((_l.rpcc_codec_workspace_bytes(1, P, min(M, 254)),), dtype=torch.uint8, device="cuda")   # (a count per 1024-pixel tile: the same for either label type)
+    _ok(getattr(_l, "rpcc_contour_encode" + sfx)(_p(seg), 1, H, W, _p(bits), _p(seq), _p(nseq), _p(ws), _s()))
     cm = np.unpackbits(bits[0].cpu().numpy())[:P].reshape(H, W).astype(np.int32)
     return cm, seq[0, :int(nseq[0])].cpu().numpy().view(np.uint16).astype(np.int32)
 
@@ -203,7 +211,8 @@ def recover_map(contour_map, idx_sequence):
     n = len(idx_sequence)
     seq[0, :n] = torch.from_numpy(np.asarray(idx_sequence).astype(np.uint16).view(np.int16)).cuda()
     M = 254
-    seg = torch.empty((1, P), dtype=torch.uint8, device="cuda")
+    wide = n > 0 and int(np.asarray(idx_sequence).max()) > 255      # labels above a byte: the uint16 form of the seam
+    seg = torch.empty((1, P), dtype=torch.uint16 if wide else torch.uint8, device="cuda")
     ws = torch.empty((_l.rpcc_codec_workspace_bytes(1, P, M),), dtype=torch.uint8, device="cuda")
-    _ok(_l.rpcc_contour_decode(_p(bits), _p(seq), 1, H, W, _p(seg), _p(ws), _s()))
+    _ok((_l.rpcc_contour_decode_wide if wide else _l.rpcc_contour_decode)(_p(bits), _p(seq), 1, H, W, _p(seg), _p(ws), _s()))
     return seg.view(H, W).cpu().numpy().astype(np.int32)

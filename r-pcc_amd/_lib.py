@@ -39,6 +39,7 @@ FPS_BRUTEFORCE = 1     # RPCC_FPS_BRUTEFORCE
 FPS_FMA1, FPS_FMA2, FPS_TIE_CUDA = 2, 4, 8   # RPCC_FPS_FMA1 / RPCC_FPS_FMA2 / RPCC_FPS_TIE_CUDA
 MAX_CLUSTERS = 254     # RPCC_MAX_CLUSTERS: labels 0 .. cluster_num + 1 are stored as uint8 on the device
 MAX_CLUSTERS_WIDE = 65533   # RPCC_MAX_CLUSTERS_WIDE: the uint16-label entries (rpcc_*_wide)
+MAX_CLUSTERS_MID = 1022     # RPCC_MAX_CLUSTERS_MID: the tuned kernels on uint16 labels; the uint16 STAGE entries (rpcc_assign_wide ...)
 ABI_VERSION = 103      # RPCC_ABI_VERSION: the layout of rpcc_batch_io / rpcc_geom this binding was written for
 
 
@@ -80,6 +81,10 @@ _SIGS = {
     "rpcc_point_model": (C.c_int, [_VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP]),
     "rpcc_predict_quantize": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _F, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
     "rpcc_intra_predict": (C.c_int, [_VP, _VP, _VP, _I, _I, _I, _VP, _VP]),
+    "rpcc_assign_wide": (C.c_int, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP]),
+    "rpcc_point_model_wide": (C.c_int, [_VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP]),
+    "rpcc_predict_quantize_wide": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _F, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "rpcc_intra_predict_wide": (C.c_int, [_VP, _VP, _VP, _I, _I, _I, _VP, _VP]),
     "rpcc_extract_features": (C.c_int, [_VP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _VP, _VP, _VP]),
     "rpcc_salience": (C.c_int, [_VP, _VP, C.POINTER(C.c_int32), C.POINTER(C.c_float), _I, _I, _I, _I, _I, _VP, _VP, _VP]),
     "rpcc_backproject": (C.c_int, [_VP, _VP, _I, _I, _VP, _VP]),

@@ -45,10 +45,13 @@ class QuantizationModule:
     def quantize_residual(self, residual, seg_idx, point_cloud=None, range_image=None):
         """-> (residual_quantized int32 [nnz], salience_level int32 [max+1] or None, key_point_map or None)."""
         h, w = seg_idx.shape[:2]
-        seg = _dev(seg_idx, self.device, np.uint8).reshape(1, h, w)
-        res = _dev(residual, self.device, np.float32).reshape(1, h * w)
         M = max(int(seg_idx.max()) - 1, 1)
         K = M + 2
+        # the uniform quantiser's stage entry exists for uint16 labels too (rpcc_predict_quantize_wide, cluster_num <= 1022); key points and salience
+        # levels stage by stage keep labels in a byte (the batch front-end, pipeline.BatchCompressor, has no such limit)
+        ops.check_cluster_num(M, stage="mid") if self.uniform else ops.check_cluster_num(M, wide=False)
+        seg = _dev(seg_idx, self.device, np.uint16 if ops.is_wide(M) else np.uint8).reshape(1, h, w)
+        res = _dev(residual, self.device, np.float32).reshape(1, h * w)
         dummy_model = torch.zeros((1, K, 4), dtype=torch.float32, device=self.device)
         tm = torch.zeros((h * w, 3), dtype=torch.float32, device=self.device)
         ri0 = torch.zeros((1, h, w), dtype=torch.float32, device=self.device)

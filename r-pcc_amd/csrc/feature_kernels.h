@@ -513,7 +513,8 @@ __global__ __launch_bounds__(256) void salience_levels_multi_kernel(const MultiA
 }
 
 // a10 as its own entry: intra_predict (cpp_modules.cpp:248-285)
-__global__ __launch_bounds__(256) void intra_predict_kernel(const uint8_t *__restrict__ seg, const float *__restrict__ model,
+template <class L = uint8_t>
+__global__ __launch_bounds__(256) void intra_predict_kernel(const L *__restrict__ seg, const float *__restrict__ model,
                                                             const float *__restrict__ tm, int P, int K,
                                                             float *__restrict__ pred) {
     const int b = blockIdx.y;

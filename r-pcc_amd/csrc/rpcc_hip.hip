@@ -3408,7 +3408,7 @@ extern "C" int rpcc_salience(const uint8_t *seg, const uint8_t *key_point_map, c
 extern "C" int rpcc_intra_predict(const uint8_t *seg, const float *model, const float *tm, int B, int P, int M, float *pred,
                                   void *stream) {
     ARG_TRY(B > 0 && B <= RPCC_MAX_BATCH && P > 0 && M > 0 && seg && model && tm && pred);
-    intra_predict_kernel<<<dim3((P + 255) / 256, B), 256, 0, (hipStream_t)stream>>>(seg, model, tm, P, M + 2, pred);
+    intra_predict_kernel<uint8_t><<<dim3((P + 255) / 256, B), 256, 0, (hipStream_t)stream>>>(seg, model, tm, P, M + 2, pred);
     LAUNCH_CHECK();
     return RPCC_OK;
 }
@@ -3800,7 +3800,6 @@ extern "C" int rpcc_compress_batch_mixed(const rpcc_batch_io *ios, const int *Bs
 // wide_kernels.h (89 k frames/s at 300 clusters against 367 k at 100: a 4 x cliff at 254 -> 255).  The scan between histogram and quantiser is
 // model_scan_kernel's job with a thread per label (K <= 1024): label totals, their exclusive prefix without label 1, the tiles' offsets, counts, nnz and the
 // point model's rows (cpp_modules.cpp:471-518).
-#define RPCC_MAX_CLUSTERS_MID 1022
 #define SCANW_THREADS 1024
 template <class L>
 __global__ __launch_bounds__(SCANW_THREADS) void model_scan_wide_kernel(const float *__restrict__ ri, const L *__restrict__ seg, const double *__restrict__ ground,
@@ -3896,6 +3895,63 @@ static int compress_batch_mid(const rpcc_batch_io *io, int B, rpcc_geom g, int M
     // (the last kernel of the batch gives the next call's projection flags a new mark: p.epoch)
     if (vec) predict_quantize_kernel<false, true, uint16_t><<<dim3(T, B), 256, sh, st>>>(io->ri, io->tm, seg, io->model, p.L.hist, acc, p.label_acc, nullptr, P, M, KP, T, io->q16, nullptr, nullptr, p.epoch);
     else     predict_quantize_kernel<false, false, uint16_t><<<dim3(T, B), 256, sh, st>>>(io->ri, io->tm, seg, io->model, p.L.hist, acc, p.label_acc, nullptr, P, M, KP, T, io->q16, nullptr, nullptr, p.epoch);
+    LAUNCH_CHECK();
+    return RPCC_OK;
+}
+
+// ---- the stage entries on uint16 labels, 255 .. RPCC_MAX_CLUSTERS_MID clusters (the reference-side classes call the stages one by one:
+// PointCloudSegment.segment / cluster_modeling('point') / intra_predict, QuantizationModule.quantize_residual with the uniform framework) ------------
+static int hist_scan_u16(const float *ri, const uint16_t *seg, const double *ground, int B, int P, int M, const WsLayout &L, float *model,
+                         int32_t *counts, int32_t *nnz, hipStream_t st) {
+    const int KP = kpad(M), T = ntiles(P);
+    const bool vec = (P & 3) == 0 && ((uintptr_t)seg & 7u) == 0 && (ri == nullptr || ((uintptr_t)ri & 15u) == 0);
+    HIP_TRY(hipMemsetAsync(L.sums, 0, (size_t)((char *)L.hist - (char *)L.sums), st));
+    if (vec) model_hist_kernel<true, uint16_t><<<dim3(T, B), 256, (size_t)KP * 12, st>>>(ri, seg, P, KP, T, L.sums, L.flags, L.hist);
+    else     model_hist_kernel<false, uint16_t><<<dim3(T, B), 256, (size_t)KP * 12, st>>>(ri, seg, P, KP, T, L.sums, L.flags, L.hist);
+    model_scan_wide_kernel<uint16_t><<<B, SCANW_THREADS, 0, st>>>(ri, seg, ground, P, M, KP, T, L.sums, L.flags, L.hist, model, counts, nnz);
+    LAUNCH_CHECK();
+    return RPCC_OK;
+}
+extern "C" int rpcc_assign_wide(const float *ri, const float *tm, const double *ground, const float *centers, int B, int H, int W, int M,
+                                uint16_t *seg, void *stream) {
+    ARG_TRY(B > 0 && B <= RPCC_MAX_BATCH && H > 0 && W > 0 && M > 0 && M <= RPCC_MAX_CLUSTERS_MID && ri && tm && ground && centers && seg);
+    hipStream_t st = (hipStream_t)stream;
+    const int ntile = ((H + ASSIGN_ROWS - 1) / ASSIGN_ROWS) * ((W + 31) / 32);
+    const dim3 grid((ntile + ASSIGN_WAVES * ASSIGN_TILES_PER_WAVE - 1) / (ASSIGN_WAVES * ASSIGN_TILES_PER_WAVE), B);
+    if (M <= 510) assign_kernel<uint16_t, 8><<<grid, 64 * ASSIGN_WAVES, (size_t)M * sizeof(float4), st>>>(ri, tm, ground, centers, H, W, M, seg, nullptr);
+    else          assign_kernel<uint16_t, 16><<<grid, 64 * ASSIGN_WAVES, (size_t)M * sizeof(float4), st>>>(ri, tm, ground, centers, H, W, M, seg, nullptr);
+    LAUNCH_CHECK();
+    return RPCC_OK;
+}
+extern "C" int rpcc_point_model_wide(const float *ri, const uint16_t *seg, const double *ground, int B, int P, int M, float *model, int32_t *counts,
+                                     void *ws, void *stream) {
+    ARG_TRY(B > 0 && B <= RPCC_MAX_BATCH && P > 0 && M > 0 && M <= RPCC_MAX_CLUSTERS_MID && ri && seg && ground && model && ws);
+    return hist_scan_u16(ri, seg, ground, B, P, M, ws_layout(ws, B, P, M), model, counts, nullptr, (hipStream_t)stream);
+}
+extern "C" int rpcc_intra_predict_wide(const uint16_t *seg, const float *model, const float *tm, int B, int P, int M, float *pred, void *stream) {
+    ARG_TRY(B > 0 && B <= RPCC_MAX_BATCH && P > 0 && M > 0 && M <= RPCC_MAX_CLUSTERS_WIDE && seg && model && tm && pred);
+    intra_predict_kernel<uint16_t><<<dim3((P + 255) / 256, B), 256, 0, (hipStream_t)stream>>>(seg, model, tm, P, M + 2, pred);
+    LAUNCH_CHECK();
+    return RPCC_OK;
+}
+extern "C" int rpcc_predict_quantize_wide(const float *ri, const float *tm, const uint16_t *seg, const float *model, const float *label_acc,
+                                          const float *residual_in, float acc, int B, int P, int M, int16_t *q16, int32_t *q32, int32_t *nnz,
+                                          float *pred, void *ws, void *stream) {
+    ARG_TRY(B > 0 && B <= RPCC_MAX_BATCH && P > 0 && M > 0 && M <= RPCC_MAX_CLUSTERS_MID && seg && ws);
+    ARG_TRY((residual_in && !pred) || (ri && tm && model));   // residual handed in, no prediction wanted: seg only
+    ARG_TRY(q16 || q32);
+    hipStream_t st = (hipStream_t)stream;
+    const int KP = kpad(M), T = ntiles(P);
+    const WsLayout L = ws_layout(ws, B, P, M);
+    int rc;
+    if ((rc = hist_scan_u16(ri, seg, nullptr, B, P, M, L, nullptr, nullptr, nnz, st))) return rc;
+    const size_t sh = (size_t)KP * 40;
+    const bool resid = residual_in && !pred;
+    const bool vec = (P & 3) == 0 && ((uintptr_t)seg & 7u) == 0 && (resid || (aligned16(ri) && aligned16(tm))) && (!residual_in || aligned16(residual_in));
+#define PQW_LAUNCH(R_, V_) predict_quantize_kernel<R_, V_, uint16_t><<<dim3(T, B), 256, sh, st>>>(ri, tm, seg, model, L.hist, acc, label_acc, residual_in, P, M, KP, T, q16, q32, pred, nullptr)
+    if (resid) { if (vec) PQW_LAUNCH(true, true); else PQW_LAUNCH(true, false); }
+    else       { if (vec) PQW_LAUNCH(false, true); else PQW_LAUNCH(false, false); }
+#undef PQW_LAUNCH
     LAUNCH_CHECK();
     return RPCC_OK;
 }

@@ -171,11 +171,27 @@ def fps_range(ri, tm, temp, info, M, fps_table=None, cen_pix=None, centers=None,
     return cen_pix, centers
 
 
+def _stage_entry(name, M, seg=None):
+    """The stage entry `name` for cluster count M: the byte-label one up to 254, its uint16 form (`name`_wide) up to 1022 -- and the label tensor's dtype
+    must be the one the entry reads."""
+    wide = is_wide(M)
+    if wide and M > _lib.MAX_CLUSTERS_MID:
+        check_cluster_num(M, stage="mid")
+    if seg is not None:
+        assert seg.dtype == (torch.uint16 if wide else torch.uint8), "labels of cluster_num = %d are %s on the device" % (M, "uint16" if wide else "uint8")
+    return getattr(_lib.lib(), name + "_wide" if wide else name)
+
+
+def label_dtype(M):
+    return torch.uint16 if is_wide(M) else torch.uint8
+
+
 def assign(ri, tm, ground, centers, out=None):
+    """a7 -> labels u8 [B,H,W] (uint16 for 255 .. 1022 centres: rpcc_assign_wide)."""
     B, H, W = ri.shape
     M = centers.shape[1]
-    seg = torch.empty((B, H, W), dtype=torch.uint8, device=_dev(ri)) if out is None else out
-    check(_lib.lib().rpcc_assign(ptr(ri), ptr(tm), ptr(ground), ptr(centers), B, H, W, M, ptr(seg), stream()))
+    seg = torch.empty((B, H, W), dtype=label_dtype(M), device=_dev(ri)) if out is None else out
+    check(_stage_entry("rpcc_assign", M, seg)(ptr(ri), ptr(tm), ptr(ground), ptr(centers), B, H, W, M, ptr(seg), stream()))
     return seg
 
 
@@ -193,8 +209,7 @@ def point_model(ri, seg, ground, M, ws=None):
     ws = workspace(B, P, M, _dev(ri)) if ws is None else ws
     model = torch.empty((B, K, 4), dtype=torch.float32, device=_dev(ri))
     counts = torch.empty((B, K), dtype=torch.int32, device=_dev(ri))
-    check(_lib.lib().rpcc_point_model(ptr(ri), ptr(seg), ptr(ground), B, P, M, ptr(model), ptr(counts), ptr(ws),
-                                      stream()))
+    check(_stage_entry("rpcc_point_model", M, seg)(ptr(ri), ptr(seg), ptr(ground), B, P, M, ptr(model), ptr(counts), ptr(ws), stream()))
     return model, counts
 
 
@@ -211,9 +226,9 @@ def predict_quantize(ri, tm, seg, model, acc, M, want_pred=False, int16=False, w
     q = torch.zeros((B, P), dtype=torch.int16 if int16 else torch.int32, device=_dev(ri)) if q_out is None else q_out
     nnz = torch.empty((B,), dtype=torch.int32, device=_dev(ri)) if nnz_out is None else nnz_out
     pred = torch.empty((B, P), dtype=torch.float32, device=_dev(ri)) if want_pred else None
-    check(_lib.lib().rpcc_predict_quantize(ptr(ri), ptr(tm), ptr(seg), ptr(model), ptr(label_acc), ptr(residual),
-                                           float(acc), B, P, M, ptr(q) if int16 else None,
-                                           None if int16 else ptr(q), ptr(nnz), ptr(pred), ptr(ws), stream()))
+    check(_stage_entry("rpcc_predict_quantize", M, seg)(ptr(ri), ptr(tm), ptr(seg), ptr(model), ptr(label_acc), ptr(residual),
+                                                        float(acc), B, P, M, ptr(q) if int16 else None,
+                                                        None if int16 else ptr(q), ptr(nnz), ptr(pred), ptr(ws), stream()))
     return q, nnz, pred
 
 
@@ -222,7 +237,8 @@ def intra_predict(seg, model, tm):
     B = seg.shape[0]
     P = seg[0].numel()
     pred = torch.empty(tuple(seg.shape), dtype=torch.float32, device=_dev(seg))
-    check(_lib.lib().rpcc_intra_predict(ptr(seg), ptr(model), ptr(tm), B, P, model.shape[1] - 2, ptr(pred), stream()))
+    fn = _lib.lib().rpcc_intra_predict_wide if seg.dtype == torch.uint16 else _lib.lib().rpcc_intra_predict    # (any label count: a row lookup per pixel)
+    check(fn(ptr(seg), ptr(model), ptr(tm), B, P, model.shape[1] - 2, ptr(pred), stream()))
     return pred
 
 
@@ -324,13 +340,19 @@ def pack_payload(q16, nnz, packed=None, capacity=None, total=None):
     return packed, total
 
 
-def check_cluster_num(M, wide=True):
+def check_cluster_num(M, wide=True, stage=None):
     """cluster_num as this build takes it.  The reference accepts any value (cfgs/compressor.yaml:22; its labels travel as uint16,
     utils/compress_utils.py:160).  Up to 254 the device keeps a pixel's label 0 .. cluster_num + 1 in ONE byte (the tuned kernels); above,
     the batch front-end (BatchBuffers / compress_batch / contour_encode / decode) takes the uint16 entries (rpcc_*_wide: the same results by
     plain kernels) up to 65 533.  wide=False: a caller that only has the byte-label stage entries (the mirror classes' per-stage calls) --
     a larger value is refused by name, before any buffer is allocated."""
     M = int(M)
+    if stage == "mid":    # the uint16 stage entries (segmentation, point model, prediction, uniform quantiser): RPCC_MAX_CLUSTERS_MID
+        if not 1 <= M <= _lib.MAX_CLUSTERS_MID:
+            raise _lib.RpccError("cluster_num = %d: the stage-by-stage entries for segmentation, point model, prediction and the uniform quantiser support 1 <= "
+                                 "cluster_num <= %d (their label tables live in LDS: RPCC_MAX_CLUSTERS_MID in include/rpcc_hip.h); pipeline.BatchCompressor "
+                                 "takes up to 65533" % (M, _lib.MAX_CLUSTERS_MID))
+        return M
     top = _lib.MAX_CLUSTERS_WIDE if wide else _lib.MAX_CLUSTERS
     if not 1 <= M <= top:
         raise _lib.RpccError("cluster_num = %d: %s supports 1 <= cluster_num <= %d (%s); the reference's default is 100 (cfgs/compressor.yaml:22)"

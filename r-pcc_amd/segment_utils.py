@@ -33,7 +33,10 @@ class PointCloudSegment:
         return torch.from_numpy(np.ascontiguousarray(range_image, dtype=np.float32).reshape(1, h, w)).to(self.device)
 
     def _seg(self, seg_idx):
-        return torch.from_numpy(np.ascontiguousarray(seg_idx).astype(np.uint8)[None]).to(self.device)
+        """labels on the device: a byte up to cluster_num 254, uint16 above (the *_wide stage entries, up to 1022)"""
+        a = np.ascontiguousarray(seg_idx)
+        wide = int(a.max()) > 255 if a.size else False
+        return torch.from_numpy(a.astype(np.uint16 if wide else np.uint8)[None]).to(self.device)
 
     # -- reference interface --------------------------------------------------------------------
     ransac_plane_segmentation = None  # assign a callable(points, threshold, ransac_n, num_iterations) to inject
@@ -46,7 +49,8 @@ class PointCloudSegment:
         if method != "FPS":
             raise NotImplementedError("DBSCAN segmentation is out of scope (SURVEY.md section 2)")
         thr = segment_cfg["ground_vertical_threshold"]
-        M = ops.check_cluster_num(segment_cfg["cluster_num"], wide=False)   # the per-stage entries keep labels in a byte: <= 254, named in the error (BatchCompressor: up to 65533)
+        # the stage entries: byte labels up to 254, uint16 ones (rpcc_assign_wide) up to 1022 -- a larger value is named in the error (BatchCompressor: 65533)
+        M = ops.check_cluster_num(segment_cfg["cluster_num"], stage="mid")
         ri = self._ri(range_image)
         inject = type(self).ransac_plane_segmentation
         if inject is not None:
@@ -83,6 +87,7 @@ class PointCloudSegment:
         if method == "point":
             model, _ = ops.point_model(ri, seg, ground, M)
         else:
+            ops.check_cluster_num(M, wide=False)     # (the plane model's stage entry keeps labels in a byte)
             model = ops.plane_model(ri, self._tm, seg, M, angle_threshold=model_cfg["angle_threshold"], seed=self.seed,
                                     frame_ids=[self.frame_id])
         return model[0, 1:nrow].cpu().numpy().astype(np.float64)

@@ -68,6 +68,11 @@ def test_cluster_num_limits_are_named():
     for bad in (255, 300):
         with pytest.raises(_lib.RpccError, match=r"cluster_num = %d.*stage-by-stage.*<= 254.*uint8.*BatchCompressor" % bad):
             ops.check_cluster_num(bad, wide=False)
+    # the stage seams that exist on uint16 labels (segmentation, point model, prediction, uniform quantiser): up to RPCC_MAX_CLUSTERS_MID
+    assert int(re.search(r"#define RPCC_MAX_CLUSTERS_MID (\d+)", hdr).group(1)) == _lib.MAX_CLUSTERS_MID == 1022
+    assert ops.check_cluster_num(300, stage="mid") == 300 and ops.check_cluster_num(1022, stage="mid") == 1022
+    with pytest.raises(_lib.RpccError, match=r"cluster_num = 1023.*<= 1022.*BatchCompressor"):
+        ops.check_cluster_num(1023, stage="mid")
     from rpcc_amd.pipeline import BatchCompressor
     with pytest.raises(_lib.RpccError, match="cluster_num = 70000"):
         BatchCompressor(None, cluster_num=70000)

@@ -86,3 +86,65 @@ def test_binding_error_reporting(rb):
     import torch
     with pytest.raises(RuntimeError, match="bad argument"):
         rb.furthest_point_sample(torch.zeros((1, 0, 3), dtype=torch.float32, device="cuda"), 4)
+
+
+def test_binding_and_mirror_classes_at_300_clusters(rb):
+    """cluster_num is a free value of the reference's YAML (cfgs/compressor.yaml:22); above 254 a label needs 16 bits.  The STAGE seams the reference
+    calls one by one -- segmentation, point model, prediction, the uniform quantiser, the contour codec -- exist in uint16 form up to 1022 clusters
+    (rpcc_assign_wide, rpcc_point_model_wide, rpcc_intra_predict_wide, rpcc_predict_quantize_wide, rpcc_contour_*_wide): through the reference-side
+    stub and through the mirror classes (PointCloudSegment, QuantizationModule) a VLP-16 sweep at cluster_num = 300 gives the oracle's labels, model
+    rows, prediction and integers; key points / salience levels stage by stage keep the byte limit and say so."""
+    from oracle import oracle as orc
+    import rpcc_amd  # noqa: F401
+    from rpcc_amd import synth
+    from rpcc_amd.segment_utils import PointCloudSegment
+    from rpcc_amd.compress_utils import QuantizationModule
+    gd = orc.GEOMS["VelodyneVLP16"]
+    g = orc.LidarGeom(**gd)
+    tm = orc.transform_map(g)
+    xyz = synth.make_frame(4242, g.H, g.W, vmax_deg=gd["vmax_deg"], vmin_deg=gd["vmin_deg"]).numpy()
+    M = 300
+    cfg = dict(orc.DEFAULT_CFG, cluster_num=M)
+    gm = np.array([0.01, -0.02, -0.9997, -1.72])
+    o = orc.compress_frame(xyz, g, tm, gm, cfg)
+    assert int(o["seg_idx"].max()) > 255
+    # the reference-side stub
+    ri = rb.point_cloud_to_range_image_even(xyz, g.H, g.W, g.horizontal_FOV, g.vertical_max, g.vertical_min)
+    seg_idx, _ = rb.segment_range_image(ri[..., 0], tm, gm, M, 0.1)
+    assert np.array_equal(seg_idx, o["seg_idx"])
+    pm = rb.point_modeling(ri, seg_idx)
+    mp = np.asarray(o["model_param"])
+    assert pm.shape[0] == mp.shape[0] and _beq(pm[2:], mp[2:, 3].astype(np.float32))
+    pred = rb.intra_predict(seg_idx, mp, tm)
+    assert _beq(pred, o["pred"])
+    q = rb.uniform_quantize(seg_idx, ri - pred, 0.04)
+    assert np.array_equal(q, o["q"])
+    cm, seq = rb.extract_contour(seg_idx)
+    cm_o, seq_o = orc.extract_contour(seg_idx.astype(np.int32))
+    assert np.array_equal(cm, cm_o) and np.array_equal(seq, seq_o) and np.array_equal(rb.recover_map(cm, seq), seg_idx)
+    with pytest.raises(ValueError, match="cluster_num = 300.*<= 254"):
+        rb.extract_features_with_segment(ri, seg_idx, 3, 8, 4, 8, 6)
+    with pytest.raises(ValueError, match="<= 1022"):
+        rb.segment_range_image(ri[..., 0], tm, gm, 1500, 0.1)
+    # the mirror classes, driven like tools/compress.py:93-125
+    PointCloudSegment.ransac_plane_segmentation = staticmethod(lambda pts, *a, **k: (None, gm))
+    try:
+        ps = PointCloudSegment(tm)
+        pc = orc.backproject(ri[..., 0], tm)
+        seg2, gm2 = ps.segment(pc, ri, dict(segment_method="FPS", ground_vertical_threshold=0.1, cluster_num=M))
+        assert np.array_equal(seg2, o["seg_idx"]) and np.array_equal(gm2, gm)
+        cmod = ps.cluster_modeling(pc, ri, seg2, dict(model_method="point"))
+        model_param = np.concatenate((gm.reshape(1, 4), cmod), 0)
+        assert _beq(model_param.astype(np.float32), mp.astype(np.float32))
+        pred2 = ps.intra_predict(seg2, model_param)
+        assert _beq(pred2, o["pred"])
+        qm = QuantizationModule(0.04, uniform=True)
+        q2, _, _ = qm.quantize_residual(ri - pred2, seg2, pc, ri)
+        assert np.array_equal(q2, o["q"])
+        from rpcc_amd import _lib
+        with pytest.raises(_lib.RpccError, match="cluster_num = 1500.*<= 1022"):
+            ps.segment(pc, ri, dict(segment_method="FPS", ground_vertical_threshold=0.1, cluster_num=1500))
+        with pytest.raises(_lib.RpccError, match="<= 254"):
+            ps.cluster_modeling(pc, ri, seg2, dict(model_method="plane", angle_threshold=75))
+    finally:
+        PointCloudSegment.ransac_plane_segmentation = None
