@@ -1772,7 +1772,8 @@ __global__ __launch_bounds__(WC_SCORE_THREADS) void ground_wc_score_kernel(const
     }
 }
 // Winner and refit: one workgroup per frame, at work only for a marked one; most inliers among the valid hypotheses, the lower one among
-// equals, then ransac_refit on every pixel -- the ordered sums of the specification, 32 points per thread in flight.
+// equals, then ransac_refit on every pixel -- the ordered sums of the specification (8 points per thread in flight: the passes are VALU-bound on the four
+// wavefronts that own the 256 partials -- 16 or 32 in flight change nothing -- and a launch that finds no marked frame should not ask for 232 registers).
 __global__ __launch_bounds__(RS_NT) void ground_wc_refit_kernel(const RansacMulti m, double thr) {
     __shared__ double sred[6 * RS_NT];
     const int gi = multi_group_of(m.first, m.n, blockIdx.x);
@@ -1790,7 +1791,7 @@ __global__ __launch_bounds__(RS_NT) void ground_wc_refit_kernel(const RansacMult
     if (wcnt >= 0) { plane[0] = w.hypd[4 * wh]; plane[1] = w.hypd[4 * wh + 1]; plane[2] = w.hypd[4 * wh + 2]; plane[3] = w.hypd[4 * wh + 3]; }
     RsPoints pts;
     pts.ri = a.ri_all + (int64_t)b * a.P; pts.tm = a.tm; pts.lds = nullptr; pts.n = a.P; pts.raw = 0;
-    ransac_refit<32>(pts, wcnt, (float)thr, plane, sred);
+    ransac_refit<8>(pts, wcnt, (float)thr, plane, sred);
     if (threadIdx.x == 0) { a.ground[4 * b] = plane[0]; a.ground[4 * b + 1] = plane[1]; a.ground[4 * b + 2] = plane[2]; a.ground[4 * b + 3] = plane[3]; }
 }
 

@@ -58,6 +58,8 @@ if all(os.path.exists(f"{G}/prof_pmc_CLASS_{x}.csv") for x in "AB"):
     for k, v in raw.items():
         avg = {c: sum(x) / len(x) for c, x in v.items()}
         total = avg.get("SQ_INSTS_VALU@A") or avg.get("SQ_INSTS_VALU@B")
+        if not total:      # (a launch that leaves at once -- the whole-cloud kernels of a batch without ground-less sweeps -- counts nothing: static mix)
+            continue
         cl = mix_of(k)["pmc_classes"]
         n = {c: avg.get("SQ_INSTS_VALU_" + c, 0.0) for c in CLASSES}
         n["UNCOUNTED"] = max(total - sum(n.values()), 0.0)
