@@ -1414,6 +1414,35 @@ def test_ground_less_frames_are_fitted_chip_wide_to_the_same_plane(env):
         assert _beq(gr["ground"][1].cpu().numpy(), np.asarray(orc.ground_model(orc.project(frames[1], g), tm, seed=9 + 7 + 1), np.float64)), g.H
 
 
+def test_ground_less_frames_in_a_batch_of_more_than_1024(env):
+    """The chip-wide scoring lists the marked frames 1024 at a time (WC_LIST): a batch of 1100 small sweeps in which every third one -- and a run of
+    them across the 1024 boundary -- has no ground returns gives the planes of rpcc_ground_ransac alone, frame for frame."""
+    torch, ops, orc, synth = env["torch"], env["ops"], env["orc"], env["synth"]
+    H, W, vmax, vmin = 16, 512, 15.0, -15.0
+    g = orc.LidarGeom(H, W, 360.0, vmax, vmin)
+    tm = ops.transform_map(g.H, g.W, g.horizontal_FOV, g.vertical_max, g.vertical_min)
+    geom = ops.make_geom(g.H, g.W, g.horizontal_FOV, g.vertical_max, g.vertical_min)
+    base = [synth.make_frame(6100 + i, H, W, vmax_deg=vmax, vmin_deg=vmin).numpy() for i in range(12)]
+    B = 1100
+    frames = []
+    for i in range(B):
+        f = base[i % 12]
+        frames.append(f[f[:, 2] > -1.45] if (i % 3 == 0 or 1015 <= i < 1040) else f)
+    offs = np.zeros(B + 1, np.int64)
+    offs[1:] = np.cumsum([f.shape[0] for f in frames])
+    fid = _to(env, np.arange(B, dtype=np.int64) + 3)
+    buf = ops.BatchBuffers(B, geom, 10, env["dev"])
+    gms = torch.zeros((B, 4), dtype=torch.float64, device=env["dev"])
+    d_tm = _to(env, tm)
+    ops.compress_batch(_to(env, np.concatenate(frames)), _to(env, offs), d_tm, gms, buf, ground_seed=2, frame_ids=fid)
+    alone, _ = ops.ground_ransac(buf.ri, d_tm, seed=2, frame_ids=fid)
+    a, b = gms.cpu().numpy().view(np.uint64), alone.cpu().numpy().view(np.uint64)
+    bad = np.flatnonzero((a != b).any(1))
+    assert bad.size == 0, bad[:10]
+    for i in (0, 1023, 1024, 1039, 1099):
+        assert _beq(gms[i].cpu().numpy(), np.asarray(orc.ground_model(orc.project(frames[i], g), tm, seed=2 + 3 + i), np.float64)), i
+
+
 def test_compress_batch_stages_equal_the_single_call(env):
     """rpcc_compress_batch_stages: the batch's stages issued one by one (and in two groups on two streams joined by an event) give the outputs of
     rpcc_compress_batch; all bits at once is the same call."""
