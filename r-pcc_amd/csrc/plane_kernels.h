@@ -18,7 +18,8 @@
 // their positions are left unwritten (about half of a frame's pixels).
 // pts4 (optional): the same list as points (x, y, z, r) so that the plane model streams a label's points instead of
 // gathering them through the pixel index.
-__device__ __forceinline__ void label_order_body(const uint8_t *__restrict__ seg, const uint32_t *__restrict__ hist,
+template <class L = uint8_t>
+__device__ __forceinline__ void label_order_body(const L *__restrict__ seg, const uint32_t *__restrict__ hist,
                                                  int P, int M, int KP, int T, uint32_t *__restrict__ order,
                                                  const float *__restrict__ ri, const float *__restrict__ tm,
                                                  float4 *__restrict__ pts4, const int b, const int t) {
@@ -38,7 +39,7 @@ __device__ __forceinline__ void label_order_body(const uint8_t *__restrict__ seg
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const uint32_t p = (uint32_t)min(t * TILE + j * 256 + (int)threadIdx.x, P - 1);
-        lraw[j] = ld_at(seg, p);
+        lraw[j] = ld_at(seg, p * (uint32_t)sizeof(L));
         if (pts4) { rr[j] = ld_at(ri, p * 4u); ray[j] = ld_at(reinterpret_cast<const f32x3 *>(tm), p * 12u); }
     }
     for (int i = threadIdx.x; i < K; i += 256) soff[i] = hist[((int64_t)b * T + t) * KP + i];
@@ -76,11 +77,12 @@ __device__ __forceinline__ void label_order_body(const uint8_t *__restrict__ seg
             if (pts4) pts4[o] = make_float4(rr[j] * ray[j].x, rr[j] * ray[j].y, rr[j] * ray[j].z, rr[j]);  // transformer.py:94-101
         }
 }
-__global__ __launch_bounds__(256) void label_order_kernel(const uint8_t *__restrict__ seg, const uint32_t *__restrict__ hist,
+template <class L = uint8_t>
+__global__ __launch_bounds__(256) void label_order_kernel(const L *__restrict__ seg, const uint32_t *__restrict__ hist,
                                                           int P, int M, int KP, int T, uint32_t *__restrict__ order,
                                                           const float *__restrict__ ri, const float *__restrict__ tm,
                                                           float4 *__restrict__ pts4) {
-    label_order_body(seg, hist, P, M, KP, T, order, ri, tm, pts4, blockIdx.y, blockIdx.x);
+    label_order_body<L>(seg, hist, P, M, KP, T, order, ri, tm, pts4, blockIdx.y, blockIdx.x);
 }
 struct OrderGroup {   // one geometry group of rpcc_compress_batch_mixed
     const uint8_t *seg;
@@ -93,7 +95,7 @@ struct OrderGroup {   // one geometry group of rpcc_compress_batch_mixed
 __global__ __launch_bounds__(256) void label_order_multi_kernel(const MultiArgs<OrderGroup> m, int M, int KP) {
     int b, t;
     const OrderGroup &a = multi_locate(m, b, t);
-    label_order_body(a.seg, a.hist, a.P, M, KP, a.T, a.order, a.ri, a.tm, a.pts4, b, t);
+    label_order_body<uint8_t>(a.seg, a.hist, a.P, M, KP, a.T, a.order, a.ri, a.tm, a.pts4, b, t);
 }
 
 // points of one label, through the ordered pixel list

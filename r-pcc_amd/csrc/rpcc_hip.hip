@@ -3443,8 +3443,8 @@ static int launch_label_order(const float *ri, const float *tm, const uint8_t *s
     WsLayout L = ws_layout(ws, B, P, M);
     // (the quantiser's round-3 layout -- four consecutive pixels per lane -- was tried here as well: 121 us against 97 us, because a
     // lane's four 16-byte point stores then lie 64 bytes apart from the next lane's; this kernel is bound by its 255 MB of stores)
-    label_order_kernel<<<dim3(T, B), 256, (size_t)16 * (KP + 1) * 4 + (size_t)KP * 4, st>>>(seg, L.hist, P, M, KP, T, reinterpret_cast<uint32_t *>(extra), ri, tm,
-                                                                                            plane_pts4(extra, B, P));
+    label_order_kernel<uint8_t><<<dim3(T, B), 256, (size_t)16 * (KP + 1) * 4 + (size_t)KP * 4, st>>>(seg, L.hist, P, M, KP, T, reinterpret_cast<uint32_t *>(extra), ri, tm,
+                                                                                                     plane_pts4(extra, B, P));
     LAUNCH_CHECK();
     return RPCC_OK;
 }
@@ -3862,7 +3862,8 @@ __global__ __launch_bounds__(SCANW_THREADS) void model_scan_wide_kernel(const fl
 // (rpcc_wide_workspace_bytes covers rpcc_workspace_bytes_general for these counts).
 static bool mid_clusters_ok(const rpcc_batch_io *io, rpcc_geom g, int M) {
     const int P = g.H * g.W;
-    return io->model_method == 0 && M <= RPCC_MAX_CLUSTERS_MID && P < (1 << 22) && fps_tiling_range(g.H, g.W).T <= FPS_TILED_MAX_TILES;
+    (void)io;
+    return M <= RPCC_MAX_CLUSTERS_MID && P < (1 << 22) && fps_tiling_range(g.H, g.W).T <= FPS_TILED_MAX_TILES;
 }
 static int compress_batch_mid(const rpcc_batch_io *io, int B, rpcc_geom g, int M, double ground_threshold, float acc, void *ws, hipStream_t st) {
     const BatchPlan p = plan_batch(io, B, io->total, g, M, ground_threshold, acc, reinterpret_cast<char *>(ws));
@@ -3878,10 +3879,20 @@ static int compress_batch_mid(const rpcc_batch_io *io, int B, rpcc_geom g, int M
     LAUNCH_CHECK();
     // (sums / flags were cleared by the batch's first kernel: BatchInit)
     const bool vec = (P & 3) == 0 && ((uintptr_t)seg & 7u) == 0 && ((uintptr_t)io->ri & 15u) == 0 && ((uintptr_t)io->tm & 15u) == 0;
-    if (vec) model_hist_kernel<true, uint16_t><<<dim3(T, B), 256, (size_t)KP * 12, st>>>(io->ri, seg, P, KP, T, p.L.sums, p.L.flags, p.L.hist);
-    else     model_hist_kernel<false, uint16_t><<<dim3(T, B), 256, (size_t)KP * 12, st>>>(io->ri, seg, P, KP, T, p.L.sums, p.L.flags, p.L.hist);
-    model_scan_wide_kernel<uint16_t><<<B, SCANW_THREADS, 0, st>>>(io->ri, seg, io->ground, P, M, KP, T, p.L.sums, p.L.flags, p.L.hist, io->model, io->counts, io->nnz);
+    const bool point = io->model_method == 0;
+    const float *ri_sums = point ? io->ri : nullptr;      // (the plane model needs the label counts and offsets only)
+    if (vec) model_hist_kernel<true, uint16_t><<<dim3(T, B), 256, (size_t)KP * 12, st>>>(ri_sums, seg, P, KP, T, p.L.sums, p.L.flags, p.L.hist);
+    else     model_hist_kernel<false, uint16_t><<<dim3(T, B), 256, (size_t)KP * 12, st>>>(ri_sums, seg, P, KP, T, p.L.sums, p.L.flags, p.L.hist);
+    model_scan_wide_kernel<uint16_t><<<B, SCANW_THREADS, 0, st>>>(ri_sums, seg, io->ground, P, M, KP, T, p.L.sums, p.L.flags, p.L.hist, point ? io->model : nullptr,
+                                                                  io->counts, io->nnz);
     LAUNCH_CHECK();
+    if (!point) {   // a9 on the label-ordered lists (label_order_kernel on uint16 labels; the fits never see a label)
+        const size_t osh = (size_t)16 * (KP + 1) * 4 + (size_t)KP * 4;
+        HIP_TRY(ensure_dyn_lds(reinterpret_cast<const void *>(&label_order_kernel<uint16_t>), (int)osh));
+        label_order_kernel<uint16_t><<<dim3(T, B), 256, osh, st>>>(seg, p.L.hist, P, M, KP, T, reinterpret_cast<uint32_t *>(p.extra), io->ri, io->tm, plane_pts4(p.extra, B, P));
+        LAUNCH_CHECK();
+        if ((rc = launch_plane_fits(io->tm, io->ground, B, P, M, io->plane_cos_cut, (uint32_t)io->plane_seed, io->frame_ids, io->model, io->counts, p.ws, p.extra, st))) return rc;
+    }
     if (io->nonuniform) {
         const rpcc_nonuniform_cfg *nu = io->nonuniform;
         if ((rc = launch_features<uint16_t>(io->ri, seg, B, g.H, g.W, nu->feature_region, nu->segments, nu->sharp_num, nu->less_sharp_num, nu->flat_num,

@@ -35,12 +35,12 @@ def _batch(env, gd, g, ids, scene="default"):
 
 
 @pytest.mark.parametrize("M,uniform,method", [(M, u, m) for M in (300, 1000) for (u, m) in ((True, "point"), (False, "point"), (True, "plane"), (False, "plane"))] +
-                         [(1100, True, "point"), (1100, False, "point"), (1022, True, "point"), (1023, True, "point")])
+                         [(1100, True, "point"), (1100, False, "point"), (1100, True, "plane"), (1100, False, "plane"), (1022, True, "point"), (1023, True, "point")])
 def test_wide_batch_vs_oracle(env, M, uniform, method):
     """cluster_num = 300 / 1000 (labels up to 1001: uint16) on VLP-16 sweeps, all four framework / model combinations: fitted ground plane, FPS
-    pixels, labels, model rows, salience levels and quantised integers equal the oracle's.  Up to 1022 clusters the point model runs the tuned
-    assignment / histogram / quantiser kernels on uint16 labels (their label tables still fit LDS); 1023 and 1100, and the plane model at any count,
-    take the radix-sort kernels of wide_kernels.h."""
+    pixels, labels, model rows, salience levels and quantised integers equal the oracle's.  Up to 1022 clusters the batch runs the tuned
+    assignment / histogram / label-order / quantiser kernels on uint16 labels (their label tables still fit LDS); 1023 and 1100 take the radix-sort
+    kernels of wide_kernels.h."""
     torch, ops, orc, dev = env["torch"], env["ops"], env["orc"], env["dev"]
     gd, g, geom, tm = _geom(env, "VelodyneVLP16")
     ids = [7100, 7101, 7102]
