@@ -367,8 +367,8 @@ int rpcc_compress_batch_mixed(const rpcc_batch_io *ios, const int *Bs, const rpc
  * meaningless as the stream's was; callers that must reject such a stream check the label range first (compress_utils.decode_frame does). */
 #define RPCC_MAX_CLUSTERS_WIDE 65533
 /* Up to RPCC_MAX_CLUSTERS_MID clusters the per-label tables of the tuned kernels still fit LDS: rpcc_compress_batch_wide then runs the assignment, the
- * label histogram and the quantiser of rpcc_compress_batch on uint16 labels (point model; 250 k frames/s at 300 clusters against 89 k through the
- * radix sort), and the reference's STAGE seams exist for such counts too -- the uint16 forms of rpcc_assign, rpcc_point_model, rpcc_intra_predict
+ * label histogram, the plane model's label order and the quantiser of rpcc_compress_batch on uint16 labels (250 k frames/s at 300 clusters against
+ * 89 k through the radix sort), and the reference's STAGE seams exist for such counts too -- the uint16 forms of rpcc_assign, rpcc_point_model, rpcc_intra_predict
  * and rpcc_predict_quantize (same arguments, `seg` as uint16; ws of rpcc_workspace_bytes(B, P, M, 0) bytes):
  * PointCloudSegment.segment / cluster_modeling('point') / intra_predict and the uniform quantize_residual stage by stage at cluster_num 255 .. 1022. */
 #define RPCC_MAX_CLUSTERS_MID 1022
