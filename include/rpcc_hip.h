@@ -374,6 +374,8 @@ int rpcc_compress_batch_mixed(const rpcc_batch_io *ios, const int *Bs, const rpc
 #define RPCC_MAX_CLUSTERS_MID 1022
 int rpcc_assign_wide(const float *ri, const float *tm, const double *ground, const float *centers, int B, int H, int W, int M, uint16_t *seg, void *stream);
 int rpcc_point_model_wide(const float *ri, const uint16_t *seg, const double *ground, int B, int P, int M, float *model, int32_t *counts, void *ws, void *stream);
+int rpcc_plane_model_wide(const float *ri, const float *tm, const uint16_t *seg, const double *ground, int B, int P, int M, double cos_cut, uint32_t seed,
+                          const int64_t *frame_ids, const double *inject_planes, float *model, int32_t *counts, void *ws, void *stream);
 int rpcc_intra_predict_wide(const uint16_t *seg, const float *model, const float *tm, int B, int P, int M, float *pred, void *stream);
 int rpcc_predict_quantize_wide(const float *ri, const float *tm, const uint16_t *seg, const float *model, const float *label_acc, const float *residual_in,
                                float acc, int B, int P, int M, int16_t *q16, int32_t *q32, int32_t *nnz, float *pred, void *ws, void *stream);

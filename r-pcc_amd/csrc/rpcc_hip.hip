@@ -3940,6 +3940,23 @@ extern "C" int rpcc_point_model_wide(const float *ri, const uint16_t *seg, const
     ARG_TRY(B > 0 && B <= RPCC_MAX_BATCH && P > 0 && M > 0 && M <= RPCC_MAX_CLUSTERS_MID && ri && seg && ground && model && ws);
     return hist_scan_u16(ri, seg, ground, B, P, M, ws_layout(ws, B, P, M), model, counts, nullptr, (hipStream_t)stream);
 }
+// rpcc_plane_model on uint16 labels (ws: rpcc_plane_workspace_bytes(B, P, M) bytes)
+extern "C" int rpcc_plane_model_wide(const float *ri, const float *tm, const uint16_t *seg, const double *ground, int B, int P, int M, double cos_cut,
+                                     uint32_t seed, const int64_t *frame_ids, const double *inject_planes, float *model, int32_t *counts, void *ws,
+                                     void *stream) {
+    ARG_TRY(B > 0 && B <= RPCC_MAX_BATCH && P > 0 && M > 0 && M <= RPCC_MAX_CLUSTERS_MID && ri && tm && seg && model && counts && ws);
+    hipStream_t st = (hipStream_t)stream;
+    const WsLayout L = ws_layout(ws, B, P, M);
+    const int KP = kpad(M), T = ntiles(P);
+    int rc;
+    if ((rc = hist_scan_u16(nullptr, seg, nullptr, B, P, M, L, nullptr, counts, nullptr, st))) return rc;
+    void *extra = reinterpret_cast<char *>(ws) + L.bytes + 256;
+    const size_t osh = (size_t)16 * (KP + 1) * 4 + (size_t)KP * 4;
+    HIP_TRY(ensure_dyn_lds(reinterpret_cast<const void *>(&label_order_kernel<uint16_t>), (int)osh));
+    label_order_kernel<uint16_t><<<dim3(T, B), 256, osh, st>>>(seg, L.hist, P, M, KP, T, reinterpret_cast<uint32_t *>(extra), ri, tm, plane_pts4(extra, B, P));
+    LAUNCH_CHECK();
+    return launch_plane_fits(tm, ground, B, P, M, cos_cut, seed, frame_ids, model, counts, ws, extra, st, inject_planes);
+}
 extern "C" int rpcc_intra_predict_wide(const uint16_t *seg, const float *model, const float *tm, int B, int P, int M, float *pred, void *stream) {
     ARG_TRY(B > 0 && B <= RPCC_MAX_BATCH && P > 0 && M > 0 && M <= RPCC_MAX_CLUSTERS_WIDE && seg && model && tm && pred);
     intra_predict_kernel<uint16_t><<<dim3((P + 255) / 256, B), 256, 0, (hipStream_t)stream>>>(seg, model, tm, P, M + 2, pred);

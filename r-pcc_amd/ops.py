@@ -549,8 +549,8 @@ def plane_model(ri, tm, seg, M, angle_threshold=75, seed=0, ground=None, want_co
     model = torch.empty((B, K, 4), dtype=torch.float32, device=_dev(ri))
     counts = torch.empty((B, K), dtype=torch.int32, device=_dev(ri))
     fid = _frame_ids(frame_ids, B, _dev(ri))
-    check(_lib.lib().rpcc_plane_model(ptr(ri), ptr(tm), ptr(seg), ptr(ground), B, P, M, angle_cos_cut(angle_threshold),
-                                      int(seed) & 0xFFFFFFFF, ptr(fid), ptr(inject), ptr(model), ptr(counts), ptr(ws), stream()))
+    check(_stage_entry("rpcc_plane_model", M, seg)(ptr(ri), ptr(tm), ptr(seg), ptr(ground), B, P, M, angle_cos_cut(angle_threshold),
+                                                   int(seed) & 0xFFFFFFFF, ptr(fid), ptr(inject), ptr(model), ptr(counts), ptr(ws), stream()))
     return (model, counts) if want_counts else model
 
 

@@ -87,7 +87,6 @@ class PointCloudSegment:
         if method == "point":
             model, _ = ops.point_model(ri, seg, ground, M)
         else:
-            ops.check_cluster_num(M, wide=False)     # (the plane model's stage entry keeps labels in a byte)
             model = ops.plane_model(ri, self._tm, seg, M, angle_threshold=model_cfg["angle_threshold"], seed=self.seed,
                                     frame_ids=[self.frame_id])
         return model[0, 1:nrow].cpu().numpy().astype(np.float64)

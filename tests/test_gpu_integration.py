@@ -144,7 +144,13 @@ def test_binding_and_mirror_classes_at_300_clusters(rb):
         from rpcc_amd import _lib
         with pytest.raises(_lib.RpccError, match="cluster_num = 1500.*<= 1022"):
             ps.segment(pc, ri, dict(segment_method="FPS", ground_vertical_threshold=0.1, cluster_num=1500))
+        # the plane model stage by stage at 300 clusters (rpcc_plane_model_wide): the oracle's rows for the same seeds
+        ps2 = PointCloudSegment(tm, seed=5, frame_id=9)
+        cpl = ps2.cluster_modeling(pc, ri, seg2, dict(model_method="plane", angle_threshold=75))
+        want = orc.cluster_modeling_plane(pc, ri[..., 0], seg2, tm, 75, 5, 9)
+        assert _beq(cpl.astype(np.float32), np.asarray(want).astype(np.float32))
+        qn = QuantizationModule(0.04, uniform=False)
         with pytest.raises(_lib.RpccError, match="<= 254"):
-            ps.cluster_modeling(pc, ri, seg2, dict(model_method="plane", angle_threshold=75))
+            qn.quantize_residual(ri - pred2, seg2, pc, ri)     # (key points / salience levels stage by stage: byte labels)
     finally:
         PointCloudSegment.ransac_plane_segmentation = None
