@@ -377,6 +377,10 @@ int rpcc_point_model_wide(const float *ri, const uint16_t *seg, const double *gr
 int rpcc_plane_model_wide(const float *ri, const float *tm, const uint16_t *seg, const double *ground, int B, int P, int M, double cos_cut, uint32_t seed,
                           const int64_t *frame_ids, const double *inject_planes, float *model, int32_t *counts, void *ws, void *stream);
 int rpcc_intra_predict_wide(const uint16_t *seg, const float *model, const float *tm, int B, int P, int M, float *pred, void *stream);
+int rpcc_extract_features_wide(const float *ri, const uint16_t *seg, int B, int H, int W, int feature_region, int segments, int sharp_num,
+                               int less_sharp_num, int flat_num, float *feat, uint8_t *key_point_map, void *stream);
+int rpcc_salience_wide(const uint16_t *seg, const uint8_t *key_point_map, const int32_t *level_kp_num, const float *level_acc, int levels,
+                       int ground_level, int B, int P, int M, uint8_t *salience, float *label_acc, void *stream);
 int rpcc_predict_quantize_wide(const float *ri, const float *tm, const uint16_t *seg, const float *model, const float *label_acc, const float *residual_in,
                                float acc, int B, int P, int M, int16_t *q16, int32_t *q32, int32_t *nnz, float *pred, void *ws, void *stream);
 size_t rpcc_wide_workspace_bytes(int B, int P, int M, int64_t total_points);

@@ -59,16 +59,15 @@ def _ws(B, P, M, total=0):
     return torch.empty((n,), dtype=torch.uint8, device="cuda")
 
 
-def _labels(seg_idx, wide_ok=True):
+def _labels(seg_idx):
     """Labels for a stage entry: a byte up to cluster_num 254; uint16 for 255 .. 1022, where the library has uint16 forms of the seams the reference
-    calls stage by stage (`<entry>_wide`: point model, prediction, uniform quantiser, contour codec); -> (device labels, M, entry-name suffix)."""
+    calls stage by stage (`<entry>_wide`: models, prediction, key points, salience levels, quantisers, contour codec); -> (device labels, M, entry-name suffix)."""
     seg_idx = np.asarray(seg_idx)
     M = max(int(seg_idx.max()) - 1, 1)
     if M <= 254:
         return _dev(seg_idx, np.uint8).reshape(1, -1), M, ""
-    if M > 1022 or not wide_ok:
-        raise ValueError("cluster_num = %d: this stage seam of librpcc_hip takes cluster_num <= %d (the fused batch entry rpcc_compress_batch_wide: 65533)"
-                         % (M, 1022 if wide_ok else 254))
+    if M > 1022:
+        raise ValueError("cluster_num = %d: the stage seams of librpcc_hip take cluster_num <= 1022 (the fused batch entry rpcc_compress_batch_wide: 65533)" % M)
     return _dev(seg_idx, np.uint16).reshape(1, -1), M, "_wide"
 
 
@@ -164,27 +163,27 @@ def uniform_quantize(seg_idx, residual, acc):
 
 def nonuniform_quantize(seg_idx, residual, key_point_map, level_kp_num, level_acc, ground_level):
     """-> (quantized residual int32 [nnz], salience level per label int32 [max(seg)+1])."""
-    seg, M, _ = _labels(seg_idx, wide_ok=False)      # (the salience seam keeps labels in a byte)
+    seg, M, sfx = _labels(seg_idx)
     P, L = seg.shape[1], len(level_kp_num)
     kp = _dev(key_point_map, np.uint8).reshape(1, P)
     sal = torch.empty((1, M + 2), dtype=torch.uint8, device="cuda")
     lacc = torch.empty((1, M + 2), dtype=torch.float32, device="cuda")
     lk = (C.c_int32 * L)(*[int(v) for v in level_kp_num])
     la = (C.c_float * L)(*[float(v) for v in level_acc])
-    _ok(_l.rpcc_salience(_p(seg), _p(kp), lk, la, L, int(ground_level), 1, P, M, _p(sal), _p(lacc), _s()))
+    _ok(getattr(_l, "rpcc_salience" + sfx)(_p(seg), _p(kp), lk, la, L, int(ground_level), 1, P, M, _p(sal), _p(lacc), _s()))
     q = _quantize(seg_idx, residual, float(level_acc[0]), lacc)
     return q, sal[0, :int(np.asarray(seg_idx).max()) + 1].cpu().numpy().astype(np.int32)
 
 
 # ---- feature_extractor_cpp -----------------------------------------------------------------------------
 def extract_features_with_segment(range_image, seg_idx, feature_region, segments, sharp_num, less_sharp_num, flat_num):
-    seg, _, _ = _labels(seg_idx, wide_ok=False)      # (the key-point seam keeps labels in a byte)
+    seg, _, sfx = _labels(seg_idx)
     H, W = np.asarray(seg_idx).shape[:2]
     ri = _dev(range_image, np.float32).reshape(1, H * W)
     feat = torch.empty((1, H, W), dtype=torch.float32, device="cuda")
     kp = torch.empty((1, H, W), dtype=torch.uint8, device="cuda")
-    _ok(_l.rpcc_extract_features(_p(ri), _p(seg), 1, H, W, feature_region, segments, sharp_num, less_sharp_num, flat_num,
-                                 _p(feat), _p(kp), _s()))
+    _ok(getattr(_l, "rpcc_extract_features" + sfx)(_p(ri), _p(seg), 1, H, W, feature_region, segments, sharp_num, less_sharp_num, flat_num,
+                                                   _p(feat), _p(kp), _s()))
     return feat[0].cpu().numpy(), kp[0].cpu().numpy().astype(np.int32)
 
 

@@ -85,6 +85,8 @@ _SIGS = {
     "rpcc_point_model_wide": (C.c_int, [_VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP]),
     "rpcc_predict_quantize_wide": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _F, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
     "rpcc_intra_predict_wide": (C.c_int, [_VP, _VP, _VP, _I, _I, _I, _VP, _VP]),
+    "rpcc_extract_features_wide": (C.c_int, [_VP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _VP, _VP, _VP]),
+    "rpcc_salience_wide": (C.c_int, [_VP, _VP, C.POINTER(C.c_int32), C.POINTER(C.c_float), _I, _I, _I, _I, _I, _VP, _VP, _VP]),
     "rpcc_plane_model_wide": (C.c_int, [_VP, _VP, _VP, _VP, _I, _I, _I, _D, C.c_uint32, _VP, _VP, _VP, _VP, _VP, _VP]),
     "rpcc_extract_features": (C.c_int, [_VP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _VP, _VP, _VP]),
     "rpcc_salience": (C.c_int, [_VP, _VP, C.POINTER(C.c_int32), C.POINTER(C.c_float), _I, _I, _I, _I, _I, _VP, _VP, _VP]),

@@ -47,9 +47,9 @@ class QuantizationModule:
         h, w = seg_idx.shape[:2]
         M = max(int(seg_idx.max()) - 1, 1)
         K = M + 2
-        # the uniform quantiser's stage entry exists for uint16 labels too (rpcc_predict_quantize_wide, cluster_num <= 1022); key points and salience
-        # levels stage by stage keep labels in a byte (the batch front-end, pipeline.BatchCompressor, has no such limit)
-        ops.check_cluster_num(M, stage="mid") if self.uniform else ops.check_cluster_num(M, wide=False)
+        # the stage entries exist for uint16 labels too (rpcc_predict_quantize_wide, rpcc_extract_features_wide, rpcc_salience_wide: cluster_num <= 1022;
+        # the batch front-end, pipeline.BatchCompressor, goes up to 65533)
+        ops.check_cluster_num(M, stage="mid")
         seg = _dev(seg_idx, self.device, np.uint16 if ops.is_wide(M) else np.uint8).reshape(1, h, w)
         res = _dev(residual, self.device, np.float32).reshape(1, h * w)
         dummy_model = torch.zeros((1, K, 4), dtype=torch.float32, device=self.device)

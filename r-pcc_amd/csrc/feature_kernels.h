@@ -430,14 +430,18 @@ struct SalienceParams {
 };
 
 #define SAL_THREADS 1024  // one workgroup per frame: 16 wavefronts hide the latency of the frame-long scan
-__global__ __launch_bounds__(SAL_THREADS) void salience_kernel(const uint8_t *__restrict__ seg, const uint8_t *__restrict__ kp, int P,
+// L: label type, KMAX: most labels (256 for byte labels, 1024 for uint16 ones up to RPCC_MAX_CLUSTERS_MID clusters)
+template <class L = uint8_t, int KMAX = 256>
+__global__ __launch_bounds__(SAL_THREADS) void salience_kernel(const L *__restrict__ seg, const uint8_t *__restrict__ kp, int P,
                                                        int M, SalienceParams sp, uint8_t *__restrict__ salience,
                                                        float *__restrict__ label_acc) {
-    __shared__ int kpn[256], pn[256];
+    static_assert(KMAX <= SAL_THREADS, "a thread per label");
+    __shared__ int kpn[KMAX], pn[KMAX];
     const int b = blockIdx.x, K = M + 2;
-    if (threadIdx.x < 256) { kpn[threadIdx.x] = 0; pn[threadIdx.x] = 0; }
+    if (threadIdx.x < KMAX) { kpn[threadIdx.x] = 0; pn[threadIdx.x] = 0; }
     __syncthreads();
-    const uint8_t *sg = seg + (int64_t)b * P, *kk = kp + (int64_t)b * P;
+    const L *sg = seg + (int64_t)b * P;
+    const uint8_t *kk = kp + (int64_t)b * P;
     for (int p0 = 0; p0 < P; p0 += SAL_THREADS * 4) {
         int lab[4], key[4];
 #pragma unroll

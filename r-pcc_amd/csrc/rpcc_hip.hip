@@ -3401,7 +3401,7 @@ extern "C" int rpcc_salience(const uint8_t *seg, const uint8_t *key_point_map, c
     for (int i = 0; i < 8; i++) { sp.level_kp_num[i] = i < levels ? level_kp_num[i] : 0; sp.level_acc[i] = i < levels ? level_acc[i] : 0.f; }
     sp.levels = levels;
     sp.ground_level = ground_level;
-    salience_kernel<<<B, SAL_THREADS, 0, (hipStream_t)stream>>>(seg, key_point_map, P, M, sp, salience, label_acc);
+    salience_kernel<uint8_t, 256><<<B, SAL_THREADS, 0, (hipStream_t)stream>>>(seg, key_point_map, P, M, sp, salience, label_acc);
     LAUNCH_CHECK();
     return RPCC_OK;
 }
@@ -3939,6 +3939,24 @@ extern "C" int rpcc_point_model_wide(const float *ri, const uint16_t *seg, const
                                      void *ws, void *stream) {
     ARG_TRY(B > 0 && B <= RPCC_MAX_BATCH && P > 0 && M > 0 && M <= RPCC_MAX_CLUSTERS_MID && ri && seg && ground && model && ws);
     return hist_scan_u16(ri, seg, ground, B, P, M, ws_layout(ws, B, P, M), model, counts, nullptr, (hipStream_t)stream);
+}
+// rpcc_extract_features / rpcc_salience on uint16 labels
+extern "C" int rpcc_extract_features_wide(const float *ri, const uint16_t *seg, int B, int H, int W, int feature_region, int segments, int sharp_num,
+                                          int less_sharp_num, int flat_num, float *feat, uint8_t *key_point_map, void *stream) {
+    ARG_TRY(B > 0 && B <= RPCC_MAX_BATCH && H > 0 && W > 0 && ri && seg && feat && key_point_map);
+    return launch_features<uint16_t>(ri, seg, B, H, W, feature_region, segments, sharp_num, less_sharp_num, flat_num, feat, key_point_map, (hipStream_t)stream);
+}
+extern "C" int rpcc_salience_wide(const uint16_t *seg, const uint8_t *key_point_map, const int32_t *level_kp_num, const float *level_acc, int levels,
+                                  int ground_level, int B, int P, int M, uint8_t *salience, float *label_acc, void *stream) {
+    ARG_TRY(B > 0 && B <= RPCC_MAX_BATCH && P > 0 && M > 0 && M <= RPCC_MAX_CLUSTERS_MID && seg && key_point_map && salience && label_acc);
+    ARG_TRY(level_kp_num && level_acc && levels >= 1 && levels <= 8 && ground_level >= 0 && ground_level < levels);
+    SalienceParams sp;
+    for (int i = 0; i < 8; i++) { sp.level_kp_num[i] = i < levels ? level_kp_num[i] : 0; sp.level_acc[i] = i < levels ? level_acc[i] : 0.f; }
+    sp.levels = levels;
+    sp.ground_level = ground_level;
+    salience_kernel<uint16_t, 1024><<<B, SAL_THREADS, 0, (hipStream_t)stream>>>(seg, key_point_map, P, M, sp, salience, label_acc);
+    LAUNCH_CHECK();
+    return RPCC_OK;
 }
 // rpcc_plane_model on uint16 labels (ws: rpcc_plane_workspace_bytes(B, P, M) bytes)
 extern "C" int rpcc_plane_model_wide(const float *ri, const float *tm, const uint16_t *seg, const double *ground, int B, int P, int M, double cos_cut,

@@ -247,8 +247,8 @@ def extract_features(ri, seg, feature_region=3, segments=8, sharp_num=4, less_sh
     B, H, W = seg.shape
     feat = torch.empty((B, H, W), dtype=torch.float32, device=_dev(seg))
     kp = torch.empty((B, H, W), dtype=torch.uint8, device=_dev(seg))
-    check(_lib.lib().rpcc_extract_features(ptr(ri), ptr(seg), B, H, W, feature_region, segments, sharp_num,
-                                           less_sharp_num, flat_num, ptr(feat), ptr(kp), stream()))
+    fn = _lib.lib().rpcc_extract_features_wide if seg.dtype == torch.uint16 else _lib.lib().rpcc_extract_features
+    check(fn(ptr(ri), ptr(seg), B, H, W, feature_region, segments, sharp_num, less_sharp_num, flat_num, ptr(feat), ptr(kp), stream()))
     return feat, kp
 
 
@@ -262,8 +262,7 @@ def salience(seg, kp, level_kp_num, level_acc, ground_level, M):
     la = (C.c_float * L)(*[float(x) for x in level_acc])
     sal = torch.empty((B, K), dtype=torch.uint8, device=_dev(seg))
     lacc = torch.empty((B, K), dtype=torch.float32, device=_dev(seg))
-    check(_lib.lib().rpcc_salience(ptr(seg), ptr(kp), lk, la, L, int(ground_level), B, P, M, ptr(sal), ptr(lacc),
-                                   stream()))
+    check(_stage_entry("rpcc_salience", M, seg)(ptr(seg), ptr(kp), lk, la, L, int(ground_level), B, P, M, ptr(sal), ptr(lacc), stream()))
     return sal, lacc
 
 
