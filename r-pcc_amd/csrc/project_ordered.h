@@ -76,8 +76,9 @@ struct OrdArgs {
 
 // Barrier of the chunk loop: LDS traffic complete (s_waitcnt lgkmcnt(0)), then s_barrier -- NOT __syncthreads(), whose fence also waits for every
 // global access in flight (vmcnt(0)): the next chunk's point loads and the stores of the rows that left the window would be waited for at every
-// barrier (measured: 44 % of the loop).  Global data written by one thread and read by another inside this kernel (a row that is re-opened, the
-// hand-off pass) is ordered by a full __syncthreads() at those places.
+// barrier.  (As it turned out the compiler's __syncthreads() does not wait for them either -- without threadgroup-split mode a workgroup-scope fence is
+// s_waitcnt lgkmcnt(0) -- so this is the same barrier, spelled out.)  Global data written by one thread and read by another inside this kernel (a row
+// that is re-opened, the hand-off pass) is ordered explicitly at those places: s_waitcnt vmcnt(0) in every wavefront, then the barrier.
 __device__ __forceinline__ void ord_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // every lane of the wavefront calls; pend: the lane holds a point outside the window, in `row`
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(ORD_THREADS) void project_ordered_kernel(const OrdA
             // (a row that comes back is read from the image: the stores of the move that wrote it must have landed -- rare, the full barrier)
             bool back = false;
             for (int r = e0; r < e0 + k; r++) back = back || ((S.ret[r >> 5] >> (r & 31)) & 1u);
-            if (back) __syncthreads();
+            if (back) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }   // (every wavefront's own stores acknowledged, then the barrier)
             move_rows(lo, e0, k);
             ord_barrier();
             if (tid == 0) {
@@ -379,6 +380,7 @@ __global__ __launch_bounds__(ORD_THREADS) void project_ordered_kernel(const OrdA
     if (!want_cnt) { TRACE_ORD_END(); return; }
     // ---- the hand-off to the ground fit, as project_band_kernel leaves it: per chunk of rs_chunk pixels the number of pixels with z = r * tz < zthr,
     // and which ones, a byte per quad.  One pass over the finished image (this CU's own stores: in its L2) and the ray table.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (a workgroup-scope barrier waits for LDS traffic only: the image stores must have landed)
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // (the image is read back: nothing stale from the CU's L1)
     if (!S.sawzero) {   // (a frame with a depth-0 point is projected again by the fix-up workgroup and counts for itself)
