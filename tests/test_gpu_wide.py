@@ -73,6 +73,39 @@ def test_wide_batch_vs_oracle(env, M, uniform, method):
             assert np.array_equal(buf.salience[i, :o["salience"].shape[0]].cpu().numpy(), o["salience"].astype(np.uint8)), tag
 
 
+def test_mid_cluster_counts_with_the_bruteforce_fps_and_groundless_frames(env):
+    """cluster_num = 300 through the fused plan (compress_batch_mid): the one-pass-per-centre FPS (RPCC_FPS_BRUTEFORCE) gives the same centres, labels
+    and integers as the pruned one, and a batch that holds a sweep without ground returns (whole-cloud fit, scored chip-wide) equals the oracle."""
+    torch, ops, orc, dev = env["torch"], env["ops"], env["orc"], env["dev"]
+    gd, g, geom, tm = _geom(env, "VelodyneVLP16")
+    ids = [7300, 7301, 7302]
+    frames, xyz, offs = _batch(env, gd, g, ids)
+    frames[1] = frames[1][frames[1][:, 2] > -1.45]                    # no ground returns
+    offs_np = np.zeros(len(frames) + 1, np.int64)
+    offs_np[1:] = np.cumsum([f.shape[0] for f in frames])
+    xyz, offs = torch.from_numpy(np.concatenate(frames)).to(dev), torch.from_numpy(offs_np).to(dev)
+    M = 300
+    cfg = dict(orc.DEFAULT_CFG, cluster_num=M)
+    fid = torch.as_tensor(np.asarray(ids, np.int64), device=dev)
+    outs = []
+    for brute in (False, True):
+        buf = ops.BatchBuffers(len(ids), geom, M, dev)
+        gms = torch.zeros((len(ids), 4), dtype=torch.float64, device=dev)
+        ops.compress_batch(xyz, offs, torch.from_numpy(tm).to(dev), gms, buf, ground_seed=5, frame_ids=fid, fps_bruteforce=brute)
+        torch.cuda.synchronize()
+        outs.append((gms.cpu().numpy(), buf.cen_pix.cpu().numpy(), buf.seg.cpu().numpy(), buf.nnz.cpu().numpy(), buf.q16.cpu().numpy(), buf.model.cpu().numpy()))
+    for u, v in zip(*outs):
+        assert np.array_equal(u.view(np.uint8), v.view(np.uint8)) if u.dtype != np.int16 else all(
+            np.array_equal(u[i, :outs[0][3][i]], v[i, :outs[0][3][i]]) for i in range(len(ids)))
+    gm_d, pix, seg, nnz, q16, _ = outs[0]
+    for i, f in enumerate(frames):
+        gm = orc.ground_model(orc.project(f, g), tm, seed=5 + ids[i])
+        assert np.array_equal(gm_d[i].view(np.uint64), np.asarray(gm, np.float64).view(np.uint64)), i
+        o = orc.compress_frame(f, g, tm, gm, cfg)
+        assert np.array_equal(pix[i], o["fps_pix"]) and np.array_equal(seg[i].reshape(-1), o["seg_idx"].reshape(-1)), i
+        assert int(nnz[i]) == o["q"].shape[0] and np.array_equal(q16[i, :nnz[i]], o["q"].astype(np.int16)), i
+
+
 @pytest.mark.parametrize("uniform,method,scene", [(True, "point", "default"), (False, "plane", "default"), (True, "point", "shell"),
                                                   (True, "point", "noise"), (True, "point", "corridor")])
 def test_wide_kernels_equal_the_byte_label_kernels(env, uniform, method, scene):
