@@ -2734,12 +2734,15 @@ extern "C" size_t rpcc_workspace_bytes_general(int B, int P, int M, int64_t tota
 // threads are consecutive words; SCAN_U tiles' loads in flight per thread) in two passes -- totals, then offsets with the label's
 // base added -- instead of staging the table in LDS (64 KB per workgroup for 64x2048: its footprint kept everything else off
 // the CU, and the 128 dependent LDS round trips of the in-LDS scan were most of the kernel's time).
-#define SCAN_U 32
-#define SCAN_THREADS 512
+#define SCAN_U 16
+#define SCAN_THREADS 256
 // Thread (g, k): label k of tile group g.  The SCAN_THREADS threads form NG = SCAN_THREADS / KP2 groups (KP2 = K rounded up to a
-// power of two: 4 groups for 102 labels), a group owns T / NG consecutive tiles; with at most SCAN_U tiles per group (128 tiles, 4
-// groups) a thread's counts stay in registers between the totals and the offsets: ONE trip to memory per thread instead of eight
-// dependent ones (12.8 -> 10.2 us alone; this kernel sits on every batch's chain between the histogram and the quantiser).
+// power of two: 2 groups for 102 labels), a group owns T / NG consecutive tiles; with at most SCAN_U tiles per group a thread's
+// counts stay in registers between the totals and the offsets (one trip to memory per thread), otherwise SCAN_U loads are in flight
+// per trip.  This kernel sits on every batch's chain between the histogram and the quantiser, and what counts there is how soon its
+// one workgroup per frame finds room on CUs that other batches' kernels fill: 512 threads x 144 registers holding 32 tiles each were
+// the fastest alone (10.2 us) and took 65 us in flight; 256 threads with 16 loads in flight (four trips for 64x2048) are slower alone
+// and 1.5 % faster per step with three batches in flight (profiles/raw/r06_ab_scan_footprint.txt: 512/32, 512/16, 512/8, 256/32, 256/24, 256/16, 256/8).
 struct ScanArgs {
     const float *ri;
     const uint8_t *seg;
